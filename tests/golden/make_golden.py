@@ -1,0 +1,327 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the reference (CPU, this container only).
+
+TEST INFRASTRUCTURE - runs only where /root/reference exists (the build container). Nothing here is
+imported by the product (`tgsr_amd/`), by `-m gpu` tests, by `bench.py` or by `smoke()`: those read
+only the committed `.npz`/`.json` fixtures this script writes.
+
+What it does: puts /root/reference on sys.path, injects attr-dict / torchvision
+stubs, makes `.cuda()` an identity and `cfg.CUDA = False`, switches the bool-mask path on
+(`server = 1`), builds the reference modules, feeds seeded inputs and dumps inputs + parameters +
+outputs.  The reference's files are never copied, only imported and called.
+
+    python tests/golden/make_golden.py            # regenerates every fixture (about a minute)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("TGSR_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- harness-side patches
+def _install_stubs():
+    sys.dont_write_bytecode = True
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+    class EasyDict(dict):
+        """attr-dict stand-in for the (absent) easydict package."""
+
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            d = dict(d or {}, **kw)
+            for k, v in d.items():
+                setattr(self, k, v)
+
+        def __setattr__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            dict.__setitem__(self, k, v)
+
+        __setitem__ = __setattr__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    m = types.ModuleType("easydict")
+    m.EasyDict = EasyDict
+    sys.modules["easydict"] = m
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    # the reference calls .cuda() unconditionally (model.py:246-248): identity on this CPU box
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.set_device = lambda *a, **k: None
+
+
+def _load_ref(ngf=32, nef=256):
+    _install_stubs()
+    from miscc.config import cfg
+    cfg.CUDA = False
+    cfg.GAN.GF_DIM = ngf
+    cfg.TEXT.EMBEDDING_DIM = nef
+    cfg.TREE.BRANCH_NUM = 4
+    cfg.TREE.BASE_SIZE = 32
+    cfg.GAN.R_NUM = 2
+    cfg.TRAIN.SMOOTH.GAMMA1 = 4.0
+    cfg.TRAIN.SMOOTH.GAMMA2 = 5.0
+    cfg.TRAIN.SMOOTH.GAMMA3 = 10.0
+    import GlobalAttention
+    import model
+    import util
+    from miscc import losses
+    GlobalAttention.server = 1
+    losses.server = 1
+    return cfg, GlobalAttention, util, model, losses
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def _sd_np(module, prefix):
+    return {prefix + k: _np(v) for k, v in module.state_dict().items()}
+
+
+def _randomize_bn(module, gen):
+    """Give every BatchNorm non-trivial affine + running statistics so eval-mode BN is exercised."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            n = m.num_features
+            m.weight.data = 1.0 + 0.2 * torch.randn(n, generator=gen)
+            m.bias.data = 0.1 * torch.randn(n, generator=gen)
+            m.running_mean = 0.1 * torch.randn(n, generator=gen)
+            m.running_var = 0.5 + torch.rand(n, generator=gen)
+
+
+def _captions(gen, lens, n_words, width=18):
+    cap = torch.zeros(len(lens), width, dtype=torch.int64)
+    for i, n in enumerate(lens):
+        cap[i, :n] = torch.randint(1, n_words, (n,), generator=gen)
+    return cap, torch.tensor(lens, dtype=torch.int64)
+
+
+# --------------------------------------------------------------------------- fixtures
+def gen_ops():
+    """Op/module-level goldens on small shapes (ngf=32 so channel counts match the HIP tiles)."""
+    cfg, GA, util, model, losses = _load_ref(ngf=32, nef=64)
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+
+    # GlobalAttentionGeneral incl. the mask.repeat quirk (GlobalAttention.py:109-116): B=3, unequal lengths
+    att = GA.GlobalAttentionGeneral(32, 64)
+    h = torch.randn(3, 32, 8, 8, generator=g)
+    ctx = torch.randn(3, 64, 6, generator=g)
+    mask = torch.tensor([[0, 0, 0, 0, 0, 0], [0, 0, 0, 0, 1, 1], [0, 0, 0, 1, 1, 1]], dtype=torch.bool)
+    att.applyMask(mask)
+    with torch.no_grad():
+        wc, am = att(h, ctx)
+    out.update({"att.h": _np(h), "att.ctx": _np(ctx), "att.mask": _np(mask),
+                "att.w": _np(att.conv_context.weight), "att.out": _np(wc), "att.attn": _np(am)})
+    # same without a mask, B=1 (shipped yml batch size)
+    att.applyMask(None)
+    with torch.no_grad():
+        wc1, am1 = att(h[:1], ctx[:1])
+    out.update({"att1.out": _np(wc1), "att1.attn": _np(am1)})
+
+    # func_attention (GlobalAttention.py:33-74)
+    q = torch.randn(4, 32, 5, generator=g)
+    c = torch.randn(4, 32, 5, 5, generator=g)
+    with torch.no_grad():
+        fw, fa = GA.func_attention(q, c, 4.0)
+    out.update({"fa.query": _np(q), "fa.context": _np(c), "fa.gamma1": np.float32(4.0),
+                "fa.out": _np(fw), "fa.attn": _np(fa)})
+
+    # ResBlock(64) / upBlock(64,32), eval and train mode (util.py:74-80, 110-130)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    out["blk.x"] = _np(x)
+    rb = util.ResBlock(64)
+    _randomize_bn(rb, g)
+    out.update(_sd_np(rb, "rb."))
+    rb.eval()
+    with torch.no_grad():
+        out["rb.eval"] = _np(rb(x.clone()))
+    rb.train()
+    with torch.no_grad():
+        out["rb.train"] = _np(rb(x.clone()))
+    out.update({"rb.after." + k: _np(v) for k, v in rb.state_dict().items() if "running" in k})
+    ub = util.upBlock(64, 32)
+    _randomize_bn(ub, g)
+    out.update(_sd_np(ub, "ub."))
+    ub.eval()
+    with torch.no_grad():
+        out["ub.eval"] = _np(ub(x))
+    ub.train()
+    with torch.no_grad():
+        out["ub.train"] = _np(ub(x))
+
+    # GLU, KL, MSE
+    with torch.no_grad():
+        out["glu.out"] = _np(util.GLU()(x))
+        mu = torch.randn(3, 100, generator=g)
+        lv = 0.3 * torch.randn(3, 100, generator=g)
+        out.update({"kl.mu": _np(mu), "kl.logvar": _np(lv), "kl.out": _np(losses.KL_loss(mu.clone(), lv.clone()))})
+        a = [torch.randn(2, 3, 8, 8, generator=g), torch.randn(2, 3, 16, 16, generator=g)]
+        b = [torch.randn(2, 3, 8, 8, generator=g), torch.randn(2, 3, 16, 16, generator=g)]
+        out.update({"mse.a0": _np(a[0]), "mse.a1": _np(a[1]), "mse.b0": _np(b[0]), "mse.b1": _np(b[1]),
+                    "mse.out": _np(losses.MSE(a, b))})
+
+    # RNN_ENCODER (util.py:175-260): vocab 41, nhidden 64, B=3, lengths 6/4/3, eval (no dropout)
+    enc = util.RNN_ENCODER(41, nhidden=64)
+    enc.eval()
+    cap, lens = _captions(g, [6, 4, 3], 41)
+    with torch.no_grad():
+        we, se = enc(cap, lens, enc.init_hidden(3))
+    out.update(_sd_np(enc, "enc."))
+    out.update({"enc.captions": _np(cap), "enc.cap_lens": _np(lens), "enc.words_emb": _np(we), "enc.sent_emb": _np(se)})
+
+    # CA_NET mu/logvar (util.py:372-400)
+    ca = util.CA_NET()
+    with torch.no_grad():
+        _, mu, lv = ca(se)
+    out.update(_sd_np(ca, "ca."))
+    out.update({"ca.mu": _np(mu), "ca.logvar": _np(lv)})
+    np.savez_compressed(os.path.join(OUT, "ops_small.npz"), **out)
+    print("ops_small.npz", len(out), "arrays")
+
+
+def gen_nets_small():
+    """Whole-generator goldens, ngf=32 / nef=64, LR 16x16, B=3 with unequal captions (Q1), eval + train BN."""
+    cfg, GA, util, model, losses = _load_ref(ngf=32, nef=64)
+    g = torch.Generator().manual_seed(4321)
+    torch.manual_seed(7)
+    out = {}
+    enc = util.RNN_ENCODER(41, nhidden=64)
+    enc.eval()
+    netGL = model.G_SR_NET_low()
+    netGH = model.NetG_highweight(weightmap=False, low="lr")
+    _randomize_bn(netGL, g)
+    _randomize_bn(netGH, g)
+    cap, lens = _captions(g, [7, 5, 4], 41)
+    LR = torch.rand(3, 3, 16, 16, generator=g) * 2 - 1
+    LRb = torch.rand(3, 3, 16, 16, generator=g) * 2 - 1
+    out.update(_sd_np(enc, "E."))
+    out.update(_sd_np(netGL, "GL."))
+    out.update(_sd_np(netGH, "GH."))
+    out.update({"captions": _np(cap), "cap_lens": _np(lens), "LR": _np(LR), "LRb": _np(LRb)})
+    for mode in ("eval", "train"):
+        netGL.train(mode == "train")
+        netGH.train(mode == "train")
+        with torch.no_grad():
+            we, se = enc(cap, lens, enc.init_hidden(3))
+            mask = (cap == 0)[:, :we.size(2)]
+            imgs, atts, mu, lv = netGL(LR, se, we, mask)
+            fine, a, one = netGH(LR, imgs, LRb)
+        p = mode + "."
+        out.update({p + "words_emb": _np(we), p + "sent_emb": _np(se), p + "mask": _np(mask),
+                    p + "mu": _np(mu), p + "logvar": _np(lv), p + "a": _np(a), p + "one": _np(one)})
+        for i in range(3):
+            out[p + "fake%d" % i] = _np(imgs[i])
+            out[p + "att%d" % i] = _np(atts[i])
+            out[p + "fine%d" % i] = _np(fine[i])
+    np.savez_compressed(os.path.join(OUT, "nets_small.npz"), **out)
+    print("nets_small.npz", len(out), "arrays")
+
+
+def gen_damsm():
+    """DAMSM words_loss / sent_loss goldens (losses.py:21-136): B=4, lens 18/15/12/9, gammas 4/5/10."""
+    cfg, GA, util, model, losses = _load_ref(ngf=32, nef=256)
+    g = torch.Generator().manual_seed(99)
+    B = 4
+    feats = torch.randn(B, 256, 17, 17, generator=g, requires_grad=True)
+    words = torch.randn(B, 256, 18, generator=g, requires_grad=True)
+    cnn_code = torch.randn(B, 256, generator=g, requires_grad=True)
+    sent = torch.randn(B, 256, generator=g, requires_grad=True)
+    lens = torch.tensor([18, 15, 12, 9])
+    labels = torch.arange(B)
+    out = {"feats": _np(feats), "words": _np(words), "cnn_code": _np(cnn_code), "sent": _np(sent),
+           "cap_lens": _np(lens), "gamma": np.array([4.0, 5.0, 10.0], np.float32)}
+    for tag, cls in (("cls", np.array([0, 1, 1, 3])), ("nocls", None)):
+        w0, w1, att = losses.words_loss(feats, words, labels, lens, cls, B)
+        s0, s1 = losses.sent_loss(cnn_code, sent, labels, cls, B)
+        total = w0 + w1 + s0 + s1
+        gr = torch.autograd.grad(total, [feats, words, cnn_code, sent])
+        out.update({tag + ".w0": _np(w0), tag + ".w1": _np(w1), tag + ".s0": _np(s0), tag + ".s1": _np(s1),
+                    tag + ".g_feats": _np(gr[0]), tag + ".g_words": _np(gr[1]),
+                    tag + ".g_cnn": _np(gr[2]), tag + ".g_sent": _np(gr[3])})
+        for i, a in enumerate(att):
+            out[tag + ".att%d" % i] = _np(a)
+        if cls is not None:
+            out["class_ids"] = cls
+    np.savez_compressed(os.path.join(OUT, "damsm.npz"), **out)
+    print("damsm.npz", len(out), "arrays")
+
+
+def gen_face_s8():
+    """Full-size C1 golden with the shipped x8 face checkpoints (B=2, lens 14/9, seed 100 = test1.py:170)."""
+    cfg, GA, util, model, losses = _load_ref(ngf=32, nef=256)
+    torch.manual_seed(100)
+    g = torch.Generator().manual_seed(100)
+    ck = os.path.join(REF, "Checkpoint", "face_S8")
+    sdL = torch.load(os.path.join(ck, "netG_epoch_7.pth"), map_location="cpu", weights_only=True)
+    sdH = torch.load(os.path.join(ck, "netGH_epoch_7.pth"), map_location="cpu", weights_only=True)
+    netGL = model.G_SR_NET_low()
+    netGH = model.NetG_highweight(weightmap=False, low="lr")
+    netGL.load_state_dict(sdL, strict=True)
+    missing = netGH.load_state_dict(sdH, strict=False)
+    assert set(missing.missing_keys) <= {"a"} and not missing.unexpected_keys, missing
+    enc = util.RNN_ENCODER(41, nhidden=256)  # text_encoder200.pth is not shipped: seeded random init
+    for m in (enc, netGL, netGH):
+        m.eval()
+    cap, lens = _captions(g, [14, 9], 41)
+    LR = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    LRb = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    with torch.no_grad():
+        we, se = enc(cap, lens, enc.init_hidden(2))
+        mask = (cap == 0)[:, :we.size(2)]
+        imgs, atts, mu, lv = netGL(LR, se, we, mask)
+        fine, a, one = netGH(LR, imgs, LRb)
+    # weights are data: commit them so the GPU box (no /root/reference there) can run the real checkpoint
+    w = {}
+    w.update({"GL." + k: _np(v) for k, v in sdL.items()})
+    w.update({"GH." + k: _np(v) for k, v in sdH.items()})
+    w.update(_sd_np(enc, "E."))
+    np.savez_compressed(os.path.join(OUT, "face_S8_weights.npz"), **w)
+    out = {"captions": _np(cap), "cap_lens": _np(lens), "LR": _np(LR), "LRb": _np(LRb),
+           "words_emb": _np(we), "sent_emb": _np(se), "mask": _np(mask), "mu": _np(mu), "logvar": _np(lv)}
+    for i in range(3):
+        out["fake%d" % i] = _np(imgs[i])
+        out["fine%d" % i] = _np(fine[i])
+    out["att0"] = _np(atts[0])
+    out["att1"] = _np(atts[1])
+    a2 = _np(atts[2])  # [2,14,128,128] = 1.8 MB: keep statistics + a strided sample + one crop
+    out["att2.mean"] = a2.mean(axis=(2, 3))
+    out["att2.sub8"] = a2[:, :, ::8, ::8]
+    out["att2.crop"] = a2[:, :, 40:72, 40:72]
+    u8 = np.round(np.maximum(0, np.minimum(255, (_np(fine[-1]) + 1.0) * 127.5))).astype(np.uint8)
+    out["sr_uint8"] = u8  # trainer_objective.py:153-155
+    np.savez_compressed(os.path.join(OUT, "face_S8_c1.npz"), **out)
+    manifest = {"netG_epoch_7": {k: [list(v.shape), str(v.dtype)] for k, v in sdL.items()},
+                "netGH_epoch_7": {k: [list(v.shape), str(v.dtype)] for k, v in sdH.items()}}
+    with open(os.path.join(OUT, "ckpt_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("face_S8_c1.npz", len(out), "arrays; weights", len(w), "tensors")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "nets", "damsm", "face"]
+    if "ops" in which:
+        gen_ops()
+    if "nets" in which:
+        gen_nets_small()
+    if "damsm" in which:
+        gen_damsm()
+    if "face" in which:
+        gen_face_s8()

@@ -1,0 +1,163 @@
+"""Pins the CPU oracle (oracle/tgsr_oracle.py) to vectors captured from the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from conftest import split_sd
+from oracle import tgsr_oracle as O
+
+ATOL = 1e-5  # restatement vs reference on CPU, same fp32 arithmetic up to summation order
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, atol=ATOL, rtol=1e-5):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), atol=atol, rtol=rtol)
+
+
+def test_glu(ops_small):
+    close(O.glu(T(ops_small["blk.x"])), ops_small["glu.out"])
+
+
+def test_word_attention_mask_quirk(ops_small):
+    g = ops_small
+    out, attn = O.word_attention(T(g["att.h"]), T(g["att.ctx"]), T(g["att.w"]), T(g["att.mask"]))
+    close(out, g["att.out"])
+    close(attn, g["att.attn"])
+    # the per-sample ("correct") masking is NOT what the reference computes for B>1 with unequal lengths
+    out2, _ = O.word_attention(T(g["att.h"]), T(g["att.ctx"]), T(g["att.w"]), T(g["att.mask"]), correct_mask=True)
+    assert np.abs(out2.numpy() - g["att.out"]).max() > 1e-3
+
+
+def test_word_attention_b1_nomask(ops_small):
+    g = ops_small
+    out, attn = O.word_attention(T(g["att.h"][:1]), T(g["att.ctx"][:1]), T(g["att.w"]), None)
+    close(out, g["att1.out"])
+    close(attn, g["att1.attn"])
+
+
+def test_func_attention(ops_small):
+    g = ops_small
+    out, attn = O.func_attention(T(g["fa.query"]), T(g["fa.context"]), float(g["fa.gamma1"]))
+    close(out, g["fa.out"])
+    close(attn, g["fa.attn"])
+
+
+def test_resblock_eval_train(ops_small):
+    g = ops_small
+    sd = split_sd(g, "rb.")
+    x = T(g["blk.x"])
+    close(O.res_block(x, sd, ""), g["rb.eval"])
+    upd = {}
+    close(O.res_block(x, sd, "", training=True, update=upd), g["rb.train"], atol=2e-5)
+    for k, v in upd.items():
+        close(v, g["rb.after." + k])
+
+
+def test_upblock_eval_train(ops_small):
+    g = ops_small
+    sd = split_sd(g, "ub.")
+    x = T(g["blk.x"])
+    close(O.up_block(x, sd, ""), g["ub.eval"])
+    close(O.up_block(x, sd, "", training=True), g["ub.train"], atol=2e-5)
+
+
+def test_rnn_encoder(ops_small):
+    g = ops_small
+    sd = split_sd(g, "enc.")
+    w, s = O.rnn_encoder(sd, T(g["enc.captions"]), g["enc.cap_lens"].tolist())
+    close(w, g["enc.words_emb"], atol=1e-6)
+    close(s, g["enc.sent_emb"], atol=1e-6)
+
+
+def test_ca_net_kl_mse(ops_small):
+    g = ops_small
+    mu, lv = O.ca_net(split_sd(g, "ca."), T(g["enc.sent_emb"]), p="")
+    close(mu, g["ca.mu"], atol=1e-6)
+    close(lv, g["ca.logvar"], atol=1e-6)
+    close(O.kl_loss(T(g["kl.mu"]), T(g["kl.logvar"])), g["kl.out"], atol=1e-6)
+    close(O.mse([T(g["mse.a0"]), T(g["mse.a1"])], [T(g["mse.b0"]), T(g["mse.b1"])]), g["mse.out"], atol=1e-6)
+
+
+def _run_nets(g, mode):
+    sdE, sdL, sdH = split_sd(g, "E."), split_sd(g, "GL."), split_sd(g, "GH.")
+    cap, lens = T(g["captions"]), g["cap_lens"].tolist()
+    words, sent = O.rnn_encoder(sdE, cap, lens)
+    mask = (cap == 0)[:, :words.shape[2]]
+    tr = mode == "train"
+    imgs, atts, mu, lv = O.g_sr_net_low(sdL, T(g["LR"]), sent, words, mask, training=tr)
+    fine, a, one = O.netg_highweight(sdH, T(g["LR"]), imgs, T(g["LRb"]), "lr", training=tr)
+    return words, sent, mask, imgs, atts, mu, lv, fine, a, one
+
+
+def test_generators_small_eval(nets_small):
+    g = nets_small
+    words, sent, mask, imgs, atts, mu, lv, fine, a, one = _run_nets(g, "eval")
+    close(words, g["eval.words_emb"], atol=1e-6)
+    assert (mask.numpy() == g["eval.mask"]).all()
+    close(mu, g["eval.mu"]); close(lv, g["eval.logvar"])
+    for i in range(3):
+        close(imgs[i], g["eval.fake%d" % i], atol=5e-5)
+        close(atts[i], g["eval.att%d" % i], atol=1e-5)
+        close(fine[i], g["eval.fine%d" % i], atol=5e-5)
+    close(a, g["eval.a"]); close(one, g["eval.one"])
+
+
+def test_generators_small_train_bn(nets_small):
+    g = nets_small
+    _, _, _, imgs, atts, _, _, fine, _, _ = _run_nets(g, "train")
+    for i in range(3):
+        close(imgs[i], g["train.fake%d" % i], atol=2e-4, rtol=1e-4)
+        close(fine[i], g["train.fine%d" % i], atol=2e-4, rtol=1e-4)
+
+
+def test_damsm_losses_and_grads(damsm_golden):
+    g = damsm_golden
+    gam = g["gamma"]
+    for tag, cls in (("cls", g["class_ids"]), ("nocls", None)):
+        feats = T(g["feats"]).requires_grad_()
+        words = T(g["words"]).requires_grad_()
+        cnn = T(g["cnn_code"]).requires_grad_()
+        sent = T(g["sent"]).requires_grad_()
+        labels = torch.arange(4)
+        w0, w1, att = O.words_loss(feats, words, labels, g["cap_lens"].tolist(), cls, 4, *map(float, gam))
+        s0, s1 = O.sent_loss(cnn, sent, labels, cls, 4, float(gam[2]))
+        close(w0, g[tag + ".w0"]); close(w1, g[tag + ".w1"])
+        close(s0, g[tag + ".s0"]); close(s1, g[tag + ".s1"])
+        for i, a in enumerate(att):
+            close(a, g[tag + ".att%d" % i], atol=1e-6)
+        gr = torch.autograd.grad(w0 + w1 + s0 + s1, [feats, words, cnn, sent])
+        for t, k in zip(gr, ("g_feats", "g_words", "g_cnn", "g_sent")):
+            close(t, g[tag + "." + k], atol=1e-6, rtol=1e-4)
+
+
+def test_full_size_face_checkpoint(face_c1, face_weights):
+    """C1: shipped x8 face checkpoints, B=2, 32->256, through the whole caller-counterpart path."""
+    g, w = face_c1, face_weights
+    r = O.sr_forward(split_sd(w, "E."), split_sd(w, "GL."), split_sd(w, "GH."), T(g["captions"]),
+                     g["cap_lens"].tolist(), T(g["LR"]), T(g["LRb"]))
+    close(r["words_emb"], g["words_emb"], atol=1e-6)
+    close(r["mu"], g["mu"]); close(r["logvar"], g["logvar"])
+    for i in range(3):
+        close(r["fake"][i], g["fake%d" % i], atol=1e-4, rtol=1e-4)
+        close(r["fine"][i], g["fine%d" % i], atol=1e-4, rtol=1e-4)
+    close(r["att"][0], g["att0"], atol=1e-5); close(r["att"][1], g["att1"], atol=1e-5)
+    a2 = r["att"][2].numpy()
+    close(a2[:, :, ::8, ::8], g["att2.sub8"], atol=1e-5)
+    close(a2[:, :, 40:72, 40:72], g["att2.crop"], atol=1e-5)
+    u8 = O.to_uint8(r["fine"][-1]).numpy()
+    assert (np.abs(u8.astype(int) - g["sr_uint8"].astype(int)) <= 1).all()
+    assert (u8 != g["sr_uint8"]).mean() < 1e-3
+
+
+def test_checkpoint_manifest_matches_random_state():
+    """state_dict contract: oracle.random_state produces exactly the shipped key/shape set."""
+    import json, os
+    from conftest import GOLDEN
+    man = json.load(open(os.path.join(GOLDEN, "ckpt_manifest.json")))
+    _, GL, GH = O.random_state()
+    assert {k: list(v.shape) for k, v in GL.items()} == {k: v[0] for k, v in man["netG_epoch_7"].items()}
+    assert {k: list(v.shape) for k, v in GH.items()} == {k: v[0] for k, v in man["netGH_epoch_7"].items()}
