@@ -1,0 +1,121 @@
+/*
+ * tgsr_hip.h - C ABI of libtgsr_hip.so: the MI355X (gfx950 / CDNA4) kernels of the TGSR
+ * text-conditioned super-resolution hot path.
+ *
+ * The reference (cxm12/TGSR) has no FFI layer: its boundary is Python module/class names backed by stock
+ * torch ops.  Each entry point below replaces the torch call sequence cited next to it (paths relative to
+ * the reference root).  Conventions for every function:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless named host_*;
+ *   - fp32, NCHW, dense inner (C,H,W) layout; the batch stride is explicit (in elements) so a kernel can read
+ *     or write a channel slice of a wider buffer (this is how the reference's torch.cat, util.py:771/817,
+ *     disappears);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - never allocates, never synchronises, no global mutable state (the attention mask is an argument,
+ *     not module state as in GlobalAttention.py:84-85), safe to capture into a hipGraph;
+ *   - returns TGSR_OK (0) or a negative TGSR_E* code; nothing throws.
+ */
+#ifndef TGSR_HIP_H
+#define TGSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGSR_OK 0
+#define TGSR_EINVAL (-1)       /* bad pointer / size / flag combination */
+#define TGSR_EUNSUPPORTED (-2) /* shape outside what the kernels tile for (see each function) */
+#define TGSR_ELAUNCH (-3)      /* hipLaunch reported an error; see tgsr_last_error() */
+
+/* Epilogue selectors for tgsr_conv3x3_fwd. */
+#define TGSR_EPI_AFFINE 0     /* y = conv*scale + bias                        (conv3x3 + BatchNorm2d eval) */
+#define TGSR_EPI_AFFINE_GLU 1 /* y = a[:C/2] * sigmoid(a[C/2:]), a = affine   (+ GLU, util.py:45-53)       */
+
+/* Activation selectors for tgsr_conv_to3_fwd. */
+#define TGSR_ACT_NONE 0 /* y = conv                                  (GET_IMAGE_G_noAct, util.py:909-919) */
+#define TGSR_ACT_TANH_AXPY 1 /* y = tanh(conv) + alpha * addend      (conv_output + a*SRb, model.py:224,280) */
+
+/* ABI version of this header; tgsr_abi_version() must return the same number. */
+#define TGSR_ABI_VERSION 1
+int tgsr_abi_version(void);
+/* Static string describing the last launch error seen by this process (debug aid). */
+const char* tgsr_last_error(void);
+
+/*
+ * Re-lay a conv weight [Cout][Cin][K][K] (torch layout) as [ceil(Cin/8)][K*K][8][Cout] with zero-filled
+ * channel padding: the order tgsr_conv3x3_fwd streams it into LDS.  Replaces nothing in the reference (layout
+ * only); done once per weight version.  wpack must hold tgsr_packed_weight_elems(Cout,Cin,K) floats.
+ */
+int64_t tgsr_packed_weight_elems(int Cout, int Cin, int K);
+int tgsr_pack_conv_weight(const float* w, float* wpack, int Cout, int Cin, int K, void* stream);
+
+/*
+ * BatchNorm2d (eval) as a per-channel affine: scale = weight / sqrt(running_var + eps),
+ * bias' = bias - running_mean * scale.  Replaces nn.BatchNorm2d.eval() at util.py:77,116,119.
+ */
+int tgsr_bn_fold(const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                 float eps, float* scale, float* shift, int C, void* stream);
+
+/*
+ * Fused 3x3 convolution (stride 1, zero pad 1, no bias), fp32 on the MFMA units.
+ * Replaces, in one launch:
+ *   conv3x3 -> BatchNorm2d(eval) -> GLU                 ResBlock.block[0..2] util.py:114-117, im2f util.py:741-744,
+ *                                                       convin/residual24/48 model.py:228-232
+ *   conv3x3 -> BatchNorm2d(eval) [+ residual]           ResBlock.block[3..4] + `out += residual` util.py:118-129
+ *   Upsample(x2, nearest) -> conv3x3 -> BN -> GLU       upBlock util.py:74-80 (upsample=1: the x2 gather is folded
+ *                                                       into the LDS tile read, the 4x larger tensor never exists)
+ * x        [B][Cin][H][W], batch stride x_bstride elements
+ * wpack    from tgsr_pack_conv_weight(K=3)
+ * scale/shift [Cout] affine applied to the conv result (NULL,NULL = identity)
+ * residual NULL or [B][Cout_out][Ho][Wo] (batch stride res_bstride) added after the affine; only with
+ *          TGSR_EPI_AFFINE
+ * out      [B][Cout_out][Ho][Wo], Ho = H*(upsample?2:1); Cout_out = Cout/2 with GLU else Cout
+ * Supported: Cout % 32 == 0 (Cout % 64 == 0 with GLU); any B, Cin, H, W >= 1.
+ */
+int tgsr_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* wpack, int Cout,
+                     const float* scale, const float* shift, const float* residual, int64_t res_bstride, float* out,
+                     int64_t out_bstride, int epilogue, int upsample, void* stream);
+
+/*
+ * KxK convolution (K = 3 or 5, stride 1, zero pad K/2, no bias) to 3 output channels + optional epilogue.
+ * Replaces GET_IMAGE_G_noAct.img (util.py:913-915; K=3, TGSR_ACT_NONE) and
+ * conv_output = conv5x5 + Tanh followed by `one*. + a*SRb` (model.py:224, 280/288/297; K=5, TGSR_ACT_TANH_AXPY).
+ * x [B][Cin][H][W] (batch stride x_bstride), w [3][Cin][K][K] (torch layout), addend NULL or [B][3][H][W] dense,
+ * out [B][3][H][W] dense.
+ */
+int tgsr_conv_to3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* w, int K,
+                      int act, const float* addend, float alpha, float* out, void* stream);
+
+/*
+ * Word-level attention of the generator (GlobalAttentionGeneral.forward, GlobalAttention.py:87-130) in two
+ * launches: the 1x1 projection of the word embeddings (:100-102) and a fused QK^T -> mask -> softmax over words
+ * -> PV kernel on MFMA (:107-128).
+ * h        [B][idf][Q] (batch stride h_bstride), idf in {32,64,128}
+ * words    [B][cdf][T] dense, T <= 32;  w_ctx [idf][cdf]
+ * mask     NULL or uint8 [B][T], non-zero = padded word (captions == 0, trainer_objective.py:136-140)
+ * mask_mode 0 = reference behaviour: score row b*Q+q is masked with mask[(b*Q+q) % B]
+ *               (`mask.repeat(queryL,1)`, GlobalAttention.py:111); 1 = per-sample masking (mask[b])
+ * src_ws   workspace, B*idf*32 floats (the projected words, zero padded to 32)
+ * c_code   [B][idf][Q] (batch stride c_bstride);  attn [B][T][Q] dense (may be NULL: not written)
+ */
+int tgsr_word_attention_fwd(const float* h, int64_t h_bstride, const float* words, const float* w_ctx,
+                            const uint8_t* mask, int mask_mode, int B, int idf, int cdf, int T, int Q, float* src_ws,
+                            float* c_code, int64_t c_bstride, float* attn, void* stream);
+
+/*
+ * Bidirectional 1-layer LSTM text encoder, eval mode (RNN_ENCODER.forward util.py:233-260: Embedding ->
+ * pack_padded_sequence -> LSTM -> pad_packed_sequence -> transpose; final hidden = sentence code).
+ * captions int64 [B][width]; cap_lens int32 [B] (each 1..Tmax <= width); emb [ntoken][ninput];
+ * w_ih [2][4H][ninput], w_hh [2][4H][H], b_ih/b_hh [2][4H]  (direction 0 = forward, 1 = reverse; gate order i,f,g,o)
+ * gates_ws workspace B*Tmax*2*4H floats.
+ * words_emb [B][2H][Tmax] (zero beyond each length), sent_emb [B][2H].   H <= 256, 4H % 64 == 0.
+ */
+int tgsr_bilstm_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax, const float* emb,
+                    int ntoken, int ninput, const float* w_ih, const float* w_hh, const float* b_ih,
+                    const float* b_hh, int H, float* gates_ws, float* words_emb, float* sent_emb, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGSR_HIP_H */

@@ -1,0 +1,49 @@
+"""CPU: the C-ABI library loads and exports every function include/tgsr_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "tgsr_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tgsr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    from tgsr_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _header_functions()
+    assert len(names) >= 9
+    for n in names:
+        assert hasattr(L, n), "libtgsr_hip.so does not export %s" % n
+    assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+    L.tgsr_abi_version.restype = ctypes.c_int
+    assert L.tgsr_abi_version() == _lib.ABI_VERSION
+    L.tgsr_packed_weight_elems.restype = ctypes.c_int64
+    assert L.tgsr_packed_weight_elems(128, 64, 3) == 8 * 9 * 8 * 128
+    assert L.tgsr_packed_weight_elems(64, 3, 3) == 1 * 9 * 8 * 64
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    import torch
+    from tgsr_amd import ops
+    from tgsr_amd._lib import TgsrError
+    with pytest.raises(TgsrError):
+        ops.pack_conv3x3_weight(torch.zeros(32, 32, 3, 3))
+    with pytest.raises(TgsrError):
+        ops.conv_to3(torch.zeros(1, 32, 8, 8), torch.zeros(3, 32, 3, 3))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from tgsr_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.TgsrError):
+        _lib.lib()

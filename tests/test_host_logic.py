@@ -1,0 +1,85 @@
+"""CPU: host-side logic of the drop-in modules (construction, state_dict contract, config, batch prep)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, split_sd
+
+
+@pytest.fixture()
+def cfg32():
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    cfg_reset()
+    cfg.GAN.GF_DIM = 32
+    cfg.TEXT.EMBEDDING_DIM = 256
+    yield cfg
+    cfg_reset()
+
+
+def test_state_dict_contract_matches_shipped_checkpoints(cfg32, face_weights):
+    from tgsr_amd import model
+    man = json.load(open(os.path.join(GOLDEN, "ckpt_manifest.json")))
+    gl, gh = model.G_SR_NET_low(), model.NetG_highweight(weightmap=False, low="lr")
+    assert {k: list(v.shape) for k, v in gl.state_dict().items()} == {k: v[0] for k, v in man["netG_epoch_7"].items()}
+    assert {k: list(v.shape) for k, v in gh.state_dict().items()} == {k: v[0] for k, v in man["netGH_epoch_7"].items()}
+    assert "a" not in gh.state_dict()            # model.py:246-248 quirk: never saved
+    gl.load_state_dict(split_sd(face_weights, "GL."), strict=True)
+    gh.load_state_dict(split_sd(face_weights, "GH."), strict=True)
+    enc = model.RNN_ENCODER(41, nhidden=256)
+    enc.load_state_dict(split_sd(face_weights, "E."), strict=True)
+
+
+def test_modules_have_no_cpu_fallback(cfg32):
+    from tgsr_amd import util
+    from tgsr_amd._lib import TgsrError
+    rb = util.ResBlock(64).eval()
+    with pytest.raises(TgsrError):
+        rb(torch.zeros(1, 64, 8, 8))
+    with pytest.raises(NotImplementedError):
+        util.ResBlock(64).train()(torch.zeros(1, 64, 8, 8))
+
+
+def test_cfg_from_file_semantics(tmp_path, cfg32):
+    from tgsr_amd.miscc.config import cfg, cfg_from_file
+    p = tmp_path / "a.yml"
+    p.write_text("TREE:\n    BRANCH_NUM: 4\n    BASE_SIZE: 32\nGAN:\n    GF_DIM: 32\n    R_NUM: 2\nTRAIN:\n    FLAG: False\n")
+    cfg_from_file(str(p))
+    assert cfg.TREE.BRANCH_NUM == 4 and cfg.GAN.GF_DIM == 32
+    p.write_text("NOPE: 1\n")
+    with pytest.raises(KeyError):
+        cfg_from_file(str(p))
+    p.write_text("GAN:\n    GF_DIM: 'x'\n")
+    with pytest.raises(ValueError):
+        cfg_from_file(str(p))
+
+
+def test_batch_prep_matches_reference_conventions():
+    from tgsr_amd.trainer import caption_mask, sort_by_caption_length
+    cap = torch.tensor([[3, 4, 0, 0, 0], [5, 6, 7, 8, 0], [9, 1, 2, 0, 0]])
+    lens = torch.tensor([2, 4, 3])
+    img = torch.arange(3).float()
+    c, l, im, idx = sort_by_caption_length(cap, lens, img)
+    assert l.tolist() == [4, 3, 2] and im.tolist() == [1.0, 2.0, 0.0] and c[0].tolist() == [5, 6, 7, 8, 0]
+    m = caption_mask(c, 4)
+    assert m.shape == (3, 4) and m[2].tolist() == [False, False, True, True]
+
+
+def test_install_dropin_registers_reference_module_names(cfg32):
+    import sys
+    import tgsr_amd
+    saved = {k: sys.modules.get(k) for k in ("model", "util", "GlobalAttention", "miscc", "miscc.config")}
+    try:
+        tgsr_amd.install_dropin()
+        from model import G_SR_NET_low, NetG_highweight, RNN_ENCODER  # noqa: F401  (trainer_objective.py:8,75-88)
+        from GlobalAttention import GlobalAttentionGeneral, func_attention  # noqa: F401
+        from miscc.config import cfg  # noqa: F401
+        assert G_SR_NET_low.__module__ == "tgsr_amd.model"
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

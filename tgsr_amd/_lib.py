@@ -1,0 +1,77 @@
+"""ctypes binding of libtgsr_hip.so (the C ABI declared in include/tgsr_hip.h).
+
+The product has no CPU or eager-PyTorch fallback: if the HIP library is missing, loading raises, and every op
+refuses non-HIP tensors.  `build()` compiles the library in-tree (tgsr_amd/lib/) with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtgsr_hip.so")
+ABI_VERSION = 1
+
+OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
+EPI_AFFINE, EPI_AFFINE_GLU = 0, 1
+ACT_NONE, ACT_TANH_AXPY = 0, 1
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); must list every function of include/tgsr_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "tgsr_abi_version": (_i, []),
+    "tgsr_last_error": (ctypes.c_char_p, []),
+    "tgsr_packed_weight_elems": (_i64, [_i, _i, _i]),
+    "tgsr_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tgsr_bn_fold": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
+    "tgsr_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
+    "tgsr_conv_to3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),
+    "tgsr_word_attention_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp]),
+    "tgsr_bilstm_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class TgsrError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source under tgsr_amd/csrc for gfx950 into tgsr_amd/lib/libtgsr_hip.so."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise TgsrError("building libtgsr_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TgsrError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                            "`make -C tgsr_amd/csrc`; tgsr_amd has no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError = a header function the library does not export
+            fn.restype = res
+            fn.argtypes = args
+        v = L.tgsr_abi_version()
+        if v != ABI_VERSION:
+            raise TgsrError("libtgsr_hip.so ABI %d != binding ABI %d: rebuild" % (v, ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc == OK:
+        return
+    names = {EINVAL: "TGSR_EINVAL", EUNSUPPORTED: "TGSR_EUNSUPPORTED", ELAUNCH: "TGSR_ELAUNCH"}
+    msg = "%s failed: %s" % (what, names.get(rc, rc))
+    if rc == ELAUNCH:
+        msg += " (%s)" % lib().tgsr_last_error().decode()
+    raise TgsrError(msg)

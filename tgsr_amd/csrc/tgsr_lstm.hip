@@ -1,0 +1,193 @@
+// Bidirectional LSTM text encoder (RNN_ENCODER.forward, util.py:233-260, eval mode) for gfx950.
+//
+// Two launches instead of nn.Embedding + pack_padded_sequence + cuDNN/MIOpen LSTM + pad_packed_sequence + transpose:
+//   1. lstm_input_gates_kernel: the input projection of EVERY (sample, step, direction) at once as one fp32 MFMA
+//      GEMM  G[b*T+t][d*4H+j] = emb[captions[b][t]] . w_ih[d][j] + b_ih[d][j] + b_hh[d][j]   (embedding gather
+//      fused into the A-tile load; M = B*Tmax, N = 8H, K = ninput).
+//   2. lstm_recurrent_kernel: one workgroup per (sample, direction), one thread per gate row with its w_hh row held
+//      in registers for the whole sequence (H <= 128: 128 VGPRs), h broadcast from LDS; per step one mat-vec,
+//      two barriers.  Packed-sequence semantics are explicit: each direction walks only the sample's own `len`
+//      tokens, outputs past `len` are zero, the sentence code is [h_fwd(len-1), h_bwd(0)].
+#include "tgsr_common.h"
+
+namespace tgsr {
+
+// C[m][n] = sum_k A[row(m)][k] * Bm[n][k] + bias0[n] + bias1[n];  A rows gathered through idx (token ids).
+// Tile: 4 waves, wave w -> columns [n0 + 32w, +32), rows [m0, m0+32).  K chunks of 64 through LDS (pitch 65).
+__global__ __launch_bounds__(256) void lstm_input_gates_kernel(const int64_t* __restrict__ captions, int width,
+                                                               int Tmax, const float* __restrict__ emb, int ntoken,
+                                                               const float* __restrict__ w_ih,
+                                                               const float* __restrict__ b_ih,
+                                                               const float* __restrict__ b_hh, int M, int N, int K,
+                                                               float* __restrict__ gates) {
+  constexpr int KC = 64, P = KC + 1;
+  __shared__ float a_s[32 * P];
+  __shared__ float b_s[128 * P];
+  __shared__ int tok_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5, wave = tid >> 6;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 128;
+  if (tid < 32) {
+    const int m = m0 + tid;
+    int tok = 0;
+    if (m < M) {
+      const int64_t v = captions[(int64_t)(m / Tmax) * width + (m % Tmax)];
+      tok = (v < 0 || v >= ntoken) ? 0 : (int)v;
+    }
+    tok_s[tid] = tok;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();
+    for (int idx = tid; idx < 32 * KC; idx += 256) {
+      const int r = idx >> 6, k = idx & 63;
+      a_s[r * P + k] = (k0 + k < K) ? emb[(int64_t)tok_s[r] * K + k0 + k] : 0.f;
+    }
+    for (int idx = tid; idx < 128 * KC; idx += 256) {
+      const int r = idx >> 6, k = idx & 63;
+      b_s[r * P + k] = (k0 + k < K && n0 + r < N) ? w_ih[(int64_t)(n0 + r) * K + k0 + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < KC; k += 2) {
+      const float av = a_s[l31 * P + k + hh];
+      const float bv = b_s[(wave * 32 + l31) * P + k + hh];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + wave * 32 + l31;
+  if (n < N) {
+    const float bias = b_ih[n] + b_hh[n];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + acc_row(i, hh);
+      if (m < M) gates[(int64_t)m * N + n] = acc[i] + bias;
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// grid (B, 2); block 4H threads.  gates [B][Tmax][2][4H]; w_hh [2][4H][H].
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __restrict__ gates,
+                                                               const int32_t* __restrict__ cap_lens, int Tmax,
+                                                               const float* __restrict__ w_hh,
+                                                               float* __restrict__ words_emb,
+                                                               float* __restrict__ sent_emb) {
+  __shared__ __attribute__((aligned(16))) float h_s[H];
+  __shared__ float g_s[4 * H];
+  const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
+  int len = cap_lens[b];
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  float w[H];
+  {
+    const float4* wr = reinterpret_cast<const float4*>(w_hh + ((int64_t)d * 4 * H + j) * H);
+#pragma unroll
+    for (int k = 0; k < H / 4; ++k) {
+      const float4 v = wr[k];
+      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+  }
+  float c = 0.f, hcur = 0.f;
+  if (j < H) h_s[j] = 0.f;
+  float* wout = words_emb + ((int64_t)b * 2 * H + d * H + j) * Tmax;  // valid for j < H
+  if (j < H)
+    for (int t = len; t < Tmax; ++t) wout[t] = 0.f;
+  __syncthreads();
+  for (int s = 0; s < len; ++s) {
+    const int t = d == 0 ? s : len - 1 - s;
+    float g = gates[(((int64_t)b * Tmax + t) * 2 + d) * 4 * H + j];
+#pragma unroll
+    for (int k = 0; k < H / 4; ++k) {
+      const float4 hv = *reinterpret_cast<const float4*>(h_s + 4 * k);
+      g = fmaf(w[4 * k], hv.x, g);
+      g = fmaf(w[4 * k + 1], hv.y, g);
+      g = fmaf(w[4 * k + 2], hv.z, g);
+      g = fmaf(w[4 * k + 3], hv.w, g);
+    }
+    g_s[j] = g;
+    __syncthreads();
+    if (j < H) {
+      const float ig = sigmoidf_(g_s[j]), fg = sigmoidf_(g_s[H + j]), gg = tanhf(g_s[2 * H + j]),
+                  og = sigmoidf_(g_s[3 * H + j]);
+      c = fg * c + ig * gg;
+      hcur = og * tanhf(c);
+      h_s[j] = hcur;
+      wout[t] = hcur;
+    }
+    __syncthreads();
+  }
+  if (j < H) sent_emb[(int64_t)b * 2 * H + d * H + j] = hcur;
+}
+
+// Any H (<= 256): w_hh streamed from L2 every step; correctness path for configurations the register kernel
+// does not cover.
+__global__ void lstm_recurrent_generic_kernel(const float* __restrict__ gates, const int32_t* __restrict__ cap_lens,
+                                              int Tmax, int H, const float* __restrict__ w_hh,
+                                              float* __restrict__ words_emb, float* __restrict__ sent_emb) {
+  __shared__ float h_s[256];
+  __shared__ float g_s[1024];
+  const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
+  int len = cap_lens[b];
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  const float* wr = w_hh + ((int64_t)d * 4 * H + j) * H;
+  float c = 0.f, hcur = 0.f;
+  if (j < H) h_s[j] = 0.f;
+  float* wout = words_emb + ((int64_t)b * 2 * H + d * H + (j < H ? j : 0)) * Tmax;
+  if (j < H)
+    for (int t = len; t < Tmax; ++t) wout[t] = 0.f;
+  __syncthreads();
+  for (int s = 0; s < len; ++s) {
+    const int t = d == 0 ? s : len - 1 - s;
+    float g = gates[(((int64_t)b * Tmax + t) * 2 + d) * 4 * H + j];
+    for (int k = 0; k < H; ++k) g = fmaf(wr[k], h_s[k], g);
+    g_s[j] = g;
+    __syncthreads();
+    if (j < H) {
+      const float ig = sigmoidf_(g_s[j]), fg = sigmoidf_(g_s[H + j]), gg = tanhf(g_s[2 * H + j]),
+                  og = sigmoidf_(g_s[3 * H + j]);
+      c = fg * c + ig * gg;
+      hcur = og * tanhf(c);
+      h_s[j] = hcur;
+      wout[t] = hcur;
+    }
+    __syncthreads();
+  }
+  if (j < H) sent_emb[(int64_t)b * 2 * H + d * H + j] = hcur;
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int tgsr_bilstm_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax,
+                               const float* emb, int ntoken, int ninput, const float* w_ih, const float* w_hh,
+                               const float* b_ih, const float* b_hh, int H, float* gates_ws, float* words_emb,
+                               float* sent_emb, void* stream) {
+  if (!captions || !cap_lens || !emb || !w_ih || !w_hh || !b_ih || !b_hh || !gates_ws || !words_emb || !sent_emb)
+    return TGSR_EINVAL;
+  if (B < 1 || Tmax < 1 || Tmax > width || ntoken < 1 || ninput < 1 || H < 1) return TGSR_EINVAL;
+  if (H > 256 || (4 * H) % 64 != 0) return TGSR_EUNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const int M = B * Tmax, N = 8 * H;
+  hipLaunchKernelGGL(lstm_input_gates_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, s, captions, width,
+                     Tmax, emb, ntoken, w_ih, b_ih, b_hh, M, N, ninput, gates_ws);
+  int rc = note_launch(hipGetLastError(), "lstm_input_gates_kernel");
+  if (rc) return rc;
+  dim3 grid(B, 2);
+  if (H == 128)
+    hipLaunchKernelGGL(lstm_recurrent_kernel<128>, grid, dim3(512), 0, s, gates_ws, cap_lens, Tmax, w_hh, words_emb,
+                       sent_emb);
+  else if (H == 64)
+    hipLaunchKernelGGL(lstm_recurrent_kernel<64>, grid, dim3(256), 0, s, gates_ws, cap_lens, Tmax, w_hh, words_emb,
+                       sent_emb);
+  else if (H == 32)
+    hipLaunchKernelGGL(lstm_recurrent_kernel<32>, grid, dim3(128), 0, s, gates_ws, cap_lens, Tmax, w_hh, words_emb,
+                       sent_emb);
+  else
+    hipLaunchKernelGGL(lstm_recurrent_generic_kernel, grid, dim3(4 * H), 0, s, gates_ws, cap_lens, Tmax, H, w_hh,
+                       words_emb, sent_emb);
+  return note_launch(hipGetLastError(), "lstm_recurrent_kernel");
+}

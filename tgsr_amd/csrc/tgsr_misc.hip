@@ -1,0 +1,68 @@
+// ABI bookkeeping + the small layout/prep kernels (weight packing, BatchNorm-eval folding).
+#include <stdio.h>
+
+#include "tgsr_common.h"
+
+namespace tgsr {
+
+static char g_last_error[256] = "no error";
+
+int note_launch(hipError_t e, const char* what) {
+  if (e == hipSuccess) return TGSR_OK;
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+  return TGSR_ELAUNCH;
+}
+
+// wpack[chunk][tap][ci][Cout] <- w[Cout][Cin][K][K]; channels past Cin are zero.
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KK,
+                                        int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    int64_t t = i / Cout;
+    const int ci = (int)(t % kConvCK);
+    t /= kConvCK;
+    const int tap = (int)(t % KK);
+    const int chunk = (int)(t / KK);
+    const int c = chunk * kConvCK + ci;
+    wp[i] = c < Cin ? w[((int64_t)co * Cin + c) * KK + tap] : 0.f;
+  }
+}
+
+__global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ m,
+                               const float* __restrict__ v, float eps, float* __restrict__ scale,
+                               float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float s = g[c] / sqrtf(v[c] + eps);
+    scale[c] = s;
+    shift[c] = b[c] - m[c] * s;
+  }
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int tgsr_abi_version(void) { return TGSR_ABI_VERSION; }
+extern "C" const char* tgsr_last_error(void) { return g_last_error; }
+
+extern "C" int64_t tgsr_packed_weight_elems(int Cout, int Cin, int K) {
+  return (int64_t)((Cin + kConvCK - 1) / kConvCK) * K * K * kConvCK * Cout;
+}
+
+extern "C" int tgsr_pack_conv_weight(const float* w, float* wpack, int Cout, int Cin, int K, void* stream) {
+  if (!w || !wpack || Cout < 1 || Cin < 1 || K < 1) return TGSR_EINVAL;
+  const int64_t total = tgsr_packed_weight_elems(Cout, Cin, K);
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, wpack, Cout, Cin,
+                     K * K, total);
+  return note_launch(hipGetLastError(), "pack_conv_weight_kernel");
+}
+
+extern "C" int tgsr_bn_fold(const float* weight, const float* bias, const float* running_mean,
+                            const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+  if (!weight || !bias || !running_mean || !running_var || !scale || !shift || C < 1) return TGSR_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), weight, bias,
+                     running_mean, running_var, eps, scale, shift, C);
+  return note_launch(hipGetLastError(), "bn_fold_kernel");
+}

@@ -1,0 +1,102 @@
+"""Drop-in for the reference's model.py (x8 generators): `G_SR_NET_low` and `NetG_highweight` on HIP kernels.
+
+`from model import RNN_ENCODER, G_SR_NET_low, NetG_highweight` (trainer_objective.py:8, 75-88) keeps working:
+same constructors (hyper-parameters read from the global `cfg`, model.py:37-39), forward signatures, return
+tuples and state_dict keys (GL 104 tensors, GH 121 tensors - tests/golden/ckpt_manifest.json).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .miscc.config import cfg
+from .util import (CA_NET, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G, RNN_ENCODER, ResBlock,
+                   _ConvBnGlu, _ResidualNoSum, conv3x3, conv5x5, upBlock)
+
+__all__ = ["G_SR_NET_low", "NetG_highweight", "RNN_ENCODER", "cfg", "torch"]
+
+
+class G_SR_NET_low(nn.Module):
+    """model.py:34-78: low-frequency SR generator, three x2 stages with word attention + three image heads."""
+
+    def __init__(self):
+        super(G_SR_NET_low, self).__init__()
+        ngf = cfg.GAN.GF_DIM
+        nef = cfg.TEXT.EMBEDDING_DIM
+        ncf = cfg.GAN.CONDITION_DIM
+        self.ca_net = CA_NET()
+        self.h_net1 = INIT_STAGE_GImgup(ngf, ncf, nef)
+        self.h_net2 = NEXT_STAGE_G(ngf, nef, ncf)
+        self.h_net3 = NEXT_STAGE_G(ngf, nef, ncf)
+        self.img_net1 = GET_IMAGE_G_noAct(ngf)
+        self.img_net2 = GET_IMAGE_G_noAct(ngf)
+        self.img_net3 = GET_IMAGE_G_noAct(ngf)
+
+    def forward(self, LR, sent_emb, word_embs, mask, outmiddle=False):
+        fake_imgs, att_maps = [], []
+        c_code, mu, logvar = self.ca_net(sent_emb)          # c_code unused downstream (model.py:51-52)
+        h_code1, att0 = self.h_net1(None, LR, word_embs, mask, wide_out=True)
+        fake_imgs.append(self.img_net1(h_code1))
+        att_maps.append(att0)
+        h_code2, att1 = self.h_net2(h_code1, None, word_embs, mask, wide_out=True)
+        fake_imgs.append(self.img_net2(h_code2))
+        att_maps.append(att1)
+        h_code3, att2 = self.h_net3(h_code2, None, word_embs, mask)
+        fake_imgs.append(self.img_net3(h_code3))
+        att_maps.append(att2)
+        if outmiddle:
+            return fake_imgs, att_maps, mu, logvar, [h_code1, h_code2, h_code3]
+        return fake_imgs, att_maps, mu, logvar
+
+
+class NetG_highweight(nn.Module):
+    """model.py:212-298 with weightmap=False: SRResNet-style high-frequency generator whose three heads are
+    `one * tanh(conv5x5(out)) + a * SRb_k`.  `a` = 0.5 and `one` = 1 are constants, not parameters: in the
+    reference `nn.Parameter(...).cuda()` leaves a plain tensor that is neither trained nor saved
+    (model.py:246-248; netGH_epoch_7.pth has no key `a`)."""
+
+    def __init__(self, weightmap=False, low='lr-lrblur', useAct=True):
+        super(NetG_highweight, self).__init__()
+        if weightmap:
+            raise NotImplementedError("weightmap=True is dead on the shipped path (trainer_objective.py:58)")
+        ngf = cfg.GAN.GF_DIM
+        self.low = low
+        self.useAct = useAct
+        self.residual = nn.Sequential(*[ResBlock(channel_num=32) for _ in range(6)])   # model.py:258-262
+        self.upscale4x = upBlock(ngf, ngf)
+        self.upscale2x = upBlock(ngf, ngf)
+        self.upscale8x = upBlock(ngf, ngf)
+        self.conv_output = nn.Sequential(conv5x5(ngf, 3), nn.Tanh()) if useAct else nn.Sequential(conv5x5(ngf, 3))
+        self.convin = _ConvBnGlu(3, ngf)
+        self.residual24 = _ResidualNoSum(ngf)
+        self.residual48 = _ResidualNoSum(ngf)
+        self.weightmap = False
+        self._a = 0.5
+
+    def _const(self, ref):
+        return ref.new_tensor([self._a]), ref.new_ones(1)
+
+    def _head(self, out, SRb):
+        if not self.useAct:
+            raise NotImplementedError("useAct=False is never constructed by the reference's callers")
+        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=self._a)
+
+    def forward(self, LR, SRb, LRb):
+        SRb2, SRb4, SRb8 = SRb[0], SRb[1], SRb[2]
+        if self.low == 'lrblur':
+            x = LRb
+        elif self.low == 'lr-lrblur':
+            x = LR - LRb
+        else:
+            x = LR
+        out = self.convin(x)
+        out = self.residual(out)
+        out = self.upscale2x(out)
+        ims2 = self._head(out, SRb2)
+        out = self.residual24(out)
+        out = self.upscale4x(out)
+        ims4 = self._head(out, SRb4)
+        out = self.residual48(out)
+        out = self.upscale8x(out)
+        ims8 = self._head(out, SRb8)
+        a, one = self._const(LR)
+        return [ims2, ims4, ims8], a, one

@@ -1,0 +1,175 @@
+"""Tensor-level wrappers over the C ABI (include/tgsr_hip.h): validate, allocate outputs with torch, launch on
+torch's current HIP stream.  PyTorch is plumbing here (device memory + streams); the arithmetic is in
+libtgsr_hip.so.  No function in this file computes on the CPU or through eager torch ops.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import TgsrError, check
+
+BN_EPS = 1e-5
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_hip(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise TgsrError("tgsr_amd ops run only on HIP tensors (got a %s tensor); there is no CPU fallback"
+                            % t.device.type)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TgsrError("%s must be float32, got %s" % (name, t.dtype))
+    return t
+
+
+def _nchw_bstride(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
+    """Accept [B,C,H,W] with a dense (C,H,W) block and ANY batch stride (channel-slice views); else copy."""
+    B, C, H, W = t.shape
+    if t.stride(3) == 1 and t.stride(2) == W and t.stride(1) == H * W:
+        return t, t.stride(0) if B > 1 else C * H * W
+    t = t.contiguous()
+    return t, C * H * W
+
+
+# ----------------------------------------------------------------------------------------- weight prep
+def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> the [ceil(Cin/8)][9][8][Cout] stream order of tgsr_conv3x3_fwd."""
+    _need_hip(w)
+    w = _f32(w.detach(), "weight").contiguous()
+    Cout, Cin, K, K2 = w.shape
+    assert K == 3 and K2 == 3
+    L = _lib.lib()
+    out = torch.empty(L.tgsr_packed_weight_elems(Cout, Cin, 3), dtype=torch.float32, device=w.device)
+    check(L.tgsr_pack_conv_weight(_p(w), _p(out), Cout, Cin, 3, _stream()), "tgsr_pack_conv_weight")
+    return out
+
+
+def bn_fold(weight, bias, running_mean, running_var, eps: float = BN_EPS):
+    """BatchNorm2d(eval) -> (scale, shift) per channel."""
+    _need_hip(weight, bias, running_mean, running_var)
+    C = weight.numel()
+    ts = [_f32(t.detach(), "bn tensor").contiguous() for t in (weight, bias, running_mean, running_var)]
+    scale = torch.empty(C, dtype=torch.float32, device=weight.device)
+    shift = torch.empty_like(scale)
+    check(_lib.lib().tgsr_bn_fold(_p(ts[0]), _p(ts[1]), _p(ts[2]), _p(ts[3]), eps, _p(scale), _p(shift), C, _stream()),
+          "tgsr_bn_fold")
+    return scale, shift
+
+
+# ----------------------------------------------------------------------------------------- convolutions
+def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Optional[torch.Tensor],
+                  shift: Optional[torch.Tensor], glu: bool = False, upsample: bool = False,
+                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3 [+nearest x2 in front] + per-channel affine + (GLU | residual add) in one launch.
+    `out` may be a channel-slice view of a wider buffer (dense C,H,W block, any batch stride)."""
+    _need_hip(x, wpack, scale, shift, residual, out)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    B, Cin, H, W = x.shape
+    Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
+    co = cout // 2 if glu else cout
+    if out is None:
+        out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (B, co, Ho, Wo) or out.stride(3) != 1 or out.stride(2) != Wo or out.stride(1) != Ho * Wo:
+        raise TgsrError("conv3x3_fused: bad `out` shape/strides %s %s" % (tuple(out.shape), out.stride()))
+    obs = out.stride(0) if B > 1 else co * Ho * Wo
+    rbs = 0
+    if residual is not None:
+        if glu:
+            raise TgsrError("conv3x3_fused: residual with GLU is not a reference pattern")
+        residual, rbs = _nchw_bstride(_f32(residual, "residual"), "residual")
+        if tuple(residual.shape) != (B, co, Ho, Wo):
+            raise TgsrError("conv3x3_fused: residual shape %s" % (tuple(residual.shape),))
+    rc = _lib.lib().tgsr_conv3x3_fwd(_p(x), xbs, B, Cin, H, W, _p(wpack), cout, _p(scale), _p(shift), _p(residual), rbs,
+                                     _p(out), obs, _lib.EPI_AFFINE_GLU if glu else _lib.EPI_AFFINE,
+                                     1 if upsample else 0, _stream())
+    check(rc, "tgsr_conv3x3_fwd")
+    return out
+
+
+def conv_to3(x: torch.Tensor, w: torch.Tensor, tanh_axpy: bool = False, addend: Optional[torch.Tensor] = None,
+             alpha: float = 0.0) -> torch.Tensor:
+    """KxK (3|5) conv to 3 channels; tanh_axpy: tanh(conv) + alpha * addend."""
+    _need_hip(x, w, addend)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    w = _f32(w.detach(), "w").contiguous()
+    B, Cin, H, W = x.shape
+    if w.shape[0] != 3 or w.shape[1] != Cin or w.shape[2] != w.shape[3]:
+        raise TgsrError("conv_to3: weight shape %s" % (tuple(w.shape),))
+    if addend is not None:
+        addend = _f32(addend, "addend").contiguous()
+        if tuple(addend.shape) != (B, 3, H, W):
+            raise TgsrError("conv_to3: addend shape %s" % (tuple(addend.shape),))
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().tgsr_conv_to3_fwd(_p(x), xbs, B, Cin, H, W, _p(w), int(w.shape[2]),
+                                      _lib.ACT_TANH_AXPY if tanh_axpy else _lib.ACT_NONE, _p(addend), float(alpha),
+                                      _p(out), _stream())
+    check(rc, "tgsr_conv_to3_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- attention
+def word_attention(h: torch.Tensor, words: torch.Tensor, w_ctx: torch.Tensor, mask: Optional[torch.Tensor],
+                   correct_mask: bool = False, out: Optional[torch.Tensor] = None, need_attn: bool = True):
+    """GlobalAttentionGeneral.forward: h [B,idf,ih,iw], words [B,cdf,T], w_ctx [idf,cdf(,1,1)], mask bool [B,T].
+    Returns (c_code [B,idf,ih,iw], attn [B,T,ih,iw])."""
+    _need_hip(h, words, w_ctx, mask, out)
+    h, hbs = _nchw_bstride(_f32(h, "h"), "h")
+    B, idf, ih, iw = h.shape
+    words = _f32(words, "words").contiguous()
+    cdf, T = words.shape[1], words.shape[2]
+    w2 = _f32(w_ctx.detach(), "w_ctx").reshape(idf, cdf).contiguous()
+    m8 = None
+    if mask is not None:
+        if tuple(mask.shape) != (B, T):
+            raise TgsrError("word_attention: mask shape %s, expected %s" % (tuple(mask.shape), (B, T)))
+        m8 = mask.to(torch.uint8).contiguous()
+    Q = ih * iw
+    if out is None:
+        out = torch.empty(B, idf, ih, iw, dtype=torch.float32, device=h.device)
+    if tuple(out.shape) != (B, idf, ih, iw) or out.stride(3) != 1 or out.stride(2) != iw or out.stride(1) != Q:
+        raise TgsrError("word_attention: bad `out`")
+    cbs = out.stride(0) if B > 1 else idf * Q
+    attn = torch.empty(B, T, ih, iw, dtype=torch.float32, device=h.device) if need_attn else None
+    ws = torch.empty(B * idf * 32, dtype=torch.float32, device=h.device)
+    rc = _lib.lib().tgsr_word_attention_fwd(_p(h), hbs, _p(words), _p(w2), _p(m8), 1 if correct_mask else 0, B, idf,
+                                            cdf, T, Q, _p(ws), _p(out), cbs, _p(attn), _stream())
+    check(rc, "tgsr_word_attention_fwd")
+    return out, attn
+
+
+# ----------------------------------------------------------------------------------------- text encoder
+def bilstm(captions: torch.Tensor, cap_lens, emb: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor,
+           b_ih: torch.Tensor, b_hh: torch.Tensor):
+    """captions int64 [B,W]; cap_lens list/tensor (host or device) ; emb [ntoken,ninput]; w_* stacked over the two
+    directions [2,4H,*].  Returns (words_emb [B,2H,Tmax], sent_emb [B,2H])."""
+    _need_hip(captions, emb, w_ih, w_hh, b_ih, b_hh)
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    B, width = captions.shape
+    if len(lens) != B or min(lens) < 1 or max(lens) > width:
+        raise TgsrError("bilstm: cap_lens %s invalid for captions %s" % (lens, tuple(captions.shape)))
+    Tmax = max(lens)
+    H = w_hh.shape[2]
+    dev = emb.device
+    captions = captions.to(torch.int64).contiguous()
+    lens_d = torch.tensor(lens, dtype=torch.int32).to(dev, non_blocking=False)
+    gates = torch.empty(B * Tmax * 8 * H, dtype=torch.float32, device=dev)
+    words = torch.empty(B, 2 * H, Tmax, dtype=torch.float32, device=dev)
+    sent = torch.empty(B, 2 * H, dtype=torch.float32, device=dev)
+    ts = [_f32(t.detach(), "lstm tensor").contiguous() for t in (emb, w_ih, w_hh, b_ih, b_hh)]
+    rc = _lib.lib().tgsr_bilstm_fwd(_p(captions), width, _p(lens_d), B, Tmax, _p(ts[0]), emb.shape[0], emb.shape[1],
+                                    _p(ts[1]), _p(ts[2]), _p(ts[3]), _p(ts[4]), H, _p(gates), _p(words), _p(sent),
+                                    _stream())
+    check(rc, "tgsr_bilstm_fwd")
+    return words, sent

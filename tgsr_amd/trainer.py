@@ -1,0 +1,61 @@
+"""Counterpart of the reference's inference caller (condGANTrainer.gen_exampleSRHL, trainer_objective.py:55-165,
+and prepare_datablur, datasets.py:71-109): batch preparation, the text-enc -> G_SR_NET_low -> NetG_highweight
+wiring and the uint8 epilogue.  Orchestration only; all arithmetic is in the modules' HIP kernels.
+"""
+import numpy as np
+import torch
+
+from .miscc.config import cfg
+from .model import G_SR_NET_low, NetG_highweight, RNN_ENCODER
+
+
+def sort_by_caption_length(captions, cap_lens, *per_sample):
+    """datasets.py:74-96: sort the batch by caption length, descending (pack_padded_sequence order)."""
+    lens, idx = torch.sort(cap_lens, 0, True)
+    return (captions[idx], lens) + tuple(t[idx] for t in per_sample) + (idx,)
+
+
+def caption_mask(captions, num_words):
+    """trainer_objective.py:136-140: mask = (captions == 0) cropped to the longest caption of the batch."""
+    mask = captions == 0
+    return mask[:, :num_words] if mask.size(1) > num_words else mask
+
+
+def to_uint8(img):
+    """trainer_objective.py:153-155: round(clip((x + 1) * 127.5, 0, 255)) (host side, like the reference)."""
+    a = img.detach().cpu().numpy()
+    return np.round(np.maximum(0, np.minimum(255, (a + 1.0) * 127.5))).astype(np.uint8)
+
+
+class SRPipeline:
+    """The three networks of the shipped x8 path, built like trainer_objective.py:62-99."""
+
+    def __init__(self, n_words, device="cuda", low="lr"):
+        self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
+        self.netGL = G_SR_NET_low()
+        self.netGH = NetG_highweight(weightmap=False, low=low)
+        self.device = torch.device(device)
+        for m in (self.text_encoder, self.netGL, self.netGH):
+            m.to(self.device)
+            m.eval()
+
+    def load_state_dicts(self, sd_E=None, sd_GL=None, sd_GH=None):
+        """strict for E and GL; GH tolerates only a missing `a` (never saved by the reference, model.py:246-248)."""
+        if sd_E is not None:
+            self.text_encoder.load_state_dict(sd_E, strict=True)
+        if sd_GL is not None:
+            self.netGL.load_state_dict(sd_GL, strict=True)
+        if sd_GH is not None:
+            self.netGH.load_state_dict({k: v for k, v in sd_GH.items() if k != "a"}, strict=True)
+        return self
+
+    @torch.no_grad()
+    def __call__(self, captions, cap_lens, LR, LRb):
+        """trainer_objective.py:134-146.  Returns the same tensors the reference loop produces."""
+        hidden = self.text_encoder.init_hidden(captions.shape[0])
+        words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
+        mask = caption_mask(captions, words_embs.size(2))
+        fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
+        fine_im, a, one = self.netGH(LR, fake_imgL, LRb)
+        return {"words_emb": words_embs, "sent_emb": sent_emb, "mask": mask, "fake": fake_imgL,
+                "att": attention_maps, "mu": mu, "logvar": logvar, "fine": fine_im}

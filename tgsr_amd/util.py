@@ -1,0 +1,310 @@
+"""Drop-in for the hot-path symbols of the reference's util.py, on the gfx950 kernels of libtgsr_hip.so.
+
+Same class / function names, constructor arguments, forward signatures, return tuples and **state_dict keys**
+as the reference (util.py:45-130, 175-260, 372-400, 726-823, 894-919), so `Checkpoint/face_S8/*.pth` load
+unchanged.  The nn.Conv2d / nn.BatchNorm2d / nn.LSTM children are parameter holders that keep the key names;
+they are never called - every forward goes through `tgsr_amd.ops` (fused conv + BN + GLU / residual, up-sample
+folded into the conv, fused word attention, BiLSTM kernels).  Inference (eval-mode BN) only for now: a module
+in training mode raises instead of silently computing something else.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .GlobalAttention import GlobalAttentionGeneral as ATT_NET
+from .miscc.config import cfg
+
+
+# ------------------------------------------------------------------------------------------ fused-parameter cache
+def _ver(*ts):
+    return tuple((t.data_ptr(), t._version, t.device) for t in ts if t is not None)
+
+
+class _FusedParams:
+    """Packed conv weight + folded BN affine for one conv(+bn) pair, rebuilt when any source tensor changes
+    (load_state_dict / optimizer step / .cuda())."""
+
+    def __init__(self):
+        self.key = None
+        self.wpack = self.scale = self.shift = None
+
+    def get(self, conv: nn.Conv2d, bn):
+        src = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+        key = _ver(*src)
+        if key != self.key:
+            self.wpack = ops.pack_conv3x3_weight(conv.weight)
+            if bn is not None:
+                self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+            else:
+                self.scale = self.shift = None
+            self.key = key
+        return self.wpack, self.scale, self.shift
+
+
+def _eval_only(m: nn.Module):
+    if m.training:
+        raise NotImplementedError("%s: train-mode BatchNorm (batch statistics) is not on the HIP path yet; call "
+                                  ".eval() (the reference's inference path, trainer_objective.py:98-99)"
+                                  % type(m).__name__)
+
+
+def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=None, out=None):
+    wpack, scale, shift = fp.get(conv, bn)
+    return ops.conv3x3_fused(x, wpack, conv.out_channels, scale, shift, glu=glu, upsample=upsample,
+                             residual=residual, out=out)
+
+
+# ------------------------------------------------------------------------------------------ blocks
+class GLU(nn.Module):
+    """util.py:45-53.  Only a marker inside the fused Sequentials below (its arithmetic is the conv epilogue)."""
+
+    def __init__(self):
+        super(GLU, self).__init__()
+
+    def forward(self, x):
+        raise NotImplementedError("GLU is fused into the producing convolution on the HIP path")
+
+
+def conv1x1(in_planes, out_planes, bias=False):
+    return nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=1, padding=0, bias=bias)
+
+
+def conv3x3(in_planes, out_planes):
+    "3x3 convolution with padding, no bias (util.py:62-65) - parameter holder"
+    return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=1, padding=1, bias=False)
+
+
+def conv5x5(in_planes, out_planes):
+    "util.py:68-69 - parameter holder"
+    return nn.Conv2d(in_planes, out_planes, kernel_size=5, stride=1, padding=2, bias=False)
+
+
+class _UpBlock(nn.Sequential):
+    """upBlock (util.py:74-80): [Upsample(x2 nearest), conv3x3, BatchNorm2d, GLU] as ONE launch
+    (keys `1.weight`, `2.*`)."""
+
+    def __init__(self, in_planes, out_planes):
+        super().__init__(nn.Upsample(scale_factor=2, mode='nearest'), conv3x3(in_planes, out_planes * 2),
+                         nn.BatchNorm2d(out_planes * 2), GLU())
+        self._fp = _FusedParams()
+
+    def forward(self, x, out=None):
+        _eval_only(self)
+        return _conv_bn(x, self._fp, self[1], self[2], glu=True, upsample=True, out=out)
+
+
+def upBlock(in_planes, out_planes):
+    return _UpBlock(in_planes, out_planes)
+
+
+class _ConvBnGlu(nn.Sequential):
+    """conv3x3 -> BatchNorm2d -> GLU (Block3x3_relu util.py:101-106, im2f util.py:741-744, convin model.py:228);
+    keys `0.weight`, `1.*`."""
+
+    def __init__(self, in_planes, out_planes):
+        super().__init__(conv3x3(in_planes, out_planes * 2), nn.BatchNorm2d(out_planes * 2), GLU())
+        self._fp = _FusedParams()
+
+    def forward(self, x, out=None):
+        _eval_only(self)
+        return _conv_bn(x, self._fp, self[0], self[1], glu=True, out=out)
+
+
+def Block3x3_relu(in_planes, out_planes):
+    return _ConvBnGlu(in_planes, out_planes)
+
+
+class _ResidualNoSum(nn.Sequential):
+    """model.py:229-232 `residual24/48`: conv-BN-GLU-conv-BN, NO skip add (keys 0,1,3,4)."""
+
+    def __init__(self, ngf):
+        super().__init__(conv3x3(ngf, ngf * 2), nn.BatchNorm2d(ngf * 2), GLU(), conv3x3(ngf, ngf),
+                         nn.BatchNorm2d(ngf))
+        self._fp0, self._fp1 = _FusedParams(), _FusedParams()
+
+    def forward(self, x):
+        _eval_only(self)
+        y = _conv_bn(x, self._fp0, self[0], self[1], glu=True)
+        return _conv_bn(y, self._fp1, self[3], self[4])
+
+
+class ResBlock(nn.Module):
+    """util.py:110-130: x + BN(conv(GLU(BN(conv(x))))) in two launches (keys `block.{0,1,3,4}.*`)."""
+
+    def __init__(self, channel_num, batchnorm=True):
+        super(ResBlock, self).__init__()
+        if not batchnorm:
+            raise NotImplementedError("ResBlock(batchnorm=False) is only used by G_SR_NET_low_stage1 (dead: "
+                                      "stage1=False, trainer_objective.py:56)")
+        self.block = nn.Sequential(conv3x3(channel_num, channel_num * 2), nn.BatchNorm2d(channel_num * 2), GLU(),
+                                   conv3x3(channel_num, channel_num), nn.BatchNorm2d(channel_num))
+        self._fp0, self._fp1 = _FusedParams(), _FusedParams()
+
+    def forward(self, x):
+        _eval_only(self)
+        y = _conv_bn(x, self._fp0, self.block[0], self.block[1], glu=True)
+        return _conv_bn(y, self._fp1, self.block[3], self.block[4], residual=x)
+
+
+# ------------------------------------------------------------------------------------------ text encoder
+class RNN_ENCODER(nn.Module):
+    """util.py:175-260.  Embedding + bidirectional 1-layer LSTM; forward = tgsr_bilstm_fwd (eval mode: the
+    reference's Dropout(0.5) is the identity there).  state_dict keys: `encoder.weight`, `rnn.*_l0[_reverse]`."""
+
+    def __init__(self, ntoken, ninput=300, drop_prob=0.5, nhidden=128, nlayers=1, bidirectional=True):
+        super(RNN_ENCODER, self).__init__()
+        self.n_steps = cfg.TEXT.WORDS_NUM
+        self.ntoken = ntoken
+        self.ninput = ninput
+        self.drop_prob = drop_prob
+        self.nlayers = nlayers
+        self.bidirectional = bidirectional
+        self.rnn_type = cfg.RNN_TYPE
+        if self.rnn_type != 'LSTM' or nlayers != 1 or not bidirectional:
+            raise NotImplementedError("HIP text encoder: 1-layer bidirectional LSTM only (the shipped configuration)")
+        self.num_directions = 2
+        self.nhidden = nhidden // self.num_directions
+        self.encoder = nn.Embedding(self.ntoken, self.ninput)
+        self.drop = nn.Dropout(self.drop_prob)
+        self.rnn = nn.LSTM(self.ninput, self.nhidden, self.nlayers, batch_first=True, bidirectional=True)
+        self.init_weights()
+        self._key = None
+        self._stacked = None
+
+    def init_weights(self):
+        self.encoder.weight.data.uniform_(-0.1, 0.1)  # util.py:214-216
+
+    def init_hidden(self, bsz):
+        w = next(self.parameters()).data
+        z = w.new_zeros(self.nlayers * self.num_directions, bsz, self.nhidden)
+        return (z, z.clone())
+
+    def _weights(self):
+        r = self.rnn
+        src = [r.weight_ih_l0, r.weight_ih_l0_reverse, r.weight_hh_l0, r.weight_hh_l0_reverse, r.bias_ih_l0,
+               r.bias_ih_l0_reverse, r.bias_hh_l0, r.bias_hh_l0_reverse]
+        key = _ver(*src)
+        if key != self._key:
+            d = [t.detach() for t in src]
+            self._stacked = (torch.stack(d[0:2]).contiguous(), torch.stack(d[2:4]).contiguous(),
+                             torch.stack(d[4:6]).contiguous(), torch.stack(d[6:8]).contiguous())
+            self._key = key
+        return self._stacked
+
+    def forward(self, captions, cap_lens, hidden=None, mask=None):
+        """captions int64 [B, n_steps] sorted by length (desc), cap_lens [B] -> (words_emb [B, 2H, T_max],
+        sent_emb [B, 2H]).  `hidden` must be the zero state of init_hidden (the only use in the reference)."""
+        if self.training and self.drop_prob > 0:
+            raise NotImplementedError("RNN_ENCODER: training-mode dropout is not on the HIP path yet; call .eval()")
+        w_ih, w_hh, b_ih, b_hh = self._weights()
+        return ops.bilstm(captions, cap_lens, self.encoder.weight, w_ih, w_hh, b_ih, b_hh)
+
+
+class CA_NET(nn.Module):
+    """util.py:372-400.  One 256->400 Linear + GLU on [B,256]: a plain library GEMM (rocBLAS through torch);
+    `c_code` is sampled to keep the reference's RNG consumption (util.py:388-396) and discarded by the caller."""
+
+    def __init__(self):
+        super(CA_NET, self).__init__()
+        self.t_dim = cfg.TEXT.EMBEDDING_DIM
+        self.c_dim = cfg.GAN.CONDITION_DIM
+        self.fc = nn.Linear(self.t_dim, self.c_dim * 4, bias=True)
+
+    def encode(self, text_embedding):
+        x = self.fc(text_embedding)
+        nc = x.size(1) // 2
+        x = x[:, :nc] * torch.sigmoid(x[:, nc:])
+        return x[:, :self.c_dim], x[:, self.c_dim:]
+
+    def reparametrize(self, mu, logvar):
+        std = logvar.mul(0.5).exp()
+        eps = torch.empty_like(std).normal_()
+        return eps.mul(std).add_(mu)
+
+    def forward(self, text_embedding):
+        mu, logvar = self.encode(text_embedding)
+        return self.reparametrize(mu, logvar), mu, logvar
+
+
+# ------------------------------------------------------------------------------------------ generator stages
+def _make_res_layers(channel_num):
+    return nn.Sequential(*[ResBlock(channel_num) for _ in range(cfg.GAN.R_NUM)])
+
+
+def _up_into(upsample, x, ngf, wide_out):
+    """Run the stage's upBlock; with wide_out the result is written as the first half of a fresh
+    [B, 2ngf, 2H, 2W] buffer (tagged on the returned view) so the next stage's torch.cat is free."""
+    if not wide_out:
+        return upsample(x)
+    B, _, H, W = x.shape
+    wide = torch.empty(B, 2 * ngf, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    out = upsample(x, out=wide[:, :ngf])
+    out._tgsr_wide = wide
+    return out
+
+
+class INIT_STAGE_GImgup(nn.Module):
+    """util.py:726-777: im2f -> word attention -> cat -> R_NUM ResBlocks -> upBlock.
+    The cat never runs: im2f and the attention kernel write the two halves of one [B, 2ngf, H, W] buffer."""
+
+    def __init__(self, ngf, ncf, nef, batchnorm=True):
+        super(INIT_STAGE_GImgup, self).__init__()
+        if not batchnorm:
+            raise NotImplementedError("INIT_STAGE_GImgup(batchnorm=False) belongs to the dead stage1 branch")
+        self.gf_dim = ngf
+        self.in_dim = cfg.GAN.Z_DIM + ncf
+        self.ef_dim = nef
+        self.att = ATT_NET(self.gf_dim, self.ef_dim)
+        self.im2f = _ConvBnGlu(3, ngf)
+        self.upsample = upBlock(ngf * 2, ngf)
+        self.residual = _make_res_layers(ngf * 2)
+
+    def forward(self, c_code0, LR, word_embs, mask, wide_out=False):
+        B, _, H, W = LR.shape
+        ngf = self.gf_dim
+        self.att.applyMask(mask)
+        hc = torch.empty(B, 2 * ngf, H, W, dtype=torch.float32, device=LR.device)
+        h_code = self.im2f(LR, out=hc[:, :ngf])
+        _, att = self.att(h_code, word_embs, out=hc[:, ngf:])
+        out_code1 = self.residual(hc)
+        return _up_into(self.upsample, out_code1, ngf, wide_out), att
+
+
+class NEXT_STAGE_G(nn.Module):
+    """util.py:781-823: word attention -> cat -> R_NUM ResBlocks -> upBlock."""
+
+    def __init__(self, ngf, nef, ncf, weightatten=False):
+        super(NEXT_STAGE_G, self).__init__()
+        if weightatten:
+            raise NotImplementedError("GlobalAttentionGeneral_weight is unused on the shipped path")
+        self.gf_dim = ngf
+        self.ef_dim = nef
+        self.cf_dim = ncf
+        self.num_residual = cfg.GAN.R_NUM
+        self.att = ATT_NET(ngf, self.ef_dim)
+        self.residual = _make_res_layers(ngf * 2)
+        self.upsample = upBlock(ngf * 2, ngf)
+
+    def forward(self, h_code, c_code0, word_embs, mask, wide_out=False):
+        B, ngf, H, W = h_code.shape
+        self.att.applyMask(mask)
+        wide = getattr(h_code, "_tgsr_wide", None)
+        if wide is None:  # stand-alone use: build the concatenated buffer (one copy, = the reference's cat)
+            wide = torch.empty(B, 2 * ngf, H, W, dtype=torch.float32, device=h_code.device)
+            wide[:, :ngf].copy_(h_code)
+            h_code = wide[:, :ngf]
+        _, att = self.att(h_code, word_embs, out=wide[:, ngf:])
+        out_code = self.residual(wide)
+        return _up_into(self.upsample, out_code, ngf, wide_out), att
+
+
+class GET_IMAGE_G_noAct(nn.Module):
+    """util.py:909-919: conv3x3 ngf -> 3, no activation (key `img.0.weight`)."""
+
+    def __init__(self, ngf):
+        super(GET_IMAGE_G_noAct, self).__init__()
+        self.gf_dim = ngf
+        self.img = nn.Sequential(conv3x3(ngf, 3))
+
+    def forward(self, h_code):
+        return ops.conv_to3(h_code, self.img[0].weight)
