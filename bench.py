@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: text-conditioned x8 super-resolution, images / second.
+
+One step = one pass of the SR hot path (BiLSTM text encoder -> G_SR_NET_low -> NetG_highweight, forward, eval-mode
+BN, fp32) over one batch of 16 synthetic CelebA-shaped samples (32x32 -> 256x256) that is already resident in HBM
+(BASELINE.json configs[1]).  With N GPUs every rank runs the same per-GPU batch on its own images (weak scaling,
+independent images, no data-path collective - SURVEY.md 8e); `value` = all images processed / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = conv3x3_mfma_kernel, per-launch HIP-event
+timing inside the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def load_weights():
+    """Shipped x8 face checkpoint (committed as a data fixture) when present, else None -> seeded random init."""
+    p = os.path.join(ROOT, "tests", "golden", "face_S8_weights.npz")
+    if not os.path.exists(p):
+        return None
+    z = np.load(p)
+    out = {"E.": {}, "GL.": {}, "GH.": {}}
+    for k in z.files:
+        for pre in out:
+            if k.startswith(pre):
+                out[pre][k[len(pre):]] = torch.from_numpy(z[k])
+    return out
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box hands one
+    GPU a share of the host's cores; running oneDNN on every visible core would only oversubscribe it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    try:
+        n = min(n, int(os.environ.get("TGSR_CPU_CORES", n)))
+    except ValueError:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(weights, batch, budget_s=20.0):
+    """The oracle (CPU restatement of the reference, plain PyTorch/oneDNN) on this host's cores, bounded sample."""
+    from oracle import tgsr_oracle as O
+    torch.set_num_threads(usable_cores())
+    if weights is None:
+        sdE, sdL, sdH = O.random_state(seed=0)
+    else:
+        sdE, sdL, sdH = weights["E."], weights["GL."], weights["GH."]
+    cap, lens, LR, LRb = O.synthetic_batch(batch)
+    with torch.no_grad():
+        O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)       # warm-up
+        ts = []
+        t_all = time.perf_counter()
+        while len(ts) < 5 and (time.perf_counter() - t_all) < budget_s:
+            t0 = time.perf_counter()
+            O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
+            ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle.sr_forward (CPU PyTorch restatement, fp32, eval BN), batch %d, warm-up 1 + median of %d "
+                      "runs, %.2f s/batch" % (batch, len(ts), med)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from tgsr_amd import _lib, ops
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.synthetic import random_init_, synthetic_batch
+    from tgsr_amd.trainer import SRPipeline
+    _lib.lib()   # no HIP library -> error, never a fallback
+    cfg_reset()
+    cfg.GAN.GF_DIM = 32
+    cfg.TEXT.EMBEDDING_DIM = 256
+    cfg.TREE.BRANCH_NUM = 4
+    cfg.TREE.BASE_SIZE = 32
+
+    weights = load_weights()
+    pipe = SRPipeline(41, device=dev, low="lr")
+    if weights is not None:
+        pipe.load_state_dicts(weights["E."], weights["GL."], weights["GH."])
+        wdesc = "shipped face_S8 checkpoint (tests/golden fixture), random-init text encoder"
+    else:
+        for i, m in enumerate((pipe.netGL, pipe.netGH)):
+            random_init_(m, seed=i)
+        wdesc = "seeded random-init weights"
+    B = args.batch
+    cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
+    cap, LR, LRb = cap.to(dev), LR.to(dev), LRb.to(dev)
+    lens = lens.tolist()
+
+    def step():
+        return pipe(cap, lens, LR, LRb)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ops.profile = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof, ops.profile = ops.profile, None
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # per-kernel totals from the HIP events recorded around every launch of the timed region
+        agg = {}
+        for name, flops, nbytes, e0, e1 in prof:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += nbytes
+            a[3] += e0.elapsed_time(e1) * 1e-3
+        n, fl, by, sec = agg["conv3x3_mfma_kernel"]
+        ach = fl / sec / 1e12
+        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": round(ach, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None, "launches_per_step": n // args.steps,
+                "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_step": fl / args.steps,
+                "hbm_GBs_algorithmic": round(by / sec / 1e9, 1)}
+        kern = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[3] / args.steps * 1e3, 4),
+                    "TFLOPs": round(v[1] / v[3] / 1e12, 2), "GBs_algorithmic": round(v[2] / v[3] / 1e9, 1)}
+                for k, v in agg.items()}
+        res = {"metric": "SR images/sec (32->256, batch 16 per GPU)", "value": round(world * B * args.steps / dt, 2),
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic inputs (seed 100); " + wdesc,
+               "config": {"workload": "CelebA face x8 (32->256) batch=16 per GPU, text-enc + G_SR_NET_low + "
+                                      "NetG_highweight forward, eval BN (BASELINE configs[1])",
+                          "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world},
+               "roofline": roof, "kernels": kern}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(weights, B)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

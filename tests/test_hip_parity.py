@@ -179,17 +179,18 @@ def test_resblock_upblock_modules_golden(ops_small, cfg_small):
     g = ops_small
     x = T(g["blk.x"])
     rb = util.ResBlock(64)
-    rb.load_state_dict(split_sd(g, "rb."))
+    params = lambda pre: {k: v for k, v in split_sd(g, pre).items() if k[0].isdigit() or k.startswith("block.")}
+    rb.load_state_dict(params("rb."))
     rb.to(DEV).eval()
     close(rb(x), g["rb.eval"], atol=2e-5)
     ub = util.upBlock(64, 32)
-    ub.load_state_dict(split_sd(g, "ub."))
+    ub.load_state_dict(params("ub."))
     ub.to(DEV).eval()
     close(ub(x), g["ub.eval"], atol=2e-5)
     # weights changed in place -> the packed/folded cache must follow
     with torch.no_grad():
         ub[1].weight.mul_(2.0)
-    sd = {k: v.clone() for k, v in split_sd(g, "ub.").items()}
+    sd = {k: v.clone() for k, v in params("ub.").items()}
     sd["1.weight"] *= 2
     close(ub(x), O.up_block(T(g["blk.x"], "cpu"), sd, ""), atol=4e-5)
 

@@ -55,6 +55,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise TgsrError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` or "
                             "`make -C tgsr_amd/csrc`; tgsr_amd has no CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): it must be in the process first so the
+        # dynamic linker binds our library to THAT runtime - two HIP runtimes in one process do not share a device.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError = a header function the library does not export

@@ -12,6 +12,16 @@ from ._lib import TgsrError, check
 
 BN_EPS = 1e-5
 
+# Per-launch measurement hook (bench.py): when `profile` is a list, every conv / attention launch is bracketed
+# with HIP events on the launch stream and appended as (kernel, algorithmic flops, algorithmic bytes, e0, e1).
+profile = None
+
+
+def _ev():
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -91,10 +101,14 @@ def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Option
         residual, rbs = _nchw_bstride(_f32(residual, "residual"), "residual")
         if tuple(residual.shape) != (B, co, Ho, Wo):
             raise TgsrError("conv3x3_fused: residual shape %s" % (tuple(residual.shape),))
+    e0 = _ev() if profile is not None else None
     rc = _lib.lib().tgsr_conv3x3_fwd(_p(x), xbs, B, Cin, H, W, _p(wpack), cout, _p(scale), _p(shift), _p(residual), rbs,
                                      _p(out), obs, _lib.EPI_AFFINE_GLU if glu else _lib.EPI_AFFINE,
                                      1 if upsample else 0, _stream())
     check(rc, "tgsr_conv3x3_fwd")
+    if profile is not None:
+        nbytes = 4 * (B * Cin * H * W + B * co * Ho * Wo * (2 if residual is not None else 1) + cout * Cin * 9)
+        profile.append(("conv3x3_mfma_kernel", 2.0 * B * Ho * Wo * cout * Cin * 9, nbytes, e0, _ev()))
     return out
 
 
@@ -112,10 +126,15 @@ def conv_to3(x: torch.Tensor, w: torch.Tensor, tanh_axpy: bool = False, addend: 
         if tuple(addend.shape) != (B, 3, H, W):
             raise TgsrError("conv_to3: addend shape %s" % (tuple(addend.shape),))
     out = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+    e0 = _ev() if profile is not None else None
     rc = _lib.lib().tgsr_conv_to3_fwd(_p(x), xbs, B, Cin, H, W, _p(w), int(w.shape[2]),
                                       _lib.ACT_TANH_AXPY if tanh_axpy else _lib.ACT_NONE, _p(addend), float(alpha),
                                       _p(out), _stream())
     check(rc, "tgsr_conv_to3_fwd")
+    if profile is not None:
+        K = int(w.shape[2])
+        nbytes = 4 * (B * Cin * H * W + B * 3 * H * W * (2 if addend is not None else 1))
+        profile.append(("conv_to3_kernel", 2.0 * B * H * W * 3 * Cin * K * K, nbytes, e0, _ev()))
     return out
 
 
@@ -143,9 +162,13 @@ def word_attention(h: torch.Tensor, words: torch.Tensor, w_ctx: torch.Tensor, ma
     cbs = out.stride(0) if B > 1 else idf * Q
     attn = torch.empty(B, T, ih, iw, dtype=torch.float32, device=h.device) if need_attn else None
     ws = torch.empty(B * idf * 32, dtype=torch.float32, device=h.device)
+    e0 = _ev() if profile is not None else None
     rc = _lib.lib().tgsr_word_attention_fwd(_p(h), hbs, _p(words), _p(w2), _p(m8), 1 if correct_mask else 0, B, idf,
                                             cdf, T, Q, _p(ws), _p(out), cbs, _p(attn), _stream())
     check(rc, "tgsr_word_attention_fwd")
+    if profile is not None:
+        nbytes = 4 * B * Q * (2 * idf + (T if need_attn else 0))
+        profile.append(("word_attention_kernel", 4.0 * B * Q * idf * T, nbytes, e0, _ev()))
     return out, attn
 
 
