@@ -43,7 +43,7 @@ int tgsr_abi_version(void);
 const char* tgsr_last_error(void);
 
 /*
- * Re-lay a conv weight [Cout][Cin][K][K] (torch layout) as [ceil(Cin/8)][K*K][8][Cout] with zero-filled
+ * Re-lay a conv weight [Cout][Cin][K][K] (torch layout) as [ceil(Cin/4)][K*K][4][Cout] with zero-filled
  * channel padding: the order tgsr_conv3x3_fwd streams it into LDS.  Replaces nothing in the reference (layout
  * only); done once per weight version.  wpack must hold tgsr_packed_weight_elems(Cout,Cin,K) floats.
  */

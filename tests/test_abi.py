@@ -27,8 +27,8 @@ def test_library_exports_every_header_symbol():
     L.tgsr_abi_version.restype = ctypes.c_int
     assert L.tgsr_abi_version() == _lib.ABI_VERSION
     L.tgsr_packed_weight_elems.restype = ctypes.c_int64
-    assert L.tgsr_packed_weight_elems(128, 64, 3) == 8 * 9 * 8 * 128
-    assert L.tgsr_packed_weight_elems(64, 3, 3) == 1 * 9 * 8 * 64
+    assert L.tgsr_packed_weight_elems(128, 64, 3) == 16 * 9 * 4 * 128
+    assert L.tgsr_packed_weight_elems(64, 3, 3) == 1 * 9 * 4 * 64
 
 
 def test_ops_refuse_cpu_tensors_loudly():

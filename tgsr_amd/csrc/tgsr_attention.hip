@@ -15,18 +15,35 @@
 
 namespace tgsr {
 
-__global__ void word_project_kernel(const float* __restrict__ words, const float* __restrict__ w_ctx,
-                                    float* __restrict__ src, int idf, int cdf, int T) {
-  // grid = B; src is [B][idf][32] with zeros for t >= T
-  const int b = blockIdx.x;
+// grid (B, idf / 8), 256 threads: thread (i = 8 * blockIdx.y + tid / 32, t = tid % 32) owns one output; the
+// sample's words are staged once in LDS as [c][32] (zero padded), the weight row is a half-wave-uniform float4 stream.
+__global__ __launch_bounds__(256) void word_project_kernel(const float* __restrict__ words,
+                                                           const float* __restrict__ w_ctx, float* __restrict__ src,
+                                                           int idf, int cdf, int T) {
+  extern __shared__ __attribute__((aligned(16))) float ws[];   // [cdf][32]
+  const int b = blockIdx.x, tid = threadIdx.x;
   const float* wb = words + (int64_t)b * cdf * T;
-  for (int o = threadIdx.x; o < idf * 32; o += blockDim.x) {
-    const int i = o >> 5, t = o & 31;
-    float acc = 0.f;
-    if (t < T)
-      for (int c = 0; c < cdf; ++c) acc = fmaf(w_ctx[i * cdf + c], wb[c * T + t], acc);
-    src[((int64_t)b * idf + i) * 32 + t] = acc;
+  for (int o = tid; o < cdf * 32; o += 256) {
+    const int c = o >> 5, t = o & 31;
+    ws[o] = t < T ? wb[c * T + t] : 0.f;
   }
+  __syncthreads();
+  const int i = blockIdx.y * 8 + (tid >> 5), t = tid & 31;
+  const float* wr = w_ctx + (int64_t)i * cdf;
+  float acc = 0.f;
+  int c = 0;
+  if ((cdf & 3) == 0) {
+#pragma unroll 4
+    for (; c < cdf; c += 4) {
+      const float4 wv = *reinterpret_cast<const float4*>(wr + c);
+      acc = fmaf(wv.x, ws[(c + 0) * 32 + t], acc);
+      acc = fmaf(wv.y, ws[(c + 1) * 32 + t], acc);
+      acc = fmaf(wv.z, ws[(c + 2) * 32 + t], acc);
+      acc = fmaf(wv.w, ws[(c + 3) * 32 + t], acc);
+    }
+  }
+  for (; c < cdf; ++c) acc = fmaf(wr[c], ws[c * 32 + t], acc);
+  src[((int64_t)b * idf + i) * 32 + t] = acc;
 }
 
 struct AttnArgs {
@@ -155,7 +172,9 @@ extern "C" int tgsr_word_attention_fwd(const float* h, int64_t h_bstride, const 
   if (!h || !words || !w_ctx || !src_ws || !c_code || B < 1 || cdf < 1 || Q < 1 || T < 1) return TGSR_EINVAL;
   if (T > 32 || (idf != 32 && idf != 64 && idf != 128)) return TGSR_EUNSUPPORTED;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(word_project_kernel, dim3(B), dim3(256), 0, s, words, w_ctx, src_ws, idf, cdf, T);
+  if (cdf > 1024) return TGSR_EUNSUPPORTED;   // words of one sample are staged in LDS (cdf * 128 bytes)
+  hipLaunchKernelGGL(word_project_kernel, dim3(B, idf / 8), dim3(256), (size_t)cdf * 32 * sizeof(float), s, words,
+                     w_ctx, src_ws, idf, cdf, T);
   int rc = note_launch(hipGetLastError(), "word_project_kernel");
   if (rc) return rc;
   AttnArgs a;

@@ -11,7 +11,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;     // CDNA wavefront
-constexpr int kConvCK = 8;    // input channels staged per LDS chunk (== the packed-weight chunk)
+constexpr int kConvCK = 4;    // input channels per LDS stage (== the packed-weight chunk)
 
 // Records a launch failure for tgsr_last_error(); returns the ABI status.
 int note_launch(hipError_t e, const char* what);

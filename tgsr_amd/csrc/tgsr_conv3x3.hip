@@ -10,10 +10,11 @@
 //   * a workgroup = 4 waves = TH x 32 output pixels x (1..4) blocks of 32 output channels; each wave owns
 //     R rows and ALL the channel blocks, so a weight fragment is reused R times and an input fragment NCB times
 //     from registers, and both come from LDS as conflict-free ds_read_b32 (32 consecutive dwords per half-wave).
-//   * K loop = input-channel chunks of 8 staged in LDS: [8][TR][PITCH] halo tile + [9 taps][8][NCB*32]
-//     weights (pre-packed on the device so the weight stage is straight float4 copies).
-//   * 48 KB LDS and ~128 accumulator VGPRs per workgroup -> 3 workgroups per CU overlap one another's
-//     staging with MFMA issue (fp32 MFMA is 64 cycles/instruction: LDS and L2 have large slack).
+//   * K loop = input-channel stages of 4, double buffered in LDS: [4][TR][PITCH] halo tile + [9 taps][4][NCB*32]
+//     weights (pre-packed on the device).  Stages are filled by LDS-DMA (global_load_lds, 16 B/lane for weights,
+//     4 B/lane for the misaligned halo rows, out-of-image lanes read a zero word) issued one stage ahead, so the
+//     copy of stage c+1 runs under the 9.2k MFMA cycles of stage c: one barrier per stage, no staging VGPRs.
+//   * <= 48 KB LDS and ~128 accumulator VGPRs per workgroup -> 2-3 workgroups per CU.
 #include "tgsr_common.h"
 
 namespace tgsr {
@@ -33,6 +34,28 @@ struct ConvArgs {
   int Ho, Wo, tiles_x, tiles_y, nchunks;
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// Source of every out-of-image / past-Cin element of a halo tile: the LDS-DMA has no predicate, so lanes that
+// would read outside the tensor read this zero instead.
+__device__ __attribute__((aligned(16))) float g_conv_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+#ifdef TGSR_CONV_STAMPS
+// Diagnostic build only (tools/conv_stamps.py): per-workgroup cycle stamps, never compiled into the shipped library.
+__device__ unsigned long long g_stamps[8 * 8192];
+#define TGSR_STAMP(k)                                                                          \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {                                               \
+      g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime();                           \
+      if ((k) == 0) g_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();           \
+      if ((k) == 3) g_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();           \
+    }                                                                                          \
+  } while (0)
+#else
+#define TGSR_STAMP(k)
+#endif
+
 template <int NOB, bool GLU, bool UP, int R>
 struct ConvCfg {
   static constexpr int NCB = NOB * (GLU ? 2 : 1);  // accumulator blocks of 32 couts per row
@@ -43,16 +66,86 @@ struct ConvCfg {
   static constexpr int PITCH = TC;
   static constexpr int PLANE = TR * PITCH;
   static constexpr int IN_ELEMS = kConvCK * PLANE;
+  static constexpr int IN_UNITS = (IN_ELEMS + 63) / 64;        // 64-dword LDS-DMA pieces
   static constexpr int W_ELEMS = 9 * kConvCK * NCOL;
+  static constexpr int W_UNITS = (W_ELEMS + 255) / 256;        // 64 x 16-byte LDS-DMA pieces
+  static constexpr int W_PAD = W_UNITS * 256;
+  static constexpr int BUF = W_PAD + IN_UNITS * 64;            // floats per stage buffer
+  static constexpr int SMEM = 2 * BUF + 2 * NCOL;              // two stages + the epilogue's scale/shift columns
+};
+
+// One stage (= kConvCK input channels): weights [9][CK][NCOL] then the input halo tile [CK][TR][PITCH], both
+// written by LDS-DMA (global_load_lds): no VGPR round trip, the copy of stage c+1 flies under the MFMAs of stage c.
+// The per-lane source offsets do not depend on the stage, so they are computed once (StagePlan) and a DMA piece
+// costs ~8 instructions; the pieces are issued one per k-step INSIDE the MFMA stream, where VALU issue is free.
+template <int NOB, bool GLU, bool UP, int R>
+struct StagePlan {
+  using C = ConvCfg<NOB, GLU, UP, R>;
+  static constexpr int WK = (C::W_UNITS + 3) / 4;   // weight pieces per wave per stage (64 lanes x 16 B each)
+  static constexpr int IK = (C::IN_UNITS + 3) / 4;  // input pieces per wave per stage (64 lanes x 4 B each)
+  int woff[WK];   // float offset inside the packed-weight stage block, -1 = padding lane
+  int ioff[IK];   // (channel-in-stage << 28) | (gy * W + gx), -1 = outside the image / padding lane
+
+  __device__ __forceinline__ void init(const ConvArgs& a, int wave, int lane, int grp, int sy0, int sx0) {
+    constexpr int NCOL = C::NCOL, TR = C::TR, TC = C::TC;
+#pragma unroll
+    for (int k = 0; k < WK; ++k) {
+      const int q = (wave + 4 * k) * 64 + lane;  // float4 index inside the stage's weight block
+      const int row = q / (NCOL / 4);
+      const int c4 = q - row * (NCOL / 4);
+      const int seg = c4 >> 3, f4 = c4 & 7;
+      int col;
+      if (GLU)
+        col = (seg < NOB ? (grp * NOB + seg) * 32 : (a.Cout >> 1) + (grp * NOB + seg - NOB) * 32);
+      else
+        col = (grp * NOB + seg) * 32;
+      woff[k] = (row < 9 * kConvCK) ? row * a.Cout + col + f4 * 4 : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < IK; ++k) {
+      const int idx = (wave + 4 * k) * 64 + lane;
+      const int c = idx / (TR * TC);
+      const int rem = idx - c * (TR * TC);
+      const int r = rem / TC, cc = rem - r * TC;
+      const int gy = sy0 + r, gx = sx0 + cc;
+      const bool ok = c < kConvCK && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      ioff[k] = ok ? ((c << 28) | (gy * a.W + gx)) : -1;
+    }
+  }
+
+  // piece p of stage `ch` -> buf;  p < WK: weights, else input.  p is a compile-time constant at every call.
+  __device__ __forceinline__ void issue(int p, const ConvArgs& a, float* buf, int ch, int wave, const float* xb,
+                                        uint32_t HW) const {
+    if (p < WK) {
+      const int u = wave + 4 * p;
+      if (4 * p + 3 < C::W_UNITS || u < C::W_UNITS) {
+        const float* wsrc = a.wpack + (int64_t)ch * 9 * kConvCK * a.Cout;
+        const float* g = woff[p] >= 0 ? wsrc + woff[p] : g_conv_zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(buf + u * 256), 16, 0, 0);
+      }
+    } else {
+      const int k = p - WK;
+      const int u = wave + 4 * k;
+      if (4 * k + 3 < C::IN_UNITS || u < C::IN_UNITS) {
+        const int v = ioff[k];
+        const int c = ch * kConvCK + (v >> 28);
+        const bool ok = v >= 0 && c < a.Cin;
+        const float* g = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(v & 0x0fffffff) : g_conv_zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(buf + C::W_PAD + u * 64), 4, 0, 0);
+      }
+    }
+  }
 };
 
 template <int NOB, bool GLU, bool UP, int R>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   using C = ConvCfg<NOB, GLU, UP, R>;
-  constexpr int NCB = C::NCB, NCOL = C::NCOL, TH = C::TH, TR = C::TR, TC = C::TC, PITCH = C::PITCH, PLANE = C::PLANE;
-  __shared__ __attribute__((aligned(16))) float smem[C::IN_ELEMS + C::W_ELEMS];
-  float* in_s = smem + C::W_ELEMS;
-  float* w_s = smem;
+  using Plan = StagePlan<NOB, GLU, UP, R>;
+  constexpr int NCB = C::NCB, NCOL = C::NCOL, TH = C::TH, PITCH = C::PITCH, PLANE = C::PLANE;
+  constexpr int NS = 9 * (kConvCK / 2);  // k-steps (tap, channel pair) per stage
+  constexpr int NP = Plan::WK + Plan::IK;  // DMA pieces per wave per stage
+  static_assert(NP <= NS, "one DMA piece per k-step must cover a stage");
+  __shared__ __attribute__((aligned(16))) float smem[C::SMEM];  // ONE array: two stage buffers + affine columns
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -66,6 +159,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   const int grp = blockIdx.y;
   const int ty0 = ty * TH, tx0 = tx * 32;
   const int sy0 = (UP ? (ty0 >> 1) : ty0) - 1, sx0 = (UP ? (tx0 >> 1) : tx0) - 1;
+  const float* xb = a.x + (int64_t)b * a.xbs;
+  const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
+
+  TGSR_STAMP(0);
+  Plan plan;
+  plan.init(a, wave, lane, grp, sy0, sx0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) plan.issue(p, a, smem, 0, wave, xb, HW);
 
   f32x16 acc[NCB][R];
 #pragma unroll
@@ -75,112 +176,131 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[cb][r][i] = 0.f;
 
-  // lane-dependent LDS offsets (in floats)
-  const int a_off = h * NCOL + l31;
+  // lane-dependent LDS offsets (floats) of the two MFMA operands inside a stage buffer
+  const int a_off = h * NCOL + l31;                      // weights: [tap][ci][NCOL]
+  const int wrow = wave * R;
+  int b_off[3][R];                                       // input: [ci][row][col], per (ky, r); kx adds b_col
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      b_off[ky][r] = C::W_PAD + h * PLANE + (UP ? (((wrow + r + ky - 1) >> 1) + 1) : (wrow + r + ky)) * PITCH;
   int b_col[3];
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx) b_col[kx] = UP ? (((l31 + kx - 1) >> 1) + 1) : (l31 + kx);
-  const int b_base = h * PLANE;
-  const int wrow = wave * R;
 
-  const float* xb = a.x + (int64_t)b * a.xbs;
-  const int64_t HW = (int64_t)a.H * a.W;
+  // per-column affine (BN eval) of this workgroup's channels -> LDS, so the epilogue issues no global loads
+  float* aff_s = smem + 2 * C::BUF;
+  if (tid < NCOL) {
+    const int seg = tid >> 5, i = tid & 31;
+    int col;
+    if (GLU)
+      col = (seg < NOB ? (grp * NOB + seg) * 32 : (a.Cout >> 1) + (grp * NOB + seg - NOB) * 32) + i;
+    else
+      col = (grp * NOB + seg) * 32 + i;
+    aff_s[tid] = a.scale ? a.scale[col] : 1.f;
+    aff_s[NCOL + tid] = a.scale ? a.shift[col] : 0.f;
+  }
+  __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the stage to every wave
+  TGSR_STAMP(1);
 
   for (int ch = 0; ch < a.nchunks; ++ch) {
-    __syncthreads();  // previous chunk's fragment reads are done
-    // ---- stage weights: [9*8 rows][NCOL] <- wpack[ch][tap][ci][Cout], NCB segments of 32 floats per row
-    {
-      const float* wsrc = a.wpack + (int64_t)ch * 9 * kConvCK * a.Cout;
-      constexpr int NF4 = 9 * kConvCK * NCB * 8;
-      for (int idx = tid; idx < NF4; idx += 256) {
-        const int row = idx / (NCB * 8);
-        const int rem = idx - row * (NCB * 8);
-        const int seg = rem >> 3, f4 = rem & 7;
-        int col;
-        if (GLU)
-          col = (seg < NOB ? (grp * NOB + seg) * 32 : (a.Cout >> 1) + (grp * NOB + seg - NOB) * 32);
-        else
-          col = (grp * NOB + seg) * 32;
-        const float4 v = *reinterpret_cast<const float4*>(wsrc + (int64_t)row * a.Cout + col + f4 * 4);
-        *reinterpret_cast<float4*>(w_s + row * NCOL + seg * 32 + f4 * 4) = v;
-      }
-    }
-    // ---- stage the input halo tile (zero padding at the image border and past Cin)
-    {
-      const int c0 = ch * kConvCK;
-      for (int idx = tid; idx < kConvCK * TR * TC; idx += 256) {
-        const int c = idx / (TR * TC);
-        const int rem = idx - c * (TR * TC);
-        const int r = rem / TC, cc = rem - r * TC;
-        const int gy = sy0 + r, gx = sx0 + cc;
-        float v = 0.f;
-        if (c0 + c < a.Cin && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-          v = xb[(int64_t)(c0 + c) * HW + (int64_t)gy * a.W + gx];
-        in_s[c * PLANE + r * PITCH + cc] = v;
-      }
-    }
-    __syncthreads();
+    const float* cur = smem + (ch & 1) * C::BUF;
+    float* nxt = smem + ((ch + 1) & 1) * C::BUF;
+    const bool more = ch + 1 < a.nchunks;
 
-    // ---- 9 taps x 4 channel pairs: NCB + R ds_read_b32, NCB*R MFMA each
+    // ---- NS k-steps, fragments fetched one step ahead of the MFMAs that use them
+    float av[NCB], bv[R], an[NCB], bn[R];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      int b_row[R];
+    for (int cb = 0; cb < NCB; ++cb) av[cb] = cur[a_off + cb * 32];
 #pragma unroll
-      for (int r = 0; r < R; ++r) b_row[r] = (UP ? (((wrow + r + ky - 1) >> 1) + 1) : (wrow + r + ky)) * PITCH;
+    for (int r = 0; r < R; ++r) bv[r] = cur[b_off[0][r] + b_col[0]];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
+    for (int s = 0; s < NS; ++s) {
+      // MFMAs of step s in two halves with the ds_reads of step s+1 pinned between them: the reads are in flight
+      // for half a step (>= 256 cycles) before the next step's first MFMA waits on them.  (Left to itself hipcc
+      // sinks every read to just before its use and exposes the LDS latency 2x per step.)
+      constexpr int NM = NCB * R, HALF = (NM + 1) / 2;
 #pragma unroll
-        for (int kk = 0; kk < kConvCK / 2; ++kk) {
-          float av[NCB], bv[R];
+      for (int m = 0; m < HALF; ++m)
+        acc[m / R][m % R] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m / R], bv[m % R], acc[m / R][m % R], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s < NP && more) plan.issue(s, a, nxt, ch + 1, wave, xb, HW);   // one DMA piece of the next stage
+      if (s + 1 < NS) {
+        const int s1 = s + 1;
+        const int tap = s1 / (kConvCK / 2), kk = s1 % (kConvCK / 2);
+        const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) av[cb] = w_s[a_off + ((ky * 3 + kx) * kConvCK + 2 * kk) * NCOL + cb * 32];
+        for (int cb = 0; cb < NCB; ++cb) an[cb] = cur[a_off + (tap * kConvCK + 2 * kk) * NCOL + cb * 32];
 #pragma unroll
-          for (int r = 0; r < R; ++r) bv[r] = in_s[b_base + 2 * kk * PLANE + b_row[r] + b_col[kx]];
+        for (int r = 0; r < R; ++r) bn[r] = cur[b_off[ky][r] + 2 * kk * PLANE + b_col[kx]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb)
+      for (int m = HALF; m < NM; ++m)
+        acc[m / R][m % R] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m / R], bv[m % R], acc[m / R][m % R], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < NS) {
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-              acc[cb][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb], bv[r], acc[cb][r], 0, 0, 0);
-        }
+        for (int cb = 0; cb < NCB; ++cb) av[cb] = an[cb];
+#pragma unroll
+        for (int r = 0; r < R; ++r) bv[r] = bn[r];
       }
     }
+    __syncthreads();  // next stage landed (vmcnt(0)) and this one is free to be overwritten
   }
 
-  // ---- epilogue: affine (BN eval), GLU, residual; each register = 32 consecutive pixels of one channel
+  TGSR_STAMP(2);
+  // ---- epilogue: affine (BN eval), GLU, residual; each register = 32 consecutive pixels of one channel.
+  // __restrict__ locals: without them every store is followed by s_waitcnt vmcnt(0) (possible alias with the
+  // next load) and the 64-128 outputs per lane serialise on full memory round trips.
   const int x = tx0 + l31;
   const int64_t HWo = (int64_t)a.Ho * a.Wo;
-  float* ob = a.out + (int64_t)b * a.obs;
-  const float* rb = a.res ? a.res + (int64_t)b * a.rbs : nullptr;
+  float* __restrict__ ob = a.out + (int64_t)b * a.obs;
+  const float* __restrict__ rb = a.res ? a.res + (int64_t)b * a.rbs : nullptr;
+  const bool xok = x < a.Wo;
 #pragma unroll
   for (int j = 0; j < NOB; ++j) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int cv = (grp * NOB + j) * 32 + acc_row(i, h);
-      float sv = 1.f, tv = 0.f, sg = 1.f, tg = 0.f;
-      if (a.scale) {
-        sv = a.scale[cv];
-        tv = a.shift[cv];
-        if (GLU) {
-          sg = a.scale[cv + (a.Cout >> 1)];
-          tg = a.shift[cv + (a.Cout >> 1)];
-        }
+    for (int i0 = 0; i0 < 16; i0 += 4) {
+      float resv[4][R];
+      if (!GLU) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int cv = (grp * NOB + j) * 32 + acc_row(i0 + ii, h);
+            const int y = ty0 + wrow + r;
+            resv[ii][r] = (rb && xok && y < a.Ho) ? rb[(int64_t)cv * HWo + (int64_t)y * a.Wo + x] : 0.f;
+          }
       }
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int y = ty0 + wrow + r;
-        float v = acc[j][r][i] * sv + tv;
+      for (int ii = 0; ii < 4; ++ii) {
+        const int i = i0 + ii;
+        const int lc = j * 32 + acc_row(i, h);   // column inside this workgroup's NCOL
+        const int cv = (grp * NOB + j) * 32 + acc_row(i, h);
+        const float sv = aff_s[lc], tv = aff_s[NCOL + lc];
+        float sg = 1.f, tg = 0.f;
         if (GLU) {
-          const float g = acc[NOB + j][r][i] * sg + tg;
-          v = v * (1.f / (1.f + __expf(-g)));
+          sg = aff_s[lc + NOB * 32];
+          tg = aff_s[NCOL + lc + NOB * 32];
         }
-        if (y < a.Ho && x < a.Wo) {
-          const int64_t o = (int64_t)cv * HWo + (int64_t)y * a.Wo + x;
-          if (!GLU && rb) v += rb[o];
-          ob[o] = v;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int y = ty0 + wrow + r;
+          float v = acc[j][r][i] * sv + tv;
+          if (GLU) {
+            const float g = acc[NOB + j][r][i] * sg + tg;
+            v = v * (1.f / (1.f + __expf(-g)));
+          } else {
+            v += resv[ii][r];
+          }
+          if (y < a.Ho && xok) ob[(int64_t)cv * HWo + (int64_t)y * a.Wo + x] = v;
         }
       }
     }
   }
+  TGSR_STAMP(3);
 }
 
 template <int NOB, bool GLU, bool UP, int R>
@@ -196,8 +316,12 @@ static int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
 
 template <int NOB, bool GLU>
 static int dispatch_up_r(const ConvArgs& a, int groups, bool up, int R, hipStream_t s) {
-  if (up) return R == 2 ? launch_conv<NOB, GLU, true, 2>(a, groups, s) : launch_conv<NOB, GLU, true, 1>(a, groups, s);
-  return R == 2 ? launch_conv<NOB, GLU, false, 2>(a, groups, s) : launch_conv<NOB, GLU, false, 1>(a, groups, s);
+  constexpr int NCB = NOB * (GLU ? 2 : 1);
+  if constexpr (NCB <= 2) {
+    if (R == 4) return up ? launch_conv<NOB, GLU, true, 4>(a, groups, s) : launch_conv<NOB, GLU, false, 4>(a, groups, s);
+  }
+  if (up) return R >= 2 ? launch_conv<NOB, GLU, true, 2>(a, groups, s) : launch_conv<NOB, GLU, true, 1>(a, groups, s);
+  return R >= 2 ? launch_conv<NOB, GLU, false, 2>(a, groups, s) : launch_conv<NOB, GLU, false, 1>(a, groups, s);
 }
 
 }  // namespace tgsr
@@ -214,6 +338,7 @@ extern "C" int tgsr_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Ci
   if (!glu && epilogue != TGSR_EPI_AFFINE) return TGSR_EINVAL;
   if (glu && residual) return TGSR_EINVAL;
   if (Cout % (glu ? 64 : 32) != 0) return TGSR_EUNSUPPORTED;
+  if ((int64_t)H * W >= (1 << 28) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
   ConvArgs a;
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W;
   a.wpack = wpack; a.Cout = Cout; a.scale = scale; a.shift = shift;
@@ -225,12 +350,21 @@ extern "C" int tgsr_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Ci
   const int unit = glu ? 64 : 32;          // couts consumed per output block
   const int nob = (Cout % (2 * unit) == 0) ? 2 : 1;
   const int groups = Cout / (unit * nob);
-  // rows per wave: 2 when that still gives every CU >= 2 workgroups, else 1 (small feature maps)
-  const int64_t tiles2 = (int64_t)B * ((a.Ho + 7) / 8) * ((a.Wo + 31) / 32) * groups;
-  const int R = tiles2 >= 512 ? 2 : 1;
+  // rows per wave (tile = 4R x 32 pixels): as many as keep 8 accumulators per wave AND >= 2 workgroups per CU
+  const int ncb = nob * (glu ? 2 : 1);
+  auto tiles = [&](int r) { return (int64_t)B * ((a.Ho + 4 * r - 1) / (4 * r)) * ((a.Wo + 31) / 32) * groups; };
+  int R = 1;
+  if (ncb <= 2 && tiles(4) >= 512) R = 4;
+  else if (tiles(2) >= 512) R = 2;
   hipStream_t s = as_stream(stream);
   if (glu) return nob == 2 ? dispatch_up_r<2, true>(a, groups, upsample != 0, R, s)
                            : dispatch_up_r<1, true>(a, groups, upsample != 0, R, s);
   return nob == 2 ? dispatch_up_r<2, false>(a, groups, upsample != 0, R, s)
                   : dispatch_up_r<1, false>(a, groups, upsample != 0, R, s);
 }
+
+#ifdef TGSR_CONV_STAMPS
+extern "C" int tgsr_debug_read_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(tgsr::g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -3;
+}
+#endif

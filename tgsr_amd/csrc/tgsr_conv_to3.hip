@@ -5,12 +5,20 @@
 // Cout = 3 does not fill an MFMA tile (a 32-row tile would waste 90 % of it), and at 256x256 the op reads
 // 8.4 MB and writes 0.8 MB per image against 0.1-0.3 GFLOP: it is a streaming kernel, so it runs on the VALU:
 //   * workgroup = 16 x 64 output pixels, thread = 4 consecutive pixels x 3 channels (12 accumulators);
-//   * the input is staged in LDS 8 channels at a time with its halo; a thread reads its 4+K-1 input floats of a
-//     row as two aligned ds_read_b128 and reuses them for all K taps x 4 pixels x 3 channels;
-//   * weights are wave-uniform -> scalar loads, used as the SGPR operand of v_fma.
+//   * the input is staged in LDS 4 channels at a time with its halo, double buffered, by LDS-DMA
+//     (global_load_lds, 16 B per lane: the tile starts 4 columns left of the output tile so every piece is an
+//     aligned float4; out-of-image pieces read a zero block) - the copy of stage c+1 runs under the FMAs of stage c;
+//   * a thread reads its 12 input floats of a row as three aligned ds_read_b128 and reuses them for all K taps x
+//     4 pixels x 3 channels; weights are wave-uniform -> scalar loads feeding the SGPR operand of v_fma.
+// Widths that are not a multiple of 4 (never on the SR path) take the 4-byte DMA form of the same kernel.
 #include "tgsr_common.h"
 
 namespace tgsr {
+
+typedef __attribute__((address_space(3))) void* lds_ptr3_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr1_t;
+
+__device__ __attribute__((aligned(16))) float g_to3_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct To3Args {
   const float* x;
@@ -23,23 +31,61 @@ struct To3Args {
   int tiles_x, tiles_y;
 };
 
-template <int K, int ACT>
-__global__ __launch_bounds__(256) void conv_to3_kernel(To3Args a) {
-  constexpr int P = K / 2, CK = 8, TH = 16, TW = 64;
-  constexpr int TR = TH + K - 1;
-  constexpr int PITCH = 72;  // >= TW + 8 so that 8 floats from column 4*tx always stay inside the row
-  __shared__ __attribute__((aligned(16))) float in_s[CK * TR * PITCH];
+__device__ __forceinline__ float fast_tanh(float v) {
+  // tanh(v) = 1 - 2 / (exp(2v) + 1); absolute error ~1e-7 (what parity needs); saturates cleanly at +-1
+  const float e = __expf(2.f * v);
+  return 1.f - 2.f / (e + 1.f);
+}
 
-  const int tid = threadIdx.x;
-  const int txi = tid & 15, tyi = tid >> 4;  // 16 x 16 threads: 4 pixels wide each
+template <int K, int ACT, bool VEC4>
+__global__ __launch_bounds__(256) void conv_to3_kernel(To3Args a) {
+  constexpr int P = K / 2, CK = 4, TH = 16, TW = 64;
+  constexpr int TR = TH + K - 1;
+  constexpr int PITCH = 72;  // LDS column j = input column x0 - 4 + j; 72 = 64 + 4 left + 4 right
+  constexpr int STAGE = CK * TR * PITCH;               // floats per stage (multiple of 4)
+  constexpr int PIECE = VEC4 ? 256 : 64;               // floats per wave DMA instruction
+  constexpr int UNITS = (STAGE + PIECE - 1) / PIECE;
+  constexpr int BUF = UNITS * PIECE;
+  constexpr int UK = (UNITS + 3) / 4;                  // pieces per wave per stage
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int txi = tid & 15, tyi = tid >> 4;  // 16 x 16 threads, 4 pixels wide each
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
   const int y0 = ty * TH, x0 = tx * TW;
-  const int64_t HW = (int64_t)a.H * a.W;
+  const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
   const float* xb = a.x + (int64_t)b * a.xbs;
+
+  // per-lane source offsets of this wave's DMA pieces: (channel-in-stage << 28) | (gy * W + gx), -1 = zero fill
+  int off[UK];
+#pragma unroll
+  for (int k = 0; k < UK; ++k) {
+    const int e = ((wave + 4 * k) * 64 + lane) * (VEC4 ? 4 : 1);   // first float of this lane's piece
+    const int c = e / (TR * PITCH);
+    const int rem = e - c * (TR * PITCH);
+    const int r = rem / PITCH, j = rem - r * PITCH;
+    const int gy = y0 - P + r, gx = x0 - 4 + j;
+    const bool ok = c < CK && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;  // VEC4: W % 4 == 0
+    off[k] = ok ? ((c << 28) | (gy * a.W + gx)) : -1;
+  }
+  auto issue = [&](int k, float* buf, int c0) {
+    const int u = wave + 4 * k;
+    if (u < UNITS) {
+      const int v = off[k];
+      const int c = c0 + (v >> 28);
+      const bool ok = v >= 0 && c < a.Cin;
+      const float* g = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(v & 0x0fffffff) : g_to3_zero;
+      if (VEC4)
+        __builtin_amdgcn_global_load_lds((glb_ptr1_t)g, (lds_ptr3_t)(buf + u * 256), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((glb_ptr1_t)g, (lds_ptr3_t)(buf + u * 64), 4, 0, 0);
+    }
+  };
 
   float acc[3][4];
 #pragma unroll
@@ -47,65 +93,73 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(To3Args a) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
 
-  for (int c0 = 0; c0 < a.Cin; c0 += CK) {
-    __syncthreads();
-    // LDS column j holds input column x0 - 4 + j (4-float left margin keeps the 16-B reads aligned)
-    for (int idx = tid; idx < CK * TR * PITCH; idx += 256) {
-      const int c = idx / (TR * PITCH);
-      const int rem = idx - c * (TR * PITCH);
-      const int r = rem / PITCH, j = rem - r * PITCH;
-      const int gy = y0 - P + r, gx = x0 - 4 + j;
-      float v = 0.f;
-      if (c0 + c < a.Cin && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-        v = xb[(int64_t)(c0 + c) * HW + (int64_t)gy * a.W + gx];
-      in_s[idx] = v;
+#pragma unroll
+  for (int k = 0; k < UK; ++k) issue(k, smem, 0);
+  __syncthreads();
+
+  const int nst = (a.Cin + CK - 1) / CK;
+  for (int st = 0; st < nst; ++st) {
+    const float* cur = smem + (st & 1) * BUF;
+    if (st + 1 < nst) {
+#pragma unroll
+      for (int k = 0; k < UK; ++k) issue(k, smem + ((st + 1) & 1) * BUF, (st + 1) * CK);
     }
-    __syncthreads();
-    const int cmax = (a.Cin - c0) < CK ? (a.Cin - c0) : CK;
-    for (int c = 0; c < cmax; ++c) {
-      const float* wc = a.w + (int64_t)(c0 + c) * K * K;  // + co * Cin*K*K
+    const int c0 = st * CK;
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const float* row = in_s + (c * TR + tyi + ky) * PITCH + 4 * txi;
-        const float4 v0 = *reinterpret_cast<const float4*>(row);
-        const float4 v1 = *reinterpret_cast<const float4*>(row + 4);
-        const float4 v2 = *reinterpret_cast<const float4*>(row + 8);
-        const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-        // pixel p (column x0 + 4*txi + p) tap kx reads LDS column 4*txi + 4 + p + kx - P
+    for (int c = 0; c < CK; ++c) {
+      if (c0 + c < a.Cin) {   // uniform
+        const float* wc = a.w + (int64_t)(c0 + c) * K * K;  // + co * Cin*K*K
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
+        for (int ky = 0; ky < K; ++ky) {
+          const float* row = cur + (c * TR + tyi + ky) * PITCH + 4 * txi;
+          const float4 v0 = *reinterpret_cast<const float4*>(row);
+          const float4 v1 = *reinterpret_cast<const float4*>(row + 4);
+          const float4 v2 = *reinterpret_cast<const float4*>(row + 8);
+          const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+          // pixel p (column x0 + 4*txi + p) tap kx reads LDS column 4*txi + 4 + p + kx - P
 #pragma unroll
-          for (int co = 0; co < 3; ++co) {
-            const float wv = wc[(int64_t)co * a.Cin * K * K + ky * K + kx];
+          for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, in[4 + p + kx - P], acc[co][p]);
+            for (int co = 0; co < 3; ++co) {
+              const float wv = wc[(int64_t)co * a.Cin * K * K + ky * K + kx];
+#pragma unroll
+              for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, in[4 + p + kx - P], acc[co][p]);
+            }
           }
         }
       }
     }
+    __syncthreads();  // next stage landed (vmcnt(0)); this one may be overwritten
   }
 
   const int y = y0 + tyi, xx = x0 + 4 * txi;
+  float* __restrict__ outp = a.out;
+  const float* __restrict__ addp = a.addend;
   if (y < a.H) {
 #pragma unroll
     for (int co = 0; co < 3; ++co) {
       const int64_t o = ((int64_t)b * 3 + co) * HW + (int64_t)y * a.W + xx;
       float r[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        float v = acc[co][p];
-        if (ACT == TGSR_ACT_TANH_AXPY) {
-          v = tanhf(v);
-          if (a.addend && xx + p < a.W) v += a.alpha * a.addend[o + p];
-        }
-        r[p] = v;
-      }
-      if (xx + 3 < a.W && (a.W & 3) == 0) {
-        *reinterpret_cast<float4*>(a.out + o) = make_float4(r[0], r[1], r[2], r[3]);
-      } else {
+      if (VEC4 && xx + 3 < a.W) {
+        float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACT == TGSR_ACT_TANH_AXPY && addp) ad = *reinterpret_cast<const float4*>(addp + o);
+        const float adv[4] = {ad.x, ad.y, ad.z, ad.w};
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (xx + p < a.W) a.out[o + p] = r[p];
+          r[p] = ACT == TGSR_ACT_TANH_AXPY ? fast_tanh(acc[co][p]) + a.alpha * adv[p] : acc[co][p];
+        *reinterpret_cast<float4*>(outp + o) = make_float4(r[0], r[1], r[2], r[3]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (xx + p < a.W) {
+            float v = acc[co][p];
+            if (ACT == TGSR_ACT_TANH_AXPY) {
+              v = fast_tanh(v);
+              if (addp) v += a.alpha * addp[o + p];
+            }
+            outp[o + p] = v;
+          }
+        }
       }
     }
   }
@@ -115,7 +169,14 @@ template <int K, int ACT>
 static int launch_to3(To3Args a, hipStream_t s) {
   a.tiles_x = (a.W + 63) / 64;
   a.tiles_y = (a.H + 15) / 16;
-  hipLaunchKernelGGL((conv_to3_kernel<K, ACT>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
+  const dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y));
+  const bool vec4 = (a.W % 4 == 0) && (a.xbs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
+                    (!a.addend || (reinterpret_cast<uintptr_t>(a.addend) & 15) == 0);
+  if (vec4)
+    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, true>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, false>), grid, dim3(256), 0, s, a);
   return note_launch(hipGetLastError(), "conv_to3_kernel");
 }
 
@@ -129,6 +190,7 @@ extern "C" int tgsr_conv_to3_fwd(const float* x, int64_t x_bstride, int B, int C
   if (K != 3 && K != 5) return TGSR_EUNSUPPORTED;
   if (act != TGSR_ACT_NONE && act != TGSR_ACT_TANH_AXPY) return TGSR_EINVAL;
   if (act == TGSR_ACT_NONE && addend) return TGSR_EINVAL;
+  if ((int64_t)H * W >= (1 << 28) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
   To3Args a;
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.w = w;
   a.addend = addend; a.alpha = alpha; a.out = out; a.tiles_x = a.tiles_y = 0;

@@ -71,9 +71,14 @@ class NetG_highweight(nn.Module):
         self.residual48 = _ResidualNoSum(ngf)
         self.weightmap = False
         self._a = 0.5
+        self._consts = {}
 
     def _const(self, ref):
-        return ref.new_tensor([self._a]), ref.new_ones(1)
+        """(a, one) on ref's device, created once per device (no per-step H2D copy)."""
+        c = self._consts.get(ref.device)
+        if c is None:
+            c = self._consts[ref.device] = (ref.new_tensor([self._a]), ref.new_ones(1))
+        return c
 
     def _head(self, out, SRb):
         if not self.useAct:

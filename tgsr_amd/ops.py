@@ -55,7 +55,7 @@ def _nchw_bstride(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
 
 # ----------------------------------------------------------------------------------------- weight prep
 def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
-    """[Cout,Cin,3,3] -> the [ceil(Cin/8)][9][8][Cout] stream order of tgsr_conv3x3_fwd."""
+    """[Cout,Cin,3,3] -> the [ceil(Cin/4)][9][4][Cout] stream order of tgsr_conv3x3_fwd."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin, K, K2 = w.shape
@@ -139,6 +139,19 @@ def conv_to3(x: torch.Tensor, w: torch.Tensor, tanh_axpy: bool = False, addend: 
 
 
 # ----------------------------------------------------------------------------------------- attention
+_MASK_CACHE = [None, None, None]   # (tensor id/version key, source (kept alive), uint8 copy)
+
+
+def _mask_u8(mask: torch.Tensor) -> torch.Tensor:
+    """bool -> uint8 once per mask tensor (the three generator stages share one mask)."""
+    if mask.dtype == torch.uint8 and mask.is_contiguous():
+        return mask
+    key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.dtype)
+    if _MASK_CACHE[0] != key or _MASK_CACHE[1] is not mask:
+        _MASK_CACHE[0], _MASK_CACHE[1], _MASK_CACHE[2] = key, mask, mask.to(torch.uint8).contiguous()
+    return _MASK_CACHE[2]
+
+
 def word_attention(h: torch.Tensor, words: torch.Tensor, w_ctx: torch.Tensor, mask: Optional[torch.Tensor],
                    correct_mask: bool = False, out: Optional[torch.Tensor] = None, need_attn: bool = True):
     """GlobalAttentionGeneral.forward: h [B,idf,ih,iw], words [B,cdf,T], w_ctx [idf,cdf(,1,1)], mask bool [B,T].
@@ -153,7 +166,7 @@ def word_attention(h: torch.Tensor, words: torch.Tensor, w_ctx: torch.Tensor, ma
     if mask is not None:
         if tuple(mask.shape) != (B, T):
             raise TgsrError("word_attention: mask shape %s, expected %s" % (tuple(mask.shape), (B, T)))
-        m8 = mask.to(torch.uint8).contiguous()
+        m8 = _mask_u8(mask)
     Q = ih * iw
     if out is None:
         out = torch.empty(B, idf, ih, iw, dtype=torch.float32, device=h.device)
@@ -173,6 +186,20 @@ def word_attention(h: torch.Tensor, words: torch.Tensor, w_ctx: torch.Tensor, ma
 
 
 # ----------------------------------------------------------------------------------------- text encoder
+_LENS_CACHE = {}
+
+
+def _lens_on_device(lens: tuple, dev) -> torch.Tensor:
+    """int32 caption lengths on the device; cached so a steady-state step issues no blocking H2D copy."""
+    key = (lens, str(dev))
+    t = _LENS_CACHE.get(key)
+    if t is None:
+        if len(_LENS_CACHE) > 256:
+            _LENS_CACHE.clear()
+        t = _LENS_CACHE[key] = torch.tensor(lens, dtype=torch.int32).to(dev)
+    return t
+
+
 def bilstm(captions: torch.Tensor, cap_lens, emb: torch.Tensor, w_ih: torch.Tensor, w_hh: torch.Tensor,
            b_ih: torch.Tensor, b_hh: torch.Tensor):
     """captions int64 [B,W]; cap_lens list/tensor (host or device) ; emb [ntoken,ninput]; w_* stacked over the two
@@ -186,7 +213,7 @@ def bilstm(captions: torch.Tensor, cap_lens, emb: torch.Tensor, w_ih: torch.Tens
     H = w_hh.shape[2]
     dev = emb.device
     captions = captions.to(torch.int64).contiguous()
-    lens_d = torch.tensor(lens, dtype=torch.int32).to(dev, non_blocking=False)
+    lens_d = _lens_on_device(tuple(lens), dev)
     gates = torch.empty(B * Tmax * 8 * H, dtype=torch.float32, device=dev)
     words = torch.empty(B, 2 * H, Tmax, dtype=torch.float32, device=dev)
     sent = torch.empty(B, 2 * H, dtype=torch.float32, device=dev)
