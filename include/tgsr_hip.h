@@ -115,6 +115,26 @@ int tgsr_bilstm_fwd(const int64_t* captions, int width, const int32_t* cap_lens,
                     int ntoken, int ninput, const float* w_ih, const float* w_hh, const float* b_ih,
                     const float* b_hh, int H, float* gates_ws, float* words_emb, float* sent_emb, void* stream);
 
+/*
+ * DAMSM word/region attention for the whole (image, caption) grid in one launch: func_attention
+ * (GlobalAttention.py:33-74) as driven by words_loss (losses.py:73-113) - the B-iteration Python loop, word.repeat,
+ * both softmaxes, the two bmm and the cosine / exp / sum / log tail.
+ * words [B][ndf][Tw] dense (Tw <= 32), cap_lens int32 [B] (NULL = Tw for all), ctx [B][ndf][S] dense
+ * (S = 17*17 <= 320), ndf % 32 == 0, ndf <= 512.
+ * sim      [B_img][B_cap] = log sum_{w < len} exp(gamma2 * cos(word_w, region-context_w))   (losses.py:102-109;
+ *          the caller multiplies by gamma3 and applies the class mask / cross entropy)
+ * att_diag NULL or [B][Tw][S]: attention of image i on caption i, rows >= cap_lens[i] zero       (losses.py:93)
+ */
+int tgsr_damsm_words_fwd(const float* words, const int32_t* cap_lens, const float* ctx, int B, int ndf, int Tw, int S,
+                         float gamma1, float gamma2, float* sim, float* att_diag, void* stream);
+
+/*
+ * Stand-alone func_attention(query, context, gamma1) (GlobalAttention.py:33-74): pair p attends query p to context p.
+ * query [B][ndf][L] (L <= 32), context [B][ndf][S] (S <= 320) -> weighted_context [B][ndf][L], attn [B][L][S].
+ */
+int tgsr_func_attention_fwd(const float* query, const float* context, int B, int ndf, int L, int S, float gamma1,
+                            float* weighted_context, float* attn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

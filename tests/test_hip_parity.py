@@ -173,6 +173,57 @@ def test_bilstm_golden(ops_small):
     close(sent, g["enc.sent_emb"], atol=1e-5)
 
 
+def test_func_attention_golden(ops_small):
+    from tgsr_amd import ops
+    g = ops_small
+    wc, attn = ops.func_attention(T(g["fa.query"]), T(g["fa.context"]), float(g["fa.gamma1"]))
+    close(wc, g["fa.out"], atol=2e-5)
+    close(attn, g["fa.attn"], atol=2e-6)
+
+
+def test_damsm_words_and_sent_loss_golden(damsm_golden, cfg_face):
+    """DAMSM goldens (losses.py:21-136): B=4, caption lengths 18/15/12/9, with and without class ids."""
+    from tgsr_amd.miscc import losses
+    g = damsm_golden
+    cfg_face.TRAIN.SMOOTH.GAMMA1, cfg_face.TRAIN.SMOOTH.GAMMA2, cfg_face.TRAIN.SMOOTH.GAMMA3 = map(float, g["gamma"])
+    labels = torch.arange(4, device=DEV)
+    for tag, cls in (("cls", g["class_ids"]), ("nocls", None)):
+        w0, w1, att = losses.words_loss(T(g["feats"]), T(g["words"]), labels, T(g["cap_lens"], "cpu"), cls, 4)
+        s0, s1 = losses.sent_loss(T(g["cnn_code"]), T(g["sent"]), labels, cls, 4)
+        close(w0, g[tag + ".w0"], atol=2e-5); close(w1, g[tag + ".w1"], atol=2e-5)
+        close(s0, g[tag + ".s0"], atol=2e-5); close(s1, g[tag + ".s1"], atol=2e-5)
+        for i, a in enumerate(att):
+            close(a, g[tag + ".att%d" % i], atol=2e-6)
+
+
+@pytest.mark.parametrize("B,ndf,Tw,S", [(16, 256, 18, 289), (3, 64, 7, 25), (5, 128, 32, 320)])
+def test_damsm_similarity_vs_oracle(B, ndf, Tw, S):
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B + Tw)
+    ih = int(S ** 0.5) if int(S ** 0.5) ** 2 == S else None
+    feats = torch.randn(B, ndf, ih or 16, ih or 20, generator=g)
+    words = torch.randn(B, ndf, Tw, generator=g)
+    lens = torch.randint(1, Tw + 1, (B,), generator=g).tolist()
+    lens[0] = Tw
+    sim, att = ops.damsm_words_similarity(feats.to(DEV), words.to(DEV), lens, 4.0, 5.0)
+    for i in range(B):
+        L = lens[i]
+        word = words[i:i + 1, :, :L].expand(B, -1, -1)
+        wc, attn = O.func_attention(word, feats, 4.0)
+        row = O.cosine_similarity(word.transpose(1, 2).reshape(B * L, -1), wc.transpose(1, 2).reshape(B * L, -1))
+        ref = torch.log(torch.exp(row.reshape(B, L) * 5.0).sum(1))
+        close(sim[:, i], ref, atol=2e-5, rtol=1e-5)
+        close(att[i, :L], attn[i], atol=2e-6)
+        assert float(att[i, L:].abs().max()) == 0.0 if L < Tw else True
+
+
+def test_kl_mse_golden(ops_small):
+    from tgsr_amd.miscc import losses
+    g = ops_small
+    close(losses.KL_loss(T(g["kl.mu"]), T(g["kl.logvar"])), g["kl.out"], atol=1e-6)
+    close(losses.MSE([T(g["mse.a0"]), T(g["mse.a1"])], [T(g["mse.b0"]), T(g["mse.b1"])]), g["mse.out"], atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ module level
 def test_resblock_upblock_modules_golden(ops_small, cfg_small):
     from tgsr_amd import util
@@ -225,8 +276,10 @@ def test_full_size_face_checkpoint_c1(face_c1, face_weights, cfg_face):
     r = p(T(g["captions"]), g["cap_lens"].tolist(), T(g["LR"]), T(g["LRb"]))
     close(r["words_emb"], g["words_emb"], atol=1e-5)
     for i in range(3):
-        close(r["fake"][i], g["fake%d" % i])
-        close(r["fine"][i], g["fine%d" % i])
+        # 256^2 images: both fp32 paths carry rounding noise vs exact arithmetic (CPU 3.7e-5, HIP 8.3e-5 max,
+        # tools/diag_precision.py) -> atol 2e-4 there, 1e-4 everywhere else
+        close(r["fake"][i], g["fake%d" % i], atol=2e-4 if i == 2 else ATOL)
+        close(r["fine"][i], g["fine%d" % i], atol=2e-4 if i == 2 else ATOL)
     close(r["att"][0], g["att0"], atol=2e-5)
     close(r["att"][1], g["att1"], atol=2e-5)
     a2 = r["att"][2].cpu().numpy()
@@ -245,8 +298,8 @@ def test_full_size_batch16_vs_oracle(face_weights, cfg_face):
     p = _pipeline(face_weights)
     r = p(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
     for i in range(3):
-        close(r["fake"][i], ref["fake"][i])
-        close(r["fine"][i], ref["fine"][i])
+        close(r["fake"][i], ref["fake"][i], atol=2e-4 if i == 2 else ATOL)
+        close(r["fine"][i], ref["fine"][i], atol=2e-4 if i == 2 else ATOL)
         close(r["att"][i], ref["att"][i], atol=2e-5)
     # size-independent properties: per-sample independence (eval BN, per-sample mask mode) and determinism
     p.netGL.h_net1.att.correct_mask = p.netGL.h_net2.att.correct_mask = p.netGL.h_net3.att.correct_mask = True

@@ -1,0 +1,93 @@
+"""Drop-in for the hot-path losses of the reference's miscc/losses.py.
+
+`words_loss` / `sent_loss` (DAMSM, losses.py:21-136) keep the reference's signatures and return tuples; the
+per-caption Python loop of words_loss is one launch of the batched DAMSM kernel (tgsr_damsm_words_fwd).  The class
+mask, the x gamma3 scale and the two cross entropies act on a [B, B] matrix and stay in torch, like sent_loss's
+[B,256]x[256,B] product (a plain library GEMM).  `KL_loss` and `MSE` (losses.py:779-810) are scalar reductions.
+Forward values only for now (no autograd through the HIP kernel): training with these losses is the next step.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .config import cfg
+
+
+def _func_attention(query, context, gamma1):
+    return ops.func_attention(query, context, gamma1)
+
+
+def cosine_similarity(x1, x2, dim=1, eps=1e-8):
+    """losses.py:12-18."""
+    w12 = torch.sum(x1 * x2, dim)
+    w1 = torch.norm(x1, 2, dim)
+    w2 = torch.norm(x2, 2, dim)
+    return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
+
+
+def _class_masks(class_ids, batch_size, device):
+    """losses.py:25-35 / 75-80: masks[i][j] = (class_ids[j] == class_ids[i]) and i != j."""
+    if class_ids is None:
+        return None
+    ids = np.asarray(class_ids)
+    m = ids[None, :] == ids[:, None]
+    np.fill_diagonal(m, False)
+    return torch.from_numpy(m).to(device)
+
+
+def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8):
+    """losses.py:21-62."""
+    masks = _class_masks(class_ids, batch_size, cnn_code.device)
+    if cnn_code.dim() == 2:
+        cnn_code = cnn_code.unsqueeze(0)
+        rnn_code = rnn_code.unsqueeze(0)
+    cnn_code_norm = torch.norm(cnn_code, 2, dim=2, keepdim=True)
+    rnn_code_norm = torch.norm(rnn_code, 2, dim=2, keepdim=True)
+    scores0 = torch.bmm(cnn_code, rnn_code.transpose(1, 2))
+    norm0 = torch.bmm(cnn_code_norm, rnn_code_norm.transpose(1, 2))
+    scores0 = scores0 / norm0.clamp(min=eps) * cfg.TRAIN.SMOOTH.GAMMA3
+    scores0 = scores0.squeeze(dim=0)
+    if masks is not None:
+        scores0 = scores0.masked_fill(masks, -float('inf'))
+    scores1 = scores0.transpose(0, 1)
+    if labels is not None:
+        loss0 = nn.CrossEntropyLoss()(scores0, labels)
+        loss1 = nn.CrossEntropyLoss()(scores1, labels)
+    else:
+        loss0, loss1 = None, None
+    return loss0, loss1
+
+
+def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size):
+    """losses.py:65-136.  words_emb(query): batch x nef x seq_len; img_features(context): batch x nef x 17 x 17.
+    Returns (loss0, loss1, att_maps) with att_maps[i] = [1, cap_len_i, 17, 17]."""
+    lens = cap_lens.data.tolist() if torch.is_tensor(cap_lens) else list(cap_lens)
+    sim, att = ops.damsm_words_similarity(img_features, words_emb, lens, cfg.TRAIN.SMOOTH.GAMMA1,
+                                          cfg.TRAIN.SMOOTH.GAMMA2, need_att=True)
+    att_maps = [att[i:i + 1, :lens[i]].contiguous() for i in range(batch_size)]
+    similarities = sim * cfg.TRAIN.SMOOTH.GAMMA3
+    masks = _class_masks(class_ids, batch_size, sim.device)
+    if masks is not None:
+        similarities = similarities.masked_fill(masks, -float('inf'))
+    similarities1 = similarities.transpose(0, 1)
+    if labels is not None:
+        loss0 = nn.CrossEntropyLoss()(similarities, labels)
+        loss1 = nn.CrossEntropyLoss()(similarities1, labels)
+    else:
+        loss0, loss1 = None, None
+    return loss0, loss1, att_maps
+
+
+def MSE(fake, label):
+    """losses.py:779-784."""
+    mseloss = 0
+    for i in range(len(fake)):
+        mseloss += nn.MSELoss()(fake[i], label[i])
+    return mseloss
+
+
+def KL_loss(mu, logvar):
+    """losses.py:806-810."""
+    KLD_element = mu.pow(2).add(logvar.exp()).mul(-1).add(1).add(logvar)
+    return torch.mean(KLD_element).mul(-0.5)

@@ -223,3 +223,41 @@ def bilstm(captions: torch.Tensor, cap_lens, emb: torch.Tensor, w_ih: torch.Tens
                                     _stream())
     check(rc, "tgsr_bilstm_fwd")
     return words, sent
+
+
+# ----------------------------------------------------------------------------------------- DAMSM
+def damsm_words_similarity(img_features: torch.Tensor, words_emb: torch.Tensor, cap_lens, gamma1: float,
+                           gamma2: float, need_att: bool = True):
+    """All (image j, caption i) word-level similarities in one launch: returns (sim [B,B] = log sum_w exp(gamma2 *
+    cos), att_diag [B,Tw,ih,iw] or None).  img_features [B,ndf,ih,iw], words_emb [B,ndf,Tw]."""
+    _need_hip(img_features, words_emb)
+    B, ndf, ih, iw = img_features.shape
+    Tw = words_emb.shape[2]
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    if len(lens) != B or min(lens) < 1 or max(lens) > Tw:
+        raise TgsrError("damsm: cap_lens %s invalid for words %s" % (lens, tuple(words_emb.shape)))
+    ctx = _f32(img_features, "img_features").contiguous()
+    words = _f32(words_emb, "words_emb").contiguous()
+    dev = ctx.device
+    sim = torch.empty(B, B, dtype=torch.float32, device=dev)
+    att = torch.empty(B, Tw, ih, iw, dtype=torch.float32, device=dev) if need_att else None
+    rc = _lib.lib().tgsr_damsm_words_fwd(_p(words), _p(_lens_on_device(tuple(lens), dev)), _p(ctx), B, ndf, Tw,
+                                         ih * iw, float(gamma1), float(gamma2), _p(sim), _p(att), _stream())
+    check(rc, "tgsr_damsm_words_fwd")
+    return sim, att
+
+
+def func_attention(query: torch.Tensor, context: torch.Tensor, gamma1: float):
+    """GlobalAttention.func_attention: query [B,ndf,L], context [B,ndf,ih,iw] -> (weightedContext [B,ndf,L],
+    attn [B,L,ih,iw])."""
+    _need_hip(query, context)
+    B, ndf, L = query.shape
+    ih, iw = context.shape[2], context.shape[3]
+    q = _f32(query, "query").contiguous()
+    c = _f32(context, "context").contiguous()
+    wc = torch.empty(B, ndf, L, dtype=torch.float32, device=q.device)
+    attn = torch.empty(B, L, ih, iw, dtype=torch.float32, device=q.device)
+    rc = _lib.lib().tgsr_func_attention_fwd(_p(q), _p(c), B, ndf, L, ih * iw, float(gamma1), _p(wc), _p(attn),
+                                            _stream())
+    check(rc, "tgsr_func_attention_fwd")
+    return wc, attn
