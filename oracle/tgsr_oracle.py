@@ -216,6 +216,23 @@ def g_sr_net_low(sd: SD, LR: Tensor, sent_emb: Tensor, words: Tensor, mask: Opti
     return imgs, atts, mu, logvar
 
 
+def g_sr_net_low16(sd: SD, LR: Tensor, sent_emb: Tensor, words: Tensor, mask: Optional[Tensor], training=False,
+                   update=None, correct_mask=False, p: str = ""):
+    """models16.py:5-39  x16 G_SR_NET_low: ONE NEXT_STAGE_G object serves stages 2-4 (`h_net4 = h_net3 = h_net2`,
+    :13) and ONE GET_IMAGE_G (conv3x3 + Tanh, util.py:894-905) serves the four heads (:14)."""
+    mu, logvar = ca_net(sd, sent_emb, p + "ca_net.")
+    w_img = sd[p + "img_net1.img.0.weight"]
+    imgs, atts = [], []
+    h, a = init_stage(sd, p + "h_net1.", LR, words, mask, training, update, correct_mask)
+    imgs.append(torch.tanh(conv3x3(h, w_img)))
+    atts.append(a)
+    for _ in range(3):
+        h, a = next_stage(sd, p + "h_net2.", h, words, mask, training, update, correct_mask)
+        imgs.append(torch.tanh(conv3x3(h, w_img)))
+        atts.append(a)
+    return imgs, atts, mu, logvar
+
+
 def netg_highweight(sd: SD, LR: Tensor, SRb: Sequence[Tensor], LRb: Tensor, low: str = "lr",
                     training=False, update=None, p: str = ""):
     """model.py:264-298  NetG_highweight.forward with weightmap=False.

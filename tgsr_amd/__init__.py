@@ -9,7 +9,7 @@ import sys
 
 __version__ = "0.1.0"
 
-_DROPIN = ("GlobalAttention", "util", "model", "miscc", "miscc.config", "miscc.losses")
+_DROPIN = ("GlobalAttention", "util", "model", "models16", "miscc", "miscc.config", "miscc.losses")
 
 
 def install_dropin():

@@ -1,0 +1,95 @@
+"""Drop-in for the reference's models16.py (x16, TREE.BRANCH_NUM = 5): same kernels as model.py, different wiring.
+
+Reference quirks kept: ONE NEXT_STAGE_G object serves stages 2-4 and ONE GET_IMAGE_G serves the four
+heads (`h_net4 = h_net3 = h_net2`, `img_net4 = ... = img_net1`, models16.py:13-14), so the state_dict lists the tied
+tensors under every alias, exactly like the reference.  In NetG_highweight the 16x stage re-uses `residual48` /
+`upscale8x` (models16.py:172-173; `residual816` / `upscale16x` hold parameters but are never called).
+One deviation, because the shipped line cannot execute: models16.py:178 adds the 8x image `SRb8` to the 16x tensor
+(a shape error in the reference - pinned by tests/golden/nets16_small.npz `gh16_runs == 0`); here the 16x head adds
+`SRb16`.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .miscc.config import cfg
+from .model import *  # noqa: F401,F403  (the reference does `from model import *`)
+from .util import (CA_NET, GET_IMAGE_G, INIT_STAGE_GImgup, NEXT_STAGE_G, ResBlock, _ConvBnGlu, _ResidualNoSum,
+                   conv5x5, upBlock)
+
+
+class G_SR_NET_low(nn.Module):
+    """models16.py:5-39."""
+
+    def __init__(self):
+        super(G_SR_NET_low, self).__init__()
+        ngf = cfg.GAN.GF_DIM
+        nef = cfg.TEXT.EMBEDDING_DIM
+        ncf = cfg.GAN.CONDITION_DIM
+        self.ca_net = CA_NET()
+        self.h_net1 = INIT_STAGE_GImgup(ngf, ncf, nef)
+        self.h_net4 = self.h_net3 = self.h_net2 = NEXT_STAGE_G(ngf, nef, ncf)
+        self.img_net4 = self.img_net3 = self.img_net2 = self.img_net1 = GET_IMAGE_G(ngf)
+
+    def forward(self, LR, sent_emb, word_embs, mask):
+        fake_imgs, att_maps = [], []
+        c_code, mu, logvar = self.ca_net(sent_emb)
+        h_code, att = self.h_net1(None, LR, word_embs, mask, wide_out=True)
+        fake_imgs.append(self.img_net1(h_code))
+        att_maps.append(att)
+        for k, (stage, head) in enumerate(((self.h_net2, self.img_net2), (self.h_net3, self.img_net3),
+                                           (self.h_net4, self.img_net4))):
+            h_code, att = stage(h_code, None, word_embs, mask, wide_out=(k < 2))
+            fake_imgs.append(head(h_code))
+            att_maps.append(att)
+        return fake_imgs, att_maps, mu, logvar
+
+
+class NetG_highweight(nn.Module):
+    """models16.py:97-179 with weightmap=False.  Here `a` IS a registered parameter (no `.cuda()` on it,
+    models16.py:126), initial value 0.5; `one` is the constant 1."""
+
+    def __init__(self, weightmap=False, low='lr-lrblur'):
+        super(NetG_highweight, self).__init__()
+        if weightmap:
+            raise NotImplementedError("weightmap=True is dead on the shipped path (trainer_objective.py:58)")
+        ngf = cfg.GAN.GF_DIM
+        self.low = low
+        self.residual = nn.Sequential(*[ResBlock(channel_num=32) for _ in range(6)])
+        self.upscale4x = upBlock(ngf, ngf)
+        self.upscale2x = upBlock(ngf, ngf)
+        self.upscale8x = upBlock(ngf, ngf)
+        self.upscale16x = upBlock(ngf, ngf)          # parameters only: never called (models16.py:173)
+        self.conv_output = nn.Sequential(conv5x5(ngf, 3), nn.Tanh())
+        self.convin = _ConvBnGlu(3, ngf)
+        self.residual24 = _ResidualNoSum(ngf)
+        self.residual48 = _ResidualNoSum(ngf)
+        self.residual816 = _ResidualNoSum(ngf)       # parameters only: never called (models16.py:172)
+        self.weightmap = False
+        self.a = nn.Parameter(torch.FloatTensor([0.5]))
+        self._one = {}
+
+    def _head(self, out, SRb):
+        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=float(self.a.item()))
+
+    def forward(self, LR, SRb, LRb):
+        SRb2, SRb4, SRb8, SRb16 = SRb[0], SRb[1], SRb[2], SRb[3]
+        if self.low == 'lrblur':
+            x = LRb
+        elif self.low == 'lr-lrblur':
+            x = LR - LRb
+        else:
+            x = LR
+        out = self.residual(self.convin(x))
+        out = self.upscale2x(out)
+        ims2 = self._head(out, SRb2)
+        out = self.upscale4x(self.residual24(out))
+        ims4 = self._head(out, SRb4)
+        out = self.upscale8x(self.residual48(out))
+        ims8 = self._head(out, SRb8)
+        out = self.upscale8x(self.residual48(out))   # models16.py:172-173: the 16x stage re-uses the 8x modules
+        ims16 = self._head(out, SRb16)               # models16.py:178 says SRb8 (shape error as shipped)
+        one = self._one.get(LR.device)
+        if one is None:
+            one = self._one[LR.device] = LR.new_ones(1)
+        return [ims2, ims4, ims8, ims16], self.a, one

@@ -308,3 +308,15 @@ class GET_IMAGE_G_noAct(nn.Module):
 
     def forward(self, h_code):
         return ops.conv_to3(h_code, self.img[0].weight)
+
+
+class GET_IMAGE_G(nn.Module):
+    """util.py:894-905: conv3x3 ngf -> 3 + Tanh (key `img.0.weight`); the x16 heads (models16.py:14)."""
+
+    def __init__(self, ngf):
+        super(GET_IMAGE_G, self).__init__()
+        self.gf_dim = ngf
+        self.img = nn.Sequential(conv3x3(ngf, 3), nn.Tanh())
+
+    def forward(self, h_code):
+        return ops.conv_to3(h_code, self.img[0].weight, tanh_axpy=True, addend=None, alpha=0.0)
