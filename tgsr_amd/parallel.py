@@ -1,0 +1,117 @@
+"""Data parallelism for the SR path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" on CPU for tests).
+
+The reference is single-process (trainer_objective.py:31, no DataParallel / distributed anywhere - SURVEY section 2).
+The path shards by image:
+  * inference: no data-path collective; each rank runs its slice of the (globally length-sorted) minibatch;
+    `gather_images` exists only for reporting / saving;
+  * training: ONE all-reduce per step over a flat fp32 bucket holding every gradient (G: 1 191 313 params =
+    4.77 MB - far below the size where bucketing into several collectives pays on 7 x 153 GB/s xGMI links), then
+    x 1/world.  BatchNorm statistics stay per shard (the DistributedDataParallel convention).
+"""
+import os
+from typing import Iterable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str = None) -> tuple:
+    """(rank, local_rank, world) from the torchrun environment; initialises the process group when world > 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def shard_bounds(n: int, rank: int, world: int) -> tuple:
+    """Rows [lo, hi) of an n-row batch owned by `rank`: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_batch(rank: int, world: int, captions: torch.Tensor, cap_lens: torch.Tensor, *per_sample: torch.Tensor):
+    """Global sort by caption length (datasets.py:74-96), then a contiguous row slice per rank.  A slice of a
+    descending sequence is still descending, which is all pack_padded_sequence / the BiLSTM kernel need.  Note the
+    reference's mask quirk (GlobalAttention.py:109-116) makes a sample's attention depend on the LOCAL batch size:
+    bit-parity with a 1-GPU run needs correct_mask=True or equal-length captions."""
+    lens, idx = torch.sort(cap_lens, 0, True)
+    lo, hi = shard_bounds(captions.shape[0], rank, world)
+    sel = idx[lo:hi]
+    return (captions[sel], lens[lo:hi]) + tuple(t[sel] for t in per_sample) + (sel,)
+
+
+class FlatGradBucket:
+    """All gradients of `params` in one flat fp32 buffer; `all_reduce_mean()` = one collective per step."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGradBucket: no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def attach(self):
+        """Make every p.grad a view of the flat buffer, so backward writes straight into the bucket (no packing)."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        return self
+
+    def pack(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+
+    def unpack(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v.clone() if p.grad is None else p.grad.copy_(v)
+
+    def all_reduce_mean(self, async_op: bool = False):
+        """sum over ranks, x 1/world.  With attach() the gradients are already in place: pack/unpack are no-ops."""
+        self.pack()
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        world = dist.get_world_size()
+        if async_op:
+            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+
+            class _Done:
+                def wait(_s):
+                    work.wait()
+                    self.flat.div_(world)
+                    self.unpack()
+            return _Done()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(world)
+        self.unpack()
+        return None
+
+
+def gather_images(img: torch.Tensor, dst: int = 0):
+    """Collect every rank's output slice on `dst` (reporting only; not on the timed path).  Equal slice sizes."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return img
+    world = dist.get_world_size()
+    out = [torch.empty_like(img) for _ in range(world)] if dist.get_rank() == dst else None
+    dist.gather(img, out, dst=dst)
+    return torch.cat(out, 0) if out is not None else None
