@@ -27,6 +27,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
+# HBM bytes per conv3x3_mfma_kernel launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes, FETCH_SIZE doubled per MI355X_MICROARCH.md, averaged over the 36 launches of a step); None until measured.
+TRAFFIC_PER_LAUNCH_BYTES = 45.90e6   # profiles/r01_c_pmc_hbm_traffic.csv (algorithmic: 44.58e6)
 
 
 def load_weights():
@@ -90,6 +93,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-every", type=int, default=4,
+                    help="bracket every launch of every Nth timed step with HIP events for the roofline (0 = never); "
+                         "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
+                         "it on every step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,14 +149,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ops.profile = []
+    prof, nprof = [], 0
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        sample = args.profile_every > 0 and k % args.profile_every == 0
+        ops.profile = prof if sample else None
+        nprof += 1 if sample else 0
         step()
+    ops.profile = None
     fence()
     dt = time.perf_counter() - t0
-    prof, ops.profile = ops.profile, None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,16 +174,19 @@ def main():
             a[1] += flops
             a[2] += nbytes
             a[3] += e0.elapsed_time(e1) * 1e-3
-        n, fl, by, sec = agg["conv3x3_mfma_kernel"]
-        ach = fl / sec / 1e12
-        roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": round(ach, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "launches_per_step": n // args.steps,
-                "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_step": fl / args.steps,
-                "hbm_GBs_algorithmic": round(by / sec / 1e9, 1)}
-        kern = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[3] / args.steps * 1e3, 4),
-                    "TFLOPs": round(v[1] / v[3] / 1e12, 2), "GBs_algorithmic": round(v[2] / v[3] / 1e9, 1)}
-                for k, v in agg.items()}
+        roof, kern = None, {}
+        if nprof:
+            n, fl, by, sec = agg["conv3x3_mfma_kernel"]
+            ach = fl / sec / 1e12
+            roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": round(ach, 2),
+                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": TRAFFIC_PER_LAUNCH_BYTES, "launches_per_step": n // nprof,
+                    "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_launch": fl / n,
+                    "algorithmic_bytes_per_launch": by / n, "hbm_GBs_algorithmic": round(by / sec / 1e9, 1),
+                    "timing": "HIP events around every launch of %d of the %d timed steps" % (nprof, args.steps)}
+            kern = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[3] / nprof * 1e3, 4),
+                        "TFLOPs": round(v[1] / v[3] / 1e12, 2), "GBs_algorithmic": round(v[2] / v[3] / 1e9, 1)}
+                    for k, v in agg.items()}
         res = {"metric": "SR images/sec (32->256, batch 16 per GPU)", "value": round(world * B * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
