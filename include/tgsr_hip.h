@@ -135,6 +135,17 @@ int tgsr_damsm_words_fwd(const float* words, const int32_t* cap_lens, const floa
 int tgsr_func_attention_fwd(const float* query, const float* context, int B, int ndf, int L, int S, float gamma1,
                             float* weighted_context, float* attn, void* stream);
 
+/*
+ * The two trainable heads of CNN_ENCODER (util.py:300-301, 364-367) as fp32 MFMA GEMMs with bias:
+ * tgsr_conv1x1_fwd : emb_features, conv1x1 Cin -> Cout on [B][Cin][S] (S = ih*iw, 17*17) -> out [B][Cout][S]
+ * tgsr_linear_fwd  : emb_cnn_code, out[b][o] = sum_k w[o][k] x[b][k] + bias[o]; x [B][K], w [Cout][K]
+ * bias may be NULL.  (The Inception-v3 trunk that produces their inputs is third-party torchvision arithmetic.)
+ */
+int tgsr_conv1x1_fwd(const float* x, int B, int Cin, int S, const float* w, const float* bias, int Cout, float* out,
+                     void* stream);
+int tgsr_linear_fwd(const float* x, int B, int K, const float* w, const float* bias, int Cout, float* out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

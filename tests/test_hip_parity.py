@@ -217,6 +217,28 @@ def test_damsm_similarity_vs_oracle(B, ndf, Tw, S):
         assert float(att[i, L:].abs().max()) == 0.0 if L < Tw else True
 
 
+def test_cnn_encoder_heads(cfg_face):
+    """emb_features (conv1x1 768->256 on 17x17) and emb_cnn_code (Linear 2048->256) vs torch; trunk injected."""
+    from tgsr_amd import util
+
+    class FakeTrunk(torch.nn.Module):
+        def forward(self, x):
+            g = torch.Generator().manual_seed(int(x.shape[0]))
+            return (torch.randn(x.shape[0], 768, 17, 17, generator=g).to(x.device),
+                    torch.randn(x.shape[0], 2048, generator=g).to(x.device))
+
+    enc = util.CNN_ENCODER(256, trunk=FakeTrunk()).to(DEV).eval()
+    assert sorted(k for k in enc.state_dict() if not k.startswith("trunk.")) == \
+        ["emb_cnn_code.bias", "emb_cnn_code.weight", "emb_features.weight"]
+    for B in (1, 5, 16):
+        x = torch.zeros(B, 3, 64, 64, device=DEV)
+        feats, code = enc(x)
+        f768, p2048 = enc.trunk(x)
+        close(feats, F.conv2d(f768.cpu(), enc.emb_features.weight.detach().cpu()), atol=5e-5, rtol=1e-4)
+        close(code, F.linear(p2048.cpu(), enc.emb_cnn_code.weight.detach().cpu(), enc.emb_cnn_code.bias.detach().cpu()),
+              atol=1e-4, rtol=1e-4)
+
+
 def test_kl_mse_golden(ops_small):
     from tgsr_amd.miscc import losses
     g = ops_small

@@ -30,6 +30,8 @@ SIGNATURES = {
     "tgsr_bilstm_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "tgsr_damsm_words_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "tgsr_func_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "tgsr_conv1x1_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "tgsr_linear_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
 }
 
 _lib = None

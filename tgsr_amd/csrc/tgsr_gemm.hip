@@ -1,0 +1,101 @@
+// Small fp32 MFMA GEMM with bias for the two trainable heads of CNN_ENCODER (util.py:300-301, 364-367):
+//   emb_features : conv1x1 768 -> nef on the 17x17 region map  out[b][o][s] = sum_k W[o][k] x[b][k][s]        ("NN")
+//   emb_cnn_code : Linear 2048 -> nef                           out[b][o]    = sum_k W[o][k] x[b][k] + bias[o] ("NT")
+// One kernel: C[m][n] = sum_k A[m][k] * B(k, n) + bias[m], MFMA "A" = weight rows (lane = m, staged in LDS,
+// pitch 65), MFMA "B" = activations (lane = n): NN reads them straight from HBM (n contiguous), NT stages a
+// [32 n][64 k] tile per wave.  Output strides are free, so both NCHW planes and [B][nef] rows are written directly.
+#include "tgsr_common.h"
+
+namespace tgsr {
+
+struct GemmArgs {
+  const float* A;      // [M][lda]
+  const float* B;      // NN: [K][ldb] (n contiguous);  NT: [N][ldb] (k contiguous)
+  const float* bias;   // [M] or null
+  float* C;
+  int M, N, K, lda, ldb;
+  int64_t csm, csn;    // C[m*csm + n*csn]
+  int64_t bsB, bsC;    // batch strides (blockIdx.z)
+};
+
+template <bool NT>
+__global__ __launch_bounds__(256) void gemm_bias_kernel(GemmArgs a) {
+  constexpr int KC = 64, P = KC + 1;
+  __shared__ float a_s[32 * P];
+  __shared__ float b_s[NT ? 4 * 32 * P : 1];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5, wave = tid >> 6;
+  const int m0 = blockIdx.y * 32, n0 = (blockIdx.x * 4 + wave) * 32;
+  const float* Bb = a.B + (int64_t)blockIdx.z * a.bsB;
+  float* Cb = a.C + (int64_t)blockIdx.z * a.bsC;
+  const int n = n0 + l31;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < a.K; k0 += KC) {
+    __syncthreads();
+    for (int idx = tid; idx < 32 * KC; idx += 256) {
+      const int r = idx >> 6, k = idx & 63;
+      a_s[r * P + k] = (m0 + r < a.M && k0 + k < a.K) ? a.A[(int64_t)(m0 + r) * a.lda + k0 + k] : 0.f;
+    }
+    if (NT) {
+      float* mine = b_s + wave * 32 * P;
+      for (int idx = lane; idx < 32 * KC; idx += 64) {
+        const int r = idx >> 6, k = idx & 63;
+        mine[r * P + k] = (n0 + r < a.N && k0 + k < a.K) ? Bb[(int64_t)(n0 + r) * a.ldb + k0 + k] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (NT) {
+      const float* mine = b_s + wave * 32 * P;
+#pragma unroll 8
+      for (int k = 0; k < KC; k += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[l31 * P + k + hh], mine[l31 * P + k + hh], acc, 0, 0, 0);
+    } else {
+      float bv[KC / 2];
+#pragma unroll
+      for (int k = 0; k < KC / 2; ++k) {
+        const int kk = k0 + 2 * k + hh;
+        bv[k] = (n < a.N && kk < a.K) ? Bb[(int64_t)kk * a.ldb + n] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KC / 2; ++k)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[l31 * P + 2 * k + hh], bv[k], acc, 0, 0, 0);
+    }
+  }
+  if (n < a.N) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = m0 + acc_row(i, hh);
+      if (m < a.M) Cb[(int64_t)m * a.csm + (int64_t)n * a.csn] = acc[i] + (a.bias ? a.bias[m] : 0.f);
+    }
+  }
+}
+
+static int gemm_launch(const GemmArgs& a, bool nt, int batch, hipStream_t s) {
+  dim3 grid((a.N + 127) / 128, (a.M + 31) / 32, batch);
+  if (nt) hipLaunchKernelGGL(gemm_bias_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gemm_bias_kernel<false>, grid, dim3(256), 0, s, a);
+  return note_launch(hipGetLastError(), "gemm_bias_kernel");
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int tgsr_conv1x1_fwd(const float* x, int B, int Cin, int S, const float* w, const float* bias, int Cout,
+                                float* out, void* stream) {
+  if (!x || !w || !out || B < 1 || Cin < 1 || S < 1 || Cout < 1) return TGSR_EINVAL;
+  GemmArgs a;
+  a.A = w; a.B = x; a.bias = bias; a.C = out; a.M = Cout; a.N = S; a.K = Cin; a.lda = Cin; a.ldb = S;
+  a.csm = S; a.csn = 1; a.bsB = (int64_t)Cin * S; a.bsC = (int64_t)Cout * S;
+  return gemm_launch(a, false, B, as_stream(stream));
+}
+
+extern "C" int tgsr_linear_fwd(const float* x, int B, int K, const float* w, const float* bias, int Cout, float* out,
+                               void* stream) {
+  if (!x || !w || !out || B < 1 || K < 1 || Cout < 1) return TGSR_EINVAL;
+  GemmArgs a;
+  a.A = w; a.B = x; a.bias = bias; a.C = out; a.M = Cout; a.N = B; a.K = K; a.lda = K; a.ldb = K;
+  a.csm = 1; a.csn = Cout; a.bsB = 0; a.bsC = 0;
+  return gemm_launch(a, true, 1, as_stream(stream));
+}

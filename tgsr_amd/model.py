@@ -9,10 +9,10 @@ import torch.nn as nn
 
 from . import ops
 from .miscc.config import cfg
-from .util import (CA_NET, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G, RNN_ENCODER, ResBlock,
+from .util import (CA_NET, CNN_ENCODER, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G, RNN_ENCODER, ResBlock,
                    _ConvBnGlu, _ResidualNoSum, conv3x3, conv5x5, upBlock)
 
-__all__ = ["G_SR_NET_low", "NetG_highweight", "RNN_ENCODER", "cfg", "torch"]
+__all__ = ["G_SR_NET_low", "NetG_highweight", "RNN_ENCODER", "CNN_ENCODER", "cfg", "torch"]
 
 
 class G_SR_NET_low(nn.Module):

@@ -261,3 +261,33 @@ def func_attention(query: torch.Tensor, context: torch.Tensor, gamma1: float):
                                             _stream())
     check(rc, "tgsr_func_attention_fwd")
     return wc, attn
+
+
+# ----------------------------------------------------------------------------------------- CNN_ENCODER heads
+def conv1x1(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """1x1 convolution [B,Cin,H,W] -> [B,Cout,H,W] (emb_features, util.py:300,367) as an MFMA GEMM."""
+    _need_hip(x, w, bias)
+    x = _f32(x, "x").contiguous()
+    B, Cin, H, W = x.shape
+    w2 = _f32(w.detach(), "w").reshape(w.shape[0], -1).contiguous()
+    if w2.shape[1] != Cin:
+        raise TgsrError("conv1x1: weight %s vs input channels %d" % (tuple(w.shape), Cin))
+    out = torch.empty(B, w2.shape[0], H, W, dtype=torch.float32, device=x.device)
+    b = None if bias is None else _f32(bias.detach(), "bias").contiguous()
+    check(_lib.lib().tgsr_conv1x1_fwd(_p(x), B, Cin, H * W, _p(w2), _p(b), w2.shape[0], _p(out), _stream()),
+          "tgsr_conv1x1_fwd")
+    return out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B,K] @ w[Cout,K]^T + bias (emb_cnn_code, util.py:301,364) as an MFMA GEMM."""
+    _need_hip(x, w, bias)
+    x = _f32(x, "x").contiguous()
+    w2 = _f32(w.detach(), "w").contiguous()
+    B, K = x.shape
+    if w2.shape[1] != K:
+        raise TgsrError("linear: weight %s vs input %s" % (tuple(w.shape), tuple(x.shape)))
+    out = torch.empty(B, w2.shape[0], dtype=torch.float32, device=x.device)
+    b = None if bias is None else _f32(bias.detach(), "bias").contiguous()
+    check(_lib.lib().tgsr_linear_fwd(_p(x), B, K, _p(w2), _p(b), w2.shape[0], _p(out), _stream()), "tgsr_linear_fwd")
+    return out

@@ -200,6 +200,73 @@ class RNN_ENCODER(nn.Module):
         return ops.bilstm(captions, cap_lens, self.encoder.weight, w_ih, w_hh, b_ih, b_hh)
 
 
+class CNN_ENCODER(nn.Module):
+    """util.py:263-368.  The frozen Inception-v3 trunk is third-party torchvision arithmetic with downloaded weights
+    (util.py:271-275): it is NOT re-implemented here.  Pass `trunk` = a module mapping images [B,3,H,W] to
+    (region features [B,768,17,17], pooled code [B,2048]) - e.g. a torchvision Inception-v3 wrapped the way
+    util.py:308-362 walks it - or let the constructor build that wrapper when torchvision is importable.  The two
+    trainable heads (`emb_features`, `emb_cnn_code`; same state_dict keys, same uniform(-0.1, 0.1) init,
+    util.py:303-306) run on the HIP GEMM kernels."""
+
+    def __init__(self, nef, trunk=None):
+        super(CNN_ENCODER, self).__init__()
+        self.nef = nef if cfg.TRAIN.FLAG else 256          # util.py:266-269
+        if trunk is None:
+            trunk = _torchvision_inception_trunk()
+        self.trunk = trunk
+        self.emb_features = conv1x1(768, self.nef)
+        self.emb_cnn_code = nn.Linear(2048, self.nef)
+        self.init_trainable_weights()
+
+    def init_trainable_weights(self):
+        self.emb_features.weight.data.uniform_(-0.1, 0.1)
+        self.emb_cnn_code.weight.data.uniform_(-0.1, 0.1)
+
+    def heads(self, features, pooled):
+        """(features [B,768,17,17], pooled [B,2048]) -> (region features [B,nef,17,17], cnn_code [B,nef])."""
+        cnn_code = ops.linear(pooled, self.emb_cnn_code.weight, self.emb_cnn_code.bias)
+        return ops.conv1x1(features, self.emb_features.weight), cnn_code
+
+    def forward(self, x):
+        features, pooled = self.trunk(x)
+        return self.heads(features, pooled)
+
+
+def _torchvision_inception_trunk():
+    try:
+        from torchvision import models
+    except ImportError as e:
+        raise ImportError("CNN_ENCODER needs an Inception-v3 trunk: torchvision is not installed here; pass "
+                          "`trunk=` (images -> (features [B,768,17,17], pooled [B,2048]))") from e
+
+    class _Trunk(nn.Module):
+        """util.py:278-362: bilinear resize to 299, the Inception-v3 stem/Mixed blocks, features after Mixed_6e,
+        8x8 average pool after Mixed_7c.  Frozen (util.py:274-275)."""
+
+        def __init__(self):
+            super().__init__()
+            self.m = models.inception_v3(weights=None, aux_logits=True, init_weights=False)
+            for p in self.m.parameters():
+                p.requires_grad = False
+
+        def forward(self, x):
+            import torch.nn.functional as F
+            m = self.m
+            x = F.interpolate(x, size=(299, 299), mode='bilinear', align_corners=False)
+            x = m.Conv2d_2b_3x3(m.Conv2d_2a_3x3(m.Conv2d_1a_3x3(x)))
+            x = F.max_pool2d(x, kernel_size=3, stride=2)
+            x = m.Conv2d_4a_3x3(m.Conv2d_3b_1x1(x))
+            x = F.max_pool2d(x, kernel_size=3, stride=2)
+            x = m.Mixed_5d(m.Mixed_5c(m.Mixed_5b(x)))
+            x = m.Mixed_6e(m.Mixed_6d(m.Mixed_6c(m.Mixed_6b(m.Mixed_6a(x)))))
+            features = x
+            x = m.Mixed_7c(m.Mixed_7b(m.Mixed_7a(x)))
+            x = F.avg_pool2d(x, kernel_size=8)
+            return features, x.view(x.size(0), -1)
+
+    return _Trunk()
+
+
 class CA_NET(nn.Module):
     """util.py:372-400.  One 256->400 Linear + GLU on [B,256]: a plain library GEMM (rocBLAS through torch);
     `c_code` is sampled to keep the reference's RNG consumption (util.py:388-396) and discarded by the caller."""
