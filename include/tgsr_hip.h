@@ -146,6 +146,48 @@ int tgsr_conv1x1_fwd(const float* x, int B, int Cin, int S, const float* w, cons
 int tgsr_linear_fwd(const float* x, int B, int K, const float* w, const float* bias, int Cout, float* out,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training path (BatchNorm2d batch statistics + backward).  The reference trains through torch autograd over
+ * nn.Conv2d / nn.BatchNorm2d(train) / GLU / nn.Upsample (util.py:74-80, 110-130); these entry points are the
+ * hand-written forward/backward of the same blocks.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Number of partial-sum splits tgsr_bn_train_* use for (B, C, HW); partial_ws must hold C * nsplit * 4 floats. */
+int tgsr_bn_train_nsplit(int B, int C, int HW);
+
+/*
+ * nn.BatchNorm2d in training mode (+ GLU | + residual) on the raw conv output: batch mean / biased variance per
+ * channel over (B, H, W), running statistics updated in place with `momentum` and the unbiased variance (either
+ * both NULL or both given), y = GLU(bn(raw)) (glu=1, C even, out has C/2 channels) or bn(raw) (+ residual).
+ * raw [B][C][HW] dense, HW % 4 == 0.  Saves mean/invstd/scale/shift [C] for the backward.
+ */
+int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, int glu, const float* residual,
+                      int64_t res_bstride, float* partial_ws, float* mean, float* invstd, float* scale, float* shift,
+                      float* out, int64_t out_bstride, void* stream);
+
+/*
+ * Backward of the above: dout [B][C or C/2][HW] dense -> draw [B][C][HW] (gradient wrt the raw conv output),
+ * dgamma, dbeta [C].  The gradient wrt a residual input is dout itself.  sums_ws: 2*C floats.
+ */
+int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, int glu, float* partial_ws,
+                      float* sums_ws, float* draw, float* dgamma, float* dbeta, void* stream);
+
+/* Backward of nn.Upsample(scale_factor=2, 'nearest'): out[bc][y][x] = sum of in[bc][2y..2y+1][2x..2x+1]. */
+int tgsr_sumpool2x2(const float* x, int64_t BC, int H, int W, float* out, void* stream);
+
+/*
+ * Weight gradient of tgsr_conv3x3_fwd: dw[Cout][Cin][3][3] = sum over (b, y, x) of grad_out * shifted input
+ * (upsample=1: the input is read through the folded nearest-x2, H/W are the PRE-upsample sizes).
+ * grad_out [B][Cout][Ho][Wo] dense; x [B][Cin][H][W] with batch stride; Cout % 32 == 0.
+ * ws must hold tgsr_conv3x3_wgrad_ws_elems(...) floats (per-workgroup partial slabs, summed in a fixed order).
+ * The data gradient is tgsr_conv3x3_fwd on the flipped / transposed weights (+ tgsr_sumpool2x2 for upsample=1).
+ */
+int64_t tgsr_conv3x3_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W, int upsample);
+int tgsr_conv3x3_wgrad(const float* grad_out, const float* x, int64_t x_bstride, int B, int Cin, int H, int W, int Cout,
+                       int upsample, float* ws, float* dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

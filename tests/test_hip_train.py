@@ -1,0 +1,73 @@
+"""GPU: training path (batch-statistics BN, backward kernels) against torch autograd over the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tgsr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(a, b, atol, rtol=1e-4):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+CASES = [
+    # B, Cin, H, W, Cout, glu, up, res
+    (3, 64, 16, 32, 128, True, False, False),
+    (3, 64, 16, 32, 64, False, False, True),
+    (2, 64, 16, 16, 64, True, True, False),
+    (4, 32, 32, 32, 64, True, False, False),
+    (4, 32, 32, 32, 32, False, False, True),
+    (2, 32, 16, 32, 32, False, False, False),
+    (2, 3, 32, 32, 64, True, False, False),
+    (16, 64, 32, 32, 128, True, False, False),
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,glu,up,res", CASES)
+def test_conv_bn_act_train_fwd_bwd(B, Cin, H, W, Cout, glu, up, res):
+    from tgsr_amd.autograd import ConvBnAct
+    g = torch.Generator().manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    gamma = 1 + 0.2 * torch.randn(Cout, generator=g)
+    beta = 0.1 * torch.randn(Cout, generator=g)
+    rm = 0.1 * torch.randn(Cout, generator=g)
+    rv = 0.5 + torch.rand(Cout, generator=g)
+    co = Cout // 2 if glu else Cout
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    r = torch.randn(B, co, Ho, Wo, generator=g) if res else None
+    dy = torch.randn(B, co, Ho, Wo, generator=g)
+
+    # reference: torch autograd over the oracle's functions (CPU)
+    xr, wr, gr, br = (t.clone().requires_grad_() for t in (x, w, gamma, beta))
+    rr = r.clone().requires_grad_() if res else None
+    sd = {"weight": gr, "bias": br, "running_mean": rm.clone(), "running_var": rv.clone()}
+    upd = {}
+    xi = xr.repeat_interleave(2, 2).repeat_interleave(2, 3) if up else xr
+    y = O.batch_norm(F.conv2d(xi, wr, None, 1, 1), sd, "", training=True, update=upd)
+    y = O.glu(y) if glu else y
+    y = y + rr if res else y
+    y.backward(dy)
+
+    xd, wd, gd, bd = (t.to(DEV).requires_grad_() for t in (x, w, gamma, beta))
+    rd = r.to(DEV).requires_grad_() if res else None
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    out = ConvBnAct.apply(xd, wd, gd, bd, rmd, rvd, rd, glu, up, 0.1, 1e-5)
+    out.backward(dy.to(DEV))
+    close(out, y, atol=5e-5)
+    close(rmd, upd["running_mean"], atol=1e-5)
+    close(rvd, upd["running_var"], atol=1e-5)
+    scale = float(dy.numel()) ** 0.5
+    if Cin >= 32:                       # the stem convs take the data image: no input gradient needed, but check anyway
+        close(xd.grad, xr.grad, atol=2e-4, rtol=1e-3)
+    close(wd.grad, wr.grad, atol=2e-5 * scale, rtol=2e-3)
+    close(gd.grad, gr.grad, atol=2e-5 * scale, rtol=2e-3)
+    close(bd.grad, br.grad, atol=2e-5 * scale, rtol=2e-3)
+    if res:
+        close(rd.grad, rr.grad, atol=1e-6)

@@ -32,6 +32,13 @@ SIGNATURES = {
     "tgsr_func_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "tgsr_conv1x1_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "tgsr_linear_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "tgsr_bn_train_nsplit": (_i, [_i, _i, _i]),
+    "tgsr_bn_train_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _i64, _vp]),
+    "tgsr_bn_train_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "tgsr_conv3x3_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "tgsr_conv3x3_wgrad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

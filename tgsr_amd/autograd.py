@@ -1,0 +1,104 @@
+"""Training path: torch.autograd.Function wrappers whose forward AND backward are HIP kernels.
+
+The reference trains through torch autograd over nn.Conv2d / nn.BatchNorm2d(train) / GLU / nn.Upsample
+(util.py:74-80, 110-130).  Here one Function = one fused block:
+    ConvBnAct: [nearest x2 ->] conv3x3 -> BatchNorm2d(batch statistics) -> GLU | (+ residual)
+        forward : tgsr_conv3x3_fwd (raw) -> tgsr_bn_train_fwd (stats, running update, normalise + GLU/residual)
+        backward: tgsr_bn_train_bwd (GLU', BN') -> data gradient = tgsr_conv3x3_fwd on flipped/transposed weights
+                  (+ tgsr_sumpool2x2 through the up-sample) and tgsr_conv3x3_wgrad
+"""
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import _p, _stream
+
+
+def _dgrad_weight(w: torch.Tensor) -> torch.Tensor:
+    """conv_transpose of a stride-1 pad-1 3x3 conv = the same conv with the kernel flipped and in/out swapped."""
+    return w.flip(2, 3).transpose(0, 1).contiguous()
+
+
+class ConvBnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps):
+        L = _lib.lib()
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        wpack = ops.pack_conv3x3_weight(weight)
+        raw = ops.conv3x3_fused(x, wpack, Cout, None, None, glu=False, upsample=upsample)
+        Ho, Wo = raw.shape[2], raw.shape[3]
+        HW = Ho * Wo
+        dev = x.device
+        nsplit = L.tgsr_bn_train_nsplit(B, Cout, HW)
+        ws = torch.empty(Cout * nsplit * 4, dtype=torch.float32, device=dev)
+        stats = torch.empty(4, Cout, dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
+        co = Cout // 2 if glu else Cout
+        out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=dev)
+        res = None if residual is None else residual.contiguous()
+        rc = L.tgsr_bn_train_fwd(_p(raw), B, Cout, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
+                                 float(momentum), _p(running_mean), _p(running_var), 1 if glu else 0, _p(res),
+                                 0 if res is None else co * HW, _p(ws), _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                                 _p(stats[3]), _p(out), co * HW, _stream())
+        check(rc, "tgsr_bn_train_fwd")
+        ctx.save_for_backward(x, weight, raw, stats)
+        ctx.cfg = (glu, upsample, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, weight, raw, stats = ctx.saved_tensors
+        glu, upsample, has_res = ctx.cfg
+        dout = dout.contiguous()
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        Ho, Wo = raw.shape[2], raw.shape[3]
+        HW = Ho * Wo
+        dev = x.device
+        co = Cout // 2 if glu else Cout
+        nsplit = L.tgsr_bn_train_nsplit(B, co, HW)
+        ws = torch.empty(co * nsplit * 4, dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
+        draw = torch.empty_like(raw)
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+        rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, Cout, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]),
+                                 1 if glu else 0, _p(ws), _p(sums), _p(draw), _p(dgamma), _p(dbeta), _stream())
+        check(rc, "tgsr_bn_train_bwd")
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wT = _dgrad_weight(weight.detach())                           # [Cin, Cout, 3, 3]
+            cpad = (Cin + 31) // 32 * 32                                  # the kernel tiles 32 output channels
+            if cpad != Cin:                                               # stem convs (Cin = 3): zero-padded rows
+                wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cout, 3, 3)), 0)
+            dxu = ops.conv3x3_fused(draw, ops.pack_conv3x3_weight(wT), cpad, None, None)
+            if cpad != Cin:
+                dxu = dxu[:, :Cin].contiguous()                           # [B, Cin, Ho, Wo]
+            if upsample:
+                dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dev)
+                check(L.tgsr_sumpool2x2(_p(dxu), B * Cin, H, W, _p(dx), _stream()), "tgsr_sumpool2x2")
+            else:
+                dx = dxu
+        if ctx.needs_input_grad[1]:
+            n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
+            wws = torch.empty(n, dtype=torch.float32, device=dev)
+            dw = torch.empty_like(weight)
+            rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0, _p(wws),
+                                      _p(dw), _stream())
+            check(rc, "tgsr_conv3x3_wgrad")
+        dres = dout if has_res else None
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+def conv_bn_act_train(x, conv, bn, glu=False, upsample=False, residual=None):
+    """Training-mode fused block over the parameter-holder modules (conv: nn.Conv2d, bn: nn.BatchNorm2d)."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the reference")
+    out = ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                          bn.running_var if bn.track_running_stats else None, residual, glu, upsample, bn.momentum,
+                          bn.eps)
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return out

@@ -1,0 +1,309 @@
+// Training-mode BatchNorm2d (+ GLU / residual) around the conv kernel, forward and backward, for gfx950.
+//
+// The reference trains with nn.BatchNorm2d batch statistics (util.py:77,116,119).  A grid-wide reduction
+// sits between the convolution and the GLU, so training runs each block as
+//     conv3x3 (tgsr_conv3x3_fwd, identity affine) -> raw [B][C][HW]
+//     bn_stats   : per-channel sum / sum of squares, one float4 stream over raw         (HBM-bound)
+//     bn_finalize: mean, biased var (combined in double), invstd, scale/shift, running-stat update (momentum, unbiased)
+//     bn_act_fwd : y = GLU(raw*scale+shift) | raw*scale+shift (+ residual)              (HBM-bound, float4)
+// and the backward as
+//     bn_act_bwd_reduce: dz = d(BN output) from dy (GLU'/identity), per-channel sum dz, sum dz*xhat
+//     bn_act_bwd_apply : draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta
+// followed by the conv data/weight gradients (tgsr_conv3x3_fwd on flipped weights, tgsr_conv3x3_wgrad).
+#include "tgsr_common.h"
+
+namespace tgsr {
+
+constexpr int kBnThreads = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// grid (C, nsplit): partial[c][s] = (sum, sumsq) of raw[b][c][:] over the b's / pixel ranges of split s
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __restrict__ raw, int64_t bstride, int B,
+                                                              int HW, float* __restrict__ partial, int nsplit) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
+  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
+  float s = 0.f, q = 0.f;
+  const bool vec = (HW & 3) == 0;
+  if (vec) {
+    for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
+      const int b = (int)(e / HW);
+      const int p = (int)(e - (int64_t)b * HW);
+      const float4 v = *reinterpret_cast<const float4*>(raw + b * bstride + (int64_t)c * HW + p);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
+      const int b = (int)(e / HW);
+      const int p = (int)(e - (int64_t)b * HW);
+      const float v = raw[b * bstride + (int64_t)c * HW + p];
+      s += v;
+      q += v * v;
+    }
+  }
+  s = block_sum(s, red);
+  q = block_sum(q, red);
+  if (threadIdx.x == 0) {
+    partial[((int64_t)c * nsplit + sp) * 2] = s;
+    partial[((int64_t)c * nsplit + sp) * 2 + 1] = q;
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nsplit, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    s += partial[((int64_t)c * nsplit + k) * 2];
+    q += partial[((int64_t)c * nsplit + k) * 2 + 1];
+  }
+  const double m = s / count;
+  double var = q / count - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)m;
+  invstd[c] = is;
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)m * sc;
+  if (running_mean) {
+    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+  }
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// y = GLU(affine(raw)) or affine(raw) (+ residual).  grid-stride over float4 groups of the OUTPUT.
+template <bool GLU>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ raw, int B, int C, int HW,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ res, int64_t rbs,
+                                                         float* __restrict__ out, int64_t obs) {
+  const int Co = GLU ? C / 2 : C;
+  const int HW4 = HW >> 2;
+  const int64_t total = (int64_t)B * Co * HW4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p4 = (int)(i % HW4);
+    const int64_t t = i / HW4;
+    const int c = (int)(t % Co), b = (int)(t / Co);
+    const float4 v = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c) * HW + 4 * p4);
+    const float sv = scale[c], tv = shift[c];
+    float4 y = make_float4(v.x * sv + tv, v.y * sv + tv, v.z * sv + tv, v.w * sv + tv);
+    if (GLU) {
+      const float4 g = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c + Co) * HW + 4 * p4);
+      const float sg = scale[c + Co], tg = shift[c + Co];
+      y.x *= sigm(g.x * sg + tg);
+      y.y *= sigm(g.y * sg + tg);
+      y.z *= sigm(g.z * sg + tg);
+      y.w *= sigm(g.w * sg + tg);
+    } else if (res) {
+      const float4 r = *reinterpret_cast<const float4*>(res + b * rbs + (int64_t)c * HW + 4 * p4);
+      y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + b * obs + (int64_t)c * HW + 4 * p4) = y;
+  }
+}
+
+// Backward, pass 1.  grid (Co, nsplit).  For output channel c: GLU -> BN channels c (value) and c+Co (gate).
+// partial[c][s] = (sum dz_v, sum dz_v*xhat_v, sum dz_g, sum dz_g*xhat_g)   (non-GLU: the last two are 0)
+template <bool GLU>
+__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
+    const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ partial, int nsplit) {
+  __shared__ float red[4];
+  const int Co = GLU ? C / 2 : C;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t per = (total + nsplit - 1) / nsplit;
+  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
+  const float sv = scale[c], tv = shift[c], mv = mean[c], iv = invstd[c];
+  float sg = 0.f, tg = 0.f, mg = 0.f, ig = 0.f;
+  if (GLU) { sg = scale[c + Co]; tg = shift[c + Co]; mg = mean[c + Co]; ig = invstd[c + Co]; }
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
+    const int b = (int)(e / HW);
+    const int p = (int)(e - (int64_t)b * HW);
+    const float dy = dout[((int64_t)b * Co + c) * HW + p];
+    const float rv = raw[((int64_t)b * C + c) * HW + p];
+    if (GLU) {
+      const float rg = raw[((int64_t)b * C + c + Co) * HW + p];
+      const float av = rv * sv + tv, s = sigm(rg * sg + tg);
+      const float dzv = dy * s, dzg = dy * av * s * (1.f - s);
+      a0 += dzv; a1 += dzv * ((rv - mv) * iv);
+      a2 += dzg; a3 += dzg * ((rg - mg) * ig);
+    } else {
+      a0 += dy; a1 += dy * ((rv - mv) * iv);
+    }
+  }
+  a0 = block_sum(a0, red); a1 = block_sum(a1, red);
+  if (GLU) { a2 = block_sum(a2, red); a3 = block_sum(a3, red); }
+  if (threadIdx.x == 0) {
+    float* o = partial + ((int64_t)c * nsplit + sp) * 4;
+    o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+  }
+}
+
+// sums[ch] = (sum dz, sum dz*xhat) per BN channel, combined in double; dgamma = sum dz*xhat, dbeta = sum dz
+template <bool GLU>
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int Co = GLU ? C / 2 : C;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Co) return;
+  double a[4] = {0, 0, 0, 0};
+  for (int k = 0; k < nsplit; ++k)
+    for (int j = 0; j < 4; ++j) a[j] += partial[((int64_t)c * nsplit + k) * 4 + j];
+  sums[2 * c] = (float)a[0]; sums[2 * c + 1] = (float)a[1];
+  dbeta[c] = (float)a[0]; dgamma[c] = (float)a[1];
+  if (GLU) {
+    sums[2 * (c + Co)] = (float)a[2]; sums[2 * (c + Co) + 1] = (float)a[3];
+    dbeta[c + Co] = (float)a[2]; dgamma[c + Co] = (float)a[3];
+  }
+}
+
+// Backward, pass 2: draw[b][ch][p] = gamma*invstd*(dz - sum_dz/N - xhat*sum_dzx/N), elementwise over the output grid
+template <bool GLU>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ sums, float invN, float* __restrict__ draw) {
+  const int Co = GLU ? C / 2 : C;
+  const int64_t total = (int64_t)B * Co * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW);
+    const int64_t t = i / HW;
+    const int c = (int)(t % Co), b = (int)(t / Co);
+    const float dy = dout[i];
+    const int64_t iv_ = ((int64_t)b * C + c) * HW + p;
+    const float rv = raw[iv_];
+    const float sv = scale[c], mv = mean[c], isv = invstd[c];   // scale = gamma * invstd
+    const float xv = (rv - mv) * isv;
+    if (GLU) {
+      const int64_t ig_ = iv_ + (int64_t)Co * HW;
+      const float rg = raw[ig_];
+      const float sg = scale[c + Co], mg = mean[c + Co], isg = invstd[c + Co];
+      const float xg = (rg - mg) * isg;
+      const float av = rv * sv + shift[c], s = sigm(rg * sg + shift[c + Co]);
+      const float dzv = dy * s, dzg = dy * av * s * (1.f - s);
+      draw[iv_] = sv * (dzv - sums[2 * c] * invN - xv * sums[2 * c + 1] * invN);
+      draw[ig_] = sg * (dzg - sums[2 * (c + Co)] * invN - xg * sums[2 * (c + Co) + 1] * invN);
+    } else {
+      draw[iv_] = sv * (dy - sums[2 * c] * invN - xv * sums[2 * c + 1] * invN);
+    }
+  }
+}
+
+// out[bc][y][x] = sum of the 2x2 block of in[bc][2y..2y+1][2x..2x+1]   (backward of the nearest x2 up-sample)
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict__ in, int64_t BC, int H, int W,
+                                                         float* __restrict__ out) {
+  const int64_t total = BC * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const int64_t t = i / W;
+    const int y = (int)(t % H);
+    const int64_t bc = t / H;
+    const float* r0 = in + (bc * 2 * H + 2 * y) * (int64_t)(2 * W) + 2 * x;
+    const float2 u = *reinterpret_cast<const float2*>(r0);
+    const float2 v = *reinterpret_cast<const float2*>(r0 + 2 * W);
+    out[i] = (u.x + u.y) + (v.x + v.y);
+  }
+}
+
+static inline int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int tgsr_bn_train_nsplit(int B, int C, int HW) {
+  // enough workgroups to fill the chip (>= 1024) without splitting below ~4k elements per workgroup
+  const int64_t total = (int64_t)B * HW;
+  int n = (int)((1024 + C - 1) / C);
+  const int64_t cap = total / 4096 > 0 ? total / 4096 : 1;
+  if (n > cap) n = (int)cap;
+  return n < 1 ? 1 : (n > 64 ? 64 : n);
+}
+
+extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, int glu,
+                                 const float* residual, int64_t res_bstride, float* partial_ws, float* mean,
+                                 float* invstd, float* scale, float* shift, float* out, int64_t out_bstride,
+                                 void* stream) {
+  if (!raw || !gamma || !beta || !partial_ws || !mean || !invstd || !scale || !shift || !out) return TGSR_EINVAL;
+  if (B < 1 || C < 1 || HW < 1 || (glu && (C & 1)) || (glu && residual)) return TGSR_EINVAL;
+  if ((HW & 3) != 0) return TGSR_EUNSUPPORTED;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return TGSR_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const int nsplit = tgsr_bn_train_nsplit(B, C, HW);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, nsplit), dim3(kBnThreads), 0, s, raw, (int64_t)C * HW, B, HW,
+                     partial_ws, nsplit);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
+                     (double)B * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  const int Co = glu ? C / 2 : C;
+  const int g = grid_for((int64_t)B * Co * (HW / 4));
+  if (glu)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(g), dim3(256), 0, s, raw, B, C, HW, scale, shift, nullptr,
+                       (int64_t)0, out, out_bstride);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(g), dim3(256), 0, s, raw, B, C, HW, scale, shift, residual,
+                       res_bstride, out, out_bstride);
+  return note_launch(hipGetLastError(), "bn_train_fwd");
+}
+
+extern "C" int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd, int glu,
+                                 float* partial_ws, float* sums_ws, float* draw, float* dgamma, float* dbeta,
+                                 void* stream) {
+  if (!dout || !raw || !scale || !shift || !mean || !invstd || !partial_ws || !sums_ws || !draw || !dgamma || !dbeta)
+    return TGSR_EINVAL;
+  if (B < 1 || C < 1 || HW < 1 || (glu && (C & 1))) return TGSR_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const int Co = glu ? C / 2 : C;
+  const int nsplit = tgsr_bn_train_nsplit(B, Co, HW);
+  const float invN = (float)(1.0 / ((double)B * HW));
+  const int g = grid_for((int64_t)B * Co * HW);
+  if (glu) {
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C, HW,
+                       scale, shift, mean, invstd, partial_ws, nsplit);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<true>, dim3((Co + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
+                       sums_ws, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(g), dim3(256), 0, s, dout, raw, B, C, HW, scale, shift,
+                       mean, invstd, sums_ws, invN, draw);
+  } else {
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<false>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C,
+                       HW, scale, shift, mean, invstd, partial_ws, nsplit);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3((Co + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
+                       sums_ws, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(g), dim3(256), 0, s, dout, raw, B, C, HW, scale, shift,
+                       mean, invstd, sums_ws, invN, draw);
+  }
+  return note_launch(hipGetLastError(), "bn_train_bwd");
+}
+
+extern "C" int tgsr_sumpool2x2(const float* x, int64_t BC, int H, int W, float* out, void* stream) {
+  if (!x || !out || BC < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  hipLaunchKernelGGL(sumpool2x2_kernel, dim3(grid_for(BC * H * W)), dim3(256), 0, as_stream(stream), x, BC, H, W, out);
+  return note_launch(hipGetLastError(), "sumpool2x2_kernel");
+}
