@@ -188,6 +188,26 @@ int64_t tgsr_conv3x3_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W, int 
 int tgsr_conv3x3_wgrad(const float* grad_out, const float* x, int64_t x_bstride, int B, int Cin, int H, int W, int Cout,
                        int upsample, float* ws, float* dw, void* stream);
 
+/*
+ * Backward of tgsr_word_attention_fwd (the attention map output carries no gradient).  P is recomputed from h and
+ * src.  dc [B][idf][Q] dense -> dh [B][idf][Q] dense and dsrc_part [B][nchunks][idf][32] (nchunks =
+ * tgsr_word_attention_bwd_chunks(Q)); the caller sums the chunks and maps dsrc to conv_context.weight / words:
+ * dW_ctx[i][c] = sum_{b,t} dsrc[b][i][t] words[b][c][t].   idf in {32, 64}, T <= 32.
+ */
+int tgsr_word_attention_bwd_chunks(int Q);
+int tgsr_word_attention_bwd(const float* h, int64_t h_bstride, const float* src, const uint8_t* mask, int mask_mode,
+                            int B, int idf, int T, int Q, const float* dc, float* dh, float* dsrc_part, void* stream);
+
+/*
+ * Backward of tgsr_conv_to3_fwd.  g = dy * (1 - t^2), t = out - alpha*addend for act = TGSR_ACT_TANH_AXPY (out = the
+ * forward output), g = dy otherwise.  dx (may be NULL) [B][Cin][H][W] dense needs w; dw (may be NULL) [3][Cin][K][K]
+ * needs x and ws = tgsr_conv_to3_bwd_ws_elems(...) floats.  d(addend) = alpha * dy is left to the caller.
+ */
+int64_t tgsr_conv_to3_bwd_ws_elems(int B, int Cin, int H, int W, int K);
+int tgsr_conv_to3_bwd(const float* dy, const float* out, const float* addend, float alpha, const float* x,
+                      int64_t x_bstride, const float* w, int B, int Cin, int H, int W, int K, int act, float* dx,
+                      float* ws, float* dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

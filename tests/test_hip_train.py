@@ -71,3 +71,52 @@ def test_conv_bn_act_train_fwd_bwd(B, Cin, H, W, Cout, glu, up, res):
     close(bd.grad, br.grad, atol=2e-5 * scale, rtol=2e-3)
     if res:
         close(rd.grad, rr.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,K,act", [(2, 32, 32, 64, 3, False), (2, 32, 32, 64, 5, True), (3, 32, 19, 70, 5, True),
+                                              (1, 32, 64, 64, 3, False), (2, 20, 16, 16, 5, True)])
+def test_conv_to3_backward(B, Cin, H, W, K, act):
+    from tgsr_amd.autograd import ConvTo3
+    g = torch.Generator().manual_seed(K * 10 + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(3, Cin, K, K, generator=g) / (K * Cin ** 0.5)
+    add = torch.randn(B, 3, H, W, generator=g) if act else None
+    dy = torch.randn(B, 3, H, W, generator=g)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    ar = add.clone().requires_grad_() if act else None
+    y = F.conv2d(xr, wr, None, 1, K // 2)
+    y = torch.tanh(y) + 0.5 * ar if act else y
+    y.backward(dy)
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    ad = add.to(DEV).requires_grad_() if act else None
+    out = ConvTo3.apply(xd, wd, ad, act, 0.5)
+    out.backward(dy.to(DEV))
+    close(out, y, atol=2e-5)
+    close(xd.grad, xr.grad, atol=2e-5, rtol=1e-3)
+    close(wd.grad, wr.grad, atol=3e-5 * float(B * H * W) ** 0.5, rtol=2e-3)
+    if act:
+        close(ad.grad, ar.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,idf,r,T_,correct", [(3, 32, 16, 6, False), (3, 32, 32, 18, True), (2, 64, 16, 9, False),
+                                                (5, 32, 20, 7, False), (16, 32, 64, 14, False)])
+def test_word_attention_backward(B, idf, r, T_, correct):
+    from tgsr_amd.autograd import WordAttention
+    g = torch.Generator().manual_seed(B * 7 + r)
+    h = torch.randn(B, idf, r, r, generator=g)
+    words = torch.randn(B, 64, T_, generator=g)
+    w = torch.randn(idf, 64, 1, 1, generator=g) / 8
+    lens = torch.randint(1, T_ + 1, (B,), generator=g)
+    lens[0] = T_
+    mask = torch.arange(T_)[None, :] >= lens[:, None]
+    dc = torch.randn(B, idf, r, r, generator=g)
+    hr, wr_, wdr = h.clone().requires_grad_(), w.clone().requires_grad_(), words.clone().requires_grad_()
+    c_ref, _ = O.word_attention(hr, wdr, wr_, mask, correct_mask=correct)
+    c_ref.backward(dc)
+    hd, wd, wdd = h.to(DEV).requires_grad_(), w.to(DEV).requires_grad_(), words.to(DEV).requires_grad_()
+    c, attn = WordAttention.apply(hd, wdd, wd, mask.to(DEV), correct)
+    c.backward(dc.to(DEV))
+    close(c, c_ref, atol=5e-5)
+    close(hd.grad, hr.grad, atol=5e-5, rtol=1e-3)
+    close(wd.grad, wr_.grad, atol=2e-4 * r, rtol=2e-3)
+    close(wdd.grad, wdr.grad, atol=2e-4 * r, rtol=2e-3)

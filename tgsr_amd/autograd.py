@@ -102,3 +102,72 @@ def conv_bn_act_train(x, conv, bn, glu=False, upsample=False, residual=None):
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return out
+
+
+class ConvTo3(torch.autograd.Function):
+    """KxK conv to 3 channels [+ tanh + alpha * addend] (the image heads), forward and backward on HIP."""
+
+    @staticmethod
+    def forward(ctx, x, weight, addend, tanh_axpy, alpha):
+        out = ops.conv_to3(x, weight, tanh_axpy=tanh_axpy, addend=addend, alpha=alpha)
+        ctx.save_for_backward(x, weight, out if tanh_axpy else None, addend)
+        ctx.cfg = (tanh_axpy, float(alpha))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, weight, out, addend = ctx.saved_tensors
+        tanh_axpy, alpha = ctx.cfg
+        dy = dy.contiguous()
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        K = weight.shape[2]
+        dev = x.device
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = torch.empty_like(x) if need_dx else None
+        dw = torch.empty_like(weight) if need_dw else None
+        ws = torch.empty(L.tgsr_conv_to3_bwd_ws_elems(B, Cin, H, W, K), dtype=torch.float32, device=dev) if need_dw else None
+        w = weight.detach().contiguous()
+        rc = L.tgsr_conv_to3_bwd(_p(dy), _p(out), _p(addend), alpha, _p(x), Cin * H * W, _p(w), B, Cin, H, W, K,
+                                 _lib.ACT_TANH_AXPY if tanh_axpy else _lib.ACT_NONE, _p(dx), _p(ws), _p(dw), _stream())
+        check(rc, "tgsr_conv_to3_bwd")
+        dadd = dy * alpha if (addend is not None and ctx.needs_input_grad[2]) else None
+        return dx, dw, dadd, None, None
+
+
+class WordAttention(torch.autograd.Function):
+    """GlobalAttentionGeneral.forward with a HIP backward for h and conv_context.weight (and words when needed)."""
+
+    @staticmethod
+    def forward(ctx, h, words, w_ctx, mask, correct_mask):
+        c_code, attn = ops.word_attention(h, words, w_ctx, mask, correct_mask)
+        ctx.save_for_backward(h, words, w_ctx, mask)
+        ctx.correct_mask = correct_mask
+        ctx.mark_non_differentiable(attn)
+        return c_code, attn
+
+    @staticmethod
+    def backward(ctx, dc, _dattn):
+        L = _lib.lib()
+        h, words, w_ctx, mask = ctx.saved_tensors
+        h = h.contiguous()
+        dc = dc.contiguous()
+        B, idf, ih, iw = h.shape
+        cdf, T = words.shape[1], words.shape[2]
+        Q = ih * iw
+        dev = h.device
+        w2 = w_ctx.detach().reshape(idf, cdf)
+        src = torch.zeros(B, idf, 32, dtype=torch.float32, device=dev)
+        src[:, :, :T] = torch.matmul(w2, words.detach())               # tiny [idf,cdf] x [B,cdf,T] (library GEMM)
+        nch = L.tgsr_word_attention_bwd_chunks(Q)
+        part = torch.empty(B, nch, idf, 32, dtype=torch.float32, device=dev)
+        dh = torch.empty_like(h)
+        m8 = None if mask is None else ops._mask_u8(mask)
+        rc = L.tgsr_word_attention_bwd(_p(h), idf * Q, _p(src), _p(m8), 1 if ctx.correct_mask else 0, B, idf, T, Q,
+                                       _p(dc), _p(dh), _p(part), _stream())
+        check(rc, "tgsr_word_attention_bwd")
+        dsrc = part.sum(1)[:, :, :T]                                      # [B, idf, T]
+        dwords = torch.matmul(w2.t(), dsrc) if ctx.needs_input_grad[1] else None
+        dw = torch.einsum("bit,bct->ic", dsrc, words.detach()).reshape(w_ctx.shape) if ctx.needs_input_grad[2] else None
+        return dh, dwords, dw, None, None
