@@ -120,3 +120,75 @@ def test_word_attention_backward(B, idf, r, T_, correct):
     close(hd.grad, hr.grad, atol=5e-5, rtol=1e-3)
     close(wd.grad, wr_.grad, atol=2e-4 * r, rtol=2e-3)
     close(wdd.grad, wdr.grad, atol=2e-4 * r, rtol=2e-3)
+
+
+def test_generators_train_mode_golden_and_gradients(nets_small):
+    """Whole x8 generators in train mode (batch-stat BN): forward vs the reference golden, every parameter gradient
+    of MSE + KL vs torch autograd over the oracle."""
+    from conftest import split_sd
+    from tgsr_amd import model
+    from tgsr_amd.miscc import losses
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    g = nets_small
+    cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 64
+    try:
+        T = lambda a, d=DEV: torch.from_numpy(np.asarray(a)).to(d)
+        sdL, sdH = split_sd(g, "GL."), {k: v for k, v in split_sd(g, "GH.").items() if k != "a"}   # `a`: model.py:246-248
+        gl, gh = model.G_SR_NET_low(), model.NetG_highweight(weightmap=False, low="lr")
+        gl.load_state_dict(sdL); gh.load_state_dict(sdH)
+        gl.to(DEV).train(); gh.to(DEV).train()
+        words, sent, mask = T(g["train.words_emb"]), T(g["train.sent_emb"]), T(g["train.mask"])
+        LR, LRb = T(g["LR"]), T(g["LRb"])
+        gen = torch.Generator().manual_seed(5)
+        hr = [torch.rand(3, 3, s, s, generator=gen) * 2 - 1 for s in (32, 64, 128)]
+        imgs, atts, mu, lv = gl(LR, sent, words, mask)
+        fine, a, one = gh(LR, imgs, LRb)
+        for i in range(3):
+            close(imgs[i], g["train.fake%d" % i], atol=2e-4)
+            close(fine[i], g["train.fine%d" % i], atol=2e-4)
+        loss = losses.MSE(imgs, [h.to(DEV) for h in hr]) + losses.MSE(fine, [h.to(DEV) for h in hr]) + losses.KL_loss(mu, lv)
+        loss.backward()
+        # oracle + torch autograd on CPU
+        pL = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sdL.items()}
+        pH = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sdH.items()}
+        ri, ra, rmu, rlv = O.g_sr_net_low(pL, T(g["LR"], "cpu"), T(g["train.sent_emb"], "cpu"), T(g["train.words_emb"], "cpu"),
+                                          T(g["train.mask"], "cpu"), training=True)
+        rf, _, _ = O.netg_highweight(pH, T(g["LR"], "cpu"), ri, T(g["LRb"], "cpu"), "lr", training=True)
+        rloss = O.mse(ri, hr) + O.mse(rf, hr) + O.kl_loss(rmu, rlv)
+        rloss.backward()
+        close(loss, rloss, atol=1e-4)
+        worst = 0.0
+        for net, ref in ((gl, pL), (gh, pH)):
+            for k, p in net.named_parameters():
+                r = ref[k].grad
+                assert p.grad is not None, k
+                denom = float(r.abs().max()) + 1e-6
+                err = float((p.grad.cpu() - r).abs().max()) / denom
+                worst = max(worst, err)
+                assert err < 5e-3, (k, err, denom)
+        print("worst relative parameter-gradient error", worst)
+    finally:
+        cfg_reset()
+
+
+def test_train_step_decreases_loss_and_updates_running_stats(nets_small):
+    from conftest import split_sd
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.train import SRTrainer
+    g = nets_small
+    cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 64
+    try:
+        tr = SRTrainer(41, device=DEV, lr=1e-3)
+        tr.text_encoder.load_state_dict(split_sd(g, "E."))
+        T = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
+        gen = torch.Generator().manual_seed(9)
+        hr = [(torch.rand(3, 3, s, s, generator=gen) * 2 - 1).to(DEV) for s in (32, 64, 128)]
+        rm0 = tr.netGH.convin[1].running_mean.clone()
+        ls = [float(tr.step(T(g["captions"]), g["cap_lens"].tolist(), T(g["LR"]), T(g["LRb"]), hr)) for _ in range(6)]
+        assert ls[-1] < ls[0], ls
+        assert not torch.equal(rm0, tr.netGH.convin[1].running_mean)
+        assert int(tr.netGH.convin[1].num_batches_tracked) == 6
+    finally:
+        cfg_reset()

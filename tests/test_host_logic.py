@@ -38,7 +38,7 @@ def test_modules_have_no_cpu_fallback(cfg32):
     rb = util.ResBlock(64).eval()
     with pytest.raises(TgsrError):
         rb(torch.zeros(1, 64, 8, 8))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TgsrError):                      # training path: same rule, no CPU fallback
         util.ResBlock(64).train()(torch.zeros(1, 64, 8, 8))
 
 

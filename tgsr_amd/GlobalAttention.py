@@ -30,6 +30,11 @@ class GlobalAttentionGeneral(nn.Module):
     def forward(self, input, context, out=None):
         """input [B, idf, ih, iw], context [B, cdf, sourceL] -> (weightedContext [B, idf, ih, iw],
         attn [B, sourceL, ih, iw])."""
+        if self.training:
+            from .autograd import WordAttention
+            if out is not None:
+                raise RuntimeError("training path does not write into channel-slice views")
+            return WordAttention.apply(input, context, self.conv_context.weight, self.mask, self.correct_mask)
         return ops.word_attention(input, context, self.conv_context.weight, self.mask, self.correct_mask, out=out)
 
 

@@ -91,3 +91,51 @@ def KL_loss(mu, logvar):
     """losses.py:806-810."""
     KLD_element = mu.pow(2).add(logvar.exp()).mul(-1).add(1).add(logvar)
     return torch.mean(KLD_element).mul(-0.5)
+
+
+def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels):
+    """losses.py:290-316.  The reference ships no discriminator class; any module exposing `COND_DNET` /
+    `UNCOND_DNET` like AttnGAN's D_NET* works (real / fake / wrong-caption terms, the wrong pair is the batch shifted
+    by one, :302)."""
+    real_features = netD(real_imgs)
+    fake_features = netD(fake_imgs.detach())
+    bce = nn.BCEWithLogitsLoss()
+    cond_real_errD = bce(netD.COND_DNET(real_features, conditions), real_labels)
+    cond_fake_errD = bce(netD.COND_DNET(fake_features, conditions), fake_labels)
+    batch_size = real_features.size(0)
+    cond_wrong_logits = netD.COND_DNET(real_features[:(batch_size - 1)], conditions[1:batch_size])
+    cond_wrong_errD = bce(cond_wrong_logits, fake_labels[1:batch_size])
+    if netD.UNCOND_DNET is not None:
+        real_errD = bce(netD.UNCOND_DNET(real_features), real_labels)
+        fake_errD = bce(netD.UNCOND_DNET(fake_features), fake_labels)
+        return (real_errD + cond_real_errD) / 2. + (fake_errD + cond_fake_errD + cond_wrong_errD) / 3.
+    return cond_real_errD + (cond_fake_errD + cond_wrong_errD) / 2.
+
+
+def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
+                   class_ids, w=1, s=1, g=1):
+    """losses.py:351-391: per-scale adversarial terms + the DAMSM words/sentence ranking loss on the last scale."""
+    numDs = len(netsD)
+    batch_size = real_labels.size(0)
+    logs = ''
+    errG_total = 0
+    bce = nn.BCEWithLogitsLoss()
+    for i in range(numDs):
+        features = netsD[i](fake_imgs[i])
+        cond_errG = bce(netsD[i].COND_DNET(features, sent_emb), real_labels)
+        if netsD[i].UNCOND_DNET is not None:
+            g_loss = bce(netsD[i].UNCOND_DNET(features), real_labels) + cond_errG
+        else:
+            g_loss = cond_errG
+        g_loss = g * g_loss
+        errG_total += g_loss
+        logs += 'g_loss%d: %.5f ' % (i, g_loss.item())
+        if i == (numDs - 1):
+            region_features, cnn_code = image_encoder(fake_imgs[i])
+            w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size)
+            w_loss = w * (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+            s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
+            s_loss = s * (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
+            errG_total += w_loss + s_loss
+            logs += 'w_loss: %.5f s_loss: %.5f ' % (w_loss.item(), s_loss.item())
+    return errG_total, logs

@@ -4,8 +4,9 @@ Same class / function names, constructor arguments, forward signatures, return t
 as the reference (util.py:45-130, 175-260, 372-400, 726-823, 894-919), so `Checkpoint/face_S8/*.pth` load
 unchanged.  The nn.Conv2d / nn.BatchNorm2d / nn.LSTM children are parameter holders that keep the key names;
 they are never called - every forward goes through `tgsr_amd.ops` (fused conv + BN + GLU / residual, up-sample
-folded into the conv, fused word attention, BiLSTM kernels).  Inference (eval-mode BN) only for now: a module
-in training mode raises instead of silently computing something else.
+folded into the conv, fused word attention, BiLSTM kernels).  `.eval()` modules take the fused inference kernels
+(BatchNorm folded to an affine, no autograd graph); `.train()` modules take the training path of
+`tgsr_amd.autograd` (batch-statistics BatchNorm, running-stat updates, HIP backward kernels).
 """
 import torch
 import torch.nn as nn
@@ -41,14 +42,15 @@ class _FusedParams:
         return self.wpack, self.scale, self.shift
 
 
-def _eval_only(m: nn.Module):
-    if m.training:
-        raise NotImplementedError("%s: train-mode BatchNorm (batch statistics) is not on the HIP path yet; call "
-                                  ".eval() (the reference's inference path, trainer_objective.py:98-99)"
-                                  % type(m).__name__)
-
-
-def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=None, out=None):
+def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=None, out=None, training=False):
+    """One fused block.  eval: conv + folded-BN affine + GLU/residual in one launch (optionally into `out`, a
+    channel-slice view).  training: batch-statistics BN through tgsr_amd.autograd (differentiable)."""
+    if training:
+        from .autograd import conv_bn_act_train
+        y = conv_bn_act_train(x, conv, bn, glu=glu, upsample=upsample, residual=residual)
+        if out is not None:
+            raise RuntimeError("training path does not write into channel-slice views")
+        return y
     wpack, scale, shift = fp.get(conv, bn)
     return ops.conv3x3_fused(x, wpack, conv.out_channels, scale, shift, glu=glu, upsample=upsample,
                              residual=residual, out=out)
@@ -89,8 +91,7 @@ class _UpBlock(nn.Sequential):
         self._fp = _FusedParams()
 
     def forward(self, x, out=None):
-        _eval_only(self)
-        return _conv_bn(x, self._fp, self[1], self[2], glu=True, upsample=True, out=out)
+        return _conv_bn(x, self._fp, self[1], self[2], glu=True, upsample=True, out=out, training=self.training)
 
 
 def upBlock(in_planes, out_planes):
@@ -106,8 +107,7 @@ class _ConvBnGlu(nn.Sequential):
         self._fp = _FusedParams()
 
     def forward(self, x, out=None):
-        _eval_only(self)
-        return _conv_bn(x, self._fp, self[0], self[1], glu=True, out=out)
+        return _conv_bn(x, self._fp, self[0], self[1], glu=True, out=out, training=self.training)
 
 
 def Block3x3_relu(in_planes, out_planes):
@@ -123,9 +123,8 @@ class _ResidualNoSum(nn.Sequential):
         self._fp0, self._fp1 = _FusedParams(), _FusedParams()
 
     def forward(self, x):
-        _eval_only(self)
-        y = _conv_bn(x, self._fp0, self[0], self[1], glu=True)
-        return _conv_bn(y, self._fp1, self[3], self[4])
+        y = _conv_bn(x, self._fp0, self[0], self[1], glu=True, training=self.training)
+        return _conv_bn(y, self._fp1, self[3], self[4], training=self.training)
 
 
 class ResBlock(nn.Module):
@@ -141,9 +140,8 @@ class ResBlock(nn.Module):
         self._fp0, self._fp1 = _FusedParams(), _FusedParams()
 
     def forward(self, x):
-        _eval_only(self)
-        y = _conv_bn(x, self._fp0, self.block[0], self.block[1], glu=True)
-        return _conv_bn(y, self._fp1, self.block[3], self.block[4], residual=x)
+        y = _conv_bn(x, self._fp0, self.block[0], self.block[1], glu=True, training=self.training)
+        return _conv_bn(y, self._fp1, self.block[3], self.block[4], residual=x, training=self.training)
 
 
 # ------------------------------------------------------------------------------------------ text encoder
@@ -301,7 +299,7 @@ def _make_res_layers(channel_num):
 def _up_into(upsample, x, ngf, wide_out):
     """Run the stage's upBlock; with wide_out the result is written as the first half of a fresh
     [B, 2ngf, 2H, 2W] buffer (tagged on the returned view) so the next stage's torch.cat is free."""
-    if not wide_out:
+    if not wide_out or upsample.training:
         return upsample(x)
     B, _, H, W = x.shape
     wide = torch.empty(B, 2 * ngf, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
@@ -330,6 +328,11 @@ class INIT_STAGE_GImgup(nn.Module):
         B, _, H, W = LR.shape
         ngf = self.gf_dim
         self.att.applyMask(mask)
+        if self.training:   # differentiable path: plain cat (autograd), like the reference (util.py:769-777)
+            h_code = self.im2f(LR)
+            c_code, att = self.att(h_code, word_embs)
+            out_code1 = self.residual(torch.cat((h_code, c_code), 1))
+            return self.upsample(out_code1), att
         hc = torch.empty(B, 2 * ngf, H, W, dtype=torch.float32, device=LR.device)
         h_code = self.im2f(LR, out=hc[:, :ngf])
         _, att = self.att(h_code, word_embs, out=hc[:, ngf:])
@@ -355,6 +358,10 @@ class NEXT_STAGE_G(nn.Module):
     def forward(self, h_code, c_code0, word_embs, mask, wide_out=False):
         B, ngf, H, W = h_code.shape
         self.att.applyMask(mask)
+        if self.training:   # util.py:814-823 through autograd
+            c_code, att = self.att(h_code, word_embs)
+            out_code = self.residual(torch.cat((h_code, c_code), 1))
+            return self.upsample(out_code), att
         wide = getattr(h_code, "_tgsr_wide", None)
         if wide is None:  # stand-alone use: build the concatenated buffer (one copy, = the reference's cat)
             wide = torch.empty(B, 2 * ngf, H, W, dtype=torch.float32, device=h_code.device)
@@ -374,6 +381,9 @@ class GET_IMAGE_G_noAct(nn.Module):
         self.img = nn.Sequential(conv3x3(ngf, 3))
 
     def forward(self, h_code):
+        if self.training:
+            from .autograd import ConvTo3
+            return ConvTo3.apply(h_code, self.img[0].weight, None, False, 0.0)
         return ops.conv_to3(h_code, self.img[0].weight)
 
 
@@ -386,4 +396,7 @@ class GET_IMAGE_G(nn.Module):
         self.img = nn.Sequential(conv3x3(ngf, 3), nn.Tanh())
 
     def forward(self, h_code):
+        if self.training:
+            from .autograd import ConvTo3
+            return ConvTo3.apply(h_code, self.img[0].weight, None, True, 0.0)
         return ops.conv_to3(h_code, self.img[0].weight, tanh_axpy=True, addend=None, alpha=0.0)
