@@ -86,6 +86,55 @@ def cpu_baseline(weights, batch, budget_s=20.0):
                       "runs, %.2f s/batch" % (batch, len(ts), med)}
 
 
+def bench_train(args, rank, world, dist, dev, weights):
+    """Generator training step: text-enc (frozen) + G_SR_NET_low + NetG_highweight forward in train-mode BN, MSE + KL
+    loss, HIP backward, one flat-bucket gradient all-reduce (N > 1), Adam, EMA.  Synthetic HR targets U(-1, 1)."""
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.train import SRTrainer
+    tr = SRTrainer(41, device=dev)
+    if weights is not None:
+        tr.text_encoder.load_state_dict(weights["E."])
+        tr.netGL.load_state_dict(weights["GL."])
+        tr.netGH.load_state_dict({k: v for k, v in weights["GH."].items() if k != "a"})
+    B = args.batch
+    cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
+    g = torch.Generator().manual_seed(7 + rank)
+    hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(dev) for s in (64, 128, 256)]
+    cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
+    for _ in range(args.warmup):
+        tr.step(cap, lens, LR, LRb, hr)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step(cap, lens, LR, LRb, hr)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "SR generator train images/sec (32->256, batch 16 per GPU, fwd+bwd+Adam)",
+            "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic inputs and HR targets",
+            "config": {"workload": "CelebA x8 generator train step (G_SR_NET_low + NetG_highweight, train-mode BN, MSE+KL, "
+                                   "Adam; no discriminator / DAMSM terms: not defined by the reference), batch=16 per GPU",
+                       "batch_per_gpu": B, "parallelism": "dp%d" % world, "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)},
+            "final_loss": round(float(loss), 5), "roofline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +142,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
+                    help="infer = the headline (BASELINE configs[1]); train = generator fwd+bwd+Adam step on MSE+KL "
+                         "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="bracket every launch of every Nth timed step with HIP events for the roofline (0 = never); "
                          "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
@@ -124,6 +176,8 @@ def main():
     cfg.TREE.BASE_SIZE = 32
 
     weights = load_weights()
+    if args.mode == "train":
+        return bench_train(args, rank, world, dist, dev, weights)
     pipe = SRPipeline(41, device=dev, low="lr")
     if weights is not None:
         pipe.load_state_dicts(weights["E."], weights["GL."], weights["GH."])

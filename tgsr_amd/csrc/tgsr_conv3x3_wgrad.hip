@@ -111,19 +111,29 @@ __global__ __launch_bounds__(64 * NCOB * NCIB) void conv3x3_wgrad_kernel(WgradAr
     }
 }
 
-// dw[co][ci][tap] = sum_slot partial[slot][tap][co][ci]  (fixed order)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int Cout, int Cin, int CinPad,
-                                    float* __restrict__ dw) {
+// dw[co][ci][tap] = sum_slot partial[slot][tap][co][ci]: block = 32 slab elements x 8 slot lanes, fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int Cout,
+                                                           int Cin, int CinPad, float* __restrict__ dw) {
+  __shared__ float red[8][32];
   const int64_t n = (int64_t)9 * Cout * CinPad;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int ci = (int)(i % CinPad);
-  const int64_t t = i / CinPad;
-  const int co = (int)(t % Cout), tap = (int)(t / Cout);
-  if (ci >= Cin) return;
+  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + o;
   float s = 0.f;
-  for (int k = 0; k < nslots; ++k) s += partial[(int64_t)k * n + i];
-  dw[((int64_t)co * Cin + ci) * 9 + tap] = s;
+  if (i < n)
+    for (int k = sg; k < nslots; k += 8) s += partial[(int64_t)k * n + i];
+  red[sg][o] = s;
+  __syncthreads();
+  if (sg == 0 && i < n) {
+    const int ci = (int)(i % CinPad);
+    const int64_t t = i / CinPad;
+    const int co = (int)(t % Cout), tap = (int)(t / Cout);
+    if (ci < Cin) {
+      float v = red[0][o];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) v += red[k][o];
+      dw[((int64_t)co * Cin + ci) * 9 + tap] = v;
+    }
+  }
 }
 
 template <int NCOB, int NCIB>
@@ -147,7 +157,9 @@ static void wgrad_plan(int B, int Cin, int Cout, int Ho, int Wo, int* ncob, int*
   *groups = (cb / *ncob) * *gi;
   *cinpad = ib * 32;
   *ntiles = B * ((Ho + 1) / 2) * ((Wo + 31) / 32);
-  int want = 768 / *groups;               // ~3 workgroups per CU over all channel groups
+  // one partial slab per workgroup: ~256 CUs x 8 waves of workgroups in flight keeps the chip full while the slabs
+  // (nslots x |dW|) stay ~75 MB for every layer shape
+  int want = 2048 / (*ncob * *ncib) / *groups;
   if (want < 1) want = 1;
   if (want > *ntiles) want = *ntiles;
   *tiles_per_wg = (*ntiles + want - 1) / want;
@@ -183,7 +195,7 @@ extern "C" int tgsr_conv3x3_wgrad(const float* grad_out, const float* x, int64_t
   else rc = launch_wgrad<1, 1>(a, nslots, groups, up, s);
   if (rc) return rc;
   const int64_t n = (int64_t)9 * Cout * cinpad;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, nslots, Cout, Cin,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, ws, nslots, Cout, Cin,
                      cinpad, dw);
   return note_launch(hipGetLastError(), "wgrad_reduce_kernel");
 }

@@ -48,8 +48,9 @@ __device__ __forceinline__ void stage_g(const To3BwdArgs& a, float* g_s, int b, 
 
 template <int K, bool TANH>
 __global__ __launch_bounds__(256) void conv_to3_dgrad_kernel(To3BwdArgs a) {
-  constexpr int P = K / 2, TR = 16 + 2 * P;
+  constexpr int P = K / 2, TR = 16 + 2 * P, MAXC = 64;
   __shared__ __attribute__((aligned(16))) float g_s[3 * TR * 72];
+  __shared__ float w_s[3 * MAXC * K * K];
   const int tid = threadIdx.x, txi = tid & 15, tyi = tid >> 4;
   int t = blockIdx.x;
   const int tx = t % a.tiles_x;
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void conv_to3_dgrad_kernel(To3BwdArgs a) {
   const int b = t / a.tiles_y;
   const int y0 = ty * 16, x0 = tx * 64;
   stage_g<K, TANH>(a, g_s, b, y0, x0, P);
+  for (int i = tid; i < 3 * a.Cin * K * K; i += 256) w_s[i] = a.w[i];
   __syncthreads();
   const int64_t HW = (int64_t)a.H * a.W;
   const int y = y0 + tyi, xx = x0 + 4 * txi;
@@ -67,20 +69,21 @@ __global__ __launch_bounds__(256) void conv_to3_dgrad_kernel(To3BwdArgs a) {
     for (int c = 0; c < 16; ++c)
 #pragma unroll
       for (int p = 0; p < 4; ++p) acc[c][p] = 0.f;
+#pragma unroll 1
+    for (int ck = 0; ck < 3 * K; ++ck) {     // not unrolled: keeps at most 16 x K weights live (no spills)
+      const int co = ck / K, ky = ck - co * K;
+      const float* row = g_s + (co * TR + tyi + (K - 1 - ky)) * 72 + 4 * txi;
+      const float4 v0 = *reinterpret_cast<const float4*>(row);
+      const float4 v1 = *reinterpret_cast<const float4*>(row + 4);
+      const float4 v2 = *reinterpret_cast<const float4*>(row + 8);
+      const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+      const float* wrow = w_s + ((co * a.Cin + c0) * K + ky) * K;   // + c*K*K + kx  (wave-uniform: LDS broadcast)
 #pragma unroll
-    for (int co = 0; co < 3; ++co) {
+      for (int c = 0; c < 16; ++c) {
+        if (c0 + c < a.Cin) {
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        const float* row = g_s + (co * TR + tyi + (K - 1 - ky)) * 72 + 4 * txi;
-        const float4 v0 = *reinterpret_cast<const float4*>(row);
-        const float4 v1 = *reinterpret_cast<const float4*>(row + 4);
-        const float4 v2 = *reinterpret_cast<const float4*>(row + 8);
-        const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            const float wv = (c0 + c < a.Cin) ? a.w[(((int64_t)co * a.Cin + c0 + c) * K + ky) * K + kx] : 0.f;
+          for (int kx = 0; kx < K; ++kx) {
+            const float wv = wrow[c * K * K + kx];
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc[c][p] = fmaf(wv, in[4 + p + P - kx], acc[c][p]);
           }
@@ -92,9 +95,13 @@ __global__ __launch_bounds__(256) void conv_to3_dgrad_kernel(To3BwdArgs a) {
       for (int c = 0; c < 16; ++c) {
         if (c0 + c < a.Cin) {
           float* o = a.dx + ((int64_t)b * a.Cin + c0 + c) * HW + (int64_t)y * a.W + xx;
+          if (xx + 3 < a.W && (a.W & 3) == 0) {
+            *reinterpret_cast<float4*>(o) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+          } else {
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            if (xx + p < a.W) o[p] = acc[c][p];
+            for (int p = 0; p < 4; ++p)
+              if (xx + p < a.W) o[p] = acc[c][p];
+          }
         }
       }
     }
@@ -186,12 +193,23 @@ __global__ __launch_bounds__(256) void conv_to3_wgrad_kernel(To3BwdArgs a) {
   }
 }
 
-__global__ void to3_wgrad_reduce_kernel(const float* __restrict__ part, int nslots, int n, float* __restrict__ dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] = sum_slot part[slot][i]: block = 32 outputs x 8 slot lanes, combined in a fixed order (reproducible)
+__global__ __launch_bounds__(256) void to3_wgrad_reduce_kernel(const float* __restrict__ part, int nslots, int n,
+                                                               float* __restrict__ dw) {
+  __shared__ float red[8][32];
+  const int o = threadIdx.x & 31, sg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
   float s = 0.f;
-  for (int k = 0; k < nslots; ++k) s += part[(int64_t)k * n + i];
-  dw[i] = s;
+  if (i < n)
+    for (int k = sg; k < nslots; k += 8) s += part[(int64_t)k * n + i];
+  red[sg][o] = s;
+  __syncthreads();
+  if (sg == 0 && i < n) {
+    float v = red[0][o];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += red[k][o];
+    dw[i] = v;
+  }
 }
 
 template <int K, bool TANH>
@@ -203,7 +221,7 @@ static int launch_to3_bwd(To3BwdArgs a, float* dw, hipStream_t s) {
   if (dw) {
     hipLaunchKernelGGL((conv_to3_wgrad_kernel<K, TANH>), dim3(nwg), dim3(256), 0, s, a);
     const int n = 3 * a.Cin * K * K;
-    hipLaunchKernelGGL(to3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.part, nwg, n, dw);
+    hipLaunchKernelGGL(to3_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, s, a.part, nwg, n, dw);
   }
   return note_launch(hipGetLastError(), "conv_to3_bwd");
 }
@@ -220,7 +238,7 @@ extern "C" int tgsr_conv_to3_bwd(const float* dy, const float* out, const float*
                                  int64_t x_bstride, const float* w, int B, int Cin, int H, int W, int K, int act,
                                  float* dx, float* ws, float* dw, void* stream) {
   if (!dy || B < 1 || Cin < 1 || H < 1 || W < 1) return TGSR_EINVAL;
-  if (K != 3 && K != 5) return TGSR_EUNSUPPORTED;
+  if ((K != 3 && K != 5) || Cin > 64) return TGSR_EUNSUPPORTED;
   if (act == TGSR_ACT_TANH_AXPY && !out) return TGSR_EINVAL;
   if (dx && !w) return TGSR_EINVAL;
   if (dw && (!x || !ws)) return TGSR_EINVAL;
