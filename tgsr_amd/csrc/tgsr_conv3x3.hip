@@ -56,11 +56,11 @@ __device__ unsigned long long g_stamps[8 * 8192];
 #define TGSR_STAMP(k)
 #endif
 
-template <int NOB, bool GLU, bool UP, int R>
+template <int NOB, bool GLU, bool UP, int R, int WV>
 struct ConvCfg {
   static constexpr int NCB = NOB * (GLU ? 2 : 1);  // accumulator blocks of 32 couts per row
   static constexpr int NCOL = NCB * 32;            // weight columns held in LDS
-  static constexpr int TH = 4 * R;                 // output rows per workgroup (4 waves)
+  static constexpr int TH = WV * R;                // output rows per workgroup (WV waves, R rows each)
   static constexpr int TR = UP ? TH / 2 + 2 : TH + 2;  // staged input rows (with halo)
   static constexpr int TC = UP ? 18 : 34;              // staged input cols (with halo)
   static constexpr int PITCH = TC;
@@ -78,11 +78,11 @@ struct ConvCfg {
 // written by LDS-DMA (global_load_lds): no VGPR round trip, the copy of stage c+1 flies under the MFMAs of stage c.
 // The per-lane source offsets do not depend on the stage, so they are computed once (StagePlan) and a DMA piece
 // costs ~8 instructions; the pieces are issued one per k-step INSIDE the MFMA stream, where VALU issue is free.
-template <int NOB, bool GLU, bool UP, int R>
+template <int NOB, bool GLU, bool UP, int R, int WV>
 struct StagePlan {
-  using C = ConvCfg<NOB, GLU, UP, R>;
-  static constexpr int WK = (C::W_UNITS + 3) / 4;   // weight pieces per wave per stage (64 lanes x 16 B each)
-  static constexpr int IK = (C::IN_UNITS + 3) / 4;  // input pieces per wave per stage (64 lanes x 4 B each)
+  using C = ConvCfg<NOB, GLU, UP, R, WV>;
+  static constexpr int WK = (C::W_UNITS + WV - 1) / WV;   // weight pieces per wave per stage (64 lanes x 16 B each)
+  static constexpr int IK = (C::IN_UNITS + WV - 1) / WV;  // input pieces per wave per stage (64 lanes x 4 B each)
   int woff[WK];   // float offset inside the packed-weight stage block, -1 = padding lane
   int ioff[IK];   // (channel-in-stage << 28) | (gy * W + gx), -1 = outside the image / padding lane
 
@@ -90,7 +90,7 @@ struct StagePlan {
     constexpr int NCOL = C::NCOL, TR = C::TR, TC = C::TC;
 #pragma unroll
     for (int k = 0; k < WK; ++k) {
-      const int q = (wave + 4 * k) * 64 + lane;  // float4 index inside the stage's weight block
+      const int q = (wave + WV * k) * 64 + lane;  // float4 index inside the stage's weight block
       const int row = q / (NCOL / 4);
       const int c4 = q - row * (NCOL / 4);
       const int seg = c4 >> 3, f4 = c4 & 7;
@@ -103,7 +103,7 @@ struct StagePlan {
     }
 #pragma unroll
     for (int k = 0; k < IK; ++k) {
-      const int idx = (wave + 4 * k) * 64 + lane;
+      const int idx = (wave + WV * k) * 64 + lane;
       const int c = idx / (TR * TC);
       const int rem = idx - c * (TR * TC);
       const int r = rem / TC, cc = rem - r * TC;
@@ -117,16 +117,16 @@ struct StagePlan {
   __device__ __forceinline__ void issue(int p, const ConvArgs& a, float* buf, int ch, int wave, const float* xb,
                                         uint32_t HW) const {
     if (p < WK) {
-      const int u = wave + 4 * p;
-      if (4 * p + 3 < C::W_UNITS || u < C::W_UNITS) {
+      const int u = wave + WV * p;
+      if (WV * p + WV - 1 < C::W_UNITS || u < C::W_UNITS) {
         const float* wsrc = a.wpack + (int64_t)ch * 9 * kConvCK * a.Cout;
         const float* g = woff[p] >= 0 ? wsrc + woff[p] : g_conv_zero;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(buf + u * 256), 16, 0, 0);
       }
     } else {
       const int k = p - WK;
-      const int u = wave + 4 * k;
-      if (4 * k + 3 < C::IN_UNITS || u < C::IN_UNITS) {
+      const int u = wave + WV * k;
+      if (WV * k + WV - 1 < C::IN_UNITS || u < C::IN_UNITS) {
         const int v = ioff[k];
         const int c = ch * kConvCK + (v >> 28);
         const bool ok = v >= 0 && c < a.Cin;
@@ -137,10 +137,10 @@ struct StagePlan {
   }
 };
 
-template <int NOB, bool GLU, bool UP, int R>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
-  using C = ConvCfg<NOB, GLU, UP, R>;
-  using Plan = StagePlan<NOB, GLU, UP, R>;
+template <int NOB, bool GLU, bool UP, int R, int WV>
+__global__ __launch_bounds__(64 * WV, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+  using C = ConvCfg<NOB, GLU, UP, R, WV>;
+  using Plan = StagePlan<NOB, GLU, UP, R, WV>;
   constexpr int NCB = C::NCB, NCOL = C::NCOL, TH = C::TH, PITCH = C::PITCH, PLANE = C::PLANE;
   constexpr int NS = 9 * (kConvCK / 2);  // k-steps (tap, channel pair) per stage
   constexpr int NP = Plan::WK + Plan::IK;  // DMA pieces per wave per stage
@@ -191,15 +191,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 
   // per-column affine (BN eval) of this workgroup's channels -> LDS, so the epilogue issues no global loads
   float* aff_s = smem + 2 * C::BUF;
-  if (tid < NCOL) {
-    const int seg = tid >> 5, i = tid & 31;
+  for (int cidx = tid; cidx < NCOL; cidx += 64 * WV) {
+    const int seg = cidx >> 5, i = cidx & 31;
     int col;
     if (GLU)
       col = (seg < NOB ? (grp * NOB + seg) * 32 : (a.Cout >> 1) + (grp * NOB + seg - NOB) * 32) + i;
     else
       col = (grp * NOB + seg) * 32 + i;
-    aff_s[tid] = a.scale ? a.scale[col] : 1.f;
-    aff_s[NCOL + tid] = a.scale ? a.shift[col] : 0.f;
+    aff_s[cidx] = a.scale ? a.scale[col] : 1.f;
+    aff_s[NCOL + cidx] = a.scale ? a.shift[col] : 0.f;
   }
   __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the stage to every wave
   TGSR_STAMP(1);
@@ -303,25 +303,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   TGSR_STAMP(3);
 }
 
-template <int NOB, bool GLU, bool UP, int R>
+template <int NOB, bool GLU, bool UP, int R, int WV>
 static int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
-  using C = ConvCfg<NOB, GLU, UP, R>;
+  using C = ConvCfg<NOB, GLU, UP, R, WV>;
   ConvArgs k = a;
   k.tiles_x = (a.Wo + 31) / 32;
   k.tiles_y = (a.Ho + C::TH - 1) / C::TH;
   dim3 grid((unsigned)(a.B * k.tiles_x * k.tiles_y), (unsigned)groups);
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<NOB, GLU, UP, R>), grid, dim3(256), 0, s, k);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<NOB, GLU, UP, R, WV>), grid, dim3(64 * WV), 0, s, k);
   return note_launch(hipGetLastError(), "conv3x3_mfma_kernel");
 }
 
-template <int NOB, bool GLU>
-static int dispatch_up_r(const ConvArgs& a, int groups, bool up, int R, hipStream_t s) {
+// rows per workgroup = WV * R: (4,4) 16 rows, (4,2) 8, (4,1) 4
+template <int NOB, bool GLU, bool UP>
+static int dispatch_r(const ConvArgs& a, int groups, int rows, hipStream_t s) {
   constexpr int NCB = NOB * (GLU ? 2 : 1);
   if constexpr (NCB <= 2) {
-    if (R == 4) return up ? launch_conv<NOB, GLU, true, 4>(a, groups, s) : launch_conv<NOB, GLU, false, 4>(a, groups, s);
+    if (rows == 16) return launch_conv<NOB, GLU, UP, 4, 4>(a, groups, s);
   }
-  if (up) return R >= 2 ? launch_conv<NOB, GLU, true, 2>(a, groups, s) : launch_conv<NOB, GLU, true, 1>(a, groups, s);
-  return R >= 2 ? launch_conv<NOB, GLU, false, 2>(a, groups, s) : launch_conv<NOB, GLU, false, 1>(a, groups, s);
+  if (rows >= 8) return launch_conv<NOB, GLU, UP, 2, 4>(a, groups, s);
+  return launch_conv<NOB, GLU, UP, 1, 4>(a, groups, s);
+}
+
+template <int NOB, bool GLU>
+static int dispatch_up_r(const ConvArgs& a, int groups, bool up, int rows, hipStream_t s) {
+  return up ? dispatch_r<NOB, GLU, true>(a, groups, rows, s) : dispatch_r<NOB, GLU, false>(a, groups, rows, s);
 }
 
 }  // namespace tgsr
@@ -346,21 +352,35 @@ extern "C" int tgsr_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Ci
   a.Ho = upsample ? 2 * H : H; a.Wo = upsample ? 2 * W : W;
   a.nchunks = (Cin + kConvCK - 1) / kConvCK;
   a.tiles_x = a.tiles_y = 0;
-  // channel blocks per workgroup: 2 output blocks when the channel count allows it (more operand reuse)
+  // Tile choice.  Candidates from most operand reuse (2 output blocks per workgroup, 8 accumulators per wave) to
+  // least (1 block, 4 rows); take the first that gives >= 2 workgroups per CU, else the first
+  // with >= 1 per CU, else the smallest tile: at B = 16 an idle CU costs more than the lost reuse.  (2-wave
+  // workgroups of 2 rows were measured: same MFMA chain per wave, no gain - the WV parameter stays for a K-split.)
   const int unit = glu ? 64 : 32;          // couts consumed per output block
-  const int nob = (Cout % (2 * unit) == 0) ? 2 : 1;
+  const int nob_max = (Cout % (2 * unit) == 0) ? 2 : 1;
+  struct Cand { int nob, rows; };
+  Cand cands[8];
+  int nc = 0;
+  for (int nb = nob_max; nb >= 1; --nb) {
+    const int ncb = nb * (glu ? 2 : 1);
+    if (ncb <= 2) cands[nc++] = {nb, 16};
+    cands[nc++] = {nb, 8};
+    cands[nc++] = {nb, 4};
+  }
+  auto ntiles = [&](const Cand& c) {
+    return (int64_t)B * ((a.Ho + c.rows - 1) / c.rows) * ((a.Wo + 31) / 32) * (Cout / (unit * c.nob));
+  };
+  int pick = nc - 1;
+  for (int pass = 0; pass < 2 && pick == nc - 1; ++pass)
+    for (int i = 0; i < nc; ++i)
+      if (ntiles(cands[i]) >= (pass == 0 ? 512 : 256)) { pick = i; break; }
+  const int nob = cands[pick].nob, rows = cands[pick].rows;
   const int groups = Cout / (unit * nob);
-  // rows per wave (tile = 4R x 32 pixels): as many as keep 8 accumulators per wave AND >= 2 workgroups per CU
-  const int ncb = nob * (glu ? 2 : 1);
-  auto tiles = [&](int r) { return (int64_t)B * ((a.Ho + 4 * r - 1) / (4 * r)) * ((a.Wo + 31) / 32) * groups; };
-  int R = 1;
-  if (ncb <= 2 && tiles(4) >= 512) R = 4;
-  else if (tiles(2) >= 512) R = 2;
   hipStream_t s = as_stream(stream);
-  if (glu) return nob == 2 ? dispatch_up_r<2, true>(a, groups, upsample != 0, R, s)
-                           : dispatch_up_r<1, true>(a, groups, upsample != 0, R, s);
-  return nob == 2 ? dispatch_up_r<2, false>(a, groups, upsample != 0, R, s)
-                  : dispatch_up_r<1, false>(a, groups, upsample != 0, R, s);
+  if (glu) return nob == 2 ? dispatch_up_r<2, true>(a, groups, upsample != 0, rows, s)
+                           : dispatch_up_r<1, true>(a, groups, upsample != 0, rows, s);
+  return nob == 2 ? dispatch_up_r<2, false>(a, groups, upsample != 0, rows, s)
+                  : dispatch_up_r<1, false>(a, groups, upsample != 0, rows, s);
 }
 
 #ifdef TGSR_CONV_STAMPS
