@@ -116,6 +116,18 @@ int tgsr_bilstm_fwd(const int64_t* captions, int width, const int32_t* cap_lens,
                     const float* b_hh, int H, float* gates_ws, float* words_emb, float* sent_emb, void* stream);
 
 /*
+ * Eval-mode form of the same encoder: with frozen weights the input projection depends on the token only, so
+ * tgsr_lstm_gate_table builds table[ntoken][2][4H] = emb[tok] . w_ih[d]^T + b_ih[d] + b_hh[d] once per weight version
+ * (the same GEMM kernel, same arithmetic per row) and tgsr_bilstm_table_fwd runs the recurrence reading its gate
+ * pre-activations through the caption: one launch per batch instead of two, bit-identical to tgsr_bilstm_fwd.
+ */
+int tgsr_lstm_gate_table(const float* emb, int ntoken, int ninput, const float* w_ih, const float* b_ih,
+                         const float* b_hh, int H, float* table, void* stream);
+int tgsr_bilstm_table_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax,
+                          const float* table, int ntoken, const float* w_hh, int H, float* words_emb, float* sent_emb,
+                          void* stream);
+
+/*
  * DAMSM word/region attention for the whole (image, caption) grid in one launch: func_attention
  * (GlobalAttention.py:33-74) as driven by words_loss (losses.py:73-113) - the B-iteration Python loop, word.repeat,
  * both softmaxes, the two bmm and the cosine / exp / sum / log tail.

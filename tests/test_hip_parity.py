@@ -171,6 +171,12 @@ def test_bilstm_golden(ops_small):
                              st("rnn.bias_hh_l0", "rnn.bias_hh_l0_reverse"))
     close(words, g["enc.words_emb"], atol=1e-5)
     close(sent, g["enc.sent_emb"], atol=1e-5)
+    # eval-mode per-token gate table: bit-identical to the per-position projection
+    table = ops.lstm_gate_table(sd["encoder.weight"], st("rnn.weight_ih_l0", "rnn.weight_ih_l0_reverse"),
+                                st("rnn.bias_ih_l0", "rnn.bias_ih_l0_reverse"), st("rnn.bias_hh_l0", "rnn.bias_hh_l0_reverse"))
+    w2, s2 = ops.bilstm_table(T(g["enc.captions"]), g["enc.cap_lens"].tolist(), table,
+                              st("rnn.weight_hh_l0", "rnn.weight_hh_l0_reverse"))
+    assert torch.equal(w2, words) and torch.equal(s2, sent)
 
 
 def test_func_attention_golden(ops_small):

@@ -4,7 +4,8 @@
 // (conv5x5 ngf->3 + Tanh, model.py:224) fused with `one * . + a * SRb` (model.py:280/288/297).
 // Cout = 3 does not fill an MFMA tile (a 32-row tile would waste 90 % of it), and at 256x256 the op reads
 // 8.4 MB and writes 0.8 MB per image against 0.1-0.3 GFLOP: it is a streaming kernel, so it runs on the VALU:
-//   * workgroup = 16 x 64 output pixels, thread = 4 consecutive pixels x 3 channels (12 accumulators);
+//   * workgroup = TH x 64 output pixels (TH = 16, or 8 / 4 on small images so that every CU gets work),
+//     thread = 4 consecutive pixels x 3 channels (12 accumulators);
 //   * the input is staged in LDS 4 channels at a time with its halo, double buffered, by LDS-DMA
 //     (global_load_lds, 16 B per lane: the tile starts 4 columns left of the output tile so every piece is an
 //     aligned float4; out-of-image pieces read a zero block) - the copy of stage c+1 runs under the FMAs of stage c;
@@ -37,21 +38,21 @@ __device__ __forceinline__ float fast_tanh(float v) {
   return 1.f - 2.f / (e + 1.f);
 }
 
-template <int K, int ACT, bool VEC4>
-__global__ __launch_bounds__(256) void conv_to3_kernel(To3Args a) {
-  constexpr int P = K / 2, CK = 4, TH = 16, TW = 64;
+template <int K, int ACT, bool VEC4, int TH>   // TH output rows x 64 columns per workgroup, 16 * TH threads
+__global__ __launch_bounds__(16 * TH) void conv_to3_kernel(To3Args a) {
+  constexpr int P = K / 2, CK = 4, TW = 64, NT = 16 * TH, NW = NT / 64;
   constexpr int TR = TH + K - 1;
   constexpr int PITCH = 72;  // LDS column j = input column x0 - 4 + j; 72 = 64 + 4 left + 4 right
   constexpr int STAGE = CK * TR * PITCH;               // floats per stage (multiple of 4)
   constexpr int PIECE = VEC4 ? 256 : 64;               // floats per wave DMA instruction
   constexpr int UNITS = (STAGE + PIECE - 1) / PIECE;
   constexpr int BUF = UNITS * PIECE;
-  constexpr int UK = (UNITS + 3) / 4;                  // pieces per wave per stage
+  constexpr int UK = (UNITS + NW - 1) / NW;            // pieces per wave per stage
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int txi = tid & 15, tyi = tid >> 4;  // 16 x 16 threads, 4 pixels wide each
+  const int txi = tid & 15, tyi = tid >> 4;  // TH x 16 threads, 4 pixels wide each
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(To3Args a) {
   int off[UK];
 #pragma unroll
   for (int k = 0; k < UK; ++k) {
-    const int e = ((wave + 4 * k) * 64 + lane) * (VEC4 ? 4 : 1);   // first float of this lane's piece
+    const int e = ((wave + NW * k) * 64 + lane) * (VEC4 ? 4 : 1);   // first float of this lane's piece
     const int c = e / (TR * PITCH);
     const int rem = e - c * (TR * PITCH);
     const int r = rem / PITCH, j = rem - r * PITCH;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(To3Args a) {
     off[k] = ok ? ((c << 28) | (gy * a.W + gx)) : -1;
   }
   auto issue = [&](int k, float* buf, int c0) {
-    const int u = wave + 4 * k;
+    const int u = wave + NW * k;
     if (u < UNITS) {
       const int v = off[k];
       const int c = c0 + (v >> 28);
@@ -165,19 +166,28 @@ __global__ __launch_bounds__(256) void conv_to3_kernel(To3Args a) {
   }
 }
 
-template <int K, int ACT>
-static int launch_to3(To3Args a, hipStream_t s) {
+template <int K, int ACT, int TH>
+static int launch_to3_th(To3Args a, hipStream_t s) {
   a.tiles_x = (a.W + 63) / 64;
-  a.tiles_y = (a.H + 15) / 16;
+  a.tiles_y = (a.H + TH - 1) / TH;
   const dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y));
   const bool vec4 = (a.W % 4 == 0) && (a.xbs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
                     (!a.addend || (reinterpret_cast<uintptr_t>(a.addend) & 15) == 0);
   if (vec4)
-    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, true, TH>), grid, dim3(16 * TH), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, false, TH>), grid, dim3(16 * TH), 0, s, a);
   return note_launch(hipGetLastError(), "conv_to3_kernel");
+}
+
+template <int K, int ACT>
+static int launch_to3(To3Args a, hipStream_t s) {
+  // 16-row tiles when they still give >= 2 workgroups per CU; smaller images take 8- or 4-row tiles (more workgroups)
+  auto tiles = [&](int th) { return (int64_t)a.B * ((a.W + 63) / 64) * ((a.H + th - 1) / th); };
+  if (tiles(16) >= 512) return launch_to3_th<K, ACT, 16>(a, s);
+  if (tiles(8) >= 512) return launch_to3_th<K, ACT, 8>(a, s);
+  return launch_to3_th<K, ACT, 4>(a, s);
 }
 
 }  // namespace tgsr

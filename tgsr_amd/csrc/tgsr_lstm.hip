@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void lstm_input_gates_kernel(const int64_t* __
     const int m = m0 + tid;
     int tok = 0;
     if (m < M) {
-      const int64_t v = captions[(int64_t)(m / Tmax) * width + (m % Tmax)];
+      const int64_t v = captions ? captions[(int64_t)(m / Tmax) * width + (m % Tmax)] : (int64_t)m;
       tok = (v < 0 || v >= ntoken) ? 0 : (int)v;
     }
     tok_s[tid] = tok;
@@ -70,12 +70,16 @@ __global__ __launch_bounds__(256) void lstm_input_gates_kernel(const int64_t* __
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // grid (B, 2); block 4H threads.  gates [B][Tmax][2][4H]; w_hh [2][4H][H].
+// gates: [B][Tmax][2][4H] per position, or (captions != nullptr) a per-TOKEN table [ntoken][2][4H] indexed through
+// the caption - the eval-mode form: the input projection of a frozen encoder is a function of the token only.
 template <int H>
 __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __restrict__ gates,
                                                                const int32_t* __restrict__ cap_lens, int Tmax,
                                                                const float* __restrict__ w_hh,
                                                                float* __restrict__ words_emb,
-                                                               float* __restrict__ sent_emb) {
+                                                               float* __restrict__ sent_emb,
+                                                               const int64_t* __restrict__ captions, int width,
+                                                               int ntoken) {
   __shared__ __attribute__((aligned(16))) float h_s[H];
   __shared__ float g_s[4 * H];
   const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
@@ -98,7 +102,12 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
   __syncthreads();
   for (int s = 0; s < len; ++s) {
     const int t = d == 0 ? s : len - 1 - s;
-    float g = gates[(((int64_t)b * Tmax + t) * 2 + d) * 4 * H + j];
+    int64_t row = (int64_t)b * Tmax + t;
+    if (captions) {
+      const int64_t v = captions[(int64_t)b * width + t];
+      row = (v < 0 || v >= ntoken) ? 0 : v;
+    }
+    float g = gates[(row * 2 + d) * 4 * H + j];
 #pragma unroll
     for (int k = 0; k < H / 4; ++k) {
       const float4 hv = *reinterpret_cast<const float4*>(h_s + 4 * k);
@@ -126,7 +135,8 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
 // does not cover.
 __global__ void lstm_recurrent_generic_kernel(const float* __restrict__ gates, const int32_t* __restrict__ cap_lens,
                                               int Tmax, int H, const float* __restrict__ w_hh,
-                                              float* __restrict__ words_emb, float* __restrict__ sent_emb) {
+                                              float* __restrict__ words_emb, float* __restrict__ sent_emb,
+                                              const int64_t* __restrict__ captions, int width, int ntoken) {
   __shared__ float h_s[256];
   __shared__ float g_s[1024];
   const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
@@ -141,7 +151,12 @@ __global__ void lstm_recurrent_generic_kernel(const float* __restrict__ gates, c
   __syncthreads();
   for (int s = 0; s < len; ++s) {
     const int t = d == 0 ? s : len - 1 - s;
-    float g = gates[(((int64_t)b * Tmax + t) * 2 + d) * 4 * H + j];
+    int64_t row = (int64_t)b * Tmax + t;
+    if (captions) {
+      const int64_t v = captions[(int64_t)b * width + t];
+      row = (v < 0 || v >= ntoken) ? 0 : v;
+    }
+    float g = gates[(row * 2 + d) * 4 * H + j];
     for (int k = 0; k < H; ++k) g = fmaf(wr[k], h_s[k], g);
     g_s[j] = g;
     __syncthreads();
@@ -162,6 +177,25 @@ __global__ void lstm_recurrent_generic_kernel(const float* __restrict__ gates, c
 
 using namespace tgsr;
 
+static int launch_recurrent(const float* gates, const int32_t* cap_lens, int B, int Tmax, const float* w_hh, int H,
+                            float* words_emb, float* sent_emb, const int64_t* captions, int width, int ntoken,
+                            hipStream_t s) {
+  dim3 grid(B, 2);
+  if (H == 128)
+    hipLaunchKernelGGL(lstm_recurrent_kernel<128>, grid, dim3(512), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
+                       sent_emb, captions, width, ntoken);
+  else if (H == 64)
+    hipLaunchKernelGGL(lstm_recurrent_kernel<64>, grid, dim3(256), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
+                       sent_emb, captions, width, ntoken);
+  else if (H == 32)
+    hipLaunchKernelGGL(lstm_recurrent_kernel<32>, grid, dim3(128), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
+                       sent_emb, captions, width, ntoken);
+  else
+    hipLaunchKernelGGL(lstm_recurrent_generic_kernel, grid, dim3(4 * H), 0, s, gates, cap_lens, Tmax, H, w_hh,
+                       words_emb, sent_emb, captions, width, ntoken);
+  return note_launch(hipGetLastError(), "lstm_recurrent_kernel");
+}
+
 extern "C" int tgsr_bilstm_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax,
                                const float* emb, int ntoken, int ninput, const float* w_ih, const float* w_hh,
                                const float* b_ih, const float* b_hh, int H, float* gates_ws, float* words_emb,
@@ -176,18 +210,25 @@ extern "C" int tgsr_bilstm_fwd(const int64_t* captions, int width, const int32_t
                      Tmax, emb, ntoken, w_ih, b_ih, b_hh, M, N, ninput, gates_ws);
   int rc = note_launch(hipGetLastError(), "lstm_input_gates_kernel");
   if (rc) return rc;
-  dim3 grid(B, 2);
-  if (H == 128)
-    hipLaunchKernelGGL(lstm_recurrent_kernel<128>, grid, dim3(512), 0, s, gates_ws, cap_lens, Tmax, w_hh, words_emb,
-                       sent_emb);
-  else if (H == 64)
-    hipLaunchKernelGGL(lstm_recurrent_kernel<64>, grid, dim3(256), 0, s, gates_ws, cap_lens, Tmax, w_hh, words_emb,
-                       sent_emb);
-  else if (H == 32)
-    hipLaunchKernelGGL(lstm_recurrent_kernel<32>, grid, dim3(128), 0, s, gates_ws, cap_lens, Tmax, w_hh, words_emb,
-                       sent_emb);
-  else
-    hipLaunchKernelGGL(lstm_recurrent_generic_kernel, grid, dim3(4 * H), 0, s, gates_ws, cap_lens, Tmax, H, w_hh,
-                       words_emb, sent_emb);
-  return note_launch(hipGetLastError(), "lstm_recurrent_kernel");
+  return launch_recurrent(gates_ws, cap_lens, B, Tmax, w_hh, H, words_emb, sent_emb, nullptr, 0, 0, s);
+}
+
+extern "C" int tgsr_lstm_gate_table(const float* emb, int ntoken, int ninput, const float* w_ih, const float* b_ih,
+                                    const float* b_hh, int H, float* table, void* stream) {
+  if (!emb || !w_ih || !b_ih || !b_hh || !table || ntoken < 1 || ninput < 1 || H < 1) return TGSR_EINVAL;
+  const int N = 8 * H;
+  hipLaunchKernelGGL(lstm_input_gates_kernel, dim3((N + 127) / 128, (ntoken + 31) / 32), dim3(256), 0,
+                     as_stream(stream), (const int64_t*)nullptr, 1, 1, emb, ntoken, w_ih, b_ih, b_hh, ntoken, N, ninput,
+                     table);
+  return note_launch(hipGetLastError(), "lstm_input_gates_kernel(table)");
+}
+
+extern "C" int tgsr_bilstm_table_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax,
+                                     const float* table, int ntoken, const float* w_hh, int H, float* words_emb,
+                                     float* sent_emb, void* stream) {
+  if (!captions || !cap_lens || !table || !w_hh || !words_emb || !sent_emb) return TGSR_EINVAL;
+  if (B < 1 || Tmax < 1 || Tmax > width || ntoken < 1 || H < 1) return TGSR_EINVAL;
+  if (H > 256 || (4 * H) % 64 != 0) return TGSR_EUNSUPPORTED;
+  return launch_recurrent(table, cap_lens, B, Tmax, w_hh, H, words_emb, sent_emb, captions, width, ntoken,
+                          as_stream(stream));
 }

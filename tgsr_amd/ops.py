@@ -225,6 +225,35 @@ def bilstm(captions: torch.Tensor, cap_lens, emb: torch.Tensor, w_ih: torch.Tens
     return words, sent
 
 
+def lstm_gate_table(emb, w_ih, b_ih, b_hh):
+    """[ntoken, 2, 4H] gate pre-activations of every token (eval mode, frozen weights); see tgsr_lstm_gate_table."""
+    _need_hip(emb, w_ih, b_ih, b_hh)
+    ts = [_f32(t.detach(), "lstm tensor").contiguous() for t in (emb, w_ih, b_ih, b_hh)]
+    H = w_ih.shape[1] // 4
+    table = torch.empty(emb.shape[0], 2, 4 * H, dtype=torch.float32, device=emb.device)
+    check(_lib.lib().tgsr_lstm_gate_table(_p(ts[0]), emb.shape[0], emb.shape[1], _p(ts[1]), _p(ts[2]), _p(ts[3]), H,
+                                          _p(table), _stream()), "tgsr_lstm_gate_table")
+    return table
+
+
+def bilstm_table(captions, cap_lens, table, w_hh):
+    """The BiLSTM recurrence over a per-token gate table (one launch).  Returns (words_emb, sent_emb)."""
+    _need_hip(captions, table, w_hh)
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    B, width = captions.shape
+    if len(lens) != B or min(lens) < 1 or max(lens) > width:
+        raise TgsrError("bilstm: cap_lens %s invalid for captions %s" % (lens, tuple(captions.shape)))
+    Tmax, H, dev = max(lens), w_hh.shape[2], table.device
+    captions = captions.to(torch.int64).contiguous()
+    words = torch.empty(B, 2 * H, Tmax, dtype=torch.float32, device=dev)
+    sent = torch.empty(B, 2 * H, dtype=torch.float32, device=dev)
+    w = _f32(w_hh.detach(), "w_hh").contiguous()
+    rc = _lib.lib().tgsr_bilstm_table_fwd(_p(captions), width, _p(_lens_on_device(tuple(lens), dev)), B, Tmax, _p(table),
+                                          table.shape[0], _p(w), H, _p(words), _p(sent), _stream())
+    check(rc, "tgsr_bilstm_table_fwd")
+    return words, sent
+
+
 # ----------------------------------------------------------------------------------------- DAMSM
 def damsm_words_similarity(img_features: torch.Tensor, words_emb: torch.Tensor, cap_lens, gamma1: float,
                            gamma2: float, need_att: bool = True):

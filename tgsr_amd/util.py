@@ -168,6 +168,8 @@ class RNN_ENCODER(nn.Module):
         self.init_weights()
         self._key = None
         self._stacked = None
+        self._table_key = None
+        self._table = None
 
     def init_weights(self):
         self.encoder.weight.data.uniform_(-0.1, 0.1)  # util.py:214-216
@@ -193,8 +195,17 @@ class RNN_ENCODER(nn.Module):
         """captions int64 [B, n_steps] sorted by length (desc), cap_lens [B] -> (words_emb [B, 2H, T_max],
         sent_emb [B, 2H]).  `hidden` must be the zero state of init_hidden (the only use in the reference)."""
         if self.training and self.drop_prob > 0:
-            raise NotImplementedError("RNN_ENCODER: training-mode dropout is not on the HIP path yet; call .eval()")
+            raise NotImplementedError("RNN_ENCODER: training-mode dropout / LSTM backward are not on the HIP path "
+                                      "(the SR training keeps the text encoder frozen in eval mode); call .eval()")
         w_ih, w_hh, b_ih, b_hh = self._weights()
+        if not self.training:
+            # frozen weights: the input projection is a function of the token only -> per-token gate table, built once
+            # per weight version with the same GEMM kernel (bit-identical), then ONE recurrence launch per batch
+            key = (self._key, _ver(self.encoder.weight))
+            if key != self._table_key:
+                self._table = ops.lstm_gate_table(self.encoder.weight, w_ih, b_ih, b_hh)
+                self._table_key = key
+            return ops.bilstm_table(captions, cap_lens, self._table, w_hh)
         return ops.bilstm(captions, cap_lens, self.encoder.weight, w_ih, w_hh, b_ih, b_hh)
 
 
