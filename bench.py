@@ -142,6 +142,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="run the two generators on ONE stream (default: NetG_highweight's trunk overlaps G_SR_NET_low on "
+                         "a second HIP stream).  Per-launch kernel timing is only meaningful single-stream, so the "
+                         "event-sampled steps always run serial; use this flag to collect a rocprofv3 summary whose "
+                         "per-kernel durations are comparable with `roofline`")
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer = the headline (BASELINE configs[1]); train = generator fwd+bwd+Adam step on MSE+KL "
                          "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
@@ -178,7 +183,7 @@ def main():
     weights = load_weights()
     if args.mode == "train":
         return bench_train(args, rank, world, dist, dev, weights)
-    pipe = SRPipeline(41, device=dev, low="lr")
+    pipe = SRPipeline(41, device=dev, low="lr", overlap=not args.serial)
     if weights is not None:
         pipe.load_state_dicts(weights["E."], weights["GL."], weights["GH."])
         wdesc = "shipped face_S8 checkpoint (tests/golden fixture), random-init text encoder"
@@ -209,6 +214,7 @@ def main():
     for k in range(args.steps):
         sample = args.profile_every > 0 and k % args.profile_every == 0
         ops.profile = prof if sample else None
+        pipe.overlap = (not args.serial) and not sample    # a launch is timed alone: sampled steps are single-stream
         nprof += 1 if sample else 0
         step()
     ops.profile = None
@@ -237,7 +243,9 @@ def main():
                     "traffic": TRAFFIC_PER_LAUNCH_BYTES, "launches_per_step": n // nprof,
                     "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_launch": fl / n,
                     "algorithmic_bytes_per_launch": by / n, "hbm_GBs_algorithmic": round(by / sec / 1e9, 1),
-                    "timing": "HIP events around every launch of %d of the %d timed steps" % (nprof, args.steps)}
+                    "timing": "HIP events around every launch of %d of the %d timed steps; those steps run "
+                              "single-stream so each launch is timed alone (the other steps overlap the two "
+                              "generators on 2 streams%s)" % (nprof, args.steps, "" if not args.serial else ": off, --serial")}
             kern = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[3] / nprof * 1e3, 4),
                         "TFLOPs": round(v[1] / v[3] / 1e12, 2), "GBs_algorithmic": round(v[2] / v[3] / 1e9, 1)}
                     for k, v in agg.items()}
@@ -247,7 +255,8 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic inputs (seed 100); " + wdesc,
                "config": {"workload": "CelebA face x8 (32->256) batch=16 per GPU, text-enc + G_SR_NET_low + "
                                       "NetG_highweight forward, eval BN (BASELINE configs[1])",
-                          "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world},
+                          "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world,
+                          "streams": 1 if args.serial else 2},
                "roofline": roof, "kernels": kern}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(weights, B)

@@ -88,23 +88,27 @@ class NetG_highweight(nn.Module):
             return ConvTo3.apply(out, self.conv_output[0].weight, SRb, True, self._a)
         return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=self._a)
 
-    def forward(self, LR, SRb, LRb):
-        SRb2, SRb4, SRb8 = SRb[0], SRb[1], SRb[2]
+    def trunk(self, LR, LRb):
+        """Everything of forward() that does not need the low-frequency images: convin -> 6 ResBlocks -> the three
+        up-scales with residual24/48 between them.  Returns the three feature maps the heads read.  (In the
+        reference the heads' outputs never feed back into this chain, model.py:264-298, so the whole trunk is
+        independent of G_SR_NET_low and can run concurrently with it.)"""
         if self.low == 'lrblur':
             x = LRb
         elif self.low == 'lr-lrblur':
             x = LR - LRb
         else:
             x = LR
-        out = self.convin(x)
-        out = self.residual(out)
-        out = self.upscale2x(out)
-        ims2 = self._head(out, SRb2)
-        out = self.residual24(out)
-        out = self.upscale4x(out)
-        ims4 = self._head(out, SRb4)
-        out = self.residual48(out)
-        out = self.upscale8x(out)
-        ims8 = self._head(out, SRb8)
+        out2 = self.upscale2x(self.residual(self.convin(x)))
+        out4 = self.upscale4x(self.residual24(out2))
+        out8 = self.upscale8x(self.residual48(out4))
+        return out2, out4, out8
+
+    def heads(self, feats, SRb):
+        """ims_k = one * tanh(conv5x5(out_k)) + a * SRb_k   (model.py:280, 288, 297)."""
+        return [self._head(f, sr) for f, sr in zip(feats, SRb)]
+
+    def forward(self, LR, SRb, LRb):
+        ims = self.heads(self.trunk(LR, LRb), SRb[:3])
         a, one = self._const(LR)
-        return [ims2, ims4, ims8], a, one
+        return ims, a, one

@@ -30,11 +30,15 @@ def to_uint8(img):
 class SRPipeline:
     """The three networks of the shipped x8 path, built like trainer_objective.py:62-99."""
 
-    def __init__(self, n_words, device="cuda", low="lr"):
+    def __init__(self, n_words, device="cuda", low="lr", overlap=True):
         self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
         self.netGL = G_SR_NET_low()
         self.netGH = NetG_highweight(weightmap=False, low=low)
         self.device = torch.device(device)
+        # NetG_highweight's trunk does not depend on G_SR_NET_low (only its three heads add the low-frequency
+        # images): run it on a second HIP stream so the two networks' small layers and kernel tails overlap
+        self.overlap = overlap
+        self._side = None
         for m in (self.text_encoder, self.netGL, self.netGH):
             m.to(self.device)
             m.eval()
@@ -55,7 +59,21 @@ class SRPipeline:
         hidden = self.text_encoder.init_hidden(captions.shape[0])
         words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
         mask = caption_mask(captions, words_embs.size(2))
-        fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
-        fine_im, a, one = self.netGH(LR, fake_imgL, LRb)
+        if self.overlap and LR.is_cuda:
+            main = torch.cuda.current_stream(LR.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=LR.device)
+            side = self._side
+            side.wait_stream(main)                       # LR / LRb are ready on the main stream
+            with torch.cuda.stream(side):
+                feats = self.netGH.trunk(LR, LRb)
+            fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
+            main.wait_stream(side)
+            for f in feats:
+                f.record_stream(main)                    # allocated on the side stream, consumed on the main one
+            fine_im = self.netGH.heads(feats, fake_imgL)
+        else:
+            fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
+            fine_im, a, one = self.netGH(LR, fake_imgL, LRb)
         return {"words_emb": words_embs, "sent_emb": sent_emb, "mask": mask, "fake": fake_imgL,
                 "att": attention_maps, "mu": mu, "logvar": logvar, "fine": fine_im}
