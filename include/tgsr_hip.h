@@ -78,6 +78,18 @@ int tgsr_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, i
                      int64_t out_bstride, int epilogue, int upsample, void* stream);
 
 /*
+ * upBlock (util.py:74-80) by sub-pixel decomposition: Upsample(x2, nearest) -> conv3x3 -> affine (BN eval) -> GLU
+ * computed as four 2x2 convolutions on the PRE-upsample tensor with pre-summed taps: 4*Cin MACs per output instead
+ * of 9*Cin, same result up to the rounding of the weight sums (tgsr_conv3x3_fwd(upsample=1) is the 9-tap form, kept
+ * for the training path).  wpack from tgsr_pack_upconv_weight (tgsr_packed_upconv_weight_elems floats).
+ * x [B][Cin][H][W] (batch stride), out [B][Cout/2][2H][2W] (batch stride, 8-byte aligned); Cout % 64 == 0.
+ */
+int64_t tgsr_packed_upconv_weight_elems(int Cout, int Cin);
+int tgsr_pack_upconv_weight(const float* w, float* wpack, int Cout, int Cin, void* stream);
+int tgsr_upconv3x3_glu_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* wpack, int Cout,
+                           const float* scale, const float* shift, float* out, int64_t out_bstride, void* stream);
+
+/*
  * KxK convolution (K = 3 or 5, stride 1, zero pad K/2, no bias) to 3 output channels + optional epilogue.
  * Replaces GET_IMAGE_G_noAct.img (util.py:913-915; K=3, TGSR_ACT_NONE) and
  * conv_output = conv5x5 + Tanh followed by `one*. + a*SRb` (model.py:224, 280/288/297; K=5, TGSR_ACT_TANH_AXPY).

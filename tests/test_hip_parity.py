@@ -98,6 +98,25 @@ def test_conv3x3_fused(B, Cin, H, W, Cout, glu, up, res):
     close(out, ref, atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 64, 16, 16, 64), (2, 32, 24, 40, 64), (1, 64, 5, 9, 64), (16, 64, 32, 32, 64),
+                                             (3, 20, 13, 33, 128), (2, 64, 128, 128, 64)])
+def test_upconv_subpixel_vs_upsample_conv(B, Cin, H, W, Cout):
+    """upBlock by sub-pixel decomposition == Upsample(x2 nearest) -> conv3x3 -> affine -> GLU."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Cin + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.3 * torch.randn(Cout, generator=g)
+    xi = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    ref = O.glu(F.conv2d(xi, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None])
+    wide = torch.full((B, Cout // 2 + 6, 2 * H, 2 * W), 3.0, device=DEV)
+    out = ops.upconv3x3_glu(x.to(DEV), ops.pack_upconv_weight(w.to(DEV)), Cout, scale.to(DEV), shift.to(DEV),
+                            out=wide[:, 2:2 + Cout // 2])
+    close(out, ref, atol=2e-5, rtol=2e-5)
+    assert (wide[:, :2] == 3).all() and (wide[:, 2 + Cout // 2:] == 3).all()
+
+
 def test_conv3x3_channel_slice_io():
     """Reads from / writes into channel slices of wider buffers (how torch.cat disappears)."""
     from tgsr_amd import ops

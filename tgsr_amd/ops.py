@@ -112,6 +112,39 @@ def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Option
     return out
 
 
+def pack_upconv_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [ceil(Cin/4)][4 phases][4 taps][4][Cout] with the sub-pixel tap sums (tgsr_upconv3x3_glu_fwd)."""
+    _need_hip(w)
+    w = _f32(w.detach(), "weight").contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = torch.empty(L.tgsr_packed_upconv_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
+    check(L.tgsr_pack_upconv_weight(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_upconv_weight")
+    return out
+
+
+def upconv3x3_glu(x: torch.Tensor, wpack_up: torch.Tensor, cout: int, scale, shift,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """upBlock in one launch by sub-pixel decomposition (4 x 2x2 convs on the pre-upsample tensor)."""
+    _need_hip(x, wpack_up, scale, shift, out)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    B, Cin, H, W = x.shape
+    co, Ho, Wo = cout // 2, 2 * H, 2 * W
+    if out is None:
+        out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (B, co, Ho, Wo) or out.stride(3) != 1 or out.stride(2) != Wo or out.stride(1) != Ho * Wo:
+        raise TgsrError("upconv3x3_glu: bad `out` shape/strides %s %s" % (tuple(out.shape), out.stride()))
+    obs = out.stride(0) if B > 1 else co * Ho * Wo
+    e0 = _ev() if profile is not None else None
+    rc = _lib.lib().tgsr_upconv3x3_glu_fwd(_p(x), xbs, B, Cin, H, W, _p(wpack_up), cout, _p(scale), _p(shift), _p(out),
+                                           obs, _stream())
+    check(rc, "tgsr_upconv3x3_glu_fwd")
+    if profile is not None:
+        nbytes = 4 * (B * Cin * H * W + B * co * Ho * Wo + cout * Cin * 9)
+        profile.append(("upconv_glu_mfma_kernel", 2.0 * B * Ho * Wo * cout * Cin * 9, nbytes, e0, _ev()))
+    return out
+
+
 def conv_to3(x: torch.Tensor, w: torch.Tensor, tanh_axpy: bool = False, addend: Optional[torch.Tensor] = None,
              alpha: float = 0.0) -> torch.Tensor:
     """KxK (3|5) conv to 3 channels; tanh_axpy: tanh(conv) + alpha * addend."""

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--only", default="")
+    ap.add_argument("--ninetap", action="store_true", help="time the 9-tap folded-upsample kernel for the upBlocks")
     a = ap.parse_args()
     dev = "cuda"
     B = a.batch
@@ -57,13 +58,18 @@ def main():
         co = cout // 2 if glu else cout
         r = torch.randn(B, co, ho, ho, device=dev) if res else None
         out = torch.empty(B, co, ho, ho, device=dev)
+        if up and glu and cout % 64 == 0 and not a.ninetap:
+            wpu = ops.pack_upconv_weight(w)
+            run = lambda: ops.upconv3x3_glu(x, wpu, cout, sc, sh, out=out)
+        else:
+            run = lambda: ops.conv3x3_fused(x, wp, cout, sc, sh, glu=bool(glu), upsample=bool(up), residual=r, out=out)
         for _ in range(3):
-            ops.conv3x3_fused(x, wp, cout, sc, sh, glu=bool(glu), upsample=bool(up), residual=r, out=out)
+            run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(a.reps):
-            ops.conv3x3_fused(x, wp, cout, sc, sh, glu=bool(glu), upsample=bool(up), residual=r, out=out)
+            run()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.reps
