@@ -10,7 +10,7 @@
 // read of the generic kernel (tgsr_conv3x3_fwd, upsample = 1), identical up to the rounding of the weight sums.
 // The upBlocks are 41 % of the conv time of one SR forward (the 256^2 one alone 23 % of all FLOPs).
 //
-// Kernel: workgroup = 8 waves = 8 source rows x 32 source columns (16 x 64 outputs) x one GLU channel block (32 value +
+// Kernel: workgroup = 4 waves = 4 source rows x 32 source columns (8 x 64 outputs) x one GLU channel block (32 value +
 // 32 gate channels); wave = 1 source row, 8 accumulators (4 phases x {value, gate}).  Per k-step (2 input channels)
 // the 9 shifted input fragments are read once and feed the 16 (phase, tap) weight fragments.  Stages of 4 input
 // channels are double buffered in LDS by LDS-DMA exactly like tgsr_conv3x3.hip; the two column phases of a lane are
@@ -36,7 +36,9 @@ struct UpArgs {
   int tiles_x, tiles_y, nchunks;
 };
 
-constexpr int kUpWV = 8;                         // waves per workgroup = source rows per tile
+constexpr int kUpWV = 4;                         // waves per workgroup = source rows per tile (two workgroups per CU:
+                                                 // one 8-wave workgroup stalls both waves of a SIMD at the same barrier;
+                                                 // a persistent grid and 8-channel stages were measured too: no gain)
 constexpr int kUpNCOL = 64;                      // 32 value + 32 gate columns
 constexpr int kUpTR = kUpWV + 2, kUpTC = 34, kUpPLANE = kUpTR * kUpTC;
 constexpr int kUpW = 16 * kConvCK * kUpNCOL;     // floats of weights per stage (4096)
