@@ -6,7 +6,7 @@
 // 8.4 MB and writes 0.8 MB per image against 0.1-0.3 GFLOP: it is a streaming kernel, so it runs on the VALU:
 //   * workgroup = TH x 64 output pixels (TH = 16, or 8 / 4 on small images so that every CU gets work),
 //     thread = 4 consecutive pixels x 3 channels (12 accumulators);
-//   * the input is staged in LDS 4 channels at a time with its halo, double buffered, by LDS-DMA
+//   * the input is staged in LDS 2 channels at a time with its halo, double buffered, by LDS-DMA
 //     (global_load_lds, 16 B per lane: the tile starts 4 columns left of the output tile so every piece is an
 //     aligned float4; out-of-image pieces read a zero block) - the copy of stage c+1 runs under the FMAs of stage c;
 //   * a thread reads its 12 input floats of a row as three aligned ds_read_b128 and reuses them for all K taps x
@@ -40,7 +40,7 @@ __device__ __forceinline__ float fast_tanh(float v) {
 
 template <int K, int ACT, bool VEC4, int TH>   // TH output rows x 64 columns per workgroup, 16 * TH threads
 __global__ __launch_bounds__(16 * TH) void conv_to3_kernel(To3Args a) {
-  constexpr int P = K / 2, CK = 4, TW = 64, NT = 16 * TH, NW = NT / 64;
+  constexpr int P = K / 2, CK = 2, TW = 64, NT = 16 * TH, NW = NT / 64;
   constexpr int TR = TH + K - 1;
   constexpr int PITCH = 72;  // LDS column j = input column x0 - 4 + j; 72 = 64 + 4 left + 4 right
   constexpr int STAGE = CK * TR * PITCH;               // floats per stage (multiple of 4)

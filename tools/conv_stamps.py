@@ -33,16 +33,20 @@ def run(B, cin, cout, h, glu, up, res):
     assert L.tgsr_debug_read_stamps(buf, n) == 0
     s = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)
     s = s[s[:, 3] > 0]
+    s = s[: B * ((2 * h if up else h) // 4 + 1) * ((2 * h if up else h) // 32 + 1)]   # drop stale rows of earlier launches
+    s = s[(s[:, 3] > s[:, 0]) & (s[:, 7] > s[:, 6])]
     clk = (s[:, 3] - s[:, 0]) / np.maximum(1, (s[:, 7] - s[:, 6])) * 100e6
     pro, main, epi = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
-    t0 = s[:, 0].min(); span = s[:, 3].max() - t0
+    rt0 = s[:, 6].min(); span = (s[:, 7].max() - rt0) * 10   # ns (100 MHz constant clock)
+    st_ns = (s[:, 6] - rt0) * 10; en_ns = (s[:, 7] - rt0) * 10
+    t0 = 0
     print("B%d %d->%d @%d glu%d up%d res%d: %.1f us, %d WGs; clock %.3f GHz (median); cycles/WG: prologue %d  main %d  epilogue %d ;"
           " kernel span %d cycles; WG start spread: %d..%d" % (B, cin, cout, h, glu, up, res, e0.elapsed_time(e1) * 1e3, len(s),
-          np.median(clk) / 1e9, np.median(pro), np.median(main), np.median(epi), span, (s[:, 0] - t0).min(), np.percentile(s[:, 0] - t0, 50)))
-    st0 = np.sort(s[:, 0] - t0); en = np.sort(s[:, 3] - t0)
-    print("   start pct 10/50/90/100: %s   end pct 10/50/90/100: %s" % (np.percentile(st0, [10, 50, 90, 100]).astype(int), np.percentile(en, [10, 50, 90, 100]).astype(int)))
+          np.median(clk) / 1e9, np.median(pro), np.median(main), np.median(epi), span, st_ns.min(), np.percentile(st_ns, 50)))
+    print("   WG start ns pct 10/50/90/100: %s   end ns pct 10/50/90/100: %s  (kernel span %d ns)" % (
+        np.percentile(st_ns, [10, 50, 90, 100]).astype(int), np.percentile(en_ns, [10, 50, 90, 100]).astype(int), span))
 if __name__ == "__main__":
     a = [int(v) for v in sys.argv[1:]]
     if a: run(*a)
     else:
-        run(16, 64, 128, 128, 1, 0, 0); run(16, 64, 64, 128, 0, 0, 1); run(16, 64, 64, 128, 1, 1, 0); run(16, 32, 64, 32, 1, 0, 0)
+        run(16, 64, 128, 128, 1, 0, 0); run(16, 64, 64, 128, 0, 0, 1); run(16, 64, 128, 64, 1, 0, 0)
