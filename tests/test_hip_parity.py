@@ -117,6 +117,37 @@ def test_upconv_subpixel_vs_upsample_conv(B, Cin, H, W, Cout):
     assert (wide[:, :2] == 3).all() and (wide[:, 2 + Cout // 2:] == 3).all()
 
 
+WINO_CASES = [
+    # B, Cin, H, W, Cout, glu, res
+    (2, 64, 32, 32, 128, True, False),
+    (2, 64, 32, 32, 64, False, True),
+    (3, 32, 32, 64, 64, True, False),
+    (1, 64, 13, 20, 128, True, False),     # ragged rows / columns (even width)
+    (1, 20, 6, 12, 64, False, True),       # Cin not a multiple of the stage
+    (16, 64, 64, 64, 128, True, False),
+    (4, 128, 16, 16, 256, True, False),    # two channel groups
+    (2, 64, 128, 128, 64, False, True),
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,glu,res", WINO_CASES)
+def test_conv3x3_winograd(B, Cin, H, W, Cout, glu, res):
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.3 * torch.randn(Cout, generator=g)
+    co = Cout // 2 if glu else Cout
+    r = torch.randn(B, co, H, W, generator=g) if res else None
+    ref = F.conv2d(x, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
+    ref = O.glu(ref) if glu else ref
+    ref = ref + r if res else ref
+    out = ops.conv3x3_wino(x.to(DEV), ops.pack_wino_weight(w.to(DEV)), Cout, scale.to(DEV), shift.to(DEV), glu=glu,
+                           residual=None if r is None else r.to(DEV))
+    close(out, ref, atol=3e-5, rtol=3e-5)
+
+
 def test_conv3x3_channel_slice_io():
     """Reads from / writes into channel slices of wider buffers (how torch.cat disappears)."""
     from tgsr_amd import ops

@@ -112,6 +112,48 @@ def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Option
     return out
 
 
+def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) transformed weights [ceil(Cin/8)][16 pos][8][Cout]."""
+    _need_hip(w)
+    w = _f32(w.detach(), "weight").contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = torch.empty(L.tgsr_packed_wino_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
+    check(L.tgsr_pack_wino_weight(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_wino_weight")
+    return out
+
+
+def wino_supported(x: torch.Tensor, cout: int) -> bool:
+    """Shapes the Winograd kernel takes: Cout % 64 == 0, width % 4 == 0, 16-byte aligned dense planes."""
+    return (cout % 64 == 0 and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and
+            (x.shape[0] == 1 or x.stride(0) % 4 == 0))
+
+
+def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, glu: bool = False,
+                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3 + affine + (GLU | residual) by Winograd F(2x2,3x3) (same contract as conv3x3_fused, no upsample)."""
+    _need_hip(x, upack, scale, shift, residual, out)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    B, Cin, H, W = x.shape
+    co = cout // 2 if glu else cout
+    if out is None:
+        out = torch.empty(B, co, H, W, dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (B, co, H, W) or out.stride(3) != 1 or out.stride(2) != W or out.stride(1) != H * W:
+        raise TgsrError("conv3x3_wino: bad `out` shape/strides %s %s" % (tuple(out.shape), out.stride()))
+    obs = out.stride(0) if B > 1 else co * H * W
+    rbs = 0
+    if residual is not None:
+        residual, rbs = _nchw_bstride(_f32(residual, "residual"), "residual")
+    e0 = _ev() if profile is not None else None
+    rc = _lib.lib().tgsr_wino_conv3x3_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(residual),
+                                          rbs, _p(out), obs, _lib.EPI_AFFINE_GLU if glu else _lib.EPI_AFFINE, _stream())
+    check(rc, "tgsr_wino_conv3x3_fwd")
+    if profile is not None:
+        nbytes = 4 * (B * Cin * H * W + B * co * H * W * (2 if residual is not None else 1) + cout * Cin * 9)
+        profile.append(("wino_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9, nbytes, e0, _ev()))
+    return out
+
+
 def pack_upconv_weight(w: torch.Tensor) -> torch.Tensor:
     """[Cout,Cin,3,3] -> [ceil(Cin/4)][4 phases][4 taps][4][Cout] with the sub-pixel tap sums (tgsr_upconv3x3_glu_fwd)."""
     _need_hip(w)

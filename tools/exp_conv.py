@@ -24,3 +24,19 @@ if __name__ == "__main__":
         for cin in (64, 128, 256, 512): run(16, cin, 128, 128, 1, 0, 0)
         for B in (16, 32, 64): run(B, 64, 128, 128, 1, 0, 0)
         for cin in (64, 256): run(16, cin, 64, 128, 0, 0, 1)
+
+
+def run_wino(B, cin, cout, h, glu, res, reps=10):
+    dev = "cuda"
+    x = torch.randn(B, cin, h, h, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
+    up = ops.pack_wino_weight(w); sc = torch.rand(cout, device=dev) + 0.5; sh = torch.randn(cout, device=dev) * 0.1
+    co = cout // 2 if glu else cout
+    r = torch.randn(B, co, h, h, device=dev) if res else None
+    out = torch.empty(B, co, h, h, device=dev)
+    for _ in range(2): ops.conv3x3_wino(x, up, cout, sc, sh, glu=bool(glu), residual=r, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): ops.conv3x3_wino(x, up, cout, sc, sh, glu=bool(glu), residual=r, out=out)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps; fl = 2.0 * B * h * h * cout * cin * 9
+    print("WINO B%d %d->%d @%d glu%d res%d: %.1f us  %.1f TFLOP/s (algorithmic)" % (B, cin, cout, h, glu, res, us, fl / us / 1e6))
