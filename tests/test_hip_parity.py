@@ -123,7 +123,9 @@ WINO_CASES = [
     (2, 64, 32, 32, 64, False, True),
     (3, 32, 32, 64, 64, True, False),
     (1, 64, 13, 20, 128, True, False),     # ragged rows / columns (even width)
-    (1, 20, 6, 12, 64, False, True),       # Cin not a multiple of the stage
+    (1, 24, 6, 12, 64, False, True),       # three stages, tile smaller than the workgroup tile
+    (1, 8, 8, 32, 64, False, False),       # a single stage
+    (1, 16, 8, 32, 128, True, False),      # two stages
     (16, 64, 64, 64, 128, True, False),
     (4, 128, 16, 16, 256, True, False),    # two channel groups
     (2, 64, 128, 128, 64, False, True),
@@ -143,7 +145,7 @@ def test_conv3x3_winograd(B, Cin, H, W, Cout, glu, res):
     ref = F.conv2d(x, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
     ref = O.glu(ref) if glu else ref
     ref = ref + r if res else ref
-    out = ops.conv3x3_wino(x.to(DEV), ops.pack_wino_weight(w.to(DEV)), Cout, scale.to(DEV), shift.to(DEV), glu=glu,
+    out = ops.conv3x3_wino(x.to(DEV), ops.pack_wino_weight(w.to(DEV), glu=glu), Cout, scale.to(DEV), shift.to(DEV), glu=glu,
                            residual=None if r is None else r.to(DEV))
     close(out, ref, atol=3e-5, rtol=3e-5)
 

@@ -29,7 +29,7 @@ SIGNATURES = {
     "tgsr_pack_upconv_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "tgsr_upconv3x3_glu_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp]),
     "tgsr_packed_wino_weight_elems": (_i64, [_i, _i]),
-    "tgsr_pack_wino_weight": (_i, [_vp, _vp, _i, _i, _vp]),
+    "tgsr_pack_wino_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tgsr_wino_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
     "tgsr_conv_to3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),
     "tgsr_word_attention_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp]),

@@ -112,20 +112,21 @@ def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Option
     return out
 
 
-def pack_wino_weight(w: torch.Tensor) -> torch.Tensor:
-    """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) transformed weights [ceil(Cin/8)][16 pos][8][Cout]."""
+def pack_wino_weight(w: torch.Tensor, glu: bool = False) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) transformed weights [ceil(Cin/8)][Cout/64][16 pos][8][64]; `glu` must
+    match the epilogue the pack is used with (it groups value channels with their gate channels)."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
     L = _lib.lib()
     out = torch.empty(L.tgsr_packed_wino_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
-    check(L.tgsr_pack_wino_weight(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_wino_weight")
+    check(L.tgsr_pack_wino_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_wino_weight")
     return out
 
 
 def wino_supported(x: torch.Tensor, cout: int) -> bool:
-    """Shapes the Winograd kernel takes: Cout % 64 == 0, width % 4 == 0, 16-byte aligned dense planes."""
-    return (cout % 64 == 0 and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and
+    """Shapes the Winograd kernel takes: Cout % 64 == 0, Cin % 8 == 0, width % 4 == 0, 16-byte aligned planes."""
+    return (cout % 64 == 0 and x.shape[1] % 8 == 0 and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and
             (x.shape[0] == 1 or x.stride(0) % 4 == 0))
 
 

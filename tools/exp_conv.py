@@ -29,7 +29,7 @@ if __name__ == "__main__":
 def run_wino(B, cin, cout, h, glu, res, reps=10):
     dev = "cuda"
     x = torch.randn(B, cin, h, h, device=dev); w = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
-    up = ops.pack_wino_weight(w); sc = torch.rand(cout, device=dev) + 0.5; sh = torch.randn(cout, device=dev) * 0.1
+    up = ops.pack_wino_weight(w, glu=bool(glu)); sc = torch.rand(cout, device=dev) + 0.5; sh = torch.randn(cout, device=dev) * 0.1
     co = cout // 2 if glu else cout
     r = torch.randn(B, co, h, h, device=dev) if res else None
     out = torch.empty(B, co, h, h, device=dev)
