@@ -29,7 +29,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 pe
 PEAK_HBM_GBS = 8000.0
 # HBM bytes per conv3x3_mfma_kernel launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
 # passes, FETCH_SIZE doubled per MI355X_MICROARCH.md, averaged over the 36 launches of a step); None until measured.
-TRAFFIC_PER_LAUNCH_BYTES = 45.90e6   # profiles/r01_c_pmc_hbm_traffic.csv (algorithmic: 44.58e6)
+TRAFFIC_PER_LAUNCH_BYTES = {"conv3x3_mfma_kernel": 45.90e6}   # profiles/r01_c_pmc_hbm_traffic.csv (algorithmic: 44.58e6)
+# share of the direct-form multiplies a kernel actually issues (Winograd F(2x2,3x3): 16/36; sub-pixel upBlock: 4/9)
+EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "upconv_glu_mfma_kernel": 4.0 / 9.0}
 
 
 def load_weights():
@@ -236,23 +238,31 @@ def main():
             a[3] += e0.elapsed_time(e1) * 1e-3
         roof, kern = None, {}
         if nprof:
-            n, fl, by, sec = agg["conv3x3_mfma_kernel"]
+            # dominant kernel = the 3x3-conv kernel with the largest share of the step.  `achieved` is ALGORITHMIC:
+            # the reference's direct-form FLOP count (2*B*H*W*Cout*Cin*9) over the launch time.  The Winograd and
+            # sub-pixel kernels issue 4/9 of those multiplies, so `mfma_executed_frac` (what the MFMA pipe really
+            # ran, over the dense fp32 peak) is reported next to `frac`.
+            conv_kernels = [k for k in ("wino_conv3x3_kernel", "conv3x3_mfma_kernel", "upconv_glu_mfma_kernel") if k in agg]
+            dom = max(conv_kernels, key=lambda k: agg[k][3])
+            n, fl, by, sec = agg[dom]
             ach = fl / sec / 1e12
-            roof = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel", "achieved": round(ach, 2),
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": TRAFFIC_PER_LAUNCH_BYTES, "launches_per_step": n // nprof,
+                    "mfma_executed_frac": round(ach * EXECUTED_MAC_FRACTION[dom] / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": TRAFFIC_PER_LAUNCH_BYTES.get(dom), "launches_per_step": n // nprof,
                     "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_launch": fl / n,
                     "algorithmic_bytes_per_launch": by / n, "hbm_GBs_algorithmic": round(by / sec / 1e9, 1),
                     "timing": "HIP events around every launch of %d of the %d timed steps; those steps run "
                               "single-stream so each launch is timed alone (the other steps overlap the two "
                               "generators on 2 streams%s)" % (nprof, args.steps, "" if not args.serial else ": off, --serial")}
-            # the whole 3x3-conv path = the generic kernel + the sub-pixel upBlock kernel (same algorithmic FLOP count
-            # as the reference's Upsample -> conv3x3, 4/9 of the MACs actually issued)
-            cp = [agg[k] for k in ("conv3x3_mfma_kernel", "upconv_glu_mfma_kernel") if k in agg]
+            # the whole 3x3-conv path = Winograd + direct + sub-pixel upBlock kernels (algorithmic FLOPs as above)
+            cp = [agg[k] for k in conv_kernels]
             cfl, csec, cby = sum(v[1] for v in cp), sum(v[3] for v in cp), sum(v[2] for v in cp)
-            roof["conv_path"] = {"kernels": ["conv3x3_mfma_kernel", "upconv_glu_mfma_kernel"],
+            cex = sum(agg[k][1] * EXECUTED_MAC_FRACTION[k] for k in conv_kernels)
+            roof["conv_path"] = {"kernels": conv_kernels,
                                  "achieved_algorithmic": round(cfl / csec / 1e12, 2), "unit": "TFLOP/s",
                                  "frac_of_fp32_mfma_peak": round(cfl / csec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                 "mfma_executed_frac": round(cex / csec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                                  "ms_per_step": round(csec / nprof * 1e3, 4),
                                  "hbm_GBs_algorithmic": round(cby / csec / 1e9, 1)}
             kern = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[3] / nprof * 1e3, 4),

@@ -123,9 +123,9 @@ WINO_CASES = [
     (2, 64, 32, 32, 64, False, True),
     (3, 32, 32, 64, 64, True, False),
     (1, 64, 13, 20, 128, True, False),     # ragged rows / columns (even width)
-    (1, 24, 6, 12, 64, False, True),       # three stages, tile smaller than the workgroup tile
-    (1, 8, 8, 32, 64, False, False),       # a single stage
-    (1, 16, 8, 32, 128, True, False),      # two stages
+    (1, 20, 6, 12, 64, False, True),       # five stages, image smaller than the workgroup tile
+    (1, 4, 8, 32, 64, False, False),       # a single stage
+    (1, 8, 10, 36, 128, True, False),      # two stages, ragged
     (16, 64, 64, 64, 128, True, False),
     (4, 128, 16, 16, 256, True, False),    # two channel groups
     (2, 64, 128, 128, 64, False, True),

@@ -10,6 +10,7 @@
 // Mapping: see the geometry comment above the kernel.
 #include "tgsr_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace tgsr {
@@ -38,7 +39,7 @@ struct WinoArgs {
   const float* x;
   int64_t xbs;
   int B, Cin, H, W;
-  const float* upack;     // [stage][group][pos 16][ci 8][64 interleaved]
+  const float* upack;     // [stage][group][pos pair 8][ci 4][cout half 2][16][4]
   int Cout;
   const float* scale;
   const float* shift;
@@ -49,261 +50,247 @@ struct WinoArgs {
   int tiles_x, tiles_y, nstages;
 };
 
-// Geometry: MFMA 16x16x4 (4 accumulator registers per 16 couts x 16 tiles), ALL 16 transformed positions live at
-// once: a wave owns 16 tiles (one tile row = 2 x 32 output pixels) x 64 output channels (4 blocks of 16: GLU value
-// blocks 0,1 and gate blocks 2,3, or 4 plain blocks) = 16 x 4 x 4 = 256 accumulator registers, one wave per SIMD; the
-// 4 waves of a workgroup take 4 consecutive tile rows (8 x 32 outputs) and share the transformed weights and the
-// raw input rows:
-//   stage = 8 input channels.
-//   U   [16 pos][8 ci][16 x 4 couts] (32 KB, double buffered): a linear LDS-DMA copy of the pre-transformed pack,
-//       whose 64 columns are stored interleaved (position 4*l + cb = column cb*16 + l) so one ds_read_b128 yields a
-//       lane's A fragments of all four cout blocks.
-//   raw [8 ci][10 rows][40 cols] (12.5 KB, double buffered, LDS-DMA in 16-byte pieces; the tile starts 4 columns
-//       left of the outputs so every piece is aligned and wholly inside or outside the image).
-//   V   per wave [16 pos][8 ci][16 tiles] (8 KB, double buffered): the wave's own input transform B^T d B.
-// One wave per SIMD means nothing hides a stall, so everything that is not an MFMA is cut into micro-operations of
-// <= 8 instructions and placed in the gaps BETWEEN the 128 MFMAs of a stage (an instruction issued right after an
-// MFMA runs under its 32 pipe cycles): the fragments of the next position, then the DMA of raw(st+2) and U(st+1),
-// then the transform raw(st+1) -> V(st+1) as reads / row sums / column sums + writes, each a few gaps apart so that
-// no LDS or DMA latency is ever waited for.  The only waits are the vmcnt(0) + barrier that ends a stage.
-constexpr int kWCK = 8;                                  // input channels per stage
-constexpr int kWTC = 40, kWTR = 10, kWPLANE = kWTR * kWTC;   // raw tile: 10 rows x (32 + 8) columns per channel
-constexpr int kWU = 16 * kWCK * 64;                      // floats of U per stage: 8192
-constexpr int kWUK = kWU / 256 / 4;                      // U DMA pieces (1 KB) per wave per stage: 8
-constexpr int kWRawN = kWCK * kWPLANE;                   // 3200 floats of raw input per stage
-constexpr int kWRawP = (kWRawN + 255) / 256;             // = 13 DMA pieces of 256 floats (the last one half used)
-constexpr int kWRaw = kWRawP * 256;                      // LDS floats per raw stage (padded to whole pieces)
-constexpr int kWIK = (kWRawP + 3) / 4;                   // raw DMA pieces per wave per stage: <= 4
-constexpr int kWV = 16 * kWCK * 16;                      // V image: [pos 16][ci 8][16 tiles]
-constexpr int kWSmem = 2 * kWU + 2 * kWRaw + 4 * 2 * kWV + 2 * 64;
+// Geometry.  MFMA 16x16x4 with ALL 16 transformed positions live: a wave owns 16 tiles (one tile row = 2 x 32 output
+// pixels) x 32 output channels (2 blocks of 16: GLU value block + its gate block, or 2 plain blocks)
+// = 16 pos x 2 x 4 = 128 accumulator registers, so TWO workgroups (8 waves) fit a CU.  That matters: measured on
+// gfx950, a wave's own VALU / LDS / DMA instructions do not overlap its own MFMAs (a variant of this kernel with one
+// 256-accumulator wave per SIMD lost ~7 cycles per non-MFMA instruction however they were scheduled), only another
+// wave's do.  A workgroup = 4 waves = 2 tile rows x 2 cout halves (4 x 32 outputs x 64 couts):
+//   stage = 4 input channels = one MFMA k-step per position.
+//   U   [8 pos pairs][4 ci][2 cout halves][16][4] (16 KB, triple buffered): a linear LDS-DMA copy of the
+//       pre-transformed pack; one ds_read_b128 yields a lane's A fragments of 2 positions x 2 cout blocks.
+//   raw [4 ci][6 rows][40 cols] (3.75 KB, triple buffered, LDS-DMA in 16-byte pieces; the tile starts 4 columns left
+//       of the outputs so every piece is aligned and wholly inside or outside the image).
+//   V   per tile row [8 pos pairs][4 ci][16 tiles][2] (4 KB, double buffered): the input transform B^T d B, shared
+//       by the two cout-half waves of the row; each of them computes two of the four rows of V for one
+//       (tile, channel) per lane, one stage ahead.
+// One barrier per stage publishes U(st+1), raw(st+2) and V(st+1).  LDS 77 KB per workgroup.
+constexpr int kWCK = 4;                                  // input channels per stage
+constexpr int kWTC = 40, kWTR = 6, kWPLANE = kWTR * kWTC;    // raw tile: 6 rows x (32 + 8) columns per channel
+constexpr int kWU = 8 * kWCK * 2 * 64;                   // floats of U per stage: 4096
+constexpr int kWUK = kWU / 256 / 4;                      // U DMA pieces (1 KB) per wave per stage: 4
+constexpr int kWRawN = kWCK * kWPLANE;                   // 960 floats of raw input per stage
+constexpr int kWRaw = 1024;                              // = 4 DMA pieces, one per wave (the last one partly used)
+constexpr int kWV = 8 * kWCK * 32;                       // V image of one tile row: 1024 floats
+constexpr int kWSmem = 3 * kWU + 3 * kWRaw + 2 * 2 * kWV + 2 * 64;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 template <bool GLU>
-__global__ __launch_bounds__(256, 1) void wino_conv3x3_kernel(WinoArgs a) {
+__global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[kWSmem];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = wave >> 1, h = wave & 1;                 // tile row / cout half of this wave
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
   const int grp = blockIdx.y;
-  const int y0 = ty * 8, x0 = tx * 32;                   // output origin of the workgroup tile
+  const int y0 = ty * 4, x0 = tx * 32;                   // output origin of the workgroup tile
   const float* xb = a.x + (int64_t)b * a.xbs;
   const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
-  float* us = smem;                                      // 2 x U stage
-  float* raws = smem + 2 * kWU;                          // 2 x raw stage
-  float* vs = smem + 2 * kWU + 2 * kWRaw + wave * 2 * kWV;   // this wave's 2 V images
-  float* aff_s = smem + 2 * kWU + 2 * kWRaw + 4 * 2 * kWV;
+  float* us = smem;                                      // 3 x U stage
+  float* raws = smem + 3 * kWU;                          // 3 x raw stage
+  float* vs = smem + 3 * kWU + 3 * kWRaw + w * 2 * kWV;  // this tile row's 2 V images
+  float* aff_s = smem + 3 * kWU + 3 * kWRaw + 2 * 2 * kWV;
   TGSR_WSTAMP(0);
 
-  // ---- DMA plan.  raw: piece q = wave + 4*k covers floats [q*256, q*256 + 256) of the stage tile.  Per lane a running
-  // source pointer and its per-stage stride; out-of-image (or past-the-tile) lanes read the zero block with stride 0,
-  // so issuing a piece is branch-free.  Cin % 8 == 0 (host-checked): a stage never reads past the last channel.
-  const float* rptr[kWIK];
-  int rstep[kWIK];
-#pragma unroll
-  for (int k = 0; k < kWIK; ++k) {
-    const int e = ((wave + 4 * k) * 64 + lane) * 4;      // first float of this lane's 16-byte piece
+  // ---- DMA plan.  raw: wave q copies floats [q*256, q*256 + 256) of the stage tile.  Per lane a running source
+  // pointer and its per-stage stride; out-of-image (or past-the-tile) lanes read the zero block with stride 0, so
+  // issuing a piece is branch-free.  Cin % 4 == 0 (host-checked): a stage never reads past the last channel.
+  const float* rptr;
+  int rstep;
+  {
+    const int e = (wave * 64 + lane) * 4;                // first float of this lane's 16-byte piece
     const int c = e / kWPLANE;
     const int rem = e - c * kWPLANE;
     const int r = rem / kWTC, j = rem - r * kWTC;
     const int gy = y0 - 1 + r, gx = x0 - 4 + j;
     const bool ok = e < kWRawN && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // W % 4 == 0
-    rptr[k] = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino_zero;
-    rstep[k] = ok ? (int)(kWCK * HW) : 0;
+    rptr = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino_zero;
+    rstep = ok ? (int)(kWCK * HW) : 0;
   }
-  auto issue_raw = [&](int k, int buf) {                 // pieces are issued for stages 0, 1, 2, ... in order
-    if (4 * k + 3 < kWRawP || wave + 4 * k < kWRawP) {   // wave-uniform; only the last k can fail
-      __builtin_amdgcn_global_load_lds((glb_ptrw_t)rptr[k], (lds_ptrw_t)(raws + buf * kWRaw + (wave + 4 * k) * 256), 16,
-                                       0, 0);
-      rptr[k] += rstep[k];
-    }
+  // The copies are issued from inline assembly: hipcc cannot tell which LDS reads a global_load_lds may alias and
+  // puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialize every stage on its own prefetch.
+  // All vmcnt / lgkmcnt synchronization of the copies is therefore explicit (the stage-end barrier below).
+  auto dma16 = [&](const float* g, float* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptrw_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
   };
-  const float* uptr = a.upack + (int64_t)grp * kWU + (wave * 64 + lane) * 4;    // this wave's pieces of stage 0
+  auto issue_raw = [&](int buf) {                        // issued for stages 0, 1, 2, ... in order
+    dma16(rptr, raws + buf * kWRaw + wave * 256);
+    rptr += rstep;
+  };
+  // U: scalar base (advances one stage per call) + four per-lane byte offsets, so a stage's copies cost no VALU work
+  const float* ubase = a.upack + (int64_t)grp * kWU;     // stage 0 of this group
   const int64_t ustride = (int64_t)gridDim.y * kWU;
-  auto issue_u = [&](int k, int buf) {                   // k = 0..7 in order; the pointer moves on after the last
-    __builtin_amdgcn_global_load_lds((glb_ptrw_t)(uptr + k * 1024), (lds_ptrw_t)(us + buf * kWU + (wave + 4 * k) * 256),
-                                     16, 0, 0);
-    if (k == kWUK - 1) uptr += ustride;
+  unsigned uoff[kWUK];
+#pragma unroll
+  for (int k = 0; k < kWUK; ++k) uoff[k] = (unsigned)(((wave + 4 * k) * 64 + lane) * 16);
+  auto issue_u = [&](int buf) {                          // issued for stages 0, 1, 2, ... in order
+#pragma unroll
+    for (int k = 0; k < kWUK; ++k) {
+      const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptrw_t)(us + buf * kWU + (wave + 4 * k) * 256));
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff[k]), "s"(ubase), "s"(l)
+                   : "memory");
+    }
+    ubase += ustride;
   };
 
-  // ---- input transform V = B^T d B of this lane's tile (l15) for channels 2*lg + cc, in micro-operations:
-  //   rd(cc, r): the 4 raw floats of patch row r      rs(cc, i): row i of B^T d (4 sums)
-  //   cw(cc, i): row i of (B^T d) B (4 sums) + its 4 LDS writes
-  float d[2][4][4], tr[2][4][4];
-  const int rlane = (2 * lg) * kWPLANE + (2 * wave) * kWTC + 2 * l15 + 3;   // patch origin inside the raw stage tile
-  const int vwl = (2 * lg) * 16 + l15;
-  auto t_rd = [&](const float* rawb, int cc, int r) {
-    const float* rp = rawb + rlane + cc * kWPLANE + r * kWTC;
+  // ---- input transform: lane = (tile l15, channel lg); this wave computes rows i = 2h, 2h+1 of V = B^T d B
+  //   h = 0: i=0: d0 - d2, i=1: d1 + d2        h = 1: i=2: d2 - d1, i=3: d1 - d3     (d_r = raw row r of the 4x4 patch)
+  // as  first = A - B,  second = C +- D  with the rows A..D picked at compile time (the stage loop is instantiated per
+  // h), then the column pass, written as float2 (positions 4i + {0,1} and 4i + {2,3}).
+  const int rlane = lg * kWPLANE + (2 * w) * kWTC + 2 * l15 + 3;
+  const int vwl = lg * 32 + l15 * 2 + (4 * h) * (kWCK * 32);           // pos pair (2h + ii) * 2 + {0, 1}
+  auto t_read = [&](auto hc, const float* rawb, float (&d)[4][4]) {    // rows A, B, C, D
+    constexpr int H = decltype(hc)::value;
+    constexpr int row[4] = {H ? 2 : 0, H ? 1 : 2, 1, H ? 3 : 2};
+    const float* rp = rawb + rlane;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) d[cc][r][q] = rp[q];
-  };
-  auto t_rs = [&](int cc, int i) {
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      tr[cc][i][q] = i == 0 ? d[cc][0][q] - d[cc][2][q]
-                            : (i == 1 ? d[cc][1][q] + d[cc][2][q]
-                                      : (i == 2 ? d[cc][2][q] - d[cc][1][q] : d[cc][1][q] - d[cc][3][q]));
+      for (int q = 0; q < 4; ++q) d[r][q] = rp[row[r] * kWTC + q];
   };
-  auto t_cw = [&](float* vdst, int cc, int i, int half) {
-    float* vp = vdst + vwl + cc * 16 + (i * 4) * 128;    // V[pos = i*4 + jj][c][tile], pos stride 8 * 16
-    if (half == 0) {
-      vp[0 * 128] = tr[cc][i][0] - tr[cc][i][2];
-      vp[1 * 128] = tr[cc][i][1] + tr[cc][i][2];
-    } else {
-      vp[2 * 128] = tr[cc][i][2] - tr[cc][i][1];
-      vp[3 * 128] = tr[cc][i][1] - tr[cc][i][3];
+  auto t_write = [&](auto hc, const float (&d)[4][4], float* vdst) {
+    constexpr int H = decltype(hc)::value;
+    float tr[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      tr[0][q] = d[0][q] - d[1][q];
+      tr[1][q] = H ? d[2][q] - d[3][q] : d[2][q] + d[3][q];
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      float* vp = vdst + vwl + (2 * ii) * (kWCK * 32);
+      *reinterpret_cast<float2*>(vp) = make_float2(tr[ii][0] - tr[ii][2], tr[ii][1] + tr[ii][2]);
+      *reinterpret_cast<float2*>(vp + kWCK * 32) = make_float2(tr[ii][2] - tr[ii][1], tr[ii][1] - tr[ii][3]);
     }
   };
-  // transform micro-operation m (0..31), <= 4 instructions each: 8 reads, 8 row sums, 16 column sums + writes
-  auto t_op = [&](int m, const float* rawb, float* vdst) {
-    if (m < 8) t_rd(rawb, (m >> 2) & 1, m & 3);
-    else if (m < 16) t_rs((m >> 2) & 1, m & 3);
-    else t_cw(vdst, (m >> 3) & 1, (m >> 1) & 3, m & 1);
-  };
 
-  if (tid < 64) {                                        // logical column tid of this workgroup -> global cout
-    int col;
-    if (GLU) col = (tid < 32 ? grp * 32 : (a.Cout >> 1) + grp * 32 - 32) + tid;
-    else col = grp * 64 + tid;
-    aff_s[tid] = a.scale ? a.scale[col] : 1.f;
-    aff_s[64 + tid] = a.scale ? a.shift[col] : 0.f;
+  if (tid < 128) {   // logical column lc = half*32 + block*16 + l of this workgroup -> global cout; [0,64) scale, [64,128) shift
+    const int lc = tid & 63, hh = lc >> 5, cb = (lc >> 4) & 1, l = lc & 15;
+    const int col = GLU ? (cb ? (a.Cout >> 1) : 0) + grp * 32 + hh * 16 + l : grp * 64 + lc;
+    aff_s[tid] = a.scale ? (tid < 64 ? a.scale[col] : a.shift[col]) : (tid < 64 ? 1.f : 0.f);
   }
 
-  f32x4v M[16][4];
-#if defined(TGSR_WINO_EXP) && TGSR_WINO_EXP == 6
-  typedef float f32x16v __attribute__((ext_vector_type(16)));
-  f32x16v MM[16];
+  f32x4v M[16][2];
 #pragma unroll
   for (int p = 0; p < 16; ++p)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) MM[p][i] = 0.f;
-#endif
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) M[p][cb][i] = 0.f;
 
-  // ---- prologue: raw(0), raw(1), U(0); transform raw(0) -> V[0]
-#pragma unroll
-  for (int k = 0; k < kWIK; ++k) issue_raw(k, 0);
-#pragma unroll
-  for (int k = 0; k < kWUK; ++k) issue_u(k, 0);
-  if (a.nstages > 1) {
-#pragma unroll
-    for (int k = 0; k < kWIK; ++k) issue_raw(k, 1);
+  // ---- prologue: raw(0..2), U(0..1); transform raw(0) -> V[0]
+  issue_raw(0);
+  issue_u(0);
+  if (a.nstages > 1) { issue_raw(1); issue_u(1); }
+  if (a.nstages > 2) issue_raw(2);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everything issued so far is visible
+  {
+    float d[4][4];
+    if (h) { t_read(std::integral_constant<int, 1>{}, raws, d); t_write(std::integral_constant<int, 1>{}, d, vs); }
+    else { t_read(std::integral_constant<int, 0>{}, raws, d); t_write(std::integral_constant<int, 0>{}, d, vs); }
   }
-  __syncthreads();                                       // vmcnt(0) + barrier: raw(0), raw(1), U(0) visible
-#pragma unroll
-  for (int m = 0; m < 32; ++m) t_op(m, raws, vs);
+  __syncthreads();                                       // V(0) visible to the other cout half
   TGSR_WSTAMP(1);
 
-  const int oy = y0 + 2 * wave, ox = x0 + 2 * l15;
+  const int ulane = (lg * 2 + h) * 64 + l15 * 4;         // A: U[pp][ci = lg][h][l15][4]
+  const int vlane = lg * 32 + l15 * 2;                   // B: V[pp][ci = lg][l15][2]
+
+  // One stage: MFMAs on U(st), V(st); transform raw(st+1) -> V(st+1) [MORE]; fetch U(st+2) [MORE2] and raw(st+3)
+  // [MORE3].  A stage is only ~1-2k cycles, shorter than a DMA round trip, so the copies run TWO stages ahead (three
+  // U / raw buffers) and the wait that ends a stage is counted: it leaves this stage's own copies in flight.
+  // Order inside a stage (pinned with sched_barrier: left alone, hipcc re-uses the fragment registers and so puts
+  // every ds_read right in front of its MFMA): all 12 fragment reads, the 5 copies, the 8 raw reads of the transform;
+  // 16 MFMAs; the transform arithmetic + 2 V writes; 16 MFMAs; wait + barrier.
+  const int oy = y0 + 2 * w, ox = x0 + 2 * l15;
   const int64_t HWo = (int64_t)a.H * a.W;
   float* __restrict__ ob = a.out + (int64_t)b * a.obs;
   const float* __restrict__ rb = a.res ? a.res + (int64_t)b * a.rbs : nullptr;
-  const bool inx = ox < a.W;
+  float2 rres[GLU ? 1 : 2][4][2];                        // residual tile of this lane (plain epilogue)
+  auto load_res = [&]() {                                // issued before the last stage, consumed in the epilogue
+    if (!GLU) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            rres[cb][i][dy] = make_float2(0.f, 0.f);
+            if (rb && ox < a.W && oy + dy < a.H)
+              rres[cb][i][dy] = *reinterpret_cast<const float2*>(
+                  rb + (int64_t)(grp * 64 + h * 32 + cb * 16 + 4 * lg + i) * HWo + (int64_t)(oy + dy) * a.W + ox);
+          }
+    }
+  };
 
-  const int ulane = lg * 64 + l15 * 4;                   // A fragments: U[(pos*8 + 4*ks + lg)][l15*4 .. +3]
-  const int vlane = lg * 16 + l15;                       // B fragment:  V[(pos*8 + 4*ks + lg)][l15]
-
-  // One stage; MORE = a next stage exists (its U is fetched, its input transformed), MORE2 = so does the one after
-  // (its raw rows are fetched).  Compile-time so that the gaps hold straight-line code.
-  auto stage = [&](auto more_c, auto more2_c, int st) {
-    constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value;
+  int b3 = 0;                                            // st % 3
+  auto stage = [&](auto hc, auto more_c, auto more2_c, auto more3_c, int st) {
+    constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value, MORE3 = decltype(more3_c)::value;
     const int par = st & 1;
-    const float* ub = us + par * kWU + ulane;
+    const int b3n = b3 == 2 ? 0 : b3 + 1, b3p = b3 == 0 ? 2 : b3 - 1;     // (st+1) % 3, (st+2) % 3
+    const float* ub = us + b3 * kWU + ulane;
     const float* vb = vs + par * kWV + vlane;
-    const float* rawn = raws + (par ^ 1) * kWRaw;
-    float* vnxt = vs + (par ^ 1) * kWV;
-    f32x4v a0[3], a1[3];                                  // A fragments (4 cout blocks) of ks = 0 / 1; positions p, p+1, p+2
-    float b0[3], b1[3];
-    auto frag = [&](int p, int slot_) {
-      a0[slot_] = *reinterpret_cast<const f32x4v*>(ub + p * 8 * 64);
-      a1[slot_] = *reinterpret_cast<const f32x4v*>(ub + (p * 8 + 4) * 64);
-      b0[slot_] = vb[p * 8 * 16];
-      b1[slot_] = vb[(p * 8 + 4) * 16];
-    };
-    frag(0, 0);
-    frag(1, 1);
-#if defined(TGSR_WINO_EXP) && TGSR_WINO_EXP == 9
-    float dummy[4] = {1.f, 2.f, 3.f, 4.f};
-#endif
-    // Gaps of a position (after its MFMA g), at most ~4 instructions each so that the next MFMA issues on time:
-    //   1, 3: one transform micro-operation (LDS traffic)   4: the fragments of position p + 2
-    //   5, 7: one DMA piece (positions 0-5)
-    // LDS operations complete in order and the fragments are fetched two positions (12 MFMAs, ~400 cycles) ahead, so
-    // the counted lgkmcnt wait at a position's first MFMA never stalls, even with the 4 waves reading in lockstep.
-    auto tslot = [&](int n) {                            // transform(st+1): 32 micro-operations
-#if !defined(TGSR_WINO_EXP) || TGSR_WINO_EXP != 8
-      if (MORE && n < 32) t_op(n, rawn, vnxt);
-#endif
-    };
-    auto dslot = [&](int n) {                            // raw(st+2): kWIK pieces, U(st+1): kWUK pieces
-#if defined(TGSR_WINO_EXP) && TGSR_WINO_EXP == 7
-      if (false) {
-#else
-      if (MORE) {
-#endif
-        if (n < kWIK) { if (MORE2) issue_raw(n, par); }
-        else if (n < kWIK + kWUK) issue_u(n - kWIK, par ^ 1);
-      }
-    };
+    f32x4v af[8];
+    float2 bf[8];
+    float d[4][4];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      const int cur = p % 3, nxt = (p + 2) % 3;
+    for (int pp = 0; pp < 8; ++pp) {
+      af[pp] = *reinterpret_cast<const f32x4v*>(ub + pp * kWCK * 128);
+      bf[pp] = *reinterpret_cast<const float2*>(vb + pp * kWCK * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (MORE) t_read(hc, raws + b3n * kWRaw, d);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int ks = g >> 2, cb = g & 3;
-#if defined(TGSR_WINO_EXP) && TGSR_WINO_EXP == 6   // diagnostic: same stream with 4 MFMA 32x32x2 per position (wrong results)
-        if ((g & 1) == 0) MM[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ks ? a1[cur][cb] : a0[cur][cb], ks ? b1[cur] : b0[cur], MM[p], 0, 0, 0);
-#else
-        M[p][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ks ? a1[cur][cb] : a0[cur][cb], ks ? b1[cur] : b0[cur], M[p][cb],
-                                                        0, 0, 0);
-#endif
+    for (int pp = 0; pp < 8; ++pp) {
+      M[2 * pp][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pp][0], bf[pp].x, M[2 * pp][0], 0, 0, 0);
+      M[2 * pp][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pp][1], bf[pp].x, M[2 * pp][1], 0, 0, 0);
+      M[2 * pp + 1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pp][2], bf[pp].y, M[2 * pp + 1][0], 0, 0, 0);
+      M[2 * pp + 1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pp][3], bf[pp].y, M[2 * pp + 1][1], 0, 0, 0);
+      if (pp == 1 || pp == 5) {                          // the copies go where no LDS reads are queued
         __builtin_amdgcn_sched_barrier(0);
-#if defined(TGSR_WINO_EXP) && TGSR_WINO_EXP == 9   // diagnostic: 4 independent VALU instructions in every gap
-        asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3"
-                     : "+v"(dummy[0]), "+v"(dummy[1]), "+v"(dummy[2]), "+v"(dummy[3]));
-#endif
-        if (g == 1 || g == 3) {
-          tslot(p * 2 + (g >> 1));
-        } else if (g == 4) {
-          if (p + 2 < 16) frag(p + 2, nxt);
-        } else if (g == 5 || g == 7) {
-          dslot(p * 2 + ((g - 5) >> 1));
-        }
+        if (pp == 1 && MORE2) issue_u(b3p);              // U(st+2) replaces U(st-1)
+        if (pp == 5 && MORE3) issue_raw(b3);             // raw(st+3) replaces raw(st), consumed one stage ago
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (pp == 3) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (MORE) t_write(hc, d, vs + (par ^ 1) * kWV);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();   // U(st+1), raw(st+2) landed (vmcnt(0)) and visible; U(st) / V(st) / raw(st+1) may be overwritten
+    // U(st+1) and raw(st+2) (issued a stage ago) landed, V(st+1) written -> barrier; this stage's copies stay in flight
+    // (no LDS is reused after the last stage: no barrier there, and the residual tile prefetched before it stays in flight)
+    constexpr int kInFlight = (MORE2 ? kWUK : 0) + (MORE3 ? 1 : 0);
+    if (MORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
+    b3 = b3n;
   };
-  {
+  auto run = [&](auto hc) {
     using T = std::true_type;
     using F = std::false_type;
     int st = 0;
-#if defined(TGSR_WINO_EXP) && (TGSR_WINO_EXP == 1 || TGSR_WINO_EXP == 9)   // diagnostic: MFMAs + fragment reads only (results are wrong)
-    for (; st + 1 < a.nstages; ++st) stage(F{}, F{}, st);
+#if defined(TGSR_WINO_EXP)   // diagnostic builds (wrong results): 1 = MFMAs + fragment reads only, 2 = + transform, 3 = + copies
+    for (; st + 3 < a.nstages; ++st)
+      stage(hc, std::integral_constant<bool, TGSR_WINO_EXP == 2>{}, std::integral_constant<bool, TGSR_WINO_EXP == 3>{},
+            std::integral_constant<bool, TGSR_WINO_EXP == 3>{}, st);
 #endif
-    for (; st + 2 < a.nstages; ++st) stage(T{}, T{}, st);
-    if (st + 1 < a.nstages) stage(T{}, F{}, st++);
-    stage(F{}, F{}, st);
-  }
+    for (; st + 3 < a.nstages; ++st) stage(hc, T{}, T{}, T{}, st);
+    if (st + 2 < a.nstages) stage(hc, T{}, T{}, F{}, st++);
+    if (st + 1 < a.nstages) stage(hc, T{}, F{}, F{}, st++);
+    load_res();
+    stage(hc, F{}, F{}, F{}, st);
+  };
+  if (h) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
   TGSR_WSTAMP(2);
-#if defined(TGSR_WINO_EXP) && TGSR_WINO_EXP == 6
-#pragma unroll
-  for (int p = 0; p < 16; ++p)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) M[p][i >> 2][i & 3] = MM[p][i];
-#endif
 
-  // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + epilogue; lane = tile (l15), registers of
-  // block cb = couts cb*16 + 4*lg + i; the two column phases of a tile leave as one float2
+  // ---- output transform Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) + epilogue; lane = tile (l15), register i of
+  // block cb = cout cb*16 + 4*lg + i of this wave's half; the two column phases of a tile leave as one float2
   auto ytile = [&](int cb, int i, float (&y)[2][2]) {
     float rr[4][2];                                      // M A: per transformed row r, the two output columns
 #pragma unroll
@@ -318,42 +305,40 @@ __global__ __launch_bounds__(256, 1) void wino_conv3x3_kernel(WinoArgs a) {
       y[1][dx] = rr[1][dx] - rr[2][dx] - rr[3][dx];
     }
   };
-  if (inx) {
-#pragma unroll
-    for (int cb = 0; cb < (GLU ? 2 : 4); ++cb) {
-      float2 rres[4][2];                                 // residual of this block: all 8 loads in flight together
-      if (!GLU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            rres[i][dy] = make_float2(0.f, 0.f);
-            if (rb && oy + dy < a.H)
-              rres[i][dy] = *reinterpret_cast<const float2*>(rb + (int64_t)(grp * 64 + cb * 16 + 4 * lg + i) * HWo +
-                                                             (int64_t)(oy + dy) * a.W + ox);
-          }
-      }
+  if (ox < a.W) {
+    if (GLU) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int lc = cb * 16 + 4 * lg + i;             // logical column of the value (or plain) channel
+        const int lc = h * 32 + 4 * lg + i;              // value column; its gate is lc + 16
         float yv[2][2], yg[2][2];
-        ytile(cb, i, yv);
-        if (GLU) ytile(cb + 2, i, yg);
-        const float sv = aff_s[lc], tv = aff_s[64 + lc];
-        const float sg = GLU ? aff_s[32 + lc] : 0.f, tg = GLU ? aff_s[64 + 32 + lc] : 0.f;
-        const int c = GLU ? grp * 32 + lc : grp * 64 + lc;
+        ytile(0, i, yv);
+        ytile(1, i, yg);
+        const float sv = aff_s[lc], tv = aff_s[64 + lc], sg = aff_s[lc + 16], tg = aff_s[64 + lc + 16];
+        const int c = grp * 32 + h * 16 + 4 * lg + i;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
           if (oy + dy >= a.H) continue;
-          float o0 = yv[dy][0] * sv + tv, o1 = yv[dy][1] * sv + tv;
-          if (GLU) {
-            o0 *= __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][0] * sg + tg)));
-            o1 *= __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][1] * sg + tg)));
-          } else {
-            o0 += rres[i][dy].x;
-            o1 += rres[i][dy].y;
-          }
+          const float o0 = (yv[dy][0] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][0] * sg + tg)));
+          const float o1 = (yv[dy][1] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][1] * sg + tg)));
           *reinterpret_cast<float2*>(ob + (int64_t)c * HWo + (int64_t)(oy + dy) * a.W + ox) = make_float2(o0, o1);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int lc = h * 32 + cb * 16 + 4 * lg + i;
+          float yv[2][2];
+          ytile(cb, i, yv);
+          const float sv = aff_s[lc], tv = aff_s[64 + lc];
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            if (oy + dy >= a.H) continue;
+            const float o0 = yv[dy][0] * sv + tv + rres[cb][i][dy].x, o1 = yv[dy][1] * sv + tv + rres[cb][i][dy].y;
+            *reinterpret_cast<float2*>(ob + (int64_t)(grp * 64 + lc) * HWo + (int64_t)(oy + dy) * a.W + ox) =
+                make_float2(o0, o1);
+          }
         }
       }
     }
@@ -361,23 +346,23 @@ __global__ __launch_bounds__(256, 1) void wino_conv3x3_kernel(WinoArgs a) {
   TGSR_WSTAMP(3);
 }
 
-// upack[stage][group][pos 16][ci 8][64] <- U = G g G^T, pos = i * 4 + j of the 4x4 transformed filter; a group is
-// the 64 output channels of one workgroup (GLU: 32 value + the 32 matching gate channels), stored interleaved:
-// position 4*l + cb holds the group's logical column cb*16 + l.
+// upack[stage][group][pos pair 8][ci 4][cout half 2][16][4] <- U = G g G^T.  A group is the 64 output channels of one
+// workgroup; element q of a 4-vector = position 2*pp + (q >> 1), cout block q & 1 of the half (GLU: block 0 = value
+// channels grp*32 + half*16 + l, block 1 = their gates Cout/2 + ...; plain: grp*64 + half*32 + block*16 + l).
 __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu,
                                         int64_t total) {
   const int ngrp = Cout / 64;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(idx & 63);
-    int64_t t = idx >> 6;
+    const int q = (int)(idx & 3), l = (int)((idx >> 2) & 15), hh = (int)((idx >> 6) & 1);
+    int64_t t = idx >> 7;
     const int ci = (int)(t % kWCK);
     t /= kWCK;
-    const int pos = (int)(t % 16);
-    t /= 16;
+    const int pp = (int)(t % 8);
+    t /= 8;
     const int grp = (int)(t % ngrp);
     const int st = (int)(t / ngrp);
-    const int lc = (q & 3) * 16 + (q >> 2);
-    const int co = glu ? (lc < 32 ? grp * 32 + lc : (Cout >> 1) + grp * 32 + lc - 32) : grp * 64 + lc;
+    const int pos = 2 * pp + (q >> 1), cb = q & 1;
+    const int co = glu ? (cb ? (Cout >> 1) : 0) + grp * 32 + hh * 16 + l : grp * 64 + hh * 32 + cb * 16 + l;
     const int c = st * kWCK + ci;
     float u = 0.f;
     if (c < Cin) {
@@ -435,9 +420,13 @@ extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, i
   WinoArgs a;
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
   a.scale = scale; a.shift = shift; a.res = residual; a.rbs = res_bstride; a.out = out; a.obs = out_bstride;
-  a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 7) / 8; a.nstages = (Cin + kWCK - 1) / kWCK;
+  a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 3) / 4; a.nstages = (Cin + kWCK - 1) / kWCK;
   dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y), (unsigned)(Cout / 64));
-  if (glu) hipLaunchKernelGGL(wino_conv3x3_kernel<true>, grid, dim3(256), 0, as_stream(stream), a);
-  else hipLaunchKernelGGL(wino_conv3x3_kernel<false>, grid, dim3(256), 0, as_stream(stream), a);
+  size_t dyn = 0;
+#ifdef TGSR_WINO_STAMPS
+  if (const char* e = getenv("TGSR_WINO_DYN")) dyn = (size_t)atoi(e);   // diagnostic: extra LDS to force 1 workgroup per CU
+#endif
+  if (glu) hipLaunchKernelGGL(wino_conv3x3_kernel<true>, grid, dim3(256), dyn, as_stream(stream), a);
+  else hipLaunchKernelGGL(wino_conv3x3_kernel<false>, grid, dim3(256), dyn, as_stream(stream), a);
   return note_launch(hipGetLastError(), "wino_conv3x3_kernel");
 }

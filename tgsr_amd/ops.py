@@ -124,10 +124,17 @@ def pack_wino_weight(w: torch.Tensor, glu: bool = False) -> torch.Tensor:
     return out
 
 
-def wino_supported(x: torch.Tensor, cout: int) -> bool:
-    """Shapes the Winograd kernel takes: Cout % 64 == 0, Cin % 8 == 0, width % 4 == 0, 16-byte aligned planes."""
-    return (cout % 64 == 0 and x.shape[1] % 8 == 0 and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and
-            (x.shape[0] == 1 or x.stride(0) % 4 == 0))
+def wino_supported(x: torch.Tensor, cout: int, out: Optional[torch.Tensor] = None,
+                   residual: Optional[torch.Tensor] = None) -> bool:
+    """Shapes the Winograd kernel takes: Cout % 64 == 0, Cin % 4 == 0, width % 4 == 0, x planes 16-byte aligned,
+    out / residual 8-byte aligned with even batch strides."""
+    if not (x.dim() == 4 and cout % 64 == 0 and x.shape[1] % 4 == 0 and x.shape[3] % 4 == 0 and
+            x.data_ptr() % 16 == 0 and (x.shape[0] == 1 or x.stride(0) % 4 == 0)):
+        return False
+    for t in (out, residual):
+        if t is not None and (t.data_ptr() % 8 != 0 or (t.shape[0] > 1 and t.stride(0) % 2 != 0)):
+            return False
+    return True
 
 
 def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, glu: bool = False,

@@ -8,6 +8,8 @@ folded into the conv, fused word attention, BiLSTM kernels).  `.eval()` modules 
 (BatchNorm folded to an affine, no autograd graph); `.train()` modules take the training path of
 `tgsr_amd.autograd` (batch-statistics BatchNorm, running-stat updates, HIP backward kernels).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -21,25 +23,41 @@ def _ver(*ts):
     return tuple((t.data_ptr(), t._version, t.device) for t in ts if t is not None)
 
 
+# Inference convolutions without upsampling go through the Winograd F(2x2,3x3) kernel where it applies
+# (ops.wino_supported: Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0); TGSR_WINOGRAD=0 keeps the direct kernel everywhere.
+WINOGRAD = os.environ.get("TGSR_WINOGRAD", "1") != "0"
+
+
 class _FusedParams:
     """Packed conv weight + folded BN affine for one conv(+bn) pair, rebuilt when any source tensor changes
-    (load_state_dict / optimizer step / .cuda())."""
+    (load_state_dict / optimizer step / .cuda()).  The direct and the Winograd packs are built on first use."""
 
     def __init__(self):
         self.key = None
-        self.wpack = self.scale = self.shift = None
+        self.wpack = self.upack = self.scale = self.shift = None
 
-    def get(self, conv: nn.Conv2d, bn):
+    def _refresh(self, conv: nn.Conv2d, bn):
         src = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
         key = _ver(*src)
         if key != self.key:
-            self.wpack = ops.pack_conv3x3_weight(conv.weight)
+            self.wpack = self.upack = None
             if bn is not None:
                 self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             else:
                 self.scale = self.shift = None
             self.key = key
+
+    def get(self, conv: nn.Conv2d, bn):
+        self._refresh(conv, bn)
+        if self.wpack is None:
+            self.wpack = ops.pack_conv3x3_weight(conv.weight)
         return self.wpack, self.scale, self.shift
+
+    def get_wino(self, conv: nn.Conv2d, bn, glu: bool):
+        self._refresh(conv, bn)
+        if self.upack is None:
+            self.upack = ops.pack_wino_weight(conv.weight, glu=glu)
+        return self.upack, self.scale, self.shift
 
 
 def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=None, out=None, training=False):
@@ -51,6 +69,9 @@ def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=
         if out is not None:
             raise RuntimeError("training path does not write into channel-slice views")
         return y
+    if WINOGRAD and not upsample and ops.wino_supported(x, conv.out_channels, out=out, residual=residual):
+        upack, scale, shift = fp.get_wino(conv, bn, glu)
+        return ops.conv3x3_wino(x, upack, conv.out_channels, scale, shift, glu=glu, residual=residual, out=out)
     wpack, scale, shift = fp.get(conv, bn)
     return ops.conv3x3_fused(x, wpack, conv.out_channels, scale, shift, glu=glu, upsample=upsample,
                              residual=residual, out=out)

@@ -31,7 +31,7 @@ def run(B, cin, cout, h, glu, res):
     n = 8 * 8192
     buf = (ctypes.c_ulonglong * n)()
     assert L.tgsr_debug_read_wstamps(buf, n) == 0
-    nwg = B * ((h + 31) // 32) * ((h + 7) // 8) * (cout // 64)
+    nwg = B * ((h + 31) // 32) * ((h + 3) // 4) * (cout // 64)
     s = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8).astype(np.int64)[:min(nwg, 8192)]
     s = s[(s[:, 3] > s[:, 0]) & (s[:, 7] > s[:, 6])]
     clk = (s[:, 3] - s[:, 0]) / np.maximum(1, (s[:, 7] - s[:, 6])) * 100e6
@@ -40,7 +40,7 @@ def run(B, cin, cout, h, glu, res):
     st_ns = (s[:, 6] - rt0) * 10; en_ns = (s[:, 7] - rt0) * 10
     print("WINO B%d %d->%d @%d glu%d res%d: %.1f us, %d WGs; clock %.3f GHz; cycles/WG: prologue %d  main %d (%d/stage)  epilogue %d ; span %d ns"
           % (B, cin, cout, h, glu, res, e0.elapsed_time(e1) * 1e3, len(s), np.median(clk) / 1e9, np.median(pro), np.median(main),
-             np.median(main) / ((cin + 7) // 8), np.median(epi), span))
+             np.median(main) / ((cin + 3) // 4), np.median(epi), span))
     print("   WG start ns pct 10/50/90/100: %s   end ns pct 10/50/90/100: %s" % (
         np.percentile(st_ns, [10, 50, 90, 100]).astype(int), np.percentile(en_ns, [10, 50, 90, 100]).astype(int)))
 if __name__ == "__main__":
