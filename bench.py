@@ -10,7 +10,7 @@ independent images, no data-path collective - SURVEY.md 8e); `value` = all image
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = conv3x3_mfma_kernel, per-launch HIP-event
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant 3x3-conv kernel by time, per-launch HIP-event
 timing inside the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores, rank 0, N=1 only).
 """
 import argparse
@@ -27,9 +27,14 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per conv3x3_mfma_kernel launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes, FETCH_SIZE doubled per MI355X_MICROARCH.md, averaged over the 36 launches of a step); None until measured.
-TRAFFIC_PER_LAUNCH_BYTES = {"conv3x3_mfma_kernel": 45.90e6}   # profiles/r01_c_pmc_hbm_traffic.csv (algorithmic: 44.58e6)
+# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
+# doubled per MI355X_MICROARCH.md, averaged over that kernel's launches of a step); None until measured.
+TRAFFIC_PER_LAUNCH_BYTES = {
+    "conv3x3_mfma_kernel": 45.90e6,   # profiles/r01_c_pmc_hbm_traffic.csv, 36-launch mix (algorithmic: 44.58e6)
+    "wino_conv3x3_kernel": 59.42e6,   # profiles/r01_i_pmc_hbm_traffic.csv, 20-launch mix (algorithmic: 49.65e6; the
+                                      # input is read once per 64-cout group)
+    "upconv_glu_mfma_kernel": 84.01e6,   # same file (algorithmic: 80.9e6)
+}
 # share of the direct-form multiplies a kernel actually issues (Winograd F(2x2,3x3): 16/36; sub-pixel upBlock: 4/9)
 EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "upconv_glu_mfma_kernel": 4.0 / 9.0}
 
