@@ -282,6 +282,15 @@ def main():
                           "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world,
                           "streams": 1 if args.serial else 2},
                "roofline": roof, "kernels": kern}
+        if "word_attention_kernel" in agg:
+            # BASELINE.json's metric also asks for the attention batched-GEMM's MFMA utilisation: the op is HBM-bound
+            # (AI ~ 7 FLOP/B), so both fractions are reported (flops = 4*B*Q*idf*T for the two GEMMs, bytes = h in,
+            # c_code + attn out)
+            n, fl, by, sec = agg["word_attention_kernel"]
+            res["attention"] = {"kernel": "word_attention_kernel", "bound": "hbm", "launches_per_step": n // nprof,
+                                "ms_per_step": round(sec / nprof * 1e3, 4),
+                                "mfma_util_pct": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS * 100, 2),
+                                "hbm_GBs": round(by / sec / 1e9, 1), "hbm_frac": round(by / sec / 1e9 / PEAK_HBM_GBS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(weights, B)
         print(json.dumps(res), flush=True)

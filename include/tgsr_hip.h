@@ -122,12 +122,21 @@ int tgsr_conv_to3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, 
  * mask     NULL or uint8 [B][T], non-zero = padded word (captions == 0, trainer_objective.py:136-140)
  * mask_mode 0 = reference behaviour: score row b*Q+q is masked with mask[(b*Q+q) % B]
  *               (`mask.repeat(queryL,1)`, GlobalAttention.py:111); 1 = per-sample masking (mask[b])
- * src_ws   workspace, B*idf*32 floats (the projected words, zero padded to 32)
+ * src_ws   workspace, B*idf*32 floats (the projected words, zero padded to 32).  With words == w_ctx == NULL the
+ *          projection is skipped and src_ws is read as the output of tgsr_word_project_fwd.
  * c_code   [B][idf][Q] (batch stride c_bstride);  attn [B][T][Q] dense (may be NULL: not written)
  */
 int tgsr_word_attention_fwd(const float* h, int64_t h_bstride, const float* words, const float* w_ctx,
                             const uint8_t* mask, int mask_mode, int B, int idf, int cdf, int T, int Q, float* src_ws,
                             float* c_code, int64_t c_bstride, float* attn, void* stream);
+
+/*
+ * The projection alone, for up to 4 conv_context weight sets over the same words in one launch (the generator's
+ * stages share the word embeddings): src_out[set][B][idf][32] = w_ctx[set] [idf][cdf] x words [B][cdf][T], zero padded
+ * to 32 words.  w_ctx: HOST array of nsets device pointers.  idf % 32 == 0, T <= 32.
+ */
+int tgsr_word_project_fwd(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf, int T,
+                          float* src_out, void* stream);
 
 /*
  * Bidirectional 1-layer LSTM text encoder, eval mode (RNN_ENCODER.forward util.py:233-260: Embedding ->

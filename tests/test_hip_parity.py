@@ -211,6 +211,26 @@ def test_word_attention_vs_oracle(B, idf, r, T_, correct):
     close(s, torch.ones_like(s), atol=1e-5)
 
 
+@pytest.mark.parametrize("B,idf,cdf,T_,n", [(16, 32, 256, 18, 3), (3, 64, 100, 7, 1), (2, 128, 37, 32, 4)])
+def test_word_project_batched(B, idf, cdf, T_, n):
+    """One-launch projection for several conv_context weight sets == conv1x1 per set; attention through `src=`."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B + idf + cdf)
+    words = torch.randn(B, cdf, T_, generator=g)
+    ws = [torch.randn(idf, cdf, 1, 1, generator=g) / cdf ** 0.5 for _ in range(n)]
+    srcs = ops.word_project(words.to(DEV), [w.to(DEV) for w in ws])
+    for w, src in zip(ws, srcs):
+        ref = torch.einsum("ic,bct->bit", w.reshape(idf, cdf).double(), words.double()).float()
+        close(src[:, :, :T_], ref, atol=2e-5, rtol=1e-5)
+        assert float(src[:, :, T_:].abs().max()) == 0.0 if T_ < 32 else True
+    h = torch.randn(B, idf, 8, 16, generator=g)
+    mask = torch.arange(T_)[None, :] >= torch.randint(1, T_ + 1, (B, 1), generator=g)
+    o0, a0 = ops.word_attention(h.to(DEV), words.to(DEV), ws[-1].to(DEV), mask.to(DEV))
+    o1, a1 = ops.word_attention(h.to(DEV), words.to(DEV), ws[-1].to(DEV), mask.to(DEV), src=srcs[-1])
+    close(o1, o0.cpu(), atol=2e-5, rtol=1e-4)
+    close(a1, a0.cpu(), atol=2e-6, rtol=1e-4)
+
+
 def test_bilstm_golden(ops_small):
     from tgsr_amd import ops
     g = ops_small

@@ -23,6 +23,7 @@ class GlobalAttentionGeneral(nn.Module):
         self.conv_context = conv1x1(cdf, idf)
         self.mask = None
         self.correct_mask = correct_mask
+        self._src = None     # projection of the words for the next forward (G_SR_NET_low batches its stages' projections)
 
     def applyMask(self, mask):
         self.mask = mask  # batch x sourceL
@@ -35,7 +36,9 @@ class GlobalAttentionGeneral(nn.Module):
             if out is not None:
                 raise RuntimeError("training path does not write into channel-slice views")
             return WordAttention.apply(input, context, self.conv_context.weight, self.mask, self.correct_mask)
-        return ops.word_attention(input, context, self.conv_context.weight, self.mask, self.correct_mask, out=out)
+        src, self._src = self._src, None
+        return ops.word_attention(input, context, self.conv_context.weight, self.mask, self.correct_mask, out=out,
+                                  src=src)
 
 
 def func_attention(query, context, gamma1):

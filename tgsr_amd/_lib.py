@@ -33,6 +33,7 @@ SIGNATURES = {
     "tgsr_wino_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
     "tgsr_conv_to3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),
     "tgsr_word_attention_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp]),
+    "tgsr_word_project_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "tgsr_bilstm_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "tgsr_lstm_gate_table": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "tgsr_bilstm_table_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),

@@ -46,6 +46,51 @@ __global__ __launch_bounds__(256) void word_project_kernel(const float* __restri
   src[((int64_t)b * idf + i) * 32 + t] = acc;
 }
 
+// The same projection on the MFMA units for up to 4 weight sets in ONE launch (the generator stages attend to the same
+// words through different conv_context weights): grid (B, nsets, idf / 32), 4 waves, each a quarter of the channel
+// pairs of src[i][t] = sum_c W[i][c] words[c][t] (A = W, lane = i; B = words, lane = t), summed through LDS.
+struct ProjArgs {
+  const float* words;
+  const float* w[4];
+  float* out;            // [nsets][B][idf][32]
+  int B, idf, cdf, T;
+};
+
+__global__ __launch_bounds__(256) void word_project_mfma_kernel(ProjArgs a) {
+  __shared__ float red[4][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5, wave = tid >> 6;
+  const int b = blockIdx.x, set = blockIdx.y, ib = blockIdx.z;
+  const float* wr = a.w[set] + (int64_t)(ib * 32 + l31) * a.cdf;
+  const float* wb = a.words + (int64_t)b * a.cdf * a.T;
+  const bool tok = l31 < a.T;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int nk = (a.cdf + 1) >> 1;
+  for (int ks = wave; ks < nk; ks += 32) {               // 8 k-steps of this wave per trip: their loads go out together
+    float av[8], bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = 2 * (ks + 4 * j) + hh;
+      const bool ok = ks + 4 * j < nk && c < a.cdf;
+      av[j] = ok ? wr[c] : 0.f;
+      bv[j] = ok && tok ? wb[c * a.T + l31] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  float* ob = a.out + ((int64_t)(set * a.B + b) * a.idf + ib * 32) * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = tid + 256 * j, r = o >> 6, ln = o & 63;
+    const float v = red[0][r][ln] + red[1][r][ln] + red[2][r][ln] + red[3][r][ln];
+    ob[acc_row(r, ln >> 5) * 32 + (ln & 31)] = v;
+  }
+}
+
 struct AttnArgs {
   const float* h;
   int64_t hbs;
@@ -67,7 +112,6 @@ __global__ __launch_bounds__(256) void word_attention_kernel(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = tid >> 6;
   const int b = blockIdx.y;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
 
   const float* sb = a.src + (int64_t)b * IDF * 32;
   for (int o = tid; o < IDF * 32; o += 256) {
@@ -82,83 +126,104 @@ __global__ __launch_bounds__(256) void word_attention_kernel(AttnArgs a) {
     mbits_s[r] = m;
   }
   __syncthreads();
-  if (q0 >= a.Q) return;
 
-  const int q = q0 + l31;
-  const bool qok = q < a.Q;
+  // A wave walks over 32-pixel tiles (stride = waves of the sample's workgroups): the staging above is paid once per
+  // workgroup, and the h rows of the next tile are in flight while this one is computed.
+  const int ntiles = (a.Q + 31) >> 5, tstride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
   const float* hb = a.h + (int64_t)b * a.hbs;
-
-  // ---- GEMM1: S[t][q], k = channel pairs
-  f32x16 s;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] = 0.f;
+  float* cb = a.c_code + (int64_t)b * a.cbs;
   float hv[IDF / 2];
+  {
+    const int q = tile * 32 + l31;
 #pragma unroll
-  for (int k = 0; k < IDF / 2; ++k) hv[k] = qok ? hb[(int64_t)(2 * k + hh) * a.Q + q] : 0.f;
-#pragma unroll
-  for (int k = 0; k < IDF / 2; ++k) {
-    const float av = src_s[(2 * k + hh) * 32 + l31];
-    s = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[k], s, 0, 0, 0);
+    for (int k = 0; k < IDF / 2; ++k) hv[k] = q < a.Q ? hb[(int64_t)(2 * k + hh) * a.Q + q] : 0.f;
   }
-
-  // ---- mask + softmax over words (rows of S: 16 in this lane, 16 in lane ^ 32)
-  unsigned mb = 0;
-  if (a.mask) {
-    int mrow = a.mask_mode ? b : (int)(((int64_t)b * a.Q + q) % a.B);   // GlobalAttention.py:111 mask.repeat(queryL,1)
-    if (mrow < 256) {
-      mb = mbits_s[mrow];
-    } else {
-      for (int t = 0; t < a.T; ++t) mb |= (a.mask[mrow * a.T + t] ? 1u : 0u) << t;
+  while (tile < ntiles) {
+    const int q = tile * 32 + l31;
+    const bool qok = q < a.Q;
+    const int tnext = tile + tstride;
+    float hn[IDF / 2];
+    {
+      const int qn = tnext * 32 + l31;
+      const bool nok = tnext < ntiles && qn < a.Q;
+#pragma unroll
+      for (int k = 0; k < IDF / 2; ++k) hn[k] = nok ? hb[(int64_t)(2 * k + hh) * a.Q + qn] : 0.f;
     }
-  }
-  const unsigned valid = (a.T >= 32 ? 0xffffffffu : ((1u << a.T) - 1u)) & ~mb;
-  float mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int t = acc_row(i, hh);
-    if (!((valid >> t) & 1u)) s[i] = -INFINITY;
-    mx = fmaxf(mx, s[i]);
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    s[i] = __expf(s[i] - mx);   // exp(-inf) = 0 for masked / padded words
-    sum += s[i];
-  }
-  sum += __shfl_xor(sum, 32);
-  const float inv = 1.f / sum;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s[i] *= inv;
 
-  if (a.attn && qok) {
-    float* ab = a.attn + (int64_t)b * a.T * a.Q + q;
+    // ---- GEMM1: S[t][q], k = channel pairs
+    f32x16 s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < IDF / 2; ++k) {
+      const float av = src_s[(2 * k + hh) * 32 + l31];
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hv[k], s, 0, 0, 0);
+    }
+
+    // ---- mask + softmax over words (rows of S: 16 in this lane, 16 in lane ^ 32)
+    unsigned mb = 0;
+    if (a.mask) {
+      int mrow = a.mask_mode ? b : (int)(((int64_t)b * a.Q + q) % a.B);   // GlobalAttention.py:111 mask.repeat(queryL,1)
+      if (mrow < 256) {
+        mb = mbits_s[mrow];
+      } else {
+        for (int t = 0; t < a.T; ++t) mb |= (a.mask[mrow * a.T + t] ? 1u : 0u) << t;
+      }
+    }
+    const unsigned valid = (a.T >= 32 ? 0xffffffffu : ((1u << a.T) - 1u)) & ~mb;
+    float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int t = acc_row(i, hh);
-      if (t < a.T) ab[(int64_t)t * a.Q] = s[i];
+      if (!((valid >> t) & 1u)) s[i] = -INFINITY;
+      mx = fmaxf(mx, s[i]);
     }
-  }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] = __expf(s[i] - mx);   // exp(-inf) = 0 for masked / padded words
+      sum += s[i];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] *= inv;
 
-  // ---- GEMM2: C[i][q] = sum_t src[i][t] P[t][q]; k-step r pairs words t0 = acc_row(r,0) and t0 + 4 (= this lane
-  // half's own register r), so P never leaves the accumulator registers.
-  float* cb = a.c_code + (int64_t)b * a.cbs;
+    if (a.attn && qok) {
+      float* __restrict__ ab = a.attn + (int64_t)b * a.T * a.Q + q;
 #pragma unroll
-  for (int blk = 0; blk < NI; ++blk) {
-    f32x16 c;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (acc_row(r, 0) < a.T) {   // wave-uniform; words >= T have P = 0 anyway
-        const float av = srcT_s[acc_row(r, hh) * IDF + blk * 32 + l31];
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[r], c, 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        const int t = acc_row(i, hh);
+        if (t < a.T) ab[(int64_t)t * a.Q] = s[i];
       }
     }
-    if (qok) {
+
+    // ---- GEMM2: C[i][q] = sum_t src[i][t] P[t][q]; k-step r pairs words t0 = acc_row(r,0) and t0 + 4 (= this lane
+    // half's own register r), so P never leaves the accumulator registers.
 #pragma unroll
-      for (int i = 0; i < 16; ++i) cb[(int64_t)(blk * 32 + acc_row(i, hh)) * a.Q + q] = c[i];
+    for (int blk = 0; blk < NI; ++blk) {
+      f32x16 c;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) c[i] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (acc_row(r, 0) < a.T) {   // wave-uniform; words >= T have P = 0 anyway
+          const float av = srcT_s[acc_row(r, hh) * IDF + blk * 32 + l31];
+          c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[r], c, 0, 0, 0);
+        }
+      }
+      if (qok) {
+        float* __restrict__ cq = cb + q;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cq[(int64_t)(blk * 32 + acc_row(i, hh)) * a.Q] = c[i];
+      }
     }
+#pragma unroll
+    for (int k = 0; k < IDF / 2; ++k) hv[k] = hn[k];
+    tile = tnext;
   }
 }
 
@@ -169,20 +234,40 @@ using namespace tgsr;
 extern "C" int tgsr_word_attention_fwd(const float* h, int64_t h_bstride, const float* words, const float* w_ctx,
                                        const uint8_t* mask, int mask_mode, int B, int idf, int cdf, int T, int Q,
                                        float* src_ws, float* c_code, int64_t c_bstride, float* attn, void* stream) {
-  if (!h || !words || !w_ctx || !src_ws || !c_code || B < 1 || cdf < 1 || Q < 1 || T < 1) return TGSR_EINVAL;
+  if (!h || !src_ws || !c_code || B < 1 || cdf < 1 || Q < 1 || T < 1) return TGSR_EINVAL;
+  if ((words == nullptr) != (w_ctx == nullptr)) return TGSR_EINVAL;
   if (T > 32 || (idf != 32 && idf != 64 && idf != 128)) return TGSR_EUNSUPPORTED;
   hipStream_t s = as_stream(stream);
-  if (cdf > 1024) return TGSR_EUNSUPPORTED;   // words of one sample are staged in LDS (cdf * 128 bytes)
-  hipLaunchKernelGGL(word_project_kernel, dim3(B, idf / 8), dim3(256), (size_t)cdf * 32 * sizeof(float), s, words,
-                     w_ctx, src_ws, idf, cdf, T);
-  int rc = note_launch(hipGetLastError(), "word_project_kernel");
-  if (rc) return rc;
+  if (words) {   // else: src_ws already holds the projection (tgsr_word_project_fwd)
+    if (cdf > 1024) return TGSR_EUNSUPPORTED;   // words of one sample are staged in LDS (cdf * 128 bytes)
+    hipLaunchKernelGGL(word_project_kernel, dim3(B, idf / 8), dim3(256), (size_t)cdf * 32 * sizeof(float), s, words,
+                       w_ctx, src_ws, idf, cdf, T);
+    int rc = note_launch(hipGetLastError(), "word_project_kernel");
+    if (rc) return rc;
+  }
   AttnArgs a;
   a.h = h; a.hbs = h_bstride; a.src = src_ws; a.mask = mask; a.mask_mode = mask_mode;
   a.B = B; a.T = T; a.Q = Q; a.c_code = c_code; a.cbs = c_bstride; a.attn = attn;
-  dim3 grid((Q + 127) / 128, B);
+  // enough workgroups to fill the chip (~4 per CU over the batch), each walking over several 128-pixel tiles
+  int gx = (Q + 127) / 128;
+  const int cap = (1024 + B - 1) / B;
+  if (gx > cap) gx = cap;
+  dim3 grid(gx, B);
   if (idf == 32) hipLaunchKernelGGL(word_attention_kernel<1>, grid, dim3(256), 0, s, a);
   else if (idf == 64) hipLaunchKernelGGL(word_attention_kernel<2>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(word_attention_kernel<4>, grid, dim3(256), 0, s, a);
   return note_launch(hipGetLastError(), "word_attention_kernel");
+}
+
+extern "C" int tgsr_word_project_fwd(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf,
+                                     int T, float* src_out, void* stream) {
+  if (!words || !w_ctx || !src_out || nsets < 1 || B < 1 || cdf < 1 || T < 1) return TGSR_EINVAL;
+  if (nsets > 4 || T > 32 || idf < 32 || (idf & 31)) return TGSR_EUNSUPPORTED;
+  ProjArgs a;
+  a.words = words; a.out = src_out; a.B = B; a.idf = idf; a.cdf = cdf; a.T = T;
+  for (int i = 0; i < 4; ++i) a.w[i] = i < nsets ? w_ctx[i] : nullptr;
+  for (int i = 0; i < nsets; ++i)
+    if (!a.w[i]) return TGSR_EINVAL;
+  hipLaunchKernelGGL(word_project_mfma_kernel, dim3(B, nsets, idf / 32), dim3(256), 0, as_stream(stream), a);
+  return note_launch(hipGetLastError(), "word_project_mfma_kernel");
 }

@@ -34,6 +34,11 @@ class G_SR_NET_low(nn.Module):
     def forward(self, LR, sent_emb, word_embs, mask, outmiddle=False):
         fake_imgs, att_maps = [], []
         c_code, mu, logvar = self.ca_net(sent_emb)          # c_code unused downstream (model.py:51-52)
+        if not self.training:
+            # the three stages attend to the same words: their conv_context projections go out as one launch
+            atts = [self.h_net1.att, self.h_net2.att, self.h_net3.att]
+            for att, src in zip(atts, ops.word_project(word_embs, [a.conv_context.weight for a in atts])):
+                att._src = src
         h_code1, att0 = self.h_net1(None, LR, word_embs, mask, wide_out=True)
         fake_imgs.append(self.img_net1(h_code1))
         att_maps.append(att0)

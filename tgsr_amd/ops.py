@@ -235,10 +235,29 @@ def _mask_u8(mask: torch.Tensor) -> torch.Tensor:
     return _MASK_CACHE[2]
 
 
+def word_project(words: torch.Tensor, w_ctxs) -> list:
+    """The conv1x1 of GlobalAttentionGeneral (GlobalAttention.py:100-102) for up to 4 weight sets over the same words in
+    one launch: words [B,cdf,T], w_ctxs = list of [idf,cdf(,1,1)] -> list of src [B,idf,32] (zero padded words),
+    to be handed to word_attention(src=...)."""
+    import ctypes
+    _need_hip(words, *w_ctxs)
+    words = _f32(words, "words").contiguous()
+    B, cdf, T = words.shape
+    n = len(w_ctxs)
+    idf = w_ctxs[0].shape[0]
+    ws = [_f32(w.detach(), "w_ctx").reshape(idf, cdf).contiguous() for w in w_ctxs]
+    out = torch.empty(n, B, idf, 32, dtype=torch.float32, device=words.device)
+    ptrs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    check(_lib.lib().tgsr_word_project_fwd(_p(words), ptrs, n, B, idf, cdf, T, _p(out), _stream()),
+          "tgsr_word_project_fwd")
+    return [out[i] for i in range(n)]
+
+
 def word_attention(h: torch.Tensor, words: torch.Tensor, w_ctx: torch.Tensor, mask: Optional[torch.Tensor],
-                   correct_mask: bool = False, out: Optional[torch.Tensor] = None, need_attn: bool = True):
+                   correct_mask: bool = False, out: Optional[torch.Tensor] = None, need_attn: bool = True,
+                   src: Optional[torch.Tensor] = None):
     """GlobalAttentionGeneral.forward: h [B,idf,ih,iw], words [B,cdf,T], w_ctx [idf,cdf(,1,1)], mask bool [B,T].
-    Returns (c_code [B,idf,ih,iw], attn [B,T,ih,iw])."""
+    Returns (c_code [B,idf,ih,iw], attn [B,T,ih,iw]).  `src` = this layer's word_project output (skips the projection)."""
     _need_hip(h, words, w_ctx, mask, out)
     h, hbs = _nchw_bstride(_f32(h, "h"), "h")
     B, idf, ih, iw = h.shape
@@ -257,9 +276,14 @@ def word_attention(h: torch.Tensor, words: torch.Tensor, w_ctx: torch.Tensor, ma
         raise TgsrError("word_attention: bad `out`")
     cbs = out.stride(0) if B > 1 else idf * Q
     attn = torch.empty(B, T, ih, iw, dtype=torch.float32, device=h.device) if need_attn else None
-    ws = torch.empty(B * idf * 32, dtype=torch.float32, device=h.device)
+    if src is not None:
+        if tuple(src.shape) != (B, idf, 32) or not src.is_contiguous():
+            raise TgsrError("word_attention: bad `src` %s" % (tuple(src.shape),))
+        ws, wp, w2p = src, None, None
+    else:
+        ws, wp, w2p = torch.empty(B * idf * 32, dtype=torch.float32, device=h.device), _p(words), _p(w2)
     e0 = _ev() if profile is not None else None
-    rc = _lib.lib().tgsr_word_attention_fwd(_p(h), hbs, _p(words), _p(w2), _p(m8), 1 if correct_mask else 0, B, idf,
+    rc = _lib.lib().tgsr_word_attention_fwd(_p(h), hbs, wp, w2p, _p(m8), 1 if correct_mask else 0, B, idf,
                                             cdf, T, Q, _p(ws), _p(out), cbs, _p(attn), _stream())
     check(rc, "tgsr_word_attention_fwd")
     if profile is not None:
