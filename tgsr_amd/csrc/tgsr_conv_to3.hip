@@ -4,7 +4,8 @@
 // (conv5x5 ngf->3 + Tanh, model.py:224) fused with `one * . + a * SRb` (model.py:280/288/297).
 // Cout = 3 does not fill an MFMA tile (a 32-row tile would waste 90 % of it), and at 256x256 the op reads
 // 8.4 MB and writes 0.8 MB per image against 0.1-0.3 GFLOP: it is a streaming kernel, so it runs on the VALU:
-//   * workgroup = TH x 64 output pixels (TH = 16, or 8 / 4 on small images so that every CU gets work),
+//   * workgroup = TH x 64 output pixels (TH = 16, or 8 / 4 on small images so that every CU gets work; there the
+//     input channels are also split over 2 / 4 thread groups whose partial sums meet in LDS),
 //     thread = 4 consecutive pixels x 3 channels (12 accumulators);
 //   * the input is staged in LDS 2 channels at a time with its halo, double buffered, by LDS-DMA
 //     (global_load_lds, 16 B per lane: the tile starts 4 columns left of the output tile so every piece is an
@@ -38,9 +39,12 @@ __device__ __forceinline__ float fast_tanh(float v) {
   return 1.f - 2.f / (e + 1.f);
 }
 
-template <int K, int ACT, bool VEC4, int TH>   // TH output rows x 64 columns per workgroup, 16 * TH threads
-__global__ __launch_bounds__(16 * TH) void conv_to3_kernel(To3Args a) {
-  constexpr int P = K / 2, CK = 2, TW = 64, NT = 16 * TH, NW = NT / 64;
+// TH output rows x 64 columns per workgroup; KS thread groups of 16 * TH threads each take 1/KS of the input channels
+// (small images have too few tiles to fill the chip: the channel split gives every CU several waves and a quarter of
+// the barrier-separated stages per wave) and are summed through LDS before the epilogue.
+template <int K, int ACT, bool VEC4, int TH, int KS>
+__global__ __launch_bounds__(16 * TH * KS) void conv_to3_kernel(To3Args a) {
+  constexpr int P = K / 2, CK = 2, TW = 64, NG = 16 * TH, NW = NG / 64;
   constexpr int TR = TH + K - 1;
   constexpr int PITCH = 72;  // LDS column j = input column x0 - 4 + j; 72 = 64 + 4 left + 4 right
   constexpr int STAGE = CK * TR * PITCH;               // floats per stage (multiple of 4)
@@ -48,10 +52,14 @@ __global__ __launch_bounds__(16 * TH) void conv_to3_kernel(To3Args a) {
   constexpr int UNITS = (STAGE + PIECE - 1) / PIECE;
   constexpr int BUF = UNITS * PIECE;
   constexpr int UK = (UNITS + NW - 1) / NW;            // pieces per wave per stage
-  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+  static_assert(NG % 64 == 0, "a channel group is a whole number of waves");
+  static_assert((KS - 1) * 12 * NG <= KS * 2 * BUF, "reduction buffer fits the stage buffers");
+  __shared__ __attribute__((aligned(16))) float smem_all[KS * 2 * BUF];
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / NG);
+  const int tid = threadIdx.x - grp * NG, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* smem = smem_all + grp * 2 * BUF;
   const int txi = tid & 15, tyi = tid >> 4;  // TH x 16 threads, 4 pixels wide each
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
@@ -94,43 +102,68 @@ __global__ __launch_bounds__(16 * TH) void conv_to3_kernel(To3Args a) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
 
+  // this group's stages: [s0, s1) of the ceil(Cin / CK) channel stages; every group runs the same number of trips
+  const int nst = (a.Cin + CK - 1) / CK, per = (nst + KS - 1) / KS;
+  const int s0 = grp * per, s1 = s0 + per < nst ? s0 + per : nst;
+  if (s0 < s1) {
 #pragma unroll
-  for (int k = 0; k < UK; ++k) issue(k, smem, 0);
+    for (int k = 0; k < UK; ++k) issue(k, smem, s0 * CK);
+  }
   __syncthreads();
 
-  const int nst = (a.Cin + CK - 1) / CK;
-  for (int st = 0; st < nst; ++st) {
-    const float* cur = smem + (st & 1) * BUF;
-    if (st + 1 < nst) {
+  for (int i = 0; i < per; ++i) {
+    const int st = s0 + i;
+    const float* cur = smem + (i & 1) * BUF;
+    if (st + 1 < s1) {
 #pragma unroll
-      for (int k = 0; k < UK; ++k) issue(k, smem + ((st + 1) & 1) * BUF, (st + 1) * CK);
+      for (int k = 0; k < UK; ++k) issue(k, smem + ((i + 1) & 1) * BUF, (st + 1) * CK);
     }
     const int c0 = st * CK;
+    if (st < s1) {   // group-uniform
 #pragma unroll
-    for (int c = 0; c < CK; ++c) {
-      if (c0 + c < a.Cin) {   // uniform
-        const float* wc = a.w + (int64_t)(c0 + c) * K * K;  // + co * Cin*K*K
+      for (int c = 0; c < CK; ++c) {
+        if (c0 + c < a.Cin) {   // uniform
+          const float* wc = a.w + (int64_t)(c0 + c) * K * K;  // + co * Cin*K*K
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-          const float* row = cur + (c * TR + tyi + ky) * PITCH + 4 * txi;
-          const float4 v0 = *reinterpret_cast<const float4*>(row);
-          const float4 v1 = *reinterpret_cast<const float4*>(row + 4);
-          const float4 v2 = *reinterpret_cast<const float4*>(row + 8);
-          const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
-          // pixel p (column x0 + 4*txi + p) tap kx reads LDS column 4*txi + 4 + p + kx - P
+          for (int ky = 0; ky < K; ++ky) {
+            const float* row = cur + (c * TR + tyi + ky) * PITCH + 4 * txi;
+            const float4 v0 = *reinterpret_cast<const float4*>(row);
+            const float4 v1 = *reinterpret_cast<const float4*>(row + 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(row + 8);
+            const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+            // pixel p (column x0 + 4*txi + p) tap kx reads LDS column 4*txi + 4 + p + kx - P
 #pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
+            for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
-            for (int co = 0; co < 3; ++co) {
-              const float wv = wc[(int64_t)co * a.Cin * K * K + ky * K + kx];
+              for (int co = 0; co < 3; ++co) {
+                const float wv = wc[(int64_t)co * a.Cin * K * K + ky * K + kx];
 #pragma unroll
-              for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, in[4 + p + kx - P], acc[co][p]);
+                for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, in[4 + p + kx - P], acc[co][p]);
+              }
             }
           }
         }
       }
     }
     __syncthreads();  // next stage landed (vmcnt(0)); this one may be overwritten
+  }
+
+  if (KS > 1) {       // sum the channel groups (fixed order) into group 0
+    float* red = smem_all;
+    if (grp > 0) {
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) red[((grp - 1) * 12 + co * 4 + p) * NG + tid] = acc[co][p];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g)
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[co][p] += red[((g - 1) * 12 + co * 4 + p) * NG + tid];
   }
 
   const int y = y0 + tyi, xx = x0 + 4 * txi;
@@ -166,7 +199,7 @@ __global__ __launch_bounds__(16 * TH) void conv_to3_kernel(To3Args a) {
   }
 }
 
-template <int K, int ACT, int TH>
+template <int K, int ACT, int TH, int KS>
 static int launch_to3_th(To3Args a, hipStream_t s) {
   a.tiles_x = (a.W + 63) / 64;
   a.tiles_y = (a.H + TH - 1) / TH;
@@ -175,19 +208,20 @@ static int launch_to3_th(To3Args a, hipStream_t s) {
                     ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
                     (!a.addend || (reinterpret_cast<uintptr_t>(a.addend) & 15) == 0);
   if (vec4)
-    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, true, TH>), grid, dim3(16 * TH), 0, s, a);
+    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, true, TH, KS>), grid, dim3(16 * TH * KS), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, false, TH>), grid, dim3(16 * TH), 0, s, a);
+    hipLaunchKernelGGL((conv_to3_kernel<K, ACT, false, TH, KS>), grid, dim3(16 * TH * KS), 0, s, a);
   return note_launch(hipGetLastError(), "conv_to3_kernel");
 }
 
 template <int K, int ACT>
 static int launch_to3(To3Args a, hipStream_t s) {
   // 16-row tiles when they still give >= 2 workgroups per CU; smaller images take 8- or 4-row tiles (more workgroups)
+  // and split the input channels over 2 / 4 thread groups (more waves per workgroup, fewer stages per wave)
   auto tiles = [&](int th) { return (int64_t)a.B * ((a.W + 63) / 64) * ((a.H + th - 1) / th); };
-  if (tiles(16) >= 512) return launch_to3_th<K, ACT, 16>(a, s);
-  if (tiles(8) >= 512) return launch_to3_th<K, ACT, 8>(a, s);
-  return launch_to3_th<K, ACT, 4>(a, s);
+  if (tiles(16) >= 512) return launch_to3_th<K, ACT, 16, 1>(a, s);
+  if (tiles(8) >= 512) return launch_to3_th<K, ACT, 8, 2>(a, s);
+  return launch_to3_th<K, ACT, 4, 4>(a, s);
 }
 
 }  // namespace tgsr
