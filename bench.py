@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--mode", choices=("infer", "train"), default="infer",
                     help="infer = the headline (BASELINE configs[1]); train = generator fwd+bwd+Adam step on MSE+KL "
                          "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (inference mode)")
     ap.add_argument("--profile-every", type=int, default=8,
                     help="bracket every launch of every Nth timed step with HIP events for the roofline (0 = never); "
                          "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
@@ -203,8 +204,11 @@ def main():
     cap, LR, LRb = cap.to(dev), LR.to(dev), LRb.to(dev)
     lens = lens.tolist()
 
-    def step():
-        return pipe(cap, lens, LR, LRb)
+    if args.graph:      # BASELINE config 5: the step replayed from a captured hipGraph (identical results; at B=16 the
+        pipe.capture(cap, lens, LR, LRb)   # launches are already hidden behind the kernels, at small B it halves latency)
+
+    def step(eager=False):
+        return pipe(cap, lens, LR, LRb) if eager or not args.graph else pipe.replay(cap, LR, LRb)
 
     for _ in range(args.warmup):
         step()
@@ -223,7 +227,7 @@ def main():
         ops.profile = prof if sample else None
         pipe.overlap = (not args.serial) and not sample    # a launch is timed alone: sampled steps are single-stream
         nprof += 1 if sample else 0
-        step()
+        step(eager=sample)                                  # per-launch events need individual launches
     ops.profile = None
     fence()
     dt = time.perf_counter() - t0
@@ -280,7 +284,7 @@ def main():
                "config": {"workload": "CelebA face x8 (32->256) batch=16 per GPU, text-enc + G_SR_NET_low + "
                                       "NetG_highweight forward, eval BN (BASELINE configs[1])",
                           "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world,
-                          "streams": 1 if args.serial else 2},
+                          "streams": 1 if args.serial else 2, "launch": "hipgraph" if args.graph else "eager"},
                "roofline": roof, "kernels": kern}
         if "word_attention_kernel" in agg:
             # BASELINE.json's metric also asks for the attention batched-GEMM's MFMA utilisation: the op is HBM-bound

@@ -434,3 +434,32 @@ def test_full_size_batch16_vs_oracle(face_weights, cfg_face):
     assert torch.equal(full[:8], half) or float((full[:8] - half).abs().max()) < 1e-5
     again = p(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))["fine"][2]
     assert torch.equal(full, again)
+
+
+def test_pipeline_hipgraph_replay_matches_eager():
+    """BASELINE config 5: the whole step (two streams, ~60 launches) captured into a hipGraph replays bit-identically,
+    also on new images copied into its static inputs."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.synthetic import random_init_, synthetic_batch
+    from tgsr_amd.trainer import SRPipeline
+    cfg_reset()
+    cfg.GAN.GF_DIM = 32
+    cfg.TEXT.EMBEDDING_DIM = 256
+    cfg.TREE.BRANCH_NUM = 4
+    cfg.TREE.BASE_SIZE = 32
+    pipe = SRPipeline(41, device=DEV, low="lr", overlap=True)
+    for i, m in enumerate((pipe.netGL, pipe.netGH)):
+        random_init_(m, seed=i)
+    cap, lens, LR, LRb = synthetic_batch(3, seed=7)
+    cap, LR, LRb, lens = cap.to(DEV), LR.to(DEV), LRb.to(DEV), lens.tolist()
+    eager = [f.clone() for f in pipe(cap, lens, LR, LRb)["fine"]]
+    pipe.capture(cap, lens, LR, LRb)
+    out = pipe.replay(cap, LR, LRb)
+    for a, b in zip(out["fine"], eager):
+        assert torch.equal(a, b)
+    _, _, LR2, LRb2 = synthetic_batch(3, seed=8)
+    out2 = [f.clone() for f in pipe.replay(cap, LR2.to(DEV), LRb2.to(DEV))["fine"]]
+    eager2 = pipe(cap, lens, LR2.to(DEV), LRb2.to(DEV))["fine"]
+    for a, b in zip(out2, eager2):
+        assert torch.equal(a, b)
+    cfg_reset()
