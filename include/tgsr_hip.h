@@ -225,6 +225,13 @@ int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW,
 int tgsr_sumpool2x2(const float* x, int64_t BC, int H, int W, float* out, void* stream);
 
 /*
+ * uint8 image epilogue of the reference's caller (trainer_objective.py:153-155):
+ * out[i] = round(clip((x[i] + 1) * 127.5, 0, 255)), float32 arithmetic and round-half-to-even exactly as the numpy
+ * expression, so the bytes equal the host-side result.  x, out dense, n elements.
+ */
+int tgsr_to_uint8(const float* x, uint8_t* out, int64_t n, void* stream);
+
+/*
  * Weight gradient of tgsr_conv3x3_fwd: dw[Cout][Cin][3][3] = sum over (b, y, x) of grad_out * shifted input
  * (upsample=1: the input is read through the folded nearest-x2, H/W are the PRE-upsample sizes).
  * grad_out [B][Cout][Ho][Wo] dense; x [B][Cin][H][W] with batch stride; Cout % 32 == 0.

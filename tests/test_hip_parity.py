@@ -463,3 +463,20 @@ def test_pipeline_hipgraph_replay_matches_eager():
     for a, b in zip(out2, eager2):
         assert torch.equal(a, b)
     cfg_reset()
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 256, 256), (1, 3, 7, 5), (5,)])
+def test_to_uint8_bytes_match_numpy(shape):
+    """trainer_objective.py:153-155 on the device: identical bytes, including .5 ties, clipping and out-of-range."""
+    import numpy as np
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g) * 1.2
+    flat = x.view(-1)
+    ties = (torch.arange(0, 256, dtype=torch.float32) + 0.5) / 127.5 - 1.0      # lands near k + 0.5
+    flat[: min(flat.numel(), ties.numel())] = ties[: flat.numel()]
+    a = x.numpy()
+    ref = np.round(np.maximum(0, np.minimum(255, (a + 1.0) * 127.5))).astype(np.uint8)
+    out = ops.to_uint8(x.to(DEV)).cpu().numpy()
+    assert out.dtype == np.uint8 and out.shape == ref.shape
+    assert np.array_equal(out, ref)

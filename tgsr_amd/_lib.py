@@ -46,6 +46,7 @@ SIGNATURES = {
                                _i64, _vp]),
     "tgsr_bn_train_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "tgsr_to_uint8": (_i, [_vp, _vp, _i64, _vp]),
     "tgsr_conv3x3_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),
     "tgsr_conv3x3_wgrad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tgsr_word_attention_bwd_chunks": (_i, [_i]),

@@ -39,6 +39,27 @@ __global__ void bn_fold_kernel(const float* __restrict__ g, const float* __restr
   }
 }
 
+// uint8 image epilogue of the reference's caller (trainer_objective.py:153-155):
+//   round(clip((x + 1) * 127.5, 0, 255)) with numpy's float32 arithmetic (add, then multiply - no FMA - and
+//   round-half-to-even), so the bytes are identical to the host-side formula.  4 pixels per thread when aligned.
+__global__ void to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  auto cvt = [](float v) {
+    const float t = __fmul_rn(__fadd_rn(v, 1.0f), 127.5f);
+    return (uint8_t)(int)rintf(fminf(255.f, fmaxf(0.f, t)));
+  };
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 3) == 0)) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += stride) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      uchar4 o;
+      o.x = cvt(v.x); o.y = cvt(v.y); o.z = cvt(v.z); o.w = cvt(v.w);
+      reinterpret_cast<uchar4*>(out)[i] = o;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = cvt(x[i]);
+  }
+}
+
 }  // namespace tgsr
 
 using namespace tgsr;
@@ -65,4 +86,12 @@ extern "C" int tgsr_bn_fold(const float* weight, const float* bias, const float*
   hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), weight, bias,
                      running_mean, running_var, eps, scale, shift, C);
   return note_launch(hipGetLastError(), "bn_fold_kernel");
+}
+
+extern "C" int tgsr_to_uint8(const float* x, uint8_t* out, int64_t n, void* stream) {
+  if (!x || !out || n < 1) return TGSR_EINVAL;
+  const int64_t work = (n + 3) / 4;
+  const int blocks = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
+  hipLaunchKernelGGL(to_uint8_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, out, n);
+  return note_launch(hipGetLastError(), "to_uint8_kernel");
 }

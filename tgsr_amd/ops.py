@@ -427,3 +427,14 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     b = None if bias is None else _f32(bias.detach(), "bias").contiguous()
     check(_lib.lib().tgsr_linear_fwd(_p(x), B, K, _p(w2), _p(b), w2.shape[0], _p(out), _stream()), "tgsr_linear_fwd")
     return out
+
+
+# ----------------------------------------------------------------------------------------- image epilogue
+def to_uint8(img: torch.Tensor) -> torch.Tensor:
+    """trainer_objective.py:153-155 on the device: round(clip((x + 1) * 127.5, 0, 255)) -> uint8, same shape.
+    Byte-identical to the reference's numpy expression (float32 add, multiply, round-half-even)."""
+    _need_hip(img)
+    x = _f32(img.detach(), "img").contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().tgsr_to_uint8(_p(x), _p(out), x.numel(), _stream()), "tgsr_to_uint8")
+    return out

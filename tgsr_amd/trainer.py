@@ -22,7 +22,12 @@ def caption_mask(captions, num_words):
 
 
 def to_uint8(img):
-    """trainer_objective.py:153-155: round(clip((x + 1) * 127.5, 0, 255)) (host side, like the reference)."""
+    """trainer_objective.py:153-155: round(clip((x + 1) * 127.5, 0, 255)) as a uint8 numpy array.  Device tensors are
+    converted on the GPU (tgsr_to_uint8, byte-identical) so that 4x fewer bytes cross PCIe; host tensors use the
+    reference's numpy expression."""
+    if img.is_cuda:
+        from . import ops
+        return ops.to_uint8(img).cpu().numpy()
     a = img.detach().cpu().numpy()
     return np.round(np.maximum(0, np.minimum(255, (a + 1.0) * 127.5))).astype(np.uint8)
 
