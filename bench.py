@@ -124,7 +124,7 @@ def bench_train(args, rank, world, dist, dev, weights):
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
@@ -171,11 +171,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal hook for a 1-GPU box: TGSR_BENCH_REHEARSAL=1 puts every rank on cuda:0 over gloo (RCCL refuses two
+        # ranks on one device); the driver's multi-GPU run never sets it
+        rehearsal = os.environ.get("TGSR_BENCH_REHEARSAL", "0") == "1"
+        dev_index = 0 if rehearsal else local_rank
+        torch.cuda.set_device(dev_index)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     from tgsr_amd import _lib, ops
     from tgsr_amd.miscc.config import cfg, cfg_reset
@@ -232,7 +240,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
