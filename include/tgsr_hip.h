@@ -176,6 +176,18 @@ int tgsr_damsm_words_fwd(const float* words, const int32_t* cap_lens, const floa
                          float gamma1, float gamma2, float* sim, float* att_diag, void* stream);
 
 /*
+ * Backward of tgsr_damsm_words_fwd (the attention maps carry no gradient, like in the reference): grad_sim
+ * [B_img][B_cap] -> grad_words32 [B][ndf][32] (word axis padded to 32; the caller keeps [:Tw]) and grad_ctx
+ * [B][ndf][S].  Each (image, caption) pair is recomputed by one workgroup; the per-pair gradients are summed in a
+ * fixed order (deterministic).  ws: tgsr_damsm_words_bwd_ws_elems(B, ndf, S) floats.  ndf % 32 == 0, ndf <= 256,
+ * Tw <= 32, S <= 320.
+ */
+int64_t tgsr_damsm_words_bwd_ws_elems(int B, int ndf, int S);
+int tgsr_damsm_words_bwd(const float* words, const int32_t* cap_lens, const float* ctx, const float* grad_sim, int B,
+                         int ndf, int Tw, int S, float gamma1, float gamma2, float* ws, float* grad_words32,
+                         float* grad_ctx, void* stream);
+
+/*
  * Stand-alone func_attention(query, context, gamma1) (GlobalAttention.py:33-74): pair p attends query p to context p.
  * query [B][ndf][L] (L <= 32), context [B][ndf][S] (S <= 320) -> weighted_context [B][ndf][L], attn [B][L][S].
  */

@@ -274,6 +274,53 @@ def test_damsm_words_and_sent_loss_golden(damsm_golden, cfg_face):
             close(a, g[tag + ".att%d" % i], atol=2e-6)
 
 
+def test_damsm_loss_gradients_golden(damsm_golden, cfg_face):
+    """Backward of words_loss + sent_loss (HIP DAMSM backward kernel) vs the gradients captured from the reference."""
+    from tgsr_amd.miscc import losses
+    g = damsm_golden
+    cfg_face.TRAIN.SMOOTH.GAMMA1, cfg_face.TRAIN.SMOOTH.GAMMA2, cfg_face.TRAIN.SMOOTH.GAMMA3 = map(float, g["gamma"])
+    labels = torch.arange(4, device=DEV)
+    for tag, cls in (("cls", g["class_ids"]), ("nocls", None)):
+        feats, words = T(g["feats"]).requires_grad_(), T(g["words"]).requires_grad_()
+        cnn, sent = T(g["cnn_code"]).requires_grad_(), T(g["sent"]).requires_grad_()
+        w0, w1, _ = losses.words_loss(feats, words, labels, T(g["cap_lens"], "cpu"), cls, 4)
+        s0, s1 = losses.sent_loss(cnn, sent, labels, cls, 4)
+        (w0 + w1 + s0 + s1).backward()
+        for name, t in (("g_feats", feats), ("g_words", words), ("g_cnn", cnn), ("g_sent", sent)):
+            ref = torch.from_numpy(g[tag + "." + name])
+            scale = float(ref.abs().max())
+            close(t.grad, ref, atol=2e-5 * scale, rtol=2e-4)
+
+
+@pytest.mark.parametrize("B,ndf,Tw,S", [(5, 256, 18, 289), (3, 64, 7, 25), (2, 128, 32, 320)])
+def test_damsm_backward_vs_oracle_autograd(B, ndf, Tw, S):
+    """tgsr_damsm_words_bwd vs torch autograd through the oracle's per-caption loop, random upstream gradient."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + Tw)
+    ih, iw = (17, 17) if S == 289 else ((5, 5) if S == 25 else (16, 20))
+    feats = torch.randn(B, ndf, ih, iw, generator=g, dtype=torch.float64).requires_grad_()
+    words = torch.randn(B, ndf, Tw, generator=g, dtype=torch.float64).requires_grad_()
+    lens = torch.randint(1, Tw + 1, (B,), generator=g).tolist()
+    lens[0] = Tw
+    gs = torch.randn(B, B, generator=g, dtype=torch.float64)
+    cols = []
+    for i in range(B):
+        L = lens[i]
+        word = words[i:i + 1, :, :L].expand(B, -1, -1)
+        wc, _ = O.func_attention(word, feats, 4.0)
+        row = O.cosine_similarity(word.transpose(1, 2).reshape(B * L, -1), wc.transpose(1, 2).reshape(B * L, -1))
+        cols.append(torch.log(torch.exp(row.reshape(B, L) * 5.0).sum(1)))
+    sim = torch.stack(cols, 1)
+    (sim * gs).sum().backward()
+    g_img, g_words = ops.damsm_words_bwd(feats.detach().float().to(DEV), words.detach().float().to(DEV), lens, 4.0, 5.0,
+                                         gs.float().to(DEV))
+    for got, ref in ((g_img, feats.grad), (g_words, words.grad)):
+        ref = ref.float()
+        close(got, ref, atol=3e-5 * float(ref.abs().max()), rtol=1e-3)
+    for i in range(B):
+        assert float(g_words[i, :, lens[i]:].abs().max()) == 0.0 if lens[i] < Tw else True
+
+
 @pytest.mark.parametrize("B,ndf,Tw,S", [(16, 256, 18, 289), (3, 64, 7, 25), (5, 128, 32, 320)])
 def test_damsm_similarity_vs_oracle(B, ndf, Tw, S):
     from tgsr_amd import ops

@@ -38,6 +38,8 @@ SIGNATURES = {
     "tgsr_lstm_gate_table": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "tgsr_bilstm_table_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "tgsr_damsm_words_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "tgsr_damsm_words_bwd_ws_elems": (_i64, [_i, _i, _i]),
+    "tgsr_damsm_words_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "tgsr_func_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "tgsr_conv1x1_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "tgsr_linear_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),

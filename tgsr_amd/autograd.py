@@ -171,3 +171,24 @@ class WordAttention(torch.autograd.Function):
         dwords = torch.matmul(w2.t(), dsrc) if ctx.needs_input_grad[1] else None
         dw = torch.einsum("bit,bct->ic", dsrc, words.detach()).reshape(w_ctx.shape) if ctx.needs_input_grad[2] else None
         return dh, dwords, dw, None, None
+
+
+class DamsmWords(torch.autograd.Function):
+    """sim[j][i] of words_loss (losses.py:73-113) with its HIP backward (tgsr_damsm_words_bwd): differentiable w.r.t.
+    the image region features and the word embeddings; the diagonal attention maps are returned without gradient,
+    as the reference only plots them."""
+
+    @staticmethod
+    def forward(ctx, img_features, words_emb, lens, gamma1, gamma2):
+        sim, att = ops.damsm_words_similarity(img_features, words_emb, lens, gamma1, gamma2, need_att=True)
+        ctx.save_for_backward(img_features, words_emb)
+        ctx.meta = (list(lens), float(gamma1), float(gamma2))
+        ctx.mark_non_differentiable(att)
+        return sim, att
+
+    @staticmethod
+    def backward(ctx, grad_sim, _grad_att):
+        img_features, words_emb = ctx.saved_tensors
+        lens, gamma1, gamma2 = ctx.meta
+        g_img, g_words = ops.damsm_words_bwd(img_features, words_emb, lens, gamma1, gamma2, grad_sim)
+        return g_img, g_words, None, None, None

@@ -1,0 +1,327 @@
+// Backward of the DAMSM word/region similarity grid (tgsr_damsm_words_fwd; words_loss, losses.py:73-113 through
+// func_attention, GlobalAttention.py:33-74) for gfx950.
+//
+// One workgroup (256 threads) owns one (image j, caption i) pair, recomputes the pair's forward quantities and
+// pushes G = dLoss/dsim[j][i] back to the caption's words and the image's region features:
+//   s[l][r]   = sum_d word[d][l] ctx[d][r]              a1 = softmax_l(s)   a2 = softmax_r(gamma1 * a1)
+//   wc[d][l]  = sum_r ctx[d][r] a2[l][r]                cos_l = <word_l, wc_l> / max(|word_l| |wc_l|, 1e-8)
+//   sim       = log sum_l exp(gamma2 cos_l)
+// Two thread mappings alternate: thread = region r (scores, both softmax backward passes; ctx columns are coalesced
+// global reads, the [ndf][32] word / dwc matrices are LDS broadcasts) and thread = feature d (weighted context and
+// every gradient row; each thread keeps its row of word, wc, dwc, gword in registers, ctx is staged through LDS in
+// [ndf][32 regions] chunks, the [32][S] attention images are broadcast reads of a per-pair global workspace).
+// Per-pair gradients go to gw_part[j][i][ndf][32] and gc_part[i][j][ndf][S]; tgsr_reduce_dim0 sums them in a fixed
+// order (deterministic, no float atomics).  This is a loss kernel (8 MFLOP per pair): clarity over speed.
+#include "tgsr_common.h"
+
+namespace tgsr {
+
+struct DamsmBwdArgs {
+  const float* words;      // [B][ndf][Tw]
+  const int32_t* lens;     // [B] or null
+  const float* ctx;        // [B][ndf][S]
+  const float* gsim;       // [B img][B cap]
+  int B, ndf, Tw, S;
+  float gamma1, gamma2;
+  float* ws;               // [B*B][3][32][S] workspace: a1, a2, da2 -> ds
+  float* gw_part;          // [B img][B cap][ndf][32]
+  float* gc_part;          // [B cap][B img][ndf][S]
+};
+
+constexpr int kBwdChunk = 32;   // regions per LDS chunk in the thread = d phases
+
+__global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int ndf = a.ndf, S = a.S;
+  float* word_s = lds;                       // [ndf][32]
+  float* dwc_s = word_s + ndf * 32;          // [ndf][32]
+  float* cs = dwc_s + ndf * 32;              // [ndf][33] ctx chunk
+  float* gcs = cs + ndf * 33;                // [ndf][33] gctx chunk
+  float* red = gcs + ndf * 33;               // [4][32] reductions
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = blockIdx.x / a.B, i = blockIdx.x - j * a.B;
+  int L = a.lens ? a.lens[i] : a.Tw;
+  L = L < 1 ? 1 : (L > a.Tw ? a.Tw : L);
+  const float* wb = a.words + (int64_t)i * ndf * a.Tw;
+  const float* cb = a.ctx + (int64_t)j * ndf * S;
+  const float G = a.gsim[(int64_t)j * a.B + i];
+  float* a1 = a.ws + (int64_t)blockIdx.x * 3 * 32 * S;
+  float* a2 = a1 + 32 * S;
+  float* a3 = a2 + 32 * S;
+
+  for (int o = tid; o < ndf * 32; o += 256) {
+    const int d = o >> 5, l = o & 31;
+    word_s[o] = l < L ? wb[d * a.Tw + l] : 0.f;
+  }
+  if (tid < 128) red[tid] = 0.f;
+  __syncthreads();
+
+  // ---- thread = r: scores, softmax over words, x gamma1
+  for (int r = tid; r < S; r += 256) {
+    float s[32];
+#pragma unroll
+    for (int l = 0; l < 32; ++l) s[l] = 0.f;
+    for (int d = 0; d < ndf; ++d) {
+      const float c = cb[(int64_t)d * S + r];
+#pragma unroll
+      for (int l = 0; l < 32; ++l) s[l] = fmaf(word_s[d * 32 + l], c, s[l]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      if (l >= L) s[l] = -INFINITY;
+      mx = fmaxf(mx, s[l]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      s[l] = expf(s[l] - mx);
+      sum += s[l];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      const float p = s[l] * inv;
+      a1[l * S + r] = p;
+      a2[l * S + r] = a.gamma1 * p;        // softmax over regions comes next
+    }
+  }
+  __syncthreads();
+
+  // ---- wave per word row: softmax over regions -> a2
+  for (int l = wave; l < 32; l += 4) {
+    float* row = a2 + l * S;
+    if (l < L) {
+      float mx = -INFINITY;
+      for (int r = lane; r < S; r += 64) mx = fmaxf(mx, row[r]);
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sum = 0.f;
+      for (int r = lane; r < S; r += 64) {
+        const float e = expf(row[r] - mx);
+        row[r] = e;
+        sum += e;
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+      const float inv = 1.f / sum;
+      for (int r = lane; r < S; r += 64) row[r] *= inv;
+    } else {
+      for (int r = lane; r < S; r += 64) row[r] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- thread = d: weighted context wc[d][l] (ctx staged through LDS in chunks of 32 regions)
+  const int d = tid;
+  const bool dok = d < ndf;
+  float wrow[32], wc[32];
+#pragma unroll
+  for (int l = 0; l < 32; ++l) {
+    wrow[l] = dok ? word_s[d * 32 + l] : 0.f;
+    wc[l] = 0.f;
+  }
+  for (int r0 = 0; r0 < S; r0 += kBwdChunk) {
+    for (int o = tid; o < ndf * kBwdChunk; o += 256) {
+      const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
+      cs[dd * 33 + rr] = r0 + rr < S ? cb[(int64_t)dd * S + r0 + rr] : 0.f;
+    }
+    __syncthreads();
+    if (dok) {
+      const int nr = S - r0 < kBwdChunk ? S - r0 : kBwdChunk;
+      for (int rr = 0; rr < nr; ++rr) {
+        const float c = cs[d * 33 + rr];
+#pragma unroll
+        for (int l = 0; l < 32; ++l) wc[l] = fmaf(c, a2[l * S + r0 + rr], wc[l]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- cosine + log-sum-exp backward: per word dot / norms over d (LDS atomics), then dwc and the direct gword
+  {
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      float dt = wrow[l] * wc[l], nc = wc[l] * wc[l], nw = wrow[l] * wrow[l];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        dt += __shfl_xor(dt, o);
+        nc += __shfl_xor(nc, o);
+        nw += __shfl_xor(nw, o);
+      }
+      if (lane == 0) {
+        atomicAdd(&red[l], dt);
+        atomicAdd(&red[32 + l], nc);
+        atomicAdd(&red[64 + l], nw);
+      }
+    }
+  }
+  __syncthreads();
+  float gw[32], dwc[32];
+  {
+    // p_l = softmax_l(gamma2 cos_l) over the caption's words; dcos_l = G gamma2 p_l
+    float cosv[32], mx = -INFINITY;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      const float den = fmaxf(sqrtf(red[64 + l]) * sqrtf(red[32 + l]), 1e-8f);
+      cosv[l] = red[l] / den;
+      if (l < L) mx = fmaxf(mx, a.gamma2 * cosv[l]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) sum += l < L ? expf(a.gamma2 * cosv[l] - mx) : 0.f;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      float gwl = 0.f, dw = 0.f;
+      if (l < L) {
+        const float dcos = G * a.gamma2 * expf(a.gamma2 * cosv[l] - mx) / sum;
+        const float nw = sqrtf(red[64 + l]), nc = sqrtf(red[32 + l]);
+        if (nw * nc > 1e-8f) {
+          const float inv = 1.f / (nw * nc);
+          dw = dcos * (wrow[l] * inv - cosv[l] * wc[l] / (nc * nc));
+          gwl = dcos * (wc[l] * inv - cosv[l] * wrow[l] / (nw * nw));
+        } else {                                  // clamped denominator: cos = dot / eps
+          dw = dcos * wrow[l] * 1e8f;
+          gwl = dcos * wc[l] * 1e8f;
+        }
+      }
+      dwc[l] = dw;
+      gw[l] = gwl;
+      if (dok) dwc_s[d * 32 + l] = dw;
+    }
+  }
+  __syncthreads();
+
+  // ---- thread = r, pass A: da2[l][r] = sum_d dwc[d][l] ctx[d][r]; row dots sum_r da2 a2 for the softmax-r backward
+  if (tid < 32) red[96 + tid] = 0.f;
+  __syncthreads();
+  {
+    float rd[32];
+#pragma unroll
+    for (int l = 0; l < 32; ++l) rd[l] = 0.f;
+    for (int r = tid; r < S; r += 256) {
+      float g[32];
+#pragma unroll
+      for (int l = 0; l < 32; ++l) g[l] = 0.f;
+      for (int dd = 0; dd < ndf; ++dd) {
+        const float c = cb[(int64_t)dd * S + r];
+#pragma unroll
+        for (int l = 0; l < 32; ++l) g[l] = fmaf(dwc_s[dd * 32 + l], c, g[l]);
+      }
+#pragma unroll
+      for (int l = 0; l < 32; ++l) {
+        a3[l * S + r] = g[l];
+        rd[l] = fmaf(g[l], a2[l * S + r], rd[l]);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      float v = rd[l];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) atomicAdd(&red[96 + l], v);
+    }
+  }
+  __syncthreads();
+  // pass B: dx = a2 (da2 - rowdot); da1 = gamma1 dx; ds = a1 (da1 - sum_l da1 a1)  -> a3
+  for (int r = tid; r < S; r += 256) {
+    float da1[32], p1[32], acc = 0.f;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) {
+      p1[l] = a1[l * S + r];
+      da1[l] = l < L ? a.gamma1 * a2[l * S + r] * (a3[l * S + r] - red[96 + l]) : 0.f;
+      acc = fmaf(da1[l], p1[l], acc);
+    }
+#pragma unroll
+    for (int l = 0; l < 32; ++l) a3[l * S + r] = p1[l] * (da1[l] - acc);
+  }
+  __syncthreads();
+
+  // ---- thread = d: gword[d][l] += sum_r ds[l][r] ctx[d][r];  gctx[d][r] = sum_l (word[d][l] ds[l][r] + dwc[d][l] a2[l][r])
+  float* gc = a.gc_part + ((int64_t)i * a.B + j) * ndf * S;
+  for (int r0 = 0; r0 < S; r0 += kBwdChunk) {
+    for (int o = tid; o < ndf * kBwdChunk; o += 256) {
+      const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
+      cs[dd * 33 + rr] = r0 + rr < S ? cb[(int64_t)dd * S + r0 + rr] : 0.f;
+    }
+    __syncthreads();
+    const int nr = S - r0 < kBwdChunk ? S - r0 : kBwdChunk;
+    if (dok) {
+      for (int rr = 0; rr < nr; ++rr) {
+        const float c = cs[d * 33 + rr];
+        float g = 0.f;
+#pragma unroll
+        for (int l = 0; l < 32; ++l) {
+          const float dsv = a3[l * S + r0 + rr];
+          gw[l] = fmaf(dsv, c, gw[l]);
+          g = fmaf(wrow[l], dsv, g);
+          g = fmaf(dwc[l], a2[l * S + r0 + rr], g);
+        }
+        gcs[d * 33 + rr] = g;
+      }
+    }
+    __syncthreads();
+    for (int o = tid; o < ndf * kBwdChunk; o += 256) {
+      const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
+      if (rr < nr) gc[(int64_t)dd * S + r0 + rr] = gcs[dd * 33 + rr];
+    }
+    __syncthreads();
+  }
+  if (dok) {
+    float* gwp = a.gw_part + (((int64_t)j * a.B + i) * ndf + d) * 32;
+#pragma unroll
+    for (int l = 0; l < 32; ++l) gwp[l] = gw[l];
+  }
+}
+
+// out[k] = sum_{p < n} parts[p][k], p ascending (deterministic)
+__global__ void reduce_dim0_kernel(const float* __restrict__ parts, int n, int64_t m, float* __restrict__ out) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < m; k += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < n; ++p) s += parts[(int64_t)p * m + k];
+    out[k] = s;
+  }
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int64_t tgsr_damsm_words_bwd_ws_elems(int B, int ndf, int S) {
+  return (int64_t)B * B * (3 * 32 * (int64_t)S + (int64_t)ndf * 32 + (int64_t)ndf * S);
+}
+
+extern "C" int tgsr_damsm_words_bwd(const float* words, const int32_t* cap_lens, const float* ctx, const float* grad_sim,
+                                    int B, int ndf, int Tw, int S, float gamma1, float gamma2, float* ws,
+                                    float* grad_words32, float* grad_ctx, void* stream) {
+  if (!words || !ctx || !grad_sim || !ws || !grad_words32 || !grad_ctx || B < 1 || Tw < 1 || S < 1) return TGSR_EINVAL;
+  if (ndf < 32 || ndf > 256 || ndf % 32 != 0 || Tw > 32 || S > 320) return TGSR_EUNSUPPORTED;
+  DamsmBwdArgs a;
+  a.words = words; a.lens = cap_lens; a.ctx = ctx; a.gsim = grad_sim; a.B = B; a.ndf = ndf; a.Tw = Tw; a.S = S;
+  a.gamma1 = gamma1; a.gamma2 = gamma2;
+  a.ws = ws;
+  a.gw_part = ws + (int64_t)B * B * 3 * 32 * S;
+  a.gc_part = a.gw_part + (int64_t)B * B * ndf * 32;
+  const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + (size_t)ndf * 33 * 2 + 128);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(damsm_pair_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return note_launch(hipGetLastError(), "hipFuncSetAttribute(damsm_pair_bwd_kernel)");
+    attr_set = true;
+  }
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(damsm_pair_bwd_kernel, dim3(B * B), dim3(256), lds, s, a);
+  int rc = note_launch(hipGetLastError(), "damsm_pair_bwd_kernel");
+  if (rc) return rc;
+  // grad_words32[i][ndf][32] = sum_j gw_part[j][i];  grad_ctx[j][ndf][S] = sum_i gc_part[i][j]
+  const int64_t mw = (int64_t)B * ndf * 32, mc = (int64_t)B * ndf * S;
+  hipLaunchKernelGGL(reduce_dim0_kernel, dim3((unsigned)((mw + 255) / 256 < 1024 ? (mw + 255) / 256 : 1024)), dim3(256),
+                     0, s, a.gw_part, B, mw, grad_words32);
+  rc = note_launch(hipGetLastError(), "reduce_dim0_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(reduce_dim0_kernel, dim3((unsigned)((mc + 255) / 256 < 1024 ? (mc + 255) / 256 : 1024)), dim3(256),
+                     0, s, a.gc_part, B, mc, grad_ctx);
+  return note_launch(hipGetLastError(), "reduce_dim0_kernel");
+}

@@ -4,7 +4,8 @@
 per-caption Python loop of words_loss is one launch of the batched DAMSM kernel (tgsr_damsm_words_fwd).  The class
 mask, the x gamma3 scale and the two cross entropies act on a [B, B] matrix and stay in torch, like sent_loss's
 [B,256]x[256,B] product (a plain library GEMM).  `KL_loss` and `MSE` (losses.py:779-810) are scalar reductions.
-Forward values only for now (no autograd through the HIP kernel): training with these losses is the next step.
+Both are differentiable: words_loss through the HIP backward of the DAMSM kernel (tgsr_damsm_words_bwd, autograd.DamsmWords),
+sent_loss through torch autograd over its [B, B] matrix.
 """
 import numpy as np
 import torch
@@ -63,8 +64,12 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
     """losses.py:65-136.  words_emb(query): batch x nef x seq_len; img_features(context): batch x nef x 17 x 17.
     Returns (loss0, loss1, att_maps) with att_maps[i] = [1, cap_len_i, 17, 17]."""
     lens = cap_lens.data.tolist() if torch.is_tensor(cap_lens) else list(cap_lens)
-    sim, att = ops.damsm_words_similarity(img_features, words_emb, lens, cfg.TRAIN.SMOOTH.GAMMA1,
-                                          cfg.TRAIN.SMOOTH.GAMMA2, need_att=True)
+    if torch.is_grad_enabled() and (img_features.requires_grad or words_emb.requires_grad):
+        from ..autograd import DamsmWords
+        sim, att = DamsmWords.apply(img_features, words_emb, lens, cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.GAMMA2)
+    else:
+        sim, att = ops.damsm_words_similarity(img_features, words_emb, lens, cfg.TRAIN.SMOOTH.GAMMA1,
+                                              cfg.TRAIN.SMOOTH.GAMMA2, need_att=True)
     att_maps = [att[i:i + 1, :lens[i]].contiguous() for i in range(batch_size)]
     similarities = sim * cfg.TRAIN.SMOOTH.GAMMA3
     masks = _class_masks(class_ids, batch_size, sim.device)

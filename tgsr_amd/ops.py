@@ -383,6 +383,27 @@ def damsm_words_similarity(img_features: torch.Tensor, words_emb: torch.Tensor, 
     return sim, att
 
 
+def damsm_words_bwd(img_features: torch.Tensor, words_emb: torch.Tensor, cap_lens, gamma1: float, gamma2: float,
+                    grad_sim: torch.Tensor):
+    """Backward of damsm_words_similarity: grad_sim [B,B] -> (grad_img_features [B,ndf,ih,iw], grad_words [B,ndf,Tw])."""
+    _need_hip(img_features, words_emb, grad_sim)
+    B, ndf, ih, iw = img_features.shape
+    Tw, S = words_emb.shape[2], ih * iw
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    ctx = _f32(img_features.detach(), "img_features").contiguous()
+    words = _f32(words_emb.detach(), "words_emb").contiguous()
+    gs = _f32(grad_sim, "grad_sim").contiguous()
+    dev = ctx.device
+    L = _lib.lib()
+    ws = torch.empty(L.tgsr_damsm_words_bwd_ws_elems(B, ndf, S), dtype=torch.float32, device=dev)
+    gw32 = torch.empty(B, ndf, 32, dtype=torch.float32, device=dev)
+    gctx = torch.empty(B, ndf, ih, iw, dtype=torch.float32, device=dev)
+    rc = L.tgsr_damsm_words_bwd(_p(words), _p(_lens_on_device(tuple(lens), dev)), _p(ctx), _p(gs), B, ndf, Tw, S,
+                                float(gamma1), float(gamma2), _p(ws), _p(gw32), _p(gctx), _stream())
+    check(rc, "tgsr_damsm_words_bwd")
+    return gctx, gw32[:, :, :Tw].contiguous()
+
+
 def func_attention(query: torch.Tensor, context: torch.Tensor, gamma1: float):
     """GlobalAttention.func_attention: query [B,ndf,L], context [B,ndf,ih,iw] -> (weightedContext [B,ndf,L],
     attn [B,L,ih,iw])."""
