@@ -163,6 +163,23 @@ int tgsr_bilstm_table_fwd(const int64_t* captions, int width, const int32_t* cap
                           void* stream);
 
 /*
+ * Training path of the same encoder.  tgsr_bilstm_train_fwd takes the already embedded (and dropped-out) inputs
+ * x [B][Tmax][ninput] and additionally saves acts [B][Tmax][2][5][H] (i, f, g, o activations and the cell state of
+ * every step).  tgsr_bilstm_bwd walks every (sample, direction) back through time from d_words [B][2H][Tmax] and
+ * d_sent [B][2H] (may be NULL) and emits the pre-activation gate gradients dgates [B][Tmax][2][4H] (zero past the
+ * caption), hprev [B][Tmax][2][H] (the hidden state entering each step) and dbias [2][4H] (= d b_ih = d b_hh; may be
+ * NULL).  The weight / input gradients are plain GEMMs on those (tgsr_linear_fwd):
+ *   dW_ih[d] = dgates[:, :, d]^T x,   dW_hh[d] = dgates[:, :, d]^T hprev[:, :, d],   dx = dgates W_ih.
+ * H in {32, 64, 128} for the backward.
+ */
+int tgsr_bilstm_train_fwd(const float* x, const int32_t* cap_lens, int B, int Tmax, int ninput, const float* w_ih,
+                          const float* w_hh, const float* b_ih, const float* b_hh, int H, float* gates_ws, float* acts,
+                          float* words_emb, float* sent_emb, void* stream);
+int tgsr_bilstm_bwd(const int32_t* cap_lens, int B, int Tmax, int H, const float* w_hh, const float* acts,
+                    const float* words_emb, const float* d_words, const float* d_sent, float* dgates, float* hprev,
+                    float* dbias, void* stream);
+
+/*
  * DAMSM word/region attention for the whole (image, caption) grid in one launch: func_attention
  * (GlobalAttention.py:33-74) as driven by words_loss (losses.py:73-113) - the B-iteration Python loop, word.repeat,
  * both softmaxes, the two bmm and the cosine / exp / sum / log tail.

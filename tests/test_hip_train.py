@@ -192,3 +192,147 @@ def test_train_step_decreases_loss_and_updates_running_stats(nets_small):
         assert int(tr.netGH.convin[1].num_batches_tracked) == 6
     finally:
         cfg_reset()
+
+
+@pytest.mark.parametrize("B,T,ntoken,ninput,H", [(5, 9, 30, 40, 32), (16, 18, 41, 300, 128), (2, 3, 10, 7, 64)])
+def test_rnn_encoder_train_backward_vs_oracle(B, T, ntoken, ninput, H):
+    """RNN_ENCODER.train(): embedding -> (dropout p=0) -> HIP LSTM forward + BPTT; every parameter gradient against
+    torch autograd through the oracle's explicit packed-sequence recurrence (fp64)."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.util import RNN_ENCODER
+    cfg_reset()
+    cfg.TEXT.WORDS_NUM = T
+    g = torch.Generator().manual_seed(B * 100 + T)
+    enc = RNN_ENCODER(ntoken, ninput=ninput, drop_prob=0.0, nhidden=2 * H).to(DEV)
+    enc.train()
+    lens = sorted(torch.randint(1, T + 1, (B,), generator=g).tolist(), reverse=True)
+    lens[0] = T
+    cap = torch.zeros(B, T, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        cap[b, :n] = torch.randint(1, ntoken, (n,), generator=g)
+    gw = torch.randn(B, 2 * H, T, generator=g, dtype=torch.float64)
+    gs = torch.randn(B, 2 * H, generator=g, dtype=torch.float64)
+    # oracle, fp64
+    sd = {k: v.detach().cpu().double().requires_grad_() for k, v in enc.state_dict().items()}
+    ow, os_ = O.rnn_encoder(sd, cap, lens)
+    ((ow * gw).sum() + (os_ * gs).sum()).backward()
+    # HIP
+    words, sent = enc(cap.to(DEV), lens, enc.init_hidden(B))
+    close(words, ow.float(), atol=1e-5)
+    close(sent, os_.float(), atol=1e-5)
+    ((words * gw.float().to(DEV)).sum() + (sent * gs.float().to(DEV)).sum()).backward()
+    for name, p in enc.named_parameters():
+        ref = sd[name].grad.float()
+        close(p.grad, ref, atol=2e-5 * max(1.0, float(ref.abs().max())), rtol=1e-3)
+    cfg_reset()
+
+
+def test_damsm_pretrain_step_decreases_loss():
+    """One pretrain_DAMSM-style step chain (pretrain_DAMSM.py:60-100): RNN_ENCODER.train() + CNN_ENCODER heads on
+    synthetic trunk features, words_loss + sent_loss, Adam, grad-clip 0.25 - all gradients from HIP kernels; the
+    loss must go down on a fixed batch."""
+    from tgsr_amd.miscc import losses
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.util import CNN_ENCODER, RNN_ENCODER
+    cfg_reset()
+    cfg.TEXT.WORDS_NUM = 12
+    cfg.TRAIN.FLAG = True
+    B, T, nef = 6, 12, 256
+    g = torch.Generator().manual_seed(11)
+    text = RNN_ENCODER(50, nhidden=nef).to(DEV).train()
+    image = CNN_ENCODER(nef, trunk=torch.nn.Identity()).to(DEV).train()
+    lens = [12, 10, 9, 7, 4, 2]
+    cap = torch.zeros(B, T, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        cap[b, :n] = torch.randint(1, 50, (n,), generator=g)
+    feats = torch.randn(B, 768, 17, 17, generator=g).to(DEV)
+    pooled = torch.randn(B, 2048, generator=g).to(DEV)
+    labels = torch.arange(B, device=DEV)
+    params = [p for p in list(text.parameters()) + [image.emb_features.weight, image.emb_cnn_code.weight,
+                                                     image.emb_cnn_code.bias]]
+    opt = torch.optim.Adam(params, lr=2e-3, betas=(0.5, 0.999))
+    torch.manual_seed(0)
+    hist = []
+    for _ in range(8):
+        opt.zero_grad()
+        words_features, sent_code = image.heads(feats, pooled)
+        words_emb, sent_emb = text(cap.to(DEV), lens, text.init_hidden(B))
+        w0, w1, _ = losses.words_loss(words_features, words_emb, labels, lens, None, B)
+        s0, s1 = losses.sent_loss(sent_code, sent_emb, labels, None, B)
+        loss = w0 + w1 + s0 + s1
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(text.parameters(), 0.25)      # pretrain_DAMSM.py:96-97
+        opt.step()
+        hist.append(float(loss.detach()))
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0] - 0.05, hist
+    cfg_reset()
+
+
+def test_damsm_trainer_epoch_protocol():
+    """DAMSMTrainer: per-epoch Adam reset, lr x 0.98, clipped text-encoder gradients, loss goes down."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.train import DAMSMTrainer
+    cfg_reset()
+    cfg.TEXT.WORDS_NUM = 10
+    cfg.TRAIN.FLAG = True
+    tr = DAMSMTrainer(40, device=DEV, lr=2e-3)
+    g = torch.Generator().manual_seed(5)
+    B = 5
+    lens = [10, 8, 6, 3, 1]
+    cap = torch.zeros(B, 10, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        cap[b, :n] = torch.randint(1, 40, (n,), generator=g)
+    feats, pooled = torch.randn(B, 768, 17, 17, generator=g).to(DEV), torch.randn(B, 2048, generator=g).to(DEV)
+    torch.manual_seed(1)
+    first = float(tr.step_features(feats, pooled, cap.to(DEV), lens))
+    for _ in range(5):
+        last = float(tr.step_features(feats, pooled, cap.to(DEV), lens))
+    opt0 = tr.opt
+    tr.end_epoch(); tr.start_epoch()
+    assert tr.opt is not opt0 and abs(tr.lr - 2e-3 * 0.98) < 1e-12
+    assert np.isfinite(last) and last < first
+    total = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in tr.text_encoder.parameters()))
+    assert float(total) <= cfg.TRAIN.RNN_GRAD_CLIP * 1.001
+    cfg_reset()
+
+
+def test_sr_trainer_with_damsm_term():
+    """SRTrainer with an image encoder: the DAMSM ranking term (generator_loss, losses.py:375-386) reaches the
+    generators through the HIP DAMSM backward; one step runs and changes the result of the pixel-only loss."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.train import SRTrainer
+    from tgsr_amd.util import CNN_ENCODER
+    cfg_reset()
+    cfg.GAN.GF_DIM = 32
+    cfg.TEXT.EMBEDDING_DIM = 256
+    cfg.TREE.BRANCH_NUM = 4
+    cfg.TREE.BASE_SIZE = 32
+
+    class Trunk(torch.nn.Module):        # stand-in for the frozen Inception trunk: any differentiable torch module
+        def __init__(self):
+            super().__init__()
+            self.f = torch.nn.Conv2d(3, 768, 1)
+            self.p = torch.nn.Linear(3, 2048)
+
+        def forward(self, x):
+            f = self.f(F.adaptive_avg_pool2d(x, 17))
+            return f, self.p(x.mean((2, 3)))
+
+    torch.manual_seed(3)
+    enc = CNN_ENCODER(256, trunk=Trunk()).to(DEV).eval()
+    for p in enc.parameters():
+        p.requires_grad = False
+    cap, lens, LR, LRb = synthetic_batch(2, seed=5)
+    cap, LR, LRb, lens = cap.to(DEV), LR.to(DEV), LRb.to(DEV), lens.tolist()
+    g = torch.Generator().manual_seed(1)
+    hr = [(torch.rand(2, 3, s, s, generator=g) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+    losses_ = []
+    for with_enc in (False, True):
+        torch.manual_seed(7)
+        tr = SRTrainer(41, device=DEV, image_encoder=enc if with_enc else None)
+        torch.manual_seed(9)
+        losses_.append(float(tr.step(cap, lens, LR, LRb, hr)))
+        assert all(torch.isfinite(p.grad).all() for p in tr.params)
+    assert np.isfinite(losses_).all() and losses_[1] > losses_[0] + 1e-3      # the ranking term is positive
+    cfg_reset()

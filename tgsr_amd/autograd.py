@@ -192,3 +192,76 @@ class DamsmWords(torch.autograd.Function):
         lens, gamma1, gamma2 = ctx.meta
         g_img, g_words = ops.damsm_words_bwd(img_features, words_emb, lens, gamma1, gamma2, grad_sim)
         return g_img, g_words, None, None, None
+
+
+def _gemm_nt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [M,K] @ b[N,K]^T on the HIP GEMM kernel (tgsr_linear_fwd)."""
+    return ops.linear(a.contiguous(), b.contiguous(), None)
+
+
+class BiLSTM(torch.autograd.Function):
+    """RNN_ENCODER's bidirectional LSTM (util.py:233-260) in training mode: forward = tgsr_bilstm_train_fwd on the
+    embedded (and dropped-out) inputs, backward = tgsr_bilstm_bwd (BPTT, one workgroup per sample and direction) plus
+    four GEMMs for dW_ih, dW_hh and dx.  w_* are the two directions stacked: [2,4H,ninput], [2,4H,H], [2,4H]."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, lens):
+        words, sent, acts = ops.bilstm_train_fwd(x, lens, w_ih, w_hh, b_ih, b_hh)
+        ctx.save_for_backward(x, w_ih, w_hh, acts, words)
+        ctx.lens = list(lens)
+        return words, sent
+
+    @staticmethod
+    def backward(ctx, d_words, d_sent):
+        x, w_ih, w_hh, acts, words = ctx.saved_tensors
+        B, Tmax, K = x.shape
+        H = w_hh.shape[2]
+        if d_words is None:
+            d_words = torch.zeros_like(words)
+        dgates, hprev, dbias = ops.bilstm_bwd(ctx.lens, w_hh, acts, words, d_words, d_sent)
+        g2 = dgates.reshape(B * Tmax, 8 * H)
+        x2 = x.detach().reshape(B * Tmax, K)
+        dw_ih = _gemm_nt(g2.t(), x2.t()).reshape(2, 4 * H, K)                        # dgates^T x
+        dx = _gemm_nt(g2, w_ih.detach().reshape(8 * H, K).t()).reshape(B, Tmax, K)   # dgates W_ih
+        dw_hh = torch.stack([_gemm_nt(dgates[:, :, d].reshape(B * Tmax, 4 * H).t(),
+                                      hprev[:, :, d].reshape(B * Tmax, H).t()) for d in range(2)])
+        return dx, dw_ih, dw_hh, dbias, dbias.clone(), None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b with all three GEMMs on the HIP kernel (CNN_ENCODER.emb_cnn_code, util.py:301,364)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return ops.linear(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = _gemm_nt(dy, w.detach().t())          # [B,N] @ W [N,K]
+        dw = _gemm_nt(dy.t(), x.detach().t())      # dy^T x
+        return dx, dw, (dy.sum(0) if ctx.has_bias else None)
+
+
+class Conv1x1Fn(torch.autograd.Function):
+    """1x1 convolution without bias (CNN_ENCODER.emb_features, util.py:300,367): forward tgsr_conv1x1_fwd, backward as
+    the same kernel on the transposed weight (dx) and one GEMM over all positions (dw)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return ops.conv1x1(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        Cout, Cin = w.shape[0], w.shape[1]
+        dy = dy.contiguous()
+        dx = ops.conv1x1(dy, w.detach().reshape(Cout, Cin).t().contiguous())
+        dy2 = dy.permute(1, 0, 2, 3).reshape(Cout, -1)                 # [Cout, B*S]
+        x2 = x.detach().permute(1, 0, 2, 3).reshape(Cin, -1)           # [Cin,  B*S]
+        dw = _gemm_nt(dy2, x2).reshape(w.shape)
+        return dx, dw

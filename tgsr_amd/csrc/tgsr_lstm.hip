@@ -79,7 +79,7 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
                                                                float* __restrict__ words_emb,
                                                                float* __restrict__ sent_emb,
                                                                const int64_t* __restrict__ captions, int width,
-                                                               int ntoken) {
+                                                               int ntoken, float* __restrict__ acts) {
   __shared__ __attribute__((aligned(16))) float h_s[H];
   __shared__ float g_s[4 * H];
   const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
@@ -125,6 +125,10 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
       hcur = og * tanhf(c);
       h_s[j] = hcur;
       wout[t] = hcur;
+      if (acts) {   // training: gate activations and cell state of this step, [B][Tmax][2][5][H]
+        float* ap = acts + (((int64_t)b * Tmax + t) * 2 + d) * 5 * H + j;
+        ap[0] = ig; ap[H] = fg; ap[2 * H] = gg; ap[3 * H] = og; ap[4 * H] = c;
+      }
     }
     __syncthreads();
   }
@@ -136,7 +140,8 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
 __global__ void lstm_recurrent_generic_kernel(const float* __restrict__ gates, const int32_t* __restrict__ cap_lens,
                                               int Tmax, int H, const float* __restrict__ w_hh,
                                               float* __restrict__ words_emb, float* __restrict__ sent_emb,
-                                              const int64_t* __restrict__ captions, int width, int ntoken) {
+                                              const int64_t* __restrict__ captions, int width, int ntoken,
+                                              float* __restrict__ acts) {
   __shared__ float h_s[256];
   __shared__ float g_s[1024];
   const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
@@ -167,10 +172,85 @@ __global__ void lstm_recurrent_generic_kernel(const float* __restrict__ gates, c
       hcur = og * tanhf(c);
       h_s[j] = hcur;
       wout[t] = hcur;
+      if (acts) {
+        float* ap = acts + (((int64_t)b * Tmax + t) * 2 + d) * 5 * H + j;
+        ap[0] = ig; ap[H] = fg; ap[2 * H] = gg; ap[3 * H] = og; ap[4 * H] = c;
+      }
     }
     __syncthreads();
   }
   if (j < H) sent_emb[(int64_t)b * 2 * H + d * H + j] = hcur;
+}
+
+// Backward through time of one (sample, direction): walks the sample's steps in reverse processing order and emits
+// the pre-activation gate gradients dgates[b][t][d][4H] (zero past len) and hprev[b][t][d][H] (the hidden state that
+// entered step t) - the operands of the weight-gradient GEMMs  dW_ih = dgates^T x,  dW_hh = dgates^T hprev,
+// dx = dgates W_ih.  grid (B, 2), 4H threads: thread (q = tid / H, k = tid % H) keeps W_hh[d][q*H .. q*H+H)[k] (a
+// column segment) in registers for dh_prev[k] = sum_j W_hh[j][k] dgate[j]; the four partial sums meet in LDS.
+template <int H>
+__global__ __launch_bounds__(4 * H) void lstm_bwd_kernel(const int32_t* __restrict__ cap_lens, int Tmax,
+                                                         const float* __restrict__ w_hh,
+                                                         const float* __restrict__ acts,
+                                                         const float* __restrict__ words_emb,
+                                                         const float* __restrict__ d_words,
+                                                         const float* __restrict__ d_sent,
+                                                         float* __restrict__ dgates, float* __restrict__ hprev) {
+  __shared__ float dg_s[4 * H];
+  __shared__ float part_s[4 * H];
+  const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, q = tid / H, k = tid - q * H;
+  int len = cap_lens[b];
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  float w[H];
+#pragma unroll
+  for (int jj = 0; jj < H; ++jj) w[jj] = w_hh[((int64_t)d * 4 * H + q * H + jj) * H + k];
+  // steps past the caption: no gradient
+  for (int t = len; t < Tmax; ++t) {
+    dgates[(((int64_t)b * Tmax + t) * 2 + d) * 4 * H + tid] = 0.f;
+    if (tid < H) hprev[(((int64_t)b * Tmax + t) * 2 + d) * H + tid] = 0.f;
+  }
+  const float* hrow = words_emb + ((int64_t)b * 2 * H + d * H + k) * Tmax;     // h[t] of unit k (tid < H)
+  const float* dwrow = d_words + ((int64_t)b * 2 * H + d * H + k) * Tmax;
+  float dh_carry = 0.f, dc_carry = 0.f;                                        // valid for tid < H
+  if (tid < H && d_sent) dh_carry = d_sent[(int64_t)b * 2 * H + d * H + k];    // final hidden state = sentence code
+  for (int s = len - 1; s >= 0; --s) {
+    const int t = d == 0 ? s : len - 1 - s;
+    const int tp = d == 0 ? t - 1 : t + 1;                                     // time of the previous step (s > 0)
+    const int64_t row = ((int64_t)b * Tmax + t) * 2 + d;
+    if (tid < H) {
+      const float* ap = acts + row * 5 * H + k;
+      const float ig = ap[0], fg = ap[H], gg = ap[2 * H], og = ap[3 * H], c = ap[4 * H];
+      const float cprev = s > 0 ? acts[(((int64_t)b * Tmax + tp) * 2 + d) * 5 * H + 4 * H + k] : 0.f;
+      const float hp = s > 0 ? hrow[tp] : 0.f;
+      const float dh = dwrow[t] + dh_carry;
+      const float tc = tanhf(c);
+      const float dc = dc_carry + dh * og * (1.f - tc * tc);
+      dg_s[k] = dc * gg * ig * (1.f - ig);                 // d a_i
+      dg_s[H + k] = dc * cprev * fg * (1.f - fg);          // d a_f
+      dg_s[2 * H + k] = dc * ig * (1.f - gg * gg);         // d a_g
+      dg_s[3 * H + k] = dh * tc * og * (1.f - og);         // d a_o
+      dc_carry = dc * fg;
+      hprev[row * H + k] = hp;
+    }
+    __syncthreads();
+    dgates[row * 4 * H + tid] = dg_s[tid];
+    float p = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) p = fmaf(w[jj], dg_s[q * H + jj], p);
+    part_s[tid] = p;
+    __syncthreads();
+    if (tid < H) dh_carry = part_s[k] + part_s[H + k] + part_s[2 * H + k] + part_s[3 * H + k];
+    __syncthreads();
+  }
+}
+
+// out[k] = sum_{p < n} parts[p][k], p ascending (bias gradients = column sums of dgates)
+__global__ void lstm_colsum_kernel(const float* __restrict__ parts, int n, int m, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < m) {
+    float s = 0.f;
+    for (int p = 0; p < n; ++p) s += parts[(int64_t)p * m + k];
+    out[k] = s;
+  }
 }
 
 }  // namespace tgsr
@@ -179,20 +259,20 @@ using namespace tgsr;
 
 static int launch_recurrent(const float* gates, const int32_t* cap_lens, int B, int Tmax, const float* w_hh, int H,
                             float* words_emb, float* sent_emb, const int64_t* captions, int width, int ntoken,
-                            hipStream_t s) {
+                            hipStream_t s, float* acts = nullptr) {
   dim3 grid(B, 2);
   if (H == 128)
     hipLaunchKernelGGL(lstm_recurrent_kernel<128>, grid, dim3(512), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
-                       sent_emb, captions, width, ntoken);
+                       sent_emb, captions, width, ntoken, acts);
   else if (H == 64)
     hipLaunchKernelGGL(lstm_recurrent_kernel<64>, grid, dim3(256), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
-                       sent_emb, captions, width, ntoken);
+                       sent_emb, captions, width, ntoken, acts);
   else if (H == 32)
     hipLaunchKernelGGL(lstm_recurrent_kernel<32>, grid, dim3(128), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
-                       sent_emb, captions, width, ntoken);
+                       sent_emb, captions, width, ntoken, acts);
   else
     hipLaunchKernelGGL(lstm_recurrent_generic_kernel, grid, dim3(4 * H), 0, s, gates, cap_lens, Tmax, H, w_hh,
-                       words_emb, sent_emb, captions, width, ntoken);
+                       words_emb, sent_emb, captions, width, ntoken, acts);
   return note_launch(hipGetLastError(), "lstm_recurrent_kernel");
 }
 
@@ -231,4 +311,47 @@ extern "C" int tgsr_bilstm_table_fwd(const int64_t* captions, int width, const i
   if (H > 256 || (4 * H) % 64 != 0) return TGSR_EUNSUPPORTED;
   return launch_recurrent(table, cap_lens, B, Tmax, w_hh, H, words_emb, sent_emb, captions, width, ntoken,
                           as_stream(stream));
+}
+
+// Training forward on dense (already embedded, possibly dropped-out) inputs x [B][Tmax][ninput]; also saves the gate
+// activations and cell states acts [B][Tmax][2][5][H] for tgsr_bilstm_bwd.
+extern "C" int tgsr_bilstm_train_fwd(const float* x, const int32_t* cap_lens, int B, int Tmax, int ninput,
+                                     const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, int H,
+                                     float* gates_ws, float* acts, float* words_emb, float* sent_emb, void* stream) {
+  if (!x || !cap_lens || !w_ih || !w_hh || !b_ih || !b_hh || !gates_ws || !acts || !words_emb || !sent_emb)
+    return TGSR_EINVAL;
+  if (B < 1 || Tmax < 1 || ninput < 1 || H < 1) return TGSR_EINVAL;
+  if (H > 256 || (4 * H) % 64 != 0) return TGSR_EUNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const int M = B * Tmax, N = 8 * H;
+  hipLaunchKernelGGL(lstm_input_gates_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, s,
+                     (const int64_t*)nullptr, 1, 1, x, M, w_ih, b_ih, b_hh, M, N, ninput, gates_ws);
+  int rc = note_launch(hipGetLastError(), "lstm_input_gates_kernel(train)");
+  if (rc) return rc;
+  return launch_recurrent(gates_ws, cap_lens, B, Tmax, w_hh, H, words_emb, sent_emb, nullptr, 0, 0, s, acts);
+}
+
+extern "C" int tgsr_bilstm_bwd(const int32_t* cap_lens, int B, int Tmax, int H, const float* w_hh, const float* acts,
+                               const float* words_emb, const float* d_words, const float* d_sent, float* dgates,
+                               float* hprev, float* dbias, void* stream) {
+  if (!cap_lens || !w_hh || !acts || !words_emb || !d_words || !dgates || !hprev || B < 1 || Tmax < 1)
+    return TGSR_EINVAL;
+  hipStream_t s = as_stream(stream);
+  dim3 grid(B, 2);
+  if (H == 128)
+    hipLaunchKernelGGL(lstm_bwd_kernel<128>, grid, dim3(512), 0, s, cap_lens, Tmax, w_hh, acts, words_emb, d_words,
+                       d_sent, dgates, hprev);
+  else if (H == 64)
+    hipLaunchKernelGGL(lstm_bwd_kernel<64>, grid, dim3(256), 0, s, cap_lens, Tmax, w_hh, acts, words_emb, d_words,
+                       d_sent, dgates, hprev);
+  else if (H == 32)
+    hipLaunchKernelGGL(lstm_bwd_kernel<32>, grid, dim3(128), 0, s, cap_lens, Tmax, w_hh, acts, words_emb, d_words,
+                       d_sent, dgates, hprev);
+  else
+    return TGSR_EUNSUPPORTED;
+  int rc = note_launch(hipGetLastError(), "lstm_bwd_kernel");
+  if (rc || !dbias) return rc;
+  const int m = 8 * H;   // dbias[2][4H] = sum over (b, t) of dgates (= d b_ih = d b_hh)
+  hipLaunchKernelGGL(lstm_colsum_kernel, dim3((m + 255) / 256), dim3(256), 0, s, dgates, B * Tmax, m, dbias);
+  return note_launch(hipGetLastError(), "lstm_colsum_kernel");
 }

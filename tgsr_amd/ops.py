@@ -332,6 +332,46 @@ def bilstm(captions: torch.Tensor, cap_lens, emb: torch.Tensor, w_ih: torch.Tens
     return words, sent
 
 
+def bilstm_train_fwd(x: torch.Tensor, cap_lens, w_ih, w_hh, b_ih, b_hh):
+    """Training forward on embedded inputs x [B,Tmax,ninput]: returns (words_emb, sent_emb, acts) where acts
+    [B,Tmax,2,5,H] holds the gate activations / cell states tgsr_bilstm_bwd needs."""
+    _need_hip(x, w_ih, w_hh, b_ih, b_hh)
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    B, Tmax, K = x.shape
+    if len(lens) != B or min(lens) < 1 or max(lens) > Tmax:
+        raise TgsrError("bilstm_train_fwd: cap_lens %s invalid for x %s" % (lens, tuple(x.shape)))
+    H = w_hh.shape[2]
+    dev = x.device
+    ts = [_f32(t.detach(), "lstm tensor").contiguous() for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    gates = torch.empty(B * Tmax * 8 * H, dtype=torch.float32, device=dev)
+    acts = torch.zeros(B, Tmax, 2, 5, H, dtype=torch.float32, device=dev)
+    words = torch.empty(B, 2 * H, Tmax, dtype=torch.float32, device=dev)
+    sent = torch.empty(B, 2 * H, dtype=torch.float32, device=dev)
+    rc = _lib.lib().tgsr_bilstm_train_fwd(_p(ts[0]), _p(_lens_on_device(tuple(lens), dev)), B, Tmax, K, _p(ts[1]),
+                                          _p(ts[2]), _p(ts[3]), _p(ts[4]), H, _p(gates), _p(acts), _p(words), _p(sent),
+                                          _stream())
+    check(rc, "tgsr_bilstm_train_fwd")
+    return words, sent, acts
+
+
+def bilstm_bwd(cap_lens, w_hh, acts, words, d_words, d_sent):
+    """BPTT of both directions: returns (dgates [B,Tmax,2,4H], hprev [B,Tmax,2,H], dbias [2,4H])."""
+    _need_hip(w_hh, acts, words, d_words, d_sent)
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    B, Tmax, _, _, H = acts.shape
+    dev = acts.device
+    dgates = torch.empty(B, Tmax, 2, 4 * H, dtype=torch.float32, device=dev)
+    hprev = torch.empty(B, Tmax, 2, H, dtype=torch.float32, device=dev)
+    dbias = torch.empty(2, 4 * H, dtype=torch.float32, device=dev)
+    dw = _f32(d_words, "d_words").contiguous()
+    ds = None if d_sent is None else _f32(d_sent, "d_sent").contiguous()
+    rc = _lib.lib().tgsr_bilstm_bwd(_p(_lens_on_device(tuple(lens), dev)), B, Tmax, H,
+                                    _p(_f32(w_hh.detach(), "w_hh").contiguous()), _p(acts), _p(words.contiguous()),
+                                    _p(dw), _p(ds), _p(dgates), _p(hprev), _p(dbias), _stream())
+    check(rc, "tgsr_bilstm_bwd")
+    return dgates, hprev, dbias
+
+
 def lstm_gate_table(emb, w_ih, b_ih, b_hh):
     """[ntoken, 2, 4H] gate pre-activations of every token (eval mode, frozen weights); see tgsr_lstm_gate_table."""
     _need_hip(emb, w_ih, b_ih, b_hh)

@@ -8,8 +8,10 @@ training mode.  What it does NOT pin down (no caller exists): loss weights, upda
 architecture (no class anywhere in the reference) and the Inception image encoder (third-party weights).  This
 harness therefore trains the two generators on the pixel + KL terms,
     errG = MSE(fake_imgL, HR pyramid) + MSE(fine_im, HR pyramid) + KL(mu, logvar),
-and takes the adversarial / DAMSM terms only when the caller supplies `netsD` / `image_encoder`.
+and takes the adversarial / DAMSM terms only when the caller supplies `netsD` / `image_encoder` (the DAMSM term
+`words_loss + sent_loss` on `image_encoder(fine_im[-1])` is differentiable through the HIP DAMSM backward kernel).
 Every forward and backward kernel of the generators is HIP (tgsr_amd.autograd); the text encoder is frozen (eval).
+`DAMSMTrainer` is the counterpart of pretrain_DAMSM.py (text encoder + CNN_ENCODER heads on the matching losses).
 Data parallel: gradients live in one flat bucket, one all-reduce per step (tgsr_amd.parallel.FlatGradBucket).
 """
 from copy import deepcopy
@@ -18,7 +20,7 @@ import torch
 
 from .miscc import losses
 from .miscc.config import cfg
-from .model import G_SR_NET_low, NetG_highweight, RNN_ENCODER
+from .model import CNN_ENCODER, G_SR_NET_low, NetG_highweight, RNN_ENCODER
 from .parallel import FlatGradBucket
 from .trainer import caption_mask
 
@@ -41,8 +43,12 @@ def prepare_labels(batch_size, device):
 
 
 class SRTrainer:
-    def __init__(self, n_words, device="cuda", low="lr", lr=None, ema_decay=0.999):
+    def __init__(self, n_words, device="cuda", low="lr", lr=None, ema_decay=0.999, image_encoder=None):
+        """image_encoder: optional frozen module image [B,3,256,256] -> (region features [B,nef,17,17], cnn_code
+        [B,nef]) (a CNN_ENCODER with its trunk): adds the DAMSM ranking term of generator_loss (losses.py:375-386)
+        on the finest image, x TRAIN.SMOOTH.LAMBDA."""
         self.device = torch.device(device)
+        self.image_encoder = image_encoder
         self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM).to(self.device).eval()
         for p in self.text_encoder.parameters():
             p.requires_grad = False
@@ -54,7 +60,7 @@ class SRTrainer:
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
 
-    def loss(self, captions, cap_lens, LR, LRb, hr_pyramid):
+    def loss(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """hr_pyramid: the 3 target scales [B,3,2s,2s], [B,3,4s,4s], [B,3,8s,8s]."""
         with torch.no_grad():
             words_embs, sent_emb = self.text_encoder(captions, cap_lens, self.text_encoder.init_hidden(captions.shape[0]))
@@ -62,6 +68,13 @@ class SRTrainer:
         fake_imgL, _att, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
         fine_im, _a, _one = self.netGH(LR, fake_imgL, LRb)
         errG = losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
+        if self.image_encoder is not None:
+            B = captions.shape[0]
+            match_labels = torch.arange(B, device=self.device)
+            region_features, cnn_code = self.image_encoder(fine_im[-1])
+            w0, w1, _ = losses.words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, B)
+            s0, s1 = losses.sent_loss(cnn_code, sent_emb, match_labels, class_ids, B)
+            errG = errG + (w0 + w1 + s0 + s1) * cfg.TRAIN.SMOOTH.LAMBDA
         return errG, fake_imgL, fine_im
 
     def step(self, captions, cap_lens, LR, LRb, hr_pyramid):
@@ -77,3 +90,63 @@ class SRTrainer:
             torch._foreach_mul_(self.avg_param_G, self.ema_decay)
             torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
         return errG.detach()
+
+
+class DAMSMTrainer:
+    """pretrain_DAMSM.py:48-125, 262-284: joint training of RNN_ENCODER and the CNN_ENCODER heads on
+    words_loss + sent_loss.  Every gradient comes from HIP kernels: DAMSM backward (tgsr_damsm_words_bwd), LSTM BPTT
+    (tgsr_bilstm_bwd) and the GEMMs of the heads; the Inception trunk is the caller's frozen module
+    (CNN_ENCODER(trunk=...)) or pre-extracted features via `step_features`.  Like the reference: a fresh
+    Adam(lr, betas (0.5, 0.999)) per epoch, lr x 0.98 per epoch down to ENCODER_LR / 10, gradient-norm clip
+    RNN_GRAD_CLIP on the text encoder only.  Data parallel: one flat gradient bucket, one all-reduce per step; the
+    contrastive losses use the local shard's negatives."""
+
+    def __init__(self, n_words, device="cuda", trunk=None, lr=None):
+        self.device = torch.device(device)
+        self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM).to(self.device).train()
+        self.image_encoder = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM,
+                                         trunk=trunk if trunk is not None else torch.nn.Identity()).to(self.device)
+        self.image_encoder.train()
+        for p in self.image_encoder.trunk.parameters():
+            p.requires_grad = False                                  # util.py:277-278
+        self.params = list(self.text_encoder.parameters()) + [p for p in self.image_encoder.parameters()
+                                                              if p.requires_grad]
+        self.bucket = FlatGradBucket(self.params).attach()
+        self.base_lr = self.lr = lr or cfg.TRAIN.ENCODER_LR
+        self.start_epoch()
+
+    def start_epoch(self):
+        """pretrain_DAMSM.py:270: the optimizer (and its moments) is rebuilt every epoch."""
+        self.opt = torch.optim.Adam(self.params, lr=self.lr, betas=(0.5, 0.999))
+
+    def end_epoch(self):
+        """pretrain_DAMSM.py:283-284."""
+        if self.lr > self.base_lr / 10.:
+            self.lr *= 0.98
+
+    def loss_from_features(self, features, pooled, captions, cap_lens, class_ids=None):
+        B = captions.shape[0]
+        labels = torch.arange(B, device=self.device)
+        words_features, sent_code = self.image_encoder.heads(features, pooled)
+        words_emb, sent_emb = self.text_encoder(captions, cap_lens, self.text_encoder.init_hidden(B))
+        w0, w1, att = losses.words_loss(words_features, words_emb, labels, cap_lens, class_ids, B)
+        s0, s1 = losses.sent_loss(sent_code, sent_emb, labels, class_ids, B)
+        return w0 + w1 + s0 + s1, (w0.detach(), w1.detach(), s0.detach(), s1.detach()), att
+
+    def step_features(self, features, pooled, captions, cap_lens, class_ids=None):
+        """One optimisation step on trunk outputs (features [B,768,17,17], pooled [B,2048]).  Returns the loss."""
+        self.bucket.flat.zero_()
+        for p, v in zip(self.bucket.params, self.bucket.views):
+            p.grad = v
+        loss, _parts, _att = self.loss_from_features(features, pooled, captions, cap_lens, class_ids)
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        torch.nn.utils.clip_grad_norm_(self.text_encoder.parameters(), cfg.TRAIN.RNN_GRAD_CLIP)   # :96-97
+        self.opt.step()
+        return loss.detach()
+
+    def step(self, imgs, captions, cap_lens, class_ids=None):
+        """pretrain_DAMSM.py:66-98 with the image through the (frozen) trunk."""
+        with torch.no_grad():
+            features, pooled = self.image_encoder.trunk(imgs)
+        return self.step_features(features, pooled, captions, cap_lens, class_ids)

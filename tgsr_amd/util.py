@@ -226,9 +226,17 @@ class RNN_ENCODER(nn.Module):
     def forward(self, captions, cap_lens, hidden=None, mask=None):
         """captions int64 [B, n_steps] sorted by length (desc), cap_lens [B] -> (words_emb [B, 2H, T_max],
         sent_emb [B, 2H]).  `hidden` must be the zero state of init_hidden (the only use in the reference)."""
-        if self.training and self.drop_prob > 0:
-            raise NotImplementedError("RNN_ENCODER: training-mode dropout / LSTM backward are not on the HIP path "
-                                      "(the SR training keeps the text encoder frozen in eval mode); call .eval()")
+        if self.training:
+            # util.py:236-252: emb = drop(encoder(captions)) (torch embedding + dropout: their gradients are
+            # autograd's), then the LSTM through its HIP forward / BPTT kernels (autograd.BiLSTM)
+            from .autograd import BiLSTM
+            lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+            r = self.rnn
+            emb = self.drop(self.encoder(captions[:, :max(lens)]))
+            return BiLSTM.apply(emb, torch.stack([r.weight_ih_l0, r.weight_ih_l0_reverse]),
+                                torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse]),
+                                torch.stack([r.bias_ih_l0, r.bias_ih_l0_reverse]),
+                                torch.stack([r.bias_hh_l0, r.bias_hh_l0_reverse]), lens)
         w_ih, w_hh, b_ih, b_hh = self._weights()
         if not self.training:
             # frozen weights: the input projection is a function of the token only -> per-token gate table, built once
@@ -265,6 +273,10 @@ class CNN_ENCODER(nn.Module):
 
     def heads(self, features, pooled):
         """(features [B,768,17,17], pooled [B,2048]) -> (region features [B,nef,17,17], cnn_code [B,nef])."""
+        if torch.is_grad_enabled() and (self.emb_cnn_code.weight.requires_grad or features.requires_grad):
+            from .autograd import Conv1x1Fn, LinearFn
+            return (Conv1x1Fn.apply(features, self.emb_features.weight),
+                    LinearFn.apply(pooled, self.emb_cnn_code.weight, self.emb_cnn_code.bias))
         cnn_code = ops.linear(pooled, self.emb_cnn_code.weight, self.emb_cnn_code.bias)
         return ops.conv1x1(features, self.emb_features.weight), cnn_code
 
