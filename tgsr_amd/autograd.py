@@ -3,9 +3,10 @@
 The reference trains through torch autograd over nn.Conv2d / nn.BatchNorm2d(train) / GLU / nn.Upsample
 (util.py:74-80, 110-130).  Here one Function = one fused block:
     ConvBnAct: [nearest x2 ->] conv3x3 -> BatchNorm2d(batch statistics) -> GLU | (+ residual)
-        forward : tgsr_conv3x3_fwd (raw) -> tgsr_bn_train_fwd (stats, running update, normalise + GLU/residual)
-        backward: tgsr_bn_train_bwd (GLU', BN') -> data gradient = tgsr_conv3x3_fwd on flipped/transposed weights
-                  (+ tgsr_sumpool2x2 through the up-sample) and tgsr_conv3x3_wgrad
+        forward : tgsr_wino_conv3x3_fwd | tgsr_conv3x3_fwd (raw) -> tgsr_bn_train_fwd (stats, running update,
+                  normalise + GLU/residual)
+        backward: tgsr_bn_train_bwd (GLU', BN') -> data gradient = the same conv kernels on flipped/transposed
+                  weights (+ tgsr_sumpool2x2 through the up-sample) and tgsr_conv3x3_wgrad
 """
 import torch
 
@@ -19,6 +20,17 @@ def _dgrad_weight(w: torch.Tensor) -> torch.Tensor:
     return w.flip(2, 3).transpose(0, 1).contiguous()
 
 
+def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False) -> torch.Tensor:
+    """conv3x3 without affine / activation (what BatchNorm's batch statistics are taken of, and the data gradient):
+    the Winograd kernel where it applies (no up-sampling, Cout % 64 == 0, Cin % 4 == 0), else the direct kernel.
+    The weights change every step, so they are packed per call (a few microseconds)."""
+    from . import util
+    Cout = weight.shape[0]
+    if util.WINOGRAD and not upsample and ops.wino_supported(x, Cout):
+        return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False), Cout, None, None)
+    return ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), Cout, None, None, glu=False, upsample=upsample)
+
+
 class ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps):
@@ -26,8 +38,7 @@ class ConvBnAct(torch.autograd.Function):
         x = x.contiguous()
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
-        wpack = ops.pack_conv3x3_weight(weight)
-        raw = ops.conv3x3_fused(x, wpack, Cout, None, None, glu=False, upsample=upsample)
+        raw = _conv_raw(x, weight.detach(), upsample)
         Ho, Wo = raw.shape[2], raw.shape[3]
         HW = Ho * Wo
         dev = x.device
@@ -73,7 +84,7 @@ class ConvBnAct(torch.autograd.Function):
             cpad = (Cin + 31) // 32 * 32                                  # the kernel tiles 32 output channels
             if cpad != Cin:                                               # stem convs (Cin = 3): zero-padded rows
                 wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cout, 3, 3)), 0)
-            dxu = ops.conv3x3_fused(draw, ops.pack_conv3x3_weight(wT), cpad, None, None)
+            dxu = _conv_raw(draw, wT)
             if cpad != Cin:
                 dxu = dxu[:, :Cin].contiguous()                           # [B, Cin, Ho, Wo]
             if upsample:
