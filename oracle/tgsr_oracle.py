@@ -269,6 +269,41 @@ def netg_highweight(sd: SD, LR: Tensor, SRb: Sequence[Tensor], LRb: Tensor, low:
     return [ims2, ims4, ims8], a, one
 
 
+def netg_highweight16(sd: SD, LR: Tensor, SRb: Sequence[Tensor], LRb: Tensor, low: str = "lr",
+                      training=False, update=None, p: str = ""):
+    """models16.py:97-179  x16 NetG_highweight.forward with weightmap=False: like the x8 one plus a fourth head whose
+    stage re-uses `residual48` / `upscale8x` (:172-173), and `a` is a registered parameter here (sd[p + "a"], :126).
+    The shipped line :178 adds the 8x image to the 16x tensor and cannot execute (shape error, pinned by
+    tests/golden/nets16_small.npz `gh16_runs == 0`); as in tgsr_amd.models16 the 16x head adds SRb[3]."""
+    if low == "lrblur":
+        x = LRb
+    elif low == "lr-lrblur":
+        x = LR - LRb
+    else:
+        x = LR
+    a = sd[p + "a"]
+    one = LR.new_ones(1)
+    out = conv_bn_glu(x, sd, p + "convin.", training, update)
+    r = 0
+    while (p + "residual.%d.block.0.weight" % r) in sd:
+        out = res_block(out, sd, p + "residual.%d." % r, training, update)
+        r += 1
+    w5 = sd[p + "conv_output.0.weight"]
+
+    def head(o, sr):
+        return one * torch.tanh(F.conv2d(o, w5, None, 1, 2)) + a * sr
+
+    out = up_block(out, sd, p + "upscale2x.", training, update)
+    ims = [head(out, SRb[0])]
+    out = up_block(residual_nosum(out, sd, p + "residual24.", training, update), sd, p + "upscale4x.", training, update)
+    ims.append(head(out, SRb[1]))
+    for k in (2, 3):                                     # 8x, then 16x through the same modules
+        out = up_block(residual_nosum(out, sd, p + "residual48.", training, update), sd, p + "upscale8x.", training,
+                       update)
+        ims.append(head(out, SRb[k]))
+    return ims, a, one
+
+
 def sr_forward(sd_E: SD, sd_GL: SD, sd_GH: SD, captions: Tensor, cap_lens, LR: Tensor, LRb: Tensor,
                low: str = "lr", correct_mask: bool = False):
     """Caller counterpart of trainer_objective.py:134-146 (eval mode): text encoder -> mask ->

@@ -336,3 +336,69 @@ def test_sr_trainer_with_damsm_term():
         assert all(torch.isfinite(p.grad).all() for p in tr.params)
     assert np.isfinite(losses_).all() and losses_[1] > losses_[0] + 1e-3      # the ranking term is positive
     cfg_reset()
+
+
+def test_models16_train_mode_gradients():
+    """x16 generators (models16.py): weight-tied stages accumulate their gradients over the three uses, the tanh heads
+    and NetG_highweight's trainable `a` train on HIP; every parameter gradient vs torch autograd over the oracle."""
+    from conftest import load_npz, split_sd
+    from tgsr_amd import models16
+    from tgsr_amd.miscc import losses
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    g = load_npz("nets16_small.npz")
+    cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 64; cfg.TREE.BRANCH_NUM = 5
+    try:
+        sdL = split_sd(g, "GL.")
+        gl = models16.G_SR_NET_low()
+        gl.load_state_dict(sdL, strict=False)
+        torch.manual_seed(4)
+        gh = models16.NetG_highweight(weightmap=False, low="lr")
+        sdH = {k: v.detach().clone() for k, v in gh.state_dict().items()}
+        gl.to(DEV).train(); gh.to(DEV).train()
+        gen = torch.Generator().manual_seed(9)
+        B = 2
+        LR = torch.rand(B, 3, 8, 8, generator=gen) * 2 - 1
+        words = torch.randn(B, 64, 6, generator=gen)
+        sent = torch.randn(B, 64, generator=gen)
+        mask = torch.arange(6)[None, :] >= torch.tensor([[6], [4]])
+        hr = [torch.rand(B, 3, s, s, generator=gen) * 2 - 1 for s in (16, 32, 64, 128)]
+        imgs, atts, mu, lv = gl(LR.to(DEV), sent.to(DEV), words.to(DEV), mask.to(DEV))
+        fine, a, one = gh(LR.to(DEV), imgs, LR.to(DEV))
+        hd = [h.to(DEV) for h in hr]
+        loss = losses.MSE(imgs, hd) + losses.MSE(fine, hd) + losses.KL_loss(mu, lv)
+        loss.backward()
+        # oracle: the fixture stores tied tensors once (under the first alias); the oracle reads h_net2 / img_net1
+        pL = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+              if v.dtype.is_floating_point else v.cpu() for k, v in sdL.items()}
+        pH = {k: (v.clone().requires_grad_() if v.dtype.is_floating_point and "running" not in k else v.clone())
+              for k, v in sdH.items()}
+        ri, ra, rmu, rlv = O.g_sr_net_low16(pL, LR, sent, words, mask, training=True)
+        rf, _, _ = O.netg_highweight16(pH, LR, ri, LR, "lr", training=True)
+        rloss = O.mse(ri, hr) + O.mse(rf, hr) + O.kl_loss(rmu, rlv)
+        rloss.backward()
+        close(loss, rloss, atol=2e-4)
+        seen = set()
+
+        def ref_key(k, ref):                         # a tied tensor is listed once, under any of its aliases
+            for grp in (("h_net2.", "h_net3.", "h_net4."), ("img_net1.", "img_net2.", "img_net3.", "img_net4.")):
+                for a_ in grp:
+                    if k.startswith(a_):
+                        for b_ in grp:
+                            if b_ + k[len(a_):] in ref and ref[b_ + k[len(a_):]].grad is not None:
+                                return b_ + k[len(a_):]
+            return k
+
+        for net, ref in ((gl, pL), (gh, pH)):
+            for k0, p in net.named_parameters():
+                k = ref_key(k0, ref)
+                if k not in ref or ref[k].grad is None:
+                    assert any(u in k0 for u in ("upscale16x", "residual816")), k0     # never-called modules only
+                    continue
+                r = ref[k].grad
+                assert p.grad is not None, k
+                err = float((p.grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-6)
+                assert err < 5e-3, (k, err)
+                seen.add(k)
+        assert "a" in seen and any(k.startswith("h_net2.") for k in seen) and "img_net1.img.0.weight" in seen
+    finally:
+        cfg_reset()

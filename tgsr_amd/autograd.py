@@ -120,9 +120,12 @@ class ConvTo3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, addend, tanh_axpy, alpha):
-        out = ops.conv_to3(x, weight, tanh_axpy=tanh_axpy, addend=addend, alpha=alpha)
+        """alpha: python float, or a 1-element tensor (models16.NetG_highweight's trainable `a`, models16.py:126)."""
+        ctx.alpha_is_tensor = torch.is_tensor(alpha)
+        alpha_f = float(alpha.detach().item()) if ctx.alpha_is_tensor else float(alpha)
+        out = ops.conv_to3(x, weight, tanh_axpy=tanh_axpy, addend=addend, alpha=alpha_f)
         ctx.save_for_backward(x, weight, out if tanh_axpy else None, addend)
-        ctx.cfg = (tanh_axpy, float(alpha))
+        ctx.cfg = (tanh_axpy, alpha_f)
         return out
 
     @staticmethod
@@ -144,7 +147,10 @@ class ConvTo3(torch.autograd.Function):
                                  _lib.ACT_TANH_AXPY if tanh_axpy else _lib.ACT_NONE, _p(dx), _p(ws), _p(dw), _stream())
         check(rc, "tgsr_conv_to3_bwd")
         dadd = dy * alpha if (addend is not None and ctx.needs_input_grad[2]) else None
-        return dx, dw, dadd, None, None
+        dalpha = None
+        if ctx.alpha_is_tensor and ctx.needs_input_grad[4] and addend is not None:
+            dalpha = (dy * addend).sum().reshape(1)              # out = tanh(conv) + alpha * addend
+        return dx, dw, dadd, None, dalpha
 
 
 class WordAttention(torch.autograd.Function):

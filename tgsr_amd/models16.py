@@ -71,8 +71,8 @@ class NetG_highweight(nn.Module):
 
     def _head(self, out, SRb):
         if self.training:
-            raise NotImplementedError("x16 NetG_highweight: the trainable `a` (models16.py:126) is not on the HIP "
-                                      "training path yet; train the x8 networks or call .eval()")
+            from .autograd import ConvTo3
+            return ConvTo3.apply(out, self.conv_output[0].weight, SRb, True, self.a)   # d/da = sum(dy * SRb)
         return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=float(self.a.item()))
 
     def forward(self, LR, SRb, LRb):
