@@ -36,7 +36,8 @@ TRAFFIC_PER_LAUNCH_BYTES = {
     "upconv_glu_mfma_kernel": 84.01e6,   # same file (algorithmic: 80.9e6)
 }
 # share of the direct-form multiplies a kernel actually issues (Winograd F(2x2,3x3): 16/36; sub-pixel upBlock: 4/9)
-EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "upconv_glu_mfma_kernel": 4.0 / 9.0}
+EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "upconv_glu_mfma_kernel": 4.0 / 9.0,
+                         "upwino_glu_kernel": 9.0 / 36.0}   # up-sample-aware Winograd: 9 of the 16 positions
 
 
 def load_weights():
@@ -259,7 +260,8 @@ def main():
             # the reference's direct-form FLOP count (2*B*H*W*Cout*Cin*9) over the launch time.  The Winograd and
             # sub-pixel kernels issue 4/9 of those multiplies, so `mfma_executed_frac` (what the MFMA pipe really
             # ran, over the dense fp32 peak) is reported next to `frac`.
-            conv_kernels = [k for k in ("wino_conv3x3_kernel", "conv3x3_mfma_kernel", "upconv_glu_mfma_kernel") if k in agg]
+            conv_kernels = [k for k in ("wino_conv3x3_kernel", "upwino_glu_kernel", "conv3x3_mfma_kernel",
+                                        "upconv_glu_mfma_kernel") if k in agg]
             dom = max(conv_kernels, key=lambda k: agg[k][3])
             n, fl, by, sec = agg[dom]
             ach = fl / sec / 1e12

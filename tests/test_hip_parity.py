@@ -117,6 +117,25 @@ def test_upconv_subpixel_vs_upsample_conv(B, Cin, H, W, Cout):
     assert (wide[:, :2] == 3).all() and (wide[:, 2 + Cout // 2:] == 3).all()
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 64, 16, 16, 64), (3, 32, 32, 32, 64), (1, 64, 9, 20, 128),
+                                             (1, 4, 3, 4, 64), (16, 64, 32, 32, 64), (2, 8, 7, 36, 128)])
+def test_upblock_winograd_vs_upsample_conv(B, Cin, H, W, Cout):
+    """upBlock by the up-sample-aware Winograd form (9 of 16 positions) == Upsample(x2) -> conv3x3 -> affine -> GLU."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Cin + H + 1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.3 * torch.randn(Cout, generator=g)
+    xi = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    ref = O.glu(F.conv2d(xi, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None])
+    wide = torch.full((B, Cout // 2 + 6, 2 * H, 2 * W), 3.0, device=DEV)
+    out = ops.upwino_glu(x.to(DEV), ops.pack_upwino_weight(w.to(DEV)), Cout, scale.to(DEV), shift.to(DEV),
+                         out=wide[:, 2:2 + Cout // 2])
+    close(out, ref, atol=2e-5, rtol=2e-5)
+    assert (wide[:, :2] == 3).all() and (wide[:, 2 + Cout // 2:] == 3).all()
+
+
 WINO_CASES = [
     # B, Cin, H, W, Cout, glu, res
     (2, 64, 32, 32, 128, True, False),

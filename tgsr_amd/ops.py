@@ -195,6 +195,47 @@ def upconv3x3_glu(x: torch.Tensor, wpack_up: torch.Tensor, cout: int, scale, shi
     return out
 
 
+def pack_upwino_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> the 9 tap-sum positions of the up-sample-aware Winograd form (tgsr_upwino_glu_fwd)."""
+    _need_hip(w)
+    w = _f32(w.detach(), "weight").contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = torch.empty(L.tgsr_packed_upwino_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
+    check(L.tgsr_pack_upwino_weight(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_upwino_weight")
+    return out
+
+
+def upwino_supported(x: torch.Tensor, cout: int, out: Optional[torch.Tensor] = None) -> bool:
+    """Shapes tgsr_upwino_glu_fwd takes: Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0, aligned planes."""
+    if not (x.dim() == 4 and cout % 64 == 0 and x.shape[1] % 4 == 0 and x.shape[3] % 4 == 0 and
+            x.data_ptr() % 16 == 0 and (x.shape[0] == 1 or x.stride(0) % 4 == 0)):
+        return False
+    return out is None or (out.data_ptr() % 8 == 0 and (out.shape[0] == 1 or out.stride(0) % 2 == 0))
+
+
+def upwino_glu(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """upBlock in one launch by Winograd on the up-sampled grid (9 products per 2x2 outputs); contract of upconv3x3_glu."""
+    _need_hip(x, upack, scale, shift, out)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    B, Cin, H, W = x.shape
+    co, Ho, Wo = cout // 2, 2 * H, 2 * W
+    if out is None:
+        out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (B, co, Ho, Wo) or out.stride(3) != 1 or out.stride(2) != Wo or out.stride(1) != Ho * Wo:
+        raise TgsrError("upwino_glu: bad `out` shape/strides %s %s" % (tuple(out.shape), out.stride()))
+    obs = out.stride(0) if B > 1 else co * Ho * Wo
+    e0 = _ev() if profile is not None else None
+    rc = _lib.lib().tgsr_upwino_glu_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(out), obs,
+                                        _stream())
+    check(rc, "tgsr_upwino_glu_fwd")
+    if profile is not None:
+        nbytes = 4 * (B * Cin * H * W + B * co * Ho * Wo + cout * Cin * 9)
+        profile.append(("upwino_glu_kernel", 2.0 * B * Ho * Wo * cout * Cin * 9, nbytes, e0, _ev()))
+    return out
+
+
 def conv_to3(x: torch.Tensor, w: torch.Tensor, tanh_axpy: bool = False, addend: Optional[torch.Tensor] = None,
              alpha: float = 0.0) -> torch.Tensor:
     """KxK (3|5) conv to 3 channels; tanh_axpy: tanh(conv) + alpha * addend."""

@@ -115,14 +115,18 @@ class _UpBlock(nn.Sequential):
     def forward(self, x, out=None):
         conv, bn = self[1], self[2]
         if not self.training and conv.out_channels % 64 == 0:
-            # inference: sub-pixel form (four 2x2 convs on the pre-upsample tensor, 4/9 of the MACs)
+            # inference: Winograd on the up-sampled grid with the up-sampling folded into the input transform (9 of the
+            # 16 positions survive: 2.25 multiplies per output); shapes it does not take use the sub-pixel form (four
+            # 2x2 convs on the pre-upsample tensor, 4 multiplies per output)
+            wino = WINOGRAD and ops.upwino_supported(x, conv.out_channels, out=out)
             src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-            key = _ver(*src)
+            key = (_ver(*src), wino)
             if key != self._up_key:
-                self._up_pack = ops.pack_upconv_weight(conv.weight)
+                self._up_pack = (ops.pack_upwino_weight if wino else ops.pack_upconv_weight)(conv.weight)
                 self._up_aff = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
                 self._up_key = key
-            return ops.upconv3x3_glu(x, self._up_pack, conv.out_channels, self._up_aff[0], self._up_aff[1], out=out)
+            fn = ops.upwino_glu if wino else ops.upconv3x3_glu
+            return fn(x, self._up_pack, conv.out_channels, self._up_aff[0], self._up_aff[1], out=out)
         return _conv_bn(x, self._fp, conv, bn, glu=True, upsample=True, out=out, training=self.training)
 
 
