@@ -34,6 +34,7 @@ TRAFFIC_PER_LAUNCH_BYTES = {
     "wino_conv3x3_kernel": 59.42e6,   # profiles/r01_i_pmc_hbm_traffic.csv, 20-launch mix (algorithmic: 49.65e6; the
                                       # input is read once per 64-cout group)
     "upconv_glu_mfma_kernel": 84.01e6,   # same file (algorithmic: 80.9e6)
+    "upwino_glu_kernel": 81.79e6,     # profiles/r01_l_pmc_hbm_traffic.csv, the 6 upBlocks (algorithmic: 80.9e6)
 }
 # share of the direct-form multiplies a kernel actually issues (Winograd F(2x2,3x3): 16/36; sub-pixel upBlock: 4/9)
 EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "upconv_glu_mfma_kernel": 4.0 / 9.0,
