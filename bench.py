@@ -160,7 +160,7 @@ def main():
                     help="infer = the headline (BASELINE configs[1]); train = generator fwd+bwd+Adam step on MSE+KL "
                          "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (inference mode)")
-    ap.add_argument("--profile-every", type=int, default=8,
+    ap.add_argument("--profile-every", type=int, default=10,
                     help="bracket every launch of every Nth timed step with HIP events for the roofline (0 = never); "
                          "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
                          "it on every step")
