@@ -94,16 +94,16 @@ class SRPipeline:
     def __call__(self, captions, cap_lens, LR, LRb):
         """trainer_objective.py:134-146.  Returns the same tensors the reference loop produces."""
         hidden = self.text_encoder.init_hidden(captions.shape[0])
-        words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
-        mask = caption_mask(captions, words_embs.size(2))
         if self.overlap and LR.is_cuda:
             main = torch.cuda.current_stream(LR.device)
             if self._side is None:
                 self._side = torch.cuda.Stream(device=LR.device)
             side = self._side
             side.wait_stream(main)                       # LR / LRb are ready on the main stream
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side):                # the trunk needs neither the text encoder nor G_SR_NET_low
                 feats = self.netGH.trunk(LR, LRb)
+            words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
+            mask = caption_mask(captions, words_embs.size(2))
             fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
             main.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
@@ -111,6 +111,8 @@ class SRPipeline:
                     f.record_stream(main)                # allocated on the side stream, consumed on the main one
             fine_im = self.netGH.heads(feats, fake_imgL)
         else:
+            words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
+            mask = caption_mask(captions, words_embs.size(2))
             fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
             fine_im, a, one = self.netGH(LR, fake_imgL, LRb)
         return {"words_emb": words_embs, "sent_emb": sent_emb, "mask": mask, "fake": fake_imgL,
