@@ -3,6 +3,8 @@
 fp32 tolerance stated by the north-star / SURVEY 8c: atol = rtol = 1e-4 on un-clamped outputs (the reference's
 own fp32-vs-fp64 deviation is 1.7e-5, thread-count nondeterminism 2.5e-6).  Op-level checks use a tighter bound.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,8 @@ from oracle import tgsr_oracle as O
 pytestmark = pytest.mark.gpu
 
 ATOL = RTOL = 1e-4
+# the 256^2 images under TGSR_WINOGRAD=0 (direct kernels); the default Winograd kernels meet ATOL there too
+ATOL256 = 2e-4 if os.environ.get("TGSR_WINOGRAD", "1") == "0" else ATOL
 DEV = "cuda"
 
 
@@ -468,10 +472,11 @@ def test_full_size_face_checkpoint_c1(face_c1, face_weights, cfg_face):
     r = p(T(g["captions"]), g["cap_lens"].tolist(), T(g["LR"]), T(g["LRb"]))
     close(r["words_emb"], g["words_emb"], atol=1e-5)
     for i in range(3):
-        # 256^2 images: both fp32 paths carry rounding noise vs exact arithmetic (CPU 3.7e-5, HIP 8.3e-5 max,
-        # tools/diag_precision.py) -> atol 2e-4 there, 1e-4 everywhere else
-        close(r["fake"][i], g["fake%d" % i], atol=2e-4 if i == 2 else ATOL)
-        close(r["fine"][i], g["fine%d" % i], atol=2e-4 if i == 2 else ATOL)
+        # stated tolerance 1e-4 everywhere with the default (Winograd) kernels: 3.1e-5 max from an fp64 run, the
+        # reference's own CPU fp32 path 3.7e-5 (tools/diag_precision.py).  TGSR_WINOGRAD=0 (direct kernels, a pure
+        # 576-step fp32 FMA chain per output: 5.6e-5 .. 8.3e-5) keeps 2e-4 on the 256^2 images
+        close(r["fake"][i], g["fake%d" % i], atol=ATOL256 if i == 2 else ATOL)
+        close(r["fine"][i], g["fine%d" % i], atol=ATOL256 if i == 2 else ATOL)
     close(r["att"][0], g["att0"], atol=2e-5)
     close(r["att"][1], g["att1"], atol=2e-5)
     a2 = r["att"][2].cpu().numpy()
@@ -490,8 +495,8 @@ def test_full_size_batch16_vs_oracle(face_weights, cfg_face):
     p = _pipeline(face_weights)
     r = p(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
     for i in range(3):
-        close(r["fake"][i], ref["fake"][i], atol=2e-4 if i == 2 else ATOL)
-        close(r["fine"][i], ref["fine"][i], atol=2e-4 if i == 2 else ATOL)
+        close(r["fake"][i], ref["fake"][i], atol=ATOL256 if i == 2 else ATOL)
+        close(r["fine"][i], ref["fine"][i], atol=ATOL256 if i == 2 else ATOL)
         close(r["att"][i], ref["att"][i], atol=2e-5)
     # size-independent properties: per-sample independence (eval BN, per-sample mask mode) and determinism
     p.netGL.h_net1.att.correct_mask = p.netGL.h_net2.att.correct_mask = p.netGL.h_net3.att.correct_mask = True
