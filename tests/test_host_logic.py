@@ -97,3 +97,31 @@ def test_models16_tied_stages_and_keys(cfg32):
     gh = models16.NetG_highweight(weightmap=False, low="lr")
     assert sorted(gh.state_dict().keys()) == sorted(g["gh16_keys"].tolist())
     assert "a" in gh.state_dict()       # models16.py:126: a registered Parameter here (unlike model.py:246-248)
+
+
+def test_committed_bench_lines_follow_the_contract():
+    """The JSON lines bench.py printed on the MI355X (committed under profiles/) carry every field of the driver's
+    contract, the roofline object and - on the default N=1 run - the CPU baseline."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_[k-z]_bench*.json")))
+    assert files, "no recent bench line committed"
+    saw_cpu = False
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d, (f, k)
+        assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+        assert d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+        assert abs(d["value"] - 16 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+            assert k in r, (f, k)
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        if "cpu_baseline" in d:
+            saw_cpu = True
+            c = d["cpu_baseline"]
+            assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert saw_cpu
