@@ -551,3 +551,18 @@ def test_to_uint8_bytes_match_numpy(shape):
     out = ops.to_uint8(x.to(DEV)).cpu().numpy()
     assert out.dtype == np.uint8 and out.shape == ref.shape
     assert np.array_equal(out, ref)
+
+
+def test_config4_lr64_input_x4_readout(face_weights, cfg_face):
+    """BASELINE config 4 as SURVEY 8 reads it (there is no x4 generator in the reference): the same fully convolutional
+    networks on a 64x64 LR input, the 64->256 result is read at index 1 (h_net3 still runs, to 512^2)."""
+    cap, lens, LR, LRb = O.synthetic_batch(2, lr=64)
+    ref = O.sr_forward(split_sd(face_weights, "E."), split_sd(face_weights, "GL."), split_sd(face_weights, "GH."),
+                       cap, lens.tolist(), LR, LRb)
+    p = _pipeline(face_weights)
+    r = p(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    assert tuple(r["fine"][1].shape) == (2, 3, 256, 256) and tuple(r["fine"][2].shape) == (2, 3, 512, 512)
+    for i in range(3):
+        close(r["fake"][i], ref["fake"][i], atol=ATOL256 if i == 2 else ATOL)
+        close(r["fine"][i], ref["fine"][i], atol=ATOL256 if i == 2 else ATOL)
+        close(r["att"][i], ref["att"][i], atol=2e-5)
