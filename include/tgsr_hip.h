@@ -93,13 +93,18 @@ int tgsr_upconv3x3_glu_fwd(const float* x, int64_t x_bstride, int B, int Cin, in
  * The same upBlock by Winograd F(2x2, 3x3) on the up-sampled image with the up-sampling folded into the input
  * transform: the doubled rows / columns zero 7 of the 16 Winograd positions, leaving 9 products per 2x2 outputs =
  * 2.25 multiplies per output (sub-pixel form above: 4, direct: 9).  fp32; the transforms only add / subtract.
- * upack from tgsr_pack_upwino_weight (tgsr_packed_upwino_weight_elems floats).  Cout % 64 == 0, Cin % 4 == 0,
+ * upack from tgsr_pack_upwino_weight (tgsr_packed_upwino_weight_elems floats; glu = 1 groups value channels with
+ * their gates and must match the entry point used).  Cout % 64 == 0, Cin % 4 == 0,
  * W % 4 == 0, x 16-byte aligned (batch stride % 4 == 0), out 8-byte aligned with an even batch stride.
  */
 int64_t tgsr_packed_upwino_weight_elems(int Cout, int Cin);
-int tgsr_pack_upwino_weight(const float* w, float* upack, int Cout, int Cin, void* stream);
+int tgsr_pack_upwino_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream);
 int tgsr_upwino_glu_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
                         const float* scale, const float* shift, float* out, int64_t out_bstride, void* stream);
+/* The same without GLU: out [B][Cout][2H][2W] = affine(conv3x3(upsample(x))) (scale/shift may be NULL: the raw
+ * convolution BatchNorm's batch statistics are taken of in training).  Pack with glu = 0. */
+int tgsr_upwino_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
+                    const float* scale, const float* shift, float* out, int64_t out_bstride, void* stream);
 
 /*
  * The same fused 3x3 convolution as tgsr_conv3x3_fwd (upsample = 0) by Winograd F(2x2, 3x3): 16 multiplies per 4

@@ -138,6 +138,13 @@ def test_upblock_winograd_vs_upsample_conv(B, Cin, H, W, Cout):
                          out=wide[:, 2:2 + Cout // 2])
     close(out, ref, atol=2e-5, rtol=2e-5)
     assert (wide[:, :2] == 3).all() and (wide[:, 2 + Cout // 2:] == 3).all()
+    # without the gate (the raw convolution of the training forward): affine and affine-free
+    raw_ref = F.conv2d(xi, w, None, 1, 1)
+    raw = ops.upwino_glu(x.to(DEV), ops.pack_upwino_weight(w.to(DEV), glu=False), Cout, None, None, glu=False)
+    close(raw, raw_ref, atol=2e-5, rtol=2e-5)
+    aff = ops.upwino_glu(x.to(DEV), ops.pack_upwino_weight(w.to(DEV), glu=False), Cout, scale.to(DEV), shift.to(DEV),
+                         glu=False)
+    close(aff, raw_ref * scale[None, :, None, None] + shift[None, :, None, None], atol=2e-5, rtol=2e-5)
 
 
 WINO_CASES = [

@@ -28,6 +28,8 @@ def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False) -> 
     Cout = weight.shape[0]
     if util.WINOGRAD and not upsample and ops.wino_supported(x, Cout):
         return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False), Cout, None, None)
+    if util.WINOGRAD and upsample and ops.upwino_supported(x, Cout):
+        return ops.upwino_glu(x, ops.pack_upwino_weight(weight, glu=False), Cout, None, None, glu=False)
     return ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), Cout, None, None, glu=False, upsample=upsample)
 
 

@@ -52,7 +52,8 @@ constexpr int kUSmem = 3 * kUU + 3 * kURaw + 2 * 2 * kUV + 2 * 64;
 
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256, 2) void upwino_glu_kernel(UpwArgs a) {
+template <bool GLU>   // GLU: value/gate blocks + sigmoid gate, out [B][Cout/2]; else plain affine, out [B][Cout]
+__global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[kUSmem];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void upwino_glu_kernel(UpwArgs a) {
 
   if (tid < 128) {   // logical column lc = half*32 + block*16 + l -> global cout; [0,64) scale, [64,128) shift
     const int lc = tid & 63, hh = lc >> 5, cb = (lc >> 4) & 1, l = lc & 15;
-    const int col = (cb ? (a.Cout >> 1) : 0) + grp * 32 + hh * 16 + l;
+    const int col = GLU ? (cb ? (a.Cout >> 1) : 0) + grp * 32 + hh * 16 + l : grp * 64 + lc;
     aff_s[tid] = a.scale ? (tid < 64 ? a.scale[col] : a.shift[col]) : (tid < 64 ? 1.f : 0.f);
   }
 
@@ -274,20 +275,36 @@ __global__ __launch_bounds__(256, 2) void upwino_glu_kernel(UpwArgs a) {
     }
   };
   if (y0 + w < a.H && x0 + l15 < a.W) {
+    if (GLU) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lc = h * 32 + 4 * lg + r;                 // value column; its gate is lc + 16
-      float yv[2][2], yg[2][2];
-      ytile(0, r, yv);
-      ytile(1, r, yg);
-      const float sv = aff_s[lc], tv = aff_s[64 + lc], sg = aff_s[lc + 16], tg = aff_s[64 + lc + 16];
-      const int c = grp * 32 + h * 16 + 4 * lg + r;
+      for (int r = 0; r < 4; ++r) {
+        const int lc = h * 32 + 4 * lg + r;               // value column; its gate is lc + 16
+        float yv[2][2], yg[2][2];
+        ytile(0, r, yv);
+        ytile(1, r, yg);
+        const float sv = aff_s[lc], tv = aff_s[64 + lc], sg = aff_s[lc + 16], tg = aff_s[64 + lc + 16];
+        const int c = grp * 32 + h * 16 + 4 * lg + r;
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const float o0 = (yv[dy][0] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][0] * sg + tg)));
-        const float o1 = (yv[dy][1] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][1] * sg + tg)));
-        *reinterpret_cast<float2*>(ob + (int64_t)c * HWo + (int64_t)(oy + dy) * Wo + ox) = make_float2(o0, o1);
+        for (int dy = 0; dy < 2; ++dy) {
+          const float o0 = (yv[dy][0] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][0] * sg + tg)));
+          const float o1 = (yv[dy][1] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][1] * sg + tg)));
+          *reinterpret_cast<float2*>(ob + (int64_t)c * HWo + (int64_t)(oy + dy) * Wo + ox) = make_float2(o0, o1);
+        }
       }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lc = h * 32 + cb * 16 + 4 * lg + r;
+          float yv[2][2];
+          ytile(cb, r, yv);
+          const float sv = aff_s[lc], tv = aff_s[64 + lc];
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+            *reinterpret_cast<float2*>(ob + (int64_t)(grp * 64 + lc) * HWo + (int64_t)(oy + dy) * Wo + ox) =
+                make_float2(yv[dy][0] * sv + tv, yv[dy][1] * sv + tv);
+        }
     }
   }
 }
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void upwino_glu_kernel(UpwArgs a) {
 // B [3 i][4 ci][2 halves][16 l][2] = (U[i][2] cb0, U[i][2] cb1);  U = G' g G'^T with G' = [[1,0,0],[1,1,1],[0,0,1]];
 // cb 0 = value channel grp*32 + half*16 + l, cb 1 = its gate Cout/2 + grp*32 + half*16 + l.
 __global__ void pack_upwino_weight_kernel(const float* __restrict__ wt, float* __restrict__ up, int Cout, int Cin,
-                                          int64_t total) {
+                                          int glu, int64_t total) {
   const int ngrp = Cout / 64;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(idx % kUU);
@@ -313,7 +330,7 @@ __global__ void pack_upwino_weight_kernel(const float* __restrict__ wt, float* _
       cb = f & 1; l = (f >> 1) & 15; hh = (f >> 5) & 1; ci = (f >> 6) & 3; i = f >> 8;
       j = 2;
     }
-    const int co = (cb ? (Cout >> 1) : 0) + grp * 32 + hh * 16 + l;
+    const int co = glu ? (cb ? (Cout >> 1) : 0) + grp * 32 + hh * 16 + l : grp * 64 + hh * 32 + cb * 16 + l;
     const int c = st * kUCK + ci;
     float u = 0.f;
     if (c < Cin) {
@@ -337,19 +354,19 @@ extern "C" int64_t tgsr_packed_upwino_weight_elems(int Cout, int Cin) {
   return (int64_t)((Cin + kUCK - 1) / kUCK) * (Cout / 64) * kUU;
 }
 
-extern "C" int tgsr_pack_upwino_weight(const float* w, float* upack, int Cout, int Cin, void* stream) {
+extern "C" int tgsr_pack_upwino_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
   if (!w || !upack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
   if (Cout % 64 != 0) return TGSR_EUNSUPPORTED;
   const int64_t total = tgsr_packed_upwino_weight_elems(Cout, Cin);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_upwino_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin,
-                     total);
+                     glu ? 1 : 0, total);
   return note_launch(hipGetLastError(), "pack_upwino_weight_kernel");
 }
 
-extern "C" int tgsr_upwino_glu_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
-                                   int Cout, const float* scale, const float* shift, float* out, int64_t out_bstride,
-                                   void* stream) {
+static int upwino_launch(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
+                         const float* scale, const float* shift, float* out, int64_t out_bstride, bool glu,
+                         void* stream) {
   if (!x || !upack || !out || B < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return TGSR_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
   if (Cout % 64 != 0 || Cin % kUCK != 0) return TGSR_EUNSUPPORTED;
@@ -362,6 +379,19 @@ extern "C" int tgsr_upwino_glu_fwd(const float* x, int64_t x_bstride, int B, int
   a.scale = scale; a.shift = shift; a.out = out; a.obs = out_bstride;
   a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 1) / 2; a.nstages = (Cin + kUCK - 1) / kUCK;
   dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y), (unsigned)(Cout / 64));
-  hipLaunchKernelGGL(upwino_glu_kernel, grid, dim3(256), 0, as_stream(stream), a);
-  return note_launch(hipGetLastError(), "upwino_glu_kernel");
+  if (glu) hipLaunchKernelGGL(upwino_kernel<true>, grid, dim3(256), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(upwino_kernel<false>, grid, dim3(256), 0, as_stream(stream), a);
+  return note_launch(hipGetLastError(), "upwino_kernel");
+}
+
+extern "C" int tgsr_upwino_glu_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                                   int Cout, const float* scale, const float* shift, float* out, int64_t out_bstride,
+                                   void* stream) {
+  return upwino_launch(x, x_bstride, B, Cin, H, W, upack, Cout, scale, shift, out, out_bstride, true, stream);
+}
+
+extern "C" int tgsr_upwino_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                               int Cout, const float* scale, const float* shift, float* out, int64_t out_bstride,
+                               void* stream) {
+  return upwino_launch(x, x_bstride, B, Cin, H, W, upack, Cout, scale, shift, out, out_bstride, false, stream);
 }

@@ -195,14 +195,15 @@ def upconv3x3_glu(x: torch.Tensor, wpack_up: torch.Tensor, cout: int, scale, shi
     return out
 
 
-def pack_upwino_weight(w: torch.Tensor) -> torch.Tensor:
-    """[Cout,Cin,3,3] -> the 9 tap-sum positions of the up-sample-aware Winograd form (tgsr_upwino_glu_fwd)."""
+def pack_upwino_weight(w: torch.Tensor, glu: bool = True) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> the 9 tap-sum positions of the up-sample-aware Winograd form (tgsr_upwino_glu_fwd; glu=False:
+    the layout of tgsr_upwino_fwd)."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
     L = _lib.lib()
     out = torch.empty(L.tgsr_packed_upwino_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
-    check(L.tgsr_pack_upwino_weight(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_upwino_weight")
+    check(L.tgsr_pack_upwino_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_upwino_weight")
     return out
 
 
@@ -215,21 +216,22 @@ def upwino_supported(x: torch.Tensor, cout: int, out: Optional[torch.Tensor] = N
 
 
 def upwino_glu(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
-               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """upBlock in one launch by Winograd on the up-sampled grid (9 products per 2x2 outputs); contract of upconv3x3_glu."""
+               out: Optional[torch.Tensor] = None, glu: bool = True) -> torch.Tensor:
+    """upBlock in one launch by Winograd on the up-sampled grid (9 products per 2x2 outputs); contract of upconv3x3_glu.
+    glu=False: Upsample -> conv3x3 -> affine without the gate (out [B,cout,2H,2W]; scale/shift may be None)."""
     _need_hip(x, upack, scale, shift, out)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
-    co, Ho, Wo = cout // 2, 2 * H, 2 * W
+    co, Ho, Wo = (cout // 2 if glu else cout), 2 * H, 2 * W
     if out is None:
         out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=x.device)
     if tuple(out.shape) != (B, co, Ho, Wo) or out.stride(3) != 1 or out.stride(2) != Wo or out.stride(1) != Ho * Wo:
         raise TgsrError("upwino_glu: bad `out` shape/strides %s %s" % (tuple(out.shape), out.stride()))
     obs = out.stride(0) if B > 1 else co * Ho * Wo
     e0 = _ev() if profile is not None else None
-    rc = _lib.lib().tgsr_upwino_glu_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(out), obs,
-                                        _stream())
-    check(rc, "tgsr_upwino_glu_fwd")
+    fn = _lib.lib().tgsr_upwino_glu_fwd if glu else _lib.lib().tgsr_upwino_fwd
+    rc = fn(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(out), obs, _stream())
+    check(rc, "tgsr_upwino_glu_fwd" if glu else "tgsr_upwino_fwd")
     if profile is not None:
         nbytes = 4 * (B * Cin * H * W + B * co * Ho * Wo + cout * Cin * 9)
         profile.append(("upwino_glu_kernel", 2.0 * B * Ho * Wo * cout * Cin * 9, nbytes, e0, _ev()))
