@@ -95,6 +95,54 @@ def cpu_baseline(weights, batch, budget_s=20.0):
                       "runs, %.2f s/batch" % (batch, len(ts), med)}
 
 
+def bench_damsm(args, rank, world, dist, dev):
+    """pretrain_DAMSM.py step (RNN_ENCODER + CNN_ENCODER heads on words_loss + sent_loss, Adam, grad clip) on synthetic
+    Inception-trunk outputs: every gradient from HIP kernels (DAMSM backward, LSTM BPTT, head GEMMs)."""
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.train import DAMSMTrainer
+    cfg_ = __import__("tgsr_amd.miscc.config", fromlist=["cfg"]).cfg
+    cfg_.TRAIN.FLAG = True
+    tr = DAMSMTrainer(41, device=dev)
+    B = args.batch
+    cap, lens, _LR, _LRb = synthetic_batch(B, seed=100 + rank)
+    g = torch.Generator().manual_seed(3 + rank)
+    feats, pooled = torch.randn(B, 768, 17, 17, generator=g).to(dev), torch.randn(B, 2048, generator=g).to(dev)
+    cap, lens = cap.to(dev), lens.tolist()
+    for _ in range(args.warmup):
+        tr.step_features(feats, pooled, cap, lens)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.step_features(feats, pooled, cap, lens)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "DAMSM pre-training caption-image pairs/sec (batch 16 per GPU, fwd+bwd+Adam)",
+            "value": round(world * B * args.steps / dt, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic captions and Inception-trunk outputs (the trunk is third-party, frozen)",
+            "config": {"workload": "pretrain_DAMSM.py step: RNN_ENCODER.train() + CNN_ENCODER heads, words_loss + "
+                                   "sent_loss, Adam, grad-clip 0.25, batch=16 per GPU", "batch_per_gpu": B,
+                       "parallelism": "dp%d" % world},
+            "final_loss": round(float(loss), 5), "roofline": None}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def bench_train(args, rank, world, dist, dev, weights):
     """Generator training step: text-enc (frozen) + G_SR_NET_low + NetG_highweight forward in train-mode BN, MSE + KL
     loss, HIP backward, one flat-bucket gradient all-reduce (N > 1), Adam, EMA.  Synthetic HR targets U(-1, 1)."""
@@ -156,7 +204,7 @@ def main():
                          "a second HIP stream).  Per-launch kernel timing is only meaningful single-stream, so the "
                          "event-sampled steps always run serial; use this flag to collect a rocprofv3 summary whose "
                          "per-kernel durations are comparable with `roofline`")
-    ap.add_argument("--mode", choices=("infer", "train"), default="infer",
+    ap.add_argument("--mode", choices=("infer", "train", "damsm"), default="infer",
                     help="infer = the headline (BASELINE configs[1]); train = generator fwd+bwd+Adam step on MSE+KL "
                          "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (inference mode)")
@@ -201,6 +249,8 @@ def main():
     weights = load_weights()
     if args.mode == "train":
         return bench_train(args, rank, world, dist, dev, weights)
+    if args.mode == "damsm":
+        return bench_damsm(args, rank, world, dist, dev)
     pipe = SRPipeline(41, device=dev, low="lr", overlap=not args.serial)
     if weights is not None:
         pipe.load_state_dicts(weights["E."], weights["GL."], weights["GH."])
