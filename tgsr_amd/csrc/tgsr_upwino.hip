@@ -14,9 +14,11 @@
 //
 // Kernel structure = tgsr_winograd.hip (see there for the measurements behind it): MFMA 16x16x4, a wave owns 16 tiles
 // (16 consecutive low-res pixels of a row = 2 x 32 outputs) x 32 couts (16 value + their 16 gate channels) with all 9
-// positions live (72 accumulators), workgroup = 4 waves = 2 low-res rows x 2 cout halves, several workgroups per CU;
-// stage = 4 input channels; U (9 KB) and the raw rows [4 ci][4 rows][24 cols] come by LDS-DMA issued from inline asm
-// two stages ahead (three buffers) with a counted vmcnt wait; V [3 rows i][4 ci][16 tiles][4] is computed one stage
+// positions live (72 accumulators), workgroup = 4 waves = 2 low-res rows x 2 cout halves; 37 KB LDS and 126 VGPRs
+// put FOUR workgroups on a CU (4 waves per SIMD), which hides a copy's latency well enough that U (9 KB per stage,
+// double buffered) is fetched one stage ahead and a stage simply ends on vmcnt(0) (3-5 % faster than three U buffers at
+// 3 workgroups per CU); the raw rows [4 ci][4 rows][24 cols] (three buffers) still come two stages ahead.  Copies are
+// LDS-DMA issued from inline asm (see tgsr_winograd.hip); V [3 rows i][4 ci][16 tiles][4] is computed one stage
 // ahead by the two cout-half waves of a row (h = 0: rows i = 0, 1; h = 1: row i = 2) and shared through LDS.
 #include "tgsr_common.h"
 
@@ -48,12 +50,13 @@ constexpr int kUU = kUA + kUB;                            // 2304 floats of U pe
 constexpr int kURawN = kUCK * kUPLANE;                    // 384 floats of raw input per stage
 constexpr int kURaw = 512;                                // = 2 DMA pieces (waves 0 and 1)
 constexpr int kUV = 3 * kUCK * 16 * 4;                    // V image of one tile row: 768 floats
-constexpr int kUSmem = 3 * kUU + 3 * kURaw + 2 * 2 * kUV + 2 * 64;
+constexpr int kUNB = 2;                                    // U buffers: the next stage's U is fetched during this one
+constexpr int kUSmem = kUNB * kUU + 3 * kURaw + 2 * 2 * kUV + 2 * 64;
 
 typedef float f32x4u __attribute__((ext_vector_type(4)));
 
 template <bool GLU>   // GLU: value/gate blocks + sigmoid gate, out [B][Cout/2]; else plain affine, out [B][Cout]
-__global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
+__global__ __launch_bounds__(256, 4) void upwino_kernel(UpwArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[kUSmem];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,9 +71,9 @@ __global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
   const float* xb = a.x + (int64_t)b * a.xbs;
   const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
   float* us = smem;                                       // 3 x U stage
-  float* raws = smem + 3 * kUU;                           // 3 x raw stage
-  float* vs = smem + 3 * kUU + 3 * kURaw + w * 2 * kUV;   // this row's 2 V images
-  float* aff_s = smem + 3 * kUU + 3 * kURaw + 2 * 2 * kUV;
+  float* raws = smem + kUNB * kUU;                        // 3 x raw stage
+  float* vs = smem + kUNB * kUU + 3 * kURaw + w * 2 * kUV;   // this row's 2 V images
+  float* aff_s = smem + kUNB * kUU + 3 * kURaw + 2 * 2 * kUV;
 
   auto dma16 = [&](const float* g, float* lds_wave_base) {
     const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptru_t)lds_wave_base);
@@ -102,7 +105,6 @@ __global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
   const float* ubase = a.upack + (int64_t)grp * kUU;
   const int64_t ustride = (int64_t)gridDim.y * kUU;
   const unsigned uoff = (unsigned)(lane * 16);
-  const int nupieces = wave == 0 ? 3 : 2;
   auto issue_u = [&](int buf) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -115,7 +117,6 @@ __global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
     }
     ubase += ustride;
   };
-  const int nraw = wave < 2 ? 1 : 0;
 
   // ---- input transform: lane = (tile l15, channel lg).  d = 3x3 low-res neighbourhood (rows y-1, y, y+1 of this wave's
   // row y = y0 + w; cols x-1, x, x+1).  Row pass t0 = a - b, t1 = b, t2 = b - c; column pass the same on each row.
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
   // ---- prologue: raw(0..2), U(0..1); transform raw(0) -> V[0]
   issue_raw(0);
   issue_u(0);
-  if (a.nstages > 1) { issue_raw(1); issue_u(1); }
+  if (a.nstages > 1) { issue_raw(1); }
   if (a.nstages > 2) issue_raw(2);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   {
@@ -193,11 +194,11 @@ __global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
   const int vlane = (lg * 16 + l15) * 4;                  // V: [i][ci = lg][l15][4]
 
   int b3 = 0;                                             // st % 3
-  auto stage = [&](auto hc, auto more_c, auto more2_c, auto more3_c, int st) {
-    constexpr bool MORE = decltype(more_c)::value, MORE2 = decltype(more2_c)::value, MORE3 = decltype(more3_c)::value;
+  auto stage = [&](auto hc, auto more_c, auto more3_c, int st) {
+    constexpr bool MORE = decltype(more_c)::value, MORE3 = decltype(more3_c)::value;
     const int par = st & 1;
-    const int b3n = b3 == 2 ? 0 : b3 + 1, b3p = b3 == 0 ? 2 : b3 - 1;
-    const float* ub = us + b3 * kUU;
+    const int b3n = b3 == 2 ? 0 : b3 + 1;
+    const float* ub = us + par * kUU;
     const float* vb = vs + par * kUV + vlane;
     f32x4u af[3], bf[3];
     float2 ag[3];
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
       M[i * 3 + 2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[i].y, bf[i][2], M[i * 3 + 2][1], 0, 0, 0);
       if (i == 0) {                                       // the copies go where no LDS reads are queued
         __builtin_amdgcn_sched_barrier(0);
-        if (MORE2) issue_u(b3p);
+        if (MORE) issue_u(par ^ 1);
         if (MORE3) issue_raw(b3);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -231,25 +232,17 @@ __global__ __launch_bounds__(256, 2) void upwino_kernel(UpwArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // U(st+1), raw(st+2) (issued a stage ago) landed, V(st+1) written -> barrier; this stage's own copies stay in flight
-    if (MORE) {
-      const int inflight = (MORE2 ? nupieces : 0) + (MORE3 ? nraw : 0);       // wave-uniform
-      if (inflight == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (inflight == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (inflight == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
+    // U(st+1) (this stage's copy), raw(st+2) landed, V(st+1) written -> barrier
+    if (MORE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     b3 = b3n;
   };
   auto run = [&](auto hc) {
     using T = std::true_type;
     using F = std::false_type;
     int st = 0;
-    for (; st + 3 < a.nstages; ++st) stage(hc, T{}, T{}, T{}, st);
-    if (st + 2 < a.nstages) stage(hc, T{}, T{}, F{}, st++);
-    if (st + 1 < a.nstages) stage(hc, T{}, F{}, F{}, st++);
-    stage(hc, F{}, F{}, F{}, st);
+    for (; st + 3 < a.nstages; ++st) stage(hc, T{}, T{}, st);
+    for (; st + 1 < a.nstages; ++st) stage(hc, T{}, F{}, st);
+    stage(hc, F{}, F{}, st);
   };
   if (h) run(std::integral_constant<int, 1>{});
   else run(std::integral_constant<int, 0>{});
