@@ -342,8 +342,8 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic inputs (seed 100); " + wdesc,
-               "config": {"workload": "CelebA face x8 (32->256) batch=16 per GPU, text-enc + G_SR_NET_low + "
-                                      "NetG_highweight forward, eval BN (BASELINE configs[1])",
+               "config": {"workload": "CelebA face x8 (32->256) batch=%d per GPU, text-enc + G_SR_NET_low + "
+                                      "NetG_highweight forward, eval BN (BASELINE configs[1])" % B,
                           "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world,
                           "streams": 1 if args.serial else 2, "launch": "hipgraph" if args.graph else "eager"},
                "roofline": roof, "kernels": kern}

@@ -115,7 +115,8 @@ def test_committed_bench_lines_follow_the_contract():
             assert k in d, (f, k)
         assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
         assert d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
-        assert abs(d["value"] - 16 * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+        per_gpu = d["config"].get("batch_per_gpu", 16)
+        assert abs(d["value"] - per_gpu * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
         r = d["roofline"]
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
             assert k in r, (f, k)
