@@ -111,7 +111,7 @@ int tgsr_upwino_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, in
  * outputs instead of 36.  fp32 throughout; the transforms only use {0, +-1, +-1/2} (end-to-end error on the shipped
  * checkpoint indistinguishable from the direct fp32 form).  upack from tgsr_pack_wino_weight
  * (tgsr_packed_wino_weight_elems floats; `glu` != 0 groups each value channel block with its gate block and must
- * match the epilogue the pack is used with).  Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0, x 16-byte aligned, out / residual 8-byte
+ * match the epilogue the pack is used with).  Cout % 32 == 0 (64-channel groups when Cout % 64 == 0, else 32), Cin % 4 == 0, W % 4 == 0, x 16-byte aligned, out / residual 8-byte
  * aligned with even batch strides; same epilogue selectors and residual rule as tgsr_conv3x3_fwd.
  */
 int64_t tgsr_packed_wino_weight_elems(int Cout, int Cin);

@@ -159,6 +159,10 @@ WINO_CASES = [
     (16, 64, 64, 64, 128, True, False),
     (4, 128, 16, 16, 256, True, False),    # two channel groups
     (2, 64, 128, 128, 64, False, True),
+    (16, 32, 32, 32, 32, False, True),     # 32-channel groups (GH ResBlock second conv)
+    (2, 32, 13, 20, 32, False, False),     # ... ragged
+    (1, 8, 64, 64, 96, False, True),       # three 32-channel groups
+    (2, 16, 24, 40, 32, True, False),      # GLU inside a 32-channel group (16 value + 16 gate)
 ]
 
 

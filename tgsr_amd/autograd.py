@@ -26,7 +26,7 @@ def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False) -> 
     The weights change every step, so they are packed per call (a few microseconds)."""
     from . import util
     Cout = weight.shape[0]
-    if util.WINOGRAD and not upsample and ops.wino_supported(x, Cout):
+    if util.WINOGRAD and not upsample and util._wino_pays(x, Cout, None, None):
         return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False), Cout, None, None)
     if util.WINOGRAD and upsample and ops.upwino_supported(x, Cout):
         return ops.upwino_glu(x, ops.pack_upwino_weight(weight, glu=False), Cout, None, None, glu=False)

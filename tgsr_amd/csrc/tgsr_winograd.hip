@@ -65,53 +65,67 @@ struct WinoArgs {
 //       by the two cout-half waves of the row; each of them computes two of the four rows of V for one
 //       (tile, channel) per lane, one stage ahead.
 // One barrier per stage publishes U(st+1), raw(st+2) and V(st+1).  LDS 77 KB per workgroup.
+// A second shape of the same kernel (NH = 1) serves layers with 32 output channels per group (Cout % 64 != 0): the 4
+// waves are 4 tile rows x ONE cout half (8 x 32 outputs x 32 couts), each wave computes its own V (all four rows).
 constexpr int kWCK = 4;                                  // input channels per stage
-constexpr int kWTC = 40, kWTR = 6, kWPLANE = kWTR * kWTC;    // raw tile: 6 rows x (32 + 8) columns per channel
-constexpr int kWU = 8 * kWCK * 2 * 64;                   // floats of U per stage: 4096
-constexpr int kWUK = kWU / 256 / 4;                      // U DMA pieces (1 KB) per wave per stage: 4
-constexpr int kWRawN = kWCK * kWPLANE;                   // 960 floats of raw input per stage
-constexpr int kWRaw = 1024;                              // = 4 DMA pieces, one per wave (the last one partly used)
+constexpr int kWTC = 40;                                 // raw tile columns: 32 + 8
 constexpr int kWV = 8 * kWCK * 32;                       // V image of one tile row: 1024 floats
-constexpr int kWSmem = 3 * kWU + 3 * kWRaw + 2 * 2 * kWV + 2 * 64;
+template <int NH>
+struct WinoGeo {
+  static constexpr int ROWS = NH == 2 ? 2 : 4;           // tile rows per workgroup
+  static constexpr int TR = 2 * ROWS + 2;                // raw rows: 6 | 10
+  static constexpr int PLANE = TR * kWTC;
+  static constexpr int U = 8 * kWCK * NH * 64;           // floats of U per stage: 4096 | 2048
+  static constexpr int UK = U / 256 / 4;                 // U DMA pieces (1 KB) per wave per stage: 4 | 2
+  static constexpr int RAWN = kWCK * PLANE;              // 960 | 1600 floats of raw input per stage
+  static constexpr int RP = (RAWN + 255) / 256;          // raw DMA pieces per stage: 4 | 7
+  static constexpr int RAW = RP * 256;                   // floats per raw buffer (the last piece partly used)
+  static constexpr int RK = (RP + 3) / 4;                // raw DMA slots per wave: 1 | 2
+  static constexpr int SMEM = 3 * U + 3 * RAW + ROWS * 2 * kWV + 2 * 64;
+};
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool GLU>
+template <bool GLU, int NH>
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[kWSmem];
+  using Geo = WinoGeo<NH>;
+  constexpr int kWPLANE = Geo::PLANE, kWU = Geo::U, kWUK = Geo::UK, kWRawN = Geo::RAWN, kWRaw = Geo::RAW;
+  __shared__ __attribute__((aligned(16))) float smem[Geo::SMEM];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int w = wave >> 1, h = wave & 1;                 // tile row / cout half of this wave
+  const int w = NH == 2 ? wave >> 1 : wave, h = NH == 2 ? wave & 1 : 0;     // tile row / cout half of this wave
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
   const int grp = blockIdx.y;
-  const int y0 = ty * 4, x0 = tx * 32;                   // output origin of the workgroup tile
+  const int y0 = ty * (2 * Geo::ROWS), x0 = tx * 32;     // output origin of the workgroup tile
   const float* xb = a.x + (int64_t)b * a.xbs;
   const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
   float* us = smem;                                      // 3 x U stage
   float* raws = smem + 3 * kWU;                          // 3 x raw stage
   float* vs = smem + 3 * kWU + 3 * kWRaw + w * 2 * kWV;  // this tile row's 2 V images
-  float* aff_s = smem + 3 * kWU + 3 * kWRaw + 2 * 2 * kWV;
+  float* aff_s = smem + 3 * kWU + 3 * kWRaw + Geo::ROWS * 2 * kWV;
   TGSR_WSTAMP(0);
 
   // ---- DMA plan.  raw: wave q copies floats [q*256, q*256 + 256) of the stage tile.  Per lane a running source
   // pointer and its per-stage stride; out-of-image (or past-the-tile) lanes read the zero block with stride 0, so
   // issuing a piece is branch-free.  Cin % 4 == 0 (host-checked): a stage never reads past the last channel.
-  const float* rptr;
-  int rstep;
-  {
-    const int e = (wave * 64 + lane) * 4;                // first float of this lane's 16-byte piece
+  const float* rptr[Geo::RK];
+  int rstep[Geo::RK];
+#pragma unroll
+  for (int k = 0; k < Geo::RK; ++k) {                    // piece wave + 4k of the stage tile
+    const int e = ((wave + 4 * k) * 64 + lane) * 4;      // first float of this lane's 16-byte piece
     const int c = e / kWPLANE;
     const int rem = e - c * kWPLANE;
     const int r = rem / kWTC, j = rem - r * kWTC;
     const int gy = y0 - 1 + r, gx = x0 - 4 + j;
     const bool ok = e < kWRawN && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // W % 4 == 0
-    rptr = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino_zero;
-    rstep = ok ? (int)(kWCK * HW) : 0;
+    rptr[k] = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino_zero;
+    rstep[k] = ok ? (int)(kWCK * HW) : 0;
   }
+  const int nraw = (Geo::RP - 1 - wave) / 4 + 1;         // raw pieces this wave copies per stage (wave-uniform)
   // The copies are issued from inline assembly: hipcc cannot tell which LDS reads a global_load_lds may alias and
   // puts s_waitcnt vmcnt(0) in front of the next ds_read, which would serialize every stage on its own prefetch.
   // All vmcnt / lgkmcnt synchronization of the copies is therefore explicit (the stage-end barrier below).
@@ -120,8 +134,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
   };
   auto issue_raw = [&](int buf) {                        // issued for stages 0, 1, 2, ... in order
-    dma16(rptr, raws + buf * kWRaw + wave * 256);
-    rptr += rstep;
+#pragma unroll
+    for (int k = 0; k < Geo::RK; ++k) {
+      if (4 * k + 3 < Geo::RP || wave + 4 * k < Geo::RP) {   // wave-uniform; only the last slot can be missing
+        dma16(rptr[k], raws + buf * kWRaw + (wave + 4 * k) * 256);
+        rptr[k] += rstep[k];
+      }
+    }
   };
   // U: scalar base (advances one stage per call) + four per-lane byte offsets, so a stage's copies cost no VALU work
   const float* ubase = a.upack + (int64_t)grp * kWU;     // stage 0 of this group
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
   // as  first = A - B,  second = C +- D  with the rows A..D picked at compile time (the stage loop is instantiated per
   // h), then the column pass, written as float2 (positions 4i + {0,1} and 4i + {2,3}).
   const int rlane = lg * kWPLANE + (2 * w) * kWTC + 2 * l15 + 3;
-  const int vwl = lg * 32 + l15 * 2 + (4 * h) * (kWCK * 32);           // pos pair (2h + ii) * 2 + {0, 1}
+  const int vwl0 = lg * 32 + l15 * 2;                                  // + (4 * half) * (kWCK * 32): pos pair (2 half + ii) * 2
   auto t_read = [&](auto hc, const float* rawb, float (&d)[4][4]) {    // rows A, B, C, D
     constexpr int H = decltype(hc)::value;
     constexpr int row[4] = {H ? 2 : 0, H ? 1 : 2, 1, H ? 3 : 2};
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
     }
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
-      float* vp = vdst + vwl + (2 * ii) * (kWCK * 32);
+      float* vp = vdst + vwl0 + (4 * H + 2 * ii) * (kWCK * 32);
       *reinterpret_cast<float2*>(vp) = make_float2(tr[ii][0] - tr[ii][2], tr[ii][1] + tr[ii][2]);
       *reinterpret_cast<float2*>(vp + kWCK * 32) = make_float2(tr[ii][2] - tr[ii][1], tr[ii][1] - tr[ii][3]);
     }
@@ -172,7 +191,9 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
 
   if (tid < 128) {   // logical column lc = half*32 + block*16 + l of this workgroup -> global cout; [0,64) scale, [64,128) shift
     const int lc = tid & 63, hh = lc >> 5, cb = (lc >> 4) & 1, l = lc & 15;
-    const int col = GLU ? (cb ? (a.Cout >> 1) : 0) + grp * 32 + hh * 16 + l : grp * 64 + lc;
+    // (NH = 1: only columns [0, 32) of the "half 0" rows are used)
+    int col = GLU ? (cb ? (a.Cout >> 1) : 0) + grp * (16 * NH) + hh * 16 + l : grp * (32 * NH) + lc;
+    if (col >= a.Cout) col = 0;
     aff_s[tid] = a.scale ? (tid < 64 ? a.scale[col] : a.shift[col]) : (tid < 64 ? 1.f : 0.f);
   }
 
@@ -192,13 +213,13 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everything issued so far is visible
   {
     float d[4][4];
-    if (h) { t_read(std::integral_constant<int, 1>{}, raws, d); t_write(std::integral_constant<int, 1>{}, d, vs); }
-    else { t_read(std::integral_constant<int, 0>{}, raws, d); t_write(std::integral_constant<int, 0>{}, d, vs); }
+    if (NH == 1 || !h) { t_read(std::integral_constant<int, 0>{}, raws, d); t_write(std::integral_constant<int, 0>{}, d, vs); }
+    if (NH == 1 || h) { t_read(std::integral_constant<int, 1>{}, raws, d); t_write(std::integral_constant<int, 1>{}, d, vs); }
   }
   __syncthreads();                                       // V(0) visible to the other cout half
   TGSR_WSTAMP(1);
 
-  const int ulane = (lg * 2 + h) * 64 + l15 * 4;         // A: U[pp][ci = lg][h][l15][4]
+  const int ulane = (lg * NH + h) * 64 + l15 * 4;        // A: U[pp][ci = lg][h][l15][4]
   const int vlane = lg * 32 + l15 * 2;                   // B: V[pp][ci = lg][l15][2]
 
   // One stage: MFMAs on U(st), V(st); transform raw(st+1) -> V(st+1) [MORE]; fetch U(st+2) [MORE2] and raw(st+3)
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
             rres[cb][i][dy] = make_float2(0.f, 0.f);
             if (rb && ox < a.W && oy + dy < a.H)
               rres[cb][i][dy] = *reinterpret_cast<const float2*>(
-                  rb + (int64_t)(grp * 64 + h * 32 + cb * 16 + 4 * lg + i) * HWo + (int64_t)(oy + dy) * a.W + ox);
+                  rb + (int64_t)(grp * (32 * NH) + h * 32 + cb * 16 + 4 * lg + i) * HWo + (int64_t)(oy + dy) * a.W + ox);
           }
     }
   };
@@ -237,14 +258,23 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
     const float* vb = vs + par * kWV + vlane;
     f32x4v af[8];
     float2 bf[8];
-    float d[4][4];
+    float d[4][4], d2[4][4];                             // d2: NH = 1, this wave transforms both row halves
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {
-      af[pp] = *reinterpret_cast<const f32x4v*>(ub + pp * kWCK * 128);
+      af[pp] = *reinterpret_cast<const f32x4v*>(ub + pp * kWCK * NH * 64);
       bf[pp] = *reinterpret_cast<const float2*>(vb + pp * kWCK * 32);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (MORE) t_read(hc, raws + b3n * kWRaw, d);
+    if (MORE) {
+      if (NH == 2) {
+        t_read(hc, raws + b3n * kWRaw, d);
+      } else {
+        t_read(H0{}, raws + b3n * kWRaw, d);
+        t_read(H1{}, raws + b3n * kWRaw, d2);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int pp = 0; pp < 8; ++pp) {
@@ -260,14 +290,30 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
       }
       if (pp == 3) {
         __builtin_amdgcn_sched_barrier(0);
-        if (MORE) t_write(hc, d, vs + (par ^ 1) * kWV);
+        if (MORE) {
+          if (NH == 2) {
+            t_write(hc, d, vs + (par ^ 1) * kWV);
+          } else {
+            t_write(H0{}, d, vs + (par ^ 1) * kWV);
+            t_write(H1{}, d2, vs + (par ^ 1) * kWV);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     // U(st+1) and raw(st+2) (issued a stage ago) landed, V(st+1) written -> barrier; this stage's copies stay in flight
     // (no LDS is reused after the last stage: no barrier there, and the residual tile prefetched before it stays in flight)
-    constexpr int kInFlight = (MORE2 ? kWUK : 0) + (MORE3 ? 1 : 0);
-    if (MORE) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
+    if (MORE) {
+      if (NH == 2) {
+        constexpr int kInFlight = (MORE2 ? kWUK : 0) + (MORE3 ? 1 : 0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kInFlight) : "memory");
+      } else {                                           // NH = 1: wave 3 copies one raw piece, the others two
+        constexpr int kU = MORE2 ? kWUK : 0;
+        if (!MORE3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kU) : "memory");
+        else if (nraw == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kU + 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kU + 1) : "memory");
+      }
+    }
     b3 = b3n;
   };
   auto run = [&](auto hc) {
@@ -285,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
     load_res();
     stage(hc, F{}, F{}, F{}, st);
   };
-  if (h) run(std::integral_constant<int, 1>{});
+  if (NH == 2 && h) run(std::integral_constant<int, 1>{});
   else run(std::integral_constant<int, 0>{});
   TGSR_WSTAMP(2);
 
@@ -314,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
         ytile(0, i, yv);
         ytile(1, i, yg);
         const float sv = aff_s[lc], tv = aff_s[64 + lc], sg = aff_s[lc + 16], tg = aff_s[64 + lc + 16];
-        const int c = grp * 32 + h * 16 + 4 * lg + i;
+        const int c = grp * (16 * NH) + h * 16 + 4 * lg + i;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
           if (oy + dy >= a.H) continue;
@@ -336,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
           for (int dy = 0; dy < 2; ++dy) {
             if (oy + dy >= a.H) continue;
             const float o0 = yv[dy][0] * sv + tv + rres[cb][i][dy].x, o1 = yv[dy][1] * sv + tv + rres[cb][i][dy].y;
-            *reinterpret_cast<float2*>(ob + (int64_t)(grp * 64 + lc) * HWo + (int64_t)(oy + dy) * a.W + ox) =
+            *reinterpret_cast<float2*>(ob + (int64_t)(grp * (32 * NH) + lc) * HWo + (int64_t)(oy + dy) * a.W + ox) =
                 make_float2(o0, o1);
           }
         }
@@ -346,15 +392,16 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
   TGSR_WSTAMP(3);
 }
 
-// upack[stage][group][pos pair 8][ci 4][cout half 2][16][4] <- U = G g G^T.  A group is the 64 output channels of one
-// workgroup; element q of a 4-vector = position 2*pp + (q >> 1), cout block q & 1 of the half (GLU: block 0 = value
-// channels grp*32 + half*16 + l, block 1 = their gates Cout/2 + ...; plain: grp*64 + half*32 + block*16 + l).
+// upack[stage][group][pos pair 8][ci 4][cout half nh][16][4] <- U = G g G^T.  A group is the 32 * nh output channels
+// of one workgroup (nh = 2 when Cout % 64 == 0, else 1); element q of a 4-vector = position 2*pp + (q >> 1), cout block
+// q & 1 of the half (GLU: block 0 = value channels grp*16*nh + half*16 + l, block 1 = their gates Cout/2 + ...;
+// plain: grp*32*nh + half*32 + block*16 + l).
 __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu,
-                                        int64_t total) {
-  const int ngrp = Cout / 64;
+                                        int nh, int64_t total) {
+  const int ngrp = Cout / (32 * nh);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(idx & 3), l = (int)((idx >> 2) & 15), hh = (int)((idx >> 6) & 1);
-    int64_t t = idx >> 7;
+    const int q = (int)(idx & 3), l = (int)((idx >> 2) & 15), hh = nh == 2 ? (int)((idx >> 6) & 1) : 0;
+    int64_t t = idx >> (nh == 2 ? 7 : 6);
     const int ci = (int)(t % kWCK);
     t /= kWCK;
     const int pp = (int)(t % 8);
@@ -362,7 +409,8 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __re
     const int grp = (int)(t % ngrp);
     const int st = (int)(t / ngrp);
     const int pos = 2 * pp + (q >> 1), cb = q & 1;
-    const int co = glu ? (cb ? (Cout >> 1) : 0) + grp * 32 + hh * 16 + l : grp * 64 + hh * 32 + cb * 16 + l;
+    const int co = glu ? (cb ? (Cout >> 1) : 0) + grp * (16 * nh) + hh * 16 + l
+                       : grp * (32 * nh) + hh * 32 + cb * 16 + l;
     const int c = st * kWCK + ci;
     float u = 0.f;
     if (c < Cin) {
@@ -395,11 +443,11 @@ extern "C" int64_t tgsr_packed_wino_weight_elems(int Cout, int Cin) {
 
 extern "C" int tgsr_pack_wino_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
   if (!w || !upack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
-  if (Cout % 64 != 0) return TGSR_EUNSUPPORTED;
+  if (Cout % 32 != 0) return TGSR_EUNSUPPORTED;
   const int64_t total = tgsr_packed_wino_weight_elems(Cout, Cin);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_wino_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin,
-                     glu ? 1 : 0, total);
+                     glu ? 1 : 0, Cout % 64 == 0 ? 2 : 1, total);
   return note_launch(hipGetLastError(), "pack_wino_weight_kernel");
 }
 
@@ -412,7 +460,7 @@ extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, i
   const bool glu = epilogue == TGSR_EPI_AFFINE_GLU;
   if (!glu && epilogue != TGSR_EPI_AFFINE) return TGSR_EINVAL;
   if (glu && residual) return TGSR_EINVAL;
-  if (Cout % 64 != 0 || Cin % kWCK != 0) return TGSR_EUNSUPPORTED;
+  if (Cout % 32 != 0 || Cin % kWCK != 0) return TGSR_EUNSUPPORTED;
   if ((int64_t)H * W >= (1 << 28) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
   if ((W & 3) || (x_bstride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7) || (out_bstride & 1) ||
       (residual && ((reinterpret_cast<uintptr_t>(residual) & 7) || (res_bstride & 1))))
@@ -420,13 +468,19 @@ extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, i
   WinoArgs a;
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
   a.scale = scale; a.shift = shift; a.res = residual; a.rbs = res_bstride; a.out = out; a.obs = out_bstride;
-  a.tiles_x = (W + 31) / 32; a.tiles_y = (H + 3) / 4; a.nstages = (Cin + kWCK - 1) / kWCK;
-  dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y), (unsigned)(Cout / 64));
+  const int nh = Cout % 64 == 0 ? 2 : 1;                 // cout halves per workgroup: 64- or 32-channel groups
+  a.tiles_x = (W + 31) / 32; a.tiles_y = nh == 2 ? (H + 3) / 4 : (H + 7) / 8; a.nstages = (Cin + kWCK - 1) / kWCK;
+  dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y), (unsigned)(Cout / (32 * nh)));
   size_t dyn = 0;
 #ifdef TGSR_WINO_STAMPS
   if (const char* e = getenv("TGSR_WINO_DYN")) dyn = (size_t)atoi(e);   // diagnostic: extra LDS to force 1 workgroup per CU
 #endif
-  if (glu) hipLaunchKernelGGL(wino_conv3x3_kernel<true>, grid, dim3(256), dyn, as_stream(stream), a);
-  else hipLaunchKernelGGL(wino_conv3x3_kernel<false>, grid, dim3(256), dyn, as_stream(stream), a);
+  if (nh == 2) {
+    if (glu) hipLaunchKernelGGL((wino_conv3x3_kernel<true, 2>), grid, dim3(256), dyn, as_stream(stream), a);
+    else hipLaunchKernelGGL((wino_conv3x3_kernel<false, 2>), grid, dim3(256), dyn, as_stream(stream), a);
+  } else {
+    if (glu) hipLaunchKernelGGL((wino_conv3x3_kernel<true, 1>), grid, dim3(256), dyn, as_stream(stream), a);
+    else hipLaunchKernelGGL((wino_conv3x3_kernel<false, 1>), grid, dim3(256), dyn, as_stream(stream), a);
+  }
   return note_launch(hipGetLastError(), "wino_conv3x3_kernel");
 }

@@ -126,9 +126,9 @@ def pack_wino_weight(w: torch.Tensor, glu: bool = False) -> torch.Tensor:
 
 def wino_supported(x: torch.Tensor, cout: int, out: Optional[torch.Tensor] = None,
                    residual: Optional[torch.Tensor] = None) -> bool:
-    """Shapes the Winograd kernel takes: Cout % 64 == 0, Cin % 4 == 0, width % 4 == 0, x planes 16-byte aligned,
+    """Shapes the Winograd kernel takes: Cout % 32 == 0, Cin % 4 == 0, width % 4 == 0, x planes 16-byte aligned,
     out / residual 8-byte aligned with even batch strides."""
-    if not (x.dim() == 4 and cout % 64 == 0 and x.shape[1] % 4 == 0 and x.shape[3] % 4 == 0 and
+    if not (x.dim() == 4 and cout % 32 == 0 and x.shape[1] % 4 == 0 and x.shape[3] % 4 == 0 and
             x.data_ptr() % 16 == 0 and (x.shape[0] == 1 or x.stride(0) % 4 == 0)):
         return False
     for t in (out, residual):

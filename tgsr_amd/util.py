@@ -60,6 +60,18 @@ class _FusedParams:
         return self.upack, self.scale, self.shift
 
 
+def _wino_pays(x, cout, out, residual):
+    """Winograd where the kernel takes the shape and is the faster one: always for 64-channel groups; 32-channel
+    groups (Cout % 64 != 0: 8-row workgroup tiles) only when the image gives >= 256 workgroups (measured at B=16:
+    32->32 @128^2 40 vs 71 us, @64^2 16 vs 20 us, @32^2 16 vs 13 us)."""
+    if not ops.wino_supported(x, cout, out=out, residual=residual):
+        return False
+    if cout % 64 == 0:
+        return True
+    B, _, H, W = x.shape
+    return B * ((W + 31) // 32) * ((H + 7) // 8) >= 256
+
+
 def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=None, out=None, training=False):
     """One fused block.  eval: conv + folded-BN affine + GLU/residual in one launch (optionally into `out`, a
     channel-slice view).  training: batch-statistics BN through tgsr_amd.autograd (differentiable)."""
@@ -69,7 +81,7 @@ def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=
         if out is not None:
             raise RuntimeError("training path does not write into channel-slice views")
         return y
-    if WINOGRAD and not upsample and ops.wino_supported(x, conv.out_channels, out=out, residual=residual):
+    if WINOGRAD and not upsample and _wino_pays(x, conv.out_channels, out, residual):
         upack, scale, shift = fp.get_wino(conv, bn, glu)
         return ops.conv3x3_wino(x, upack, conv.out_channels, scale, shift, glu=glu, residual=residual, out=out)
     wpack, scale, shift = fp.get(conv, bn)
