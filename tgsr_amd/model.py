@@ -31,9 +31,11 @@ class G_SR_NET_low(nn.Module):
         self.img_net2 = GET_IMAGE_G_noAct(ngf)
         self.img_net3 = GET_IMAGE_G_noAct(ngf)
 
-    def forward(self, LR, sent_emb, word_embs, mask, outmiddle=False):
+    def forward(self, LR, sent_emb, word_embs, mask, outmiddle=False, ca=None):
+        """ca: optional precomputed `self.ca_net(sent_emb)` (SRPipeline runs that chain of tiny launches on its
+        second stream: nothing downstream reads c_code, model.py:51-52, only mu / logvar are returned)."""
         fake_imgs, att_maps = [], []
-        c_code, mu, logvar = self.ca_net(sent_emb)          # c_code unused downstream (model.py:51-52)
+        c_code, mu, logvar = self.ca_net(sent_emb) if ca is None else ca   # c_code unused downstream (model.py:51-52)
         if not self.training:
             # the three stages attend to the same words: their conv_context projections go out as one launch
             atts = [self.h_net1.att, self.h_net2.att, self.h_net3.att]

@@ -103,9 +103,20 @@ class SRPipeline:
             with torch.cuda.stream(side):                # the trunk needs neither the text encoder nor G_SR_NET_low
                 feats = self.netGH.trunk(LR, LRb)
             words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
+            # CA_NET (a dozen tiny launches; its c_code feeds nothing, only mu / logvar are returned) leaves the
+            # critical stream too: it runs behind the trunk on the side stream
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                ca = self.netGL.ca_net(sent_emb)
             mask = caption_mask(captions, words_embs.size(2))
-            fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
+            fake_imgL, attention_maps, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask, ca=ca)
             main.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                sent_emb.record_stream(side)
+                for t in ca:
+                    t.record_stream(main)
             if not torch.cuda.is_current_stream_capturing():
                 for f in feats:
                     f.record_stream(main)                # allocated on the side stream, consumed on the main one
