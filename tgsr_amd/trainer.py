@@ -97,8 +97,10 @@ class SRPipeline:
         if self.overlap and LR.is_cuda:
             main = torch.cuda.current_stream(LR.device)
             if self._side is None:
-                self._side = torch.cuda.Stream(device=LR.device)
-            side = self._side
+                self._side = {}
+            side = self._side.get(main.cuda_stream)      # one side stream per calling stream (callers may alternate
+            if side is None:                             # lanes to overlap consecutive steps)
+                side = self._side[main.cuda_stream] = torch.cuda.Stream(device=LR.device)
             side.wait_stream(main)                       # LR / LRb are ready on the main stream
             with torch.cuda.stream(side):                # the trunk needs neither the text encoder nor G_SR_NET_low
                 feats = self.netGH.trunk(LR, LRb)

@@ -1,0 +1,27 @@
+"""Throughput with consecutive steps alternating between two stream lanes (each lane = main + side stream), so that a
+step's small kernels and tail fill the gaps of the previous one.  python tools/two_lane_check.py [B]"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+import bench
+from tgsr_amd.miscc.config import cfg, cfg_reset
+from tgsr_amd.trainer import SRPipeline
+from tgsr_amd.synthetic import synthetic_batch
+cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 256; cfg.TREE.BRANCH_NUM = 4; cfg.TREE.BASE_SIZE = 32
+dev = torch.device("cuda:0")
+pipe = SRPipeline(41, device=dev, low="lr", overlap=True)
+w = bench.load_weights(); pipe.load_state_dicts(w["E."], w["GL."], w["GH."])
+cap, lens, LR, LRb = synthetic_batch(BATCH, seed=100)
+cap, LR, LRb = cap.to(dev), LR.to(dev), LRb.to(dev); lens = lens.tolist()
+lanes = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("LANES", "2")))]
+def run(n, nl):
+    for k in range(n):
+        if nl == 0:
+            pipe(cap, lens, LR, LRb)
+        else:
+            with torch.cuda.stream(lanes[k % nl]):
+                pipe(cap, lens, LR, LRb)
+for nl in (0, 1, 2, len(lanes)):
+    run(6, nl); torch.cuda.synchronize()
+    t0 = time.perf_counter(); run(60, nl); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 60
+    print("lanes %d: %.3f ms/step  %.0f img/s" % (nl, dt * 1e3, BATCH / dt))
