@@ -577,3 +577,25 @@ def test_config4_lr64_input_x4_readout(face_weights, cfg_face):
         close(r["fake"][i], ref["fake"][i], atol=ATOL256 if i == 2 else ATOL)
         close(r["fine"][i], ref["fine"][i], atol=ATOL256 if i == 2 else ATOL)
         close(r["att"][i], ref["att"][i], atol=2e-5)
+
+
+def test_pipeline_stream_lanes_match_single_stream(nets_small, cfg_small):
+    """Consecutive independent batches alternating over three stream lanes (what bench.py does) give exactly the
+    results of running them one at a time."""
+    from tgsr_amd.synthetic import synthetic_batch
+    p = _pipeline(nets_small)
+    batches = []
+    for k in range(6):
+        cap, lens, LR, LRb = synthetic_batch(3, seed=20 + k, lr=16)
+        batches.append((cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV)))
+    ref = [[f.clone() for f in p(*b)["fine"]] for b in batches]
+    torch.cuda.synchronize()
+    lanes = p.lanes(3)
+    outs = []
+    for k, b in enumerate(batches):
+        with torch.cuda.stream(lanes[k % 3]):
+            outs.append(p(*b)["fine"])
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref):
+        for a, b_ in zip(o, r):
+            assert torch.equal(a, b_)

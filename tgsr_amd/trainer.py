@@ -58,6 +58,18 @@ class SRPipeline:
             self.netGH.load_state_dict({k: v for k, v in sd_GH.items() if k != "a"}, strict=True)
         return self
 
+    # ------------------------------------------------------------------ throughput: stream lanes
+    def lanes(self, n=3):
+        """n HIP streams to alternate consecutive, independent batches over:
+
+            for k, batch in enumerate(batches):
+                with torch.cuda.stream(lanes[k % n]):
+                    out = pipe(*batch)          # consume `out` on that stream (or synchronise it first)
+
+        The ~60 dependent launches of one forward leave the GPU idle ~10 % of the time; another batch's kernels fill
+        those gaps (B=16: 1.74 -> 1.57 ms per step with three lanes).  Each lane keeps its own activation buffers."""
+        return [torch.cuda.Stream(device=self.device) for _ in range(n)]
+
     # ------------------------------------------------------------------ hipGraph replay (BASELINE config 5)
     @torch.no_grad()
     def capture(self, captions, cap_lens, LR, LRb, warmup=3):
