@@ -67,7 +67,9 @@ class SRPipeline:
                     out = pipe(*batch)          # consume `out` on that stream (or synchronise it first)
 
         The ~60 dependent launches of one forward leave the GPU idle ~10 % of the time; another batch's kernels fill
-        those gaps (B=16: 1.74 -> 1.57 ms per step with three lanes).  Each lane keeps its own activation buffers."""
+        those gaps (B=16: 1.74 -> 1.57 ms per step with three lanes).  Each lane keeps its own activation buffers.
+        Weight packs and the per-token gate table are built on first use, on whatever stream that forward runs: do
+        one warm-up forward and `torch.cuda.synchronize()` after loading / changing weights before fanning out."""
         return [torch.cuda.Stream(device=self.device) for _ in range(n)]
 
     # ------------------------------------------------------------------ hipGraph replay (BASELINE config 5)
