@@ -287,7 +287,9 @@ def main():
     # sampled steps run alone (lanes drained before and after) so that a launch is timed in isolation.
     nlanes = 1 if (args.serial or args.graph) else max(1, args.lanes)
     lanes = [torch.cuda.Stream(device=dev) for _ in range(nlanes)] if nlanes > 1 else []
-    for i, ln in enumerate(lanes):          # untimed: every lane allocates its activation buffers once
+    if lanes:
+        torch.cuda.synchronize()            # weight packs / caches of the warm-up steps are complete before fanning out
+    for ln in lanes:                        # untimed: every lane allocates its activation buffers once
         with torch.cuda.stream(ln):
             step()
     prof, nprof = [], 0
