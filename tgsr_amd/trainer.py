@@ -79,30 +79,24 @@ class SRPipeline:
         `replay(captions, LR, LRb)` then copies new inputs in and relaunches the whole step with one call.  The
         caption lengths (hence T_max and the mask shape) are part of the captured step: a batch with other lengths
         needs its own capture, like the reference's cudnn.benchmark re-tunes per shape."""
-        dev = LR.device
-        self._g_in = (captions.clone(), LR.clone(), LRb.clone())
-        self._g_lens = list(cap_lens)
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):                       # weight packs, caches and the allocator warm up outside the graph
-            for _ in range(warmup):
-                self(self._g_in[0], self._g_lens, self._g_in[1], self._g_in[2])
-        torch.cuda.current_stream(dev).wait_stream(s)
-        torch.cuda.synchronize(dev)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._g_out = self(self._g_in[0], self._g_lens, self._g_in[1], self._g_in[2])
-        return self._g_out
+        self._graphed = GraphedStep(self, captions, cap_lens, LR, LRb, warmup=warmup)
+        return self._graphed.out
 
     @torch.no_grad()
     def replay(self, captions=None, LR=None, LRb=None):
         """Relaunch the captured step (on new inputs when given: same shapes, same caption lengths).  The returned
         tensors are the graph's static outputs: consume them before the next replay."""
-        for dst, src in zip(self._g_in, (captions, LR, LRb)):
-            if src is not None and src is not dst:
-                dst.copy_(src, non_blocking=True)
-        self._graph.replay()
-        return self._g_out
+        return self._graphed.replay(captions, LR, LRb)
+
+    @torch.no_grad()
+    def capture_lanes(self, n, captions, cap_lens, LR, LRb):
+        """n independent captured steps, each with its own static buffers and its own stream, for
+        `lanes[k % n].replay(...)`: one host call per step (0.17 ms of host time instead of the ~1.3 ms of ~60 eager
+        launches).  Measured on ROCm 7.2 the replays of different graphs do NOT overlap the way eager lanes do
+        (B=16: 1.70-1.75 ms per step against 1.57 ms with three eager lanes, tools/two_lane_check.py), so bench.py
+        keeps eager lanes; this is the option for a host that cannot keep up with the enqueue rate."""
+        return [GraphedStep(self, captions, cap_lens, LR, LRb, stream=torch.cuda.Stream(device=self.device))
+                for _ in range(n)]
 
     @torch.no_grad()
     def __call__(self, captions, cap_lens, LR, LRb):
@@ -144,3 +138,41 @@ class SRPipeline:
             fine_im, a, one = self.netGH(LR, fake_imgL, LRb)
         return {"words_emb": words_embs, "sent_emb": sent_emb, "mask": mask, "fake": fake_imgL,
                 "att": attention_maps, "mu": mu, "logvar": logvar, "fine": fine_im}
+
+
+class GraphedStep:
+    """One captured inference step of an SRPipeline: a hipGraph + the static input / output tensors it is bound to.
+    With `stream` the replay (and the copy of new inputs) runs on that stream."""
+
+    @torch.no_grad()
+    def __init__(self, pipe, captions, cap_lens, LR, LRb, stream=None, warmup=3):
+        dev = LR.device
+        self.stream = stream
+        self.inputs = (captions.clone(), LR.clone(), LRb.clone())
+        self.lens = list(cap_lens)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):                       # weight packs, caches and the allocator warm up outside the graph
+            for _ in range(warmup):
+                pipe(self.inputs[0], self.lens, self.inputs[1], self.inputs[2])
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = pipe(self.inputs[0], self.lens, self.inputs[1], self.inputs[2])
+
+    @torch.no_grad()
+    def replay(self, captions=None, LR=None, LRb=None):
+        """Copy new inputs (same shapes, same caption lengths) into the static buffers and relaunch the step.  Returns
+        the static outputs: consume them (on `stream`, or after synchronising it) before this lane's next replay."""
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                return self._go(captions, LR, LRb)
+        return self._go(captions, LR, LRb)
+
+    def _go(self, captions, LR, LRb):
+        for dst, src in zip(self.inputs, (captions, LR, LRb)):
+            if src is not None and src is not dst:
+                dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.out

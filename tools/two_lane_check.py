@@ -25,3 +25,14 @@ for nl in (0, 1, 2, len(lanes)):
     run(6, nl); torch.cuda.synchronize()
     t0 = time.perf_counter(); run(60, nl); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 60
     print("lanes %d: %.3f ms/step  %.0f img/s" % (nl, dt * 1e3, BATCH / dt))
+
+# the same with one captured hipGraph per lane (one host call per step)
+for nl in (1, 2, 3, 4):
+    gl = pipe.capture_lanes(nl, cap, lens, LR, LRb)
+    def rung(n):
+        for k in range(n):
+            gl[k % nl].replay(cap, LR, LRb)
+    rung(6); torch.cuda.synchronize()
+    t0 = time.perf_counter(); rung(60); t1 = time.perf_counter(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 60
+    print("graph lanes %d: %.3f ms/step  %.0f img/s   (host %.3f ms/step)" % (nl, dt * 1e3, BATCH / dt, (t1 - t0) / 60 * 1e3))
+    del gl
