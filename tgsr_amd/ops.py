@@ -23,7 +23,14 @@ def _ev():
     return e
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """torch's current HIP stream of the current device as a void*.  The raw-handle query costs < 1 us; going through
+    torch.cuda.current_stream() costs ~5 us, i.e. 0.25 ms of host time per forward at ~50 launches."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
