@@ -599,3 +599,36 @@ def test_pipeline_stream_lanes_match_single_stream(nets_small, cfg_small):
     for o, r in zip(outs, ref):
         for a, b_ in zip(o, r):
             assert torch.equal(a, b_)
+
+
+def test_winograd_kernels_random_shape_sweep():
+    """Seeded sweep over ragged shapes (every Cin % 4, Cout % 32 / % 64 class, H from 1, W % 4 == 0) of both Winograd
+    kernels against the direct convolution - tile-edge, single-stage and many-stage cases the layer shapes never hit."""
+    from tgsr_amd import ops
+    rng = np.random.RandomState(1234)
+    for it in range(24):
+        B = int(rng.randint(1, 4))
+        Cin = 4 * int(rng.randint(1, 10))
+        H = int(rng.randint(1, 23))
+        W = 4 * int(rng.randint(1, 13))
+        glu = bool(rng.randint(0, 2))
+        Cout = int(rng.choice([32, 64, 96, 128])) if not glu else int(rng.choice([32, 64, 128]))
+        res = (not glu) and bool(rng.randint(0, 2))
+        g = torch.Generator().manual_seed(1000 + it)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+        scale, shift = 0.5 + torch.rand(Cout, generator=g), 0.3 * torch.randn(Cout, generator=g)
+        co = Cout // 2 if glu else Cout
+        r = torch.randn(B, co, H, W, generator=g) if res else None
+        ref = F.conv2d(x, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
+        ref = O.glu(ref) if glu else ref
+        ref = ref + r if res else ref
+        out = ops.conv3x3_wino(x.to(DEV), ops.pack_wino_weight(w.to(DEV), glu=glu), Cout, scale.to(DEV), shift.to(DEV),
+                               glu=glu, residual=None if r is None else r.to(DEV))
+        close(out, ref, atol=3e-5, rtol=3e-5)
+        if Cout % 64 == 0:            # the up-sample-aware form on the same operands
+            xi = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+            uref = F.conv2d(xi, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
+            up = ops.upwino_glu(x.to(DEV), ops.pack_upwino_weight(w.to(DEV), glu=glu), Cout, scale.to(DEV),
+                                shift.to(DEV), glu=glu)
+            close(up, O.glu(uref) if glu else uref, atol=3e-5, rtol=3e-5)
