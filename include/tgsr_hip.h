@@ -289,6 +289,17 @@ int tgsr_conv3x3_wgrad(const float* grad_out, const float* x, int64_t x_bstride,
                        int upsample, float* ws, float* dw, void* stream);
 
 /*
+ * The same weight gradient for the upBlock convolution (upsample = 1) in the domain of the up-sample-aware Winograd
+ * form: dU'[p] = sum over LOW-resolution pixels of dM[p] (x) V[p] for the 9 positions, then dW = G'^T dU' G' - 4x fewer
+ * multiplies than the direct form.  grad_out [B][Cout][2H][2W] dense (8-byte aligned), x [B][Cin][H][W] with batch
+ * stride; Cout % 64 == 0, Cin % 32 == 0.  ws: tgsr_upwino_wgrad_ws_elems floats (per-workgroup partial slabs, summed
+ * in a fixed order).  dw [Cout][Cin][3][3].
+ */
+int64_t tgsr_upwino_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W);
+int tgsr_upwino_wgrad(const float* grad_out, const float* x, int64_t x_bstride, int B, int Cin, int H, int W, int Cout,
+                      float* ws, float* dw, void* stream);
+
+/*
  * Backward of tgsr_word_attention_fwd (the attention map output carries no gradient).  P is recomputed from h and
  * src.  dc [B][idf][Q] dense -> dh [B][idf][Q] dense and dsrc_part [B][nchunks][idf][32] (nchunks =
  * tgsr_word_attention_bwd_chunks(Q)); the caller sums the chunks and maps dsrc to conv_context.weight / words:

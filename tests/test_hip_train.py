@@ -21,6 +21,8 @@ CASES = [
     (3, 64, 16, 32, 128, True, False, False),
     (3, 64, 16, 32, 64, False, False, True),
     (2, 64, 16, 16, 64, True, True, False),
+    (3, 32, 9, 20, 64, True, True, False),      # upBlock wgrad in the Winograd domain: ragged, 32-channel input
+    (2, 64, 24, 40, 128, True, True, False),    # ... two cout groups, several chunks per row
     (4, 32, 32, 32, 64, True, False, False),
     (4, 32, 32, 32, 32, False, False, True),
     (2, 32, 16, 32, 32, False, False, False),
