@@ -300,6 +300,16 @@ int tgsr_upwino_wgrad(const float* grad_out, const float* x, int64_t x_bstride, 
                       float* ws, float* dw, void* stream);
 
 /*
+ * Weight gradient of the plain conv3x3 (upsample = 0) in the Winograd F(2x2,3x3) domain: dU[p] = sum over 2x2 output
+ * tiles of dM[p] (x) V[p] for the 16 positions, then dW = G^T dU G - 2.25x fewer multiplies than tgsr_conv3x3_wgrad.
+ * grad_out [B][Cout][H][W] dense, x [B][Cin][H][W] with batch stride; Cout % 64 == 0, Cin % 32 == 0.
+ * ws: tgsr_wino_wgrad_ws_elems floats (per-workgroup partial slabs, summed in a fixed order).  dw [Cout][Cin][3][3].
+ */
+int64_t tgsr_wino_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W);
+int tgsr_wino_wgrad(const float* grad_out, const float* x, int64_t x_bstride, int B, int Cin, int H, int W, int Cout,
+                    float* ws, float* dw, void* stream);
+
+/*
  * Backward of tgsr_word_attention_fwd (the attention map output carries no gradient).  P is recomputed from h and
  * src.  dc [B][idf][Q] dense -> dh [B][idf][Q] dense and dsrc_part [B][nchunks][idf][32] (nchunks =
  * tgsr_word_attention_bwd_chunks(Q)); the caller sums the chunks and maps dsrc to conv_context.weight / words:

@@ -28,6 +28,8 @@ CASES = [
     (2, 32, 16, 32, 32, False, False, False),
     (2, 3, 32, 32, 64, True, False, False),
     (16, 64, 32, 32, 128, True, False, False),
+    (2, 32, 13, 20, 64, True, False, False),     # Winograd-domain wgrad: odd height (partial tiles), 32-channel input
+    (1, 64, 5, 40, 64, False, False, True),      # ... several chunks per tile row
 ]
 
 

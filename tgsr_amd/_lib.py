@@ -59,6 +59,8 @@ SIGNATURES = {
     "tgsr_conv3x3_wgrad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tgsr_upwino_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i]),
     "tgsr_upwino_wgrad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "tgsr_wino_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i]),
+    "tgsr_wino_wgrad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tgsr_word_attention_bwd_chunks": (_i, [_i]),
     "tgsr_word_attention_bwd": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "tgsr_conv_to3_bwd_ws_elems": (_i64, [_i, _i, _i, _i, _i]),

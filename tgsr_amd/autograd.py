@@ -103,6 +103,11 @@ class ConvBnAct(torch.autograd.Function):
                 wws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
                 rc = L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
                 check(rc, "tgsr_upwino_wgrad")
+            elif (not upsample) and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
+                # plain conv: 16 Winograd positions per 2x2 output tile (2.25x fewer multiplies than 9 taps per pixel)
+                wws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
+                rc = L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
+                check(rc, "tgsr_wino_wgrad")
             else:
                 n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
                 wws = torch.empty(n, dtype=torch.float32, device=dev)
