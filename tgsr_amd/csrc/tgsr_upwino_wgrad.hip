@@ -183,7 +183,7 @@ static void upwgrad_plan(int B, int Cin, int Cout, int H, int W, int* nci, int* 
   *gi = Cin / (32 * *nci);
   *groups = (Cout / 64) * *gi;
   *nchunks = B * H * ((W + kUWT - 1) / kUWT);
-  int want = 1024 / *groups;                 // ~4 workgroups per CU in flight; slabs stay small (nslots x 9 x |dW| / 9)
+  int want = 512 / *groups;                  // two workgroups per CU in flight; fewer, longer K walks keep the slabs small
   if (want < 1) want = 1;
   if (want > *nchunks) want = *nchunks;
   *cpw = (*nchunks + want - 1) / want;
