@@ -273,9 +273,9 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = _gemm_nt(dy, w.detach().t())          # [B,N] @ W [N,K]
-        dw = _gemm_nt(dy.t(), x.detach().t())      # dy^T x
-        return dx, dw, (dy.sum(0) if ctx.has_bias else None)
+        dx = _gemm_nt(dy, w.detach().t()) if ctx.needs_input_grad[0] else None          # [B,N] @ W [N,K]
+        dw = _gemm_nt(dy.t(), x.detach().t()) if ctx.needs_input_grad[1] else None      # dy^T x
+        return dx, dw, (dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None)
 
 
 class Conv1x1Fn(torch.autograd.Function):
@@ -292,8 +292,11 @@ class Conv1x1Fn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         Cout, Cin = w.shape[0], w.shape[1]
         dy = dy.contiguous()
-        dx = ops.conv1x1(dy, w.detach().reshape(Cout, Cin).t().contiguous())
-        dy2 = dy.permute(1, 0, 2, 3).reshape(Cout, -1)                 # [Cout, B*S]
-        x2 = x.detach().permute(1, 0, 2, 3).reshape(Cin, -1)           # [Cin,  B*S]
-        dw = _gemm_nt(dy2, x2).reshape(w.shape)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:                                    # (the frozen trunk's features need none)
+            dx = ops.conv1x1(dy, w.detach().reshape(Cout, Cin).t().contiguous())
+        if ctx.needs_input_grad[1]:
+            dy2 = dy.permute(1, 0, 2, 3).reshape(Cout, -1)             # [Cout, B*S]
+            x2 = x.detach().permute(1, 0, 2, 3).reshape(Cin, -1)       # [Cin,  B*S]
+            dw = _gemm_nt(dy2, x2).reshape(w.shape)
         return dx, dw
