@@ -9,7 +9,7 @@ sent_loss through torch autograd over its [B, B] matrix.
 """
 import numpy as np
 import torch
-import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import ops
 from .config import cfg
@@ -20,11 +20,10 @@ def _func_attention(query, context, gamma1):
 
 
 def cosine_similarity(x1, x2, dim=1, eps=1e-8):
-    """losses.py:12-18."""
-    w12 = torch.sum(x1 * x2, dim)
-    w1 = torch.norm(x1, 2, dim)
-    w2 = torch.norm(x2, 2, dim)
-    return (w12 / (w1 * w2).clamp(min=eps)).squeeze()
+    """losses.py:12-18: <x1, x2> / max(|x1| |x2|, eps) along `dim`."""
+    dot = (x1 * x2).sum(dim)
+    scale = (x1.norm(p=2, dim=dim) * x2.norm(p=2, dim=dim)).clamp_min(eps)
+    return (dot / scale).squeeze()
 
 
 def _class_masks(class_ids, batch_size, device):
@@ -37,27 +36,24 @@ def _class_masks(class_ids, batch_size, device):
     return torch.from_numpy(m).to(device)
 
 
+def _ranking_ce(scores, labels):
+    """The two cross entropies of a [B, B] matching matrix (rows = images, columns = captions) - losses.py:56-59."""
+    if labels is None:
+        return None, None
+    return F.cross_entropy(scores, labels), F.cross_entropy(scores.t(), labels)
+
+
 def sent_loss(cnn_code, rnn_code, labels, class_ids, batch_size, eps=1e-8):
-    """losses.py:21-62."""
-    masks = _class_masks(class_ids, batch_size, cnn_code.device)
-    if cnn_code.dim() == 2:
-        cnn_code = cnn_code.unsqueeze(0)
-        rnn_code = rnn_code.unsqueeze(0)
-    cnn_code_norm = torch.norm(cnn_code, 2, dim=2, keepdim=True)
-    rnn_code_norm = torch.norm(rnn_code, 2, dim=2, keepdim=True)
-    scores0 = torch.bmm(cnn_code, rnn_code.transpose(1, 2))
-    norm0 = torch.bmm(cnn_code_norm, rnn_code_norm.transpose(1, 2))
-    scores0 = scores0 / norm0.clamp(min=eps) * cfg.TRAIN.SMOOTH.GAMMA3
-    scores0 = scores0.squeeze(dim=0)
-    if masks is not None:
-        scores0 = scores0.masked_fill(masks, -float('inf'))
-    scores1 = scores0.transpose(0, 1)
-    if labels is not None:
-        loss0 = nn.CrossEntropyLoss()(scores0, labels)
-        loss1 = nn.CrossEntropyLoss()(scores1, labels)
-    else:
-        loss0, loss1 = None, None
-    return loss0, loss1
+    """losses.py:21-62: gamma3-scaled cosine matrix between the image codes and the sentence codes, same-class pairs
+    masked out, cross entropy along both axes."""
+    img = cnn_code.reshape(-1, cnn_code.shape[-1])                    # the reference's [1, B, D] form is the same matrix
+    txt = rnn_code.reshape(-1, rnn_code.shape[-1])
+    norms = img.norm(p=2, dim=1, keepdim=True) * txt.norm(p=2, dim=1, keepdim=True).t()
+    scores = img @ txt.t() / norms.clamp_min(eps) * cfg.TRAIN.SMOOTH.GAMMA3
+    same_class = _class_masks(class_ids, batch_size, scores.device)
+    if same_class is not None:
+        scores = scores.masked_fill(same_class, float("-inf"))
+    return _ranking_ce(scores, labels)
 
 
 def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size):
@@ -75,72 +71,60 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
     masks = _class_masks(class_ids, batch_size, sim.device)
     if masks is not None:
         similarities = similarities.masked_fill(masks, -float('inf'))
-    similarities1 = similarities.transpose(0, 1)
-    if labels is not None:
-        loss0 = nn.CrossEntropyLoss()(similarities, labels)
-        loss1 = nn.CrossEntropyLoss()(similarities1, labels)
-    else:
-        loss0, loss1 = None, None
+    loss0, loss1 = _ranking_ce(similarities, labels)
     return loss0, loss1, att_maps
 
 
 def MSE(fake, label):
-    """losses.py:779-784."""
-    mseloss = 0
-    for i in range(len(fake)):
-        mseloss += nn.MSELoss()(fake[i], label[i])
-    return mseloss
+    """losses.py:779-784: sum over the image scales of the mean squared error."""
+    return sum(F.mse_loss(f, t) for f, t in zip(fake, label))
 
 
 def KL_loss(mu, logvar):
-    """losses.py:806-810."""
-    KLD_element = mu.pow(2).add(logvar.exp()).mul(-1).add(1).add(logvar)
-    return torch.mean(KLD_element).mul(-0.5)
+    """losses.py:806-810: -0.5 * mean(1 + logvar - mu^2 - exp(logvar))."""
+    return -0.5 * torch.mean(1.0 + logvar - mu * mu - logvar.exp())
+
+
+def _bce(logits, target):
+    return F.binary_cross_entropy_with_logits(logits, target)
 
 
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels):
     """losses.py:290-316.  The reference ships no discriminator class; any module exposing `COND_DNET` /
-    `UNCOND_DNET` like AttnGAN's D_NET* works (real / fake / wrong-caption terms, the wrong pair is the batch shifted
-    by one, :302)."""
-    real_features = netD(real_imgs)
-    fake_features = netD(fake_imgs.detach())
-    bce = nn.BCEWithLogitsLoss()
-    cond_real_errD = bce(netD.COND_DNET(real_features, conditions), real_labels)
-    cond_fake_errD = bce(netD.COND_DNET(fake_features, conditions), fake_labels)
-    batch_size = real_features.size(0)
-    cond_wrong_logits = netD.COND_DNET(real_features[:(batch_size - 1)], conditions[1:batch_size])
-    cond_wrong_errD = bce(cond_wrong_logits, fake_labels[1:batch_size])
-    if netD.UNCOND_DNET is not None:
-        real_errD = bce(netD.UNCOND_DNET(real_features), real_labels)
-        fake_errD = bce(netD.UNCOND_DNET(fake_features), fake_labels)
-        return (real_errD + cond_real_errD) / 2. + (fake_errD + cond_fake_errD + cond_wrong_errD) / 3.
-    return cond_real_errD + (cond_fake_errD + cond_wrong_errD) / 2.
+    `UNCOND_DNET` like AttnGAN's D_NET* works: real / fake / wrong-caption terms, the wrong pair being the batch
+    shifted by one (:302)."""
+    feat_real, feat_fake = netD(real_imgs), netD(fake_imgs.detach())
+    n = feat_real.size(0)
+    cond = {"real": _bce(netD.COND_DNET(feat_real, conditions), real_labels),
+            "fake": _bce(netD.COND_DNET(feat_fake, conditions), fake_labels),
+            "wrong": _bce(netD.COND_DNET(feat_real[:n - 1], conditions[1:n]), fake_labels[1:n])}
+    if netD.UNCOND_DNET is None:
+        return cond["real"] + (cond["fake"] + cond["wrong"]) / 2.
+    unc_real = _bce(netD.UNCOND_DNET(feat_real), real_labels)
+    unc_fake = _bce(netD.UNCOND_DNET(feat_fake), fake_labels)
+    return (unc_real + cond["real"]) / 2. + (unc_fake + cond["fake"] + cond["wrong"]) / 3.
 
 
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
                    class_ids, w=1, s=1, g=1):
-    """losses.py:351-391: per-scale adversarial terms + the DAMSM words/sentence ranking loss on the last scale."""
-    numDs = len(netsD)
-    batch_size = real_labels.size(0)
-    logs = ''
-    errG_total = 0
-    bce = nn.BCEWithLogitsLoss()
-    for i in range(numDs):
-        features = netsD[i](fake_imgs[i])
-        cond_errG = bce(netsD[i].COND_DNET(features, sent_emb), real_labels)
-        if netsD[i].UNCOND_DNET is not None:
-            g_loss = bce(netsD[i].UNCOND_DNET(features), real_labels) + cond_errG
-        else:
-            g_loss = cond_errG
-        g_loss = g * g_loss
-        errG_total += g_loss
-        logs += 'g_loss%d: %.5f ' % (i, g_loss.item())
-        if i == (numDs - 1):
-            region_features, cnn_code = image_encoder(fake_imgs[i])
-            w_loss0, w_loss1, _ = words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, batch_size)
-            w_loss = w * (w_loss0 + w_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-            s_loss0, s_loss1 = sent_loss(cnn_code, sent_emb, match_labels, class_ids, batch_size)
-            s_loss = s * (s_loss0 + s_loss1) * cfg.TRAIN.SMOOTH.LAMBDA
-            errG_total += w_loss + s_loss
-            logs += 'w_loss: %.5f s_loss: %.5f ' % (w_loss.item(), s_loss.item())
-    return errG_total, logs
+    """losses.py:351-391: per-scale adversarial terms + the DAMSM words / sentence ranking loss on the last scale
+    (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log string) like the reference."""
+    B = real_labels.size(0)
+    total, parts = 0, []
+    for k, (netD, img) in enumerate(zip(netsD, fake_imgs)):
+        feat = netD(img)
+        adv = _bce(netD.COND_DNET(feat, sent_emb), real_labels)
+        if netD.UNCOND_DNET is not None:
+            adv = adv + _bce(netD.UNCOND_DNET(feat), real_labels)
+        adv = g * adv
+        total = total + adv
+        parts.append("g_loss%d: %.5f " % (k, adv.item()))
+        if k == len(netsD) - 1:
+            regions, code = image_encoder(img)
+            w0, w1, _ = words_loss(regions, words_embs, match_labels, cap_lens, class_ids, B)
+            s0, s1 = sent_loss(code, sent_emb, match_labels, class_ids, B)
+            w_term = w * (w0 + w1) * cfg.TRAIN.SMOOTH.LAMBDA
+            s_term = s * (s0 + s1) * cfg.TRAIN.SMOOTH.LAMBDA
+            total = total + w_term + s_term
+            parts.append("w_loss: %.5f s_loss: %.5f " % (w_term.item(), s_term.item()))
+    return total, "".join(parts)
