@@ -329,6 +329,44 @@ int tgsr_conv_to3_bwd(const float* dy, const float* out, const float* addend, fl
                       int64_t x_bstride, const float* w, int B, int Cin, int H, int W, int K, int act, float* dx,
                       float* ws, float* dw, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Reduced-precision inference path (BASELINE.json configs[4]: "bf16 ... MFMA bf16 attention + fused conv").
+ * Storage type `dtype` = TGSR_DT_BF16 or TGSR_DT_F16 (2-byte elements), MFMA operands in that type, fp32 accumulation,
+ * fp32 epilogue arithmetic, one round-to-nearest-even per stored element.  Activation layout ("lp image"):
+ *     [B][H + 2][W + 2][cpitch]  channels-last with a one-pixel ZERO border that no kernel ever writes
+ * (allocate the buffer zeroed once).  `cpitch` is the channel pitch of the buffer, `coff` the first channel a call
+ * reads / writes: two producers writing channel ranges [0,32) and [32,64) of one cpitch-64 image replace the
+ * reference's torch.cat((h_code, c_code), 1) (util.py:771, 817).  All pointers are to element [0][0][0][0] of the
+ * padded image.  Shapes: W % 32 == 0, H % 4 == 0 (every layer of the x8 / x16 generators at LR >= 32).
+ */
+#define TGSR_DT_BF16 1
+#define TGSR_DT_F16 2
+
+/* fp32 NCHW [B][C][H][W] <-> channels [coff, coff + C) of an lp image (interior pixels only). */
+int tgsr_lp_from_nchw(int dtype, const float* x, void* out, int B, int C, int H, int W, int cpitch, int coff,
+                      void* stream);
+int tgsr_lp_to_nchw(int dtype, const void* x, float* out, int B, int C, int H, int W, int cpitch, int coff,
+                    void* stream);
+
+/* conv weight [Cout][Cin][3][3] (fp32, torch layout) -> MFMA fragment order
+ * [kernel row 3][Cin/16][kernel column 3][Cout/32][lane 64][8], rounded to `dtype`
+ * (tgsr_lp_packed_conv3x3_elems 2-byte elements).  Cout % 32 == 0, Cin % 16 == 0. */
+int64_t tgsr_lp_packed_conv3x3_elems(int Cout, int Cin);
+int tgsr_lp_pack_conv3x3_weight(int dtype, const float* w, void* wpack, int Cout, int Cin, void* stream);
+
+/*
+ * The fused blocks of tgsr_conv3x3_fwd on lp images (same reference sites: ResBlock.block util.py:110-130, upBlock
+ * util.py:74-80, residual24/48 model.py:229-232):
+ *   out = epilogue(scale * conv3x3(upsample ? nearest_x2(x) : x) + shift), epilogue = TGSR_EPI_AFFINE (+ residual when
+ *   `residual` != NULL) or TGSR_EPI_AFFINE_GLU (Cout/2 output channels).
+ * H, W are the OUTPUT size (x is H/2 x W/2 when upsample != 0; only with TGSR_EPI_AFFINE_GLU).  scale / shift fp32
+ * [Cout] (NULL, NULL = identity).  (Cin, Cout) in {(64,128), (64,64), (32,64), (32,32)}: the generator's layers.
+ */
+int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                        int Cout, const float* scale, const float* shift, const void* residual, int res_cpitch,
+                        int res_coff, void* out, int out_cpitch, int out_coff, int epilogue, int upsample,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,157 @@
+"""CPU model of the reduced-precision (bf16 / f16) inference path.  TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file.
+
+The reference (cxm12/TGSR) computes in fp32 only; BASELINE.json configs[4] asks for a bf16 path.  This file restates
+`oracle.tgsr_oracle` with the rounding points of the HIP lp path made explicit, so that the kernels can be checked
+tightly (same roundings, fp32 accumulation order aside) AND the cost of the reduced precision against the fp32 oracle
+can be stated independently of any kernel:
+
+  * every activation the generators store is rounded once to `dtype` (round-to-nearest-even); conv / attention MFMA
+    operands are those stored values and `dtype`-rounded weights; accumulation, BatchNorm affine, GLU, residual add,
+    softmax and tanh are fp32;
+  * the two 3-channel stems (im2f util.py:741-744, convin model.py:228) read the fp32 LR image with fp32 weights;
+  * the text encoder, CA_NET and the word projection `conv_context` (GlobalAttention.py:100-102) stay fp32; the
+    projected words are rounded to `dtype` once; the attention maps returned to the caller are the fp32 softmax;
+  * the six image heads return fp32 images (no rounding of the outputs).
+
+Measured with this model on the shipped face checkpoint (B=4, seed 100), PSNR of the finest SR image against the fp32
+oracle (peak 2.0): bf16 45.0 dB, f16 62.3 dB.  Rounding ONLY the weights to bf16, or ONLY the conv operands, each gives
+48.3-48.6 dB with everything else (storage, accumulation) in fp32: the bf16 figure is the price of 8-bit-mantissa
+operands on this network, not of storage or of a kernel, and cannot reach the 50 dB SURVEY.md 8c hoped for.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import tgsr_oracle as O
+
+Tensor = torch.Tensor
+
+
+def rnd(x: Tensor, dtype) -> Tensor:
+    """Round to `dtype` (nearest even), return as fp32."""
+    return x.to(dtype).to(torch.float32)
+
+
+def _fold(sd, p):
+    """BatchNorm2d eval as (scale, shift) (tgsr_bn_fold)."""
+    s = sd[p + "weight"] / torch.sqrt(sd[p + "running_var"] + O.BN_EPS)
+    return s, sd[p + "bias"] - sd[p + "running_mean"] * s
+
+
+def conv_block(x: Tensor, w: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], dtype, glu: bool = False,
+               upsample: bool = False, residual: Optional[Tensor] = None, round_w: bool = True) -> Tensor:
+    """tgsr_lp_conv3x3_fwd: x, residual hold `dtype`-representable values (NCHW fp32 tensors)."""
+    if upsample:
+        x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    y = F.conv2d(x, rnd(w, dtype) if round_w else w, None, 1, 1)
+    if scale is not None:
+        y = y * scale[None, :, None, None] + shift[None, :, None, None]
+    if glu:
+        y = O.glu(y)
+    if residual is not None:
+        y = y + residual
+    return rnd(y, dtype)
+
+
+def word_attention(h: Tensor, words: Tensor, w_ctx: Tensor, mask: Optional[Tensor], dtype, correct_mask=False):
+    """tgsr_lp_word_attention_fwd: h holds `dtype` values; returns (c_code rounded to dtype, attn fp32)."""
+    B, idf, ih, iw = h.shape
+    T = words.shape[2]
+    Q = ih * iw
+    src = rnd(torch.einsum("ic,bct->bit", w_ctx.reshape(idf, -1), words), dtype)
+    s = torch.einsum("biq,bit->bqt", h.reshape(B, idf, Q), src)
+    if mask is not None:
+        if correct_mask:
+            m = mask[:, None, :].expand(B, Q, T)
+        else:
+            rows = torch.arange(B * Q) % B
+            m = mask[rows].reshape(B, Q, T)
+        s = s.masked_fill(m, float("-inf"))
+    p = torch.softmax(s, dim=2)
+    wc = torch.einsum("bit,bqt->biq", src, rnd(p, dtype))
+    return rnd(wc, dtype).reshape(B, idf, ih, iw), p.transpose(1, 2).reshape(B, T, ih, iw)
+
+
+def _res_block(x, sd, p, dtype):
+    s0, t0 = _fold(sd, p + "block.1.")
+    s1, t1 = _fold(sd, p + "block.4.")
+    y = conv_block(x, sd[p + "block.0.weight"], s0, t0, dtype, glu=True)
+    return conv_block(y, sd[p + "block.3.weight"], s1, t1, dtype, residual=x)
+
+
+def _up_block(x, sd, p, dtype):
+    s, t = _fold(sd, p + "2.")
+    return conv_block(x, sd[p + "1.weight"], s, t, dtype, glu=True, upsample=True)
+
+
+def _stem(x, sd, p, dtype):
+    s, t = _fold(sd, p + "1.")
+    return conv_block(x, sd[p + "0.weight"], s, t, dtype, glu=True, round_w=False)
+
+
+def _stage(sd, p, h, words, mask, dtype, correct_mask):
+    c, att = word_attention(h, words, sd[p + "att.conv_context.weight"], mask, dtype, correct_mask)
+    x = torch.cat((h, c), 1)
+    r = 0
+    while (p + "residual.%d.block.0.weight" % r) in sd:
+        x = _res_block(x, sd, p + "residual.%d." % r, dtype)
+        r += 1
+    return _up_block(x, sd, p + "upsample.", dtype), att
+
+
+def g_sr_net_low(sd, LR, sent_emb, words, mask, dtype, correct_mask=False):
+    mu, logvar = O.ca_net(sd, sent_emb, "ca_net.")
+    imgs, atts = [], []
+    h = _stem(LR, sd, "h_net1.im2f.", dtype)
+    for k in (1, 2, 3):
+        h, a = _stage(sd, "h_net%d." % k, h, words, mask, dtype, correct_mask)
+        imgs.append(F.conv2d(h, rnd(sd["img_net%d.img.0.weight" % k], dtype), None, 1, 1))
+        atts.append(a)
+    return imgs, atts, mu, logvar
+
+
+def netg_highweight(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr"):
+    x = LRb if low == "lrblur" else (LR - LRb if low == "lr-lrblur" else LR)
+    out = _stem(x, sd, "convin.", dtype)
+    r = 0
+    while ("residual.%d.block.0.weight" % r) in sd:
+        out = _res_block(out, sd, "residual.%d." % r, dtype)
+        r += 1
+    w5 = rnd(sd["conv_output.0.weight"], dtype)
+
+    def head(o, sr):
+        return torch.tanh(F.conv2d(o, w5, None, 1, 2)) + 0.5 * sr
+
+    def nosum(x, p):
+        s0, t0 = _fold(sd, p + "1.")
+        s1, t1 = _fold(sd, p + "4.")
+        y = conv_block(x, sd[p + "0.weight"], s0, t0, dtype, glu=True)
+        return conv_block(y, sd[p + "3.weight"], s1, t1, dtype)
+
+    out = _up_block(out, sd, "upscale2x.", dtype)
+    ims2 = head(out, SRb[0])
+    out = _up_block(nosum(out, "residual24."), sd, "upscale4x.", dtype)
+    ims4 = head(out, SRb[1])
+    out = _up_block(nosum(out, "residual48."), sd, "upscale8x.", dtype)
+    return [ims2, ims4, head(out, SRb[2])]
+
+
+def sr_forward(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype, low="lr", correct_mask=False):
+    """`oracle.tgsr_oracle.sr_forward` with the lp path's rounding points."""
+    words, sent = O.rnn_encoder(sd_E, captions, cap_lens)
+    mask = (captions == 0)[:, :words.shape[2]]
+    imgs, atts, mu, logvar = g_sr_net_low(sd_GL, LR, sent, words, mask, dtype, correct_mask)
+    fine = netg_highweight(sd_GH, LR, imgs, LRb, dtype, low)
+    return {"words_emb": words, "sent_emb": sent, "mask": mask, "fake": imgs, "att": atts, "mu": mu, "logvar": logvar,
+            "fine": fine}
+
+
+def psnr(a: Tensor, b: Tensor, peak: float = 2.0) -> float:
+    """10 log10(peak^2 / MSE); peak 2.0 = the [-1, 1] range images are normalised to (datasets.py:286-288)."""
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * torch.log10(torch.tensor(peak * peak / mse)).item()

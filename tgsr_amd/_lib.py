@@ -14,6 +14,7 @@ ABI_VERSION = 1
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 EPI_AFFINE, EPI_AFFINE_GLU = 0, 1
 ACT_NONE, ACT_TANH_AXPY = 0, 1
+DT_BF16, DT_F16 = 1, 2
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -65,6 +66,12 @@ SIGNATURES = {
     "tgsr_word_attention_bwd": (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "tgsr_conv_to3_bwd_ws_elems": (_i64, [_i, _i, _i, _i, _i]),
     "tgsr_conv_to3_bwd": (_i, [_vp, _vp, _vp, _f, _vp, _i64, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    # reduced-precision inference path (lp images: zero-bordered channels-last bf16 / f16)
+    "tgsr_lp_from_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "tgsr_lp_to_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "tgsr_lp_packed_conv3x3_elems": (_i64, [_i, _i]),
+    "tgsr_lp_pack_conv3x3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
+    "tgsr_lp_conv3x3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,368 @@
+// Reduced-precision fused 3x3 convolution for the inference path (BASELINE.json configs[4]: "MFMA bf16 ... fused conv"):
+// conv3x3 (stride 1, zero pad 1, no bias) [+ nearest x2 in front] + BatchNorm(eval) affine + GLU | + residual, on
+// v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation.  Replaces the same reference blocks as tgsr_conv3x3_fwd:
+// ResBlock.block util.py:110-130, upBlock util.py:74-80, residual24/48 model.py:229-232.
+//
+// Layout: activations are zero-bordered channels-last images [B][H+2][W+2][cpitch] of 2-byte elements
+// (tgsr_lp_common.h).  Implicit GEMM D[cout][pixel] = sum_k W[cout][k] X[k][pixel], k = (tap, cin):
+//   MFMA A = weights: lane l holds cout l&31, the 8 input channels 8(l>>5).. of a 16-channel k-step of one tap;
+//   MFMA B = input  : lane l holds pixel l&31 (32 consecutive columns of one row, shifted by the tap), same 8 channels;
+//   D: lane = pixel, registers = 16 of the 32 couts (4 runs of 4 consecutive couts) -> 8-byte channels-last stores, and
+//      the GLU pair (c, c + Cout/2) sits in the same lane/register of two accumulators.
+// Workgroup = 4 waves = TR rows x 32 columns of outputs x ALL Cout; a wave owns TR/4 rows.
+//   input tile  [(TR+2) x 34 pixels][CIN] in LDS, fetched ONCE by LDS-DMA with the 16-byte slots of a pixel XOR-swizzled
+//               through the per-lane SOURCE address (the LDS side of a DMA is linear), so that the B-fragment
+//               ds_read_b128 of 32 neighbouring pixels is bank-conflict free (checked by simulation: 4 LDS cycles);
+//               with `UP` the source address is the low-resolution pixel (y >> 1, x >> 1): the up-sampled tensor of
+//               upBlock never exists;
+//   weights     streamed through LDS in chunks of (one kernel row = 3 taps) x 16 input channels x Cout, packed on the
+//               host side in exactly fragment order (a chunk is a linear copy, an A fragment a linear 1-KiB read),
+//               double buffered: chunk c+1 is in flight while chunk c feeds 3 * (Cout/32) * (TR/4) MFMAs per wave;
+//               one barrier per chunk.
+// LDS <= 67.5 KB (CIN 64, Cout 128, TR 8) -> two workgroups per CU; accumulators <= 128 registers.
+#include "tgsr_lp_common.h"
+
+namespace tgsr {
+
+struct LpConvArgs {
+  const char* x;       // input, element [b][0][0][0] of the padded image
+  int xcp;             // input channel pitch (elements)
+  int B, H, W;         // OUTPUT spatial size
+  int Hi, Wi;          // input spatial size (H, W or H/2, W/2)
+  const char* wpack;
+  const float* scale;
+  const float* shift;
+  const char* res;
+  int rcp, rco;
+  char* out;
+  int ocp, oco;
+  int tiles_x, tiles_y;
+};
+
+constexpr int kEpiAffine = 0, kEpiGlu = 1, kEpiRes = 2;
+
+template <int CIN>
+__device__ __forceinline__ int lp_swz(int c) {
+  return CIN == 64 ? (c >> 1) & 7 : (c >> 2) & 3;
+}
+
+template <int COUT, int TR>
+constexpr int lp_conv_occ() {
+  return (COUT / 32) * (TR / 4) * 16 >= 64 ? 2 : 4;
+}
+
+template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
+__global__ __launch_bounds__(256, (lp_conv_occ<COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
+  constexpr int NCB = COUT / 32, RW = TR / 4, TC = 34, NPIX = (TR + 2) * TC;
+  constexpr int PB = CIN * 2, NSL = CIN / 8;
+  constexpr int TILE_SLOTS = NPIX * NSL, TILE_INSTR = (TILE_SLOTS + 63) / 64, TILE_BYTES = TILE_INSTR * 1024;
+  constexpr int CHUNK_INSTR = 3 * NCB, CHUNK_BYTES = CHUNK_INSTR * 1024;
+  constexpr int NK16 = CIN / 16, NCH = 3 * NK16;
+  __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + 2 * CHUNK_BYTES + COUT * 8];
+  char* tile = smem;
+  char* wbuf = smem + TILE_BYTES;
+  float* aff = reinterpret_cast<float*>(smem + TILE_BYTES + 2 * CHUNK_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, c0 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int y0 = ty * TR, x0 = tx * 32;                         // output origin (unpadded coordinates)
+
+  // ---- input tile: all lanes of the 4 waves copy 16-byte slots; slot S of the tile = pixel S / NSL, physical slot
+  // S % NSL holding the pixel's logical slot (S % NSL) ^ swz(column)
+  {
+    const int64_t img = (int64_t)(a.Hi + 2) * (a.Wi + 2) * a.xcp * 2;
+    const char* xb = a.x + (int64_t)b * img;
+    const int64_t rowb = (int64_t)(a.Wi + 2) * a.xcp * 2;
+#pragma unroll
+    for (int k = 0; k < (TILE_INSTR + 3) / 4; ++k) {
+      const int ins = wave + 4 * k;
+      if (ins < TILE_INSTR) {                                   // wave-uniform
+        const int S = ins * 64 + lane;
+        int pix = S / NSL;
+        const int ps = S % NSL;
+        if (pix >= NPIX) pix = 0;                               // tail lanes of the last piece: any valid address
+        const int r = pix / TC, c = pix - r * TC;
+        const int ls = ps ^ lp_swz<CIN>(c);
+        const int sy = UP ? (y0 + 1 + r) >> 1 : y0 + r;         // padded source coordinates
+        const int sx = UP ? (x0 + 1 + c) >> 1 : x0 + c;
+        lds_dma16(xb + sy * rowb + (int64_t)sx * (a.xcp * 2) + ls * 16, tile + ins * 1024);
+      }
+    }
+  }
+  auto issue_w = [&](int ch, int buf) {
+    const char* src = a.wpack + (int64_t)ch * CHUNK_BYTES + lane * 16;
+#pragma unroll
+    for (int k = 0; k < (CHUNK_INSTR + 3) / 4; ++k) {
+      const int ins = wave + 4 * k;
+      if (ins < CHUNK_INSTR) lds_dma16(src + ins * 1024, wbuf + buf * CHUNK_BYTES + ins * 1024);
+    }
+  };
+  issue_w(0, 0);
+  if (tid < COUT) {
+    aff[tid] = a.scale ? a.scale[tid] : 1.f;
+    aff[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
+  }
+
+  f32x16v acc[NCB][RW];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int pr = 0; pr < RW; ++pr)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][pr][i] = 0.f;
+
+  // per-lane B-fragment bases: pixel (row wave*RW, column c0 + dx), slot (k16*2 + h) ^ swz = (2 k16) ^ (h ^ swz)
+  int bbase[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+    bbase[dx] = ((wave * RW) * TC + c0 + dx) * PB + ((h ^ lp_swz<CIN>(c0 + dx)) << 4);
+
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    // my pieces of chunk ch (and, first time, of the input tile) have landed; after the barrier everybody's have, and
+    // everybody is done reading the other weight buffer (chunk ch-1)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + 1 < NCH) issue_w(ch + 1, (ch + 1) & 1);
+    const int dy = ch / NK16, k16 = ch % NK16;
+    const char* wb = wbuf + (ch & 1) * CHUNK_BYTES + lane * 16;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      u32x4 af[NCB], bf[RW];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) af[cb] = *reinterpret_cast<const u32x4*>(wb + (dx * NCB + cb) * 1024);
+#pragma unroll
+      for (int pr = 0; pr < RW; ++pr)
+        bf[pr] = *reinterpret_cast<const u32x4*>(tile + (bbase[dx] ^ (k16 << 5)) + (pr + dy) * TC * PB);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int pr = 0; pr < RW; ++pr) acc[cb][pr] = LP<T>::mfma32(af[cb], bf[pr], acc[cb][pr]);
+    }
+  }
+
+  // ---- epilogue: affine (+ GLU | + residual), pack to 2-byte elements, 8-byte channels-last stores
+  constexpr int NOB = EPI == kEpiGlu ? NCB / 2 : NCB;
+  const int64_t orow = (int64_t)(a.W + 2) * a.ocp * 2;
+  char* ob = a.out + (int64_t)b * (a.H + 2) * orow;
+  const int64_t rrow = (int64_t)(a.W + 2) * a.rcp * 2;
+  const char* rb = EPI == kEpiRes ? a.res + (int64_t)b * (a.H + 2) * rrow : nullptr;
+#pragma unroll
+  for (int pr = 0; pr < RW; ++pr) {
+    const int y = y0 + wave * RW + pr + 1, x = x0 + c0 + 1;      // padded coordinates
+    char* op = ob + y * orow + (int64_t)x * (a.ocp * 2) + a.oco * 2;
+    const char* rp = EPI == kEpiRes ? rb + y * rrow + (int64_t)x * (a.rcp * 2) + a.rco * 2 : nullptr;
+#pragma unroll
+    for (int cb = 0; cb < NOB; ++cb) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ch0 = cb * 32 + 8 * rg + 4 * h;
+        const f32x4w s = *reinterpret_cast<const f32x4w*>(aff + ch0);
+        const f32x4w sh = *reinterpret_cast<const f32x4w*>(aff + COUT + ch0);
+        float o[4];
+        if (EPI == kEpiGlu) {
+          const f32x4w gs = *reinterpret_cast<const f32x4w*>(aff + COUT / 2 + ch0);
+          const f32x4w gsh = *reinterpret_cast<const f32x4w*>(aff + COUT + COUT / 2 + ch0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float v = acc[cb][pr][4 * rg + q] * s[q] + sh[q];
+            const float g = acc[cb + NCB / 2][pr][4 * rg + q] * gs[q] + gsh[q];
+            o[q] = v * sigmoidf_fast(g);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = acc[cb][pr][4 * rg + q] * s[q] + sh[q];
+          if (EPI == kEpiRes) {
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(rp + ch0 * 2);
+            o[0] += LP<T>::lo(rv[0]);
+            o[1] += LP<T>::hi(rv[0]);
+            o[2] += LP<T>::lo(rv[1]);
+            o[3] += LP<T>::hi(rv[1]);
+          }
+        }
+        u32x2 pk;
+        pk[0] = LP<T>::pack2(o[0], o[1]);
+        pk[1] = LP<T>::pack2(o[2], o[3]);
+        *reinterpret_cast<u32x2*>(op + ch0 * 2) = pk;
+      }
+    }
+  }
+}
+
+// wpack[chunk = dy * (Cin/16) + k16][dx][cb][lane 64][8] <- w[Cout][Cin][3][3]:
+// element j of lane l = w[cb*32 + (l & 31)][k16*16 + 8 (l >> 5) + j][dy][dx], rounded to T.
+template <class T>
+__global__ void lp_pack_conv3x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout, int Cin,
+                                       int64_t total) {
+  const int ncb = Cout / 32, nk16 = Cin / 16;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), l = (int)((i >> 3) & 63);
+    int64_t t = i >> 9;
+    const int cb = (int)(t % ncb);
+    t /= ncb;
+    const int dx = (int)(t % 3);
+    t /= 3;
+    const int k16 = (int)(t % nk16);
+    const int dy = (int)(t / nk16);
+    const int co = cb * 32 + (l & 31), ci = k16 * 16 + 8 * (l >> 5) + j;
+    wp[i] = LP<T>::one(w[((int64_t)co * Cin + ci) * 9 + dy * 3 + dx]);
+  }
+}
+
+// fp32 NCHW [B][C][H][W] -> zero-bordered channels-last T [B][H+2][W+2][cpitch] at channel offset coff (interior only)
+template <class T>
+__global__ void lp_from_nchw_kernel(const float* __restrict__ x, unsigned short* __restrict__ out, int B, int C, int H,
+                                    int W, int cpitch, int coff) {
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    int64_t t = i / C;
+    const int xx = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    out[(((int64_t)b * (H + 2) + y + 1) * (W + 2) + xx + 1) * cpitch + coff + c] =
+        LP<T>::one(x[(((int64_t)b * C + c) * H + y) * W + xx]);
+  }
+}
+
+template <class T>
+__global__ void lp_to_nchw_kernel(const unsigned short* __restrict__ x, float* __restrict__ out, int B, int C, int H,
+                                  int W, int cpitch, int coff) {
+  const int64_t total = (int64_t)B * C * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W);
+    int64_t t = i / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    const unsigned v = x[(((int64_t)b * (H + 2) + y + 1) * (W + 2) + xx + 1) * cpitch + coff + c];
+    out[i] = LP<T>::lo(v);
+  }
+}
+
+template <class T, int CIN, int COUT, int EPI, bool UP>
+static int launch_lp_conv_tr(const LpConvArgs& a0, hipStream_t s) {
+  LpConvArgs a = a0;
+  // rows per workgroup: 8 when that still gives >= 2 workgroups per CU, else 4
+  const bool big = (int64_t)a.B * (a.H / 8) * (a.W / 32) >= 512 && a.H % 8 == 0;
+  a.tiles_x = a.W / 32;
+  if (big) {
+    a.tiles_y = a.H / 8;
+    hipLaunchKernelGGL((lp_conv3x3_kernel<T, CIN, COUT, EPI, UP, 8>), dim3(a.B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+  } else {
+    a.tiles_y = a.H / 4;
+    hipLaunchKernelGGL((lp_conv3x3_kernel<T, CIN, COUT, EPI, UP, 4>), dim3(a.B * a.tiles_x * a.tiles_y), dim3(256), 0, s, a);
+  }
+  return note_launch(hipGetLastError(), "lp_conv3x3_kernel");
+}
+
+template <class T, int CIN, int COUT>
+static int launch_lp_conv_epi(const LpConvArgs& a, int epi, bool up, hipStream_t s) {
+  if (epi == kEpiGlu) {
+    if constexpr (COUT >= 64) {
+      return up ? launch_lp_conv_tr<T, CIN, COUT, kEpiGlu, true>(a, s) : launch_lp_conv_tr<T, CIN, COUT, kEpiGlu, false>(a, s);
+    } else {
+      return TGSR_EUNSUPPORTED;
+    }
+  }
+  if (up) return TGSR_EUNSUPPORTED;          // the reference only up-samples in front of a GLU block (util.py:74-80)
+  if (epi == kEpiRes) return launch_lp_conv_tr<T, CIN, COUT, kEpiRes, false>(a, s);
+  return launch_lp_conv_tr<T, CIN, COUT, kEpiAffine, false>(a, s);
+}
+
+template <class T>
+static int launch_lp_conv(const LpConvArgs& a, int Cin, int Cout, int epi, bool up, hipStream_t s) {
+  if (Cin == 64 && Cout == 128) return launch_lp_conv_epi<T, 64, 128>(a, epi, up, s);
+  if (Cin == 64 && Cout == 64) return launch_lp_conv_epi<T, 64, 64>(a, epi, up, s);
+  if (Cin == 32 && Cout == 64) return launch_lp_conv_epi<T, 32, 64>(a, epi, up, s);
+  if (Cin == 32 && Cout == 32) return launch_lp_conv_epi<T, 32, 32>(a, epi, up, s);
+  return TGSR_EUNSUPPORTED;
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int64_t tgsr_lp_packed_conv3x3_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9; }
+
+extern "C" int tgsr_lp_pack_conv3x3_weight(int dtype, const float* w, void* wpack, int Cout, int Cin, void* stream) {
+  if (!w || !wpack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
+  if (Cout % 32 != 0 || Cin % 16 != 0) return TGSR_EUNSUPPORTED;
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  unsigned short* o = static_cast<unsigned short*>(wpack);
+  if (dtype == TGSR_DT_BF16)
+    hipLaunchKernelGGL(lp_pack_conv3x3_kernel<BF16>, dim3(blocks), dim3(256), 0, as_stream(stream), w, o, Cout, Cin, total);
+  else if (dtype == TGSR_DT_F16)
+    hipLaunchKernelGGL(lp_pack_conv3x3_kernel<F16>, dim3(blocks), dim3(256), 0, as_stream(stream), w, o, Cout, Cin, total);
+  else
+    return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_pack_conv3x3_kernel");
+}
+
+extern "C" int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                                   int Cout, const float* scale, const float* shift, const void* residual, int res_cpitch,
+                                   int res_coff, void* out, int out_cpitch, int out_coff, int epilogue, int upsample,
+                                   void* stream) {
+  if (!x || !wpack || !out || B < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
+  if (epilogue != TGSR_EPI_AFFINE && epilogue != TGSR_EPI_AFFINE_GLU) return TGSR_EINVAL;
+  if (epilogue == TGSR_EPI_AFFINE_GLU && residual) return TGSR_EINVAL;
+  if (dtype != TGSR_DT_BF16 && dtype != TGSR_DT_F16) return TGSR_EINVAL;
+  const int co = epilogue == TGSR_EPI_AFFINE_GLU ? Cout / 2 : Cout;
+  if (W % 32 != 0 || H % 4 != 0 || (upsample && ((H | W) & 1))) return TGSR_EUNSUPPORTED;
+  if (x_cpitch < Cin || x_cpitch % 8 != 0 || out_cpitch % 4 != 0 || out_coff % 4 != 0 || out_coff + co > out_cpitch)
+    return TGSR_EUNSUPPORTED;
+  if (residual && (res_cpitch % 4 != 0 || res_coff % 4 != 0 || res_coff + co > res_cpitch)) return TGSR_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wpack) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(residual) & 7))
+    return TGSR_EUNSUPPORTED;
+  if ((int64_t)(H + 2) * (W + 2) * (x_cpitch > out_cpitch ? x_cpitch : out_cpitch) * 2 >= (1ll << 31)) return TGSR_EUNSUPPORTED;
+  LpConvArgs a;
+  a.x = static_cast<const char*>(x); a.xcp = x_cpitch; a.B = B; a.H = H; a.W = W;
+  a.Hi = upsample ? H / 2 : H; a.Wi = upsample ? W / 2 : W;
+  a.wpack = static_cast<const char*>(wpack); a.scale = scale; a.shift = shift;
+  a.res = static_cast<const char*>(residual); a.rcp = res_cpitch; a.rco = res_coff;
+  a.out = static_cast<char*>(out); a.ocp = out_cpitch; a.oco = out_coff;
+  a.tiles_x = a.tiles_y = 0;
+  const int epi = epilogue == TGSR_EPI_AFFINE_GLU ? kEpiGlu : (residual ? kEpiRes : kEpiAffine);
+  if (dtype == TGSR_DT_BF16) return launch_lp_conv<BF16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
+  return launch_lp_conv<F16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
+}
+
+extern "C" int tgsr_lp_from_nchw(int dtype, const float* x, void* out, int B, int C, int H, int W, int cpitch, int coff,
+                                 void* stream) {
+  if (!x || !out || B < 1 || C < 1 || H < 1 || W < 1 || coff < 0 || coff + C > cpitch) return TGSR_EINVAL;
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  unsigned short* o = static_cast<unsigned short*>(out);
+  if (dtype == TGSR_DT_BF16)
+    hipLaunchKernelGGL(lp_from_nchw_kernel<BF16>, dim3(blocks), dim3(256), 0, as_stream(stream), x, o, B, C, H, W, cpitch, coff);
+  else if (dtype == TGSR_DT_F16)
+    hipLaunchKernelGGL(lp_from_nchw_kernel<F16>, dim3(blocks), dim3(256), 0, as_stream(stream), x, o, B, C, H, W, cpitch, coff);
+  else
+    return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_from_nchw_kernel");
+}
+
+extern "C" int tgsr_lp_to_nchw(int dtype, const void* x, float* out, int B, int C, int H, int W, int cpitch, int coff,
+                               void* stream) {
+  if (!x || !out || B < 1 || C < 1 || H < 1 || W < 1 || coff < 0 || coff + C > cpitch) return TGSR_EINVAL;
+  const int64_t total = (int64_t)B * C * H * W;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  const unsigned short* i = static_cast<const unsigned short*>(x);
+  if (dtype == TGSR_DT_BF16)
+    hipLaunchKernelGGL(lp_to_nchw_kernel<BF16>, dim3(blocks), dim3(256), 0, as_stream(stream), i, out, B, C, H, W, cpitch, coff);
+  else if (dtype == TGSR_DT_F16)
+    hipLaunchKernelGGL(lp_to_nchw_kernel<F16>, dim3(blocks), dim3(256), 0, as_stream(stream), i, out, B, C, H, W, cpitch, coff);
+  else
+    return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_to_nchw_kernel");
+}

@@ -1,0 +1,111 @@
+"""Reduced-precision (bf16 / f16 storage, fp32 accumulate) inference ops over the C ABI's `tgsr_lp_*` entry points.
+
+BASELINE.json configs[4] ("bf16 ... MFMA bf16 attention + fused conv, hipGraph-captured step").  Activations are
+"lp images": zero-bordered channels-last tensors [B, H+2, W+2, cpitch] of torch.bfloat16 / torch.float16 (layout and
+border rule: include/tgsr_hip.h, tgsr_lp_common.h).  As in `tgsr_amd.ops`, nothing here computes on the CPU or through
+eager torch arithmetic: torch allocates (zeroed) buffers and supplies the stream.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import TgsrError, check
+from .ops import _need_hip, _p, _stream
+
+DT = {torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16, "bf16": _lib.DT_BF16, "f16": _lib.DT_F16}
+TORCH_DT = {"bf16": torch.bfloat16, "f16": torch.float16, torch.bfloat16: torch.bfloat16, torch.float16: torch.float16}
+
+
+def torch_dtype(dtype):
+    try:
+        return TORCH_DT[dtype]
+    except KeyError:
+        raise TgsrError("reduced-precision dtype must be 'bf16' or 'f16', got %r" % (dtype,))
+
+
+def new_image(B: int, H: int, W: int, cpitch: int, dtype, device) -> torch.Tensor:
+    """A zeroed lp image [B, H+2, W+2, cpitch]; kernels only ever write its interior, so the border stays zero."""
+    return torch.zeros(B, H + 2, W + 2, cpitch, dtype=torch_dtype(dtype), device=device)
+
+
+def _img(t: torch.Tensor, name: str):
+    if t.dim() != 4 or t.dtype not in (torch.bfloat16, torch.float16) or not t.is_contiguous():
+        raise TgsrError("%s must be a contiguous lp image [B,H+2,W+2,C] of bf16/f16, got %s %s" %
+                        (name, tuple(t.shape), t.dtype))
+    return t.shape[0], t.shape[1] - 2, t.shape[2] - 2, t.shape[3]
+
+
+def from_nchw(x: torch.Tensor, dtype=None, cpitch: Optional[int] = None, coff: int = 0,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 NCHW -> channels [coff, coff+C) of an lp image (a new zeroed one unless `out` is given)."""
+    _need_hip(x, out)
+    x = x.contiguous()
+    if x.dtype != torch.float32:
+        raise TgsrError("from_nchw: x must be float32")
+    B, C, H, W = x.shape
+    if out is None:
+        out = new_image(B, H, W, cpitch or C, dtype, x.device)
+    ob, oh, ow, ocp = _img(out, "out")
+    if (ob, oh, ow) != (B, H, W):
+        raise TgsrError("from_nchw: out %s does not match x %s" % (tuple(out.shape), tuple(x.shape)))
+    check(_lib.lib().tgsr_lp_from_nchw(DT[out.dtype], _p(x), _p(out), B, C, H, W, ocp, coff, _stream()),
+          "tgsr_lp_from_nchw")
+    return out
+
+
+def to_nchw(img: torch.Tensor, C: Optional[int] = None, coff: int = 0) -> torch.Tensor:
+    """Channels [coff, coff+C) of an lp image -> fp32 NCHW."""
+    _need_hip(img)
+    B, H, W, cp = _img(img, "img")
+    C = cp - coff if C is None else C
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=img.device)
+    check(_lib.lib().tgsr_lp_to_nchw(DT[img.dtype], _p(img), _p(out), B, C, H, W, cp, coff, _stream()),
+          "tgsr_lp_to_nchw")
+    return out
+
+
+def pack_conv3x3_weight(w: torch.Tensor, dtype) -> torch.Tensor:
+    """[Cout,Cin,3,3] fp32 -> MFMA fragment order, rounded to `dtype` (tgsr_lp_pack_conv3x3_weight)."""
+    _need_hip(w)
+    w = w.detach().contiguous()
+    if w.dtype != torch.float32 or w.dim() != 4 or w.shape[2:] != (3, 3):
+        raise TgsrError("pack_conv3x3_weight: weight %s %s" % (tuple(w.shape), w.dtype))
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = torch.empty(L.tgsr_lp_packed_conv3x3_elems(Cout, Cin), dtype=torch_dtype(dtype), device=w.device)
+    check(L.tgsr_lp_pack_conv3x3_weight(DT[out.dtype], _p(w), _p(out), Cout, Cin, _stream()),
+          "tgsr_lp_pack_conv3x3_weight")
+    return out
+
+
+def conv3x3(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, shift, glu: bool = False,
+            upsample: bool = False, residual: Optional[torch.Tensor] = None, res_coff: int = 0,
+            out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cpitch: Optional[int] = None) -> torch.Tensor:
+    """conv3x3 [+ nearest x2 in front] + affine + (GLU | + residual) on lp images in one launch.  Reads channels
+    [0, cin) of `x`; writes channels [out_coff, out_coff + cout') of `out` (a new zeroed image unless given)."""
+    _need_hip(x, wpack, scale, shift, residual, out)
+    B, Hi, Wi, xcp = _img(x, "x")
+    H, W = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
+    co = cout // 2 if glu else cout
+    if out is None:
+        out = new_image(B, H, W, out_cpitch or (out_coff + co), x.dtype, x.device)
+    ob, oh, ow, ocp = _img(out, "out")
+    if (ob, oh, ow) != (B, H, W) or out.dtype != x.dtype or wpack.dtype != x.dtype:
+        raise TgsrError("lp.conv3x3: out %s / dtypes do not match" % (tuple(out.shape),))
+    rcp = 0
+    if residual is not None:
+        rb, rh, rw, rcp = _img(residual, "residual")
+        if (rb, rh, rw) != (B, H, W) or residual.dtype != x.dtype:
+            raise TgsrError("lp.conv3x3: residual %s" % (tuple(residual.shape),))
+    from . import ops
+    e0 = ops._ev() if ops.profile is not None else None
+    rc = _lib.lib().tgsr_lp_conv3x3_fwd(DT[x.dtype], _p(x), xcp, B, cin, H, W, _p(wpack), cout, _p(scale), _p(shift),
+                                        _p(residual), rcp, res_coff, _p(out), ocp, out_coff,
+                                        _lib.EPI_AFFINE_GLU if glu else _lib.EPI_AFFINE, 1 if upsample else 0, _stream())
+    check(rc, "tgsr_lp_conv3x3_fwd")
+    if ops.profile is not None:
+        nbytes = 2 * (B * cin * Hi * Wi + B * co * H * W * (2 if residual is not None else 1) + cout * cin * 9)
+        ops.profile.append(("lp_conv3x3_kernel", 2.0 * B * H * W * cout * cin * 9, nbytes, e0, ops._ev()))
+    return out

@@ -6,13 +6,29 @@ tuples and state_dict keys (GL 104 tensors, GH 121 tensors - tests/golden/ckpt_m
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Variable      # re-exported: the reference's model.py does `from util import *` (model.py:3,
+                                         # util.py:1-11) and its callers import `Variable, torch, cfg` FROM `model`
+                                         # (trainer_objective.py:8)
 
 from . import ops
 from .miscc.config import cfg
-from .util import (CA_NET, CNN_ENCODER, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G, RNN_ENCODER, ResBlock,
-                   _ConvBnGlu, _ResidualNoSum, conv3x3, conv5x5, upBlock)
+from .util import (CA_NET, CNN_ENCODER, GET_IMAGE_G, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G, RNN_ENCODER,
+                   ResBlock, Block3x3_relu, _ConvBnGlu, _ResidualNoSum, conv1x1, conv3x3, conv5x5, upBlock)
 
-__all__ = ["G_SR_NET_low", "NetG_highweight", "RNN_ENCODER", "CNN_ENCODER", "cfg", "torch"]
+__all__ = ["G_SR_NET_low", "G_SR_NET_low_stage1", "NetG_highweight", "RNN_ENCODER", "CNN_ENCODER", "CA_NET",
+           "INIT_STAGE_GImgup", "NEXT_STAGE_G", "GET_IMAGE_G", "GET_IMAGE_G_noAct", "ResBlock", "GLU", "upBlock",
+           "Block3x3_relu", "conv1x1", "conv3x3", "conv5x5", "Variable", "cfg", "torch", "nn", "F"]
+
+
+class G_SR_NET_low_stage1(nn.Module):
+    """model.py:81-130.  Importable because trainer_objective.py:8 imports the name; never constructed on the shipped
+    path (`stage1 = False` is hard-coded, trainer_objective.py:56) and not built here: constructing it raises."""
+
+    def __init__(self, *args, **kwargs):
+        super(G_SR_NET_low_stage1, self).__init__()
+        raise NotImplementedError("G_SR_NET_low_stage1 is dead code in the reference (stage1=False, "
+                                  "trainer_objective.py:56); tgsr_amd builds G_SR_NET_low")
 
 
 class G_SR_NET_low(nn.Module):

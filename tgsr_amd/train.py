@@ -14,26 +14,14 @@ Every forward and backward kernel of the generators is HIP (tgsr_amd.autograd); 
 `DAMSMTrainer` is the counterpart of pretrain_DAMSM.py (text encoder + CNN_ENCODER heads on the matching losses).
 Data parallel: gradients live in one flat bucket, one all-reduce per step (tgsr_amd.parallel.FlatGradBucket).
 """
-from copy import deepcopy
-
 import torch
 
 from .miscc import losses
 from .miscc.config import cfg
+from .miscc.utils import copy_G_params, load_params  # noqa: F401  (miscc/utils.py:467-474: the generator EMA helpers)
 from .model import CNN_ENCODER, G_SR_NET_low, NetG_highweight, RNN_ENCODER
 from .parallel import FlatGradBucket
 from .trainer import caption_mask
-
-
-def copy_G_params(model):
-    """miscc/utils.py:472-474."""
-    return deepcopy(list(p.data for p in model.parameters()))
-
-
-def load_params(model, new_param):
-    """miscc/utils.py:467-469."""
-    for p, new_p in zip(model.parameters(), new_param):
-        p.data.copy_(new_p)
 
 
 def prepare_labels(batch_size, device):
