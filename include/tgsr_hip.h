@@ -367,6 +367,36 @@ int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, 
                         int res_coff, void* out, int out_cpitch, int out_coff, int epilogue, int upsample,
                         void* stream);
 
+/*
+ * The two 3-channel stems on the fp32 LR image: conv3x3 3 -> 2C + BatchNorm(eval) affine + GLU, written as C channels
+ * of an lp image (im2f util.py:741-744, convin model.py:228).  x [B][3][H][W] fp32 dense, w [2C][3][3][3] fp32 (torch
+ * layout, NOT rounded: 27 MACs per output run on the VALU), scale / shift [2C].  C % 8 == 0.
+ */
+int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
+                     const float* shift, void* out, int out_cpitch, int out_coff, void* stream);
+
+/*
+ * The image heads on an lp image (tgsr_conv_to3_fwd's reference sites: GET_IMAGE_G_noAct util.py:913-915; conv_output
+ * + `one*. + a*SRb` model.py:224, 280/288/297).  w [3][32][K][K] fp32 -> wpack (K*K*512 2-byte elements, the 3 output
+ * channels padded to a 16-row MFMA fragment); x = channels [0, 32) of an lp image; addend / out fp32 [B][3][H][W] dense.
+ * Cin == 32, K in {3, 5}, W % 32 == 0, H % 8 == 0.
+ */
+int tgsr_lp_pack_to3_weight(int dtype, const float* w, void* wpack, int Cin, int K, void* stream);
+int tgsr_lp_conv_to3_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack, int K,
+                         int act, const float* addend, float alpha, float* out, void* stream);
+
+/*
+ * GlobalAttentionGeneral.forward (GlobalAttention.py:87-130) on lp images: h = channels [0, idf) of an lp image,
+ * src = the fp32 word projection [B][idf][32] of tgsr_word_project_fwd (rounded to `dtype` inside), mask / mask_mode as
+ * in tgsr_word_attention_fwd (0 = the reference's mask.repeat row order, GlobalAttention.py:109-116; 1 = per sample).
+ * Writes c_code (rounded) to channels [c_coff, c_coff + idf) of c_img - normally the same image h lives in, which is
+ * the reference's torch.cat((h_code, c_code), 1) - and the fp32 softmax to attn [B][T][H*W] (NULL = not needed).
+ * idf == 32, T <= 32, W % 32 == 0.
+ */
+int tgsr_lp_word_attention_fwd(int dtype, const void* h, int h_cpitch, const float* src, const uint8_t* mask,
+                               int mask_mode, int B, int idf, int T, int H, int W, void* c_img, int c_cpitch, int c_coff,
+                               float* attn, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

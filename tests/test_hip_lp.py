@@ -90,3 +90,140 @@ def test_lp_conv3x3(case, name, td, ulp):
     assert float(out[..., :32].abs().max()) == 0, "channels outside the slice were written"
     assert float(out[:, 0].abs().max()) == 0 and float(out[:, -1].abs().max()) == 0, "border written"
     assert float(out[:, :, 0].abs().max()) == 0 and float(out[:, :, -1].abs().max()) == 0, "border written"
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+def test_lp_stem(name, td, ulp):
+    from tgsr_amd import lp
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 3, 32, 12, 32
+    x = torch.rand(B, 3, H, W, generator=g) * 2 - 1
+    w = torch.randn(2 * C, 3, 3, 3, generator=g) / 5.0
+    scale, shift = 1 + 0.1 * torch.randn(2 * C, generator=g), 0.1 * torch.randn(2 * C, generator=g)
+    ref = OL.conv_block(x, w, scale, shift, td, glu=True, round_w=False)
+    out = lp.new_image(B, H, W, 64, name, DEV)
+    lp.stem(x.to(DEV), w.to(DEV), scale.to(DEV), shift.to(DEV), out=out, out_coff=0)
+    lp_close(lp.to_nchw(out, C, 0), ref, ulp, "lp stem " + name)
+    assert float(out[..., 32:].abs().max()) == 0 and float(out[:, 0].abs().max()) == 0
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("K,act,B,H,W,cp", [(3, False, 2, 8, 32, 64), (5, True, 3, 16, 64, 32), (5, True, 1, 8, 32, 32),
+                                            (3, False, 17, 64, 64, 32)])
+def test_lp_conv_to3(K, act, B, H, W, cp, name, td, ulp):
+    import torch.nn.functional as F
+    from tgsr_amd import lp
+    g = torch.Generator().manual_seed(K * 100 + H)
+    x = OL.rnd(torch.randn(B, 32, H, W, generator=g), td)
+    w = torch.randn(3, 32, K, K, generator=g) / (K * 32 ** 0.5)
+    add = torch.randn(B, 3, H, W, generator=g) if act else None
+    ref = F.conv2d(x, OL.rnd(w, td), None, 1, K // 2)
+    if act:
+        ref = torch.tanh(ref) + 0.5 * add
+    xi = lp.from_nchw(x.to(DEV), name, cpitch=cp)
+    got = lp.conv_to3(xi, lp.pack_to3_weight(w.to(DEV), name), K, tanh_axpy=act, addend=None if add is None else add.to(DEV),
+                      alpha=0.5)
+    # fp32 outputs of a K*K*32-term sum of low-precision products accumulated in fp32: only summation order differs
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("B,H,W,T,correct", [(3, 8, 32, 7, False), (2, 32, 32, 18, False), (5, 16, 64, 12, True), (1, 4, 32, 1, False)])
+def test_lp_word_attention(B, H, W, T, correct, name, td, ulp):
+    from tgsr_amd import lp, ops
+    g = torch.Generator().manual_seed(B * 10 + T)
+    h = OL.rnd(torch.randn(B, 32, H, W, generator=g), td)
+    words = torch.randn(B, 48, T, generator=g)
+    wctx = torch.randn(32, 48, 1, 1, generator=g) / 48 ** 0.5
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    mask = torch.arange(T)[None, :] >= lens[:, None]
+    c_ref, a_ref = OL.word_attention(h, words, wctx, mask, td, correct_mask=correct)
+    img = lp.from_nchw(h.to(DEV), name, cpitch=64)
+    src = ops.word_project(words.to(DEV), [wctx.to(DEV)])[0]
+    attn = lp.word_attention(img, src, mask.to(DEV), T, correct_mask=correct)
+    # the projected words are rounded to `dtype` on both sides, from fp32 values that differ in their last bits (MFMA
+    # vs CPU summation order): an element on a rounding boundary lands one ulp apart and moves a score by
+    # ulp * |src| * |h| - a few ulp relative on the softmax
+    np.testing.assert_allclose(attn.cpu().numpy(), a_ref.numpy(), atol=2 * ulp, rtol=8 * ulp)
+    # c_code = sum_t src_T * P_T: P is rounded to `dtype` before the product, so a P that straddles a rounding boundary
+    # moves c by up to ulp * |src|: bound by 2 ulp of the largest |src| of the sample + one ulp of the value itself
+    got = lp.to_nchw(img, 32, 32).cpu()
+    smax = float(torch.einsum("ic,bct->bit", wctx.reshape(32, 48), words).abs().max())
+    assert float((got - c_ref).abs().max()) <= 2 * ulp * smax + 1e-5
+    assert torch.equal(lp.to_nchw(img, 32, 0).cpu(), h), "h channels must be untouched"
+
+
+def _pipe(cfg_face, face_weights, dtype, overlap=True):
+    from conftest import split_sd
+    from tgsr_amd.trainer import SRPipeline
+    p = SRPipeline(41, device=DEV, low="lr", overlap=overlap, dtype=dtype)
+    return p.load_state_dicts(split_sd(face_weights, "E."), split_sd(face_weights, "GL."), split_sd(face_weights, "GH."))
+
+
+@pytest.fixture()
+def cfg_face():
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    cfg_reset()
+    cfg.GAN.GF_DIM = 32
+    cfg.TEXT.EMBEDDING_DIM = 256
+    yield cfg
+    cfg_reset()
+
+
+# PSNR (peak 2.0) of the finest SR image against the fp32 oracle, shipped face checkpoint.  The CPU model of the same
+# rounding points gives bf16 45.0 dB / f16 62.3 dB (oracle/tgsr_oracle_lp.py: bf16 operands alone cost 48.3 dB, so the
+# 50 dB SURVEY.md 8c hoped for is out of reach for ANY bf16-operand implementation of this network); the kernels must
+# land within 1 dB of the model and above these floors.
+PSNR_FLOOR = {"bf16": 43.5, "f16": 60.0}
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("B", [2, 16])
+def test_lp_pipeline_full_size(B, name, td, ulp, cfg_face, face_weights):
+    from conftest import split_sd
+    sdE, sdL, sdH = (split_sd(face_weights, k) for k in ("E.", "GL.", "GH."))
+    cap, lens, LR, LRb = O.synthetic_batch(B)
+    with torch.no_grad():
+        ref32 = O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
+        model = OL.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb, td)
+    pipe = _pipe(cfg_face, face_weights, name)
+    out = pipe(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    torch.cuda.synchronize()
+    for k in ("fake", "fine"):
+        for i in range(3):
+            got = out[k][i].cpu()
+            p32, pm, pmodel = OL.psnr(got, ref32[k][i]), OL.psnr(got, model[k][i]), OL.psnr(model[k][i], ref32[k][i])
+            assert abs(p32 - pmodel) < 1.0, "%s %s[%d]: %.2f dB vs fp32, the CPU model predicts %.2f" % (name, k, i, p32, pmodel)
+            assert pm > pmodel + 3.0, "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
+    assert OL.psnr(out["fine"][2].cpu(), ref32["fine"][2]) >= PSNR_FLOOR[name]
+    for i in range(3):   # attention maps are the fp32 softmax of lp scores
+        assert OL.psnr(out["att"][i].cpu(), model["att"][i], peak=1.0) > 45.0
+    np.testing.assert_allclose(out["mu"].cpu().numpy(), ref32["mu"].numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_lp_pipeline_hipgraph_and_determinism(name, cfg_face, face_weights):
+    B = 4
+    cap, lens, LR, LRb = O.synthetic_batch(B)
+    pipe = _pipe(cfg_face, face_weights, name)
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    a = pipe(*args)
+    b = pipe(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(a["fine"][2], b["fine"][2]), "two eager runs differ"
+    serial = _pipe(cfg_face, face_weights, name, overlap=False)(*args)
+    assert torch.equal(a["fine"][2], serial["fine"][2]), "two-stream run differs from the single-stream one"
+    pipe.capture(*args)
+    g = pipe.replay()
+    torch.cuda.synchronize()
+    for k in ("fake", "fine", "att"):
+        for i in range(3):
+            assert torch.equal(g[k][i], a[k][i]), "hipGraph replay differs from eager (%s[%d])" % (k, i)
+    # new inputs through the captured step
+    cap2, lens2, LR2, LRb2 = O.synthetic_batch(B, seed=7)
+    if lens2.tolist() == lens.tolist():
+        g2 = pipe.replay(cap2.to(DEV), LR2.to(DEV), LRb2.to(DEV))
+        e2 = pipe(cap2.to(DEV), lens2.tolist(), LR2.to(DEV), LRb2.to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(g2["fine"][2], e2["fine"][2])

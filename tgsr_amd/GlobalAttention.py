@@ -23,20 +23,20 @@ class GlobalAttentionGeneral(nn.Module):
         self.conv_context = conv1x1(cdf, idf)
         self.mask = None
         self.correct_mask = correct_mask
-        self._src = None     # projection of the words for the next forward (G_SR_NET_low batches its stages' projections)
 
     def applyMask(self, mask):
         self.mask = mask  # batch x sourceL
 
-    def forward(self, input, context, out=None):
+    def forward(self, input, context, out=None, src=None):
         """input [B, idf, ih, iw], context [B, cdf, sourceL] -> (weightedContext [B, idf, ih, iw],
-        attn [B, sourceL, ih, iw])."""
+        attn [B, sourceL, ih, iw]).  `src`: this layer's word projection when the caller already has it
+        (G_SR_NET_low projects the words for its three stages in one launch, ops.word_project); an argument, not
+        module state, so the module stays re-entrant across streams."""
         if self.training:
             from .autograd import WordAttention
             if out is not None:
                 raise RuntimeError("training path does not write into channel-slice views")
             return WordAttention.apply(input, context, self.conv_context.weight, self.mask, self.correct_mask)
-        src, self._src = self._src, None
         return ops.word_attention(input, context, self.conv_context.weight, self.mask, self.correct_mask, out=out,
                                   src=src)
 

@@ -72,6 +72,10 @@ SIGNATURES = {
     "tgsr_lp_packed_conv3x3_elems": (_i64, [_i, _i]),
     "tgsr_lp_pack_conv3x3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_conv3x3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "tgsr_lp_stem_fwd": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "tgsr_lp_pack_to3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
+    "tgsr_lp_conv_to3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),
+    "tgsr_lp_word_attention_fwd": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -125,8 +125,13 @@ def conv_bn_act_train(x, conv, bn, glu=False, upsample=False, residual=None):
     out = ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                           bn.running_var if bn.track_running_stats else None, residual, glu, upsample, bn.momentum,
                           bn.eps)
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+    if bn.track_running_stats:
+        # tgsr_bn_train_fwd wrote the running statistics through raw pointers: tell autograd's version counters, which
+        # the eval-mode caches (util._FusedParams, lp_pipeline.LpExecutor) key their folded affines on
+        torch.autograd.graph.increment_version(bn.running_mean)
+        torch.autograd.graph.increment_version(bn.running_var)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
     return out
 
 
@@ -138,6 +143,8 @@ class ConvTo3(torch.autograd.Function):
         """alpha: python float, or a 1-element tensor (models16.NetG_highweight's trainable `a`, models16.py:126)."""
         ctx.alpha_is_tensor = torch.is_tensor(alpha)
         alpha_f = float(alpha.detach().item()) if ctx.alpha_is_tensor else float(alpha)
+        if addend is not None:
+            addend = addend.contiguous()     # backward hands the saved tensor's raw pointer to the kernel as dense NCHW
         out = ops.conv_to3(x, weight, tanh_axpy=tanh_axpy, addend=addend, alpha=alpha_f)
         ctx.save_for_backward(x, weight, out if tanh_axpy else None, addend)
         ctx.cfg = (tanh_axpy, alpha_f)

@@ -209,12 +209,14 @@ static int damsm_launch(DamsmArgs a, void* stream) {
   if (a.ndf % 32 != 0 || a.Tw > 32 || a.S > 320 || a.ndf > 512) return TGSR_EUNSUPPORTED;
   const size_t lds = sizeof(float) * ((size_t)a.ndf * 32 + 32 * kSP + 4 * 32 * 65 + 96);
   const int pairs = a.paired ? a.B : a.B * a.B;
-  static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in once per process
-  if (!attr_set) {
+  static bool attr_set[64] = {false};   // > 64 KB of dynamic LDS needs the opt-in once per DEVICE (a function attribute
+  int dev = 0;                          // belongs to the device's code object, not to the process)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(damsm_pair_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return note_launch(hipGetLastError(), "hipFuncSetAttribute(damsm_pair_kernel)");
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL(damsm_pair_kernel, dim3(pairs), dim3(256), lds, as_stream(stream), a);
   return note_launch(hipGetLastError(), "damsm_pair_kernel");

@@ -1,0 +1,370 @@
+// Reduced-precision inference path: the 3-channel stems, the 3-channel image heads and the word attention on lp
+// images (tgsr_lp_common.h).  BASELINE.json configs[4].
+//
+//   lp_stem_kernel      conv3x3 3 -> 2C + BN affine + GLU from the fp32 LR image (im2f util.py:741-744, convin
+//                       model.py:228): 27 MACs per output, VALU, fp32 weights; writes C channels of an lp image.
+//   lp_to3_kernel<K>    KxK conv C=32 -> 3 (+ tanh + alpha * addend) reading an lp image, writing the fp32 NCHW image
+//                       (GET_IMAGE_G_noAct util.py:913-915, conv_output + a*SRb model.py:224, 280): MFMA 16x16x32 with
+//                       the 3 output channels padded to a 16-row A fragment - one k-step = the 32 channels of a tap.
+//   lp_word_attention_kernel   GlobalAttentionGeneral.forward (GlobalAttention.py:87-130) on MFMA 32x32x16: scores,
+//                       masked softmax over words (in-lane + one lane^32 exchange) and the weighted context, with the
+//                       softmax consumed as the second MFMA's B operand straight from the accumulator registers.
+#include "tgsr_lp_common.h"
+
+namespace tgsr {
+
+// ------------------------------------------------------------------------------------------------------------ stem
+struct LpStemArgs {
+  const float* x;        // [B][3][H][W] fp32
+  const float* w;        // [2C][3][3][3] fp32 (torch layout)
+  const float* scale;    // [2C]
+  const float* shift;
+  unsigned short* out;   // lp image
+  int B, H, W, C, ocp, oco;
+};
+
+// thread = (pixel, group of 8 output channels): 8 value + 8 gate channels x 27 MACs, one 16-byte store
+template <class T>
+__global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
+  const int ng = a.C / 8;
+  const int64_t total = (int64_t)a.B * a.H * a.W * ng;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int g = (int)(i % ng);
+  int64_t t = i / ng;
+  const int x = (int)(t % a.W);
+  t /= a.W;
+  const int y = (int)(t % a.H);
+  const int b = (int)(t / a.H);
+  float in[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int yy = y + dy - 1, xx = x + dx - 1;
+        in[c * 9 + dy * 3 + dx] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                                      ? a.x[(((int64_t)b * 3 + c) * a.H + yy) * a.W + xx] : 0.f;
+      }
+  float o[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int cv = g * 8 + q, cg = a.C + cv;
+    const float* wv = a.w + cv * 27;
+    const float* wg = a.w + cg * 27;
+    float v = 0.f, gt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      v = fmaf(wv[k], in[k], v);
+      gt = fmaf(wg[k], in[k], gt);
+    }
+    v = v * a.scale[cv] + a.shift[cv];
+    gt = gt * a.scale[cg] + a.shift[cg];
+    o[q] = v * sigmoidf_fast(gt);
+  }
+  u32x4 pk;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pk[q] = LP<T>::pack2(o[2 * q], o[2 * q + 1]);
+  unsigned short* op = a.out + (((int64_t)b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.ocp + a.oco + g * 8;
+  *reinterpret_cast<u32x4*>(op) = pk;
+}
+
+// ------------------------------------------------------------------------------------------------------------ heads
+struct LpTo3Args {
+  const char* x;         // lp image, channels [0, 32)
+  int xcp;
+  const char* wpack;     // [K*K][lane 64][8]
+  const float* addend;   // [B][3][H][W] fp32 or null
+  float alpha;
+  float* out;            // [B][3][H][W] fp32
+  int B, H, W, tiles_x, tiles_y;
+};
+
+// Workgroup = 4 waves = 8 rows x 32 columns of outputs; wave w owns rows 2w, 2w+1 (two 16-pixel segments each).
+// Halo tile [(8 + K - 1) x (32 + K - 1) pixels][32 ch] by LDS-DMA, 16-byte slots swizzled by (column >> 1) & 3
+// (ds_read_b128 of 16 neighbouring pixels x 4 channel groups conflict free; checked by simulation).  Pixels further
+// than one outside the image (K = 5) are fetched from the image's top-left border pixel, which is zero by the layout rule.
+template <class T, int K, int ACT>
+__global__ __launch_bounds__(256) void lp_to3_kernel(LpTo3Args a) {
+  constexpr int P = K / 2, TR = 8 + 2 * P, TC = 32 + 2 * P, NPIX = TR * TC;
+  constexpr int TILE_SLOTS = NPIX * 4, TILE_INSTR = (TILE_SLOTS + 63) / 64;
+  __shared__ __attribute__((aligned(1024))) char tile[TILE_INSTR * 1024];
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int y0 = ty * 8, x0 = tx * 32;
+  const int64_t rowb = (int64_t)(a.W + 2) * a.xcp * 2;
+  const char* xb = a.x + (int64_t)b * (a.H + 2) * rowb;
+#pragma unroll
+  for (int k = 0; k < (TILE_INSTR + 3) / 4; ++k) {
+    const int ins = wave + 4 * k;
+    if (ins < TILE_INSTR) {
+      const int S = ins * 64 + lane;
+      int pix = S >> 2;
+      const int ps = S & 3;
+      if (pix >= NPIX) pix = 0;
+      const int r = pix / TC, c = pix - r * TC;
+      const int ls = ps ^ ((c >> 1) & 3);
+      int sy = y0 + r + 1 - P, sx = x0 + c + 1 - P;            // padded source coordinates
+      if ((unsigned)sy > (unsigned)(a.H + 1) || (unsigned)sx > (unsigned)(a.W + 1)) sy = sx = 0;
+      lds_dma16(xb + sy * rowb + (int64_t)sx * (a.xcp * 2) + ls * 16, tile + ins * 1024);
+    }
+  }
+  u32x4 af[K * K];
+#pragma unroll
+  for (int k = 0; k < K * K; ++k) af[k] = *reinterpret_cast<const u32x4*>(a.wpack + (k * 64 + lane) * 16);
+  f32x4w acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[r][s][i] = 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int c = s * 16 + p + dx;
+          const u32x4 bf = *reinterpret_cast<const u32x4*>(tile + ((2 * wave + r + dy) * TC + c) * 64 +
+                                                           ((g ^ ((c >> 1) & 3)) << 4));
+          acc[r][s] = LP<T>::mfma16(af[dy * K + dx], bf, acc[r][s]);
+        }
+  // D[row = 4 g + reg][col = p]: the three output channels are registers 0..2 of lanes 0..15
+  if (g == 0) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int y = y0 + 2 * wave + r, x = x0 + s * 16 + p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int64_t o = (((int64_t)b * 3 + c) * a.H + y) * a.W + x;
+          float v = acc[r][s][c];
+          if (ACT == TGSR_ACT_TANH_AXPY) v = tanhf(v) + (a.addend ? a.alpha * a.addend[o] : 0.f);
+          a.out[o] = v;
+        }
+      }
+  }
+}
+
+// wpack[tap][lane][8] <- w[3][32][K][K]: element j of lane l = w[l & 15][8 (l >> 4) + j][tap] for rows < 3, else 0
+template <class T>
+__global__ void lp_pack_to3_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int KK, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = i & 7, l = (i >> 3) & 63, tap = i >> 9;
+  const int row = l & 15, ci = 8 * (l >> 4) + j;
+  wp[i] = LP<T>::one(row < 3 ? w[(row * 32 + ci) * KK + tap] : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------------ attention
+struct LpAttnArgs {
+  const char* h;         // lp image, channels [0, 32) = h_code
+  int hcp;
+  const float* src;      // [B][32][32] fp32 projected words (tgsr_word_project_fwd), zero padded past T
+  const uint8_t* mask;   // [B][T] or null
+  int mask_mode, B, T, H, W;
+  char* c;               // lp image receiving c_code at channels [cco, cco + 32)
+  int ccp, cco;
+  float* attn;           // [B][T][H*W] fp32 or null
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void lp_word_attention_kernel(LpAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned short frag_s[4][64][8];   // A fragments: GEMM1 k-steps 0,1; GEMM2 0,1
+  __shared__ unsigned mbits_s[256];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int Q = a.H * a.W;
+  const float* sb = a.src + (int64_t)b * 32 * 32;          // [i][t]
+  for (int o = tid; o < 4 * 64 * 8; o += 256) {
+    const int j = o & 7, l = (o >> 3) & 63, f = o >> 9;
+    const int lr = l & 31, lh = l >> 5;
+    float v;
+    if (f < 2) v = sb[(16 * f + 8 * lh + j) * 32 + lr];                                // A[row t = lr][k = i]
+    else v = sb[lr * 32 + 16 * (f - 2) + 8 * (j >> 2) + 4 * lh + (j & 3)];             // A[row i = lr][k = t (permuted)]
+    frag_s[f][l][j] = LP<T>::one(v);
+  }
+  const int nrows = a.mask ? (a.B < 256 ? a.B : 256) : 0;
+  for (int r = tid; r < nrows; r += 256) {
+    unsigned m = 0;
+    for (int t = 0; t < a.T; ++t) m |= (a.mask[r * a.T + t] ? 1u : 0u) << t;
+    mbits_s[r] = m;
+  }
+  __syncthreads();
+  u32x4 fa[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) fa[f] = *reinterpret_cast<const u32x4*>(&frag_s[f][lane][0]);
+
+  const int ntiles = Q >> 5, tstride = gridDim.x * 4;
+  const int64_t hrow = (int64_t)(a.W + 2) * a.hcp * 2, crow = (int64_t)(a.W + 2) * a.ccp * 2;
+  const char* hb = a.h + (int64_t)b * (a.H + 2) * hrow;
+  char* cb = a.c + (int64_t)b * (a.H + 2) * crow;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += tstride) {
+    const int q = tile * 32 + l31;
+    const int y = q / a.W, x = q - y * a.W;
+    const char* hp = hb + (y + 1) * hrow + (int64_t)(x + 1) * (a.hcp * 2) + hh * 16;
+    const u32x4 b0 = *reinterpret_cast<const u32x4*>(hp);          // channels 8 hh .. (k-step 0)
+    const u32x4 b1 = *reinterpret_cast<const u32x4*>(hp + 32);     // channels 16 + 8 hh ..
+    f32x16v s;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = 0.f;
+    s = LP<T>::mfma32(fa[0], b0, s);
+    s = LP<T>::mfma32(fa[1], b1, s);
+
+    unsigned mb = 0;
+    if (a.mask) {
+      const int mrow = a.mask_mode ? b : (int)(((int64_t)b * Q + q) % a.B);   // GlobalAttention.py:111 mask.repeat(queryL,1)
+      if (mrow < 256) {
+        mb = mbits_s[mrow];
+      } else {
+        for (int t = 0; t < a.T; ++t) mb |= (a.mask[mrow * a.T + t] ? 1u : 0u) << t;
+      }
+    }
+    const unsigned valid = (a.T >= 32 ? 0xffffffffu : ((1u << a.T) - 1u)) & ~mb;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = acc_row(i, hh);
+      if (!((valid >> t) & 1u)) s[i] = -INFINITY;
+      mx = fmaxf(mx, s[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      s[i] = __expf(s[i] - mx);
+      sum += s[i];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] *= inv;
+    if (a.attn) {
+      float* __restrict__ ab = a.attn + (int64_t)b * a.T * Q + q;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int t = acc_row(i, hh);
+        if (t < a.T) ab[(int64_t)t * Q] = s[i];
+      }
+    }
+    // weighted context: B operand of k-step ks = registers 8 ks .. 8 ks + 7 of P, rounded to T (their word order is
+    // the one the GEMM2 A fragments were packed in)
+    u32x4 p0, p1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      p0[j] = LP<T>::pack2(s[2 * j], s[2 * j + 1]);
+      p1[j] = LP<T>::pack2(s[8 + 2 * j], s[8 + 2 * j + 1]);
+    }
+    f32x16v c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    c = LP<T>::mfma32(fa[2], p0, c);
+    c = LP<T>::mfma32(fa[3], p1, c);
+    char* cp = cb + (y + 1) * crow + (int64_t)(x + 1) * (a.ccp * 2) + a.cco * 2;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      u32x2 pk;
+      pk[0] = LP<T>::pack2(c[4 * rg], c[4 * rg + 1]);
+      pk[1] = LP<T>::pack2(c[4 * rg + 2], c[4 * rg + 3]);
+      *reinterpret_cast<u32x2*>(cp + (8 * rg + 4 * hh) * 2) = pk;
+    }
+  }
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
+                                const float* shift, void* out, int out_cpitch, int out_coff, void* stream) {
+  if (!x || !w || !scale || !shift || !out || B < 1 || H < 1 || W < 1 || C < 8) return TGSR_EINVAL;
+  if (C % 8 != 0 || out_cpitch % 8 != 0 || out_coff % 8 != 0 || out_coff + C > out_cpitch ||
+      (reinterpret_cast<uintptr_t>(out) & 15))
+    return TGSR_EUNSUPPORTED;
+  LpStemArgs a;
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.out = static_cast<unsigned short*>(out);
+  a.B = B; a.H = H; a.W = W; a.C = C; a.ocp = out_cpitch; a.oco = out_coff;
+  const int64_t total = (int64_t)B * H * W * (C / 8);
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL(lp_stem_kernel<BF16>, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+  else if (dtype == TGSR_DT_F16) hipLaunchKernelGGL(lp_stem_kernel<F16>, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+  else return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_stem_kernel");
+}
+
+extern "C" int tgsr_lp_pack_to3_weight(int dtype, const float* w, void* wpack, int Cin, int K, void* stream) {
+  if (!w || !wpack) return TGSR_EINVAL;
+  if (Cin != 32 || (K != 3 && K != 5)) return TGSR_EUNSUPPORTED;
+  const int total = K * K * 512;
+  unsigned short* o = static_cast<unsigned short*>(wpack);
+  if (dtype == TGSR_DT_BF16)
+    hipLaunchKernelGGL(lp_pack_to3_kernel<BF16>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), w, o, K * K, total);
+  else if (dtype == TGSR_DT_F16)
+    hipLaunchKernelGGL(lp_pack_to3_kernel<F16>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), w, o, K * K, total);
+  else
+    return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_pack_to3_kernel");
+}
+
+template <class T>
+static int launch_to3(const LpTo3Args& a, int K, int act, hipStream_t s) {
+  const dim3 grid((unsigned)(a.B * a.tiles_x * a.tiles_y));
+  if (K == 3 && act == TGSR_ACT_NONE) hipLaunchKernelGGL((lp_to3_kernel<T, 3, TGSR_ACT_NONE>), grid, dim3(256), 0, s, a);
+  else if (K == 3) hipLaunchKernelGGL((lp_to3_kernel<T, 3, TGSR_ACT_TANH_AXPY>), grid, dim3(256), 0, s, a);
+  else if (act == TGSR_ACT_NONE) hipLaunchKernelGGL((lp_to3_kernel<T, 5, TGSR_ACT_NONE>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lp_to3_kernel<T, 5, TGSR_ACT_TANH_AXPY>), grid, dim3(256), 0, s, a);
+  return note_launch(hipGetLastError(), "lp_to3_kernel");
+}
+
+extern "C" int tgsr_lp_conv_to3_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                                    int K, int act, const float* addend, float alpha, float* out, void* stream) {
+  if (!x || !wpack || !out || B < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  if (act != TGSR_ACT_NONE && act != TGSR_ACT_TANH_AXPY) return TGSR_EINVAL;
+  if (Cin != 32 || (K != 3 && K != 5) || W % 32 != 0 || H % 8 != 0 || x_cpitch < 32 || x_cpitch % 8 != 0 ||
+      (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wpack) & 15))
+    return TGSR_EUNSUPPORTED;
+  LpTo3Args a;
+  a.x = static_cast<const char*>(x); a.xcp = x_cpitch; a.wpack = static_cast<const char*>(wpack);
+  a.addend = addend; a.alpha = alpha; a.out = out; a.B = B; a.H = H; a.W = W;
+  a.tiles_x = W / 32; a.tiles_y = H / 8;
+  if (dtype == TGSR_DT_BF16) return launch_to3<BF16>(a, K, act, as_stream(stream));
+  if (dtype == TGSR_DT_F16) return launch_to3<F16>(a, K, act, as_stream(stream));
+  return TGSR_EINVAL;
+}
+
+extern "C" int tgsr_lp_word_attention_fwd(int dtype, const void* h, int h_cpitch, const float* src, const uint8_t* mask,
+                                          int mask_mode, int B, int idf, int T, int H, int W, void* c_img, int c_cpitch,
+                                          int c_coff, float* attn, void* stream) {
+  if (!h || !src || !c_img || B < 1 || T < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  if (idf != 32 || T > 32 || W % 32 != 0 || h_cpitch < 32 || h_cpitch % 8 != 0 || c_cpitch % 4 != 0 || c_coff % 4 != 0 ||
+      c_coff + 32 > c_cpitch || (reinterpret_cast<uintptr_t>(h) & 15) || (reinterpret_cast<uintptr_t>(c_img) & 7))
+    return TGSR_EUNSUPPORTED;
+  LpAttnArgs a;
+  a.h = static_cast<const char*>(h); a.hcp = h_cpitch; a.src = src; a.mask = mask; a.mask_mode = mask_mode;
+  a.B = B; a.T = T; a.H = H; a.W = W; a.c = static_cast<char*>(c_img); a.ccp = c_cpitch; a.cco = c_coff; a.attn = attn;
+  const int Q = H * W;
+  int gx = (Q + 127) / 128;
+  const int cap = (2048 + B - 1) / B;
+  if (gx > cap) gx = cap;
+  const dim3 grid(gx, B);
+  if (dtype == TGSR_DT_BF16)
+    hipLaunchKernelGGL(lp_word_attention_kernel<BF16>, grid, dim3(256), 0, as_stream(stream), a);
+  else if (dtype == TGSR_DT_F16)
+    hipLaunchKernelGGL(lp_word_attention_kernel<F16>, grid, dim3(256), 0, as_stream(stream), a);
+  else
+    return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_word_attention_kernel");
+}

@@ -109,3 +109,87 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, sh
         nbytes = 2 * (B * cin * Hi * Wi + B * co * H * W * (2 if residual is not None else 1) + cout * cin * 9)
         ops.profile.append(("lp_conv3x3_kernel", 2.0 * B * H * W * cout * cin * 9, nbytes, e0, ops._ev()))
     return out
+
+
+def stem(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, dtype=None,
+         out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cpitch: Optional[int] = None) -> torch.Tensor:
+    """conv3x3 3 -> 2C + affine + GLU from the fp32 NCHW image into C channels of an lp image (tgsr_lp_stem_fwd)."""
+    _need_hip(x, w, scale, shift, out)
+    x = x.contiguous()
+    w = w.detach().contiguous()
+    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape[1:]) != (3, 3, 3):
+        raise TgsrError("lp.stem: x %s / w %s" % (tuple(x.shape), tuple(w.shape)))
+    B, _, H, W = x.shape
+    C = w.shape[0] // 2
+    if out is None:
+        out = new_image(B, H, W, out_cpitch or (out_coff + C), dtype, x.device)
+    ob, oh, ow, ocp = _img(out, "out")
+    if (ob, oh, ow) != (B, H, W):
+        raise TgsrError("lp.stem: out %s" % (tuple(out.shape),))
+    check(_lib.lib().tgsr_lp_stem_fwd(DT[out.dtype], _p(x), B, H, W, _p(w), C, _p(scale), _p(shift), _p(out), ocp,
+                                      out_coff, _stream()), "tgsr_lp_stem_fwd")
+    return out
+
+
+def pack_to3_weight(w: torch.Tensor, dtype) -> torch.Tensor:
+    """[3,32,K,K] fp32 -> the 16-row-padded MFMA fragments of tgsr_lp_conv_to3_fwd."""
+    _need_hip(w)
+    w = w.detach().contiguous()
+    if w.dtype != torch.float32 or w.dim() != 4 or w.shape[0] != 3 or w.shape[2] != w.shape[3]:
+        raise TgsrError("pack_to3_weight: weight %s" % (tuple(w.shape),))
+    K = int(w.shape[2])
+    out = torch.empty(K * K * 512, dtype=torch_dtype(dtype), device=w.device)
+    check(_lib.lib().tgsr_lp_pack_to3_weight(DT[out.dtype], _p(w), _p(out), int(w.shape[1]), K, _stream()),
+          "tgsr_lp_pack_to3_weight")
+    return out
+
+
+def conv_to3(x: torch.Tensor, wpack: torch.Tensor, K: int, tanh_axpy: bool = False,
+             addend: Optional[torch.Tensor] = None, alpha: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """KxK conv of channels [0,32) of an lp image to a 3-channel fp32 NCHW image [+ tanh + alpha * addend]."""
+    _need_hip(x, wpack, addend, out)
+    B, H, W, xcp = _img(x, "x")
+    if addend is not None:
+        addend = addend.contiguous()
+        if addend.dtype != torch.float32 or tuple(addend.shape) != (B, 3, H, W):
+            raise TgsrError("lp.conv_to3: addend %s" % (tuple(addend.shape),))
+    if out is None:
+        out = torch.empty(B, 3, H, W, dtype=torch.float32, device=x.device)
+    from . import ops
+    e0 = ops._ev() if ops.profile is not None else None
+    rc = _lib.lib().tgsr_lp_conv_to3_fwd(DT[x.dtype], _p(x), xcp, B, 32, H, W, _p(wpack), K,
+                                         _lib.ACT_TANH_AXPY if tanh_axpy else _lib.ACT_NONE, _p(addend), float(alpha),
+                                         _p(out), _stream())
+    check(rc, "tgsr_lp_conv_to3_fwd")
+    if ops.profile is not None:
+        nbytes = B * H * W * (2 * 32 + 4 * 3 * (2 if addend is not None else 1))
+        ops.profile.append(("lp_to3_kernel", 2.0 * B * H * W * 3 * 32 * K * K, nbytes, e0, ops._ev()))
+    return out
+
+
+def word_attention(h_img: torch.Tensor, src: torch.Tensor, mask: Optional[torch.Tensor], T: int,
+                   correct_mask: bool = False, c_coff: int = 32, attn: Optional[torch.Tensor] = None,
+                   need_attn: bool = True):
+    """GlobalAttentionGeneral.forward on an lp image: reads h = channels [0,32), writes c_code to channels
+    [c_coff, c_coff+32) of the SAME image (the reference's cat), returns the fp32 attention maps [B,T,H,W] (or None).
+    src = this stage's fp32 word projection [B,32,32] (ops.word_project)."""
+    _need_hip(h_img, src, mask, attn)
+    B, H, W, cp = _img(h_img, "h_img")
+    if tuple(src.shape) != (B, 32, 32) or src.dtype != torch.float32 or not src.is_contiguous():
+        raise TgsrError("lp.word_attention: src %s" % (tuple(src.shape),))
+    from . import ops
+    m8 = None
+    if mask is not None:
+        if tuple(mask.shape) != (B, T):
+            raise TgsrError("lp.word_attention: mask shape %s, expected %s" % (tuple(mask.shape), (B, T)))
+        m8 = ops._mask_u8(mask)
+    if attn is None and need_attn:
+        attn = torch.empty(B, T, H, W, dtype=torch.float32, device=h_img.device)
+    e0 = ops._ev() if ops.profile is not None else None
+    rc = _lib.lib().tgsr_lp_word_attention_fwd(DT[h_img.dtype], _p(h_img), cp, _p(src), _p(m8), 1 if correct_mask else 0,
+                                               B, 32, T, H, W, _p(h_img), cp, c_coff, _p(attn), _stream())
+    check(rc, "tgsr_lp_word_attention_fwd")
+    if ops.profile is not None:
+        nbytes = B * H * W * (2 * 2 * 32 + (4 * T if attn is not None else 0))
+        ops.profile.append(("lp_word_attention_kernel", 4.0 * B * H * W * 32 * T, nbytes, e0, ops._ev()))
+    return attn

@@ -52,18 +52,18 @@ class G_SR_NET_low(nn.Module):
         second stream: nothing downstream reads c_code, model.py:51-52, only mu / logvar are returned)."""
         fake_imgs, att_maps = [], []
         c_code, mu, logvar = self.ca_net(sent_emb) if ca is None else ca   # c_code unused downstream (model.py:51-52)
+        srcs = [None, None, None]
         if not self.training:
             # the three stages attend to the same words: their conv_context projections go out as one launch
             atts = [self.h_net1.att, self.h_net2.att, self.h_net3.att]
-            for att, src in zip(atts, ops.word_project(word_embs, [a.conv_context.weight for a in atts])):
-                att._src = src
-        h_code1, att0 = self.h_net1(None, LR, word_embs, mask, wide_out=True)
+            srcs = ops.word_project(word_embs, [a.conv_context.weight for a in atts])
+        h_code1, att0 = self.h_net1(None, LR, word_embs, mask, wide_out=True, src=srcs[0])
         fake_imgs.append(self.img_net1(h_code1))
         att_maps.append(att0)
-        h_code2, att1 = self.h_net2(h_code1, None, word_embs, mask, wide_out=True)
+        h_code2, att1 = self.h_net2(h_code1, None, word_embs, mask, wide_out=True, src=srcs[1])
         fake_imgs.append(self.img_net2(h_code2))
         att_maps.append(att1)
-        h_code3, att2 = self.h_net3(h_code2, None, word_embs, mask)
+        h_code3, att2 = self.h_net3(h_code2, None, word_embs, mask, src=srcs[2])
         fake_imgs.append(self.img_net3(h_code3))
         att_maps.append(att2)
         if outmiddle:

@@ -68,12 +68,16 @@ class NetG_highweight(nn.Module):
         self.weightmap = False
         self.a = nn.Parameter(torch.FloatTensor([0.5]))
         self._one = {}
+        self._a_host = (None, 0.5)       # (version key, host copy of `a`): one D2H sync per weight version, not per head
 
     def _head(self, out, SRb):
         if self.training:
             from .autograd import ConvTo3
             return ConvTo3.apply(out, self.conv_output[0].weight, SRb, True, self.a)   # d/da = sum(dy * SRb)
-        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=float(self.a.item()))
+        key = (self.a.data_ptr(), self.a._version)
+        if self._a_host[0] != key:
+            self._a_host = (key, float(self.a.item()))
+        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=self._a_host[1])
 
     def forward(self, LR, SRb, LRb):
         SRb2, SRb4, SRb8, SRb16 = SRb[0], SRb[1], SRb[2], SRb[3]

@@ -39,10 +39,22 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def _need_hip(*ts):
+    """Every tensor on ONE HIP device, and that device the current one: the kernels launch on the current device's
+    stream (`_stream()`), so a tensor living elsewhere would be read through a foreign pointer on the wrong queue."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise TgsrError("tgsr_amd ops run only on HIP tensors (got a %s tensor); there is no CPU fallback"
                             % t.device.type)
+        if dev is None:
+            dev = t.device.index
+        elif t.device.index != dev:
+            raise TgsrError("tgsr_amd op got tensors on different devices (cuda:%d and cuda:%d)" % (dev, t.device.index))
+    if dev is not None and dev != torch.cuda.current_device():
+        raise TgsrError("tensors live on cuda:%d but the current device is cuda:%d: run the call under "
+                        "`with torch.cuda.device(%d):` (SRPipeline / the trainers do)" % (dev, torch.cuda.current_device(), dev))
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:

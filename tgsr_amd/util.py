@@ -89,6 +89,23 @@ def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=
                              residual=residual, out=out)
 
 
+def invalidate_caches(module: nn.Module):
+    """Drop every packed-weight / folded-BatchNorm / gate-table cache under `module`, so the next eval forward rebuilds
+    them.  The caches key on (data_ptr, version counter) of their source tensors, which every torch in-place op bumps;
+    this is the explicit hook for writers that bypass the counters (raw-pointer kernels, `.data` tricks)."""
+    for m in module.modules():
+        for name in ("_fp", "_fp0", "_fp1"):
+            fp = getattr(m, name, None)
+            if isinstance(fp, _FusedParams):
+                fp.key = None
+        if hasattr(m, "_up_key"):
+            m._up_key = None
+        if hasattr(m, "_table_key"):
+            m._key = m._table_key = None
+        if hasattr(m, "_a_host"):
+            m._a_host = (None, 0.5)
+
+
 # ------------------------------------------------------------------------------------------ blocks
 class GLU(nn.Module):
     """util.py:45-53.  Only a marker inside the fused Sequentials below (its arithmetic is the conv epilogue)."""
@@ -395,7 +412,7 @@ class INIT_STAGE_GImgup(nn.Module):
         self.upsample = upBlock(ngf * 2, ngf)
         self.residual = _make_res_layers(ngf * 2)
 
-    def forward(self, c_code0, LR, word_embs, mask, wide_out=False):
+    def forward(self, c_code0, LR, word_embs, mask, wide_out=False, src=None):
         B, _, H, W = LR.shape
         ngf = self.gf_dim
         self.att.applyMask(mask)
@@ -406,7 +423,7 @@ class INIT_STAGE_GImgup(nn.Module):
             return self.upsample(out_code1), att
         hc = torch.empty(B, 2 * ngf, H, W, dtype=torch.float32, device=LR.device)
         h_code = self.im2f(LR, out=hc[:, :ngf])
-        _, att = self.att(h_code, word_embs, out=hc[:, ngf:])
+        _, att = self.att(h_code, word_embs, out=hc[:, ngf:], src=src)
         out_code1 = self.residual(hc)
         return _up_into(self.upsample, out_code1, ngf, wide_out), att
 
@@ -426,7 +443,7 @@ class NEXT_STAGE_G(nn.Module):
         self.residual = _make_res_layers(ngf * 2)
         self.upsample = upBlock(ngf * 2, ngf)
 
-    def forward(self, h_code, c_code0, word_embs, mask, wide_out=False):
+    def forward(self, h_code, c_code0, word_embs, mask, wide_out=False, src=None):
         B, ngf, H, W = h_code.shape
         self.att.applyMask(mask)
         if self.training:   # util.py:814-823 through autograd
@@ -438,7 +455,7 @@ class NEXT_STAGE_G(nn.Module):
             wide = torch.empty(B, 2 * ngf, H, W, dtype=torch.float32, device=h_code.device)
             wide[:, :ngf].copy_(h_code)
             h_code = wide[:, :ngf]
-        _, att = self.att(h_code, word_embs, out=wide[:, ngf:])
+        _, att = self.att(h_code, word_embs, out=wide[:, ngf:], src=src)
         out_code = self.residual(wide)
         return _up_into(self.upsample, out_code, ngf, wide_out), att
 

@@ -5,8 +5,10 @@
 
 Every counter found is averaged per kernel launch.  When FETCH_SIZE and WRITE_SIZE are both present the HBM traffic
 column is   (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes   (gfx950: FETCH_SIZE reports half the bytes of wide coalesced
-reads, MI355X_MICROARCH.md section HBM; both counters are in KiB).  `mfma_busy_frac` = SQ_VALU_MFMA_BUSY_CYCLES /
-SQ_BUSY_CYCLES when both are present (share of the shader-busy cycles in which a matrix instruction was executing)."""
+reads, MI355X_MICROARCH.md section HBM; both counters are in KiB).  With `--stats <kernel_stats.csv>` (the rocprofv3
+--stats summary of the SAME command) two more columns: `avg_us` and `mfma_busy_frac_of_peak` =
+SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x avg duration x 2.4 GHz): the share of the chip's matrix-pipe cycles at the spec
+clock in which an MFMA was executing (SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over the SIMDs)."""
 import csv
 import re
 import sys
@@ -21,7 +23,13 @@ def kname(s):
 
 def main():
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))     # kernel -> counter -> [n, sum]
-    for path in sys.argv[1:]:
+    args, dur = sys.argv[1:], {}
+    if "--stats" in args:
+        i = args.index("--stats")
+        for r in csv.DictReader(open(args[i + 1])):
+            dur[kname(r["Name"])] = float(r["AverageNs"])
+        del args[i:i + 2]
+    for path in args:
         for r in csv.DictReader(open(path)):
             a = acc[kname(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += 1
@@ -29,11 +37,11 @@ def main():
     counters = sorted({c for k in acc for c in acc[k]})
     cols = ["kernel", "launches"] + ["avg_" + c for c in counters]
     hbm = "FETCH_SIZE" in counters and "WRITE_SIZE" in counters
-    busy = "SQ_VALU_MFMA_BUSY_CYCLES" in counters and "SQ_BUSY_CYCLES" in counters
+    busy = "SQ_VALU_MFMA_BUSY_CYCLES" in counters and bool(dur)
     if hbm:
         cols.append("avg_HBM_MB_per_launch")
     if busy:
-        cols.append("mfma_busy_frac")
+        cols += ["avg_us", "mfma_busy_frac_of_peak"]
     print(",".join(cols))
 
     def total(k):
@@ -46,7 +54,8 @@ def main():
         if hbm:
             row.append("%.3f" % ((2 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024 / 1e6))
         if busy:
-            row.append("%.4f" % (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / max(avg["SQ_BUSY_CYCLES"], 1.0)))
+            ns = dur.get(k, float("nan"))
+            row += ["%.2f" % (ns / 1e3), "%.4f" % (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * ns * 2.4))]
         print(",".join(row))
 
 
