@@ -6,16 +6,23 @@ BN, fp32) over one batch of 16 synthetic CelebA-shaped samples (32x32 -> 256x256
 (BASELINE.json configs[1]).  With N GPUs every rank runs the same per-GPU batch on its own images (weak scaling,
 independent images, no data-path collective - SURVEY.md 8e); `value` = all images processed / max-over-ranks time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 16] [--dtype fp32|bf16|f16] [--graph] [--no-cpu-baseline]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+`--gpus N` (N > 1) without a torchrun environment starts that command itself, as a child process, before anything
+touches the GPU, and relays its JSON line.  `--dtype bf16|f16` runs BASELINE configs[4]'s reduced-precision path
+(fp32 stays the parity configuration and the default).
 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant 3x3-conv kernel by time, per-launch HIP-event
 timing inside the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores, rank 0, N=1 only).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,19 +33,56 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+PEAK_LP_MFMA_TFLOPS = 2500.0    # dense bf16 / f16 MFMA peak (same guide; AMD's 5 PF figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
-# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
-# doubled per MI355X_MICROARCH.md, averaged over that kernel's launches of a step); None until measured.
-TRAFFIC_PER_LAUNCH_BYTES = {
-    "conv3x3_mfma_kernel": 45.90e6,   # profiles/r01_c_pmc_hbm_traffic.csv, 36-launch mix (algorithmic: 44.58e6)
-    "wino_conv3x3_kernel": 59.42e6,   # profiles/r01_i_pmc_hbm_traffic.csv, 20-launch mix (algorithmic: 49.65e6; the
-                                      # input is read once per 64-cout group)
-    "upconv_glu_mfma_kernel": 84.01e6,   # same file (algorithmic: 80.9e6)
-    "upwino_glu_kernel": 81.79e6,     # profiles/r01_l_pmc_hbm_traffic.csv, the 6 upBlocks (algorithmic: 80.9e6)
-}
-# share of the direct-form multiplies a kernel actually issues (Winograd F(2x2,3x3): 16/36; sub-pixel upBlock: 4/9)
+# share of the direct-form multiplies a kernel actually issues (Winograd F(2x2,3x3): 16/36; sub-pixel upBlock: 4/9;
+# up-sample-aware Winograd: 9 of the 16 positions of a 2x2 output tile = 9/36)
 EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "upconv_glu_mfma_kernel": 4.0 / 9.0,
-                         "upwino_glu_kernel": 9.0 / 36.0}   # up-sample-aware Winograd: 9 of the 16 positions
+                         "upwino_glu_kernel": 9.0 / 36.0, "lp_conv3x3_kernel": 1.0, "lp_upconv_glu_kernel": 4.0 / 9.0}
+# bench name of a kernel -> prefix of its name in the rocprofv3 tables under profiles/
+PMC_NAME = {"upwino_glu_kernel": "upwino_kernel"}
+
+
+def pmc_table(dtype):
+    """Per-kernel counter averages of the newest `profiles/r*_<dtype>_pmc.csv` (tools/profile_pmc.sh: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate passes over `bench.py --serial`, FETCH_SIZE doubled
+    per MI355X_MICROARCH.md).  Returns (file name, {kernel name: row dict}); nothing is hard-coded in this file."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.csv" % dtype)))
+    if not files:
+        return None, {}
+    rows = {}
+    with open(files[-1]) as f:
+        for r in csv.DictReader(line for line in f if not line.startswith("#")):
+            rows[r["kernel"]] = r
+    return os.path.basename(files[-1]), rows
+
+
+def pmc_lookup(rows, name):
+    """Launch-weighted HBM MB per launch and time-weighted MFMA-busy fraction over the template instances of `name`."""
+    pre = PMC_NAME.get(name, name)
+    hit = [r for k, r in rows.items() if k.startswith(pre)]
+    if not hit:
+        return None, None
+    n = sum(float(r["launches"]) for r in hit)
+    mb = sum(float(r["launches"]) * float(r["avg_HBM_MB_per_launch"]) for r in hit) / n
+    busy = None
+    if "mfma_busy_frac_of_peak" in hit[0]:
+        t = sum(float(r["launches"]) * float(r["avg_us"]) for r in hit)
+        busy = sum(float(r["launches"]) * float(r["avg_us"]) * float(r["mfma_busy_frac_of_peak"]) for r in hit) / t
+    return mb * 1e6, busy
+
+
+def maybe_spawn(args):
+    """`--gpus N` outside a torchrun environment: launch the N-rank job as a CHILD process (never an exec: nothing in
+    this process has touched the GPU yet, and nothing will) and exit with its code."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def load_weights():
@@ -93,6 +137,43 @@ def cpu_baseline(weights, batch, budget_s=20.0):
     return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle.sr_forward (CPU PyTorch restatement, fp32, eval BN), batch %d, warm-up 1 + median of %d "
                       "runs, %.2f s/batch" % (batch, len(ts), med)}
+
+
+CONV_GFLOP_PER_IMAGE = 20.5     # direct-form FLOPs of the 36 conv3x3 launches of one forward
+
+
+def cpu_baseline_train(weights, batch, budget_s=25.0):
+    """Generator train step on the CPU: the oracle's forward in train-mode BatchNorm + MSE + KL through torch autograd
+    (what the reference would run: plain PyTorch ops), bounded sample of `batch` images."""
+    from oracle import tgsr_oracle as O
+    torch.set_num_threads(usable_cores())
+    sdE, sdL, sdH = O.random_state(seed=0) if weights is None else (weights["E."], weights["GL."], weights["GH."])
+    sdL = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sdL.items()}
+    sdH = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sdH.items()
+           if k != "a"}
+    cap, lens, LR, LRb = O.synthetic_batch(batch)
+    g = torch.Generator().manual_seed(7)
+    hr = [torch.rand(batch, 3, s, s, generator=g) * 2 - 1 for s in (64, 128, 256)]
+    with torch.no_grad():
+        words, sent = O.rnn_encoder(sdE, cap, lens.tolist())
+    mask = (cap == 0)[:, :words.shape[2]]
+
+    def one():
+        imgs, _att, mu, logvar = O.g_sr_net_low(sdL, LR, sent, words, mask, training=True)
+        fine, _a, _one = O.netg_highweight(sdH, LR, imgs, LRb, "lr", training=True)
+        loss = O.mse(imgs, hr) + O.mse(fine, hr) + O.kl_loss(mu, logvar)
+        loss.backward()
+
+    one()
+    ts, t_all = [], time.perf_counter()
+    while len(ts) < 3 and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle generators in train-mode BN, MSE + KL, torch autograd backward (fp32), batch %d, warm-up 1 + "
+                      "median of %d runs, %.2f s/step" % (batch, len(ts), med)}
 
 
 def bench_damsm(args, rank, world, dist, dev):
@@ -186,10 +267,85 @@ def bench_train(args, rank, world, dist, dev, weights):
             "config": {"workload": "CelebA x8 generator train step (G_SR_NET_low + NetG_highweight, train-mode BN, MSE+KL, "
                                    "Adam; no discriminator / DAMSM terms: not defined by the reference), batch=16 per GPU",
                        "batch_per_gpu": B, "parallelism": "dp%d" % world, "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)},
-            "final_loss": round(float(loss), 5), "roofline": None}), flush=True)
+            "final_loss": round(float(loss), 5),
+            # whole-step figure: the conv kernels of forward, data gradient and weight gradient are ~3x the forward's
+            # direct-form FLOPs (36 conv launches, 20.5 GFLOP per image); `achieved` counts those algorithmic FLOPs over
+            # the WHOLE step time (BatchNorm statistics, optimizer and EMA included), so it is a lower bound of what the
+            # MFMA kernels reach and includes the Winograd saving in the numerator
+            "roofline": {"bound": "mfma", "kernel": "train step: conv forward + dgrad + wgrad kernels over the whole step",
+                         "achieved": round(3 * CONV_GFLOP_PER_IMAGE * B * args.steps / dt / 1e3, 2),
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(3 * CONV_GFLOP_PER_IMAGE * B * args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                         "traffic": None,
+                         "note": "algorithmic (direct-form) FLOPs / step time; per-kernel shares: profiles/*train*kernel_stats*"},
+            **({"cpu_baseline": cpu_baseline_train(weights, min(B, 4))} if world == 1 and not args.no_cpu_baseline else {}),
+        }), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_objects(agg, nprof, dtype, serial, steps):
+    """`roofline` (dominant conv kernel), per-kernel table and the attention object from the HIP events recorded around
+    every launch of the sampled steps.  Nothing here is a literal: HBM traffic and the MFMA-busy share come from the
+    newest rocprofv3 table under profiles/ for this dtype (pmc_table), looked up by kernel name."""
+    lp = dtype != "fp32"
+    peak_mfma = PEAK_LP_MFMA_TFLOPS if lp else PEAK_FP32_MFMA_TFLOPS
+    pmc_file, pmc = pmc_table(dtype)
+    conv_kernels = [k for k in ("lp_conv3x3_kernel", "lp_upconv_glu_kernel", "wino_conv3x3_kernel", "upwino_glu_kernel", "conv3x3_mfma_kernel",
+                                "upconv_glu_mfma_kernel") if k in agg]
+    dom = max(conv_kernels, key=lambda k: agg[k][3])
+    n, fl, by, sec = agg[dom]
+    alg_tf, alg_gbs = fl / sec / 1e12, by / sec / 1e9
+    exe_tf = alg_tf * EXECUTED_MAC_FRACTION[dom]               # what the MFMA pipe really issued
+    traffic, busy = pmc_lookup(pmc, dom)
+    mfma_frac, hbm_frac = exe_tf / peak_mfma, alg_gbs / PEAK_HBM_GBS
+    # the roofline that binds = the one the kernel sits closer to
+    if mfma_frac >= hbm_frac:
+        roof = {"bound": "mfma", "achieved": round(exe_tf, 2), "peak": peak_mfma, "unit": "TFLOP/s",
+                "frac": round(mfma_frac, 4)}
+    else:
+        roof = {"bound": "hbm", "achieved": round(alg_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(hbm_frac, 4)}
+    roof.update({
+        "kernel": dom, "traffic": traffic, "launches_per_step": n // nprof, "avg_launch_us": round(sec / n * 1e6, 2),
+        "flop_per_launch": fl / n, "algorithmic_bytes_per_launch": by / n,
+        "achieved_algorithmic_TFLOPs": round(alg_tf, 2),          # the reference's direct-form FLOP count / time
+        "executed_mac_fraction": round(EXECUTED_MAC_FRACTION[dom], 4),
+        "mfma_frac": round(mfma_frac, 4), "hbm_frac_algorithmic": round(hbm_frac, 4),
+        "hbm_frac_counter": None if traffic is None else round(traffic * n / sec / 1e9 / PEAK_HBM_GBS, 4),
+        "traffic_over_algorithmic": None if traffic is None else round(traffic / (by / n), 3),
+        "mfma_busy_frac_measured": None if busy is None else round(busy, 4),
+        "counters_from": pmc_file,
+        "timing": "HIP events around every launch of %d of the %d timed steps; those steps run single-stream so each "
+                  "launch is timed alone%s" % (nprof, steps, "" if not serial else " (--serial: every step does)")})
+    cp = [agg[k] for k in conv_kernels]
+    cfl, csec, cby = sum(v[1] for v in cp), sum(v[3] for v in cp), sum(v[2] for v in cp)
+    cex = sum(agg[k][1] * EXECUTED_MAC_FRACTION[k] for k in conv_kernels)
+    ctr = [(pmc_lookup(pmc, k)[0], agg[k][0]) for k in conv_kernels]
+    roof["conv_path"] = {"kernels": conv_kernels, "ms_per_step": round(csec / nprof * 1e3, 4),
+                         "achieved_algorithmic_TFLOPs": round(cfl / csec / 1e12, 2),
+                         "mfma_frac": round(cex / csec / 1e12 / peak_mfma, 4),
+                         "hbm_GBs_algorithmic": round(cby / csec / 1e9, 1),
+                         "hbm_frac_algorithmic": round(cby / csec / 1e9 / PEAK_HBM_GBS, 4),
+                         "hbm_frac_counter": (None if any(t is None for t, _ in ctr) else
+                                              round(sum(t * c for t, c in ctr) / csec / 1e9 / PEAK_HBM_GBS, 4))}
+    kern = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[3] / nprof * 1e3, 4),
+                "TFLOPs": round(v[1] / v[3] / 1e12, 2), "GBs_algorithmic": round(v[2] / v[3] / 1e9, 1)}
+            for k, v in agg.items()}
+    att = None
+    ak = "lp_word_attention_kernel" if lp else "word_attention_kernel"
+    if ak in agg:
+        # BASELINE.json's metric also asks for the attention batched-GEMM's MFMA utilisation: the op is HBM-bound
+        # (AI ~ 7 FLOP/B), so both fractions are reported (flops = 4*B*Q*idf*T for the two GEMMs)
+        n, fl, by, sec = agg[ak]
+        tr, bz = pmc_lookup(pmc, ak)
+        att = {"kernel": ak, "bound": "hbm", "launches_per_step": n // nprof, "ms_per_step": round(sec / nprof * 1e3, 4),
+               "mfma_util_pct": round(fl / sec / 1e12 / peak_mfma * 100, 2),
+               "mfma_busy_pct_measured": None if bz is None else round(bz * 100, 2),
+               "hbm_GBs": round(by / sec / 1e9, 1), "hbm_frac": round(by / sec / 1e9 / PEAK_HBM_GBS, 4),
+               "hbm_frac_counter": None if tr is None else round(tr * n / sec / 1e9 / PEAK_HBM_GBS, 4)}
+    return roof, kern, att
 
 
 def main():
@@ -198,6 +354,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--dtype", choices=("fp32", "bf16", "f16"), default="fp32",
+                    help="fp32 = the parity configuration (BASELINE configs[1]); bf16 / f16 = the reduced-precision "
+                         "inference path of configs[4] (2-byte channels-last activations, MFMA bf16/f16, fp32 accumulate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true",
                     help="run the two generators on ONE stream (default: NetG_highweight's trunk overlaps G_SR_NET_low on "
@@ -215,6 +374,7 @@ def main():
                          "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
                          "it on every step")
     args = ap.parse_args()
+    maybe_spawn(args)          # --gpus N without torchrun: run the N ranks as a child process, relay, exit
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -253,7 +413,7 @@ def main():
         return bench_train(args, rank, world, dist, dev, weights)
     if args.mode == "damsm":
         return bench_damsm(args, rank, world, dist, dev)
-    pipe = SRPipeline(41, device=dev, low="lr", overlap=not args.serial)
+    pipe = SRPipeline(41, device=dev, low="lr", overlap=not args.serial, dtype=args.dtype)
     if weights is not None:
         pipe.load_state_dicts(weights["E."], weights["GL."], weights["GH."])
         wdesc = "shipped face_S8 checkpoint (tests/golden fixture), random-init text encoder"
@@ -266,8 +426,8 @@ def main():
     cap, LR, LRb = cap.to(dev), LR.to(dev), LRb.to(dev)
     lens = lens.tolist()
 
-    if args.graph:      # BASELINE config 5: the step replayed from a captured hipGraph (identical results; at B=16 the
-        pipe.capture(cap, lens, LR, LRb)   # launches are already hidden behind the kernels, at small B it halves latency)
+    if args.graph:      # BASELINE config 5: the step replayed from a captured hipGraph (identical results)
+        pipe.capture(cap, lens, LR, LRb)
 
     def step(eager=False):
         return pipe(cap, lens, LR, LRb) if eager or not args.graph else pipe.replay(cap, LR, LRb)
@@ -292,6 +452,8 @@ def main():
     for ln in lanes:                        # untimed: every lane allocates its activation buffers once
         with torch.cuda.stream(ln):
             step()
+    if args.graph and args.profile_every > 0:
+        step(eager=True)                    # untimed: the event-sampled steps run eagerly and own a buffer set too
     prof, nprof = [], 0
     fence()
     t0 = time.perf_counter()
@@ -313,13 +475,22 @@ def main():
     ops.profile = None
     fence()
     dt = time.perf_counter() - t0
+    # the same K steps one at a time (one lane = the "batch 16" latency figure), measured in this run, outside the
+    # timed region above: no sampling, two streams, eager or graph as selected
+    pipe.overlap = not args.serial
+    fence()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        step()
+    fence()
+    dt1 = time.perf_counter() - t1
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt, dt1], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt1 = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
-        # per-kernel totals from the HIP events recorded around every launch of the timed region
+        # per-kernel totals from the HIP events recorded around every launch of the sampled steps
         agg = {}
         for name, flops, nbytes, e0, e1 in prof:
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
@@ -327,58 +498,28 @@ def main():
             a[1] += flops
             a[2] += nbytes
             a[3] += e0.elapsed_time(e1) * 1e-3
-        roof, kern = None, {}
-        if nprof:
-            # dominant kernel = the 3x3-conv kernel with the largest share of the step.  `achieved` is ALGORITHMIC:
-            # the reference's direct-form FLOP count (2*B*H*W*Cout*Cin*9) over the launch time.  The Winograd and
-            # sub-pixel kernels issue 4/9 of those multiplies, so `mfma_executed_frac` (what the MFMA pipe really
-            # ran, over the dense fp32 peak) is reported next to `frac`.
-            conv_kernels = [k for k in ("wino_conv3x3_kernel", "upwino_glu_kernel", "conv3x3_mfma_kernel",
-                                        "upconv_glu_mfma_kernel") if k in agg]
-            dom = max(conv_kernels, key=lambda k: agg[k][3])
-            n, fl, by, sec = agg[dom]
-            ach = fl / sec / 1e12
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2),
-                    "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "mfma_executed_frac": round(ach * EXECUTED_MAC_FRACTION[dom] / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": TRAFFIC_PER_LAUNCH_BYTES.get(dom), "launches_per_step": n // nprof,
-                    "avg_launch_us": round(sec / n * 1e6, 2), "flop_per_launch": fl / n,
-                    "algorithmic_bytes_per_launch": by / n, "hbm_GBs_algorithmic": round(by / sec / 1e9, 1),
-                    "timing": "HIP events around every launch of %d of the %d timed steps; those steps run "
-                              "single-stream so each launch is timed alone (the other steps overlap the two "
-                              "generators on 2 streams%s)" % (nprof, args.steps, "" if not args.serial else ": off, --serial")}
-            # the whole 3x3-conv path = Winograd + direct + sub-pixel upBlock kernels (algorithmic FLOPs as above)
-            cp = [agg[k] for k in conv_kernels]
-            cfl, csec, cby = sum(v[1] for v in cp), sum(v[3] for v in cp), sum(v[2] for v in cp)
-            cex = sum(agg[k][1] * EXECUTED_MAC_FRACTION[k] for k in conv_kernels)
-            roof["conv_path"] = {"kernels": conv_kernels,
-                                 "achieved_algorithmic": round(cfl / csec / 1e12, 2), "unit": "TFLOP/s",
-                                 "frac_of_fp32_mfma_peak": round(cfl / csec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                 "mfma_executed_frac": round(cex / csec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                 "ms_per_step": round(csec / nprof * 1e3, 4),
-                                 "hbm_GBs_algorithmic": round(cby / csec / 1e9, 1)}
-            kern = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[3] / nprof * 1e3, 4),
-                        "TFLOPs": round(v[1] / v[3] / 1e12, 2), "GBs_algorithmic": round(v[2] / v[3] / 1e9, 1)}
-                    for k, v in agg.items()}
+        roof, kern, att = roofline_objects(agg, nprof, args.dtype, args.serial, args.steps) if nprof else (None, {}, None)
+        dname = {"fp32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
         res = {"metric": "SR images/sec (32->256, batch 16 per GPU)", "value": round(world * B * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic inputs (seed 100); " + wdesc,
+               "vs_baseline": None, "dtype": dname, "data": "synthetic inputs (seed 100); " + wdesc,
+               "value_one_lane": round(world * B * args.steps / dt1, 2),
+               "ms_per_step_one_lane": round(dt1 / args.steps * 1e3, 4),
                "config": {"workload": "CelebA face x8 (32->256) batch=%d per GPU, text-enc + G_SR_NET_low + "
-                                      "NetG_highweight forward, eval BN (BASELINE configs[1])" % B,
+                                      "NetG_highweight forward, eval BN (BASELINE configs[%d])" %
+                                      (B, 1 if args.dtype == "fp32" else 4),
                           "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world,
                           "streams": 1 if args.serial else 2, "launch": "hipgraph" if args.graph else "eager",
-                          "lanes": nlanes},
+                          "lanes": nlanes, "storage": "fp32 NCHW" if args.dtype == "fp32" else
+                          "%s channels-last (zero-bordered), fp32 accumulate; inputs / outputs fp32" % args.dtype,
+                          "sampled_steps": nprof,
+                          "note": "`value` covers all %d steps incl. the %d event-sampled single-stream one(s) "
+                                  "(~1 %% of the mean at the default K); `value_one_lane` = the same K steps issued one "
+                                  "at a time, measured right after" % (args.steps, nprof)},
                "roofline": roof, "kernels": kern}
-        if "word_attention_kernel" in agg:
-            # BASELINE.json's metric also asks for the attention batched-GEMM's MFMA utilisation: the op is HBM-bound
-            # (AI ~ 7 FLOP/B), so both fractions are reported (flops = 4*B*Q*idf*T for the two GEMMs, bytes = h in,
-            # c_code + attn out)
-            n, fl, by, sec = agg["word_attention_kernel"]
-            res["attention"] = {"kernel": "word_attention_kernel", "bound": "hbm", "launches_per_step": n // nprof,
-                                "ms_per_step": round(sec / nprof * 1e3, 4),
-                                "mfma_util_pct": round(fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS * 100, 2),
-                                "hbm_GBs": round(by / sec / 1e9, 1), "hbm_frac": round(by / sec / 1e9 / PEAK_HBM_GBS, 4)}
+        if att is not None:
+            res["attention"] = att
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(weights, B)
         print(json.dumps(res), flush=True)

@@ -252,6 +252,8 @@ int tgsr_bn_train_nsplit(int B, int C, int HW);
  * nn.BatchNorm2d in training mode (+ GLU | + residual) on the raw conv output: batch mean / biased variance per
  * channel over (B, H, W), running statistics updated in place with `momentum` and the unbiased variance (either
  * both NULL or both given), y = GLU(bn(raw)) (glu=1, C even, out has C/2 channels) or bn(raw) (+ residual).
+ * `glu` is the activation selector: 0 = none (+ residual), 1 = GLU, 2 = LeakyReLU(0.2) (downBlock util.py:92-98 and
+ * the discriminators' conv3x3 -> BN -> LeakyReLU blocks; no residual).
  * raw [B][C][HW] dense, HW % 4 == 0.  Saves mean/invstd/scale/shift [C] for the backward.
  */
 int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma, const float* beta, float eps,
@@ -266,6 +268,27 @@ int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma
 int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int glu, float* partial_ws,
                       float* sums_ws, float* draw, float* dgamma, float* dbeta, void* stream);
+
+/*
+ * downBlock's convolution (util.py:92-98: nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False)) for the discriminators, fp32 MFMA
+ * implicit GEMMs that gather straight from the NCHW tensors (no im2col buffer).  H, W (even) = INPUT size; out / dy
+ * [B][Cout][H/2][W/2] dense.  BatchNorm + LeakyReLU behind it = tgsr_bn_train_fwd(glu = 2); `act` = 1 applies
+ * LeakyReLU(0.2) in the epilogue (the discriminators' first layer has no BatchNorm).
+ *   tgsr_conv4x4s2_fwd   out = conv(x, w)            w [Cout][Cin][4][4] torch layout
+ *   tgsr_conv4x4s2_dgrad dx  = conv_transpose(dy, w) wpack_ws: 16*Cin*Cout floats of scratch (the per-parity-class
+ *                                                    weight regrouping, rebuilt by every call: weights change per step)
+ *   tgsr_conv4x4s2_wgrad dw  = sum_n dy x_gather     ws: tgsr_conv4x4s2_wgrad_ws_elems floats (split reduction slabs,
+ *                                                    summed in a fixed order - reproducible, no float atomics)
+ * tgsr_leaky_relu: out = x > 0 ? x : 0.2 x, or with y_for_bwd != NULL the backward out = x * (y > 0 ? 1 : 0.2).
+ */
+int tgsr_conv4x4s2_fwd(const float* x, int B, int Cin, int H, int W, const float* w, int Cout, int act, float* out,
+                       void* stream);
+int tgsr_conv4x4s2_dgrad(const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* wpack_ws,
+                         float* dx, void* stream);
+int64_t tgsr_conv4x4s2_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W);
+int tgsr_conv4x4s2_wgrad(const float* dy, const float* x, int B, int Cin, int H, int W, int Cout, float* ws, float* dw,
+                         void* stream);
+int tgsr_leaky_relu(const float* x, const float* y_for_bwd, float* out, int64_t n, void* stream);
 
 /* Backward of nn.Upsample(scale_factor=2, 'nearest'): out[bc][y][x] = sum of in[bc][2y..2y+1][2x..2x+1]. */
 int tgsr_sumpool2x2(const float* x, int64_t BC, int H, int W, float* out, void* stream);
@@ -366,6 +389,19 @@ int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, 
                         int Cout, const float* scale, const float* shift, const void* residual, int res_cpitch,
                         int res_coff, void* out, int out_cpitch, int out_coff, int epilogue, int upsample,
                         void* stream);
+
+/*
+ * upBlock (util.py:74-80: Upsample(x2, nearest) -> conv3x3 -> BN -> GLU) on lp images by sub-pixel decomposition: each
+ * output phase (row & 1, column & 1) is a 2x2 convolution of the LOW-resolution image with taps pre-summed in fp32 and
+ * rounded once to `dtype` - 16 products per low-res pixel instead of 36 (tgsr_lp_conv3x3_fwd(upsample = 1) is the
+ * direct 9-tap form on the same layout).  H, W = size of the LOW-resolution input x; out [B][2H+2][2W+2][out_cpitch]
+ * receives Cout/2 = 32 channels at out_coff.  Cout == 64, Cin in {32, 64}, W % 32 == 0, H % 4 == 0.
+ */
+int64_t tgsr_lp_packed_upconv_elems(int Cout, int Cin);
+int tgsr_lp_pack_upconv_weight(int dtype, const float* w, void* wpack, int Cout, int Cin, void* stream);
+int tgsr_lp_upconv_glu_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                           int Cout, const float* scale, const float* shift, void* out, int out_cpitch, int out_coff,
+                           void* stream);
 
 /*
  * The two 3-channel stems on the fp32 LR image: conv3x3 3 -> 2C + BatchNorm(eval) affine + GLU, written as C channels

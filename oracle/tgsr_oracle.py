@@ -387,6 +387,82 @@ def mse(fake: Sequence[Tensor], label: Sequence[Tensor]) -> Tensor:
     return sum(F.mse_loss(f, l) for f, l in zip(fake, label))
 
 
+# --------------------------------------------------------------------------------------- discriminators + GAN losses
+# The reference calls `netD(img)`, `netD.COND_DNET(features, sent_emb)` and `netD.UNCOND_DNET(features)` (losses.py:
+# 290-316, 351-366) but defines no discriminator class: the ARCHITECTURE below is the build's declaration (AttnGAN
+# topology, tgsr_amd/model.py::_D_NET) restated with stock torch ops so the HIP kernels can be checked - parity
+# UNPINNED for the architecture.  `downBlock` (util.py:92-98) and the two loss functions ARE the reference's.
+def leaky(x: Tensor) -> Tensor:
+    return F.leaky_relu(x, 0.2)
+
+
+def down_block(x: Tensor, sd: SD, p: str, training: bool = True, update: Optional[SD] = None) -> Tensor:
+    """util.py:92-98  Conv2d(in, out, 4, 2, 1, bias=False) -> BatchNorm2d -> LeakyReLU(0.2) (Sequential 0..2)."""
+    return leaky(batch_norm(F.conv2d(x, sd[p + "0.weight"], None, 2, 1), sd, p + "1.", training, update))
+
+
+def block3x3_leaky(x: Tensor, sd: SD, p: str, training: bool = True, update: Optional[SD] = None) -> Tensor:
+    """conv3x3 -> BatchNorm2d -> LeakyReLU(0.2)."""
+    return leaky(batch_norm(conv3x3(x, sd[p + "0.weight"]), sd, p + "1.", training, update))
+
+
+def d_features(sd: SD, x: Tensor, training: bool = True, update: Optional[SD] = None, p: str = "") -> Tensor:
+    """_D_NET.forward: image -> [B, 8 ndf, 4, 4]."""
+    h = leaky(F.conv2d(x, sd[p + "img_code_s16.conv0.weight"], None, 2, 1))
+    for k in (1, 2, 3):
+        h = down_block(h, sd, p + "img_code_s16.down%d." % k, training, update)
+    k = 0
+    while (p + "extra.%d.0.weight" % k) in sd:
+        h = down_block(h, sd, p + "extra.%d." % k, training, update)
+        k += 1
+    k = 0
+    while (p + "reduce.%d.0.weight" % k) in sd:
+        h = block3x3_leaky(h, sd, p + "reduce.%d." % k, training, update)
+        k += 1
+    return h
+
+
+def d_logits(sd: SD, p: str, h: Tensor, c: Optional[Tensor] = None, training: bool = True,
+             update: Optional[SD] = None) -> Tensor:
+    """D_GET_LOGITS.forward: [conditional: tile the sentence code over 4x4, cat, conv3x3-BN-LeakyReLU] -> 4x4/stride-4
+    conv to one logit per sample."""
+    if c is not None and (p + "jointConv.0.weight") in sd:
+        cc = c.view(c.shape[0], -1, 1, 1).repeat(1, 1, 4, 4)
+        h = block3x3_leaky(torch.cat((h, cc), 1), sd, p + "jointConv.", training, update)
+    return F.conv2d(h, sd[p + "outlogits.0.weight"], sd[p + "outlogits.0.bias"], 4).view(-1)
+
+
+def discriminator_loss(sd: SD, real: Tensor, fake: Tensor, cond: Tensor, real_labels: Tensor, fake_labels: Tensor,
+                       training: bool = True) -> Tensor:
+    """losses.py:290-316.  real / fake / wrong-caption (batch shifted by one, :302) BCE-with-logits terms."""
+    bce = F.binary_cross_entropy_with_logits
+    fr, ff = d_features(sd, real, training), d_features(sd, fake.detach(), training)
+    n = fr.shape[0]
+    c_real = bce(d_logits(sd, "COND_DNET.", fr, cond, training), real_labels)
+    c_fake = bce(d_logits(sd, "COND_DNET.", ff, cond, training), fake_labels)
+    c_wrong = bce(d_logits(sd, "COND_DNET.", fr[:n - 1], cond[1:n], training), fake_labels[1:n])
+    if "UNCOND_DNET.outlogits.0.weight" in sd:
+        u_real = bce(d_logits(sd, "UNCOND_DNET.", fr, None, training), real_labels)
+        u_fake = bce(d_logits(sd, "UNCOND_DNET.", ff, None, training), fake_labels)
+        return (u_real + c_real) / 2. + (u_fake + c_fake + c_wrong) / 3.
+    return c_real + (c_fake + c_wrong) / 2.
+
+
+def generator_adv_loss(sds: Sequence[SD], fakes: Sequence[Tensor], sent_emb: Tensor, real_labels: Tensor,
+                       training: bool = True, g: float = 1.0) -> Tensor:
+    """The adversarial half of generator_loss (losses.py:358-371): per scale, BCE-with-logits of the conditional
+    (+ unconditional) logits of the fake image against the REAL labels, times g."""
+    bce = F.binary_cross_entropy_with_logits
+    total = 0
+    for sd, img in zip(sds, fakes):
+        f = d_features(sd, img, training)
+        e = bce(d_logits(sd, "COND_DNET.", f, sent_emb, training), real_labels)
+        if "UNCOND_DNET.outlogits.0.weight" in sd:
+            e = e + bce(d_logits(sd, "UNCOND_DNET.", f, None, training), real_labels)
+        total = total + g * e
+    return total
+
+
 # --------------------------------------------------------------------------------------- synthetic workload
 def synthetic_batch(B: int, n_words: int = 41, seed: int = 100, lr: int = 32, width: int = 18,
                     fixed_len: Optional[int] = None):

@@ -43,12 +43,34 @@ def _fold(sd, p):
     return s, sd[p + "bias"] - sd[p + "running_mean"] * s
 
 
+def subpixel_upconv(x: Tensor, w: Tensor, dtype) -> Tensor:
+    """conv3x3(nearest_x2(x)) as tgsr_lp_upconv_glu_fwd computes it: output phase (a, b) is a 2x2 convolution of the
+    low-res x with the 3x3 taps that fall on the same low-res pixel pre-summed in fp32 and rounded ONCE to `dtype`
+    (a = 0: rows {y-1: w0, y: w1+w2}; a = 1: rows {y: w0+w1, y+1: w2}; same for columns).  Mathematically equal to
+    the direct form; the rounding of the summed taps is what differs, so the model restates it."""
+    B, _, H, W = x.shape
+    rows = [[w[:, :, 0], w[:, :, 1] + w[:, :, 2]], [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]]      # [a][row slot] -> [Co,Ci,3]
+    out = x.new_empty(B, w.shape[0], 2 * H, 2 * W)
+    for a in (0, 1):
+        for b in (0, 1):
+            k = torch.stack([torch.stack([r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if b == 0 else
+                                         [r[:, :, 0] + r[:, :, 1], r[:, :, 2]], dim=-1) for r in rows[a]], dim=-2)
+            xp = F.pad(x, (1 - b, b, 1 - a, a))                  # a/b = 0 reach up/left, 1 reach down/right
+            out[:, :, a::2, b::2] = F.conv2d(xp, rnd(k, dtype))
+    return out
+
+
 def conv_block(x: Tensor, w: Tensor, scale: Optional[Tensor], shift: Optional[Tensor], dtype, glu: bool = False,
-               upsample: bool = False, residual: Optional[Tensor] = None, round_w: bool = True) -> Tensor:
-    """tgsr_lp_conv3x3_fwd: x, residual hold `dtype`-representable values (NCHW fp32 tensors)."""
-    if upsample:
-        x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
-    y = F.conv2d(x, rnd(w, dtype) if round_w else w, None, 1, 1)
+               upsample: bool = False, residual: Optional[Tensor] = None, round_w: bool = True,
+               subpixel: bool = False) -> Tensor:
+    """tgsr_lp_conv3x3_fwd (subpixel=True: tgsr_lp_upconv_glu_fwd): x, residual hold `dtype`-representable values
+    (NCHW fp32 tensors)."""
+    if upsample and subpixel:
+        y = subpixel_upconv(x, w, dtype)
+    else:
+        if upsample:
+            x = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        y = F.conv2d(x, rnd(w, dtype) if round_w else w, None, 1, 1)
     if scale is not None:
         y = y * scale[None, :, None, None] + shift[None, :, None, None]
     if glu:
@@ -86,7 +108,7 @@ def _res_block(x, sd, p, dtype):
 
 def _up_block(x, sd, p, dtype):
     s, t = _fold(sd, p + "2.")
-    return conv_block(x, sd[p + "1.weight"], s, t, dtype, glu=True, upsample=True)
+    return conv_block(x, sd[p + "1.weight"], s, t, dtype, glu=True, upsample=True, subpixel=True)
 
 
 def _stem(x, sd, p, dtype):

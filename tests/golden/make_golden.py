@@ -118,6 +118,7 @@ def gen_ops():
     """Op/module-level goldens on small shapes (ngf=32 so channel counts match the HIP tiles)."""
     cfg, GA, util, model, losses = _load_ref(ngf=32, nef=64)
     g = torch.Generator().manual_seed(1234)
+    torch.manual_seed(1234)          # module constructors draw their initial weights from the GLOBAL generator
     out = {}
 
     # GlobalAttentionGeneral incl. the mask.repeat quirk (GlobalAttention.py:109-116): B=3, unequal lengths

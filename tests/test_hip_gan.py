@@ -1,0 +1,220 @@
+"""GPU: the discriminator path (SURVEY.md 8(f)1 / BASELINE configs[2]) - downBlock's strided-conv kernels, the
+conv -> BatchNorm(batch statistics) -> LeakyReLU blocks, the D_NET64/128/256 modules, `discriminator_loss` /
+`generator_loss` (losses.py:290-316, 351-391) and the G/D alternation of `SRTrainer`, against the oracle's torch
+restatement (values and gradients through torch autograd on the CPU).
+
+The discriminator ARCHITECTURE is the build's declaration (none exists in the reference): parity is "HIP kernels ==
+their torch restatement", not "== the reference".  The two loss functions and downBlock are the reference's.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import tgsr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    from tgsr_amd import _lib
+    _lib.lib()
+    assert torch.cuda.is_available()
+
+
+@pytest.fixture()
+def cfg_d():
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    cfg_reset()
+    cfg.GAN.GF_DIM = 32
+    cfg.GAN.DF_DIM = 8
+    cfg.TEXT.EMBEDDING_DIM = 32
+    yield cfg
+    cfg_reset()
+
+
+def close(a, b, atol=1e-4, rtol=1e-4):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,leaky", [(2, 3, 8, 16, 16, True), (3, 8, 16, 8, 12, False), (1, 40, 33, 4, 4, False),
+                                                   (2, 64, 128, 8, 8, False), (5, 16, 32, 32, 32, True)])
+def test_conv4x4s2_fwd_dgrad_wgrad(B, Cin, Cout, H, W, leaky):
+    from tgsr_amd.autograd import DownConv
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g) / (4 * Cin ** 0.5)).requires_grad_(True)
+    dy = torch.randn(B, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x, w, None, 2, 1)
+    ref = F.leaky_relu(ref, 0.2) if leaky else ref
+    ref.backward(dy)
+    xd, wd = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    out = DownConv.apply(xd, wd, leaky)
+    out.backward(dy.to(DEV))
+    close(out, ref)
+    close(xd.grad, x.grad)
+    close(wd.grad, w.grad, atol=2e-4 * float(w.grad.abs().max()), rtol=2e-4)
+
+
+def _sd_cpu(m):
+    return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H", [("down", 4, 16, 32, 16), ("3x3", 3, 64, 32, 4), ("down", 2, 32, 64, 8)])
+def test_conv_bn_leaky_block(kind, B, Cin, Cout, H, cfg_d):
+    from tgsr_amd import util
+    torch.manual_seed(3)
+    blk = (util.downBlock if kind == "down" else util.Block3x3_leakRelu)(Cin, Cout)
+    with torch.no_grad():
+        blk[1].weight.normal_(1.0, 0.2)
+        blk[1].bias.normal_(0.0, 0.2)
+    sd = _sd_cpu(blk)
+    blk.to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    Ho = H // 2 if kind == "down" else H
+    dy = torch.randn(B, Cout, Ho, Ho, generator=g)
+    # oracle: same block through torch autograd, train-mode BN, running statistics into `upd`
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    upd = {}
+    ref = (O.down_block if kind == "down" else O.block3x3_leaky)(xr, sdr, "", True, upd)
+    ref.backward(dy)
+    xd = x.to(DEV).requires_grad_(True)
+    out = blk(xd)
+    out.backward(dy.to(DEV))
+    close(out, ref, atol=2e-4)
+    close(xd.grad, xr.grad, atol=2e-4)
+    close(blk[0].weight.grad, sdr["0.weight"].grad, atol=3e-4 * float(sdr["0.weight"].grad.abs().max()) + 1e-6, rtol=1e-3)
+    close(blk[1].weight.grad, sdr["1.weight"].grad, atol=1e-3, rtol=1e-3)
+    close(blk[1].bias.grad, sdr["1.bias"].grad, atol=1e-3, rtol=1e-3)
+    close(blk[1].running_mean, upd["1.running_mean"], atol=1e-5)
+    close(blk[1].running_var, upd["1.running_var"], atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        blk.eval()(xd)
+
+
+@pytest.mark.parametrize("name,size", [("D_NET64", 64), ("D_NET128", 128), ("D_NET256", 256)])
+def test_discriminator_loss_values_and_grads(name, size, cfg_d):
+    """discriminator_loss (losses.py:290-316) through the HIP discriminator vs the oracle: the loss and EVERY parameter
+    gradient; also the wrong-caption pairing (batch shifted by one, :302) since cond differs per sample."""
+    from tgsr_amd import model
+    from tgsr_amd.miscc import losses
+    torch.manual_seed(11)
+    d = getattr(model, name)()
+    for m in d.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.normal_(1.0, 0.1)
+    sd = _sd_cpu(d)
+    d.to(DEV).train()
+    B = 4
+    g = torch.Generator().manual_seed(5)
+    real, fake = torch.rand(B, 3, size, size, generator=g) * 2 - 1, torch.rand(B, 3, size, size, generator=g) * 2 - 1
+    cond = torch.randn(B, 32, generator=g)
+    rl, fl = torch.ones(B), torch.zeros(B)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    ref = O.discriminator_loss(sdr, real, fake, cond, rl, fl)
+    ref.backward()
+    got = losses.discriminator_loss(d, real.to(DEV), fake.to(DEV), cond.to(DEV), rl.to(DEV), fl.to(DEV))
+    got.backward()
+    assert abs(float(got) - float(ref)) < 2e-4 * max(1.0, abs(float(ref)))
+    worst = 0.0
+    for k, p in d.named_parameters():
+        gr = sdr[k].grad
+        assert p.grad is not None and gr is not None, k
+        err = float((p.grad.cpu() - gr).abs().max()) / (float(gr.abs().max()) + 1e-6)
+        worst = max(worst, err)
+        assert err < 5e-3, "%s: relative gradient error %g" % (k, err)
+    assert worst < 5e-3
+
+
+def test_generator_loss_adversarial_term(cfg_d):
+    """The adversarial half of generator_loss (losses.py:358-371) on three scales: value and the gradient that reaches
+    the fake images (what drives the generators), vs the oracle."""
+    from tgsr_amd import model
+    from tgsr_amd.miscc import losses
+    torch.manual_seed(2)
+    ds = [model.D_NET64(), model.D_NET128(), model.D_NET256()]
+    sds = [_sd_cpu(d) for d in ds]
+    for d in ds:
+        d.to(DEV).train()
+    B = 3
+    g = torch.Generator().manual_seed(8)
+    fakes = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1) for s in (64, 128, 256)]
+    sent = torch.randn(B, 32, generator=g)
+    rl = torch.ones(B)
+    fr = [f.clone().requires_grad_(True) for f in fakes]
+    ref = O.generator_adv_loss(sds, fr, sent, rl)
+    ref.backward()
+    fd = [f.to(DEV).requires_grad_(True) for f in fakes]
+    got, log = losses.generator_loss(ds, None, fd, rl.to(DEV), None, sent.to(DEV), None, None, None)
+    got.backward()
+    assert abs(float(got) - float(ref)) < 2e-4 * max(1.0, abs(float(ref))) and "g_loss2" in log
+    for a, b in zip(fd, fr):
+        err = float((a.grad.cpu() - b.grad).abs().max()) / (float(b.grad.abs().max()) + 1e-9)
+        assert err < 5e-3, err
+
+
+def test_full_size_gan_train_step_parity(face_weights):
+    """BASELINE configs[2] at FULL size: CelebA x8, B = 16, shipped generator weights, DF_DIM 64 discriminators.  One
+    G/D alternation of SRTrainer vs the oracle (torch autograd on the CPU): the three discriminator losses, the
+    generator loss, and a sample of parameter gradients of both generators (first / middle / last layers of each)."""
+    from conftest import split_sd
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.train import SRTrainer
+    cfg_reset()
+    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.DF_DIM = 32, 256, 64
+    try:
+        torch.manual_seed(0)
+        tr = SRTrainer(41, device=DEV, discriminators=True)
+        sdE, sdL, sdH = (split_sd(face_weights, k) for k in ("E.", "GL.", "GH."))
+        tr.text_encoder.load_state_dict(sdE)
+        tr.netGL.load_state_dict(sdL)
+        tr.netGH.load_state_dict({k: v for k, v in sdH.items() if k != "a"})
+        sdD = [_sd_cpu(d) for d in tr.netsD]
+        B = 16
+        cap, lens, LR, LRb = O.synthetic_batch(B)
+        g = torch.Generator().manual_seed(7)
+        hr = [torch.rand(B, 3, s, s, generator=g) * 2 - 1 for s in (64, 128, 256)]
+        # ---- oracle: the same alternation with torch autograd.  The discriminators are not updated between the two
+        # losses here and on the HIP side (lr = 0 for D below), so both sides see identical discriminator weights.
+        req = lambda sd: {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+                          for k, v in sd.items()}
+        rL, rH = req(sdL), req({k: v for k, v in sdH.items() if k != "a"})
+        with torch.no_grad():
+            words, sent = O.rnn_encoder(sdE, cap, lens.tolist())
+        mask = (cap == 0)[:, :words.shape[2]]
+        imgs, _att, mu, logvar = O.g_sr_net_low(rL, LR, sent, words, mask, training=True)
+        fine, _a, _one = O.netg_highweight(rH, LR, imgs, LRb, "lr", training=True)
+        rl, fl = torch.ones(B), torch.zeros(B)
+        refD = [float(O.discriminator_loss(sd, hr[i], fine[i], sent, rl, fl)) for i, sd in enumerate(sdD)]
+        refG = O.generator_adv_loss(sdD, fine, sent, rl) + O.mse(imgs, hr) + O.mse(fine, hr) + O.kl_loss(mu, logvar)
+        refG.backward()
+        # ---- HIP
+        for o in tr.optsD:
+            for gq in o.param_groups:
+                gq["lr"] = 0.0
+        for gq in tr.opt.param_groups:
+            gq["lr"] = 0.0
+        errG, errsD = tr.step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), [h.to(DEV) for h in hr])
+        torch.cuda.synchronize()
+        for a, b in zip(errsD, refD):
+            assert abs(float(a) - b) < 1e-3 * max(1.0, abs(b)), (float(a), b)
+        assert abs(float(errG) - float(refG)) < 1e-3 * max(1.0, abs(float(refG))), (float(errG), float(refG))
+        sample = ["h_net1.im2f.0.weight", "h_net1.residual.0.block.0.weight", "h_net2.att.conv_context.weight",
+                  "h_net3.residual.1.block.3.weight", "h_net3.upsample.1.weight", "img_net3.img.0.weight",
+                  "h_net2.residual.0.block.1.weight"]
+        gl = dict(tr.netGL.named_parameters())
+        for k in sample:
+            err = float((gl[k].grad.cpu() - rL[k].grad).abs().max()) / (float(rL[k].grad.abs().max()) + 1e-12)
+            assert err < 2e-3, "GL %s: relative gradient error %g" % (k, err)
+        gh = dict(tr.netGH.named_parameters())
+        for k in ("convin.0.weight", "residual.3.block.0.weight", "upscale8x.1.weight", "conv_output.0.weight",
+                  "residual48.3.weight", "residual.5.block.4.bias"):
+            err = float((gh[k].grad.cpu() - rH[k].grad).abs().max()) / (float(rH[k].grad.abs().max()) + 1e-12)
+            assert err < 2e-3, "GH %s: relative gradient error %g" % (k, err)
+    finally:
+        cfg_reset()

@@ -93,6 +93,27 @@ def test_lp_conv3x3(case, name, td, ulp):
 
 
 @pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("B,Cin,Hi,Wi", [(2, 64, 4, 32), (1, 32, 8, 64), (3, 64, 16, 32), (17, 32, 32, 32), (9, 64, 32, 64)])
+def test_lp_upconv_subpixel(B, Cin, Hi, Wi, name, td, ulp):
+    """upBlock by sub-pixel decomposition against the CPU model of the same pre-summed, once-rounded taps, and (loosely)
+    against the direct form it is mathematically equal to."""
+    from tgsr_amd import lp
+    g = torch.Generator().manual_seed(B * 7 + Cin)
+    x = OL.rnd(torch.randn(B, Cin, Hi, Wi, generator=g), td)
+    w = torch.randn(64, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    scale, shift = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    ref = OL.conv_block(x, w, scale, shift, td, glu=True, upsample=True, subpixel=True)
+    xi = lp.from_nchw(x.to(DEV), name, cpitch=Cin)
+    out = lp.new_image(B, 2 * Hi, 2 * Wi, 64, name, DEV)
+    lp.upconv_glu(xi, lp.pack_upconv_weight(w.to(DEV), name), Cin, 64, scale.to(DEV), shift.to(DEV), out=out, out_coff=0)
+    got = lp.to_nchw(out, 32, 0)
+    lp_close(got, ref, ulp, "lp upconv %s" % name)
+    assert float(out[..., 32:].abs().max()) == 0 and float(out[:, 0].abs().max()) == 0 and float(out[:, :, -1].abs().max()) == 0
+    direct = OL.conv_block(x, w, scale, shift, td, glu=True, upsample=True)
+    assert OL.psnr(got.cpu(), direct, peak=float(direct.abs().max())) > (40 if name == "bf16" else 58)
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
 def test_lp_stem(name, td, ulp):
     from tgsr_amd import lp
     g = torch.Generator().manual_seed(5)

@@ -54,6 +54,11 @@ SIGNATURES = {
     "tgsr_bn_train_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, _vp]),
     "tgsr_bn_train_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tgsr_conv4x4s2_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "tgsr_conv4x4s2_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "tgsr_conv4x4s2_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i]),
+    "tgsr_conv4x4s2_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "tgsr_leaky_relu": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "tgsr_to_uint8": (_i, [_vp, _vp, _i64, _vp]),
     "tgsr_conv3x3_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),
@@ -72,6 +77,9 @@ SIGNATURES = {
     "tgsr_lp_packed_conv3x3_elems": (_i64, [_i, _i]),
     "tgsr_lp_pack_conv3x3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_conv3x3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "tgsr_lp_packed_upconv_elems": (_i64, [_i, _i]),
+    "tgsr_lp_pack_upconv_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
+    "tgsr_lp_upconv_glu_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_stem_fwd": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_pack_to3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_conv_to3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),

@@ -135,6 +135,102 @@ def conv_bn_act_train(x, conv, bn, glu=False, upsample=False, residual=None):
     return out
 
 
+class DownConv(torch.autograd.Function):
+    """nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False) [+ LeakyReLU(0.2)] - the first layer of the discriminators'
+    image encoder (no BatchNorm) - forward, data and weight gradient on the gather-GEMM kernels of tgsr_down.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, leaky):
+        out = ops.conv4x4s2(x, weight, leaky=leaky)
+        ctx.save_for_backward(x, weight, out if leaky else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, out = ctx.saved_tensors
+        g = dy.contiguous() if out is None else ops.leaky_relu_bwd(dy, out)
+        dx = ops.conv4x4s2_dgrad(g, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
+        dw = ops.conv4x4s2_wgrad(g, x) if ctx.needs_input_grad[1] else None
+        return dx, dw, None
+
+
+class ConvBnLeaky(torch.autograd.Function):
+    """conv -> BatchNorm2d(batch statistics) -> LeakyReLU(0.2) with `kind` = "down" (conv4x4 stride 2: downBlock,
+    util.py:92-98) or "3x3" (the discriminators' Block3x3_leakRelu).  BatchNorm + activation forward / backward =
+    tgsr_bn_train_fwd / _bwd(act = 2); the 3x3 convolution and its gradients are the generator's fp32 kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, momentum, eps):
+        L = _lib.lib()
+        x = x.contiguous()
+        raw = ops.conv4x4s2(x, weight) if kind == "down" else \
+            ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), weight.shape[0], None, None)
+        B, C, Ho, Wo = raw.shape
+        HW, dev = Ho * Wo, x.device
+        nsplit = L.tgsr_bn_train_nsplit(B, C, HW)
+        ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+        out = torch.empty_like(raw)
+        rc = L.tgsr_bn_train_fwd(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum),
+                                 _p(running_mean), _p(running_var), 2, None, 0, _p(ws), _p(stats[0]), _p(stats[1]),
+                                 _p(stats[2]), _p(stats[3]), _p(out), C * HW, _stream())
+        check(rc, "tgsr_bn_train_fwd")
+        ctx.save_for_backward(x, weight, raw, stats)
+        ctx.kind = kind
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        x, weight, raw, stats = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, C, Ho, Wo = raw.shape
+        HW, dev = Ho * Wo, x.device
+        nsplit = L.tgsr_bn_train_nsplit(B, C, HW)
+        ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        draw = torch.empty_like(raw)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, C, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), 2,
+                                 _p(ws), _p(sums), _p(draw), _p(dgamma), _p(dbeta), _stream())
+        check(rc, "tgsr_bn_train_bwd")
+        dx = dw = None
+        Cin, H, W = x.shape[1], x.shape[2], x.shape[3]
+        if ctx.kind == "down":
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv4x4s2_dgrad(draw, weight, H, W)
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv4x4s2_wgrad(draw, x)
+        else:
+            if ctx.needs_input_grad[0]:
+                wT = _dgrad_weight(weight.detach())
+                cpad = (Cin + 31) // 32 * 32
+                if cpad != Cin:
+                    wT = torch.cat((wT, wT.new_zeros(cpad - Cin, C, 3, 3)), 0)
+                dx = ops.conv3x3_fused(draw, ops.pack_conv3x3_weight(wT), cpad, None, None)
+                if cpad != Cin:
+                    dx = dx[:, :Cin].contiguous()
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+                wws = torch.empty(L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, C, H, W, 0), dtype=torch.float32, device=dev)
+                check(L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, C, 0, _p(wws), _p(dw), _stream()),
+                      "tgsr_conv3x3_wgrad")
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+def conv_bn_leaky_train(x, conv, bn, kind):
+    """Training-mode conv + BatchNorm + LeakyReLU(0.2) over the parameter-holder modules."""
+    out = ConvBnLeaky.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                            bn.running_var if bn.track_running_stats else None, kind, bn.momentum, bn.eps)
+    if bn.track_running_stats:
+        torch.autograd.graph.increment_version(bn.running_mean)
+        torch.autograd.graph.increment_version(bn.running_var)
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += 1
+    return out
+
+
 class ConvTo3(torch.autograd.Function):
     """KxK conv to 3 channels [+ tanh + alpha * addend] (the image heads), forward and backward on HIP."""
 

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ res, int64_t rbs,
-                                                         float* __restrict__ out, int64_t obs) {
+                                                         float* __restrict__ out, int64_t obs, int leaky) {
   const int Co = GLU ? C / 2 : C;
   const int HW4 = HW >> 2;
   const int64_t total = (int64_t)B * Co * HW4;
@@ -117,6 +117,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     } else if (res) {
       const float4 r = *reinterpret_cast<const float4*>(res + b * rbs + (int64_t)c * HW + 4 * p4);
       y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    } else if (leaky) {                                    // LeakyReLU(0.2): downBlock / Block3x3_leakRelu (util.py:92-98)
+      y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y;
+      y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
     }
     *reinterpret_cast<float4*>(out + b * obs + (int64_t)c * HW + 4 * p4) = y;
   }
@@ -128,7 +131,7 @@ template <bool GLU>
 __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, float* __restrict__ partial, int nsplit) {
+    const float* __restrict__ invstd, float* __restrict__ partial, int nsplit, int leaky) {
   __shared__ float red[4];
   const int Co = GLU ? C / 2 : C;
   const int c = blockIdx.x, sp = blockIdx.y;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
   for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
     const int b = (int)(e / HW);
     const int p = (int)(e - (int64_t)b * HW);
-    const float dy = dout[((int64_t)b * Co + c) * HW + p];
+    float dy = dout[((int64_t)b * Co + c) * HW + p];
     const float rv = raw[((int64_t)b * C + c) * HW + p];
     if (GLU) {
       const float rg = raw[((int64_t)b * C + c + Co) * HW + p];
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
       a0 += dzv; a1 += dzv * ((rv - mv) * iv);
       a2 += dzg; a3 += dzg * ((rg - mg) * ig);
     } else {
+      if (leaky && rv * sv + tv <= 0.f) dy *= 0.2f;
       a0 += dy; a1 += dy * ((rv - mv) * iv);
     }
   }
@@ -185,17 +189,18 @@ template <bool GLU>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ sums, float invN, float* __restrict__ draw) {
+    const float* __restrict__ invstd, const float* __restrict__ sums, float invN, float* __restrict__ draw, int leaky) {
   const int Co = GLU ? C / 2 : C;
   const int64_t total = (int64_t)B * Co * HW;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int p = (int)(i % HW);
     const int64_t t = i / HW;
     const int c = (int)(t % Co), b = (int)(t / Co);
-    const float dy = dout[i];
+    float dy = dout[i];
     const int64_t iv_ = ((int64_t)b * C + c) * HW + p;
     const float rv = raw[iv_];
     const float sv = scale[c], mv = mean[c], isv = invstd[c];   // scale = gamma * invstd
+    if (!GLU && leaky && rv * sv + shift[c] <= 0.f) dy *= 0.2f;
     const float xv = (rv - mv) * isv;
     if (GLU) {
       const int64_t ig_ = iv_ + (int64_t)Co * HW;
@@ -252,7 +257,10 @@ extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const f
                                  float* invstd, float* scale, float* shift, float* out, int64_t out_bstride,
                                  void* stream) {
   if (!raw || !gamma || !beta || !partial_ws || !mean || !invstd || !scale || !shift || !out) return TGSR_EINVAL;
-  if (B < 1 || C < 1 || HW < 1 || (glu && (C & 1)) || (glu && residual)) return TGSR_EINVAL;
+  if (glu < 0 || glu > 2) return TGSR_EINVAL;             // `glu` is the activation selector: 0 none, 1 GLU, 2 LeakyReLU(0.2)
+  const int leaky = glu == 2 ? 1 : 0;
+  glu = glu == 1 ? 1 : 0;
+  if (B < 1 || C < 1 || HW < 1 || (glu && (C & 1)) || ((glu || leaky) && residual)) return TGSR_EINVAL;
   if ((HW & 3) != 0) return TGSR_EUNSUPPORTED;
   if ((running_mean == nullptr) != (running_var == nullptr)) return TGSR_EINVAL;
   hipStream_t s = as_stream(stream);
@@ -265,10 +273,10 @@ extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const f
   const int g = grid_for((int64_t)B * Co * (HW / 4));
   if (glu)
     hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(g), dim3(256), 0, s, raw, B, C, HW, scale, shift, nullptr,
-                       (int64_t)0, out, out_bstride);
+                       (int64_t)0, out, out_bstride, 0);
   else
     hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(g), dim3(256), 0, s, raw, B, C, HW, scale, shift, residual,
-                       res_bstride, out, out_bstride);
+                       res_bstride, out, out_bstride, leaky);
   return note_launch(hipGetLastError(), "bn_train_fwd");
 }
 
@@ -278,6 +286,9 @@ extern "C" int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int
                                  void* stream) {
   if (!dout || !raw || !scale || !shift || !mean || !invstd || !partial_ws || !sums_ws || !draw || !dgamma || !dbeta)
     return TGSR_EINVAL;
+  if (glu < 0 || glu > 2) return TGSR_EINVAL;
+  const int leaky = glu == 2 ? 1 : 0;
+  glu = glu == 1 ? 1 : 0;
   if (B < 1 || C < 1 || HW < 1 || (glu && (C & 1))) return TGSR_EINVAL;
   hipStream_t s = as_stream(stream);
   const int Co = glu ? C / 2 : C;
@@ -286,18 +297,18 @@ extern "C" int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int
   const int g = grid_for((int64_t)B * Co * HW);
   if (glu) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C, HW,
-                       scale, shift, mean, invstd, partial_ws, nsplit);
+                       scale, shift, mean, invstd, partial_ws, nsplit, 0);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<true>, dim3((Co + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
                        sums_ws, dgamma, dbeta);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(g), dim3(256), 0, s, dout, raw, B, C, HW, scale, shift,
-                       mean, invstd, sums_ws, invN, draw);
+                       mean, invstd, sums_ws, invN, draw, 0);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<false>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C,
-                       HW, scale, shift, mean, invstd, partial_ws, nsplit);
+                       HW, scale, shift, mean, invstd, partial_ws, nsplit, leaky);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3((Co + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
                        sums_ws, dgamma, dbeta);
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(g), dim3(256), 0, s, dout, raw, B, C, HW, scale, shift,
-                       mean, invstd, sums_ws, invN, draw);
+                       mean, invstd, sums_ws, invN, draw, leaky);
   }
   return note_launch(hipGetLastError(), "bn_train_bwd");
 }

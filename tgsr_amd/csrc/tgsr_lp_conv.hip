@@ -46,18 +46,26 @@ __device__ __forceinline__ int lp_swz(int c) {
   return CIN == 64 ? (c >> 1) & 7 : (c >> 2) & 3;
 }
 
-template <int COUT, int TR>
-constexpr int lp_conv_occ() {
-  return (COUT / 32) * (TR / 4) * 16 >= 64 ? 2 : 4;
+template <int CIN, int COUT, int TR>
+constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the CIN = 64 tiles are LDS-limited to 2 workgroups
+  return (CIN == 64 || (COUT / 32) * (TR / 4) * 16 >= 64) ? 2 : 4;
 }
 
 template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
-__global__ __launch_bounds__(256, (lp_conv_occ<COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
+__global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
   constexpr int NCB = COUT / 32, RW = TR / 4, TC = 34, NPIX = (TR + 2) * TC;
   constexpr int PB = CIN * 2, NSL = CIN / 8;
   constexpr int TILE_SLOTS = NPIX * NSL, TILE_INSTR = (TILE_SLOTS + 63) / 64, TILE_BYTES = TILE_INSTR * 1024;
-  constexpr int CHUNK_INSTR = 3 * NCB, CHUNK_BYTES = CHUNK_INSTR * 1024;
-  constexpr int NK16 = CIN / 16, NCH = 3 * NK16;
+  // a weight chunk = one kernel row (3 taps) x KC16 k-steps of 16 input channels: sized so that a chunk feeds >= 24
+  // MFMAs per wave (768+ matrix-pipe cycles) - the LDS-DMA of the NEXT chunk has to land within one chunk's compute
+  // (measured: with 12-MFMA chunks the Cout = 64 layers spent 71 % of their wave cycles parked on that wait)
+  constexpr int NK16 = CIN / 16;
+  constexpr int KC16_WANT = (RW == 1 ? 2 : 1) * (128 / COUT > 1 ? 128 / COUT : 1);
+  constexpr int KC16 = KC16_WANT < NK16 ? KC16_WANT : NK16;
+  constexpr int STEP_BYTES = 3 * NCB * 1024;                     // one k16-step of a kernel row: [dx][cb][lane][8]
+  constexpr int CHUNK_INSTR = 3 * NCB * KC16, CHUNK_BYTES = CHUNK_INSTR * 1024;
+  constexpr int NKG = NK16 / KC16, NCH = 3 * NKG;
+  static_assert(NK16 % KC16 == 0, "chunking");
   __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + 2 * CHUNK_BYTES + COUT * 8];
   char* tile = smem;
   char* wbuf = smem + TILE_BYTES;
@@ -129,34 +137,56 @@ __global__ __launch_bounds__(256, (lp_conv_occ<COUT, TR>())) void lp_conv3x3_ker
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (ch + 1 < NCH) issue_w(ch + 1, (ch + 1) & 1);
-    const int dy = ch / NK16, k16 = ch % NK16;
-    const char* wb = wbuf + (ch & 1) * CHUNK_BYTES + lane * 16;
+    const int dy = ch / NKG, kg = ch % NKG;                      // the pack is [dy][k16][dx][cb]: a chunk is contiguous
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      u32x4 af[NCB], bf[RW];
+    for (int kk = 0; kk < KC16; ++kk) {
+      const int k16 = kg * KC16 + kk;
+      const char* wb = wbuf + (ch & 1) * CHUNK_BYTES + kk * STEP_BYTES + lane * 16;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) af[cb] = *reinterpret_cast<const u32x4*>(wb + (dx * NCB + cb) * 1024);
+      for (int dx = 0; dx < 3; ++dx) {
+        u32x4 af[NCB], bf[RW];
 #pragma unroll
-      for (int pr = 0; pr < RW; ++pr)
-        bf[pr] = *reinterpret_cast<const u32x4*>(tile + (bbase[dx] ^ (k16 << 5)) + (pr + dy) * TC * PB);
+        for (int cb = 0; cb < NCB; ++cb) af[cb] = *reinterpret_cast<const u32x4*>(wb + (dx * NCB + cb) * 1024);
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
+        for (int pr = 0; pr < RW; ++pr)
+          bf[pr] = *reinterpret_cast<const u32x4*>(tile + (bbase[dx] ^ (k16 << 5)) + (pr + dy) * TC * PB);
 #pragma unroll
-        for (int pr = 0; pr < RW; ++pr) acc[cb][pr] = LP<T>::mfma32(af[cb], bf[pr], acc[cb][pr]);
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int pr = 0; pr < RW; ++pr) acc[cb][pr] = LP<T>::mfma32(af[cb], bf[pr], acc[cb][pr]);
+      }
     }
   }
 
-  // ---- epilogue: affine (+ GLU | + residual), pack to 2-byte elements, 8-byte channels-last stores
+  // ---- epilogue: affine (+ GLU | + residual) in registers, then through LDS so that HBM sees whole lines.
+  // The accumulator layout gives a lane 4 consecutive channels (8 bytes) of one pixel: stored directly that is 16
+  // partial writes per 128-byte line (measured: WRITE_SIZE 2x the tensor).  Instead every wave stages its RW x 32
+  // pixels x OC channels in its own LDS region [pixel][OC] (16-byte chunks XOR-swizzled by the pixel index; the input
+  // tile and weight buffers are dead by now), reads them back 16 bytes per lane with 8 (4) consecutive lanes covering
+  // one pixel, and stores full pixel rows.  The residual tile comes in the same way in the opposite direction (LDS-DMA
+  // with the swizzle on the source address) and the output overwrites it in place.
   constexpr int NOB = EPI == kEpiGlu ? NCB / 2 : NCB;
+  constexpr int OC = NOB * 32, OB = OC * 2, NCHK = OB / 16;          // output channels, bytes and 16-byte chunks per pixel
+  constexpr int STG_WAVE = RW * 32 * OB, STG_INSTR = STG_WAVE / 1024;
+  static_assert(4 * STG_WAVE <= TILE_BYTES + 2 * CHUNK_BYTES, "staging fits the dead tile + weight buffers");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                     // every wave is done reading the tile / weights
+  char* stg = smem + wave * STG_WAVE;
   const int64_t orow = (int64_t)(a.W + 2) * a.ocp * 2;
-  char* ob = a.out + (int64_t)b * (a.H + 2) * orow;
-  const int64_t rrow = (int64_t)(a.W + 2) * a.rcp * 2;
-  const char* rb = EPI == kEpiRes ? a.res + (int64_t)b * (a.H + 2) * rrow : nullptr;
+  char* ob = a.out + ((int64_t)b * (a.H + 2) + y0 + wave * RW + 1) * orow + (int64_t)(x0 + 1) * (a.ocp * 2) + a.oco * 2;
+  if (EPI == kEpiRes) {
+    const int64_t rrow = (int64_t)(a.W + 2) * a.rcp * 2;
+    const char* rb = a.res + ((int64_t)b * (a.H + 2) + y0 + wave * RW + 1) * rrow + (int64_t)(x0 + 1) * (a.rcp * 2) + a.rco * 2;
+#pragma unroll
+    for (int j = 0; j < STG_INSTR; ++j) {
+      const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ (pw & (NCHK - 1));
+      lds_dma16(rb + (pw >> 5) * rrow + (int64_t)(pw & 31) * (a.rcp * 2) + q * 16, stg + j * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
 #pragma unroll
   for (int pr = 0; pr < RW; ++pr) {
-    const int y = y0 + wave * RW + pr + 1, x = x0 + c0 + 1;      // padded coordinates
-    char* op = ob + y * orow + (int64_t)x * (a.ocp * 2) + a.oco * 2;
-    const char* rp = EPI == kEpiRes ? rb + y * rrow + (int64_t)x * (a.rcp * 2) + a.rco * 2 : nullptr;
+    const int pw = pr * 32 + c0;
 #pragma unroll
     for (int cb = 0; cb < NOB; ++cb) {
 #pragma unroll
@@ -164,6 +194,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<COUT, TR>())) void lp_conv3x3_ker
         const int ch0 = cb * 32 + 8 * rg + 4 * h;
         const f32x4w s = *reinterpret_cast<const f32x4w*>(aff + ch0);
         const f32x4w sh = *reinterpret_cast<const f32x4w*>(aff + COUT + ch0);
+        char* sp = stg + pw * OB + (((cb * 4 + rg) ^ (pw & (NCHK - 1))) << 4) + 8 * h;
         float o[4];
         if (EPI == kEpiGlu) {
           const f32x4w gs = *reinterpret_cast<const f32x4w*>(aff + COUT / 2 + ch0);
@@ -178,7 +209,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<COUT, TR>())) void lp_conv3x3_ker
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[q] = acc[cb][pr][4 * rg + q] * s[q] + sh[q];
           if (EPI == kEpiRes) {
-            const u32x2 rv = *reinterpret_cast<const u32x2*>(rp + ch0 * 2);
+            const u32x2 rv = *reinterpret_cast<const u32x2*>(sp);
             o[0] += LP<T>::lo(rv[0]);
             o[1] += LP<T>::hi(rv[0]);
             o[2] += LP<T>::lo(rv[1]);
@@ -188,9 +219,208 @@ __global__ __launch_bounds__(256, (lp_conv_occ<COUT, TR>())) void lp_conv3x3_ker
         u32x2 pk;
         pk[0] = LP<T>::pack2(o[0], o[1]);
         pk[1] = LP<T>::pack2(o[2], o[3]);
-        *reinterpret_cast<u32x2*>(op + ch0 * 2) = pk;
+        *reinterpret_cast<u32x2*>(sp) = pk;
       }
     }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // this wave's own staging writes have landed
+#pragma unroll
+  for (int j = 0; j < STG_INSTR; ++j) {
+    const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ (pw & (NCHK - 1));
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
+    *reinterpret_cast<u32x4*>(ob + (pw >> 5) * orow + (int64_t)(pw & 31) * (a.ocp * 2) + q * 16) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// upBlock (util.py:74-80) by sub-pixel decomposition: Upsample(x2, nearest) -> conv3x3 only ever combines a 2x2
+// low-resolution neighbourhood per output pixel, so output phase (a, b) = (row & 1, column & 1) is a 2x2 convolution of
+// the LOW-resolution image with pre-summed taps (summed in fp32, rounded once to T):
+//     a = 0: rows {y-1: w[0], y: w[1]+w[2]}      a = 1: rows {y: w[0]+w[1], y+1: w[2]}       (same for columns / b)
+// 16 (phase, tap) products per low-res pixel instead of 36: 2.25x fewer MFMAs than the direct form on the up-sampled grid.
+// Workgroup = 4 low-res rows x 32 low-res columns (8 x 64 outputs) x 64 couts; wave = (row pair rp, row phase a): its 8
+// accumulators are [2 low-res rows][column phase b][value | gate block].  Same staging as lp_conv3x3_kernel: the
+// low-res halo tile once by swizzled LDS-DMA, the phase weights streamed in 16-KB chunks [k16][column group][8 combos]
+// (column group 0 = the outer columns dx = -1 (b = 0) and +1 (b = 1), 1 = the centre column feeding both b), double
+// buffered, one barrier per chunk; an A fragment feeds 2 MFMAs, a B fragment 2-4.
+template <class T, int CIN>
+__global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
+  constexpr int TRL = 4, TC = 34, NPIX = (TRL + 2) * TC, PB = CIN * 2, NSL = CIN / 8, COUT = 64;
+  constexpr int TILE_SLOTS = NPIX * NSL, TILE_INSTR = (TILE_SLOTS + 63) / 64, TILE_BYTES = TILE_INSTR * 1024;
+  constexpr int CHUNK_INSTR = 16, CHUNK_BYTES = CHUNK_INSTR * 1024;
+  constexpr int NK16 = CIN / 16, NCH = 2 * NK16;
+  __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + 2 * CHUNK_BYTES + COUT * 8];
+  char* tile = smem;
+  char* wbuf = smem + TILE_BYTES;
+  float* aff = reinterpret_cast<float*>(smem + TILE_BYTES + 2 * CHUNK_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, c0 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rp = wave >> 1, ph = wave & 1;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int y0 = ty * TRL, x0 = tx * 32;                         // low-res origin (unpadded)
+  {
+    const int64_t rowb = (int64_t)(a.Wi + 2) * a.xcp * 2;
+    const char* xb = a.x + (int64_t)b * (a.Hi + 2) * rowb;
+#pragma unroll
+    for (int k = 0; k < (TILE_INSTR + 3) / 4; ++k) {
+      const int ins = wave + 4 * k;
+      if (ins < TILE_INSTR) {
+        const int S = ins * 64 + lane;
+        int pix = S / NSL;
+        const int ps = S % NSL;
+        if (pix >= NPIX) pix = 0;
+        const int r = pix / TC, c = pix - r * TC;
+        const int ls = ps ^ lp_swz<CIN>(c);
+        lds_dma16(xb + (y0 + r) * rowb + (int64_t)(x0 + c) * (a.xcp * 2) + ls * 16, tile + ins * 1024);
+      }
+    }
+  }
+  auto issue_w = [&](int ch, int buf) {
+    const char* src = a.wpack + (int64_t)ch * CHUNK_BYTES + lane * 16;
+#pragma unroll
+    for (int k = 0; k < CHUNK_INSTR / 4; ++k) {
+      const int ins = wave + 4 * k;
+      lds_dma16(src + ins * 1024, wbuf + buf * CHUNK_BYTES + ins * 1024);
+    }
+  };
+  issue_w(0, 0);
+  if (tid < COUT) {
+    aff[tid] = a.scale ? a.scale[tid] : 1.f;
+    aff[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
+  }
+  f32x16v acc[2][2][2];                                          // [low-res row][column phase b][value | gate]
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rr][bb][cb][i] = 0.f;
+  // B-fragment bases: tile row (2 rp + ph) [+ rr + dys], tile column c0 + dxi (dxi = 0..2 <-> dx = -1..+1)
+  int bbase[3];
+#pragma unroll
+  for (int dxi = 0; dxi < 3; ++dxi)
+    bbase[dxi] = ((2 * rp + ph) * TC + c0 + dxi) * PB + ((h ^ lp_swz<CIN>(c0 + dxi)) << 4);
+
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + 1 < NCH) issue_w(ch + 1, (ch + 1) & 1);
+    const int k16 = ch >> 1;
+    const char* wb = wbuf + (ch & 1) * CHUNK_BYTES + lane * 16 + ph * (8 * 1024);   // this row phase's 4 combos
+    if ((ch & 1) == 0) {                                          // outer columns: dx = -1 feeds b = 0, dx = +1 feeds b = 1
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int dys = 0; dys < 2; ++dys) {
+          u32x4 af[2], bf[2];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) af[cb] = *reinterpret_cast<const u32x4*>(wb + ((sb * 2 + dys) * 2 + cb) * 1024);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+            bf[rr] = *reinterpret_cast<const u32x4*>(tile + (bbase[2 * sb] ^ (k16 << 5)) + (rr + dys) * TC * PB);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rr][sb][cb] = LP<T>::mfma32(af[cb], bf[rr], acc[rr][sb][cb]);
+        }
+    } else {                                                      // centre column: feeds both column phases
+#pragma unroll
+      for (int dys = 0; dys < 2; ++dys) {
+        u32x4 bf[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+          bf[rr] = *reinterpret_cast<const u32x4*>(tile + (bbase[1] ^ (k16 << 5)) + (rr + dys) * TC * PB);
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          u32x4 af[2];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) af[cb] = *reinterpret_cast<const u32x4*>(wb + ((sb * 2 + dys) * 2 + cb) * 1024);
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[rr][sb][cb] = LP<T>::mfma32(af[cb], bf[rr], acc[rr][sb][cb]);
+        }
+      }
+    }
+  }
+
+  // epilogue through LDS (see lp_conv3x3_kernel): a wave owns two output rows (2 (y0 + 2 rp + rr) + ph) of 64 pixels x
+  // 32 channels; staged [rr][64 pixels][64 bytes] with the 4 chunks of a pixel XOR-swizzled, stored as whole pixel rows
+  constexpr int OB = 64, NCHK = 4, STG_WAVE = 2 * 64 * OB, STG_INSTR = STG_WAVE / 1024;
+  static_assert(4 * STG_WAVE <= TILE_BYTES + 2 * CHUNK_BYTES, "staging fits the dead tile + weight buffers");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  char* stg = smem + wave * STG_WAVE;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int pw = rr * 64 + 2 * c0 + sb;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ch0 = 8 * rg + 4 * h;
+        const f32x4w s = *reinterpret_cast<const f32x4w*>(aff + ch0);
+        const f32x4w sh = *reinterpret_cast<const f32x4w*>(aff + COUT + ch0);
+        const f32x4w gs = *reinterpret_cast<const f32x4w*>(aff + 32 + ch0);
+        const f32x4w gsh = *reinterpret_cast<const f32x4w*>(aff + COUT + 32 + ch0);
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = acc[rr][sb][0][4 * rg + q] * s[q] + sh[q];
+          const float g = acc[rr][sb][1][4 * rg + q] * gs[q] + gsh[q];
+          o[q] = v * sigmoidf_fast(g);
+        }
+        u32x2 pk;
+        pk[0] = LP<T>::pack2(o[0], o[1]);
+        pk[1] = LP<T>::pack2(o[2], o[3]);
+        *reinterpret_cast<u32x2*>(stg + pw * OB + ((rg ^ (pw & (NCHK - 1))) << 4) + 8 * h) = pk;
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const int64_t orow = (int64_t)(a.W + 2) * a.ocp * 2;
+  char* ob = a.out + ((int64_t)b * (a.H + 2) + 2 * (y0 + 2 * rp) + ph + 1) * orow + (int64_t)(2 * x0 + 1) * (a.ocp * 2) +
+             a.oco * 2;
+#pragma unroll
+  for (int j = 0; j < STG_INSTR; ++j) {
+    const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ (pw & (NCHK - 1));
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
+    *reinterpret_cast<u32x4*>(ob + (pw >> 6) * (2 * orow) + (int64_t)(pw & 63) * (a.ocp * 2) + q * 16) = v;
+  }
+}
+
+// wpack[k16][column group 2][combo 8][cb 2][lane 64][8] <- pre-summed sub-pixel taps of w[64][Cin][3][3].
+// combo = a * 4 + sb * 2 + dys: row phase a, row offset dyi = a + dys (0..2 <-> dy = -1..+1), column phase b = sb and
+// column offset dxi = (group 0: 2 sb | group 1: 1).
+template <class T>
+__global__ void lp_pack_upconv_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), l = (int)((i >> 3) & 63), cb = (int)((i >> 9) & 1), combo = (int)((i >> 10) & 7);
+    const int grp = (int)((i >> 13) & 1), k16 = (int)(i >> 14);
+    const int pa = combo >> 2, sb = (combo >> 1) & 1, dys = combo & 1;
+    const int dyi = pa + dys, dxi = grp == 0 ? 2 * sb : 1;
+    const int co = cb * 32 + (l & 31), ci = k16 * 16 + 8 * (l >> 5) + j;
+    const float* g = w + ((int64_t)co * Cin + ci) * 9;
+    // taps of the 3x3 kernel that land on low-res offset d (0..2) for phase p: p=0: {0 | 1,2 | -}, p=1: {- | 0,1 | 2}
+    auto lo = [](int p, int d) { return p == 0 ? (d == 0 ? 0 : 1) : (d == 1 ? 0 : 2); };
+    auto hi = [](int p, int d) { return p == 0 ? (d == 0 ? 0 : 2) : (d == 1 ? 1 : 2); };
+    // fp32 sums in the order of the CPU model (oracle/tgsr_oracle_lp.py subpixel_upconv): rows first, then columns
+    float v = 0.f;
+    bool first = true;
+    for (int kx = lo(sb, dxi); kx <= hi(sb, dxi); ++kx) {
+      float c = g[lo(pa, dyi) * 3 + kx];
+      if (hi(pa, dyi) != lo(pa, dyi)) c += g[hi(pa, dyi) * 3 + kx];
+      v = first ? c : v + c;
+      first = false;
+    }
+    wp[i] = LP<T>::one(v);
   }
 }
 
@@ -318,11 +548,11 @@ extern "C" int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B
   if (dtype != TGSR_DT_BF16 && dtype != TGSR_DT_F16) return TGSR_EINVAL;
   const int co = epilogue == TGSR_EPI_AFFINE_GLU ? Cout / 2 : Cout;
   if (W % 32 != 0 || H % 4 != 0 || (upsample && ((H | W) & 1))) return TGSR_EUNSUPPORTED;
-  if (x_cpitch < Cin || x_cpitch % 8 != 0 || out_cpitch % 4 != 0 || out_coff % 4 != 0 || out_coff + co > out_cpitch)
-    return TGSR_EUNSUPPORTED;
-  if (residual && (res_cpitch % 4 != 0 || res_coff % 4 != 0 || res_coff + co > res_cpitch)) return TGSR_EUNSUPPORTED;
+  if (x_cpitch < Cin || x_cpitch % 8 != 0 || out_cpitch % 8 != 0 || out_coff % 8 != 0 || out_coff + co > out_cpitch)
+    return TGSR_EUNSUPPORTED;                      // rows of pixels move as 16-byte pieces: offsets / pitches % 8 channels
+  if (residual && (res_cpitch % 8 != 0 || res_coff % 8 != 0 || res_coff + co > res_cpitch)) return TGSR_EUNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wpack) & 15) ||
-      (reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(residual) & 7))
+      (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(residual) & 15))
     return TGSR_EUNSUPPORTED;
   if ((int64_t)(H + 2) * (W + 2) * (x_cpitch > out_cpitch ? x_cpitch : out_cpitch) * 2 >= (1ll << 31)) return TGSR_EUNSUPPORTED;
   LpConvArgs a;
@@ -335,6 +565,50 @@ extern "C" int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B
   const int epi = epilogue == TGSR_EPI_AFFINE_GLU ? kEpiGlu : (residual ? kEpiRes : kEpiAffine);
   if (dtype == TGSR_DT_BF16) return launch_lp_conv<BF16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
   return launch_lp_conv<F16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
+}
+
+extern "C" int64_t tgsr_lp_packed_upconv_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 16; }
+
+extern "C" int tgsr_lp_pack_upconv_weight(int dtype, const float* w, void* wpack, int Cout, int Cin, void* stream) {
+  if (!w || !wpack) return TGSR_EINVAL;
+  if (Cout != 64 || (Cin != 32 && Cin != 64)) return TGSR_EUNSUPPORTED;
+  const int64_t total = (int64_t)Cout * Cin * 16;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  unsigned short* o = static_cast<unsigned short*>(wpack);
+  if (dtype == TGSR_DT_BF16)
+    hipLaunchKernelGGL(lp_pack_upconv_kernel<BF16>, dim3(blocks), dim3(256), 0, as_stream(stream), w, o, Cin, total);
+  else if (dtype == TGSR_DT_F16)
+    hipLaunchKernelGGL(lp_pack_upconv_kernel<F16>, dim3(blocks), dim3(256), 0, as_stream(stream), w, o, Cin, total);
+  else
+    return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_pack_upconv_kernel");
+}
+
+extern "C" int tgsr_lp_upconv_glu_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                                      int Cout, const float* scale, const float* shift, void* out, int out_cpitch,
+                                      int out_coff, void* stream) {
+  if (!x || !wpack || !out || B < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
+  if (dtype != TGSR_DT_BF16 && dtype != TGSR_DT_F16) return TGSR_EINVAL;
+  if (Cout != 64 || (Cin != 32 && Cin != 64) || W % 32 != 0 || H % 4 != 0) return TGSR_EUNSUPPORTED;   // H, W: LOW-res size
+  if (x_cpitch < Cin || x_cpitch % 8 != 0 || out_cpitch % 8 != 0 || out_coff % 8 != 0 || out_coff + 32 > out_cpitch ||
+      (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wpack) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+    return TGSR_EUNSUPPORTED;
+  if ((int64_t)(2 * H + 2) * (2 * W + 2) * out_cpitch * 2 >= (1ll << 31)) return TGSR_EUNSUPPORTED;
+  LpConvArgs a;
+  a.x = static_cast<const char*>(x); a.xcp = x_cpitch; a.B = B; a.H = 2 * H; a.W = 2 * W; a.Hi = H; a.Wi = W;
+  a.wpack = static_cast<const char*>(wpack); a.scale = scale; a.shift = shift; a.res = nullptr; a.rcp = a.rco = 0;
+  a.out = static_cast<char*>(out); a.ocp = out_cpitch; a.oco = out_coff; a.tiles_x = W / 32; a.tiles_y = H / 4;
+  const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y));
+  hipStream_t s = as_stream(stream);
+  if (dtype == TGSR_DT_BF16) {
+    if (Cin == 64) hipLaunchKernelGGL((lp_upconv_glu_kernel<BF16, 64>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lp_upconv_glu_kernel<BF16, 32>), grid, dim3(256), 0, s, a);
+  } else {
+    if (Cin == 64) hipLaunchKernelGGL((lp_upconv_glu_kernel<F16, 64>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((lp_upconv_glu_kernel<F16, 32>), grid, dim3(256), 0, s, a);
+  }
+  return note_launch(hipGetLastError(), "lp_upconv_glu_kernel");
 }
 
 extern "C" int tgsr_lp_from_nchw(int dtype, const float* x, void* out, int B, int C, int H, int W, int cpitch, int coff,

@@ -23,15 +23,15 @@ struct LpStemArgs {
   int B, H, W, C, ocp, oco;
 };
 
-// thread = (pixel, group of 8 output channels): 8 value + 8 gate channels x 27 MACs, one 16-byte store
+// thread = (pixel, group of 8 output channels): 8 value + 8 gate channels x 27 MACs, one 16-byte store.  The channel
+// group is blockIdx.y, i.e. uniform over the wave: the 16 x 27 weights of a group come in through scalar loads.
 template <class T>
 __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
-  const int ng = a.C / 8;
-  const int64_t total = (int64_t)a.B * a.H * a.W * ng;
+  const int64_t total = (int64_t)a.B * a.H * a.W;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int g = (int)(i % ng);
-  int64_t t = i / ng;
+  const int g = blockIdx.y;
+  int64_t t = i;
   const int x = (int)(t % a.W);
   t /= a.W;
   const int y = (int)(t % a.H);
@@ -297,10 +297,10 @@ extern "C" int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, 
   LpStemArgs a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.out = static_cast<unsigned short*>(out);
   a.B = B; a.H = H; a.W = W; a.C = C; a.ocp = out_cpitch; a.oco = out_coff;
-  const int64_t total = (int64_t)B * H * W * (C / 8);
-  const unsigned blocks = (unsigned)((total + 255) / 256);
-  if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL(lp_stem_kernel<BF16>, dim3(blocks), dim3(256), 0, as_stream(stream), a);
-  else if (dtype == TGSR_DT_F16) hipLaunchKernelGGL(lp_stem_kernel<F16>, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+  const int64_t total = (int64_t)B * H * W;
+  const dim3 grid((unsigned)((total + 255) / 256), (unsigned)(C / 8));
+  if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL(lp_stem_kernel<BF16>, grid, dim3(256), 0, as_stream(stream), a);
+  else if (dtype == TGSR_DT_F16) hipLaunchKernelGGL(lp_stem_kernel<F16>, grid, dim3(256), 0, as_stream(stream), a);
   else return TGSR_EINVAL;
   return note_launch(hipGetLastError(), "lp_stem_kernel");
 }

@@ -193,3 +193,43 @@ def word_attention(h_img: torch.Tensor, src: torch.Tensor, mask: Optional[torch.
         nbytes = B * H * W * (2 * 2 * 32 + (4 * T if attn is not None else 0))
         ops.profile.append(("lp_word_attention_kernel", 4.0 * B * H * W * 32 * T, nbytes, e0, ops._ev()))
     return attn
+
+
+def pack_upconv_weight(w: torch.Tensor, dtype) -> torch.Tensor:
+    """[64,Cin,3,3] fp32 -> the pre-summed sub-pixel taps of tgsr_lp_upconv_glu_fwd (fp32 sums, rounded once)."""
+    _need_hip(w)
+    w = w.detach().contiguous()
+    if w.dtype != torch.float32 or w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise TgsrError("pack_upconv_weight: weight %s %s" % (tuple(w.shape), w.dtype))
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = torch.empty(L.tgsr_lp_packed_upconv_elems(Cout, Cin), dtype=torch_dtype(dtype), device=w.device)
+    check(L.tgsr_lp_pack_upconv_weight(DT[out.dtype], _p(w), _p(out), Cout, Cin, _stream()),
+          "tgsr_lp_pack_upconv_weight")
+    return out
+
+
+def upconv_supported(cin: int, cout: int, Hi: int, Wi: int) -> bool:
+    return cout == 64 and cin in (32, 64) and Wi % 32 == 0 and Hi % 4 == 0
+
+
+def upconv_glu(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, shift,
+               out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cpitch: Optional[int] = None) -> torch.Tensor:
+    """upBlock (Upsample x2 -> conv3x3 -> affine -> GLU) on lp images by sub-pixel decomposition, one launch."""
+    _need_hip(x, wpack, scale, shift, out)
+    B, Hi, Wi, xcp = _img(x, "x")
+    co = cout // 2
+    if out is None:
+        out = new_image(B, 2 * Hi, 2 * Wi, out_cpitch or (out_coff + co), x.dtype, x.device)
+    ob, oh, ow, ocp = _img(out, "out")
+    if (ob, oh, ow) != (B, 2 * Hi, 2 * Wi) or out.dtype != x.dtype or wpack.dtype != x.dtype:
+        raise TgsrError("lp.upconv_glu: out %s / dtypes do not match" % (tuple(out.shape),))
+    from . import ops
+    e0 = ops._ev() if ops.profile is not None else None
+    rc = _lib.lib().tgsr_lp_upconv_glu_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift),
+                                           _p(out), ocp, out_coff, _stream())
+    check(rc, "tgsr_lp_upconv_glu_fwd")
+    if ops.profile is not None:
+        nbytes = 2 * (B * cin * Hi * Wi + B * co * 4 * Hi * Wi + cout * cin * 16)
+        ops.profile.append(("lp_upconv_glu_kernel", 2.0 * B * 4 * Hi * Wi * cout * cin * 9, nbytes, e0, ops._ev()))
+    return out

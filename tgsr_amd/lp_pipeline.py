@@ -8,10 +8,16 @@ between the first and the last convolution differs.  Rounding points: oracle/tgs
 tests compare against).  Every activation buffer is allocated (zeroed) once per (batch, LR size): the step touches no
 allocator and captures into a hipGraph as is.
 """
+import os
+
 import torch
 
 from . import lp, ops
 from .util import _ver
+
+# upBlocks by sub-pixel decomposition (tgsr_lp_upconv_glu_fwd: 2.25x fewer MFMAs); TGSR_LP_SUBPIXEL=0 keeps the direct
+# 9-tap form on the up-sampled grid (tgsr_lp_conv3x3_fwd(upsample=1)) for A/B runs
+SUBPIXEL = os.environ.get("TGSR_LP_SUBPIXEL", "1") != "0"
 
 
 class _Conv:
@@ -25,6 +31,22 @@ class _Conv:
     def __call__(self, x, glu=False, upsample=False, residual=None, out=None, out_coff=0):
         return lp.conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, glu=glu, upsample=upsample,
                           residual=residual, out=out, out_coff=out_coff)
+
+
+class _UpConv:
+    """upBlock: sub-pixel pack where the kernel takes the shape, else the direct form."""
+
+    def __init__(self, conv, bn, dtype):
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.sub = SUBPIXEL and self.cout == 64 and self.cin in (32, 64)
+        self.wsub = lp.pack_upconv_weight(conv.weight, dtype) if self.sub else None
+        self.wpack = lp.pack_conv3x3_weight(conv.weight, dtype)
+        self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+    def __call__(self, x, out):
+        if self.sub and lp.upconv_supported(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2):
+            return lp.upconv_glu(x, self.wsub, self.cin, self.cout, self.scale, self.shift, out=out)
+        return lp.conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, glu=True, upsample=True, out=out)
 
 
 class _Stem:
@@ -64,11 +86,11 @@ class LpExecutor:
         self.gl_stem = _Stem(GL.h_net1.im2f)
         self.gl_stage = []
         for st, img in ((GL.h_net1, GL.img_net1), (GL.h_net2, GL.img_net2), (GL.h_net3, GL.img_net3)):
-            self.gl_stage.append({"res": [res(rb) for rb in st.residual], "up": _Conv(st.upsample[1], st.upsample[2], dt),
+            self.gl_stage.append({"res": [res(rb) for rb in st.residual], "up": _UpConv(st.upsample[1], st.upsample[2], dt),
                                   "head": lp.pack_to3_weight(img.img[0].weight, dt), "att": st.att})
         self.gh_stem = _Stem(GH.convin)
         self.gh_res = [res(rb) for rb in GH.residual]
-        self.gh_up = [_Conv(u[1], u[2], dt) for u in (GH.upscale2x, GH.upscale4x, GH.upscale8x)]
+        self.gh_up = [_UpConv(u[1], u[2], dt) for u in (GH.upscale2x, GH.upscale4x, GH.upscale8x)]
         self.gh_mid = [(_Conv(m[0], m[1], dt), _Conv(m[3], m[4], dt)) for m in (GH.residual24, GH.residual48)]
         self.gh_head = lp.pack_to3_weight(GH.conv_output[0].weight, dt)
         self.key = key
@@ -113,7 +135,7 @@ class LpExecutor:
                 c1(bb["tmp"], residual=x, out=o)
                 x = o
             nxt = bufs["gl"][k + 1]["wide"] if k < 2 else bufs["h3"]
-            st["up"](x, glu=True, upsample=True, out=nxt)                      # upBlock -> channels [0, 32) of the next stage
+            st["up"](x, out=nxt)                                               # upBlock -> channels [0, 32) of the next stage
             fake.append(lp.conv_to3(nxt, st["head"], 3))
         return fake, atts, mu, logvar
 
@@ -135,7 +157,7 @@ class LpExecutor:
                 c0(cur, glu=True, out=m["t"])
                 c1(m["t"], out=m["v"])
                 cur = m["v"]
-            self.gh_up[k](cur, glu=True, upsample=True, out=bufs["u"][k])
+            self.gh_up[k](cur, out=bufs["u"][k])
             cur = bufs["u"][k]
             feats.append(cur)
         return feats

@@ -108,7 +108,8 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
                    class_ids, w=1, s=1, g=1):
     """losses.py:351-391: per-scale adversarial terms + the DAMSM words / sentence ranking loss on the last scale
-    (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log string) like the reference."""
+    (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log string) like the reference.  `image_encoder=None` (the reference
+    always has one; its Inception-v3 weights are third-party and not shipped) leaves the ranking term out."""
     B = real_labels.size(0)
     total, parts = 0, []
     for k, (netD, img) in enumerate(zip(netsD, fake_imgs)):
@@ -119,7 +120,7 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
         adv = g * adv
         total = total + adv
         parts.append("g_loss%d: %.5f " % (k, adv.item()))
-        if k == len(netsD) - 1:
+        if k == len(netsD) - 1 and image_encoder is not None:
             regions, code = image_encoder(img)
             w0, w1, _ = words_loss(regions, words_embs, match_labels, cap_lens, class_ids, B)
             s0, s1 = sent_loss(code, sent_emb, match_labels, class_ids, B)

@@ -13,12 +13,14 @@ from torch.autograd import Variable      # re-exported: the reference's model.py
 
 from . import ops
 from .miscc.config import cfg
-from .util import (CA_NET, CNN_ENCODER, GET_IMAGE_G, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G, RNN_ENCODER,
-                   ResBlock, Block3x3_relu, _ConvBnGlu, _ResidualNoSum, conv1x1, conv3x3, conv5x5, upBlock)
+from .util import (CA_NET, CNN_ENCODER, D_GET_LOGITS, GET_IMAGE_G, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G,
+                   RNN_ENCODER, ResBlock, Block3x3_leakRelu, Block3x3_relu, _ConvBnGlu, _ResidualNoSum, conv1x1, conv3x3,
+                   conv5x5, downBlock, encode_image_by_16times, upBlock)
 
 __all__ = ["G_SR_NET_low", "G_SR_NET_low_stage1", "NetG_highweight", "RNN_ENCODER", "CNN_ENCODER", "CA_NET",
            "INIT_STAGE_GImgup", "NEXT_STAGE_G", "GET_IMAGE_G", "GET_IMAGE_G_noAct", "ResBlock", "GLU", "upBlock",
-           "Block3x3_relu", "conv1x1", "conv3x3", "conv5x5", "Variable", "cfg", "torch", "nn", "F"]
+           "Block3x3_relu", "conv1x1", "conv3x3", "conv5x5", "Variable", "cfg", "torch", "nn", "F",
+           "D_NET64", "D_NET128", "D_NET256", "D_GET_LOGITS", "downBlock", "Block3x3_leakRelu"]
 
 
 class G_SR_NET_low_stage1(nn.Module):
@@ -135,3 +137,53 @@ class NetG_highweight(nn.Module):
         ims = self.heads(self.trunk(LR, LRb), SRb[:3])
         a, one = self._const(LR)
         return ims, a, one
+
+
+# ----------------------------------------------------------------------------------------------- discriminators
+class _D_NET(nn.Module):
+    """The reference CALLS discriminators (`netD(img)`, `netD.COND_DNET(features, sent_emb)`, `netD.UNCOND_DNET(features)`,
+    miscc/losses.py:290-316, 351-366) but ships no class for them (`grep D_NET` only hits losses.py).  These are the
+    build's declaration of that interface in the AttnGAN topology TGSR was forked from (README.md:4): an image encoder
+    down to [B, 8 ndf, 4, 4] built from downBlock (util.py:92-98), plus the two logit heads.  The ARCHITECTURE is
+    therefore parity-unpinned; its kernels are pinned against a torch restatement in the oracle."""
+
+    def __init__(self, extra_down, b_jcu=True):
+        super().__init__()
+        ndf, nef = cfg.GAN.DF_DIM, cfg.TEXT.EMBEDDING_DIM
+        self.img_code_s16 = encode_image_by_16times(ndf)
+        ch = ndf * 8
+        self.extra = nn.ModuleList()
+        for _ in range(extra_down):                                # one more downBlock per extra factor of 2 ...
+            self.extra.append(downBlock(ch, ch * 2))
+            ch *= 2
+        self.reduce = nn.ModuleList()
+        while ch > ndf * 8:                                        # ... then conv3x3 blocks back down to 8 ndf channels
+            self.reduce.append(Block3x3_leakRelu(ch, ch // 2))
+            ch //= 2
+        self.UNCOND_DNET = D_GET_LOGITS(ndf, nef, bcondition=False) if b_jcu else None
+        self.COND_DNET = D_GET_LOGITS(ndf, nef, bcondition=True)
+
+    def forward(self, x_var):
+        x = self.img_code_s16(x_var)
+        for m in self.extra:
+            x = m(x)
+        for m in self.reduce:
+            x = m(x)
+        return x                                                   # [B, 8 ndf, 4, 4]
+
+
+class D_NET64(_D_NET):
+    """Discriminator for 64 x 64 images (the first output scale of the x8 generators)."""
+
+    def __init__(self, b_jcu=True):
+        super().__init__(0, b_jcu)
+
+
+class D_NET128(_D_NET):
+    def __init__(self, b_jcu=True):
+        super().__init__(1, b_jcu)
+
+
+class D_NET256(_D_NET):
+    def __init__(self, b_jcu=True):
+        super().__init__(2, b_jcu)

@@ -561,3 +561,56 @@ def to_uint8(img: torch.Tensor) -> torch.Tensor:
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     check(_lib.lib().tgsr_to_uint8(_p(x), _p(out), x.numel(), _stream()), "tgsr_to_uint8")
     return out
+
+
+# ----------------------------------------------------------------------------------------- discriminator: downBlock conv
+def conv4x4s2(x: torch.Tensor, w: torch.Tensor, leaky: bool = False) -> torch.Tensor:
+    """nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False) (downBlock, util.py:92-98) [+ LeakyReLU(0.2)]: x [B,Cin,H,W] ->
+    [B,Cout,H/2,W/2]."""
+    _need_hip(x, w)
+    x = _f32(x, "x").contiguous()
+    w = _f32(w.detach(), "w").contiguous()
+    B, Cin, H, W = x.shape
+    if tuple(w.shape[1:]) != (Cin, 4, 4):
+        raise TgsrError("conv4x4s2: weight %s vs input %s" % (tuple(w.shape), tuple(x.shape)))
+    out = torch.empty(B, w.shape[0], H // 2, W // 2, dtype=torch.float32, device=x.device)
+    check(_lib.lib().tgsr_conv4x4s2_fwd(_p(x), B, Cin, H, W, _p(w), w.shape[0], 1 if leaky else 0, _p(out), _stream()),
+          "tgsr_conv4x4s2_fwd")
+    return out
+
+
+def conv4x4s2_dgrad(dy: torch.Tensor, w: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """Data gradient of conv4x4s2: dy [B,Cout,H/2,W/2] -> dx [B,Cin,H,W]."""
+    _need_hip(dy, w)
+    dy = _f32(dy, "dy").contiguous()
+    w = _f32(w.detach(), "w").contiguous()
+    B, Cout, Cin = dy.shape[0], w.shape[0], w.shape[1]
+    dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dy.device)
+    ws = torch.empty(16 * Cin * Cout, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().tgsr_conv4x4s2_dgrad(_p(dy), B, Cin, H, W, _p(w), Cout, _p(ws), _p(dx), _stream()),
+          "tgsr_conv4x4s2_dgrad")
+    return dx
+
+
+def conv4x4s2_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Weight gradient of conv4x4s2: dy [B,Cout,H/2,W/2], x [B,Cin,H,W] -> dw [Cout,Cin,4,4]."""
+    _need_hip(dy, x)
+    dy = _f32(dy, "dy").contiguous()
+    x = _f32(x, "x").contiguous()
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    L = _lib.lib()
+    ws = torch.empty(L.tgsr_conv4x4s2_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=x.device)
+    dw = torch.empty(Cout, Cin, 4, 4, dtype=torch.float32, device=x.device)
+    check(L.tgsr_conv4x4s2_wgrad(_p(dy), _p(x), B, Cin, H, W, Cout, _p(ws), _p(dw), _stream()), "tgsr_conv4x4s2_wgrad")
+    return dw
+
+
+def leaky_relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dy * (y > 0 ? 1 : 0.2) from the forward OUTPUT y of a LeakyReLU(0.2)."""
+    _need_hip(dy, y)
+    dy = _f32(dy, "dy").contiguous()
+    y = _f32(y, "y").contiguous()
+    out = torch.empty_like(dy)
+    check(_lib.lib().tgsr_leaky_relu(_p(dy), _p(y), _p(out), dy.numel(), _stream()), "tgsr_leaky_relu")
+    return out

@@ -31,10 +31,18 @@ def prepare_labels(batch_size, device):
 
 
 class SRTrainer:
-    def __init__(self, n_words, device="cuda", low="lr", lr=None, ema_decay=0.999, image_encoder=None):
+    def __init__(self, n_words, device="cuda", low="lr", lr=None, ema_decay=0.999, image_encoder=None,
+                 discriminators=False, d_lr=None):
         """image_encoder: optional frozen module image [B,3,256,256] -> (region features [B,nef,17,17], cnn_code
         [B,nef]) (a CNN_ENCODER with its trunk): adds the DAMSM ranking term of generator_loss (losses.py:375-386)
-        on the finest image, x TRAIN.SMOOTH.LAMBDA."""
+        on the finest image, x TRAIN.SMOOTH.LAMBDA.
+        discriminators: True builds one discriminator per output scale (model.D_NET64 / 128 / 256 for the x8
+        generators' 64 / 128 / 256 images) or pass a list of modules exposing COND_DNET / UNCOND_DNET; `step()` then
+        alternates the discriminator update (discriminator_loss, losses.py:290-316) and the generator update
+        (generator_loss :351-391 + MSE + KL), each discriminator with its own Adam(DISCRIMINATOR_LR, betas (0.5, 0.999))
+        and flat gradient bucket.  The reference defines the two loss functions but neither the discriminators nor the
+        loop: architecture and update order (D first, then G on the same fake images, as in the AttnGAN
+        trainer TGSR was forked from) are the build's declaration."""
         self.device = torch.device(device)
         self.image_encoder = image_encoder
         self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM).to(self.device).eval()
@@ -47,6 +55,16 @@ class SRTrainer:
         self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999))
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
+        self.netsD, self.optsD, self.bucketsD = [], [], []
+        if discriminators:
+            from . import model
+            self.netsD = list(discriminators) if not isinstance(discriminators, bool) else \
+                [model.D_NET64(), model.D_NET128(), model.D_NET256()]
+            for d in self.netsD:
+                d.to(self.device).train()
+                self.bucketsD.append(FlatGradBucket(d.parameters()).attach())
+                self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
+                                                   betas=(0.5, 0.999)))
 
     def loss(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """hr_pyramid: the 3 target scales [B,3,2s,2s], [B,3,4s,4s], [B,3,8s,8s]."""
@@ -65,11 +83,66 @@ class SRTrainer:
             errG = errG + (w0 + w1 + s0 + s1) * cfg.TRAIN.SMOOTH.LAMBDA
         return errG, fake_imgL, fine_im
 
-    def step(self, captions, cap_lens, LR, LRb, hr_pyramid):
-        """forward + backward + gradient all-reduce (if distributed) + Adam + EMA.  Returns the loss tensor."""
-        self.bucket.flat.zero_()                      # p.grad are views of the flat bucket (attach()): one memset
-        for p, v in zip(self.bucket.params, self.bucket.views):
+    @staticmethod
+    def _zero(bucket):
+        bucket.flat.zero_()                           # p.grad are views of the flat bucket (attach()): one memset
+        for p, v in zip(bucket.params, bucket.views):
             p.grad = v
+
+    def forward_G(self, captions, cap_lens, LR, LRb):
+        """Text encoder (frozen) + both generators in training mode: (fake_imgL, fine_im, mu, logvar, words, sent)."""
+        with torch.no_grad():
+            words_embs, sent_emb = self.text_encoder(captions, cap_lens, self.text_encoder.init_hidden(captions.shape[0]))
+        mask = caption_mask(captions, words_embs.size(2))
+        fake_imgL, _att, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
+        fine_im, _a, _one = self.netGH(LR, fake_imgL, LRb)
+        return fake_imgL, fine_im, mu, logvar, words_embs, sent_emb
+
+    def d_losses(self, fine_im, hr_pyramid, sent_emb):
+        """discriminator_loss (losses.py:290-316) of every scale: real = HR pyramid, fake = the generators' output."""
+        B = sent_emb.shape[0]
+        real_labels, fake_labels, _ = prepare_labels(B, self.device)
+        return [losses.discriminator_loss(d, hr_pyramid[i], fine_im[i], sent_emb, real_labels, fake_labels)
+                for i, d in enumerate(self.netsD)]
+
+    def g_loss(self, fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids=None):
+        """generator_loss (losses.py:351-391) on the fine images + the pixel and KL terms of `loss`."""
+        B = sent_emb.shape[0]
+        real_labels, _fake, match_labels = prepare_labels(B, self.device)
+        adv, _log = losses.generator_loss(self.netsD, self.image_encoder, fine_im, real_labels, words_embs, sent_emb,
+                                          match_labels, cap_lens, class_ids)
+        return adv + losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
+
+    def step_gan(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
+        """One G/D alternation: forward the generators once; update every discriminator on (real, fake.detach());
+        then update the generators through the UPDATED discriminators on the same fake images.  Returns
+        (errG, [errD_i]) as detached tensors."""
+        fake_imgL, fine_im, mu, logvar, words_embs, sent_emb = self.forward_G(captions, cap_lens, LR, LRb)
+        for b in self.bucketsD:
+            self._zero(b)
+        errsD = self.d_losses(fine_im, hr_pyramid, sent_emb)
+        for e, b, o in zip(errsD, self.bucketsD, self.optsD):
+            e.backward()
+            b.all_reduce_mean()
+            o.step()
+        self._zero(self.bucket)
+        for b in self.bucketsD:                       # the generator step also deposits gradients in the discriminators'
+            self._zero(b)                             # parameters; they are discarded (zeroed again next step)
+        errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
+        errG.backward()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+        with torch.no_grad():
+            torch._foreach_mul_(self.avg_param_G, self.ema_decay)
+            torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
+        return errG.detach(), [e.detach() for e in errsD]
+
+    def step(self, captions, cap_lens, LR, LRb, hr_pyramid):
+        """forward + backward + gradient all-reduce (if distributed) + Adam + EMA.  Returns the loss tensor.  With
+        discriminators this is `step_gan` (the generator loss is returned)."""
+        if self.netsD:
+            return self.step_gan(captions, cap_lens, LR, LRb, hr_pyramid)[0]
+        self._zero(self.bucket)
         errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
         errG.backward()
         self.bucket.all_reduce_mean()

@@ -179,6 +179,77 @@ def Block3x3_relu(in_planes, out_planes):
     return _ConvBnGlu(in_planes, out_planes)
 
 
+# ------------------------------------------------------------------------------------------ discriminator blocks
+class _ConvBnLeaky(nn.Sequential):
+    """[conv, BatchNorm2d, LeakyReLU(0.2)] as one fused training block (keys `0.weight`, `1.*`).  `kind` = "down":
+    downBlock, nn.Conv2d(in, out, 4, 2, 1, bias=False) (util.py:92-98); "3x3": conv3x3 (the discriminators'
+    Block3x3_leakRelu).  The discriminators only exist in training (losses.py:290-374 call them with batch-statistics
+    BatchNorm), so there is no folded inference form."""
+
+    def __init__(self, conv, out_planes, kind):
+        super().__init__(conv, nn.BatchNorm2d(out_planes), nn.LeakyReLU(0.2, inplace=True))
+        self._kind = kind
+
+    def forward(self, x):
+        if not self.training:
+            raise NotImplementedError("discriminator blocks run with batch-statistics BatchNorm only (training mode)")
+        from .autograd import conv_bn_leaky_train
+        return conv_bn_leaky_train(x, self[0], self[1], self._kind)
+
+
+def downBlock(in_planes, out_planes):
+    "util.py:92-98: Conv2d(4, stride 2, pad 1, no bias) -> BatchNorm2d -> LeakyReLU(0.2); halves the spatial size"
+    return _ConvBnLeaky(nn.Conv2d(in_planes, out_planes, 4, 2, 1, bias=False), out_planes, "down")
+
+
+def Block3x3_leakRelu(in_planes, out_planes):
+    "conv3x3 -> BatchNorm2d -> LeakyReLU(0.2); keeps the spatial size"
+    return _ConvBnLeaky(conv3x3(in_planes, out_planes), out_planes, "3x3")
+
+
+class _EncodeBy16(nn.Module):
+    """Image -> ndf*8 channels at 1/16 of the resolution: Conv2d(3, ndf, 4, 2, 1) + LeakyReLU, then three downBlocks
+    (the AttnGAN-style `encode_image_by_16times`; build-declared, see model.D_NET64)."""
+
+    def __init__(self, ndf):
+        super().__init__()
+        self.conv0 = nn.Conv2d(3, ndf, 4, 2, 1, bias=False)
+        self.down1 = downBlock(ndf, ndf * 2)
+        self.down2 = downBlock(ndf * 2, ndf * 4)
+        self.down3 = downBlock(ndf * 4, ndf * 8)
+
+    def forward(self, x):
+        from .autograd import DownConv
+        return self.down3(self.down2(self.down1(DownConv.apply(x, self.conv0.weight, True))))
+
+
+def encode_image_by_16times(ndf):
+    return _EncodeBy16(ndf)
+
+
+class D_GET_LOGITS(nn.Module):
+    """The conditional / unconditional logit heads `netD.COND_DNET(features, sent_emb)` / `netD.UNCOND_DNET(features)`
+    that losses.py:292-316, 359-366 call.  features [B, 8 ndf, 4, 4]; conditional: the sentence code is tiled over the
+    4x4 grid, concatenated, passed through conv3x3 -> BN -> LeakyReLU (jointConv); then a 4x4 / stride-4 convolution
+    to one LOGIT per sample (no sigmoid: the reference's losses are BCEWithLogits)."""
+
+    def __init__(self, ndf, nef, bcondition=False):
+        super().__init__()
+        self.df_dim, self.ef_dim, self.bcondition = ndf, nef, bcondition
+        if bcondition:
+            self.jointConv = Block3x3_leakRelu(ndf * 8 + nef, ndf * 8)
+        self.outlogits = nn.Sequential(nn.Conv2d(ndf * 8, 1, kernel_size=4, stride=4))
+
+    def forward(self, h_code, c_code=None):
+        from .autograd import LinearFn
+        if self.bcondition and c_code is not None:
+            c = c_code.view(-1, self.ef_dim, 1, 1).repeat(1, 1, 4, 4)
+            h_code = self.jointConv(torch.cat((h_code, c), 1))
+        conv = self.outlogits[0]                                  # a 4x4 / stride 4 conv on a 4x4 map = one dot product
+        out = LinearFn.apply(h_code.reshape(h_code.size(0), -1), conv.weight.reshape(1, -1), conv.bias)
+        return out.view(-1)
+
+
 class _ResidualNoSum(nn.Sequential):
     """model.py:229-232 `residual24/48`: conv-BN-GLU-conv-BN, NO skip add (keys 0,1,3,4)."""
 

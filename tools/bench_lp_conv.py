@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--direct-up", action="store_true", help="upBlocks by the direct 9-tap form instead of sub-pixel")
     a = ap.parse_args()
     dev, B = "cuda", a.batch
     g = torch.Generator().manual_seed(0)
@@ -39,12 +40,21 @@ def main():
         r = lp.from_nchw(torch.randn(B, co, H, H, generator=g).to(dev), a.dtype) if res else None
         out = lp.new_image(B, H, H, co, a.dtype, dev)
         sc, sh = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        sub = up and not a.direct_up
+        if sub:
+            w = lp.pack_upconv_weight((torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev), a.dtype)
+
+        def run():
+            if sub:
+                lp.upconv_glu(x, w, cin, cout, sc, sh, out=out)
+            else:
+                lp.conv3x3(x, w, cin, cout, sc, sh, glu=glu, upsample=up, residual=r, out=out)
         for _ in range(3):
-            lp.conv3x3(x, w, cin, cout, sc, sh, glu=glu, upsample=up, residual=r, out=out)
+            run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.reps):
-            lp.conv3x3(x, w, cin, cout, sc, sh, glu=glu, upsample=up, residual=r, out=out)
+            run()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / a.reps

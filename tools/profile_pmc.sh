@@ -24,6 +24,8 @@ rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $RAW/write -o $
 echo "[$TAG] write done"
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $RAW/mfma -o $TAG -- python3 $ROOT/bench.py "$@" > $OUT/${TAG}_mfma.log 2>&1 || echo "[$TAG] mfma counter pass failed (see log)"
 echo "[$TAG] mfma done"
-python3 $ROOT/tools/pmc_summary.py --stats $KS $(find $RAW/fetch $RAW/write $RAW/mfma -name "*counter_collection.csv") > $OUT/${TAG}_pmc.csv
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d $RAW/sq -o $TAG -- python3 $ROOT/bench.py "$@" > $OUT/${TAG}_sq.log 2>&1 || echo "[$TAG] sq counter pass failed (see log)"
+echo "[$TAG] sq done"
+python3 $ROOT/tools/pmc_summary.py --stats $KS $(find $RAW/fetch $RAW/write $RAW/mfma $RAW/sq -name "*counter_collection.csv") > $OUT/${TAG}_pmc.csv
 head -12 $OUT/${TAG}_pmc.csv
 rm -rf $RAW
