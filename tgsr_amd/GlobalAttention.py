@@ -37,8 +37,10 @@ class GlobalAttentionGeneral(nn.Module):
             if out is not None:
                 raise RuntimeError("training path does not write into channel-slice views")
             return WordAttention.apply(input, context, self.conv_context.weight, self.mask, self.correct_mask)
-        return ops.word_attention(input, context, self.conv_context.weight, self.mask, self.correct_mask, out=out,
-                                  src=src)
+        from . import custom_ops as C
+        if out is None:
+            return C.word_attention(input, context, self.conv_context.weight, self.mask, self.correct_mask, src)
+        return out, C.word_attention_out(input, context, self.conv_context.weight, self.mask, self.correct_mask, src, out)
 
 
 def func_attention(query, context, gamma1):

@@ -108,10 +108,8 @@ class NetG_highweight(nn.Module):
     def _head(self, out, SRb):
         if not self.useAct:
             raise NotImplementedError("useAct=False is never constructed by the reference's callers")
-        if self.training:
-            from .autograd import ConvTo3
-            return ConvTo3.apply(out, self.conv_output[0].weight, SRb, True, self._a)
-        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=self._a)
+        from . import custom_ops as C
+        return C.conv_to3(out, self.conv_output[0].weight, True, SRb, self._a)   # torch.ops.tgsr.conv_to3 (+ autograd)
 
     def trunk(self, LR, LRb):
         """Everything of forward() that does not need the low-frequency images: convin -> 6 ResBlocks -> the three

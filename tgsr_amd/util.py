@@ -13,6 +13,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import custom_ops as C            # registers torch.ops.tgsr.* (the PyTorch-ROCm custom operators over the C ABI)
 from . import ops
 from .GlobalAttention import GlobalAttentionGeneral as ATT_NET
 from .miscc.config import cfg
@@ -83,10 +84,15 @@ def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=
         return y
     if WINOGRAD and not upsample and _wino_pays(x, conv.out_channels, out, residual):
         upack, scale, shift = fp.get_wino(conv, bn, glu)
-        return ops.conv3x3_wino(x, upack, conv.out_channels, scale, shift, glu=glu, residual=residual, out=out)
+        if out is None:
+            return C.conv3x3_wino(x, upack, conv.out_channels, scale, shift, glu, residual)
+        C.conv3x3_wino_out(x, upack, conv.out_channels, scale, shift, glu, residual, out)
+        return out
     wpack, scale, shift = fp.get(conv, bn)
-    return ops.conv3x3_fused(x, wpack, conv.out_channels, scale, shift, glu=glu, upsample=upsample,
-                             residual=residual, out=out)
+    if out is None:
+        return C.conv3x3_fused(x, wpack, conv.out_channels, scale, shift, glu, upsample, residual)
+    C.conv3x3_fused_out(x, wpack, conv.out_channels, scale, shift, glu, upsample, residual, out)
+    return out
 
 
 def invalidate_caches(module: nn.Module):
@@ -154,8 +160,12 @@ class _UpBlock(nn.Sequential):
                 self._up_pack = (ops.pack_upwino_weight if wino else ops.pack_upconv_weight)(conv.weight)
                 self._up_aff = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
                 self._up_key = key
-            fn = ops.upwino_glu if wino else ops.upconv3x3_glu
-            return fn(x, self._up_pack, conv.out_channels, self._up_aff[0], self._up_aff[1], out=out)
+            if out is None:
+                return (C.upwino_glu if wino else C.upconv3x3_glu)(x, self._up_pack, conv.out_channels, self._up_aff[0],
+                                                                 self._up_aff[1])
+            (C.upwino_glu_out if wino else C.upconv3x3_glu_out)(x, self._up_pack, conv.out_channels, self._up_aff[0],
+                                                               self._up_aff[1], out)
+            return out
         return _conv_bn(x, self._fp, conv, bn, glu=True, upsample=True, out=out, training=self.training)
 
 
@@ -219,8 +229,7 @@ class _EncodeBy16(nn.Module):
         self.down3 = downBlock(ndf * 4, ndf * 8)
 
     def forward(self, x):
-        from .autograd import DownConv
-        return self.down3(self.down2(self.down1(DownConv.apply(x, self.conv0.weight, True))))
+        return self.down3(self.down2(self.down1(C.conv4x4s2(x, self.conv0.weight, True))))
 
 
 def encode_image_by_16times(ndf):
@@ -540,10 +549,7 @@ class GET_IMAGE_G_noAct(nn.Module):
         self.img = nn.Sequential(conv3x3(ngf, 3))
 
     def forward(self, h_code):
-        if self.training:
-            from .autograd import ConvTo3
-            return ConvTo3.apply(h_code, self.img[0].weight, None, False, 0.0)
-        return ops.conv_to3(h_code, self.img[0].weight)
+        return C.conv_to3(h_code, self.img[0].weight, False, None, 0.0)       # differentiable custom op (register_autograd)
 
 
 class GET_IMAGE_G(nn.Module):
@@ -555,7 +561,4 @@ class GET_IMAGE_G(nn.Module):
         self.img = nn.Sequential(conv3x3(ngf, 3), nn.Tanh())
 
     def forward(self, h_code):
-        if self.training:
-            from .autograd import ConvTo3
-            return ConvTo3.apply(h_code, self.img[0].weight, None, True, 0.0)
-        return ops.conv_to3(h_code, self.img[0].weight, tanh_axpy=True, addend=None, alpha=0.0)
+        return C.conv_to3(h_code, self.img[0].weight, True, None, 0.0)
