@@ -301,6 +301,26 @@ int tgsr_sumpool2x2(const float* x, int64_t BC, int H, int W, float* out, void* 
 int tgsr_to_uint8(const float* x, uint8_t* out, int64_t n, void* stream);
 
 /*
+ * The image pyramid of the reference's data loader on the GPU (datasets.py:151-197 get_imgs_blur, :236-278), byte-
+ * identical to the Pillow arithmetic it delegates to.  Images are planar uint8 [N][H][W] (N = batch x 3 planes).
+ *   tgsr_resize_bilinear_u8  transforms.Resize on a PIL image = PIL resize(BILINEAR): horizontal then vertical pass of
+ *       a triangle filter in 22-bit fixed point.  hbounds / vbounds: int32 [out][2] = (first input index, tap count);
+ *       hcoef / vcoef: int32 [out][hk | vk] taps (the host computes both in double exactly like Pillow's
+ *       precompute_coeffs; a pass whose size does not change is skipped and its tables may be NULL).  tmp: N*Hin*Wout
+ *       bytes when both passes run.
+ *   tgsr_gaussian_blur_u8    ImageFilter.GaussianBlur(radius): `passes` extended-box-blur passes per axis with integer
+ *       radius, centre weight ww and far-pixel weight fw in 24-bit fixed point (radius 2, 3 passes: 1, 4473924, 1677722);
+ *       clamped borders.  tmp: N*H*W bytes.  `in` may not alias `out` or `tmp`.
+ *   tgsr_u8_normalize        ToTensor + Normalize(0.5, 0.5): float32 (u8 / 255 - 0.5) / 0.5 (datasets.py:286-288).
+ */
+int tgsr_resize_bilinear_u8(const uint8_t* in, int N, int Hin, int Win, int Hout, int Wout, const int32_t* hbounds,
+                            const int32_t* hcoef, int hk, const int32_t* vbounds, const int32_t* vcoef, int vk,
+                            uint8_t* tmp, uint8_t* out, void* stream);
+int tgsr_gaussian_blur_u8(const uint8_t* in, int N, int H, int W, int radius, uint32_t ww, uint32_t fw, int passes,
+                          uint8_t* tmp, uint8_t* out, void* stream);
+int tgsr_u8_normalize(const uint8_t* in, float* out, int64_t n, void* stream);
+
+/*
  * Weight gradient of tgsr_conv3x3_fwd: dw[Cout][Cin][3][3] = sum over (b, y, x) of grad_out * shifted input
  * (upsample=1: the input is read through the folded nearest-x2, H/W are the PRE-upsample sizes).
  * grad_out [B][Cout][Ho][Wo] dense; x [B][Cin][H][W] with batch stride; Cout % 32 == 0.
@@ -413,8 +433,8 @@ int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, const float
 
 /*
  * The image heads on an lp image (tgsr_conv_to3_fwd's reference sites: GET_IMAGE_G_noAct util.py:913-915; conv_output
- * + `one*. + a*SRb` model.py:224, 280/288/297).  w [3][32][K][K] fp32 -> wpack (K*K*512 2-byte elements, the 3 output
- * channels padded to a 16-row MFMA fragment); x = channels [0, 32) of an lp image; addend / out fp32 [B][3][H][W] dense.
+ * + `one*. + a*SRb` model.py:224, 280/288/297).  w [3][32][K][K] fp32 -> wpack (K*512 2-byte elements: one 16-row MFMA
+ * fragment per kernel row whose rows are the (output channel, kernel column) pairs); x = channels [0, 32) of an lp image; addend / out fp32 [B][3][H][W] dense.
  * Cin == 32, K in {3, 5}, W % 32 == 0, H % 8 == 0.
  */
 int tgsr_lp_pack_to3_weight(int dtype, const float* w, void* wpack, int Cin, int K, void* stream);

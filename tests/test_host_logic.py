@@ -100,29 +100,39 @@ def test_models16_tied_stages_and_keys(cfg32):
 
 
 def test_committed_bench_lines_follow_the_contract():
-    """The JSON lines bench.py printed on the MI355X (committed under profiles/) carry every field of the driver's
-    contract, the roofline object and - on the default N=1 run - the CPU baseline."""
+    """The JSON lines bench.py printed on the MI355X this round (committed under profiles/) carry every field of the
+    driver's contract, an honest roofline object (frac = achieved / peak <= 1, counters looked up from a committed
+    rocprofv3 table) and - on the default N=1 runs - the CPU baseline."""
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r01_[k-z]_bench*.json")))
-    assert files, "no recent bench line committed"
-    saw_cpu = False
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r02d_bench_*.json")))
+    assert len(files) >= 6, "round-2 bench lines missing"
+    saw_cpu = saw_lp = saw_train = False
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                   "vs_baseline", "dtype", "data", "config", "roofline"):
             assert k in d, (f, k)
         assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-        assert d["dtype"] == "f32" and "workload" in d["config"] and "model" not in d["config"]
+        assert d["dtype"] in ("f32", "bf16", "f16") and "workload" in d["config"] and "model" not in d["config"]
         per_gpu = d["config"].get("batch_per_gpu", 16)
         assert abs(d["value"] - per_gpu * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
         r = d["roofline"]
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
             assert k in r, (f, k)
-        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
+        if "train" in os.path.basename(f):
+            saw_train = True
+        else:
+            assert "value_one_lane" in d and d["value_one_lane"] > 0
+        if d["dtype"] != "f32":
+            saw_lp = True
+            assert "channels-last" in d["config"]["storage"] and r["peak"] == 2500.0
         if "cpu_baseline" in d:
             saw_cpu = True
             c = d["cpu_baseline"]
             assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert saw_cpu
+    assert saw_cpu and saw_lp and saw_train
+    two = json.loads(open(os.path.join(root, "profiles", "r02d_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
+    assert two["n_gpus"] == 2                       # `bench.py --gpus 2` launched its two ranks itself

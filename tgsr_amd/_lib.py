@@ -60,6 +60,9 @@ SIGNATURES = {
     "tgsr_conv4x4s2_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tgsr_leaky_relu": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
+    "tgsr_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "tgsr_gaussian_blur_u8": (_i, [_vp, _i, _i, _i, _i, ctypes.c_uint32, ctypes.c_uint32, _i, _vp, _vp, _vp]),
+    "tgsr_u8_normalize": (_i, [_vp, _vp, _i64, _vp]),
     "tgsr_to_uint8": (_i, [_vp, _vp, _i64, _vp]),
     "tgsr_conv3x3_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),
     "tgsr_conv3x3_wgrad": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -20,6 +20,14 @@ def _dgrad_weight(w: torch.Tensor) -> torch.Tensor:
     return w.flip(2, 3).transpose(0, 1).contiguous()
 
 
+def _grad_out(param, shape, dev):
+    """Where a parameter gradient is written: the parameter's region of its flat gradient bucket when that is open
+    (parallel.grad_slot: no accumulation kernel afterwards), else a fresh tensor."""
+    from .parallel import grad_slot
+    slot = grad_slot(param) if param is not None else None
+    return slot if slot is not None else torch.empty(tuple(shape), dtype=torch.float32, device=dev)
+
+
 def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False) -> torch.Tensor:
     """conv3x3 without affine / activation (what BatchNorm's batch statistics are taken of, and the data gradient):
     the Winograd kernel where it applies (no up-sampling, Cout % 64 == 0, Cin % 4 == 0), else the direct kernel.
@@ -57,6 +65,7 @@ class ConvBnAct(torch.autograd.Function):
         check(rc, "tgsr_bn_train_fwd")
         ctx.save_for_backward(x, weight, raw, stats)
         ctx.cfg = (glu, upsample, residual is not None)
+        ctx.bn_params = (gamma, beta)          # only to look up their gradient slots (parallel.grad_slot) in backward
         return out
 
     @staticmethod
@@ -75,8 +84,8 @@ class ConvBnAct(torch.autograd.Function):
         ws = torch.empty(co * nsplit * 4, dtype=torch.float32, device=dev)
         sums = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
         draw = torch.empty_like(raw)
-        dgamma = torch.empty(Cout, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(Cout, dtype=torch.float32, device=dev)
+        gamma, beta = ctx.bn_params
+        dgamma, dbeta = _grad_out(gamma, (Cout,), dev), _grad_out(beta, (Cout,), dev)
         rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, Cout, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]),
                                  1 if glu else 0, _p(ws), _p(sums), _p(draw), _p(dgamma), _p(dbeta), _stream())
         check(rc, "tgsr_bn_train_bwd")
@@ -96,7 +105,7 @@ class ConvBnAct(torch.autograd.Function):
                 dx = dxu
         if ctx.needs_input_grad[1]:
             from . import util
-            dw = torch.empty_like(weight)
+            dw = _grad_out(weight, weight.shape, dev)
             if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
                 # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
                 # up-sampled grid)

@@ -17,9 +17,10 @@
 //               upBlock never exists;
 //   weights     streamed through LDS in chunks of (one kernel row = 3 taps) x 16 input channels x Cout, packed on the
 //               host side in exactly fragment order (a chunk is a linear copy, an A fragment a linear 1-KiB read),
-//               double buffered: chunk c+1 is in flight while chunk c feeds 3 * (Cout/32) * (TR/4) MFMAs per wave;
-//               one barrier per chunk.
-// LDS <= 67.5 KB (CIN 64, Cout 128, TR 8) -> two workgroups per CU; accumulators <= 128 registers.
+//               triple buffered: chunks c+1 and c+2 are in flight while chunk c feeds >= 24 MFMAs per wave (counted
+//               s_waitcnt vmcnt); one barrier per chunk.
+// LDS <= 79 KB (CIN 64, Cout 128, TR 8: 43 KB tile + 3 x 12 KB weight chunks) -> two workgroups per CU;
+// accumulators <= 128 registers.
 #include "tgsr_lp_common.h"
 
 namespace tgsr {
@@ -48,7 +49,7 @@ __device__ __forceinline__ int lp_swz(int c) {
 
 template <int CIN, int COUT, int TR>
 constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the CIN = 64 tiles are LDS-limited to 2 workgroups
-  return (CIN == 64 || (COUT / 32) * (TR / 4) * 16 >= 64) ? 2 : 4;
+  return (CIN == 64 || (COUT / 32) * (TR / 4) * 16 >= 64) ? 2 : 3;
 }
 
 template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
@@ -60,16 +61,21 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   // MFMAs per wave (768+ matrix-pipe cycles) - the LDS-DMA of the NEXT chunk has to land within one chunk's compute
   // (measured: with 12-MFMA chunks the Cout = 64 layers spent 71 % of their wave cycles parked on that wait)
   constexpr int NK16 = CIN / 16;
-  constexpr int KC16_WANT = (RW == 1 ? 2 : 1) * (128 / COUT > 1 ? 128 / COUT : 1);
+  constexpr int KC16_WANT = 128 / COUT > 1 ? 128 / COUT : 1;
   constexpr int KC16 = KC16_WANT < NK16 ? KC16_WANT : NK16;
+  // Three chunk buffers, chunk c+2 in flight while chunk c computes: an LDS-DMA takes ~1.1 us from issue to landed
+  // (MI355X_MICROARCH.md, ldsdma-fill) but a 24-MFMA chunk shared by two waves of a SIMD is only ~0.7 us of matrix
+  // pipe - with one chunk of look-ahead every chunk start waited for its weights (27 % of the wave cycles parked).
+  constexpr int NBUF = 3;
+  constexpr int WAVE_INSTR = (3 * NCB * KC16) / 4;               // weight DMAs per wave and chunk (at least)
   constexpr int STEP_BYTES = 3 * NCB * 1024;                     // one k16-step of a kernel row: [dx][cb][lane][8]
   constexpr int CHUNK_INSTR = 3 * NCB * KC16, CHUNK_BYTES = CHUNK_INSTR * 1024;
   constexpr int NKG = NK16 / KC16, NCH = 3 * NKG;
   static_assert(NK16 % KC16 == 0, "chunking");
-  __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + 2 * CHUNK_BYTES + COUT * 8];
+  __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + NBUF * CHUNK_BYTES];
   char* tile = smem;
   char* wbuf = smem + TILE_BYTES;
-  float* aff = reinterpret_cast<float*>(smem + TILE_BYTES + 2 * CHUNK_BYTES);
+  float* aff = reinterpret_cast<float*>(smem + TILE_BYTES + NBUF * CHUNK_BYTES - COUT * 8);   // written after the main loop
 
   const int tid = threadIdx.x, lane = tid & 63, c0 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,10 +117,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
     }
   };
   issue_w(0, 0);
-  if (tid < COUT) {
-    aff[tid] = a.scale ? a.scale[tid] : 1.f;
-    aff[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
-  }
+  if (NCH > 1) issue_w(1, 1);
 
   f32x16v acc[NCB][RW];
 #pragma unroll
@@ -132,16 +135,18 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    // my pieces of chunk ch (and, first time, of the input tile) have landed; after the barrier everybody's have, and
-    // everybody is done reading the other weight buffer (chunk ch-1)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // my pieces of chunk ch (and, first time, of the input tile) have landed - the DMAs of chunk ch+1 may still be in
+    // flight (VMEM completes in order: all but the youngest WAVE_INSTR operations are done); after the barrier
+    // everybody's pieces of chunk ch have, and everybody is done reading the buffer of chunk ch-1, which chunk ch+2 reuses
+    if (ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAVE_INSTR) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ch + 1 < NCH) issue_w(ch + 1, (ch + 1) & 1);
+    if (ch + 2 < NCH) issue_w(ch + 2, (ch + 2) % NBUF);
     const int dy = ch / NKG, kg = ch % NKG;                      // the pack is [dy][k16][dx][cb]: a chunk is contiguous
 #pragma unroll
     for (int kk = 0; kk < KC16; ++kk) {
       const int k16 = kg * KC16 + kk;
-      const char* wb = wbuf + (ch & 1) * CHUNK_BYTES + kk * STEP_BYTES + lane * 16;
+      const char* wb = wbuf + (ch % NBUF) * CHUNK_BYTES + kk * STEP_BYTES + lane * 16;
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         u32x4 af[NCB], bf[RW];
@@ -168,9 +173,15 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   constexpr int NOB = EPI == kEpiGlu ? NCB / 2 : NCB;
   constexpr int OC = NOB * 32, OB = OC * 2, NCHK = OB / 16;          // output channels, bytes and 16-byte chunks per pixel
   constexpr int STG_WAVE = RW * 32 * OB, STG_INSTR = STG_WAVE / 1024;
-  static_assert(4 * STG_WAVE <= TILE_BYTES + 2 * CHUNK_BYTES, "staging fits the dead tile + weight buffers");
+  static_assert(4 * STG_WAVE + COUT * 8 <= TILE_BYTES + NBUF * CHUNK_BYTES, "staging fits the dead tile + weight buffers");
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                     // every wave is done reading the tile / weights
+  if (tid < COUT) {
+    aff[tid] = a.scale ? a.scale[tid] : 1.f;
+    aff[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   char* stg = smem + wave * STG_WAVE;
   const int64_t orow = (int64_t)(a.W + 2) * a.ocp * 2;
   char* ob = a.out + ((int64_t)b * (a.H + 2) + y0 + wave * RW + 1) * orow + (int64_t)(x0 + 1) * (a.ocp * 2) + a.oco * 2;
@@ -248,11 +259,11 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
   constexpr int TRL = 4, TC = 34, NPIX = (TRL + 2) * TC, PB = CIN * 2, NSL = CIN / 8, COUT = 64;
   constexpr int TILE_SLOTS = NPIX * NSL, TILE_INSTR = (TILE_SLOTS + 63) / 64, TILE_BYTES = TILE_INSTR * 1024;
   constexpr int CHUNK_INSTR = 16, CHUNK_BYTES = CHUNK_INSTR * 1024;
-  constexpr int NK16 = CIN / 16, NCH = 2 * NK16;
-  __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + 2 * CHUNK_BYTES + COUT * 8];
+  constexpr int NK16 = CIN / 16, NCH = 2 * NK16, NBUF = 3, WAVE_INSTR = CHUNK_INSTR / 4;   // see lp_conv3x3_kernel
+  __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + NBUF * CHUNK_BYTES];
   char* tile = smem;
   char* wbuf = smem + TILE_BYTES;
-  float* aff = reinterpret_cast<float*>(smem + TILE_BYTES + 2 * CHUNK_BYTES);
+  float* aff = reinterpret_cast<float*>(smem + TILE_BYTES + NBUF * CHUNK_BYTES - COUT * 8);
   const int tid = threadIdx.x, lane = tid & 63, c0 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rp = wave >> 1, ph = wave & 1;
@@ -288,10 +299,7 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
     }
   };
   issue_w(0, 0);
-  if (tid < COUT) {
-    aff[tid] = a.scale ? a.scale[tid] : 1.f;
-    aff[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
-  }
+  issue_w(1, 1);
   f32x16v acc[2][2][2];                                          // [low-res row][column phase b][value | gate]
 #pragma unroll
   for (int rr = 0; rr < 2; ++rr)
@@ -309,11 +317,12 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
 
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAVE_INSTR) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ch + 1 < NCH) issue_w(ch + 1, (ch + 1) & 1);
+    if (ch + 2 < NCH) issue_w(ch + 2, (ch + 2) % NBUF);
     const int k16 = ch >> 1;
-    const char* wb = wbuf + (ch & 1) * CHUNK_BYTES + lane * 16 + ph * (8 * 1024);   // this row phase's 4 combos
+    const char* wb = wbuf + (ch % NBUF) * CHUNK_BYTES + lane * 16 + ph * (8 * 1024);   // this row phase's 4 combos
     if ((ch & 1) == 0) {                                          // outer columns: dx = -1 feeds b = 0, dx = +1 feeds b = 1
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb)
@@ -354,7 +363,13 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
   // epilogue through LDS (see lp_conv3x3_kernel): a wave owns two output rows (2 (y0 + 2 rp + rr) + ph) of 64 pixels x
   // 32 channels; staged [rr][64 pixels][64 bytes] with the 4 chunks of a pixel XOR-swizzled, stored as whole pixel rows
   constexpr int OB = 64, NCHK = 4, STG_WAVE = 2 * 64 * OB, STG_INSTR = STG_WAVE / 1024;
-  static_assert(4 * STG_WAVE <= TILE_BYTES + 2 * CHUNK_BYTES, "staging fits the dead tile + weight buffers");
+  static_assert(4 * STG_WAVE + COUT * 8 <= TILE_BYTES + NBUF * CHUNK_BYTES, "staging fits the dead tile + weight buffers");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (tid < COUT) {
+    aff[tid] = a.scale ? a.scale[tid] : 1.f;
+    aff[COUT + tid] = a.shift ? a.shift[tid] : 0.f;
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   char* stg = smem + wave * STG_WAVE;

@@ -138,7 +138,7 @@ def pack_to3_weight(w: torch.Tensor, dtype) -> torch.Tensor:
     if w.dtype != torch.float32 or w.dim() != 4 or w.shape[0] != 3 or w.shape[2] != w.shape[3]:
         raise TgsrError("pack_to3_weight: weight %s" % (tuple(w.shape),))
     K = int(w.shape[2])
-    out = torch.empty(K * K * 512, dtype=torch_dtype(dtype), device=w.device)
+    out = torch.empty(K * 512, dtype=torch_dtype(dtype), device=w.device)
     check(_lib.lib().tgsr_lp_pack_to3_weight(DT[out.dtype], _p(w), _p(out), int(w.shape[1]), K, _stream()),
           "tgsr_lp_pack_to3_weight")
     return out

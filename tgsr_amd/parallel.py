@@ -52,6 +52,28 @@ def shard_batch(rank: int, world: int, captions: torch.Tensor, cap_lens: torch.T
     return (captions[sel], lens[lo:hi]) + tuple(t[sel] for t in per_sample) + (sel,)
 
 
+# Direct gradient slots: data_ptr of a parameter -> (bucket, index).  The HIP backward Functions (autograd.ConvBnAct, ...)
+# ask `grad_slot(param)` for the parameter's region of its flat bucket and let their weight-gradient kernels write
+# there; autograd's AccumulateGrad then adopts that tensor as `.grad` without an add kernel (it only adds when a `.grad`
+# already exists).  Profile of the round-1 train step: 148 elementwise adds per step (0.78 ms) were exactly these
+# accumulations into pre-set `.grad` views.
+_SLOTS = {}
+
+
+def grad_slot(param: torch.Tensor):
+    """A fresh view of `param`'s gradient region in its bucket when the bucket runs in direct mode and the region has
+    not been written this step; else None (the caller allocates as usual and autograd accumulates)."""
+    hit = _SLOTS.get(param.data_ptr())
+    if hit is None:
+        return None
+    bucket, i = hit
+    if not bucket.direct or bucket.filled[i]:
+        return None
+    bucket.filled[i] = True
+    off, n = bucket.offsets[i]
+    return bucket.flat[off:off + n].view(bucket.params[i].shape)   # a NEW tensor object: autograd may adopt it
+
+
 class FlatGradBucket:
     """All gradients of `params` in one flat fp32 buffer; `all_reduce_mean()` = one collective per step."""
 
@@ -62,10 +84,13 @@ class FlatGradBucket:
         dev, dt = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
-        self.views, off = [], 0
+        self.views, self.offsets, off = [], [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            self.offsets.append((off, p.numel()))
             off += p.numel()
+        self.direct = False
+        self.filled = [False] * len(self.params)
 
     def attach(self):
         """Make every p.grad a view of the flat buffer, so backward writes straight into the bucket (no packing)."""
@@ -73,6 +98,26 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
         return self
+
+    def begin_step(self):
+        """Direct mode: zero the bucket, clear every `.grad` and open the slots.  The backward kernels then write weight
+        gradients straight into the bucket (grad_slot) and autograd adopts those tensors as `.grad`."""
+        self.direct = True
+        self.flat.zero_()
+        for i, p in enumerate(self.params):
+            p.grad = None
+            self.filled[i] = False
+            _SLOTS[p.data_ptr()] = (self, i)
+
+    def end_step(self):
+        """After backward: every `.grad` becomes its bucket view - adopted slots already are (same memory), gradients
+        that arrived through other paths are copied in, parameters that received none read zeros."""
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+            p.grad = v
+        self.direct = False
 
     def pack(self):
         for p, v in zip(self.params, self.views):

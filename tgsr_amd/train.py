@@ -85,9 +85,9 @@ class SRTrainer:
 
     @staticmethod
     def _zero(bucket):
-        bucket.flat.zero_()                           # p.grad are views of the flat bucket (attach()): one memset
-        for p, v in zip(bucket.params, bucket.views):
-            p.grad = v
+        """Open a step: one memset of the flat bucket; `.grad` cleared and the gradient slots opened, so the weight-
+        gradient kernels write straight into the bucket (parallel.grad_slot) instead of autograd adding into views."""
+        bucket.begin_step()
 
     def forward_G(self, captions, cap_lens, LR, LRb):
         """Text encoder (frozen) + both generators in training mode: (fake_imgL, fine_im, mu, logvar, words, sent)."""
@@ -123,6 +123,7 @@ class SRTrainer:
         errsD = self.d_losses(fine_im, hr_pyramid, sent_emb)
         for e, b, o in zip(errsD, self.bucketsD, self.optsD):
             e.backward()
+            b.end_step()
             b.all_reduce_mean()
             o.step()
         self._zero(self.bucket)
@@ -130,6 +131,9 @@ class SRTrainer:
             self._zero(b)                             # parameters; they are discarded (zeroed again next step)
         errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
         errG.backward()
+        self.bucket.end_step()
+        for b in self.bucketsD:
+            b.end_step()
         self.bucket.all_reduce_mean()
         self.opt.step()
         with torch.no_grad():
@@ -145,6 +149,7 @@ class SRTrainer:
         self._zero(self.bucket)
         errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
         errG.backward()
+        self.bucket.end_step()
         self.bucket.all_reduce_mean()
         self.opt.step()
         with torch.no_grad():

@@ -1,0 +1,32 @@
+#!/bin/bash
+# Final measurement set of a round (run on the GPU box through gpurun):  bash tools/final_profiles.sh <round tag>
+# bench lines (default fp32, bf16 graph, f16 graph, bf16 eager lanes, bf16 B=8 graph, train) + rocprofv3 stats / PMC of
+# the fp32 and bf16 paths.  Everything lands in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+set -e
+TAG=${1:-r02z}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+cd $ROOT
+python3 bench.py > $OUT/${TAG}_bench_fp32.json 2> $OUT/${TAG}_bench_fp32.err
+echo "fp32 done"
+python3 bench.py --dtype bf16 --graph > $OUT/${TAG}_bench_bf16_graph.json 2> $OUT/${TAG}_bench_bf16_graph.err
+echo "bf16 graph done"
+python3 bench.py --dtype f16 --graph --no-cpu-baseline > $OUT/${TAG}_bench_f16_graph.json 2> $OUT/${TAG}_bench_f16_graph.err
+python3 bench.py --dtype bf16 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_lanes.json 2> $OUT/${TAG}_bench_bf16_lanes.err
+python3 bench.py --dtype bf16 --graph --batch 8 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b8.json 2> $OUT/${TAG}_bench_bf16_graph_b8.err
+python3 bench.py --dtype bf16 --graph --batch 64 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b64.json 2> $OUT/${TAG}_bench_bf16_graph_b64.err
+echo "lp variants done"
+python3 bench.py --mode train --steps 10 > $OUT/${TAG}_bench_train.json 2> $OUT/${TAG}_bench_train.err
+echo "train done"
+TGSR_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_rehearsal_2ranks.json 2> $OUT/${TAG}_bench_rehearsal.err || echo "rehearsal failed"
+bash tools/profile_pmc.sh ${TAG}_fp32 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial
+bash tools/profile_pmc.sh ${TAG}_bf16 --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial
+for f in $OUT/${TAG}_bench_*.json; do python3 -c "
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1].split('/')[-1], d['value'], d['ms_per_step'], d.get('value_one_lane'), (d.get('roofline') or {}).get('frac'))
+except Exception as e:
+    print(sys.argv[1], 'unreadable', e)
+" $f; done
