@@ -229,7 +229,7 @@ def bench_train(args, rank, world, dist, dev, weights):
     loss, HIP backward, one flat-bucket gradient all-reduce (N > 1), Adam, EMA.  Synthetic HR targets U(-1, 1)."""
     from tgsr_amd.synthetic import synthetic_batch
     from tgsr_amd.train import SRTrainer
-    tr = SRTrainer(41, device=dev)
+    tr = SRTrainer(41, device=dev, discriminators=args.gan)
     if weights is not None:
         tr.text_encoder.load_state_dict(weights["E."])
         tr.netGL.load_state_dict(weights["GL."])
@@ -260,12 +260,16 @@ def bench_train(args, rank, world, dist, dev, weights):
         dt = float(t.item())
     if rank == 0:
         print(json.dumps({
-            "metric": "SR generator train images/sec (32->256, batch 16 per GPU, fwd+bwd+Adam)",
+            "metric": ("SR G/D alternation train images/sec (32->256, batch 16 per GPU, 3 discriminators + generators, Adam)"
+                       if args.gan else "SR generator train images/sec (32->256, batch 16 per GPU, fwd+bwd+Adam)"),
             "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic inputs and HR targets",
-            "config": {"workload": "CelebA x8 generator train step (G_SR_NET_low + NetG_highweight, train-mode BN, MSE+KL, "
-                                   "Adam; no discriminator / DAMSM terms: not defined by the reference), batch=16 per GPU",
+            "config": {"workload": ("CelebA x8 G/D alternation (losses.py:290-374 with D_NET64/128/256 as DESIGN.md 3.9 declares "
+                                    "them: three discriminator updates on (real, fake.detach()), then the generator update "
+                                    "through them + MSE + KL), batch=16 per GPU" if args.gan else
+                                    "CelebA x8 generator train step (G_SR_NET_low + NetG_highweight, train-mode BN, MSE+KL, "
+                                    "Adam; no discriminator / DAMSM terms), batch=16 per GPU"),
                        "batch_per_gpu": B, "parallelism": "dp%d" % world, "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)},
             "final_loss": round(float(loss), 5),
             # whole-step figure: the conv kernels of forward, data gradient and weight gradient are ~3x the forward's
@@ -277,8 +281,11 @@ def bench_train(args, rank, world, dist, dev, weights):
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(3 * CONV_GFLOP_PER_IMAGE * B * args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                          "traffic": None,
-                         "note": "algorithmic (direct-form) FLOPs / step time; per-kernel shares: profiles/*train*kernel_stats*"},
-            **({"cpu_baseline": cpu_baseline_train(weights, min(B, 4))} if world == 1 and not args.no_cpu_baseline else {}),
+                         "note": "algorithmic (direct-form) FLOPs / step time; per-kernel shares: profiles/*train*kernel_stats*"
+                                 + ("; --gan: the numerator still counts the GENERATOR convolutions only (the discriminators' "
+                                    "4x4 stride-2 convolutions add work that is not credited)" if args.gan else "")},
+            **({"cpu_baseline": cpu_baseline_train(weights, min(B, 4))}
+               if world == 1 and not args.no_cpu_baseline and not args.gan else {}),
         }), flush=True)
     if dist is not None:
         dist.barrier()
@@ -366,6 +373,7 @@ def main():
     ap.add_argument("--mode", choices=("infer", "train", "damsm"), default="infer",
                     help="infer = the headline (BASELINE configs[1]); train = generator fwd+bwd+Adam step on MSE+KL "
                          "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
+    ap.add_argument("--gan", action="store_true", help="--mode train with the three discriminators (G/D alternation)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (inference mode)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="inference: consecutive steps alternate between this many stream lanes (1 = one step at a time)")

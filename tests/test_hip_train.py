@@ -78,7 +78,11 @@ def test_conv_bn_act_train_fwd_bwd(B, Cin, H, W, Cout, glu, up, res):
 
 
 @pytest.mark.parametrize("B,Cin,H,W,K,act", [(2, 32, 32, 64, 3, False), (2, 32, 32, 64, 5, True), (3, 32, 19, 70, 5, True),
-                                              (1, 32, 64, 64, 3, False), (2, 20, 16, 16, 5, True)])
+                                              (1, 32, 64, 64, 3, False), (2, 20, 16, 16, 5, True),
+                                              # MFMA weight gradient: ragged tile (W = 48, H % 4 != 0), Cin 16 / 64, and
+                                              # the taller wave tiles big launches pick (2 and 4 rows per wave)
+                                              (2, 64, 41, 48, 3, False), (2, 16, 24, 32, 5, True), (3, 48, 18, 80, 5, False),
+                                              (8, 32, 256, 256, 5, True), (16, 32, 256, 256, 3, False)])
 def test_conv_to3_backward(B, Cin, H, W, K, act):
     from tgsr_amd.autograd import ConvTo3
     g = torch.Generator().manual_seed(K * 10 + H)

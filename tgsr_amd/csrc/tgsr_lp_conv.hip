@@ -52,6 +52,9 @@ constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the
   return (CIN == 64 || (COUT / 32) * (TR / 4) * 16 >= 64) ? 2 : 3;
 }
 
+#ifndef LP_DBG
+#define LP_DBG 0   // timing experiments only (tools/lp_conv_experiments.sh): bits switch parts of the kernel off
+#endif
 template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
 __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
   constexpr int NCB = COUT / 32, RW = TR / 4, TC = 34, NPIX = (TR + 2) * TC;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 #pragma unroll
     for (int k = 0; k < (TILE_INSTR + 3) / 4; ++k) {
       const int ins = wave + 4 * k;
-      if (ins < TILE_INSTR) {                                   // wave-uniform
+      if (ins < TILE_INSTR && (!(LP_DBG & 16) || k == 0)) {     // wave-uniform
         const int S = ins * 64 + lane;
         int pix = S / NSL;
         const int ps = S % NSL;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
     if (ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAVE_INSTR) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ch + 2 < NCH) issue_w(ch + 2, (ch + 2) % NBUF);
+    if (ch + 2 < NCH && !(LP_DBG & 1)) issue_w(ch + 2, (ch + 2) % NBUF);
     const int dy = ch / NKG, kg = ch % NKG;                      // the pack is [dy][k16][dx][cb]: a chunk is contiguous
 #pragma unroll
     for (int kk = 0; kk < KC16; ++kk) {
@@ -151,10 +154,12 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
       for (int dx = 0; dx < 3; ++dx) {
         u32x4 af[NCB], bf[RW];
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) af[cb] = *reinterpret_cast<const u32x4*>(wb + (dx * NCB + cb) * 1024);
+        for (int cb = 0; cb < NCB; ++cb)
+          af[cb] = *reinterpret_cast<const u32x4*>((LP_DBG & 8) ? wbuf + lane * 16 + cb * 1024 : wb + (dx * NCB + cb) * 1024);
 #pragma unroll
         for (int pr = 0; pr < RW; ++pr)
-          bf[pr] = *reinterpret_cast<const u32x4*>(tile + (bbase[dx] ^ (k16 << 5)) + (pr + dy) * TC * PB);
+          bf[pr] = *reinterpret_cast<const u32x4*>((LP_DBG & 4) ? tile + bbase[0] + pr * TC * PB
+                                                                : tile + (bbase[dx] ^ (k16 << 5)) + (pr + dy) * TC * PB);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   for (int j = 0; j < STG_INSTR; ++j) {
     const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ (pw & (NCHK - 1));
     const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
-    *reinterpret_cast<u32x4*>(ob + (pw >> 5) * orow + (int64_t)(pw & 31) * (a.ocp * 2) + q * 16) = v;
+    if (!(LP_DBG & 2) || j == 0) *reinterpret_cast<u32x4*>(ob + (pw >> 5) * orow + (int64_t)(pw & 31) * (a.ocp * 2) + q * 16) = v;
   }
 }
 

@@ -27,12 +27,14 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--direct-up", action="store_true", help="upBlocks by the direct 9-tap form instead of sub-pixel")
+    ap.add_argument("--layers", default="", help="comma-separated indices into LAYERS (default: all)")
     a = ap.parse_args()
+    layers = [LAYERS[int(i)] for i in a.layers.split(",")] if a.layers else LAYERS
     dev, B = "cuda", a.batch
     g = torch.Generator().manual_seed(0)
     tot_us = tot_fl = 0.0
     print("cin cout  H   glu up res |   us/launch  TFLOP/s  GB/s(alg) | x launches")
-    for cin, cout, H, glu, up, res, n in LAYERS:
+    for cin, cout, H, glu, up, res, n in layers:
         Hi = H // 2 if up else H
         x = lp.from_nchw(torch.randn(B, cin, Hi, Hi, generator=g).to(dev), a.dtype)
         w = lp.pack_conv3x3_weight((torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev), a.dtype)
