@@ -49,6 +49,10 @@ const char* tgsr_last_error(void);
  */
 int64_t tgsr_packed_weight_elems(int Cout, int Cin, int K);
 int tgsr_pack_conv_weight(const float* w, float* wpack, int Cout, int Cin, int K, void* stream);
+/* The pack of the DATA-GRADIENT convolution straight from the forward conv's weight: w is [Cin][Cout][K][K] (the forward
+ * layer maps Cout -> Cin channels) and the packed filter is w'[co][ci][ky][kx] = w[ci][co][K-1-ky][K-1-kx] - what
+ * autograd's conv_transpose of a stride-1 "same" convolution computes; no flip / transpose / copy kernels. */
+int tgsr_pack_conv_weight_dgrad(const float* w, float* wpack, int Cout, int Cin, int K, void* stream);
 
 /*
  * BatchNorm2d (eval) as a per-channel affine: scale = weight / sqrt(running_var + eps),
@@ -116,6 +120,9 @@ int tgsr_upwino_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, in
  */
 int64_t tgsr_packed_wino_weight_elems(int Cout, int Cin);
 int tgsr_pack_wino_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream);
+/* Winograd pack of the data-gradient convolution from the forward weight [Cin][Cout][3][3] (see
+ * tgsr_pack_conv_weight_dgrad); plain channel order (no GLU grouping). */
+int tgsr_pack_wino_weight_dgrad(const float* w, float* upack, int Cout, int Cin, void* stream);
 int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
                           const float* scale, const float* shift, const float* residual, int64_t res_bstride,
                           float* out, int64_t out_bstride, int epilogue, void* stream);
@@ -254,12 +261,13 @@ int tgsr_bn_train_nsplit(int B, int C, int HW);
  * both NULL or both given), y = GLU(bn(raw)) (glu=1, C even, out has C/2 channels) or bn(raw) (+ residual).
  * `glu` is the activation selector: 0 = none (+ residual), 1 = GLU, 2 = LeakyReLU(0.2) (downBlock util.py:92-98 and
  * the discriminators' conv3x3 -> BN -> LeakyReLU blocks; no residual).
- * raw [B][C][HW] dense, HW % 4 == 0.  Saves mean/invstd/scale/shift [C] for the backward.
+ * raw [B][C][HW] dense, HW % 4 == 0.  Saves mean/invstd/scale/shift [C] for the backward.  num_batches_tracked (device
+ * int64 scalar, may be NULL) is incremented by one, as nn.BatchNorm2d.forward does in training mode.
  */
 int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, int glu, const float* residual,
                       int64_t res_bstride, float* partial_ws, float* mean, float* invstd, float* scale, float* shift,
-                      float* out, int64_t out_bstride, void* stream);
+                      float* out, int64_t out_bstride, int64_t* num_batches_tracked, void* stream);
 
 /*
  * Backward of the above: dout [B][C or C/2][HW] dense -> draw [B][C][HW] (gradient wrt the raw conv output),

@@ -62,7 +62,9 @@ def test_conv_bn_act_train_fwd_bwd(B, Cin, H, W, Cout, glu, up, res):
     xd, wd, gd, bd = (t.to(DEV).requires_grad_() for t in (x, w, gamma, beta))
     rd = r.to(DEV).requires_grad_() if res else None
     rmd, rvd = rm.to(DEV), rv.to(DEV)
-    out = ConvBnAct.apply(xd, wd, gd, bd, rmd, rvd, rd, glu, up, 0.1, 1e-5)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    out = ConvBnAct.apply(xd, wd, gd, bd, rmd, rvd, rd, glu, up, 0.1, 1e-5, nbt)
+    assert int(nbt) == 1
     out.backward(dy.to(DEV))
     close(out, y, atol=5e-5)
     close(rmd, upd["running_mean"], atol=1e-5)

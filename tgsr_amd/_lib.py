@@ -25,6 +25,7 @@ SIGNATURES = {
     "tgsr_last_error": (ctypes.c_char_p, []),
     "tgsr_packed_weight_elems": (_i64, [_i, _i, _i]),
     "tgsr_pack_conv_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tgsr_pack_conv_weight_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tgsr_bn_fold": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp]),
     "tgsr_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "tgsr_packed_upconv_weight_elems": (_i64, [_i, _i]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     "tgsr_upwino_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp]),
     "tgsr_packed_wino_weight_elems": (_i64, [_i, _i]),
     "tgsr_pack_wino_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tgsr_pack_wino_weight_dgrad": (_i, [_vp, _vp, _i, _i, _vp]),
     "tgsr_wino_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
     "tgsr_conv_to3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),
     "tgsr_word_attention_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp]),
@@ -53,7 +55,7 @@ SIGNATURES = {
     "tgsr_linear_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "tgsr_bn_train_nsplit": (_i, [_i, _i, _i]),
     "tgsr_bn_train_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
-                               _i64, _vp]),
+                               _i64, _vp, _vp]),
     "tgsr_bn_train_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_conv4x4s2_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "tgsr_conv4x4s2_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),

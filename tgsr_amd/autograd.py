@@ -28,22 +28,25 @@ def _grad_out(param, shape, dev):
     return slot if slot is not None else torch.empty(tuple(shape), dtype=torch.float32, device=dev)
 
 
-def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False) -> torch.Tensor:
+def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgrad: bool = False) -> torch.Tensor:
     """conv3x3 without affine / activation (what BatchNorm's batch statistics are taken of, and the data gradient):
     the Winograd kernel where it applies (no up-sampling, Cout % 64 == 0, Cin % 4 == 0), else the direct kernel.
-    The weights change every step, so they are packed per call (a few microseconds)."""
+    The weights change every step, so they are packed per call (a few microseconds).  `dgrad`: `weight` is the forward
+    layer's [Cin_of_x... = weight.shape[0]] filter and the conv applied is its transpose (pack kernels read it
+    transposed and flipped: no flip / transpose / copy kernels)."""
     from . import util
-    Cout = weight.shape[0]
+    Cout = weight.shape[1] if dgrad else weight.shape[0]
     if util.WINOGRAD and not upsample and util._wino_pays(x, Cout, None, None):
-        return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False), Cout, None, None)
+        return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False, dgrad=dgrad), Cout, None, None)
     if util.WINOGRAD and upsample and ops.upwino_supported(x, Cout):
+        assert not dgrad
         return ops.upwino_glu(x, ops.pack_upwino_weight(weight, glu=False), Cout, None, None, glu=False)
-    return ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), Cout, None, None, glu=False, upsample=upsample)
+    return ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight, dgrad=dgrad), Cout, None, None, glu=False, upsample=upsample)
 
 
 class ConvBnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps, nbt=None):
         L = _lib.lib()
         x = x.contiguous()
         B, Cin, H, W = x.shape
@@ -61,7 +64,7 @@ class ConvBnAct(torch.autograd.Function):
         rc = L.tgsr_bn_train_fwd(_p(raw), B, Cout, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
                                  float(momentum), _p(running_mean), _p(running_var), 1 if glu else 0, _p(res),
                                  0 if res is None else co * HW, _p(ws), _p(stats[0]), _p(stats[1]), _p(stats[2]),
-                                 _p(stats[3]), _p(out), co * HW, _stream())
+                                 _p(stats[3]), _p(out), co * HW, _p(nbt), _stream())
         check(rc, "tgsr_bn_train_fwd")
         ctx.save_for_backward(x, weight, raw, stats)
         ctx.cfg = (glu, upsample, residual is not None)
@@ -91,13 +94,13 @@ class ConvBnAct(torch.autograd.Function):
         check(rc, "tgsr_bn_train_bwd")
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wT = _dgrad_weight(weight.detach())                           # [Cin, Cout, 3, 3]
             cpad = (Cin + 31) // 32 * 32                                  # the kernel tiles 32 output channels
             if cpad != Cin:                                               # stem convs (Cin = 3): zero-padded rows
+                wT = _dgrad_weight(weight.detach())                       # [Cin, Cout, 3, 3]
                 wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cout, 3, 3)), 0)
-            dxu = _conv_raw(draw, wT)
-            if cpad != Cin:
-                dxu = dxu[:, :Cin].contiguous()                           # [B, Cin, Ho, Wo]
+                dxu = _conv_raw(draw, wT)[:, :Cin].contiguous()           # [B, Cin, Ho, Wo]
+            else:
+                dxu = _conv_raw(draw, weight.detach(), dgrad=True)
             if upsample:
                 dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dev)
                 check(L.tgsr_sumpool2x2(_p(dxu), B * Cin, H, W, _p(dx), _stream()), "tgsr_sumpool2x2")
@@ -124,7 +127,17 @@ class ConvBnAct(torch.autograd.Function):
                                           _p(wws), _p(dw), _stream())
                 check(rc, "tgsr_conv3x3_wgrad")
         dres = dout if has_res else None
-        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+def _nbt(bn):
+    """bn.num_batches_tracked when the kernel can bump it in place (int64 scalar on the device), else None."""
+    t = bn.num_batches_tracked if bn.track_running_stats else None
+    if t is None:
+        return None
+    if t.dtype != torch.int64 or not t.is_cuda:
+        raise RuntimeError("BatchNorm num_batches_tracked must be an int64 tensor on the GPU")
+    return t
 
 
 def conv_bn_act_train(x, conv, bn, glu=False, upsample=False, residual=None):
@@ -133,14 +146,13 @@ def conv_bn_act_train(x, conv, bn, glu=False, upsample=False, residual=None):
         raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the reference")
     out = ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                           bn.running_var if bn.track_running_stats else None, residual, glu, upsample, bn.momentum,
-                          bn.eps)
+                          bn.eps, _nbt(bn))
     if bn.track_running_stats:
-        # tgsr_bn_train_fwd wrote the running statistics through raw pointers: tell autograd's version counters, which
-        # the eval-mode caches (util._FusedParams, lp_pipeline.LpExecutor) key their folded affines on
+        # tgsr_bn_train_fwd wrote the running statistics (and num_batches_tracked) through raw pointers: tell autograd's
+        # version counters, which the eval-mode caches (util._FusedParams, lp_pipeline.LpExecutor) key their folded
+        # affines on
         torch.autograd.graph.increment_version(bn.running_mean)
         torch.autograd.graph.increment_version(bn.running_var)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
     return out
 
 
@@ -169,7 +181,7 @@ class ConvBnLeaky(torch.autograd.Function):
     tgsr_bn_train_fwd / _bwd(act = 2); the 3x3 convolution and its gradients are the generator's fp32 kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, momentum, eps):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, momentum, eps, nbt=None):
         L = _lib.lib()
         x = x.contiguous()
         raw = ops.conv4x4s2(x, weight) if kind == "down" else \
@@ -182,7 +194,7 @@ class ConvBnLeaky(torch.autograd.Function):
         out = torch.empty_like(raw)
         rc = L.tgsr_bn_train_fwd(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum),
                                  _p(running_mean), _p(running_var), 2, None, 0, _p(ws), _p(stats[0]), _p(stats[1]),
-                                 _p(stats[2]), _p(stats[3]), _p(out), C * HW, _stream())
+                                 _p(stats[2]), _p(stats[3]), _p(out), C * HW, _p(nbt), _stream())
         check(rc, "tgsr_bn_train_fwd")
         ctx.save_for_backward(x, weight, raw, stats)
         ctx.kind = kind
@@ -225,18 +237,16 @@ class ConvBnLeaky(torch.autograd.Function):
                 wws = torch.empty(L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, C, H, W, 0), dtype=torch.float32, device=dev)
                 check(L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, C, 0, _p(wws), _p(dw), _stream()),
                       "tgsr_conv3x3_wgrad")
-        return dx, dw, dgamma, dbeta, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
 
 
 def conv_bn_leaky_train(x, conv, bn, kind):
     """Training-mode conv + BatchNorm + LeakyReLU(0.2) over the parameter-holder modules."""
     out = ConvBnLeaky.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                            bn.running_var if bn.track_running_stats else None, kind, bn.momentum, bn.eps)
+                            bn.running_var if bn.track_running_stats else None, kind, bn.momentum, bn.eps, _nbt(bn))
     if bn.track_running_stats:
         torch.autograd.graph.increment_version(bn.running_mean)
         torch.autograd.graph.increment_version(bn.running_var)
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked += 1
     return out
 
 

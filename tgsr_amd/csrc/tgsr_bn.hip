@@ -64,8 +64,10 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __res
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nsplit, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* running_mean, float* running_var, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   long long* num_batches_tracked) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
   for (int k = 0; k < nsplit; ++k) {
@@ -255,7 +257,7 @@ extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const f
                                  float eps, float momentum, float* running_mean, float* running_var, int glu,
                                  const float* residual, int64_t res_bstride, float* partial_ws, float* mean,
                                  float* invstd, float* scale, float* shift, float* out, int64_t out_bstride,
-                                 void* stream) {
+                                 int64_t* num_batches_tracked, void* stream) {
   if (!raw || !gamma || !beta || !partial_ws || !mean || !invstd || !scale || !shift || !out) return TGSR_EINVAL;
   if (glu < 0 || glu > 2) return TGSR_EINVAL;             // `glu` is the activation selector: 0 none, 1 GLU, 2 LeakyReLU(0.2)
   const int leaky = glu == 2 ? 1 : 0;
@@ -268,7 +270,8 @@ extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const f
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C, nsplit), dim3(kBnThreads), 0, s, raw, (int64_t)C * HW, B, HW,
                      partial_ws, nsplit);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
-                     (double)B * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+                     (double)B * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
+                     reinterpret_cast<long long*>(num_batches_tracked));
   const int Co = glu ? C / 2 : C;
   const int g = grid_for((int64_t)B * Co * (HW / 4));
   if (glu)

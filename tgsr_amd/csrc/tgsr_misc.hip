@@ -14,8 +14,10 @@ int note_launch(hipError_t e, const char* what) {
 }
 
 // wpack[chunk][tap][ci][Cout] <- w[Cout][Cin][K][K]; channels past Cin are zero.
+// tr != 0: the source is the FORWARD conv's weight [Cin][Cout][K][K] and the pack is of the data-gradient conv
+// w'[co][c][tap] = w[c][co][KK - 1 - tap] (in/out swapped, taps flipped) - no flip/transpose/copy kernels beforehand
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int KK,
-                                        int64_t total) {
+                                        int tr, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int co = (int)(i % Cout);
     int64_t t = i / Cout;
@@ -24,7 +26,7 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
     const int tap = (int)(t % KK);
     const int chunk = (int)(t / KK);
     const int c = chunk * kConvCK + ci;
-    wp[i] = c < Cin ? w[((int64_t)co * Cin + c) * KK + tap] : 0.f;
+    wp[i] = c < Cin ? (tr ? w[((int64_t)c * Cout + co) * KK + (KK - 1 - tap)] : w[((int64_t)co * Cin + c) * KK + tap]) : 0.f;
   }
 }
 
@@ -71,13 +73,21 @@ extern "C" int64_t tgsr_packed_weight_elems(int Cout, int Cin, int K) {
   return (int64_t)((Cin + kConvCK - 1) / kConvCK) * K * K * kConvCK * Cout;
 }
 
-extern "C" int tgsr_pack_conv_weight(const float* w, float* wpack, int Cout, int Cin, int K, void* stream) {
+static int pack_conv_weight(const float* w, float* wpack, int Cout, int Cin, int K, int tr, void* stream) {
   if (!w || !wpack || Cout < 1 || Cin < 1 || K < 1) return TGSR_EINVAL;
   const int64_t total = tgsr_packed_weight_elems(Cout, Cin, K);
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, wpack, Cout, Cin,
-                     K * K, total);
+                     K * K, tr, total);
   return note_launch(hipGetLastError(), "pack_conv_weight_kernel");
+}
+
+extern "C" int tgsr_pack_conv_weight(const float* w, float* wpack, int Cout, int Cin, int K, void* stream) {
+  return pack_conv_weight(w, wpack, Cout, Cin, K, 0, stream);
+}
+
+extern "C" int tgsr_pack_conv_weight_dgrad(const float* w, float* wpack, int Cout, int Cin, int K, void* stream) {
+  return pack_conv_weight(w, wpack, Cout, Cin, K, 1, stream);
 }
 
 extern "C" int tgsr_bn_fold(const float* weight, const float* bias, const float* running_mean,

@@ -400,8 +400,10 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
 // of one workgroup (nh = 2 when Cout % 64 == 0, else 1); element q of a 4-vector = position 2*pp + (q >> 1), cout block
 // q & 1 of the half (GLU: block 0 = value channels grp*16*nh + half*16 + l, block 1 = their gates Cout/2 + ...;
 // plain: grp*32*nh + half*32 + block*16 + l).
+// tr != 0: the source is the FORWARD conv's weight [Cin][Cout][3][3]; the pack is of the data-gradient conv
+// w'[co][c][r][k] = w[c][co][2 - r][2 - k]
 __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu,
-                                        int nh, int64_t total) {
+                                        int nh, int tr, int64_t total) {
   const int ngrp = Cout / (32 * nh);
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int q = (int)(idx & 3), l = (int)((idx >> 2) & 15), hh = nh == 2 ? (int)((idx >> 6) & 1) : 0;
@@ -419,10 +421,10 @@ __global__ void pack_wino_weight_kernel(const float* __restrict__ w, float* __re
     float u = 0.f;
     if (c < Cin) {
       const int i = pos >> 2, j = pos & 3;
-      const float* g = w + ((int64_t)co * Cin + c) * 9;
+      const float* g = tr ? w + ((int64_t)c * Cout + co) * 9 : w + ((int64_t)co * Cin + c) * 9;
       float gi[3];   // row i of G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] applied to the filter rows
       for (int k = 0; k < 3; ++k) {
-        const float g0 = g[0 * 3 + k], g1 = g[1 * 3 + k], g2 = g[2 * 3 + k];
+        const float g0 = tr ? g[8 - k] : g[0 * 3 + k], g1 = tr ? g[5 - k] : g[1 * 3 + k], g2 = tr ? g[2 - k] : g[2 * 3 + k];
         gi[k] = i == 0 ? g0 : (i == 1 ? 0.5f * (g0 + g1 + g2) : (i == 2 ? 0.5f * (g0 - g1 + g2) : g2));
       }
       u = j == 0 ? gi[0] : (j == 1 ? 0.5f * (gi[0] + gi[1] + gi[2]) : (j == 2 ? 0.5f * (gi[0] - gi[1] + gi[2]) : gi[2]));
@@ -445,14 +447,22 @@ extern "C" int64_t tgsr_packed_wino_weight_elems(int Cout, int Cin) {
   return (int64_t)((Cin + kWCK - 1) / kWCK) * 16 * kWCK * Cout;
 }
 
-extern "C" int tgsr_pack_wino_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
+static int pack_wino_weight(const float* w, float* upack, int Cout, int Cin, int glu, int tr, void* stream) {
   if (!w || !upack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
   if (Cout % 32 != 0) return TGSR_EUNSUPPORTED;
   const int64_t total = tgsr_packed_wino_weight_elems(Cout, Cin);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_wino_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin,
-                     glu ? 1 : 0, Cout % 64 == 0 ? 2 : 1, total);
+                     glu ? 1 : 0, Cout % 64 == 0 ? 2 : 1, tr, total);
   return note_launch(hipGetLastError(), "pack_wino_weight_kernel");
+}
+
+extern "C" int tgsr_pack_wino_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
+  return pack_wino_weight(w, upack, Cout, Cin, glu, 0, stream);
+}
+
+extern "C" int tgsr_pack_wino_weight_dgrad(const float* w, float* upack, int Cout, int Cin, void* stream) {
+  return pack_wino_weight(w, upack, Cout, Cin, 0, 1, stream);
 }
 
 extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W,

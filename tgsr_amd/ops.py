@@ -73,15 +73,21 @@ def _nchw_bstride(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
 
 
 # ----------------------------------------------------------------------------------------- weight prep
-def pack_conv3x3_weight(w: torch.Tensor) -> torch.Tensor:
-    """[Cout,Cin,3,3] -> the [ceil(Cin/4)][9][4][Cout] stream order of tgsr_conv3x3_fwd."""
+def pack_conv3x3_weight(w: torch.Tensor, dgrad: bool = False) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> the [ceil(Cin/4)][9][4][Cout] stream order of tgsr_conv3x3_fwd.  `dgrad`: w is the forward
+    conv's weight and the pack is of its data-gradient conv (in/out swapped, taps flipped) - no flip/transpose copies."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin, K, K2 = w.shape
     assert K == 3 and K2 == 3
+    if dgrad:
+        Cout, Cin = Cin, Cout
     L = _lib.lib()
     out = torch.empty(L.tgsr_packed_weight_elems(Cout, Cin, 3), dtype=torch.float32, device=w.device)
-    check(L.tgsr_pack_conv_weight(_p(w), _p(out), Cout, Cin, 3, _stream()), "tgsr_pack_conv_weight")
+    if dgrad:
+        check(L.tgsr_pack_conv_weight_dgrad(_p(w), _p(out), Cout, Cin, 3, _stream()), "tgsr_pack_conv_weight_dgrad")
+    else:
+        check(L.tgsr_pack_conv_weight(_p(w), _p(out), Cout, Cin, 3, _stream()), "tgsr_pack_conv_weight")
     return out
 
 
@@ -131,15 +137,22 @@ def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Option
     return out
 
 
-def pack_wino_weight(w: torch.Tensor, glu: bool = False) -> torch.Tensor:
+def pack_wino_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False) -> torch.Tensor:
     """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) transformed weights [ceil(Cin/8)][Cout/64][16 pos][8][64]; `glu` must
-    match the epilogue the pack is used with (it groups value channels with their gate channels)."""
+    match the epilogue the pack is used with (it groups value channels with their gate channels).  `dgrad`: w is the
+    forward conv's weight, the pack is of its data-gradient conv (see pack_conv3x3_weight)."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
+    if dgrad:
+        Cout, Cin = Cin, Cout
     L = _lib.lib()
     out = torch.empty(L.tgsr_packed_wino_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
-    check(L.tgsr_pack_wino_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_wino_weight")
+    if dgrad:
+        assert not glu
+        check(L.tgsr_pack_wino_weight_dgrad(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_wino_weight_dgrad")
+    else:
+        check(L.tgsr_pack_wino_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_wino_weight")
     return out
 
 
