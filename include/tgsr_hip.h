@@ -37,7 +37,7 @@ extern "C" {
 #define TGSR_ACT_TANH_AXPY 1 /* y = tanh(conv) + alpha * addend      (conv_output + a*SRb, model.py:224,280) */
 
 /* ABI version of this header; tgsr_abi_version() must return the same number. */
-#define TGSR_ABI_VERSION 1
+#define TGSR_ABI_VERSION 2
 int tgsr_abi_version(void);
 /* Static string describing the last launch error seen by this process (debug aid). */
 const char* tgsr_last_error(void);
@@ -246,6 +246,15 @@ int tgsr_conv1x1_fwd(const float* x, int B, int Cin, int S, const float* w, cons
 int tgsr_linear_fwd(const float* x, int B, int K, const float* w, const float* bias, int Cout, float* out,
                     void* stream);
 
+/*
+ * The discriminators' logit heads (nn.Conv2d(8 ndf, 1, kernel_size=4, stride=4) on a 4x4 map, called by
+ * losses.py:292-316 / 359-366 as netD.COND_DNET / UNCOND_DNET): out[b] = sum_k x[b][k] w[k] + bias[0], one workgroup
+ * per sample, fixed-order reduction.  Backward: dx[b][k] = dy[b] w[k] (dx may be NULL), dw[k] = sum_b dy[b] x[b][k]
+ * (dw may be NULL).  x, w 16-byte aligned.
+ */
+int tgsr_rowdot_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K, void* stream);
+int tgsr_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int B, int K, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Training path (BatchNorm2d batch statistics + backward).  The reference trains through torch autograd over
  * nn.Conv2d / nn.BatchNorm2d(train) / GLU / nn.Upsample (util.py:74-80, 110-130); these entry points are the
@@ -278,24 +287,34 @@ int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW,
                       float* sums_ws, float* draw, float* dgamma, float* dbeta, void* stream);
 
 /*
- * downBlock's convolution (util.py:92-98: nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False)) for the discriminators, fp32 MFMA
- * implicit GEMMs that gather straight from the NCHW tensors (no im2col buffer).  H, W (even) = INPUT size; out / dy
- * [B][Cout][H/2][W/2] dense.  BatchNorm + LeakyReLU behind it = tgsr_bn_train_fwd(glu = 2); `act` = 1 applies
+ * The discriminators' convolutions: downBlock's nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False) (util.py:92-98) and the 3x3
+ * stride-1 pad-1 convolutions of their 4x4-pixel, 512...2048-channel blocks, as one fp32 MFMA implicit-GEMM kernel
+ * (128 x 128 x 16 LDS tiles, operands gathered from the NCHW tensors by index arithmetic - no im2col buffer; the
+ * reduction is split into slabs where M x N alone cannot fill the chip, summed in a fixed order: reproducible, no
+ * float atomics).  H, W = INPUT size (even for the 4x4 form); out / dy [B][Cout][H/2][W/2] (4x4) or [B][Cout][H][W]
+ * (3x3), dense; w in torch layout.  BatchNorm + LeakyReLU behind it = tgsr_bn_train_fwd(glu = 2); `act` = 1 applies
  * LeakyReLU(0.2) in the epilogue (the discriminators' first layer has no BatchNorm).
- *   tgsr_conv4x4s2_fwd   out = conv(x, w)            w [Cout][Cin][4][4] torch layout
- *   tgsr_conv4x4s2_dgrad dx  = conv_transpose(dy, w) wpack_ws: 16*Cin*Cout floats of scratch (the per-parity-class
- *                                                    weight regrouping, rebuilt by every call: weights change per step)
- *   tgsr_conv4x4s2_wgrad dw  = sum_n dy x_gather     ws: tgsr_conv4x4s2_wgrad_ws_elems floats (split reduction slabs,
- *                                                    summed in a fixed order - reproducible, no float atomics)
+ *   *_fwd   out = conv(x, w)              *_dgrad  dx = conv_transpose(dy, w)          *_wgrad  dw = sum_pixels dy x_gather
+ * ws: *_ws_elems(op, ...) floats with op = 0 forward, 1 data gradient, 2 weight gradient (slabs; for the 4x4 data
+ * gradient also the per-parity-class weight regrouping, rebuilt by every call: weights change per step).
+ * The generator's 3x3 convolutions (32 ... 128 channels on 32^2 ... 256^2 pixels) are tgsr_wino_conv3x3_fwd /
+ * tgsr_conv3x3_fwd, not these.
  * tgsr_leaky_relu: out = x > 0 ? x : 0.2 x, or with y_for_bwd != NULL the backward out = x * (y > 0 ? 1 : 0.2).
  */
-int tgsr_conv4x4s2_fwd(const float* x, int B, int Cin, int H, int W, const float* w, int Cout, int act, float* out,
-                       void* stream);
-int tgsr_conv4x4s2_dgrad(const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* wpack_ws,
-                         float* dx, void* stream);
-int64_t tgsr_conv4x4s2_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W);
+int64_t tgsr_conv4x4s2_ws_elems(int op, int B, int Cin, int H, int W, int Cout);
+int tgsr_conv4x4s2_fwd(const float* x, int B, int Cin, int H, int W, const float* w, int Cout, int act, float* ws,
+                       float* out, void* stream);
+int tgsr_conv4x4s2_dgrad(const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* ws, float* dx,
+                         void* stream);
 int tgsr_conv4x4s2_wgrad(const float* dy, const float* x, int B, int Cin, int H, int W, int Cout, float* ws, float* dw,
                          void* stream);
+int64_t tgsr_conv3x3_gemm_ws_elems(int op, int B, int Cin, int H, int W, int Cout);
+int tgsr_conv3x3_gemm_fwd(const float* x, int B, int Cin, int H, int W, const float* w, int Cout, float* ws, float* out,
+                          void* stream);
+int tgsr_conv3x3_gemm_dgrad(const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* ws, float* dx,
+                            void* stream);
+int tgsr_conv3x3_gemm_wgrad(const float* dy, const float* x, int B, int Cin, int H, int W, int Cout, float* ws, float* dw,
+                            void* stream);
 int tgsr_leaky_relu(const float* x, const float* y_for_bwd, float* out, int64_t n, void* stream);
 
 /* Backward of nn.Upsample(scale_factor=2, 'nearest'): out[bc][y][x] = sum of in[bc][2y..2y+1][2x..2x+1]. */

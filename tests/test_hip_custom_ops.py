@@ -28,7 +28,7 @@ def test_opcheck_conv_to3_and_conv4x4s2():
     wd = (torch.randn(16, 8, 4, 4, generator=g) / 11.0).to(DEV).requires_grad_(True)
     torch.library.opcheck(torch.ops.tgsr.conv4x4s2.default, (xd, wd, True), test_utils=utils)
     torch.library.opcheck(torch.ops.tgsr.conv3x3_fused_out.default,
-                          (torch.randn(1, 32, 8, 32, device=DEV), torch.zeros(32 * 32 * 9 + 1024, device=DEV), 32, None, None,
+                          (torch.randn(1, 32, 8, 32, device=DEV), torch.zeros(32 * 32 * 9, device=DEV), 32, None, None,
                            False, False, None, torch.empty(1, 32, 8, 32, device=DEV)), test_utils=("test_schema", "test_faketensor"))
 
 
@@ -67,3 +67,22 @@ def test_modules_dispatch_through_torch_ops(monkeypatch):
     assert y.shape == (2, 64, 16, 32) and calls["n"] == 2
     assert "tgsr::conv3x3_wino" in str(torch.ops.tgsr.conv3x3_wino.default._schema)
     cfg_reset()
+
+
+def test_filter_packed_for_another_channel_count_raises():
+    """A weight [Cout, Cin', 3, 3] applied to a Cin-channel input is a shape error in torch (the reference raises it for
+    NetG_highweight at GF_DIM != 32: ResBlock(channel_num=32) is hard-coded, model.py:258-262).  The HIP kernels walk
+    the packed filter by the INPUT's channel count, so the wrappers must refuse instead of reading past the pack."""
+    from tgsr_amd import lp, ops
+    from tgsr_amd._lib import TgsrError
+    x = torch.randn(2, 128, 32, 32, device=DEV)
+    w = torch.randn(64, 32, 3, 3, device=DEV)
+    with pytest.raises(TgsrError):
+        ops.conv3x3_wino(x, ops.pack_wino_weight(w), 64, None, None)
+    with pytest.raises(TgsrError):
+        ops.conv3x3_fused(x, ops.pack_conv3x3_weight(w), 64, None, None)
+    with pytest.raises(TgsrError):
+        ops.upwino_glu(x, ops.pack_upwino_weight(w, glu=False), 64, None, None, glu=False)
+    xi = lp.from_nchw(x[:, :64].contiguous(), "bf16")
+    with pytest.raises(TgsrError):
+        lp.conv3x3(xi, lp.pack_conv3x3_weight(w, "bf16"), 64, 64, None, None)

@@ -40,7 +40,10 @@ def close(a, b, atol=1e-4, rtol=1e-4):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,leaky", [(2, 3, 8, 16, 16, True), (3, 8, 16, 8, 12, False), (1, 40, 33, 4, 4, False),
-                                                   (2, 64, 128, 8, 8, False), (5, 16, 32, 32, 32, True)])
+                                                   (2, 64, 128, 8, 8, False), (5, 16, 32, 32, 32, True),
+                                                   # split reductions (few pixels, many channels) and ragged 128-tiles
+                                                   (4, 256, 520, 8, 8, False), (16, 3, 64, 64, 64, True),
+                                                   (3, 130, 200, 6, 10, False)])
 def test_conv4x4s2_fwd_dgrad_wgrad(B, Cin, Cout, H, W, leaky):
     from tgsr_amd.autograd import DownConv
     g = torch.Generator().manual_seed(B + Cin)
@@ -62,7 +65,25 @@ def _sd_cpu(m):
     return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("kind,B,Cin,Cout,H", [("down", 4, 16, 32, 16), ("3x3", 3, 64, 32, 4), ("down", 2, 32, 64, 8)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 256, 256, 4, 4), (16, 512, 384, 4, 4), (3, 300, 260, 5, 7), (1, 8, 16, 12, 9)])
+def test_conv3x3_gemm_fwd_dgrad_wgrad(B, Cin, Cout, H, W):
+    """The implicit-GEMM 3x3 form (the discriminators' 4x4-pixel blocks) against torch: forward, data gradient (filter
+    read transposed + flipped in the kernel) and weight gradient, with split reductions and ragged tiles."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B * 3 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).requires_grad_(True)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    ref = F.conv2d(x, w, None, 1, 1)
+    ref.backward(dy)
+    xd, wd, dyd = x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV)
+    close(ops.conv3x3_gemm(xd, wd), ref, atol=2e-5, rtol=1e-4)
+    close(ops.conv3x3_gemm_dgrad(dyd, wd), x.grad, atol=2e-5, rtol=1e-4)
+    close(ops.conv3x3_gemm_wgrad(dyd, xd), w.grad, atol=2e-4 * float(w.grad.abs().max()), rtol=2e-4)
+
+
+@pytest.mark.parametrize("kind,B,Cin,Cout,H", [("down", 4, 16, 32, 16), ("3x3", 3, 64, 32, 4), ("down", 2, 32, 64, 8),
+                                               ("3x3", 4, 256, 256, 4)])
 def test_conv_bn_leaky_block(kind, B, Cin, Cout, H, cfg_d):
     from tgsr_amd import util
     torch.manual_seed(3)

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TGSR_LIB_PATH: another build of the same library (tools/lp_conv_experiments.sh); never a different implementation
 LIB_PATH = os.environ.get("TGSR_LIB_PATH") or os.path.join(_HERE, "lib", "libtgsr_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 EPI_AFFINE, EPI_AFFINE_GLU = 0, 1
@@ -53,14 +53,20 @@ SIGNATURES = {
     "tgsr_func_attention_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "tgsr_conv1x1_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "tgsr_linear_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
+    "tgsr_rowdot_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tgsr_rowdot_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tgsr_bn_train_nsplit": (_i, [_i, _i, _i]),
     "tgsr_bn_train_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,
                                _i64, _vp, _vp]),
     "tgsr_bn_train_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "tgsr_conv4x4s2_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "tgsr_conv4x4s2_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "tgsr_conv4x4s2_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "tgsr_conv4x4s2_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
-    "tgsr_conv4x4s2_wgrad_ws_elems": (_i64, [_i, _i, _i, _i, _i]),
     "tgsr_conv4x4s2_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "tgsr_conv3x3_gemm_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "tgsr_conv3x3_gemm_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "tgsr_conv3x3_gemm_dgrad": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "tgsr_conv3x3_gemm_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tgsr_leaky_relu": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "tgsr_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -184,8 +184,12 @@ class ConvBnLeaky(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, momentum, eps, nbt=None):
         L = _lib.lib()
         x = x.contiguous()
-        raw = ops.conv4x4s2(x, weight) if kind == "down" else \
-            ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), weight.shape[0], None, None)
+        if kind == "down":
+            raw = ops.conv4x4s2(x, weight)
+        elif ops.conv3x3_gemm_pays(x.shape[1], weight.shape[0], x.shape[2], x.shape[3]):
+            raw = ops.conv3x3_gemm(x, weight)                 # many channels on 4x4 pixels: the implicit-GEMM form
+        else:
+            raw = ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), weight.shape[0], None, None)
         B, C, Ho, Wo = raw.shape
         HW, dev = Ho * Wo, x.device
         nsplit = L.tgsr_bn_train_nsplit(B, C, HW)
@@ -198,6 +202,7 @@ class ConvBnLeaky(torch.autograd.Function):
         check(rc, "tgsr_bn_train_fwd")
         ctx.save_for_backward(x, weight, raw, stats)
         ctx.kind = kind
+        ctx.bn_params = (gamma, beta)          # only to look up their gradient slots (parallel.grad_slot) in backward
         return out
 
     @staticmethod
@@ -211,8 +216,8 @@ class ConvBnLeaky(torch.autograd.Function):
         ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
         sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
         draw = torch.empty_like(raw)
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        gamma, beta = ctx.bn_params
+        dgamma, dbeta = _grad_out(gamma, (C,), dev), _grad_out(beta, (C,), dev)
         rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, C, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), 2,
                                  _p(ws), _p(sums), _p(draw), _p(dgamma), _p(dbeta), _stream())
         check(rc, "tgsr_bn_train_bwd")
@@ -222,7 +227,12 @@ class ConvBnLeaky(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = ops.conv4x4s2_dgrad(draw, weight, H, W)
             if ctx.needs_input_grad[1]:
-                dw = ops.conv4x4s2_wgrad(draw, x)
+                dw = ops.conv4x4s2_wgrad(draw, x, out=_grad_out(weight, weight.shape, dev))
+        elif ops.conv3x3_gemm_pays(Cin, C, H, W):
+            if ctx.needs_input_grad[0]:
+                dx = ops.conv3x3_gemm_dgrad(draw, weight)
+            if ctx.needs_input_grad[1]:
+                dw = ops.conv3x3_gemm_wgrad(draw, x, out=_grad_out(weight, weight.shape, dev))
         else:
             if ctx.needs_input_grad[0]:
                 wT = _dgrad_weight(weight.detach())
@@ -398,6 +408,37 @@ class LinearFn(torch.autograd.Function):
         dx = _gemm_nt(dy, w.detach().t()) if ctx.needs_input_grad[0] else None          # [B,N] @ W [N,K]
         dw = _gemm_nt(dy.t(), x.detach().t()) if ctx.needs_input_grad[1] else None      # dy^T x
         return dx, dw, (dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+
+
+class RowDot(torch.autograd.Function):
+    """out[b] = <x[b, :], w> + bias: the discriminators' logit heads (a 4x4 / stride-4 conv of a 4x4 map to one
+    channel), tgsr_rowdot_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        L = _lib.lib()
+        x = x.contiguous()
+        w = w.detach().contiguous().view(-1)
+        B, K = x.shape
+        out = torch.empty(B, dtype=torch.float32, device=x.device)
+        check(L.tgsr_rowdot_fwd(_p(x), _p(w), _p(None if bias is None else bias.detach()), _p(out), B, K, _stream()),
+              "tgsr_rowdot_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.wshape = None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, K = x.shape
+        ndx, ndw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = torch.empty_like(x) if ndx else None
+        dw = torch.empty(K, dtype=torch.float32, device=x.device) if ndw else None
+        if ndx or ndw:
+            check(L.tgsr_rowdot_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), B, K, _stream()), "tgsr_rowdot_bwd")
+        return dx, dw, (dy.sum().reshape(1) if ctx.needs_input_grad[2] else None)
 
 
 class Conv1x1Fn(torch.autograd.Function):

@@ -1,99 +1,235 @@
-// downBlock's strided convolution for the discriminators (util.py:92-98: Conv2d(Cin, Cout, 4, 2, 1, bias=False) ->
-// BatchNorm2d -> LeakyReLU(0.2)): forward, data gradient and weight gradient as fp32 MFMA (32x32x2) implicit GEMMs that
-// gather their "B" operand straight from the NCHW tensors - no im2col buffer.  BatchNorm (batch statistics) + LeakyReLU
-// is tgsr_bn_train_fwd / _bwd with act = 2 (tgsr_bn.hip); the first discriminator layer (no BatchNorm) takes the
-// LeakyReLU in this kernel's epilogue.  SURVEY.md 8(f)1; the discriminator ARCHITECTURE is the build's (AttnGAN-style,
-// no class exists in the reference), these kernels are pinned against a torch fp32 restatement in the oracle.
+// The discriminators' convolutions (the build's AttnGAN-style D_NET64/128/256 behind losses.py:290-374): downBlock's
+// Conv2d(Cin, Cout, 4, 2, 1, bias=False) (util.py:92-98) and the 3x3 stride-1 convolutions of Block3x3_leakRelu at
+// 4x4 pixels with 512 ... 2048 channels - forward, data gradient and weight gradient - as ONE fp32 MFMA (32x32x2)
+// implicit-GEMM kernel.  These layers are GEMM-shaped the generator's are not: K = 16 Cin up to 16384 against as few as
+// 256 output pixels, so the kernel is a 128 x 128 x 16 LDS-tiled GEMM whose operands are gathered from the NCHW tensors
+// by index arithmetic (no im2col buffer), with the reduction split over blockIdx.z into slabs when M x N alone cannot
+// fill 256 CUs; slabs are summed in a fixed order (bitwise reproducible, no float atomics).
 //
-//   forward : out[b][co][oy][ox] = sum_{ci,ky,kx} w[co][ci][ky][kx] x[b][ci][2oy+ky-1][2ox+kx-1]
-//             GEMM M = Cout, K = 16 Cin, N = B Ho Wo; A = w (already [Cout][16 Cin] row-major), B gathered.
-//   dgrad   : dx[b][ci][iy][ix] = sum over the (co, ky, kx) that reach it.  Input pixels of parity class (p, q) =
-//             ((iy+1)&1, (ix+1)&1) only see taps ky in {p, p+2}, kx in {q, q+2}: four GEMMs M = Cin, K = 4 Cout,
-//             N = B (H/2)(W/2), A = the class's re-grouped weights (tgsr_conv4x4s2_pack_dgrad), B gathered from dy.
-//   wgrad   : dw[co][ci][ky][kx] = sum_n dy[co][n] x_gather[k][n]: reduction over N = B Ho Wo split over blockIdx.z
-//             into slabs that a second kernel sums in a fixed order (bitwise reproducible, no float atomics).
+//   forward (4x4 s2 | 3x3 s1): out[b][co][p] = sum_j w[co][j] S(p, j),  j = (ci, ky, kx)       M = Cout, N = pixels, K = j
+//   dgrad 4x4 s2: input pixels of parity class (p, q) = ((iy+1)&1, (ix+1)&1) only see taps ky in {p, p+2}, kx in
+//                 {q, q+2}: four GEMMs M = Cin, K = 4 Cout, N = B (H/2)(W/2) over re-grouped weights (pack kernel)
+//   dgrad 3x3 s1: the same conv over dy with the filter read transposed and flipped                M = Cin, K = 9 Cout
+//   wgrad       : dw[co][j] = sum_pixels dy[co][p] S(p, j)                                         M = Cout, N = j, K = pixels
+// BatchNorm (batch statistics) + LeakyReLU(0.2) is tgsr_bn_train_fwd / _bwd with act = 2 (tgsr_bn.hip); the first layer
+// (no BatchNorm) takes the LeakyReLU in this kernel's epilogue.  SURVEY.md 8(f)1.
 #include "tgsr_common.h"
 
 namespace tgsr {
 
-struct DownArgs {
-  const float* A;        // forward: w [Cout][16 Cin]; dgrad: packed [4][Cin][4 Cout]
-  const float* X;        // forward: x [B][Cin][H][W]; dgrad: dy [B][Cout][Ho][Wo]
-  float* out;
-  int B, Cin, H, W, Cout, Ho, Wo;
-  int act;               // forward only: 1 = LeakyReLU(0.2) epilogue
+enum { kFwd4 = 0, kFwd3 = 1, kDgrad4 = 2, kDgrad3 = 3, kWgrad4 = 4, kWgrad3 = 5 };
+
+struct IgArgs {
+  const float* A;        // fwd: w [Cout][K]; dgrad4: packed [4][Cin][4 Cout]; dgrad3: w [Cout][Cin][3][3]; wgrad: dy
+  const float* S;        // gathered tensor: fwd / wgrad x [B][C][Hs][Ws]; dgrad: dy
+  float* out;            // output, or slab 0 when nsplit > 1
+  int M, N, K;           // GEMM sizes (K = reduction)
+  int C, Hs, Ws;         // channels and spatial size of S
+  int PH, PW;            // the pixel grid the pixel index runs over (output pixels; dgrad4: one parity class)
+  int OH, OW;            // spatial size of the NCHW output (dgrad4: the full input)
+  int nsplit, chunks_per_split;
+  int64_t slab_stride;
+  int act;               // forward, nsplit == 1 only: 1 = LeakyReLU(0.2) epilogue
 };
 
-// C[m][n] = sum_k A[m][k] G(k, n): workgroup = 32 m x 128 n (wave = 32 n), A chunk [32][64] through LDS (pitch 65,
-// conflict free for the lane = m reads), G gathered per lane straight from global memory.
-template <int MODE>   // 0 = forward, 1 = dgrad (blockIdx.z = parity class)
-__global__ __launch_bounds__(256) void conv4x4s2_gemm_kernel(DownArgs a) {
-  constexpr int KC = 64, P = KC + 1;
-  __shared__ float a_s[32 * P];
+constexpr int kIgKC = 16, kIgP = 132;   // K-chunk; LDS pitch: (4 k + m) mod 64 is a bijection over a wave's writes
+
+// decode a column index j = (channel, taps) of the gathered operand into (element offset, row shift, column shift)
+template <int MODE>
+__device__ __forceinline__ void ig_decode_j(const IgArgs& a, int j, int cls, int& off, int& dyk, int& dxk) {
+  if (MODE == kFwd4 || MODE == kWgrad4) {
+    const int c = j >> 4;
+    dyk = ((j >> 2) & 3) - 1;
+    dxk = (j & 3) - 1;
+    off = c * a.Hs * a.Ws;
+  } else if (MODE == kDgrad4) {
+    const int c = j >> 2;
+    dyk = 1 - (cls >> 1) - ((j >> 1) & 1);
+    dxk = 1 - (cls & 1) - (j & 1);
+    off = c * a.Hs * a.Ws;
+  } else {
+    const int c = j / 9, t = j - 9 * c, ky = t / 3;
+    dyk = ky - 1;
+    dxk = t - 3 * ky - 1;
+    off = c * a.Hs * a.Ws;
+  }
+}
+
+// decode a pixel index into (element offset of (b, channel 0, row 0, col 0), top row, left column) of its window
+template <int MODE>
+__device__ __forceinline__ void ig_decode_p(const IgArgs& a, int p, int& off, int& iy0, int& ix0) {
+  const int hw = a.PH * a.PW;
+  const int b = p / hw, r = p - b * hw, py = r / a.PW, px = r - py * a.PW;
+  constexpr int S = (MODE == kFwd4 || MODE == kWgrad4) ? 2 : 1;
+  iy0 = S * py;
+  ix0 = S * px;
+  off = b * a.C * a.Hs * a.Ws;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void dconv_igemm_kernel(IgArgs a) {
+  constexpr bool WG = MODE == kWgrad4 || MODE == kWgrad3;
+  __shared__ float a_s[2][kIgKC * kIgP];
+  __shared__ float b_s[2][kIgKC * kIgP];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5, wave = tid >> 6;
-  const int cls = MODE == 1 ? blockIdx.z : 0, pp = cls >> 1, qq = cls & 1;
-  const int M = MODE == 0 ? a.Cout : a.Cin;
-  const int K = MODE == 0 ? a.Cin * 16 : a.Cout * 4;
-  const int nH = MODE == 0 ? a.Ho : a.H / 2, nW = MODE == 0 ? a.Wo : a.W / 2;
-  const int64_t N = (int64_t)a.B * nH * nW;
-  const float* Ab = a.A + (MODE == 1 ? (int64_t)cls * M * K : 0);
-  const int m0 = blockIdx.y * 32;
-  const int64_t n = ((int64_t)blockIdx.x * 4 + wave) * 32 + l31;
-  const bool nok = n < N;
-  int nb = 0, ny = 0, nx = 0;
-  if (nok) {
-    nx = (int)(n % nW);
-    const int64_t t = n / nW;
-    ny = (int)(t % nH);
-    nb = (int)(t / nH);
-  }
-  f32x16 acc;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ncls = MODE == kDgrad4 ? 4 : 1;
+  const int cls = MODE == kDgrad4 ? (int)blockIdx.z % ncls : 0;
+  const int z = (int)blockIdx.z / ncls;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  const int kbeg = z * a.chunks_per_split * kIgKC;
+  const int kend = min(a.K, kbeg + a.chunks_per_split * kIgKC);
+  const int nchunks = (kend - kbeg + kIgKC - 1) / kIgKC;
+  const float* Ab = a.A + (MODE == kDgrad4 ? (int64_t)cls * a.M * a.K : 0);
+
+  // ---- loader state.  A tile [128 m][16 k]: k = tid & 15, m = (tid >> 4) + 16 i.
+  const int ak = tid & 15, am = tid >> 4;
+  // B tile [16 k][128 n]: forward-like (n = pixel): n = tid & 127, k = (tid >> 7) + 2 i;  weight-gradient-like
+  // (k = pixel, n = j): k = tid & 15, n = (tid >> 4) + 16 i - consecutive lanes walk consecutive pixels either way
+  int poff = 0, piy = 0, pix_ = 0;            // forward-like: this thread's pixel
+  bool pok = false;
+  int joff[8], jsh[8];                        // weight-gradient-like: this thread's 8 columns j (shifts packed)
+  if (!WG) {
+    const int n = n0 + (tid & 127);
+    pok = n < a.N;
+    if (pok) ig_decode_p<MODE>(a, n, poff, piy, pix_);
+  } else {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += KC) {
-    __syncthreads();
-    for (int idx = tid; idx < 32 * KC; idx += 256) {
-      const int r = idx >> 6, k = idx & 63;
-      a_s[r * P + k] = (m0 + r < M && k0 + k < K) ? Ab[(int64_t)(m0 + r) * K + k0 + k] : 0.f;
+    for (int i = 0; i < 8; ++i) {
+      const int j = n0 + (tid >> 4) + 16 * i;
+      int off = 0, dyk = 0, dxk = 0;
+      if (j < a.N) ig_decode_j<MODE>(a, j, 0, off, dyk, dxk);
+      joff[i] = j < a.N ? off : -1;
+      jsh[i] = (dyk + 4) | ((dxk + 4) << 4);
     }
-    __syncthreads();
-    float bv[KC / 2];
-#pragma unroll
-    for (int j = 0; j < KC / 2; ++j) {
-      const int k = k0 + 2 * j + hh;
-      float v = 0.f;
-      if (nok && k < K) {
-        if (MODE == 0) {
-          const int ci = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
-          const int iy = 2 * ny + ky - 1, ix = 2 * nx + kx - 1;
-          if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-            v = a.X[(((int64_t)nb * a.Cin + ci) * a.H + iy) * a.W + ix];
-        } else {
-          const int co = k >> 2, ta = (k >> 1) & 1, tc = k & 1;
-          const int oy = ny + 1 - pp - ta, ox = nx + 1 - qq - tc;
-          if ((unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo)
-            v = a.X[(((int64_t)nb * a.Cout + co) * a.Ho + oy) * a.Wo + ox];
-        }
-      }
-      bv[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < KC / 2; ++j)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[l31 * P + 2 * j + hh], bv[j], acc, 0, 0, 0);
   }
-  if (nok) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int m = m0 + acc_row(i, hh);
-      if (m >= M) continue;
-      float v = acc[i];
-      if (MODE == 0) {
-        if (a.act) v = v > 0.f ? v : 0.2f * v;
-        a.out[(((int64_t)nb * a.Cout + m) * a.Ho + ny) * a.Wo + nx] = v;
+  float ra[8], rb[8];
+  auto load = [&](int c) {
+    const int k0 = kbeg + c * kIgKC;
+    // A
+    {
+      const int k = k0 + ak;
+      const bool kok = k < kend;
+      int64_t base = 0, stride = 0;
+      if (MODE == kFwd4 || MODE == kFwd3 || MODE == kDgrad4) {
+        base = k;
+        stride = a.K;
+      } else if (MODE == kDgrad3) {
+        const int co = k / 9, t = k - 9 * co;
+        base = (int64_t)co * a.M * 9 + 8 - t;
+        stride = 9;
       } else {
-        a.out[(((int64_t)nb * a.Cin + m) * a.H + 2 * ny + 1 - pp) * a.W + 2 * nx + 1 - qq] = v;
+        const int hw = a.PH * a.PW, b = k / hw, r = k - b * hw;
+        base = (int64_t)b * a.M * hw + r;
+        stride = hw;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + am + 16 * i;
+        ra[i] = (kok && m < a.M) ? Ab[base + (int64_t)m * stride] : 0.f;
       }
     }
+    // B
+    if (!WG) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int j = k0 + (tid >> 7) + 2 * i;
+        float v = 0.f;
+        if (pok && j < kend) {
+          int off, dyk, dxk;
+          ig_decode_j<MODE>(a, j, cls, off, dyk, dxk);
+          const int iy = piy + dyk, ix = pix_ + dxk;
+          if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws) v = a.S[poff + off + iy * a.Ws + ix];
+        }
+        rb[i] = v;
+      }
+    } else {
+      const int p = k0 + ak;
+      int off = 0, iy0 = 0, ix0 = 0;
+      const bool ok = p < kend;
+      if (ok) ig_decode_p<MODE>(a, p, off, iy0, ix0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float v = 0.f;
+        if (ok && joff[i] >= 0) {
+          const int iy = iy0 + (jsh[i] & 15) - 4, ix = ix0 + (jsh[i] >> 4) - 4;
+          if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws) v = a.S[off + joff[i] + iy * a.Ws + ix];
+        }
+        rb[i] = v;
+      }
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a_s[buf][ak * kIgP + am + 16 * i] = ra[i];
+    if (!WG) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b_s[buf][((tid >> 7) + 2 * i) * kIgP + (tid & 127)] = rb[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b_s[buf][ak * kIgP + am + 16 * i] = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+  if (nchunks > 0) load(0);
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    store(buf);
+    __syncthreads();                   // also: everybody finished computing from the other buffer one iteration ago
+    if (c + 1 < nchunks) load(c + 1);  // global loads in flight under the MFMAs below
+    const float* as = a_s[buf] + wm * 64 + l31;
+    const float* bs = b_s[buf] + wn * 64 + l31;
+#pragma unroll
+    for (int s = 0; s < kIgKC / 2; ++s) {
+      const int kr = (2 * s + hh) * kIgP;
+      const float a0 = as[kr], a1 = as[kr + 32], b0 = bs[kr], b1 = bs[kr + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: D[row = acc_row(i, hh)][col = lane & 31]; consecutive lanes = consecutive n (pixels | j): coalesced
+  float* ob = a.out + (int64_t)z * a.slab_stride;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wn * 64 + nb * 32 + l31;
+    if (n >= a.N) continue;
+    int64_t obase;
+    int64_t mstride;
+    if (WG) {
+      obase = n;
+      mstride = a.N;
+    } else {
+      const int hw = a.PH * a.PW, b = n / hw, r = n - b * hw;
+      if (MODE == kDgrad4) {
+        const int py = r / a.PW, px = r - py * a.PW;
+        obase = (int64_t)b * a.M * a.OH * a.OW + (2 * py + 1 - (cls >> 1)) * a.OW + 2 * px + 1 - (cls & 1);
+        mstride = (int64_t)a.OH * a.OW;
+      } else {
+        obase = (int64_t)b * a.M * hw + r;
+        mstride = hw;
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm * 64 + mb * 32 + acc_row(i, hh);
+        if (m >= a.M) continue;
+        float v = acc[mb][nb][i];
+        if (a.act) v = v > 0.f ? v : 0.2f * v;
+        ob[obase + m * mstride] = v;
+      }
   }
 }
 
@@ -109,77 +245,12 @@ __global__ void conv4x4s2_pack_dgrad_kernel(const float* __restrict__ w, float* 
   }
 }
 
-struct DownWgradArgs {
-  const float* dy;       // [B][Cout][Ho][Wo]
-  const float* x;        // [B][Cin][H][W]
-  float* ws;             // [nsplit][Cout][16 Cin]
-  int B, Cin, H, W, Cout, Ho, Wo, nsplit;
-};
-
-// slab[z][co][k] = sum over the n range of split z of dy[co][n] * x_gather[k][n]: workgroup = 32 co x 128 k
-// (wave = 32 k); both operands staged through LDS in [row][64 n] tiles (n contiguous in dy -> coalesced).
-__global__ __launch_bounds__(256) void conv4x4s2_wgrad_kernel(DownWgradArgs a) {
-  constexpr int RC = 64, P = RC + 1;
-  __shared__ float a_s[32 * P];
-  __shared__ float b_s[4 * 32 * P];
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5, wave = tid >> 6;
-  const int K = a.Cin * 16, HW = a.Ho * a.Wo;
-  const int64_t N = (int64_t)a.B * HW;
-  const int m0 = blockIdx.y * 32, kb = (blockIdx.x * 4 + wave) * 32;
-  const int64_t per = ((N + a.nsplit - 1) / a.nsplit + RC - 1) / RC * RC;
-  const int64_t lo = (int64_t)blockIdx.z * per, hi = lo + per < N ? lo + per : N;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float* mine = b_s + wave * 32 * P;
-  for (int64_t r0 = lo; r0 < hi; r0 += RC) {
-    __syncthreads();
-    for (int idx = tid; idx < 32 * RC; idx += 256) {
-      const int row = idx >> 6, rr = idx & 63;
-      const int64_t n = r0 + rr;
-      float v = 0.f;
-      if (m0 + row < a.Cout && n < hi) {
-        const int b = (int)(n / HW), pix = (int)(n - (int64_t)b * HW);
-        v = a.dy[((int64_t)b * a.Cout + m0 + row) * HW + pix];
-      }
-      a_s[row * P + rr] = v;
-    }
-    for (int idx = lane; idx < 32 * RC; idx += 64) {
-      const int row = idx >> 6, rr = idx & 63;
-      const int64_t n = r0 + rr;
-      const int k = kb + row;
-      float v = 0.f;
-      if (k < K && n < hi) {
-        const int b = (int)(n / HW), pix = (int)(n - (int64_t)b * HW);
-        const int oy = pix / a.Wo, ox = pix - oy * a.Wo;
-        const int ci = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
-        const int iy = 2 * oy + ky - 1, ix = 2 * ox + kx - 1;
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-          v = a.x[(((int64_t)b * a.Cin + ci) * a.H + iy) * a.W + ix];
-      }
-      mine[row * P + rr] = v;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < RC; r += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_s[l31 * P + r + hh], mine[l31 * P + r + hh], acc, 0, 0, 0);
-  }
-  const int k = kb + l31;
-  if (k < K) {
-    float* slab = a.ws + (int64_t)blockIdx.z * a.Cout * K;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int m = m0 + acc_row(i, hh);
-      if (m < a.Cout) slab[(int64_t)m * K + k] = acc[i];
-    }
-  }
-}
-
-__global__ void slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int nsplit) {
+// out[i] = sum_z slab[z][i] in a fixed order (+ LeakyReLU)
+__global__ void slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, int64_t n, int nsplit, int act) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int z = 0; z < nsplit; ++z) s += ws[(int64_t)z * n + i];
-    out[i] = s;
+    out[i] = act ? (s > 0.f ? s : 0.2f * s) : s;
   }
 }
 
@@ -191,67 +262,155 @@ __global__ void leaky_kernel(const float* __restrict__ g, const float* __restric
   }
 }
 
-static int down_nsplit(int B, int Cin, int Cout, int Ho, int Wo) {
-  const int64_t tiles = (int64_t)((Cout + 31) / 32) * ((Cin * 16 + 127) / 128);
-  const int64_t N = (int64_t)B * Ho * Wo;
-  int64_t s = (1024 + tiles - 1) / tiles;          // aim at >= 1024 workgroups
-  const int64_t cap = (N + 255) / 256;             // at least 256 reduction elements per split
+// reduction splits: enough workgroups for two per CU, at least 8 chunks (128 reduction elements) per split
+static int ig_nsplit(int64_t M, int64_t N, int64_t K, int ncls) {
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128) * ncls;
+  int64_t s = (512 + tiles - 1) / tiles;
+  const int64_t cap = (K + 8 * kIgKC - 1) / (8 * kIgKC);
   if (s > cap) s = cap;
   return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+
+// Shapes of one convolution in GEMM terms.  kind: 4 = 4x4 stride 2 pad 1, 3 = 3x3 stride 1 pad 1; op: 0 forward,
+// 1 data gradient, 2 weight gradient.  out_elems = elements of the tensor the GEMM produces.
+struct IgShape { int64_t M, N, K, out_elems; int ncls, nsplit; };
+static IgShape ig_shape(int kind, int op, int B, int Cin, int H, int W, int Cout) {
+  const int T = kind == 4 ? 16 : 9, Ho = kind == 4 ? H / 2 : H, Wo = kind == 4 ? W / 2 : W;
+  IgShape s;
+  s.ncls = 1;
+  if (op == 0) { s.M = Cout; s.N = (int64_t)B * Ho * Wo; s.K = (int64_t)Cin * T; s.out_elems = (int64_t)B * Cout * Ho * Wo; }
+  else if (op == 1 && kind == 4) { s.M = Cin; s.N = (int64_t)B * Ho * Wo; s.K = 4ll * Cout; s.ncls = 4; s.out_elems = (int64_t)B * Cin * H * W; }
+  else if (op == 1) { s.M = Cin; s.N = (int64_t)B * H * W; s.K = 9ll * Cout; s.out_elems = (int64_t)B * Cin * H * W; }
+  else { s.M = Cout; s.N = (int64_t)Cin * T; s.K = (int64_t)B * Ho * Wo; s.out_elems = (int64_t)Cout * Cin * T; }
+  s.nsplit = ig_nsplit(s.M, s.N, s.K, s.ncls);
+  return s;
+}
+
+static int64_t ig_ws_elems(int kind, int op, int B, int Cin, int H, int W, int Cout) {
+  const IgShape s = ig_shape(kind, op, B, Cin, H, W, Cout);
+  int64_t n = s.nsplit > 1 ? s.nsplit * s.out_elems : 0;
+  if (kind == 4 && op == 1) n += 16ll * Cin * Cout;          // the parity-class weight pack
+  return n > 0 ? n : 1;
+}
+
+template <int MODE>
+static int ig_launch(IgArgs a, const IgShape& sh, float* slabs, float* out, hipStream_t s, const char* what) {
+  if (sh.M >= (1ll << 31) || sh.N >= (1ll << 31) || sh.K >= (1ll << 31) || sh.out_elems >= (1ll << 31)) return TGSR_EUNSUPPORTED;
+  a.M = (int)sh.M; a.N = (int)sh.N; a.K = (int)sh.K;
+  a.nsplit = sh.nsplit;
+  const int chunks = (int)((sh.K + kIgKC - 1) / kIgKC);
+  a.chunks_per_split = (chunks + sh.nsplit - 1) / sh.nsplit;
+  a.nsplit = (chunks + a.chunks_per_split - 1) / a.chunks_per_split;     // no empty splits
+  a.slab_stride = a.nsplit > 1 ? sh.out_elems : 0;
+  a.out = a.nsplit > 1 ? slabs : out;
+  if (a.nsplit > 1) a.act = 0;                                           // the slab sum applies it
+  const dim3 grid((unsigned)((sh.N + 127) / 128), (unsigned)((sh.M + 127) / 128), (unsigned)(a.nsplit * sh.ncls));
+  hipLaunchKernelGGL(dconv_igemm_kernel<MODE>, grid, dim3(256), 0, s, a);
+  return note_launch(hipGetLastError(), what);
+}
+
+static int ig_finish(const IgArgs& a, int nsplit_used, int act, const float* slabs, float* out, int64_t n, hipStream_t s) {
+  if (nsplit_used <= 1) return TGSR_OK;
+  const int rb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(rb), dim3(256), 0, s, slabs, out, n, nsplit_used, act);
+  return note_launch(hipGetLastError(), "slab_sum_kernel");
+}
+
+static int ig_used_splits(const IgShape& sh) {
+  const int chunks = (int)((sh.K + kIgKC - 1) / kIgKC);
+  const int cps = (chunks + sh.nsplit - 1) / sh.nsplit;
+  return (chunks + cps - 1) / cps;
+}
+
+static int dconv_fwd(int kind, const float* x, int B, int Cin, int H, int W, const float* w, int Cout, int act, float* ws,
+                     float* out, void* stream) {
+  if (!x || !w || !out || !ws || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
+  if (kind == 4 && ((H | W) & 1)) return TGSR_EUNSUPPORTED;
+  const IgShape sh = ig_shape(kind, 0, B, Cin, H, W, Cout);
+  IgArgs a = {};
+  a.A = w; a.S = x; a.C = Cin; a.Hs = H; a.Ws = W;
+  a.PH = kind == 4 ? H / 2 : H; a.PW = kind == 4 ? W / 2 : W; a.OH = a.PH; a.OW = a.PW; a.act = act ? 1 : 0;
+  hipStream_t s = as_stream(stream);
+  const int rc = kind == 4 ? ig_launch<kFwd4>(a, sh, ws, out, s, "dconv_igemm_kernel<fwd4>")
+                           : ig_launch<kFwd3>(a, sh, ws, out, s, "dconv_igemm_kernel<fwd3>");
+  if (rc) return rc;
+  return ig_finish(a, ig_used_splits(sh), act ? 1 : 0, ws, out, sh.out_elems, s);
+}
+
+static int dconv_dgrad(int kind, const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* ws,
+                       float* dx, void* stream) {
+  if (!dy || !w || !ws || !dx || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
+  if (kind == 4 && ((H | W) & 1)) return TGSR_EUNSUPPORTED;
+  const IgShape sh = ig_shape(kind, 1, B, Cin, H, W, Cout);
+  hipStream_t s = as_stream(stream);
+  IgArgs a = {};
+  a.S = dy; a.C = Cout; a.OH = H; a.OW = W;
+  int rc;
+  float* slabs = ws;
+  if (kind == 4) {
+    const int64_t total = 16ll * Cin * Cout;
+    const int pb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv4x4s2_pack_dgrad_kernel, dim3(pb), dim3(256), 0, s, w, ws, Cout, Cin, total);
+    slabs = ws + total;
+    a.A = ws; a.Hs = H / 2; a.Ws = W / 2; a.PH = H / 2; a.PW = W / 2;
+    rc = ig_launch<kDgrad4>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad4>");
+  } else {
+    a.A = w; a.Hs = H; a.Ws = W; a.PH = H; a.PW = W;
+    rc = ig_launch<kDgrad3>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad3>");
+  }
+  if (rc) return rc;
+  return ig_finish(a, ig_used_splits(sh), 0, slabs, dx, sh.out_elems, s);
+}
+
+static int dconv_wgrad(int kind, const float* dy, const float* x, int B, int Cin, int H, int W, int Cout, float* ws,
+                       float* dw, void* stream) {
+  if (!dy || !x || !ws || !dw || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
+  if (kind == 4 && ((H | W) & 1)) return TGSR_EUNSUPPORTED;
+  const IgShape sh = ig_shape(kind, 2, B, Cin, H, W, Cout);
+  IgArgs a = {};
+  a.A = dy; a.S = x; a.C = Cin; a.Hs = H; a.Ws = W;
+  a.PH = kind == 4 ? H / 2 : H; a.PW = kind == 4 ? W / 2 : W; a.OH = a.PH; a.OW = a.PW;
+  hipStream_t s = as_stream(stream);
+  const int rc = kind == 4 ? ig_launch<kWgrad4>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad4>")
+                           : ig_launch<kWgrad3>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad3>");
+  if (rc) return rc;
+  return ig_finish(a, ig_used_splits(sh), 0, ws, dw, sh.out_elems, s);
 }
 
 }  // namespace tgsr
 
 using namespace tgsr;
 
+extern "C" int64_t tgsr_conv4x4s2_ws_elems(int op, int B, int Cin, int H, int W, int Cout) {
+  return (op < 0 || op > 2) ? 0 : ig_ws_elems(4, op, B, Cin, H, W, Cout);
+}
 extern "C" int tgsr_conv4x4s2_fwd(const float* x, int B, int Cin, int H, int W, const float* w, int Cout, int act,
-                                  float* out, void* stream) {
-  if (!x || !w || !out || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
-  if ((H | W) & 1) return TGSR_EUNSUPPORTED;
-  DownArgs a;
-  a.A = w; a.X = x; a.out = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = H / 2; a.Wo = W / 2;
-  a.act = act ? 1 : 0;
-  const int64_t N = (int64_t)B * a.Ho * a.Wo;
-  const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Cout + 31) / 32), 1);
-  hipLaunchKernelGGL(conv4x4s2_gemm_kernel<0>, grid, dim3(256), 0, as_stream(stream), a);
-  return note_launch(hipGetLastError(), "conv4x4s2_gemm_kernel<fwd>");
+                                  float* ws, float* out, void* stream) {
+  return dconv_fwd(4, x, B, Cin, H, W, w, Cout, act, ws, out, stream);
 }
-
-extern "C" int tgsr_conv4x4s2_dgrad(const float* dy, int B, int Cin, int H, int W, const float* w, int Cout,
-                                    float* wpack_ws, float* dx, void* stream) {
-  if (!dy || !w || !wpack_ws || !dx || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
-  if ((H | W) & 1) return TGSR_EUNSUPPORTED;
-  hipStream_t s = as_stream(stream);
-  const int64_t total = (int64_t)16 * Cin * Cout;
-  const int pb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(conv4x4s2_pack_dgrad_kernel, dim3(pb), dim3(256), 0, s, w, wpack_ws, Cout, Cin, total);
-  DownArgs a;
-  a.A = wpack_ws; a.X = dy; a.out = dx; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = H / 2;
-  a.Wo = W / 2; a.act = 0;
-  const int64_t N = (int64_t)B * (H / 2) * (W / 2);
-  const dim3 grid((unsigned)((N + 127) / 128), (unsigned)((Cin + 31) / 32), 4);
-  hipLaunchKernelGGL(conv4x4s2_gemm_kernel<1>, grid, dim3(256), 0, s, a);
-  return note_launch(hipGetLastError(), "conv4x4s2_gemm_kernel<dgrad>");
+extern "C" int tgsr_conv4x4s2_dgrad(const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* ws,
+                                    float* dx, void* stream) {
+  return dconv_dgrad(4, dy, B, Cin, H, W, w, Cout, ws, dx, stream);
 }
-
-extern "C" int64_t tgsr_conv4x4s2_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W) {
-  return (int64_t)down_nsplit(B, Cin, Cout, H / 2, W / 2) * Cout * Cin * 16;
-}
-
 extern "C" int tgsr_conv4x4s2_wgrad(const float* dy, const float* x, int B, int Cin, int H, int W, int Cout, float* ws,
                                     float* dw, void* stream) {
-  if (!dy || !x || !ws || !dw || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
-  if ((H | W) & 1) return TGSR_EUNSUPPORTED;
-  hipStream_t s = as_stream(stream);
-  DownWgradArgs a;
-  a.dy = dy; a.x = x; a.ws = ws; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.Ho = H / 2; a.Wo = W / 2;
-  a.nsplit = down_nsplit(B, Cin, Cout, a.Ho, a.Wo);
-  const dim3 grid((unsigned)((Cin * 16 + 127) / 128), (unsigned)((Cout + 31) / 32), (unsigned)a.nsplit);
-  hipLaunchKernelGGL(conv4x4s2_wgrad_kernel, grid, dim3(256), 0, s, a);
-  const int64_t n = (int64_t)Cout * Cin * 16;
-  const int rb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(rb), dim3(256), 0, s, ws, dw, n, a.nsplit);
-  return note_launch(hipGetLastError(), "conv4x4s2_wgrad_kernel");
+  return dconv_wgrad(4, dy, x, B, Cin, H, W, Cout, ws, dw, stream);
+}
+
+extern "C" int64_t tgsr_conv3x3_gemm_ws_elems(int op, int B, int Cin, int H, int W, int Cout) {
+  return (op < 0 || op > 2) ? 0 : ig_ws_elems(3, op, B, Cin, H, W, Cout);
+}
+extern "C" int tgsr_conv3x3_gemm_fwd(const float* x, int B, int Cin, int H, int W, const float* w, int Cout, float* ws,
+                                     float* out, void* stream) {
+  return dconv_fwd(3, x, B, Cin, H, W, w, Cout, 0, ws, out, stream);
+}
+extern "C" int tgsr_conv3x3_gemm_dgrad(const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* ws,
+                                       float* dx, void* stream) {
+  return dconv_dgrad(3, dy, B, Cin, H, W, w, Cout, ws, dx, stream);
+}
+extern "C" int tgsr_conv3x3_gemm_wgrad(const float* dy, const float* x, int B, int Cin, int H, int W, int Cout, float* ws,
+                                       float* dw, void* stream) {
+  return dconv_wgrad(3, dy, x, B, Cin, H, W, Cout, ws, dw, stream);
 }
 
 extern "C" int tgsr_leaky_relu(const float* x, const float* y_for_bwd, float* out, int64_t n, void* stream) {

@@ -94,6 +94,9 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, sh
     ob, oh, ow, ocp = _img(out, "out")
     if (ob, oh, ow) != (B, H, W) or out.dtype != x.dtype or wpack.dtype != x.dtype:
         raise TgsrError("lp.conv3x3: out %s / dtypes do not match" % (tuple(out.shape),))
+    if cin > xcp or wpack.numel() != _lib.lib().tgsr_lp_packed_conv3x3_elems(cout, cin):
+        raise TgsrError("lp.conv3x3: a [%d, %d, 3, 3] filter does not fit the input (%d channels) / the pack (%d values)"
+                        % (cout, cin, xcp, wpack.numel()))
     rcp = 0
     if residual is not None:
         rb, rh, rw, rcp = _img(residual, "residual")
@@ -224,6 +227,9 @@ def upconv_glu(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale,
     ob, oh, ow, ocp = _img(out, "out")
     if (ob, oh, ow) != (B, 2 * Hi, 2 * Wi) or out.dtype != x.dtype or wpack.dtype != x.dtype:
         raise TgsrError("lp.upconv_glu: out %s / dtypes do not match" % (tuple(out.shape),))
+    if cin > xcp or wpack.numel() != _lib.lib().tgsr_lp_packed_upconv_elems(cout, cin):
+        raise TgsrError("lp.upconv_glu: a [%d, %d, 3, 3] filter does not fit the input (%d channels) / the pack (%d values)"
+                        % (cout, cin, xcp, wpack.numel()))
     from . import ops
     e0 = ops._ev() if ops.profile is not None else None
     rc = _lib.lib().tgsr_lp_upconv_glu_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift),

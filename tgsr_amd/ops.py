@@ -3,6 +3,7 @@ torch's current HIP stream.  PyTorch is plumbing here (device memory + streams);
 libtgsr_hip.so.  No function in this file computes on the CPU or through eager torch ops.
 """
 import ctypes
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -73,6 +74,24 @@ def _nchw_bstride(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
 
 
 # ----------------------------------------------------------------------------------------- weight prep
+@functools.lru_cache(maxsize=None)
+def _pack_elems(kind: str, cout: int, cin: int) -> int:
+    L = _lib.lib()
+    return int({"conv": lambda: L.tgsr_packed_weight_elems(cout, cin, 3), "wino": lambda: L.tgsr_packed_wino_weight_elems(cout, cin),
+                "upconv": lambda: L.tgsr_packed_upconv_weight_elems(cout, cin),
+                "upwino": lambda: L.tgsr_packed_upwino_weight_elems(cout, cin)}[kind]())
+
+
+def _check_pack(what: str, kind: str, pack: torch.Tensor, cout: int, cin: int):
+    """The kernels walk the packed filter by (Cout, Cin of the INPUT): a pack made for another channel count would be
+    read past its end.  torch raises a shape error for the same mistake (weight [Cout, Cin', 3, 3] on a Cin-channel
+    input); so does this."""
+    if pack.numel() != _pack_elems(kind, cout, cin):
+        raise TgsrError("%s: the packed weight holds %d values, not the %d of a [%d, %d, 3, 3] filter - the input has %d "
+                        "channels, the weight was packed for another count" % (what, pack.numel(), _pack_elems(kind, cout, cin),
+                                                                              cout, cin, cin))
+
+
 def pack_conv3x3_weight(w: torch.Tensor, dgrad: bool = False) -> torch.Tensor:
     """[Cout,Cin,3,3] -> the [ceil(Cin/4)][9][4][Cout] stream order of tgsr_conv3x3_fwd.  `dgrad`: w is the forward
     conv's weight and the pack is of its data-gradient conv (in/out swapped, taps flipped) - no flip/transpose copies."""
@@ -112,6 +131,7 @@ def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Option
     _need_hip(x, wpack, scale, shift, residual, out)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
+    _check_pack("conv3x3_fused", "conv", wpack, cout, Cin)
     Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
     co = cout // 2 if glu else cout
     if out is None:
@@ -175,6 +195,7 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
     _need_hip(x, upack, scale, shift, residual, out)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
+    _check_pack("conv3x3_wino", "wino", upack, cout, Cin)
     co = cout // 2 if glu else cout
     if out is None:
         out = torch.empty(B, co, H, W, dtype=torch.float32, device=x.device)
@@ -211,6 +232,7 @@ def upconv3x3_glu(x: torch.Tensor, wpack_up: torch.Tensor, cout: int, scale, shi
     _need_hip(x, wpack_up, scale, shift, out)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
+    _check_pack("upconv3x3_glu", "upconv", wpack_up, cout, Cin)
     co, Ho, Wo = cout // 2, 2 * H, 2 * W
     if out is None:
         out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=x.device)
@@ -254,6 +276,7 @@ def upwino_glu(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
     _need_hip(x, upack, scale, shift, out)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
+    _check_pack("upwino_glu", "upwino", upack, cout, Cin)
     co, Ho, Wo = (cout // 2 if glu else cout), 2 * H, 2 * W
     if out is None:
         out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=x.device)
@@ -576,47 +599,93 @@ def to_uint8(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
-# ----------------------------------------------------------------------------------------- discriminator: downBlock conv
-def conv4x4s2(x: torch.Tensor, w: torch.Tensor, leaky: bool = False) -> torch.Tensor:
-    """nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False) (downBlock, util.py:92-98) [+ LeakyReLU(0.2)]: x [B,Cin,H,W] ->
-    [B,Cout,H/2,W/2]."""
+# ----------------------------------------------------------------------------------------- discriminator convolutions
+def _dconv(kind: int):
+    L = _lib.lib()
+    if kind == 4:
+        return L.tgsr_conv4x4s2_ws_elems, L.tgsr_conv4x4s2_fwd, L.tgsr_conv4x4s2_dgrad, L.tgsr_conv4x4s2_wgrad, "tgsr_conv4x4s2"
+    return (L.tgsr_conv3x3_gemm_ws_elems, L.tgsr_conv3x3_gemm_fwd, L.tgsr_conv3x3_gemm_dgrad, L.tgsr_conv3x3_gemm_wgrad,
+            "tgsr_conv3x3_gemm")
+
+
+def _dconv_fwd(kind, x, w, leaky):
     _need_hip(x, w)
     x = _f32(x, "x").contiguous()
     w = _f32(w.detach(), "w").contiguous()
     B, Cin, H, W = x.shape
-    if tuple(w.shape[1:]) != (Cin, 4, 4):
-        raise TgsrError("conv4x4s2: weight %s vs input %s" % (tuple(w.shape), tuple(x.shape)))
-    out = torch.empty(B, w.shape[0], H // 2, W // 2, dtype=torch.float32, device=x.device)
-    check(_lib.lib().tgsr_conv4x4s2_fwd(_p(x), B, Cin, H, W, _p(w), w.shape[0], 1 if leaky else 0, _p(out), _stream()),
-          "tgsr_conv4x4s2_fwd")
+    if tuple(w.shape[1:]) != (Cin, kind, kind):
+        raise TgsrError("conv%dx%d: weight %s vs input %s" % (kind, kind, tuple(w.shape), tuple(x.shape)))
+    ws_elems, fwd, _, _, name = _dconv(kind)
+    Cout = w.shape[0]
+    Ho, Wo = (H // 2, W // 2) if kind == 4 else (H, W)
+    out = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    ws = torch.empty(ws_elems(0, B, Cin, H, W, Cout), dtype=torch.float32, device=x.device)
+    if kind == 4:
+        check(fwd(_p(x), B, Cin, H, W, _p(w), Cout, 1 if leaky else 0, _p(ws), _p(out), _stream()), name + "_fwd")
+    else:
+        assert not leaky
+        check(fwd(_p(x), B, Cin, H, W, _p(w), Cout, _p(ws), _p(out), _stream()), name + "_fwd")
     return out
 
 
-def conv4x4s2_dgrad(dy: torch.Tensor, w: torch.Tensor, H: int, W: int) -> torch.Tensor:
-    """Data gradient of conv4x4s2: dy [B,Cout,H/2,W/2] -> dx [B,Cin,H,W]."""
+def _dconv_dgrad(kind, dy, w, H, W):
     _need_hip(dy, w)
     dy = _f32(dy, "dy").contiguous()
     w = _f32(w.detach(), "w").contiguous()
     B, Cout, Cin = dy.shape[0], w.shape[0], w.shape[1]
+    ws_elems, _, dgrad, _, name = _dconv(kind)
     dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dy.device)
-    ws = torch.empty(16 * Cin * Cout, dtype=torch.float32, device=dy.device)
-    check(_lib.lib().tgsr_conv4x4s2_dgrad(_p(dy), B, Cin, H, W, _p(w), Cout, _p(ws), _p(dx), _stream()),
-          "tgsr_conv4x4s2_dgrad")
+    ws = torch.empty(ws_elems(1, B, Cin, H, W, Cout), dtype=torch.float32, device=dy.device)
+    check(dgrad(_p(dy), B, Cin, H, W, _p(w), Cout, _p(ws), _p(dx), _stream()), name + "_dgrad")
     return dx
 
 
-def conv4x4s2_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """Weight gradient of conv4x4s2: dy [B,Cout,H/2,W/2], x [B,Cin,H,W] -> dw [Cout,Cin,4,4]."""
+def _dconv_wgrad(kind, dy, x, out=None):
     _need_hip(dy, x)
     dy = _f32(dy, "dy").contiguous()
     x = _f32(x, "x").contiguous()
     B, Cin, H, W = x.shape
     Cout = dy.shape[1]
-    L = _lib.lib()
-    ws = torch.empty(L.tgsr_conv4x4s2_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=x.device)
-    dw = torch.empty(Cout, Cin, 4, 4, dtype=torch.float32, device=x.device)
-    check(L.tgsr_conv4x4s2_wgrad(_p(dy), _p(x), B, Cin, H, W, Cout, _p(ws), _p(dw), _stream()), "tgsr_conv4x4s2_wgrad")
+    ws_elems, _, _, wgrad, name = _dconv(kind)
+    ws = torch.empty(ws_elems(2, B, Cin, H, W, Cout), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty(Cout, Cin, kind, kind, dtype=torch.float32, device=x.device)
+    check(wgrad(_p(dy), _p(x), B, Cin, H, W, Cout, _p(ws), _p(dw), _stream()), name + "_wgrad")
     return dw
+
+
+def conv4x4s2(x: torch.Tensor, w: torch.Tensor, leaky: bool = False) -> torch.Tensor:
+    """nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False) (downBlock, util.py:92-98) [+ LeakyReLU(0.2)]: x [B,Cin,H,W] ->
+    [B,Cout,H/2,W/2]."""
+    return _dconv_fwd(4, x, w, leaky)
+
+
+def conv4x4s2_dgrad(dy: torch.Tensor, w: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """Data gradient of conv4x4s2: dy [B,Cout,H/2,W/2] -> dx [B,Cin,H,W]."""
+    return _dconv_dgrad(4, dy, w, H, W)
+
+
+def conv4x4s2_wgrad(dy: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
+    """Weight gradient of conv4x4s2: dy [B,Cout,H/2,W/2], x [B,Cin,H,W] -> dw [Cout,Cin,4,4]."""
+    return _dconv_wgrad(4, dy, x, out)
+
+
+def conv3x3_gemm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """conv3x3 stride 1 pad 1 without bias as an implicit GEMM: the discriminators' many-channel, few-pixel layers
+    (Block3x3_leakRelu at 4x4 pixels, 512 ... 2048 channels)."""
+    return _dconv_fwd(3, x, w, False)
+
+
+def conv3x3_gemm_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    return _dconv_dgrad(3, dy, w, dy.shape[2], dy.shape[3])
+
+
+def conv3x3_gemm_wgrad(dy: torch.Tensor, x: torch.Tensor, out=None) -> torch.Tensor:
+    return _dconv_wgrad(3, dy, x, out)
+
+
+def conv3x3_gemm_pays(Cin: int, Cout: int, H: int, W: int) -> bool:
+    """Many channels on few pixels: the GEMM form; the generator's shapes stay on the tiled conv kernels."""
+    return Cin >= 256 and Cout >= 256 and H * W <= 64 * 64
 
 
 def leaky_relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

@@ -129,8 +129,18 @@ class SRTrainer:
         self._zero(self.bucket)
         for b in self.bucketsD:                       # the generator step also deposits gradients in the discriminators'
             self._zero(b)                             # parameters; they are discarded (zeroed again next step)
-        errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
-        errG.backward()
+        # the discriminators only pass the gradient through to the images here: their own parameter gradients would be
+        # discarded (netsD[i].zero_grad() opens the next discriminator step), so they are not computed
+        for b in self.bucketsD:
+            for p in b.params:
+                p.requires_grad_(False)
+        try:
+            errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
+            errG.backward()
+        finally:
+            for b in self.bucketsD:
+                for p in b.params:
+                    p.requires_grad_(True)
         self.bucket.end_step()
         for b in self.bucketsD:
             b.end_step()

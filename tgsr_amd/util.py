@@ -250,13 +250,12 @@ class D_GET_LOGITS(nn.Module):
         self.outlogits = nn.Sequential(nn.Conv2d(ndf * 8, 1, kernel_size=4, stride=4))
 
     def forward(self, h_code, c_code=None):
-        from .autograd import LinearFn
+        from .autograd import RowDot
         if self.bcondition and c_code is not None:
             c = c_code.view(-1, self.ef_dim, 1, 1).repeat(1, 1, 4, 4)
             h_code = self.jointConv(torch.cat((h_code, c), 1))
         conv = self.outlogits[0]                                  # a 4x4 / stride 4 conv on a 4x4 map = one dot product
-        out = LinearFn.apply(h_code.reshape(h_code.size(0), -1), conv.weight.reshape(1, -1), conv.bias)
-        return out.view(-1)
+        return RowDot.apply(h_code.reshape(h_code.size(0), -1), conv.weight.reshape(-1), conv.bias)
 
 
 class _ResidualNoSum(nn.Sequential):
