@@ -11,7 +11,7 @@ The reference trains through torch autograd over nn.Conv2d / nn.BatchNorm2d(trai
 import torch
 
 from . import _lib, ops
-from ._lib import check
+from ._lib import TgsrError, check
 from .ops import _p, _stream
 
 
@@ -135,8 +135,12 @@ def _nbt(bn):
     t = bn.num_batches_tracked if bn.track_running_stats else None
     if t is None:
         return None
-    if t.dtype != torch.int64 or not t.is_cuda:
-        raise RuntimeError("BatchNorm num_batches_tracked must be an int64 tensor on the GPU")
+    if t.dtype != torch.int64:
+        raise TgsrError("BatchNorm num_batches_tracked must be an int64 tensor")
+    if not t.is_cuda:
+        if bn.running_mean is not None and bn.running_mean.is_cuda:
+            raise TgsrError("BatchNorm num_batches_tracked is on the CPU while the module is on the GPU")
+        return None    # a CPU module is refused by the first HIP op of the block (ops._need_hip): no fallback
     return t
 
 
