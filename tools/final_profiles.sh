@@ -18,7 +18,12 @@ python3 bench.py --dtype bf16 --graph --batch 8 --no-cpu-baseline > $OUT/${TAG}_
 python3 bench.py --dtype bf16 --graph --batch 64 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b64.json 2> $OUT/${TAG}_bench_bf16_graph_b64.err
 echo "lp variants done"
 python3 bench.py --mode train --steps 10 > $OUT/${TAG}_bench_train.json 2> $OUT/${TAG}_bench_train.err
+python3 bench.py --mode train --gan --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_train_gan.json 2> $OUT/${TAG}_bench_train_gan.err
 echo "train done"
+bash tools/profile_stats.sh ${TAG}_train --mode train --steps 8 --warmup 2 --no-cpu-baseline
+bash tools/profile_stats.sh ${TAG}_train_gan --mode train --gan --steps 4 --warmup 2 --no-cpu-baseline
+rm -f $OUT/${TAG}_train_stats.log $OUT/${TAG}_train_gan_stats.log
+echo "train profiles done"
 TGSR_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_rehearsal_2ranks.json 2> $OUT/${TAG}_bench_rehearsal.err || echo "rehearsal failed"
 bash tools/profile_pmc.sh ${TAG}_fp32 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial
 bash tools/profile_pmc.sh ${TAG}_bf16 --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial
