@@ -200,7 +200,11 @@ def test_conv3x3_channel_slice_io():
 
 @pytest.mark.parametrize("B,Cin,H,W,K,act", [(2, 32, 64, 64, 3, False), (2, 32, 64, 64, 5, True),
                                               (3, 32, 19, 37, 5, True), (1, 32, 16, 16, 3, False),
-                                              (1, 20, 33, 70, 5, True), (4, 32, 128, 128, 5, True)])
+                                              (1, 20, 33, 70, 5, True), (4, 32, 128, 128, 5, True),
+                                              # the MFMA form of the 5x5 heads (>= 512 tiles of 8 x 64): both activations,
+                                              # 2 and 3 channel chunks, and the same shape below the threshold
+                                              (16, 32, 128, 128, 5, True), (8, 48, 256, 256, 5, False),
+                                              (16, 32, 64, 128, 5, True)])
 def test_conv_to3(B, Cin, H, W, K, act):
     from tgsr_amd import ops
     g = torch.Generator().manual_seed(K * 100 + H)

@@ -199,6 +199,119 @@ __global__ __launch_bounds__(16 * TH * KS) void conv_to3_kernel(To3Args a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same heads on the matrix cores (fp32 MFMA 16x16x4, exact fmaf chains) for the large images.  Three output channels
+// cannot fill an MFMA tile, so the kernel column kx moves into the M dimension: rows r = co * K + kx (15 of 16 for the
+// 5x5 heads) and
+//     V[(co, kx)][u] = sum_{ky, ci} w[co][ci][ky][kx] * x[ci][y + ky - P][u],      out[co][y][x] = sum_kx V[(co, kx)][x + kx - P]
+// i.e. K * Cin / 4 MFMAs per 16 input columns instead of K * K * 3 * Cin VALU FMAs per pixel; the K-term shift-sum over
+// kx goes through a small per-wave LDS image of V.  Workgroup = 8 rows x 64 columns, wave = 2 rows x 5 column tiles of 16
+// (80 columns from x0 - 4: the halo and float4 alignment); the input is staged 16 channels at a time [ch][row][80] with a
+// channel stride = 16 mod 64 words, so the B-fragment read (4 channels x 16 columns per lane group) touches 64 banks.
+template <int K, int ACT, int CH>
+__global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
+  constexpr int NJ = CH / 4;                                       // MFMA k-steps (4 channels) per staged chunk
+  constexpr int P = K / 2, TRO = 8, ROWS = TRO + K - 1, PITCH = 80;
+  constexpr int CS = (ROWS * PITCH) % 64 == 0 ? ROWS * PITCH + 16 : (ROWS * PITCH + 63) / 64 * 64 + 16 - ((ROWS * PITCH) % 64 <= 16 ? 64 : 0);
+  static_assert(CS % 64 == 16 && CS >= ROWS * PITCH && CS % 4 == 0, "channel stride");
+  constexpr int VP = 84;                                           // V image pitch
+  constexpr int SM = CH * CS > 4 * 2 * 16 * VP ? CH * CS : 4 * 2 * 16 * VP;   // the V images go on top of the dead input tile
+  __shared__ __attribute__((aligned(16))) float x_s[SM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int y0 = ty * TRO, x0 = tx * 64;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const float* xb = a.x + (int64_t)b * a.xbs;
+  const int co = col / K, kx = col - co * K;                      // this lane's A row (co, kx); rows >= 3K are zero
+  const bool arow = col < 3 * K;
+  f32x4 acc[2][5];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int ut = 0; ut < 5; ++ut) acc[r][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging: thread = one float4 column group (row, q) of the tile, looping over the chunk's 16 channels (consecutive
+  // threads = consecutive float4s of a row: coalesced); the NEXT chunk's loads are issued before this chunk's MFMAs
+  constexpr int NU = ROWS * (PITCH / 4);
+  static_assert(NU <= 256, "one staging unit per thread");
+  const int srow = tid / (PITCH / 4), sq = tid - srow * (PITCH / 4);
+  const int gy = y0 - P + srow, gx = x0 - 4 + 4 * sq;
+  const bool sin = tid < NU && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+  const float* src = xb + (sin ? (int64_t)gy * a.W + gx : 0);
+  float4 pre[CH];
+  float af[K][NJ], afn[K][NJ];
+  auto wload = [&](int c0, float (&dst)[K][NJ]) {
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        dst[ky][j] = arow ? a.w[(((int64_t)co * a.Cin + c0 + 4 * j + kq) * K + ky) * K + kx] : 0.f;
+  };
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch)
+      pre[ch] = sin ? *reinterpret_cast<const float4*>(src + (int64_t)(c0 + ch) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  gload(0);
+  wload(0, afn);
+  for (int c0 = 0; c0 < a.Cin; c0 += CH) {
+    __syncthreads();                                               // everybody is done reading the previous chunk
+    if (tid < NU) {
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch) *reinterpret_cast<float4*>(x_s + ch * CS + srow * PITCH + 4 * sq) = pre[ch];
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) af[ky][j] = afn[ky][j];
+    __syncthreads();
+    if (c0 + CH < a.Cin) {
+      gload(c0 + CH);
+      wload(c0 + CH, afn);
+    }
+    const float* bs = x_s + kq * CS + (2 * wave) * PITCH + col;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int ut = 0; ut < 5; ++ut)   // innermost: consecutive MFMAs go to different accumulators
+            acc[r][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky][j], bs[4 * j * CS + (r + ky) * PITCH + ut * 16], acc[r][ut], 0, 0, 0);
+  }
+  __syncthreads();                                                 // the input tile is dead: V images go on top of it
+  float* vs = x_s + wave * (2 * 16 * VP);
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int ut = 0; ut < 5; ++ut)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vs[(r * 16 + 4 * kq + q) * VP + ut * 16 + col] = acc[r][ut][q];   // D: row 4 (l >> 4) + reg
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's own V images are written
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int y = y0 + 2 * wave + r;
+#pragma unroll
+    for (int oc = 0; oc < 3; ++oc) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) v += vs[(r * 16 + oc * K + k) * VP + lane + k - P + 4];   // column j = x - x0 + 4
+      const int64_t o = ((int64_t)b * 3 + oc) * HW + (int64_t)y * a.W + x0 + lane;
+      if (ACT == TGSR_ACT_TANH_AXPY) {
+        v = fast_tanh(v);
+        if (a.addend) v += a.alpha * a.addend[o];
+      }
+      a.out[o] = v;
+    }
+  }
+}
+
 template <int K, int ACT, int TH, int KS>
 static int launch_to3_th(To3Args a, hipStream_t s) {
   a.tiles_x = (a.W + 63) / 64;
@@ -219,6 +332,16 @@ static int launch_to3(To3Args a, hipStream_t s) {
   // 16-row tiles when they still give >= 2 workgroups per CU; smaller images take 8- or 4-row tiles (more workgroups)
   // and split the input channels over 2 / 4 thread groups (more waves per workgroup, fewer stages per wave)
   auto tiles = [&](int th) { return (int64_t)a.B * ((a.W + 63) / 64) * ((a.H + th - 1) / th); };
+  // large images of the 5x5 heads: the MFMA form (measured at B = 16: 256^2 116 -> 83 us, 128^2 34 -> 25 us); the 3x3
+  // heads fill 9 of 16 MFMA rows and gain nothing over the streaming kernel
+  if (K == 5 && a.Cin % 16 == 0 && a.W % 64 == 0 && a.H % 8 == 0 && tiles(8) >= 512 && a.xbs % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) {
+    a.tiles_x = a.W / 64;
+    a.tiles_y = a.H / 8;
+    // 8-channel chunks (31 KB of LDS, 4 workgroups per CU): 83 us on the 256^2 head against 90 us with 16-channel chunks
+    hipLaunchKernelGGL((conv_to3_mfma_kernel<K, ACT, 8>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
+    return note_launch(hipGetLastError(), "conv_to3_mfma_kernel");
+  }
   if (tiles(16) >= 512) return launch_to3_th<K, ACT, 16, 1>(a, s);
   if (tiles(8) >= 512) return launch_to3_th<K, ACT, 8, 2>(a, s);
   return launch_to3_th<K, ACT, 4, 4>(a, s);

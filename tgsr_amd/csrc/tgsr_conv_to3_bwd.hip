@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_to3_wgrad_mfma_kernel(To3BwdArgs a, 
   float* g_s = smem_f;
   float* red_s = smem_f;                                            // [wave 1..3][ky][cg][row 16][col 16], after the main loop
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
-  int t = blockIdx.x;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;

@@ -76,6 +76,8 @@ __device__ __forceinline__ void lds_dma16(const void* g, void* lds_wave_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
 }
 
-__device__ __forceinline__ float sigmoidf_fast(float g) { return __frcp_rn(1.f + __expf(-g)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each): __frcp_rn expands to the 10-instruction IEEE division sequence, which made the
+// GLU epilogue (64 gates per lane) half of the kernel's VALU work
+__device__ __forceinline__ float sigmoidf_fast(float g) { return __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
 
 }  // namespace tgsr
