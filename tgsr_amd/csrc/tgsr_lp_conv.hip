@@ -163,7 +163,19 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-          for (int pr = 0; pr < RW; ++pr) acc[cb][pr] = LP<T>::mfma32(af[cb], bf[pr], acc[cb][pr]);
+          for (int pr = 0; pr < RW; ++pr) {
+            if (LP_DBG & 64) {   // timing experiment: the same FLOPs as two 16x16x32 MFMAs (results meaningless)
+              f32x4w lo, hi2;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { lo[q] = acc[cb][pr][q]; hi2[q] = acc[cb][pr][4 + q]; }
+              lo = LP<T>::mfma16(af[cb], bf[pr], lo);
+              hi2 = LP<T>::mfma16(bf[pr], af[cb], hi2);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { acc[cb][pr][q] = lo[q]; acc[cb][pr][4 + q] = hi2[q]; }
+            } else {
+              acc[cb][pr] = LP<T>::mfma32(af[cb], bf[pr], acc[cb][pr]);
+            }
+          }
       }
     }
   }
