@@ -375,6 +375,9 @@ def main():
                          "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
     ap.add_argument("--gan", action="store_true", help="--mode train with the three discriminators (G/D alternation)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (inference mode)")
+    ap.add_argument("--graph-lanes", type=int, default=1,
+                    help="--graph: capture this many independent batches as parallel branches of ONE hipGraph (a replay = "
+                         "that many steps; --steps must be a multiple)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="inference: consecutive steps alternate between this many stream lanes (1 = one step at a time)")
     ap.add_argument("--profile-every", type=int, default=20,
@@ -434,8 +437,15 @@ def main():
     cap, LR, LRb = cap.to(dev), LR.to(dev), LRb.to(dev)
     lens = lens.tolist()
 
+    glanes = max(1, args.graph_lanes) if args.graph else 1
     if args.graph:      # BASELINE config 5: the step replayed from a captured hipGraph (identical results)
-        pipe.capture(cap, lens, LR, LRb)
+        if args.steps % glanes:
+            raise SystemExit("--steps must be a multiple of --graph-lanes (a replay runs that many steps)")
+        pipe.capture(cap, lens, LR, LRb)                   # the one-lane step
+    multi = None
+    if glanes > 1:
+        from tgsr_amd.trainer import GraphedStep
+        multi = GraphedStep(pipe, cap, lens, LR, LRb, lanes=glanes)   # `glanes` independent batches in one graph
 
     def step(eager=False):
         return pipe(cap, lens, LR, LRb) if eager or not args.graph else pipe.replay(cap, LR, LRb)
@@ -465,7 +475,10 @@ def main():
     prof, nprof = [], 0
     fence()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(args.steps // glanes):
+        if multi is not None:               # one replay = `glanes` steps; the per-launch sampling happens in the one-lane
+            multi.replay()                  # pass below (a replay of several lanes has no single step to sample)
+            continue
         # sampled steps are counted from the END of the run: the last step drains the lanes anyway
         sample = args.profile_every > 0 and (args.steps - 1 - k) % args.profile_every == 0
         ops.profile = prof if sample else None
@@ -489,7 +502,14 @@ def main():
     fence()
     t1 = time.perf_counter()
     for k in range(args.steps):
-        step()
+        sample = multi is not None and args.profile_every > 0 and (args.steps - 1 - k) % args.profile_every == 0
+        if sample:
+            ops.profile, pipe.overlap = prof, False
+            nprof += 1
+            step(eager=True)
+            ops.profile, pipe.overlap = None, not args.serial
+        else:
+            step()
     fence()
     dt1 = time.perf_counter() - t1
     if dist is not None:
@@ -519,12 +539,16 @@ def main():
                                       (B, 1 if args.dtype == "fp32" else 4),
                           "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world,
                           "streams": 1 if args.serial else 2, "launch": "hipgraph" if args.graph else "eager",
-                          "lanes": nlanes, "storage": "fp32 NCHW" if args.dtype == "fp32" else
+                          "lanes": nlanes, **({"graph_lanes": glanes} if glanes > 1 else {}), "storage": "fp32 NCHW" if args.dtype == "fp32" else
                           "%s channels-last (zero-bordered), fp32 accumulate; inputs / outputs fp32" % args.dtype,
                           "sampled_steps": nprof,
                           "note": "`value` covers all %d steps incl. the %d event-sampled single-stream one(s) "
                                   "(~1 %% of the mean at the default K); `value_one_lane` = the same K steps issued one "
-                                  "at a time, measured right after" % (args.steps, nprof)},
+                                  "at a time, measured right after" % (args.steps, nprof) +
+                                  ("; --graph-lanes %d: a replay runs %d independent batches of %d as parallel branches of "
+                                   "one hipGraph, the timed region is %d replays with no sampling - the event-sampled "
+                                   "steps are part of the one-lane pass instead" % (glanes, glanes, B, args.steps // glanes)
+                                   if glanes > 1 else "")},
                "roofline": roof, "kernels": kern}
         if att is not None:
             res["attention"] = att

@@ -3,6 +3,7 @@ and prepare_datablur, datasets.py:71-109): batch preparation, the text-enc -> G_
 wiring and the uint8 epilogue.  Orchestration only; all arithmetic is in the modules' HIP kernels.
 """
 import numpy as np
+
 import torch
 
 from .miscc.config import cfg
@@ -82,12 +83,13 @@ class SRPipeline:
 
     # ------------------------------------------------------------------ hipGraph replay (BASELINE config 5)
     @torch.no_grad()
-    def capture(self, captions, cap_lens, LR, LRb, warmup=3):
-        """Capture one forward (both streams, ~60 launches) into a hipGraph bound to static input buffers.
+    def capture(self, captions, cap_lens, LR, LRb, warmup=3, lanes=1):
+        """Capture one forward (both streams, ~60 launches) into a hipGraph bound to static input buffers (`lanes` > 1:
+        that many independent batches as parallel branches of the graph, see GraphedStep).
         `replay(captions, LR, LRb)` then copies new inputs in and relaunches the whole step with one call.  The
         caption lengths (hence T_max and the mask shape) are part of the captured step: a batch with other lengths
         needs its own capture, like the reference's cudnn.benchmark re-tunes per shape."""
-        self._graphed = GraphedStep(self, captions, cap_lens, LR, LRb, warmup=warmup)
+        self._graphed = GraphedStep(self, captions, cap_lens, LR, LRb, warmup=warmup, lanes=lanes)
         return self._graphed.out
 
     @torch.no_grad()
@@ -178,46 +180,83 @@ class SRPipeline:
 
 class GraphedStep:
     """One captured inference step of an SRPipeline: a hipGraph + the static input / output tensors it is bound to.
-    With `stream` the replay (and the copy of new inputs) runs on that stream."""
+    With `stream` the replay (and the copy of new inputs) runs on that stream.
+
+    `lanes` > 1 captures that many INDEPENDENT batches (each with its own static inputs, outputs and activation buffers)
+    as parallel branches of the one graph: a replay then runs `lanes` steps whose kernels interleave on the device the
+    way eager stream lanes do, without the host cost of ~60 launches per step and without relying on separate graph
+    launches overlapping (measured: they do not).  `inputs` / `out` are then lists of length `lanes`."""
 
     @torch.no_grad()
-    def __init__(self, pipe, captions, cap_lens, LR, LRb, stream=None, warmup=3):
+    def __init__(self, pipe, captions, cap_lens, LR, LRb, stream=None, warmup=3, lanes=1):
         dev = LR.device
         self.stream = stream
-        self.inputs = (captions.clone(), LR.clone(), LRb.clone())
+        self.lanes = max(1, int(lanes))
+        sets = [(captions.clone(), LR.clone(), LRb.clone()) for _ in range(self.lanes)]
         self.lens = list(cap_lens)
         lpx = getattr(pipe, "_lp", None)
-        if lpx is not None:                              # reduced-precision path: the step is bound to its own set of
+        bufs = None
+        if lpx is not None:                              # reduced-precision path: every lane is bound to its own set of
             lpx.refresh()                                # activation images, allocated (zeroed) outside the graph
-            self.bufs = lpx.alloc(LR.shape[0], LR.shape[2], LR.shape[3], dev)
-            lpx.force_bufs = self.bufs
+            bufs = [lpx.alloc(LR.shape[0], LR.shape[2], LR.shape[3], dev) for _ in range(self.lanes)]
+            lpx.force_bufs = bufs[0]
+        self.bufs = bufs
+        overlap = pipe.overlap
         try:
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):                   # weight packs, caches and the allocator warm up outside the graph
                 for _ in range(warmup):
-                    pipe(self.inputs[0], self.lens, self.inputs[1], self.inputs[2])
+                    pipe(sets[0][0], self.lens, sets[0][1], sets[0][2])
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
+            branch = [torch.cuda.Stream(device=dev) for _ in range(self.lanes - 1)]
+            outs = []
+            if self.lanes > 1:
+                # every lane is ONE chain: the lanes provide the concurrency the GL / GH stream split provides inside a
+                # single step.  (Two streams per lane would be a fork nested inside a forked branch: hipStreamEndCapture
+                # segfaults on that topology on ROCm 7.2 - also with the side streams created before the capture.)
+                pipe.overlap = False
             with torch.cuda.graph(self.graph):
-                self.out = pipe(self.inputs[0], self.lens, self.inputs[1], self.inputs[2])
+                main = torch.cuda.current_stream(dev)
+                for k in range(self.lanes):
+                    st = main if k == 0 else branch[k - 1]
+                    if k:
+                        st.wait_stream(main)             # fork: the branch joins the capture
+                    with torch.cuda.stream(st):
+                        if lpx is not None:
+                            lpx.force_bufs = bufs[k]
+                        outs.append(pipe(sets[k][0], self.lens, sets[k][1], sets[k][2]))
+                for st in branch:
+                    main.wait_stream(st)                 # join
         finally:
             if lpx is not None:
                 lpx.force_bufs = None
+            if self.lanes > 1:
+                pipe.overlap = overlap
+        self.inputs = sets[0] if self.lanes == 1 else sets
+        self.out = outs[0] if self.lanes == 1 else outs
 
     @torch.no_grad()
     def replay(self, captions=None, LR=None, LRb=None):
         """Copy new inputs (same shapes, same caption lengths) into the static buffers and relaunch the step.  Returns
-        the static outputs: consume them (on `stream`, or after synchronising it) before this lane's next replay."""
+        the static outputs: consume them (on `stream`, or after synchronising it) before this lane's next replay.
+        With `lanes` > 1 each argument is a list of `lanes` tensors (or None: keep the buffers' contents)."""
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
                 return self._go(captions, LR, LRb)
         return self._go(captions, LR, LRb)
 
     def _go(self, captions, LR, LRb):
-        for dst, src in zip(self.inputs, (captions, LR, LRb)):
-            if src is not None and src is not dst:
-                dst.copy_(src, non_blocking=True)
+        if self.lanes == 1:
+            for dst, src in zip(self.inputs, (captions, LR, LRb)):
+                if src is not None and src is not dst:
+                    dst.copy_(src, non_blocking=True)
+        else:
+            for k in range(self.lanes):
+                for dst, src in zip(self.inputs[k], (captions, LR, LRb)):
+                    if src is not None and src[k] is not dst:
+                        dst.copy_(src[k], non_blocking=True)
         self.graph.replay()
         return self.out
