@@ -17,6 +17,7 @@ python3 bench.py --dtype bf16 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_lanes.j
 python3 bench.py --dtype bf16 --graph --batch 8 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b8.json 2> $OUT/${TAG}_bench_bf16_graph_b8.err
 python3 bench.py --dtype bf16 --graph --batch 64 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b64.json 2> $OUT/${TAG}_bench_bf16_graph_b64.err
 python3 bench.py --dtype bf16 --graph --graph-lanes 4 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_lanes4.json 2> $OUT/${TAG}_bench_bf16_graph_lanes4.err
+python3 bench.py --dtype bf16 --graph --graph-lanes 8 --batch 8 --steps 48 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b8_lanes8.json 2> $OUT/${TAG}_bench_bf16_graph_b8_lanes8.err
 echo "lp variants done"
 python3 bench.py --mode train --steps 10 > $OUT/${TAG}_bench_train.json 2> $OUT/${TAG}_bench_train.err
 python3 bench.py --mode train --gan --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_train_gan.json 2> $OUT/${TAG}_bench_train_gan.err
