@@ -88,6 +88,10 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
   const int y0 = ty * TR, x0 = tx * 32;                         // output origin (unpadded coordinates)
+  if (LP_DBG & (128 | 256 | 512)) {   // timing experiment: half of the workgroups start ~3 us late (which half: 3 guesses
+    const int sel = (LP_DBG & 128) ? (blockIdx.x >> 3) & 1 : (LP_DBG & 256) ? (blockIdx.x >> 8) & 1 : blockIdx.x & 1;
+    if (sel) { __builtin_amdgcn_s_sleep(100); }                 // at how two co-residents of a CU are numbered)
+  }
 
   // ---- input tile: all lanes of the 4 waves copy 16-byte slots; slot S of the tile = pixel S / NSL, physical slot
   // S % NSL holding the pixel's logical slot (S % NSL) ^ swz(column)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Timing decomposition of lp_conv3x3_kernel: builds variants of the library with parts of the kernel switched off
 # (-DLP_DBG bits: 1 no weight LDS-DMA after the prologue, 2 no output stores, 4 no B-fragment ds_reads, 8 no A-fragment
-# ds_reads, 16 no tile LDS-DMA, 64 the same FLOPs as 16x16x32 MFMAs) and, on a GPU box, times the generator's layer shapes with each.  Results are WRONG by
+# ds_reads, 16 no tile LDS-DMA, 64 the same FLOPs as 16x16x32 MFMAs, 128 | 256 | 512 a 3 us head start for half of
+# the workgroups) and, on a GPU box, times the generator's layer shapes with each.  Results are WRONG by
 # construction; only the times mean anything.   build here:  bash tools/lp_conv_experiments.sh build
 #                                               on the box:  bash tools/lp_conv_experiments.sh run > gpurun_out/lp_dbg.txt
 set -e
