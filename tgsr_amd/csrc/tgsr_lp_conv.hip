@@ -55,6 +55,24 @@ constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the
 #ifndef LP_DBG
 #define LP_DBG 0   // timing experiments only (tools/lp_conv_experiments.sh): bits switch parts of the kernel off
 #endif
+#if LP_DBG & 1024
+// diagnostic build only: shader-clock and 100 MHz wall stamps around the main loop of every workgroup (in-kernel clock =
+// d(s_memtime) / d(s_memrealtime) x 100 MHz, MI355X_MICROARCH.md DVFS item 6); never part of the shipped library
+__device__ unsigned long long g_lp_stamps[10 * 4096];  // [workgroup][4 shader-clock stamps, 4 wall stamps, HW_ID, XCC_ID]
+#define LP_STAMP(k)                                                                      \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {                                         \
+      g_lp_stamps[blockIdx.x * 10 + (k)] = __builtin_amdgcn_s_memtime();                 \
+      g_lp_stamps[blockIdx.x * 10 + 4 + (k)] = __builtin_amdgcn_s_memrealtime();         \
+      if ((k) == 0) {                                                                    \
+        g_lp_stamps[blockIdx.x * 10 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    \
+        g_lp_stamps[blockIdx.x * 10 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
+#else
+#define LP_STAMP(k) do { } while (0)
+#endif
 template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
 __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
   constexpr int NCB = COUT / 32, RW = TR / 4, TC = 34, NPIX = (TR + 2) * TC;
@@ -82,6 +100,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 
   const int tid = threadIdx.x, lane = tid & 63, c0 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  LP_STAMP(0);
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
@@ -140,6 +159,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   for (int dx = 0; dx < 3; ++dx)
     bbase[dx] = ((wave * RW) * TC + c0 + dx) * PB + ((h ^ lp_swz<CIN>(c0 + dx)) << 4);
 
+  LP_STAMP(1);
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     // my pieces of chunk ch (and, first time, of the input tile) have landed - the DMAs of chunk ch+1 may still be in
@@ -184,6 +204,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
     }
   }
 
+  LP_STAMP(2);
   // ---- epilogue: affine (+ GLU | + residual) in registers, then through LDS so that HBM sees whole lines.
   // The accumulator layout gives a lane 4 consecutive channels (8 bytes) of one pixel: stored directly that is 16
   // partial writes per 128-byte line (measured: WRITE_SIZE 2x the tensor).  Instead every wave stages its RW x 32
@@ -262,6 +283,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
     const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
     if (!(LP_DBG & 2) || j == 0) *reinterpret_cast<u32x4*>(ob + (pw >> 5) * orow + (int64_t)(pw & 31) * (a.ocp * 2) + q * 16) = v;
   }
+  LP_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -555,6 +577,12 @@ static int launch_lp_conv(const LpConvArgs& a, int Cin, int Cout, int epi, bool 
 }  // namespace tgsr
 
 using namespace tgsr;
+
+#if LP_DBG & 1024
+extern "C" int tgsr_debug_read_lp_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(tgsr::g_lp_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int64_t tgsr_lp_packed_conv3x3_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9; }
 
