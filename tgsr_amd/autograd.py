@@ -8,6 +8,8 @@ The reference trains through torch autograd over nn.Conv2d / nn.BatchNorm2d(trai
         backward: tgsr_bn_train_bwd (GLU', BN') -> data gradient = the same conv kernels on flipped/transposed
                   weights (+ tgsr_sumpool2x2 through the up-sample) and tgsr_conv3x3_wgrad
 """
+import contextlib
+
 import torch
 
 from . import _lib, ops
@@ -18,6 +20,17 @@ from .ops import _p, _stream
 def _dgrad_weight(w: torch.Tensor) -> torch.Tensor:
     """conv_transpose of a stride-1 pad-1 3x3 conv = the same conv with the kernel flipped and in/out swapped."""
     return w.flip(2, 3).transpose(0, 1).contiguous()
+
+
+# Weight gradients are leaves of the backward graph (nothing downstream waits for them until the optimizer): while a side
+# stream is registered here they run beside the data-gradient chain instead of inside it.  Only train.SRTrainer registers
+# one, for the duration of a step's backward, and joins it before anything reads the gradients; modules driven directly
+# (`loss.backward()` then `p.grad`) stay on one stream.
+WGRAD_SIDE = {}          # device index -> torch.cuda.Stream
+
+
+def wgrad_stream(dev):
+    return WGRAD_SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
 
 
 def _grad_out(param, shape, dev):
@@ -109,23 +122,29 @@ class ConvBnAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             from . import util
             dw = _grad_out(weight, weight.shape, dev)
-            if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
-                # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
-                # up-sampled grid)
-                wws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
-                rc = L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
-                check(rc, "tgsr_upwino_wgrad")
-            elif (not upsample) and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
-                # plain conv: 16 Winograd positions per 2x2 output tile (2.25x fewer multiplies than 9 taps per pixel)
-                wws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
-                rc = L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
-                check(rc, "tgsr_wino_wgrad")
-            else:
-                n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
-                wws = torch.empty(n, dtype=torch.float32, device=dev)
-                rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0,
-                                          _p(wws), _p(dw), _stream())
-                check(rc, "tgsr_conv3x3_wgrad")
+            side = wgrad_stream(dev)
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(dev))           # draw (and the zeroed bucket) are ready
+                draw.record_stream(side)
+                x.record_stream(side)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
+                    # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
+                    # up-sampled grid)
+                    wws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
+                    rc = L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
+                    check(rc, "tgsr_upwino_wgrad")
+                elif (not upsample) and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
+                    # plain conv: 16 Winograd positions per 2x2 output tile (2.25x fewer multiplies than 9 taps per pixel)
+                    wws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
+                    rc = L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
+                    check(rc, "tgsr_wino_wgrad")
+                else:
+                    n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
+                    wws = torch.empty(n, dtype=torch.float32, device=dev)
+                    rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0,
+                                              _p(wws), _p(dw), _stream())
+                    check(rc, "tgsr_conv3x3_wgrad")
         dres = dout if has_res else None
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
