@@ -33,6 +33,27 @@ def wgrad_stream(dev):
     return WGRAD_SIDE.get(dev.index if dev.index is not None else torch.cuda.current_device())
 
 
+def on_wgrad_stream(dev, inputs, fn, adopted):
+    """Run `fn` (a weight-gradient launch reading `inputs`) on the registered side stream, ordered after everything
+    already queued on the current stream; without a registered stream: just run it.  `adopted`: the gradient goes
+    straight into the parameter's bucket slot and autograd adopts it without a kernel - only then may it still be in
+    flight when backward() moves on.  A gradient autograd will ADD to an existing .grad (a parameter used twice: the tied
+    stages of models16, the discriminators' real + fake passes) is computed on the current stream, after the side stream
+    has drained, because that add runs on the current stream."""
+    side = wgrad_stream(dev)
+    if side is None:
+        return fn()
+    if not adopted:
+        torch.cuda.current_stream(dev).wait_stream(side)
+        return fn()
+    side.wait_stream(torch.cuda.current_stream(dev))
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        return fn()
+
+
 def _grad_out(param, shape, dev):
     """Where a parameter gradient is written: the parameter's region of its flat gradient bucket when that is open
     (parallel.grad_slot: no accumulation kernel afterwards), else a fresh tensor."""
@@ -122,12 +143,9 @@ class ConvBnAct(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             from . import util
             dw = _grad_out(weight, weight.shape, dev)
-            side = wgrad_stream(dev)
-            if side is not None:
-                side.wait_stream(torch.cuda.current_stream(dev))           # draw (and the zeroed bucket) are ready
-                draw.record_stream(side)
-                x.record_stream(side)
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            adopted = dw.data_ptr() != 0 and dw._base is not None      # a view of the flat bucket (parallel.grad_slot)
+
+            def wgrad():
                 if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
                     # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
                     # up-sampled grid)
@@ -145,6 +163,7 @@ class ConvBnAct(torch.autograd.Function):
                     rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0,
                                               _p(wws), _p(dw), _stream())
                     check(rc, "tgsr_conv3x3_wgrad")
+            on_wgrad_stream(dev, (draw, x), wgrad, adopted)
         dres = dout if has_res else None
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
 
