@@ -73,6 +73,8 @@ class SRTrainer:
                 self.bucketsD.append(FlatGradBucket(d.parameters()).attach())
                 self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
                                                    betas=(0.5, 0.999)))
+        self._dstreams = [torch.cuda.Stream(device=self.device) for _ in self.netsD] \
+            if self.device.type == "cuda" and os.environ.get("TGSR_D_STREAMS", "1") != "0" else []
 
     def loss(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """hr_pyramid: the 3 target scales [B,3,2s,2s], [B,3,4s,4s], [B,3,8s,8s]."""
@@ -142,12 +144,33 @@ class SRTrainer:
         fake_imgL, fine_im, mu, logvar, words_embs, sent_emb = self.forward_G(captions, cap_lens, LR, LRb)
         for b in self.bucketsD:
             self._zero(b)
-        errsD = self.d_losses(fine_im, hr_pyramid, sent_emb)
-        for e, b, o in zip(errsD, self.bucketsD, self.optsD):
-            e.backward()
-            b.end_step()
-            b.all_reduce_mean()
-            o.step()
+        if self._dstreams:
+            # the three discriminators are independent of each other: each one's forward, backward, all-reduce and Adam
+            # step run on a stream of their own (the 64^2 / 128^2 discriminators' layers leave most CUs idle)
+            B = sent_emb.shape[0]
+            real_labels, fake_labels, _ = prepare_labels(B, self.device)
+            main = torch.cuda.current_stream(self.device)
+            errsD = []
+            for i, (d, b, o, st) in enumerate(zip(self.netsD, self.bucketsD, self.optsD, self._dstreams)):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    for t in (fine_im[i], hr_pyramid[i], sent_emb):
+                        t.record_stream(st)
+                    e = losses.discriminator_loss(d, hr_pyramid[i], fine_im[i], sent_emb, real_labels, fake_labels)
+                    e.backward()
+                    b.end_step()
+                    b.all_reduce_mean()
+                    o.step()
+                errsD.append(e)
+            for st in self._dstreams:
+                main.wait_stream(st)
+        else:
+            errsD = self.d_losses(fine_im, hr_pyramid, sent_emb)
+            for e, b, o in zip(errsD, self.bucketsD, self.optsD):
+                e.backward()
+                b.end_step()
+                b.all_reduce_mean()
+                o.step()
         self._zero(self.bucket)
         for b in self.bucketsD:                       # the generator step also deposits gradients in the discriminators'
             self._zero(b)                             # parameters; they are discarded (zeroed again next step)
