@@ -3,12 +3,12 @@
 // The reference trains with nn.BatchNorm2d batch statistics (util.py:77,116,119).  A grid-wide reduction
 // sits between the convolution and the GLU, so training runs each block as
 //     conv3x3 (tgsr_conv3x3_fwd, identity affine) -> raw [B][C][HW]
-//     bn_stats   : per-channel sum / sum of squares, one float4 stream over raw         (HBM-bound)
-//     bn_finalize: mean, biased var (combined in double), invstd, scale/shift, running-stat update (momentum, unbiased)
-//     bn_act_fwd : y = GLU(raw*scale+shift) | raw*scale+shift (+ residual)              (HBM-bound, float4)
+//     bn_stats       : per-channel sum / sum of squares, one float4 stream over raw     (HBM-bound)
+//     bn_fin_act_fwd : every workgroup combines its channel's partials (double): mean, biased var, invstd, scale/shift,
+//                      running-stat update (momentum, unbiased); then y = GLU(raw*scale+shift) | raw*scale+shift (+ residual)
 // and the backward as
-//     bn_act_bwd_reduce: dz = d(BN output) from dy (GLU'/identity), per-channel sum dz, sum dz*xhat
-//     bn_act_bwd_apply : draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta
+//     bn_act_bwd_reduce   : dz = d(BN output) from dy (GLU'/identity), per-channel sum dz, sum dz*xhat
+//     bn_fin_act_bwd_apply: combines those partials, draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta
 // followed by the conv data/weight gradients (tgsr_conv3x3_fwd on flipped weights, tgsr_conv3x3_wgrad).
 #include "tgsr_common.h"
 
@@ -61,71 +61,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __res
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nsplit, int C, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* running_mean, float* running_var, float* __restrict__ mean,
-                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
-                                   long long* num_batches_tracked) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int k = 0; k < nsplit; ++k) {
-    s += partial[((int64_t)c * nsplit + k) * 2];
-    q += partial[((int64_t)c * nsplit + k) * 2 + 1];
-  }
-  const double m = s / count;
-  double var = q / count - m * m;
-  var = var < 0.0 ? 0.0 : var;
-  const float is = (float)(1.0 / sqrt(var + (double)eps));
-  mean[c] = (float)m;
-  invstd[c] = is;
-  const float sc = gamma[c] * is;
-  scale[c] = sc;
-  shift[c] = beta[c] - (float)m * sc;
-  if (running_mean) {
-    const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-  }
-}
-
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
-
-// y = GLU(affine(raw)) or affine(raw) (+ residual).  grid-stride over float4 groups of the OUTPUT.
-template <bool GLU>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ raw, int B, int C, int HW,
-                                                         const float* __restrict__ scale,
-                                                         const float* __restrict__ shift,
-                                                         const float* __restrict__ res, int64_t rbs,
-                                                         float* __restrict__ out, int64_t obs, int leaky) {
-  const int Co = GLU ? C / 2 : C;
-  const int HW4 = HW >> 2;
-  const int64_t total = (int64_t)B * Co * HW4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int p4 = (int)(i % HW4);
-    const int64_t t = i / HW4;
-    const int c = (int)(t % Co), b = (int)(t / Co);
-    const float4 v = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c) * HW + 4 * p4);
-    const float sv = scale[c], tv = shift[c];
-    float4 y = make_float4(v.x * sv + tv, v.y * sv + tv, v.z * sv + tv, v.w * sv + tv);
-    if (GLU) {
-      const float4 g = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c + Co) * HW + 4 * p4);
-      const float sg = scale[c + Co], tg = shift[c + Co];
-      y.x *= sigm(g.x * sg + tg);
-      y.y *= sigm(g.y * sg + tg);
-      y.z *= sigm(g.z * sg + tg);
-      y.w *= sigm(g.w * sg + tg);
-    } else if (res) {
-      const float4 r = *reinterpret_cast<const float4*>(res + b * rbs + (int64_t)c * HW + 4 * p4);
-      y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
-    } else if (leaky) {                                    // LeakyReLU(0.2): downBlock / Block3x3_leakRelu (util.py:92-98)
-      y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y;
-      y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
-    }
-    *reinterpret_cast<float4*>(out + b * obs + (int64_t)c * HW + 4 * p4) = y;
-  }
-}
 
 // Backward, pass 1.  grid (Co, nsplit).  For output channel c: GLU -> BN channels c (value) and c+Co (gate).
 // partial[c][s] = (sum dz_v, sum dz_v*xhat_v, sum dz_g, sum dz_g*xhat_g)   (non-GLU: the last two are 0)
@@ -168,53 +104,153 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
   }
 }
 
-// sums[ch] = (sum dz, sum dz*xhat) per BN channel, combined in double; dgamma = sum dz*xhat, dbeta = sum dz
-template <bool GLU>
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nsplit, int C, float* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int Co = GLU ? C / 2 : C;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= Co) return;
-  double a[4] = {0, 0, 0, 0};
-  for (int k = 0; k < nsplit; ++k)
-    for (int j = 0; j < 4; ++j) a[j] += partial[((int64_t)c * nsplit + k) * 4 + j];
-  sums[2 * c] = (float)a[0]; sums[2 * c + 1] = (float)a[1];
-  dbeta[c] = (float)a[0]; dgamma[c] = (float)a[1];
-  if (GLU) {
-    sums[2 * (c + Co)] = (float)a[2]; sums[2 * (c + Co) + 1] = (float)a[3];
-    dbeta[c + Co] = (float)a[2]; dgamma[c + Co] = (float)a[3];
+// ---------------------------------------------------------------------------------------------------------------------
+// The finalize steps folded into their consumers (72 four-microsecond launches per generator step sat on the dependent
+// chain between the statistics pass and the pass that uses them): every workgroup of the normalise / backward-apply pass
+// owns ONE output channel and a slice of its (b, pixel) range - grid (Co, nsplit) like the statistics pass - and first
+// combines that channel's partial sums itself (<= 64 values, lanes of wave 0, pairwise tree in double: every workgroup
+// of a channel computes bit-identical statistics); the workgroup of slice 0 also writes what the old finalize kernels
+// wrote (mean / invstd / scale / shift, running statistics, dgamma / dbeta).
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// channel ch: (scale, shift) from the statistics partials; slice-0 workgroups publish the statistics
+__device__ __forceinline__ void bn_channel_affine(const float* __restrict__ partial, int nsplit, int ch, double count,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                  float momentum, float* running_mean, float* running_var, float* mean,
+                                                  float* invstd, float* scale, float* shift, bool publish, float* bc) {
+  if (threadIdx.x < 64) {
+    double s = 0.0, q = 0.0;
+    if ((int)threadIdx.x < nsplit) {
+      s = partial[((int64_t)ch * nsplit + threadIdx.x) * 2];
+      q = partial[((int64_t)ch * nsplit + threadIdx.x) * 2 + 1];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (threadIdx.x == 0) {
+      const double m = s / count;
+      double var = q / count - m * m;
+      var = var < 0.0 ? 0.0 : var;
+      const float is = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[ch] * is, sh = beta[ch] - (float)m * sc;
+      bc[0] = sc;
+      bc[1] = sh;
+      if (publish) {
+        mean[ch] = (float)m;
+        invstd[ch] = is;
+        scale[ch] = sc;
+        shift[ch] = sh;
+        if (running_mean) {
+          const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+          running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+          running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+        }
+      }
+    }
   }
 }
 
-// Backward, pass 2: draw[b][ch][p] = gamma*invstd*(dz - sum_dz/N - xhat*sum_dzx/N), elementwise over the output grid
 template <bool GLU>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+__global__ __launch_bounds__(kBnThreads) void bn_fin_act_fwd_kernel(
+    const float* __restrict__ raw, int B, int C, int HW, const float* __restrict__ partial, int nsplit_stats,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+    float* running_var, float* mean, float* invstd, float* scale, float* shift, long long* num_batches_tracked,
+    const float* __restrict__ res, int64_t rbs, float* __restrict__ out, int64_t obs, int leaky, int nsplit) {
+  __shared__ float bc[4];
+  const int Co = GLU ? C / 2 : C;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const double count = (double)B * HW;
+  bn_channel_affine(partial, nsplit_stats, c, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                    scale, shift, sp == 0, bc);
+  if (GLU) {
+    __syncthreads();      // (bc[0..1] written by thread 0; the gate channel goes to bc[2..3])
+    bn_channel_affine(partial, nsplit_stats, c + Co, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                      invstd, scale, shift, sp == 0, bc + 2);
+  }
+  if (c == 0 && sp == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  __syncthreads();
+  const float sv = bc[0], tv = bc[1], sg = GLU ? bc[2] : 0.f, tg = GLU ? bc[3] : 0.f;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
+  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
+  for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
+    const int b = (int)(e / HW);
+    const int p = (int)(e - (int64_t)b * HW);
+    const float4 v = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c) * HW + p);
+    float4 y = make_float4(v.x * sv + tv, v.y * sv + tv, v.z * sv + tv, v.w * sv + tv);
+    if (GLU) {
+      const float4 g = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c + Co) * HW + p);
+      y.x *= sigm(g.x * sg + tg);
+      y.y *= sigm(g.y * sg + tg);
+      y.z *= sigm(g.z * sg + tg);
+      y.w *= sigm(g.w * sg + tg);
+    } else if (res) {
+      const float4 r = *reinterpret_cast<const float4*>(res + b * rbs + (int64_t)c * HW + p);
+      y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+    } else if (leaky) {                                    // LeakyReLU(0.2): downBlock / Block3x3_leakRelu (util.py:92-98)
+      y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y;
+      y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
+    }
+    *reinterpret_cast<float4*>(out + b * obs + (int64_t)c * HW + p) = y;
+  }
+}
+
+// Backward, pass 2 with the finalize folded in: grid (Co, nsplit) - the partials of bn_act_bwd_reduce_kernel on the same grid
+template <bool GLU>
+__global__ __launch_bounds__(kBnThreads) void bn_fin_act_bwd_apply_kernel(
     const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, const float* __restrict__ sums, float invN, float* __restrict__ draw, int leaky) {
+    const float* __restrict__ invstd, const float* __restrict__ partial, int nsplit, float invN,
+    float* __restrict__ draw, float* __restrict__ dgamma, float* __restrict__ dbeta, int leaky) {
+  __shared__ float bs[4];
   const int Co = GLU ? C / 2 : C;
-  const int64_t total = (int64_t)B * Co * HW;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int p = (int)(i % HW);
-    const int64_t t = i / HW;
-    const int c = (int)(t % Co), b = (int)(t / Co);
-    float dy = dout[i];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  if (threadIdx.x < 64) {
+    double a[4] = {0, 0, 0, 0};
+    if ((int)threadIdx.x < nsplit)
+      for (int j = 0; j < 4; ++j) a[j] = partial[((int64_t)c * nsplit + threadIdx.x) * 4 + j];
+    for (int j = 0; j < 4; ++j) a[j] = wave_sum_d(a[j]);
+    if (threadIdx.x == 0) {
+      for (int j = 0; j < 4; ++j) bs[j] = (float)a[j];
+      if (sp == 0) {
+        dbeta[c] = (float)a[0];
+        dgamma[c] = (float)a[1];
+        if (GLU) {
+          dbeta[c + Co] = (float)a[2];
+          dgamma[c + Co] = (float)a[3];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float s0 = bs[0] * invN, s1 = bs[1] * invN, s2 = bs[2] * invN, s3 = bs[3] * invN;
+  const float sv = scale[c], tv = shift[c], mv = mean[c], isv = invstd[c];   // scale = gamma * invstd
+  float sg = 0.f, tg = 0.f, mg = 0.f, isg = 0.f;
+  if (GLU) { sg = scale[c + Co]; tg = shift[c + Co]; mg = mean[c + Co]; isg = invstd[c + Co]; }
+  const int64_t total = (int64_t)B * HW;
+  const int64_t per = (total + nsplit - 1) / nsplit;
+  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
+  for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
+    const int b = (int)(e / HW);
+    const int p = (int)(e - (int64_t)b * HW);
+    float dy = dout[((int64_t)b * Co + c) * HW + p];
     const int64_t iv_ = ((int64_t)b * C + c) * HW + p;
     const float rv = raw[iv_];
-    const float sv = scale[c], mv = mean[c], isv = invstd[c];   // scale = gamma * invstd
-    if (!GLU && leaky && rv * sv + shift[c] <= 0.f) dy *= 0.2f;
     const float xv = (rv - mv) * isv;
     if (GLU) {
       const int64_t ig_ = iv_ + (int64_t)Co * HW;
       const float rg = raw[ig_];
-      const float sg = scale[c + Co], mg = mean[c + Co], isg = invstd[c + Co];
       const float xg = (rg - mg) * isg;
-      const float av = rv * sv + shift[c], s = sigm(rg * sg + shift[c + Co]);
+      const float av = rv * sv + tv, s = sigm(rg * sg + tg);
       const float dzv = dy * s, dzg = dy * av * s * (1.f - s);
-      draw[iv_] = sv * (dzv - sums[2 * c] * invN - xv * sums[2 * c + 1] * invN);
-      draw[ig_] = sg * (dzg - sums[2 * (c + Co)] * invN - xg * sums[2 * (c + Co) + 1] * invN);
+      draw[iv_] = sv * (dzv - s0 - xv * s1);
+      draw[ig_] = sg * (dzg - s2 - xg * s3);
     } else {
-      draw[iv_] = sv * (dy - sums[2 * c] * invN - xv * sums[2 * c + 1] * invN);
+      if (leaky && rv * sv + tv <= 0.f) dy *= 0.2f;
+      draw[iv_] = sv * (dy - s0 - xv * s1);
     }
   }
 }
@@ -269,17 +305,17 @@ extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const f
   const int nsplit = tgsr_bn_train_nsplit(B, C, HW);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(C, nsplit), dim3(kBnThreads), 0, s, raw, (int64_t)C * HW, B, HW,
                      partial_ws, nsplit);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
-                     (double)B * HW, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift,
-                     reinterpret_cast<long long*>(num_batches_tracked));
   const int Co = glu ? C / 2 : C;
-  const int g = grid_for((int64_t)B * Co * (HW / 4));
+  const int ns2 = tgsr_bn_train_nsplit(B, Co, HW);
+  long long* nbt = reinterpret_cast<long long*>(num_batches_tracked);
   if (glu)
-    hipLaunchKernelGGL(bn_act_fwd_kernel<true>, dim3(g), dim3(256), 0, s, raw, B, C, HW, scale, shift, nullptr,
-                       (int64_t)0, out, out_bstride, 0);
+    hipLaunchKernelGGL(bn_fin_act_fwd_kernel<true>, dim3(Co, ns2), dim3(kBnThreads), 0, s, raw, B, C, HW, partial_ws, nsplit,
+                       gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, nbt, nullptr,
+                       (int64_t)0, out, out_bstride, 0, ns2);
   else
-    hipLaunchKernelGGL(bn_act_fwd_kernel<false>, dim3(g), dim3(256), 0, s, raw, B, C, HW, scale, shift, residual,
-                       res_bstride, out, out_bstride, leaky);
+    hipLaunchKernelGGL(bn_fin_act_fwd_kernel<false>, dim3(Co, ns2), dim3(kBnThreads), 0, s, raw, B, C, HW, partial_ws, nsplit,
+                       gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, nbt, residual,
+                       res_bstride, out, out_bstride, leaky, ns2);
   return note_launch(hipGetLastError(), "bn_train_fwd");
 }
 
@@ -297,21 +333,17 @@ extern "C" int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int
   const int Co = glu ? C / 2 : C;
   const int nsplit = tgsr_bn_train_nsplit(B, Co, HW);
   const float invN = (float)(1.0 / ((double)B * HW));
-  const int g = grid_for((int64_t)B * Co * HW);
+  (void)sums_ws;                         // (was the finalize kernel's output; the apply pass combines the partials itself)
   if (glu) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C, HW,
                        scale, shift, mean, invstd, partial_ws, nsplit, 0);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<true>, dim3((Co + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
-                       sums_ws, dgamma, dbeta);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(g), dim3(256), 0, s, dout, raw, B, C, HW, scale, shift,
-                       mean, invstd, sums_ws, invN, draw, 0);
+    hipLaunchKernelGGL(bn_fin_act_bwd_apply_kernel<true>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C, HW,
+                       scale, shift, mean, invstd, partial_ws, nsplit, invN, draw, dgamma, dbeta, 0);
   } else {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<false>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C,
                        HW, scale, shift, mean, invstd, partial_ws, nsplit, leaky);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3((Co + 63) / 64), dim3(64), 0, s, partial_ws, nsplit, C,
-                       sums_ws, dgamma, dbeta);
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(g), dim3(256), 0, s, dout, raw, B, C, HW, scale, shift,
-                       mean, invstd, sums_ws, invN, draw, leaky);
+    hipLaunchKernelGGL(bn_fin_act_bwd_apply_kernel<false>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C, HW,
+                       scale, shift, mean, invstd, partial_ws, nsplit, invN, draw, dgamma, dbeta, leaky);
   }
   return note_launch(hipGetLastError(), "bn_train_bwd");
 }
