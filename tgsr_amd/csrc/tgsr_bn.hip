@@ -74,19 +74,14 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
   const int Co = GLU ? C / 2 : C;
   const int c = blockIdx.x, sp = blockIdx.y;
   const int64_t total = (int64_t)B * HW;
-  const int64_t per = (total + nsplit - 1) / nsplit;
+  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
   const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
   const float sv = scale[c], tv = shift[c], mv = mean[c], iv = invstd[c];
   float sg = 0.f, tg = 0.f, mg = 0.f, ig = 0.f;
   if (GLU) { sg = scale[c + Co]; tg = shift[c + Co]; mg = mean[c + Co]; ig = invstd[c + Co]; }
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
-    const int b = (int)(e / HW);
-    const int p = (int)(e - (int64_t)b * HW);
-    float dy = dout[((int64_t)b * Co + c) * HW + p];
-    const float rv = raw[((int64_t)b * C + c) * HW + p];
+  auto acc1 = [&](float dy, float rv, float rg) {
     if (GLU) {
-      const float rg = raw[((int64_t)b * C + c + Co) * HW + p];
       const float av = rv * sv + tv, s = sigm(rg * sg + tg);
       const float dzv = dy * s, dzg = dy * av * s * (1.f - s);
       a0 += dzv; a1 += dzv * ((rv - mv) * iv);
@@ -94,6 +89,24 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
     } else {
       if (leaky && rv * sv + tv <= 0.f) dy *= 0.2f;
       a0 += dy; a1 += dy * ((rv - mv) * iv);
+    }
+  };
+  if ((HW & 3) == 0 && (per & 3) == 0) {                 // float4 streams (every slice starts on a multiple of 4)
+    for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
+      const int b = (int)(e / HW);
+      const int p = (int)(e - (int64_t)b * HW);
+      const float4 dy = *reinterpret_cast<const float4*>(dout + ((int64_t)b * Co + c) * HW + p);
+      const float4 rv = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c) * HW + p);
+      float4 rg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GLU) rg = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c + Co) * HW + p);
+      acc1(dy.x, rv.x, rg.x); acc1(dy.y, rv.y, rg.y); acc1(dy.z, rv.z, rg.z); acc1(dy.w, rv.w, rg.w);
+    }
+  } else {
+    for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
+      const int b = (int)(e / HW);
+      const int p = (int)(e - (int64_t)b * HW);
+      acc1(dout[((int64_t)b * Co + c) * HW + p], raw[((int64_t)b * C + c) * HW + p],
+           GLU ? raw[((int64_t)b * C + c + Co) * HW + p] : 0.f);
     }
   }
   a0 = block_sum(a0, red); a1 = block_sum(a1, red);
@@ -231,26 +244,44 @@ __global__ __launch_bounds__(kBnThreads) void bn_fin_act_bwd_apply_kernel(
   float sg = 0.f, tg = 0.f, mg = 0.f, isg = 0.f;
   if (GLU) { sg = scale[c + Co]; tg = shift[c + Co]; mg = mean[c + Co]; isg = invstd[c + Co]; }
   const int64_t total = (int64_t)B * HW;
-  const int64_t per = (total + nsplit - 1) / nsplit;
+  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
   const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
-  for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
-    const int b = (int)(e / HW);
-    const int p = (int)(e - (int64_t)b * HW);
-    float dy = dout[((int64_t)b * Co + c) * HW + p];
-    const int64_t iv_ = ((int64_t)b * C + c) * HW + p;
-    const float rv = raw[iv_];
+  auto one = [&](float dy, float rv, float rg, float& ov, float& og) {
     const float xv = (rv - mv) * isv;
     if (GLU) {
-      const int64_t ig_ = iv_ + (int64_t)Co * HW;
-      const float rg = raw[ig_];
       const float xg = (rg - mg) * isg;
       const float av = rv * sv + tv, s = sigm(rg * sg + tg);
       const float dzv = dy * s, dzg = dy * av * s * (1.f - s);
-      draw[iv_] = sv * (dzv - s0 - xv * s1);
-      draw[ig_] = sg * (dzg - s2 - xg * s3);
+      ov = sv * (dzv - s0 - xv * s1);
+      og = sg * (dzg - s2 - xg * s3);
     } else {
       if (leaky && rv * sv + tv <= 0.f) dy *= 0.2f;
-      draw[iv_] = sv * (dy - s0 - xv * s1);
+      ov = sv * (dy - s0 - xv * s1);
+    }
+  };
+  if ((HW & 3) == 0) {
+    for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
+      const int b = (int)(e / HW);
+      const int p = (int)(e - (int64_t)b * HW);
+      const int64_t iv_ = ((int64_t)b * C + c) * HW + p, ig_ = iv_ + (int64_t)Co * HW;
+      const float4 dy = *reinterpret_cast<const float4*>(dout + ((int64_t)b * Co + c) * HW + p);
+      const float4 rv = *reinterpret_cast<const float4*>(raw + iv_);
+      float4 rg = make_float4(0.f, 0.f, 0.f, 0.f), ov, og;
+      if (GLU) rg = *reinterpret_cast<const float4*>(raw + ig_);
+      one(dy.x, rv.x, rg.x, ov.x, og.x); one(dy.y, rv.y, rg.y, ov.y, og.y);
+      one(dy.z, rv.z, rg.z, ov.z, og.z); one(dy.w, rv.w, rg.w, ov.w, og.w);
+      *reinterpret_cast<float4*>(draw + iv_) = ov;
+      if (GLU) *reinterpret_cast<float4*>(draw + ig_) = og;
+    }
+  } else {
+    for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
+      const int b = (int)(e / HW);
+      const int p = (int)(e - (int64_t)b * HW);
+      const int64_t iv_ = ((int64_t)b * C + c) * HW + p, ig_ = iv_ + (int64_t)Co * HW;
+      float ov, og = 0.f;
+      one(dout[((int64_t)b * Co + c) * HW + p], raw[iv_], GLU ? raw[ig_] : 0.f, ov, og);
+      draw[iv_] = ov;
+      if (GLU) draw[ig_] = og;
     }
   }
 }
