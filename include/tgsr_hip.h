@@ -280,7 +280,8 @@ int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma
 
 /*
  * Backward of the above: dout [B][C or C/2][HW] dense -> draw [B][C][HW] (gradient wrt the raw conv output),
- * dgamma, dbeta [C].  The gradient wrt a residual input is dout itself.  sums_ws: 2*C floats.
+ * dgamma, dbeta [C].  The gradient wrt a residual input is dout itself.  sums_ws: no longer used (the apply pass combines
+ * the partials itself); any non-NULL pointer, e.g. partial_ws.
  */
 int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW, const float* scale,
                       const float* shift, const float* mean, const float* invstd, int glu, float* partial_ws,

@@ -62,7 +62,8 @@ def _grad_out(param, shape, dev):
     return slot if slot is not None else torch.empty(tuple(shape), dtype=torch.float32, device=dev)
 
 
-def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgrad: bool = False) -> torch.Tensor:
+def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgrad: bool = False,
+              residual: torch.Tensor = None) -> torch.Tensor:
     """conv3x3 without affine / activation (what BatchNorm's batch statistics are taken of, and the data gradient):
     the Winograd kernel where it applies (no up-sampling, Cout % 64 == 0, Cin % 4 == 0), else the direct kernel.
     The weights change every step, so they are packed per call (a few microseconds).  `dgrad`: `weight` is the forward
@@ -71,35 +72,106 @@ def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgr
     from . import util
     Cout = weight.shape[1] if dgrad else weight.shape[0]
     if util.WINOGRAD and not upsample and util._wino_pays(x, Cout, None, None):
-        return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False, dgrad=dgrad), Cout, None, None)
+        return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False, dgrad=dgrad), Cout, None, None, residual=residual)
     if util.WINOGRAD and upsample and ops.upwino_supported(x, Cout):
-        assert not dgrad
+        assert not dgrad and residual is None
         return ops.upwino_glu(x, ops.pack_upwino_weight(weight, glu=False), Cout, None, None, glu=False)
-    return ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight, dgrad=dgrad), Cout, None, None, glu=False, upsample=upsample)
+    return ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight, dgrad=dgrad), Cout, None, None, glu=False, upsample=upsample,
+                             residual=residual)
+
+
+def _cba_forward(x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps, nbt):
+    """conv3x3 (raw) -> BatchNorm batch statistics -> normalise (+ GLU | + residual).  Returns (out, raw, stats)."""
+    L = _lib.lib()
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    raw = _conv_raw(x, weight.detach(), upsample)
+    Ho, Wo = raw.shape[2], raw.shape[3]
+    HW = Ho * Wo
+    dev = x.device
+    nsplit = L.tgsr_bn_train_nsplit(B, Cout, HW)
+    ws = torch.empty(Cout * nsplit * 4, dtype=torch.float32, device=dev)
+    stats = torch.empty(4, Cout, dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
+    co = Cout // 2 if glu else Cout
+    out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=dev)
+    res = None if residual is None else residual.contiguous()
+    rc = L.tgsr_bn_train_fwd(_p(raw), B, Cout, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
+                             float(momentum), _p(running_mean), _p(running_var), 1 if glu else 0, _p(res),
+                             0 if res is None else co * HW, _p(ws), _p(stats[0]), _p(stats[1]), _p(stats[2]),
+                             _p(stats[3]), _p(out), co * HW, _p(nbt), _stream())
+    check(rc, "tgsr_bn_train_fwd")
+    return out, raw, stats
+
+
+def _cba_backward(x, weight, raw, stats, gamma, beta, glu, upsample, dout, need_dx, need_dw, dx_addend=None):
+    """Backward of _cba_forward: (dx, dw, dgamma, dbeta).  `dx_addend` (the gradient arriving at x through a skip
+    connection) is added in the data-gradient conv's epilogue instead of by a separate elementwise kernel."""
+    L = _lib.lib()
+    dout = dout.contiguous()
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    Ho, Wo = raw.shape[2], raw.shape[3]
+    HW = Ho * Wo
+    dev = x.device
+    co = Cout // 2 if glu else Cout
+    nsplit = L.tgsr_bn_train_nsplit(B, co, HW)
+    ws = torch.empty(co * nsplit * 4, dtype=torch.float32, device=dev)
+    draw = torch.empty_like(raw)
+    dgamma, dbeta = _grad_out(gamma, (Cout,), dev), _grad_out(beta, (Cout,), dev)
+    rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, Cout, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]),
+                             1 if glu else 0, _p(ws), _p(ws), _p(draw), _p(dgamma), _p(dbeta), _stream())
+    check(rc, "tgsr_bn_train_bwd")
+    dx = dw = None
+    if need_dx:
+        cpad = (Cin + 31) // 32 * 32                                  # the kernel tiles 32 output channels
+        if cpad != Cin:                                               # stem convs (Cin = 3): zero-padded rows
+            wT = _dgrad_weight(weight.detach())                       # [Cin, Cout, 3, 3]
+            wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cout, 3, 3)), 0)
+            dxu = _conv_raw(draw, wT)[:, :Cin].contiguous()           # [B, Cin, Ho, Wo]
+            if dx_addend is not None:
+                dxu = dxu + dx_addend
+        else:
+            dxu = _conv_raw(draw, weight.detach(), dgrad=True, residual=None if upsample else dx_addend)
+        if upsample:
+            dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dev)
+            check(L.tgsr_sumpool2x2(_p(dxu), B * Cin, H, W, _p(dx), _stream()), "tgsr_sumpool2x2")
+            if dx_addend is not None:
+                dx = dx + dx_addend
+        else:
+            dx = dxu
+    if need_dw:
+        from . import util
+        dw = _grad_out(weight, weight.shape, dev)
+        adopted = dw._base is not None                                # a view of the flat bucket (parallel.grad_slot)
+
+        def wgrad():
+            if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
+                # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
+                # up-sampled grid)
+                wws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
+                rc = L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
+                check(rc, "tgsr_upwino_wgrad")
+            elif (not upsample) and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
+                # plain conv: 16 Winograd positions per 2x2 output tile (2.25x fewer multiplies than 9 taps per pixel)
+                wws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
+                rc = L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
+                check(rc, "tgsr_wino_wgrad")
+            else:
+                n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
+                wws = torch.empty(n, dtype=torch.float32, device=dev)
+                rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0,
+                                          _p(wws), _p(dw), _stream())
+                check(rc, "tgsr_conv3x3_wgrad")
+        on_wgrad_stream(dev, (draw, x), wgrad, adopted)
+    return dx, dw, dgamma, dbeta
 
 
 class ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps, nbt=None):
-        L = _lib.lib()
         x = x.contiguous()
-        B, Cin, H, W = x.shape
-        Cout = weight.shape[0]
-        raw = _conv_raw(x, weight.detach(), upsample)
-        Ho, Wo = raw.shape[2], raw.shape[3]
-        HW = Ho * Wo
-        dev = x.device
-        nsplit = L.tgsr_bn_train_nsplit(B, Cout, HW)
-        ws = torch.empty(Cout * nsplit * 4, dtype=torch.float32, device=dev)
-        stats = torch.empty(4, Cout, dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
-        co = Cout // 2 if glu else Cout
-        out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=dev)
-        res = None if residual is None else residual.contiguous()
-        rc = L.tgsr_bn_train_fwd(_p(raw), B, Cout, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
-                                 float(momentum), _p(running_mean), _p(running_var), 1 if glu else 0, _p(res),
-                                 0 if res is None else co * HW, _p(ws), _p(stats[0]), _p(stats[1]), _p(stats[2]),
-                                 _p(stats[3]), _p(out), co * HW, _p(nbt), _stream())
-        check(rc, "tgsr_bn_train_fwd")
+        out, raw, stats = _cba_forward(x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum,
+                                       eps, nbt)
         ctx.save_for_backward(x, weight, raw, stats)
         ctx.cfg = (glu, upsample, residual is not None)
         ctx.bn_params = (gamma, beta)          # only to look up their gradient slots (parallel.grad_slot) in backward
@@ -107,65 +179,39 @@ class ConvBnAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        L = _lib.lib()
         x, weight, raw, stats = ctx.saved_tensors
         glu, upsample, has_res = ctx.cfg
-        dout = dout.contiguous()
-        B, Cin, H, W = x.shape
-        Cout = weight.shape[0]
-        Ho, Wo = raw.shape[2], raw.shape[3]
-        HW = Ho * Wo
-        dev = x.device
-        co = Cout // 2 if glu else Cout
-        nsplit = L.tgsr_bn_train_nsplit(B, co, HW)
-        ws = torch.empty(co * nsplit * 4, dtype=torch.float32, device=dev)
-        sums = torch.empty(2 * Cout, dtype=torch.float32, device=dev)
-        draw = torch.empty_like(raw)
         gamma, beta = ctx.bn_params
-        dgamma, dbeta = _grad_out(gamma, (Cout,), dev), _grad_out(beta, (Cout,), dev)
-        rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, Cout, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]),
-                                 1 if glu else 0, _p(ws), _p(sums), _p(draw), _p(dgamma), _p(dbeta), _stream())
-        check(rc, "tgsr_bn_train_bwd")
-        dx = dw = None
-        if ctx.needs_input_grad[0]:
-            cpad = (Cin + 31) // 32 * 32                                  # the kernel tiles 32 output channels
-            if cpad != Cin:                                               # stem convs (Cin = 3): zero-padded rows
-                wT = _dgrad_weight(weight.detach())                       # [Cin, Cout, 3, 3]
-                wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cout, 3, 3)), 0)
-                dxu = _conv_raw(draw, wT)[:, :Cin].contiguous()           # [B, Cin, Ho, Wo]
-            else:
-                dxu = _conv_raw(draw, weight.detach(), dgrad=True)
-            if upsample:
-                dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dev)
-                check(L.tgsr_sumpool2x2(_p(dxu), B * Cin, H, W, _p(dx), _stream()), "tgsr_sumpool2x2")
-            else:
-                dx = dxu
-        if ctx.needs_input_grad[1]:
-            from . import util
-            dw = _grad_out(weight, weight.shape, dev)
-            adopted = dw.data_ptr() != 0 and dw._base is not None      # a view of the flat bucket (parallel.grad_slot)
-
-            def wgrad():
-                if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
-                    # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
-                    # up-sampled grid)
-                    wws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
-                    rc = L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
-                    check(rc, "tgsr_upwino_wgrad")
-                elif (not upsample) and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
-                    # plain conv: 16 Winograd positions per 2x2 output tile (2.25x fewer multiplies than 9 taps per pixel)
-                    wws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
-                    rc = L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
-                    check(rc, "tgsr_wino_wgrad")
-                else:
-                    n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
-                    wws = torch.empty(n, dtype=torch.float32, device=dev)
-                    rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0,
-                                              _p(wws), _p(dw), _stream())
-                    check(rc, "tgsr_conv3x3_wgrad")
-            on_wgrad_stream(dev, (draw, x), wgrad, adopted)
+        dx, dw, dgamma, dbeta = _cba_backward(x, weight, raw, stats, gamma, beta, glu, upsample, dout,
+                                              ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         dres = dout if has_res else None
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+class ResBlockFn(torch.autograd.Function):
+    """ResBlock (util.py:110-130): x + BN(conv(GLU(BN(conv(x))))) as ONE autograd node, so that the skip connection's
+    gradient is added to the first conv's data gradient in that conv kernel's epilogue (its `residual` input) instead of
+    by an elementwise add per block (10 per generator step on tensors of up to 67 MB)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, rm1, rv1, nbt1, mom1, eps1, w2, g2, b2, rm2, rv2, nbt2, mom2, eps2):
+        x = x.contiguous()
+        y, raw1, st1 = _cba_forward(x, w1, g1, b1, rm1, rv1, None, True, False, mom1, eps1, nbt1)
+        out, raw2, st2 = _cba_forward(y, w2, g2, b2, rm2, rv2, x, False, False, mom2, eps2, nbt2)
+        ctx.save_for_backward(x, w1, raw1, st1, y, w2, raw2, st2)
+        ctx.bn_params = (g1, b1, g2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1, raw1, st1, y, w2, raw2, st2 = ctx.saved_tensors
+        g1, b1, g2, b2 = ctx.bn_params
+        dout = dout.contiguous()
+        ni = ctx.needs_input_grad
+        dy, dw2, dg2, db2 = _cba_backward(y, w2, raw2, st2, g2, b2, False, False, dout, True, ni[9])
+        dx, dw1, dg1, db1 = _cba_backward(x, w1, raw1, st1, g1, b1, True, False, dy, ni[0], ni[1],
+                                          dx_addend=dout if ni[0] else None)
+        return dx, dw1, dg1, db1, None, None, None, None, None, dw2, dg2, db2, None, None, None, None, None
 
 
 def _nbt(bn):
@@ -195,6 +241,23 @@ def conv_bn_act_train(x, conv, bn, glu=False, upsample=False, residual=None):
         # affines on
         torch.autograd.graph.increment_version(bn.running_mean)
         torch.autograd.graph.increment_version(bn.running_var)
+    return out
+
+
+def res_block_train(x, conv1, bn1, conv2, bn2):
+    """Training-mode ResBlock over its parameter-holder modules (one autograd node: ResBlockFn)."""
+    for bn in (bn1, bn2):
+        if bn.momentum is None:
+            raise NotImplementedError("BatchNorm2d(momentum=None) (cumulative average) is not used by the reference")
+    t1, t2 = bn1.track_running_stats, bn2.track_running_stats
+    out = ResBlockFn.apply(x, conv1.weight, bn1.weight, bn1.bias, bn1.running_mean if t1 else None,
+                           bn1.running_var if t1 else None, _nbt(bn1), bn1.momentum, bn1.eps,
+                           conv2.weight, bn2.weight, bn2.bias, bn2.running_mean if t2 else None,
+                           bn2.running_var if t2 else None, _nbt(bn2), bn2.momentum, bn2.eps)
+    for bn in (bn1, bn2):
+        if bn.track_running_stats:
+            torch.autograd.graph.increment_version(bn.running_mean)
+            torch.autograd.graph.increment_version(bn.running_var)
     return out
 
 
