@@ -550,6 +550,16 @@ def main():
                                    "steps are part of the one-lane pass instead" % (glanes, glanes, B, args.steps // glanes)
                                    if glanes > 1 else "")},
                "roofline": roof, "kernels": kern}
+        # the whole step against SURVEY.md 8(d)'s compulsory conv-path bytes (173.9 MB per image at the reference's layer
+        # boundaries in fp32, half of that with 2-byte storage) and 21.07 GFLOP per image: the "fraction of the HBM
+        # roofline" BASELINE.json's north_star speaks of, per GPU
+        mb_img = 173.9 if args.dtype == "fp32" else 173.9 / 2
+        res["step_roofline"] = {
+            "compulsory_MB_per_image": mb_img, "GFLOP_per_image": 21.07,
+            "hbm_frac": round(res["value"] / world * mb_img * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
+            "algorithmic_TFLOPs": round(res["value"] / world * 21.07e9 / 1e12, 1),   # direct-form FLOPs (Winograd /
+            "mfma_peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_LP_MFMA_TFLOPS,   # sub-pixel forms execute fewer)
+            "hbm_frac_one_lane": round(res["value_one_lane"] / world * mb_img * 1e6 / (PEAK_HBM_GBS * 1e9), 4)}
         if att is not None:
             res["attention"] = att
         if world == 1 and not args.no_cpu_baseline:

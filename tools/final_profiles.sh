@@ -18,6 +18,7 @@ python3 bench.py --dtype bf16 --graph --batch 8 --no-cpu-baseline > $OUT/${TAG}_
 python3 bench.py --dtype bf16 --graph --batch 64 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b64.json 2> $OUT/${TAG}_bench_bf16_graph_b64.err
 python3 bench.py --dtype bf16 --graph --graph-lanes 4 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_lanes4.json 2> $OUT/${TAG}_bench_bf16_graph_lanes4.err
 python3 bench.py --dtype bf16 --graph --graph-lanes 8 --batch 8 --steps 48 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b8_lanes8.json 2> $OUT/${TAG}_bench_bf16_graph_b8_lanes8.err
+python3 bench.py --dtype bf16 --graph --batch 128 --steps 6 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b128.json 2> $OUT/${TAG}_bench_bf16_graph_b128.err
 echo "lp variants done"
 python3 bench.py --mode train --steps 10 > $OUT/${TAG}_bench_train.json 2> $OUT/${TAG}_bench_train.err
 python3 bench.py --mode train --gan --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_train_gan.json 2> $OUT/${TAG}_bench_train_gan.err
