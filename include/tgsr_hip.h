@@ -253,6 +253,15 @@ int tgsr_linear_fwd(const float* x, int B, int K, const float* w, const float* b
  * (dw may be NULL).  x, w 16-byte aligned.
  */
 int tgsr_rowdot_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K, void* stream);
+
+/*
+ * CA_NET.forward (util.py:372-400) in one launch: x = fc(sent_emb) (w [4 ncf][tdim], bias [4 ncf]); GLU halves;
+ * mu = h[:ncf], logvar = h[ncf:] ([B][ncf] each); c_code = eps * exp(0.5 * logvar) + mu with eps [B][ncf] standard
+ * normals drawn by the caller (the reference draws them from torch's generator, util.py:388-396).  c_code and eps may
+ * both be NULL (the x8 generators discard c_code, model.py:51-52).
+ */
+int tgsr_ca_net_fwd(const float* sent_emb, const float* w, const float* bias, const float* eps, int B, int tdim, int ncf,
+                    float* c_code, float* mu, float* logvar, void* stream);
 int tgsr_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int B, int K, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

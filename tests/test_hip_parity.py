@@ -636,3 +636,27 @@ def test_winograd_kernels_random_shape_sweep():
             up = ops.upwino_glu(x.to(DEV), ops.pack_upwino_weight(w.to(DEV), glu=glu), Cout, scale.to(DEV),
                                 shift.to(DEV), glu=glu)
             close(up, O.glu(uref) if glu else uref, atol=3e-5, rtol=3e-5)
+
+
+def test_ca_net_fused_inference_kernel():
+    """CA_NET.forward in eval mode under no_grad is one HIP launch (tgsr_ca_net_fwd): same mu / logvar / c_code as the
+    torch formulation of util.py:372-400 (which training keeps), drawing the same normals from torch's generator."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd import util
+    cfg_reset()
+    try:
+        torch.manual_seed(5)
+        ca = util.CA_NET().to(DEV)
+        x = torch.randn(7, cfg.TEXT.EMBEDDING_DIM, device=DEV)
+        torch.manual_seed(11)
+        with torch.enable_grad():
+            c_ref, mu_ref, lv_ref = ca.eval()(x)                 # grad enabled -> the torch path
+        torch.manual_seed(11)
+        with torch.no_grad():
+            c, mu, lv = ca(x)
+        close(mu, mu_ref, atol=2e-6)
+        close(lv, lv_ref, atol=2e-6)
+        close(c, c_ref, atol=5e-6)
+        assert mu.shape == (7, cfg.GAN.CONDITION_DIM) and c.shape == mu.shape
+    finally:
+        cfg_reset()

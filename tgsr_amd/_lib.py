@@ -54,6 +54,7 @@ SIGNATURES = {
     "tgsr_conv1x1_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "tgsr_linear_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "tgsr_rowdot_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tgsr_ca_net_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "tgsr_rowdot_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tgsr_bn_train_nsplit": (_i, [_i, _i, _i]),
     "tgsr_bn_train_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -112,6 +112,47 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
   if (dw) dw[k] = s;
 }
 
+// CA_NET (util.py:372-400) in one launch: x = fc(sent_emb) [4 ncf]; h = x[:2ncf] * sigmoid(x[2ncf:]) (GLU);
+// mu = h[:ncf], logvar = h[ncf:]; c_code = eps * exp(0.5 logvar) + mu.  One workgroup per sample: the sentence code in
+// LDS, a thread per output of the Linear (float4 over its weight row), the GLU pairs meet in LDS.  The eager form was
+// a library GEMM plus eight pointwise launches.  eps comes from the caller (torch's generator: the reference consumes
+// exactly ncf normals per sample here, util.py:388-396).
+__global__ __launch_bounds__(256) void ca_net_kernel(const float* __restrict__ sent, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ eps,
+                                                     int tdim, int ncf, float* __restrict__ c_code,
+                                                     float* __restrict__ mu, float* __restrict__ logvar) {
+  extern __shared__ float sm[];            // [tdim] sentence code, then [4 ncf] Linear outputs
+  float* xs = sm;
+  float* ys = sm + tdim;
+  const int b = blockIdx.x;
+  for (int k = threadIdx.x; k < tdim; k += 256) xs[k] = sent[(int64_t)b * tdim + k];
+  __syncthreads();
+  for (int j = threadIdx.x; j < 4 * ncf; j += 256) {
+    const float* wr = w + (int64_t)j * tdim;
+    float s = 0.f;
+    if ((tdim & 3) == 0) {
+      for (int k = 0; k < tdim; k += 4) {
+        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+        s += wv.x * xs[k] + wv.y * xs[k + 1] + wv.z * xs[k + 2] + wv.w * xs[k + 3];
+      }
+    } else {
+      for (int k = 0; k < tdim; ++k) s += wr[k] * xs[k];
+    }
+    ys[j] = s + bias[j];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * ncf; j += 256) {
+    const float h = ys[j] * (1.f / (1.f + __expf(-ys[j + 2 * ncf])));
+    if (j < ncf) mu[(int64_t)b * ncf + j] = h;
+    else logvar[(int64_t)b * ncf + j - ncf] = h;
+    ys[j] = h;
+  }
+  __syncthreads();
+  if (c_code)
+    for (int j = threadIdx.x; j < ncf; j += 256)
+      c_code[(int64_t)b * ncf + j] = eps[(int64_t)b * ncf + j] * __expf(0.5f * ys[ncf + j]) + ys[j];
+}
+
 static int gemm_launch(const GemmArgs& a, bool nt, int batch, hipStream_t s) {
   dim3 grid((a.N + 127) / 128, (a.M + 31) / 32, batch);
   if (nt) hipLaunchKernelGGL(gemm_bias_kernel<true>, grid, dim3(256), 0, s, a);
@@ -130,6 +171,16 @@ extern "C" int tgsr_conv1x1_fwd(const float* x, int B, int Cin, int S, const flo
   a.A = w; a.B = x; a.bias = bias; a.C = out; a.M = Cout; a.N = S; a.K = Cin; a.lda = Cin; a.ldb = S;
   a.csm = S; a.csn = 1; a.bsB = (int64_t)Cin * S; a.bsC = (int64_t)Cout * S;
   return gemm_launch(a, false, B, as_stream(stream));
+}
+
+extern "C" int tgsr_ca_net_fwd(const float* sent_emb, const float* w, const float* bias, const float* eps, int B, int tdim,
+                               int ncf, float* c_code, float* mu, float* logvar, void* stream) {
+  if (!sent_emb || !w || !bias || !mu || !logvar || B < 1 || tdim < 1 || ncf < 1 || (c_code && !eps)) return TGSR_EINVAL;
+  if ((size_t)(tdim + 4 * ncf) * sizeof(float) > 60 * 1024) return TGSR_EUNSUPPORTED;
+  if ((tdim & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15)) return TGSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(ca_net_kernel, dim3(B), dim3(256), (size_t)(tdim + 4 * ncf) * sizeof(float), as_stream(stream), sent_emb,
+                     w, bias, eps, tdim, ncf, c_code, mu, logvar);
+  return note_launch(hipGetLastError(), "ca_net_kernel");
 }
 
 extern "C" int tgsr_rowdot_fwd(const float* x, const float* w, const float* bias, float* out, int B, int K, void* stream) {

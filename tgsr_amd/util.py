@@ -436,8 +436,10 @@ def _torchvision_inception_trunk():
 
 
 class CA_NET(nn.Module):
-    """util.py:372-400.  One 256->400 Linear + GLU on [B,256]: a plain library GEMM (rocBLAS through torch);
-    `c_code` is sampled to keep the reference's RNG consumption (util.py:388-396) and discarded by the caller."""
+    """util.py:372-400.  One 256->400 Linear + GLU + re-parametrisation on [B,256].  Inference (eval mode under
+    no_grad): one HIP launch (tgsr_ca_net_fwd).  Training: torch ops (a library GEMM and pointwise kernels - the KL
+    term differentiates through them).  `c_code` is sampled to keep the reference's RNG consumption (util.py:388-396)
+    and discarded by the x8 caller."""
 
     def __init__(self):
         super(CA_NET, self).__init__()
@@ -457,6 +459,21 @@ class CA_NET(nn.Module):
         return eps.mul(std).add_(mu)
 
     def forward(self, text_embedding):
+        if not self.training and not torch.is_grad_enabled():
+            # inference: the Linear, the GLU and the re-parametrisation in one HIP launch (tgsr_ca_net_fwd); the normals
+            # still come from torch's generator, as many as the reference draws
+            from . import _lib
+            from .ops import _need_hip, _p, _stream
+            x = text_embedding.contiguous()
+            w, b = self.fc.weight.detach().contiguous(), self.fc.bias.detach().contiguous()
+            _need_hip(x, w, b)
+            B = x.shape[0]
+            mu = torch.empty(B, self.c_dim, dtype=torch.float32, device=x.device)
+            logvar, c_code = torch.empty_like(mu), torch.empty_like(mu)
+            eps = torch.empty_like(mu).normal_()
+            _lib.check(_lib.lib().tgsr_ca_net_fwd(_p(x), _p(w), _p(b), _p(eps), B, self.t_dim, self.c_dim, _p(c_code), _p(mu),
+                                                  _p(logvar), _stream()), "tgsr_ca_net_fwd")
+            return c_code, mu, logvar
         mu, logvar = self.encode(text_embedding)
         return self.reparametrize(mu, logvar), mu, logvar
 
