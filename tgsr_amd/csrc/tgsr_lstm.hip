@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void lstm_input_gates_kernel(const int64_t* __
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// the register kernel's step is latency, not throughput: v_exp_f32 / v_rcp_f32 forms (absolute error ~1e-7, far inside the
+// 1e-5 the encoder is pinned to) instead of the ~40-instruction library expf / tanhf
+__device__ __forceinline__ float fsig_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
 
 // grid (B, 2); block 4H threads.  gates [B][Tmax][2][4H]; w_hh [2][4H][H].
 // gates: [B][Tmax][2][4H] per position, or (captions != nullptr) a per-TOKEN table [ntoken][2][4H] indexed through
@@ -107,22 +111,23 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
       const int64_t v = captions[(int64_t)b * width + t];
       row = (v < 0 || v >= ntoken) ? 0 : v;
     }
-    float g = gates[(row * 2 + d) * 4 * H + j];
+    // four independent accumulation chains (one dependent chain of H FMAs was the step's latency: 1.7 us per step at
+    // H = 128), combined pairwise
+    float g0 = gates[(row * 2 + d) * 4 * H + j], g1 = 0.f, g2 = 0.f, g3 = 0.f;
 #pragma unroll
     for (int k = 0; k < H / 4; ++k) {
       const float4 hv = *reinterpret_cast<const float4*>(h_s + 4 * k);
-      g = fmaf(w[4 * k], hv.x, g);
-      g = fmaf(w[4 * k + 1], hv.y, g);
-      g = fmaf(w[4 * k + 2], hv.z, g);
-      g = fmaf(w[4 * k + 3], hv.w, g);
+      g0 = fmaf(w[4 * k], hv.x, g0);
+      g1 = fmaf(w[4 * k + 1], hv.y, g1);
+      g2 = fmaf(w[4 * k + 2], hv.z, g2);
+      g3 = fmaf(w[4 * k + 3], hv.w, g3);
     }
-    g_s[j] = g;
+    g_s[j] = (g0 + g1) + (g2 + g3);
     __syncthreads();
     if (j < H) {
-      const float ig = sigmoidf_(g_s[j]), fg = sigmoidf_(g_s[H + j]), gg = tanhf(g_s[2 * H + j]),
-                  og = sigmoidf_(g_s[3 * H + j]);
+      const float ig = fsig_(g_s[j]), fg = fsig_(g_s[H + j]), gg = ftanh_(g_s[2 * H + j]), og = fsig_(g_s[3 * H + j]);
       c = fg * c + ig * gg;
-      hcur = og * tanhf(c);
+      hcur = og * ftanh_(c);
       h_s[j] = hcur;
       wout[t] = hcur;
       if (acts) {   // training: gate activations and cell state of this step, [B][Tmax][2][5][H]
