@@ -113,44 +113,47 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
 }
 
 // CA_NET (util.py:372-400) in one launch: x = fc(sent_emb) [4 ncf]; h = x[:2ncf] * sigmoid(x[2ncf:]) (GLU);
-// mu = h[:ncf], logvar = h[ncf:]; c_code = eps * exp(0.5 logvar) + mu.  One workgroup per sample: the sentence code in
-// LDS, a thread per output of the Linear (float4 over its weight row), the GLU pairs meet in LDS.  The eager form was
-// a library GEMM plus eight pointwise launches.  eps comes from the caller (torch's generator: the reference consumes
-// exactly ncf normals per sample here, util.py:388-396).
+// mu = h[:ncf], logvar = h[ncf:]; c_code = eps * exp(0.5 logvar) + mu.  Grid (sample, half): a workgroup owns the
+// outputs i of its half of [0, ncf) and computes the four Linear rows each of them needs (i, i + 2ncf for mu; ncf + i,
+// 3ncf + i for logvar) - a thread per row, float4 along its weight row (independent loads: a wave-per-row form with a
+// shuffle reduction per row serialised 100 L2 latencies and took 212 us), the GLU pairs meet in LDS.  The eager form
+// was a library GEMM plus eight pointwise launches.  eps comes from the caller (torch's generator: the reference
+// consumes exactly ncf normals per sample here, util.py:388-396).
 __global__ __launch_bounds__(256) void ca_net_kernel(const float* __restrict__ sent, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ eps,
                                                      int tdim, int ncf, float* __restrict__ c_code,
                                                      float* __restrict__ mu, float* __restrict__ logvar) {
-  extern __shared__ float sm[];            // [tdim] sentence code, then [4 ncf] Linear outputs
+  extern __shared__ float sm[];            // [tdim] sentence code, then [4][per] Linear outputs
   float* xs = sm;
   float* ys = sm + tdim;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, per = (ncf + 1) / 2, i0 = blockIdx.y * per, ni = min(per, ncf - i0);
   for (int k = threadIdx.x; k < tdim; k += 256) xs[k] = sent[(int64_t)b * tdim + k];
   __syncthreads();
-  for (int j = threadIdx.x; j < 4 * ncf; j += 256) {
-    const float* wr = w + (int64_t)j * tdim;
-    float s = 0.f;
-    if ((tdim & 3) == 0) {
-      for (int k = 0; k < tdim; k += 4) {
-        const float4 wv = *reinterpret_cast<const float4*>(wr + k);
-        s += wv.x * xs[k] + wv.y * xs[k + 1] + wv.z * xs[k + 2] + wv.w * xs[k + 3];
+  for (int t = threadIdx.x; t < 4 * ni; t += 256) {
+    const int kind = t / ni, i = i0 + t - kind * ni;
+    const int row = (kind & 2 ? ncf : 0) + (kind & 1 ? 2 * ncf : 0) + i;      // 0: i, 1: i + 2ncf, 2: ncf + i, 3: 3ncf + i
+    const float* wr = w + (int64_t)row * tdim;
+    float s0 = 0.f, s1 = 0.f;
+    if ((tdim & 7) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+      for (int k = 0; k < tdim; k += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(wr + k), c = *reinterpret_cast<const float4*>(wr + k + 4);
+        s0 += a.x * xs[k] + a.y * xs[k + 1] + a.z * xs[k + 2] + a.w * xs[k + 3];
+        s1 += c.x * xs[k + 4] + c.y * xs[k + 5] + c.z * xs[k + 6] + c.w * xs[k + 7];
       }
     } else {
-      for (int k = 0; k < tdim; ++k) s += wr[k] * xs[k];
+      for (int k = 0; k < tdim; ++k) s0 += wr[k] * xs[k];
     }
-    ys[j] = s + bias[j];
+    ys[kind * per + (i - i0)] = s0 + s1 + bias[row];
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < 2 * ncf; j += 256) {
-    const float h = ys[j] * (1.f / (1.f + __expf(-ys[j + 2 * ncf])));
-    if (j < ncf) mu[(int64_t)b * ncf + j] = h;
-    else logvar[(int64_t)b * ncf + j - ncf] = h;
-    ys[j] = h;
+  for (int t = threadIdx.x; t < ni; t += 256) {
+    const int i = i0 + t;
+    const float m = ys[t] * (1.f / (1.f + __expf(-ys[per + t])));
+    const float lv = ys[2 * per + t] * (1.f / (1.f + __expf(-ys[3 * per + t])));
+    mu[(int64_t)b * ncf + i] = m;
+    logvar[(int64_t)b * ncf + i] = lv;
+    if (c_code) c_code[(int64_t)b * ncf + i] = eps[(int64_t)b * ncf + i] * __expf(0.5f * lv) + m;
   }
-  __syncthreads();
-  if (c_code)
-    for (int j = threadIdx.x; j < ncf; j += 256)
-      c_code[(int64_t)b * ncf + j] = eps[(int64_t)b * ncf + j] * __expf(0.5f * ys[ncf + j]) + ys[j];
 }
 
 static int gemm_launch(const GemmArgs& a, bool nt, int batch, hipStream_t s) {
@@ -177,9 +180,8 @@ extern "C" int tgsr_ca_net_fwd(const float* sent_emb, const float* w, const floa
                                int ncf, float* c_code, float* mu, float* logvar, void* stream) {
   if (!sent_emb || !w || !bias || !mu || !logvar || B < 1 || tdim < 1 || ncf < 1 || (c_code && !eps)) return TGSR_EINVAL;
   if ((size_t)(tdim + 4 * ncf) * sizeof(float) > 60 * 1024) return TGSR_EUNSUPPORTED;
-  if ((tdim & 3) == 0 && (reinterpret_cast<uintptr_t>(w) & 15)) return TGSR_EUNSUPPORTED;
-  hipLaunchKernelGGL(ca_net_kernel, dim3(B), dim3(256), (size_t)(tdim + 4 * ncf) * sizeof(float), as_stream(stream), sent_emb,
-                     w, bias, eps, tdim, ncf, c_code, mu, logvar);
+  hipLaunchKernelGGL(ca_net_kernel, dim3(B, 2), dim3(256), (size_t)(tdim + 4 * ncf + 8) * sizeof(float), as_stream(stream),
+                     sent_emb, w, bias, eps, tdim, ncf, c_code, mu, logvar);
   return note_launch(hipGetLastError(), "ca_net_kernel");
 }
 

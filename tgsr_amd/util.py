@@ -469,8 +469,13 @@ class CA_NET(nn.Module):
             _need_hip(x, w, b)
             B = x.shape[0]
             mu = torch.empty(B, self.c_dim, dtype=torch.float32, device=x.device)
-            logvar, c_code = torch.empty_like(mu), torch.empty_like(mu)
-            eps = torch.empty_like(mu).normal_()
+            logvar = torch.empty_like(mu)
+            c_code = eps = None
+            if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+                # inside a hipGraph capture the draw is skipped (c_code is None): a captured normal_() makes every replay
+                # fill two philox-state tensors first, and the x8 / x16 generators discard c_code anyway (model.py:51-52)
+                c_code = torch.empty_like(mu)
+                eps = torch.empty_like(mu).normal_()
             _lib.check(_lib.lib().tgsr_ca_net_fwd(_p(x), _p(w), _p(b), _p(eps), B, self.t_dim, self.c_dim, _p(c_code), _p(mu),
                                                   _p(logvar), _stream()), "tgsr_ca_net_fwd")
             return c_code, mu, logvar
