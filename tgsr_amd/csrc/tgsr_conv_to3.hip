@@ -209,14 +209,15 @@ __global__ __launch_bounds__(16 * TH * KS) void conv_to3_kernel(To3Args a) {
 // kx goes through a small per-wave LDS image of V.  Workgroup = 8 rows x 64 columns, wave = 2 rows x 5 column tiles of 16
 // (80 columns from x0 - 4: the halo and float4 alignment); the input is staged 16 channels at a time [ch][row][80] with a
 // channel stride = 16 mod 64 words, so the B-fragment read (4 channels x 16 columns per lane group) touches 64 banks.
-template <int K, int ACT, int CH>
+template <int K, int ACT, int CH, int TRO>
 __global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
+  constexpr int RPW = TRO / 4;                                      // output rows per wave
   constexpr int NJ = CH / 4;                                       // MFMA k-steps (4 channels) per staged chunk
-  constexpr int P = K / 2, TRO = 8, ROWS = TRO + K - 1, PITCH = 80;
+  constexpr int P = K / 2, ROWS = TRO + K - 1, PITCH = 80;
   constexpr int CS = (ROWS * PITCH) % 64 == 0 ? ROWS * PITCH + 16 : (ROWS * PITCH + 63) / 64 * 64 + 16 - ((ROWS * PITCH) % 64 <= 16 ? 64 : 0);
   static_assert(CS % 64 == 16 && CS >= ROWS * PITCH && CS % 4 == 0, "channel stride");
   constexpr int VP = 84;                                           // V image pitch
-  constexpr int SM = CH * CS > 4 * 2 * 16 * VP ? CH * CS : 4 * 2 * 16 * VP;   // the V images go on top of the dead input tile
+  constexpr int SM = CH * CS > 4 * 16 * VP ? CH * CS : 4 * 16 * VP;   // the V images go on top of the dead input tile
   __shared__ __attribute__((aligned(16))) float x_s[SM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, kq = lane >> 4;
   int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -229,20 +230,28 @@ __global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
   const float* xb = a.x + (int64_t)b * a.xbs;
   const int co = col / K, kx = col - co * K;                      // this lane's A row (co, kx); rows >= 3K are zero
   const bool arow = col < 3 * K;
-  f32x4 acc[2][5];
+  f32x4 acc[RPW][5];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < RPW; ++r)
 #pragma unroll
     for (int ut = 0; ut < 5; ++ut) acc[r][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
   // staging: thread = one float4 column group (row, q) of the tile, looping over the chunk's 16 channels (consecutive
   // threads = consecutive float4s of a row: coalesced); the NEXT chunk's loads are issued before this chunk's MFMAs
-  constexpr int NU = ROWS * (PITCH / 4);
-  static_assert(NU <= 256, "one staging unit per thread");
-  const int srow = tid / (PITCH / 4), sq = tid - srow * (PITCH / 4);
-  const int gy = y0 - P + srow, gx = x0 - 4 + 4 * sq;
-  const bool sin = tid < NU && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-  const float* src = xb + (sin ? (int64_t)gy * a.W + gx : 0);
-  float4 pre[CH];
+  constexpr int NU = ROWS * (PITCH / 4), NUPT = (NU + 255) / 256;      // staging units (row, float4 column) and units per thread
+  int soff[NUPT];
+  bool sin[NUPT], suse[NUPT];
+  const float* src[NUPT];
+#pragma unroll
+  for (int u = 0; u < NUPT; ++u) {
+    const int id = tid + 256 * u;
+    const int srow = id / (PITCH / 4), sq = id - srow * (PITCH / 4);
+    const int gy = y0 - P + srow, gx = x0 - 4 + 4 * sq;
+    suse[u] = id < NU;
+    sin[u] = suse[u] && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    src[u] = xb + (sin[u] ? (int64_t)gy * a.W + gx : 0);
+    soff[u] = srow * PITCH + 4 * sq;
+  }
+  float4 pre[NUPT][CH];
   float af[K][NJ], afn[K][NJ];
   auto wload = [&](int c0, float (&dst)[K][NJ]) {
 #pragma unroll
@@ -253,17 +262,21 @@ __global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
   };
   auto gload = [&](int c0) {
 #pragma unroll
-    for (int ch = 0; ch < CH; ++ch)
-      pre[ch] = sin ? *reinterpret_cast<const float4*>(src + (int64_t)(c0 + ch) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < NUPT; ++u)
+#pragma unroll
+      for (int ch = 0; ch < CH; ++ch)
+        pre[u][ch] = sin[u] ? *reinterpret_cast<const float4*>(src[u] + (int64_t)(c0 + ch) * HW) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   gload(0);
   wload(0, afn);
   for (int c0 = 0; c0 < a.Cin; c0 += CH) {
     __syncthreads();                                               // everybody is done reading the previous chunk
-    if (tid < NU) {
 #pragma unroll
-      for (int ch = 0; ch < CH; ++ch) *reinterpret_cast<float4*>(x_s + ch * CS + srow * PITCH + 4 * sq) = pre[ch];
-    }
+    for (int u = 0; u < NUPT; ++u)
+      if (suse[u]) {
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) *reinterpret_cast<float4*>(x_s + ch * CS + soff[u]) = pre[u][ch];
+      }
 #pragma unroll
     for (int ky = 0; ky < K; ++ky)
 #pragma unroll
@@ -273,9 +286,9 @@ __global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
       gload(c0 + CH);
       wload(c0 + CH, afn);
     }
-    const float* bs = x_s + kq * CS + (2 * wave) * PITCH + col;
+    const float* bs = x_s + kq * CS + (RPW * wave) * PITCH + col;
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
       for (int ky = 0; ky < K; ++ky)
 #pragma unroll
@@ -285,23 +298,21 @@ __global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
             acc[r][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ky][j], bs[4 * j * CS + (r + ky) * PITCH + ut * 16], acc[r][ut], 0, 0, 0);
   }
   __syncthreads();                                                 // the input tile is dead: V images go on top of it
-  float* vs = x_s + wave * (2 * 16 * VP);
+  float* vs = x_s + wave * (16 * VP);                              // one row's V image per wave, reused row after row
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < RPW; ++r) {
 #pragma unroll
     for (int ut = 0; ut < 5; ++ut)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) vs[(r * 16 + 4 * kq + q) * VP + ut * 16 + col] = acc[r][ut][q];   // D: row 4 (l >> 4) + reg
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's own V images are written
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int y = y0 + 2 * wave + r;
+      for (int q = 0; q < 4; ++q) vs[(4 * kq + q) * VP + ut * 16 + col] = acc[r][ut][q];   // D: row 4 (l >> 4) + reg
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's own V image is written
+    __builtin_amdgcn_wave_barrier();
+    const int y = y0 + RPW * wave + r;
 #pragma unroll
     for (int oc = 0; oc < 3; ++oc) {
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < K; ++k) v += vs[(r * 16 + oc * K + k) * VP + lane + k - P + 4];   // column j = x - x0 + 4
+      for (int k = 0; k < K; ++k) v += vs[(oc * K + k) * VP + lane + k - P + 4];   // column j = x - x0 + 4
       const int64_t o = ((int64_t)b * 3 + oc) * HW + (int64_t)y * a.W + x0 + lane;
       if (ACT == TGSR_ACT_TANH_AXPY) {
         v = fast_tanh(v);
@@ -309,6 +320,8 @@ __global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
       }
       a.out[o] = v;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // read before the next row overwrites it
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -337,9 +350,10 @@ static int launch_to3(To3Args a, hipStream_t s) {
   if (K == 5 && a.Cin % 16 == 0 && a.W % 64 == 0 && a.H % 8 == 0 && tiles(8) >= 512 && a.xbs % 4 == 0 &&
       (reinterpret_cast<uintptr_t>(a.x) & 15) == 0) {
     a.tiles_x = a.W / 64;
-    a.tiles_y = a.H / 8;
     // 8-channel chunks (31 KB of LDS, 4 workgroups per CU): 83 us on the 256^2 head against 90 us with 16-channel chunks
-    hipLaunchKernelGGL((conv_to3_mfma_kernel<K, ACT, 8>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
+    // (16-row tiles - 1.25x halo rows instead of 1.5x - measured 85 us: the re-read is not what bounds it)
+    a.tiles_y = a.H / 8;
+    hipLaunchKernelGGL((conv_to3_mfma_kernel<K, ACT, 8, 8>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), 0, s, a);
     return note_launch(hipGetLastError(), "conv_to3_mfma_kernel");
   }
   if (tiles(16) >= 512) return launch_to3_th<K, ACT, 16, 1>(a, s);
