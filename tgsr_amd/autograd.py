@@ -47,9 +47,10 @@ def on_wgrad_stream(dev, inputs, fn, adopted):
         torch.cuda.current_stream(dev).wait_stream(side)
         return fn()
     side.wait_stream(torch.cuda.current_stream(dev))
-    for t in inputs:
-        if t is not None:
-            t.record_stream(side)
+    if not torch.cuda.is_current_stream_capturing():     # (inside a graph capture the pool keeps its tensors alive)
+        for t in inputs:
+            if t is not None:
+                t.record_stream(side)
     with torch.cuda.stream(side):
         return fn()
 
