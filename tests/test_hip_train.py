@@ -183,6 +183,49 @@ def test_generators_train_mode_golden_and_gradients(nets_small):
         cfg_reset()
 
 
+def test_side_stream_weight_gradients_change_nothing(monkeypatch):
+    """SRTrainer issues the generators' weight gradients on a side stream while a step's backward is in flight
+    (autograd.on_wgrad_stream) and joins it before anything reads them.  Same weights, same batch: one backward with the
+    side stream must give bit-identical gradients to one backward on a single stream (same kernels, same order per
+    stream; a missing join or a gradient accumulated on the wrong stream would show up as a stale or torn value).  The
+    attention projections' weight gradient is the one exception: it is not bitwise reproducible run to run on ONE stream
+    either (1e-11 differences), so it is compared with a tolerance."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.train import SRTrainer
+    cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 256
+    try:
+        B = 4
+        cap, lens, LR, LRb = synthetic_batch(B, seed=3)
+        gen = torch.Generator().manual_seed(21)
+        hr = [(torch.rand(B, 3, s, s, generator=gen) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+        args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+        a = SRTrainer(41, device=DEV)
+        assert a._wside is not None
+        monkeypatch.setenv("TGSR_WGRAD_SIDE", "0")
+        b = SRTrainer(41, device=DEV)
+        assert b._wside is None
+        for m, n in ((a.text_encoder, b.text_encoder), (a.netGL, b.netGL), (a.netGH, b.netGH)):
+            n.load_state_dict(m.state_dict())
+        grads = []
+        for t in (a, b):
+            torch.manual_seed(5)                      # CA_NET draws its normals from the global generator
+            t._zero(t.bucket)
+            loss, _, _ = t.loss(*args)
+            with t._wgrad_side():
+                loss.backward()
+            t.bucket.end_step()
+            torch.cuda.synchronize()
+            grads.append({n: p.grad.clone() for n, p in list(t.netGL.named_parameters()) + list(t.netGH.named_parameters())})
+        for n, ga in grads[0].items():
+            if n.endswith("att.conv_context.weight"):
+                close(ga, grads[1][n], atol=1e-9, rtol=1e-5)
+            else:
+                assert torch.equal(ga, grads[1][n]), n
+    finally:
+        cfg_reset()
+
+
 def test_train_step_decreases_loss_and_updates_running_stats(nets_small):
     from conftest import split_sd
     from tgsr_amd.miscc.config import cfg, cfg_reset
