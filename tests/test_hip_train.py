@@ -187,9 +187,7 @@ def test_side_stream_weight_gradients_change_nothing(monkeypatch):
     """SRTrainer issues the generators' weight gradients on a side stream while a step's backward is in flight
     (autograd.on_wgrad_stream) and joins it before anything reads them.  Same weights, same batch: one backward with the
     side stream must give bit-identical gradients to one backward on a single stream (same kernels, same order per
-    stream; a missing join or a gradient accumulated on the wrong stream would show up as a stale or torn value).  The
-    attention projections' weight gradient is the one exception: it is not bitwise reproducible run to run on ONE stream
-    either (1e-11 differences), so it is compared with a tolerance."""
+    stream; a missing join or a gradient accumulated on the wrong stream would show up as a stale or torn value)."""
     from tgsr_amd.miscc.config import cfg, cfg_reset
     from tgsr_amd.synthetic import synthetic_batch
     from tgsr_amd.train import SRTrainer
@@ -218,10 +216,7 @@ def test_side_stream_weight_gradients_change_nothing(monkeypatch):
             torch.cuda.synchronize()
             grads.append({n: p.grad.clone() for n, p in list(t.netGL.named_parameters()) + list(t.netGH.named_parameters())})
         for n, ga in grads[0].items():
-            if n.endswith("att.conv_context.weight"):
-                close(ga, grads[1][n], atol=1e-9, rtol=1e-5)
-            else:
-                assert torch.equal(ga, grads[1][n]), n
+            assert torch.equal(ga, grads[1][n]), n
     finally:
         cfg_reset()
 

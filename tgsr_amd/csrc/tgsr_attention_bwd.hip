@@ -155,11 +155,19 @@ __global__ __launch_bounds__(256) void word_attention_bwd_kernel(AttnBwdArgs a) 
     }
   }
   // reduce the 4 waves, one slab per workgroup: [idf][32]; lane = word t, register rows = channel i
+  // (the waves take turns, in order: an LDS atomicAdd here made d(conv_context.weight) differ by 1e-11 from run to run)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int blk = 0; blk < NI; ++blk)
+      for (int blk = 0; blk < NI; ++blk)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) atomicAdd(&red_s[blk][acc_row(i, hh) * 32 + l31], dsrc[blk][i]);
-  __syncthreads();
+        for (int i = 0; i < 16; ++i) {
+          float* d = &red_s[blk][acc_row(i, hh) * 32 + l31];
+          *d = (w == 0 ? 0.f : *d) + dsrc[blk][i];
+        }
+    }
+    __syncthreads();
+  }
   float* o = a.dsrc_part + ((int64_t)b * gridDim.x + blockIdx.x) * IDF * 32;
   for (int e = tid; e < IDF * 32; e += 256) o[e] = (&red_s[0][0])[e];
 }
