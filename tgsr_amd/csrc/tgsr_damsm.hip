@@ -182,11 +182,15 @@ __global__ __launch_bounds__(256) void damsm_pair_kernel(DamsmArgs a) {
   dot += __shfl_xor(dot, 32);
   nwc += __shfl_xor(nwc, 32);
   nwd += __shfl_xor(nwd, 32);
+  // the four waves' partial sums meet in a fixed order (an LDS atomicAdd here made sim differ in the last bit run to run)
+  float* wpart_s = red_s + 96;                 // [4 waves][96] (dynamic LDS: the launch reserves it)
   if (hh == 0) {
-    atomicAdd(&red_s[l31], dot);
-    atomicAdd(&red_s[32 + l31], nwc);
-    atomicAdd(&red_s[64 + l31], nwd);
+    wpart_s[wave * 96 + l31] = dot;
+    wpart_s[wave * 96 + 32 + l31] = nwc;
+    wpart_s[wave * 96 + 64 + l31] = nwd;
   }
+  __syncthreads();
+  if (tid < 96) red_s[tid] = ((wpart_s[tid] + wpart_s[96 + tid]) + wpart_s[192 + tid]) + wpart_s[288 + tid];
   __syncthreads();
   if (a.sim && wave == 0) {
     float e = 0.f;
@@ -207,7 +211,7 @@ using namespace tgsr;
 static int damsm_launch(DamsmArgs a, void* stream) {
   if (!a.words || !a.ctx || a.B < 1 || a.ndf < 32 || a.Tw < 1 || a.S < 1) return TGSR_EINVAL;
   if (a.ndf % 32 != 0 || a.Tw > 32 || a.S > 320 || a.ndf > 512) return TGSR_EUNSUPPORTED;
-  const size_t lds = sizeof(float) * ((size_t)a.ndf * 32 + 32 * kSP + 4 * 32 * 65 + 96);
+  const size_t lds = sizeof(float) * ((size_t)a.ndf * 32 + 32 * kSP + 4 * 32 * 65 + 96 + 4 * 96);
   const int pairs = a.paired ? a.B : a.B * a.B;
   static bool attr_set[64] = {false};   // > 64 KB of dynamic LDS needs the opt-in once per DEVICE (a function attribute
   int dev = 0;                          // belongs to the device's code object, not to the process)

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   float* cs = dwc_s + ndf * 32;              // [ndf][33] ctx chunk
   float* gcs = cs + ndf * 33;                // [ndf][33] gctx chunk
   float* red = gcs + ndf * 33;               // [4][32] reductions
+  float* wpart = red + 128;                  // [4 waves][128]: the waves' partial sums of those, combined in a fixed order
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = blockIdx.x / a.B, i = blockIdx.x - j * a.B;
@@ -151,12 +152,14 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
         nw += __shfl_xor(nw, o);
       }
       if (lane == 0) {
-        atomicAdd(&red[l], dt);
-        atomicAdd(&red[32 + l], nc);
-        atomicAdd(&red[64 + l], nw);
+        wpart[wave * 128 + l] = dt;
+        wpart[wave * 128 + 32 + l] = nc;
+        wpart[wave * 128 + 64 + l] = nw;
       }
     }
   }
+  __syncthreads();
+  if (tid < 96) red[tid] = ((wpart[tid] + wpart[128 + tid]) + wpart[256 + tid]) + wpart[384 + tid];   // fixed order, no atomics
   __syncthreads();
   float gw[32], dwc[32];
   {
@@ -220,9 +223,11 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
       float v = rd[l];
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0) atomicAdd(&red[96 + l], v);
+      if (lane == 0) wpart[wave * 128 + 96 + l] = v;
     }
   }
+  __syncthreads();
+  if (tid < 32) red[96 + tid] = ((wpart[96 + tid] + wpart[224 + tid]) + wpart[352 + tid]) + wpart[480 + tid];
   __syncthreads();
   // pass B: dx = a2 (da2 - rowdot); da1 = gamma1 dx; ds = a1 (da1 - sum_l da1 a1)  -> a3
   for (int r = tid; r < S; r += 256) {
@@ -303,7 +308,7 @@ extern "C" int tgsr_damsm_words_bwd(const float* words, const int32_t* cap_lens,
   a.ws = ws;
   a.gw_part = ws + (int64_t)B * B * 3 * 32 * S;
   a.gc_part = a.gw_part + (int64_t)B * B * ndf * 32;
-  const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + (size_t)ndf * 33 * 2 + 128);
+  const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + (size_t)ndf * 33 * 2 + 128 + 4 * 128);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(damsm_pair_bwd_kernel),
