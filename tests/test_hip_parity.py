@@ -660,3 +660,21 @@ def test_ca_net_fused_inference_kernel():
         assert mu.shape == (7, cfg.GAN.CONDITION_DIM) and c.shape == mu.shape
     finally:
         cfg_reset()
+
+
+def test_damsm_kernels_are_bitwise_reproducible():
+    """No float atomics anywhere in the library: the DAMSM similarity and its backward give bit-identical results run
+    after run (the four waves' partial sums of a workgroup meet in a fixed order)."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, ndf, T_ = 6, 256, 12
+    feats = torch.randn(B, ndf, 17, 17, generator=g).to(DEV)
+    words = torch.randn(B, ndf, T_, generator=g).to(DEV)
+    lens = [12, 11, 9, 7, 5, 3]
+    gs = torch.randn(B, B, generator=g).to(DEV)
+    sims = [ops.damsm_words_similarity(feats, words, lens, 4.0, 5.0)[0].clone() for _ in range(3)]
+    grads = [tuple(t.clone() for t in ops.damsm_words_bwd(feats, words, lens, 4.0, 5.0, gs)) for _ in range(3)]
+    for s in sims[1:]:
+        assert torch.equal(s, sims[0])
+    for gi, gw in grads[1:]:
+        assert torch.equal(gi, grads[0][0]) and torch.equal(gw, grads[0][1])
