@@ -95,8 +95,10 @@ template <class T, int K, int ACT>
 __global__ __launch_bounds__(256) void lp_to3_kernel(LpTo3Args a) {
   constexpr int P = K / 2, TR = 8 + 2 * P, TC = 48, NPIX = TR * TC, VP = 52;
   constexpr int TILE_SLOTS = NPIX * 4, TILE_INSTR = (TILE_SLOTS + 63) / 64;
+  // the per-wave V images go on top of the input tile once every wave is done reading it: 37 KB (5x5) / 31 KB (3x3) of
+  // LDS per workgroup = 4-5 workgroups per CU in flight to cover each other's tile-load latency
+  static_assert(4 * 16 * VP * 4 <= TILE_INSTR * 1024, "V images fit the tile");
   __shared__ __attribute__((aligned(1024))) char tile[TILE_INSTR * 1024];
-  __shared__ float vs[4][16 * VP];
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -127,14 +129,13 @@ __global__ __launch_bounds__(256) void lp_to3_kernel(LpTo3Args a) {
   for (int k = 0; k < K; ++k) af[k] = *reinterpret_cast<const u32x4*>(a.wpack + (k * 64 + lane) * 16);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  float* v = vs[wave];
+  f32x4w acc[2][3];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
-    f32x4w acc[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+      for (int i = 0; i < 4; ++i) acc[r][j][i] = 0.f;
 #pragma unroll
     for (int dy = 0; dy < K; ++dy)
 #pragma unroll
@@ -142,13 +143,19 @@ __global__ __launch_bounds__(256) void lp_to3_kernel(LpTo3Args a) {
         const int c = 16 * j + p;
         const u32x4 bf = *reinterpret_cast<const u32x4*>(tile + ((2 * wave + r + dy) * TC + c) * 64 +
                                                          ((g ^ ((c >> 1) & 3)) << 4));
-        acc[j] = LP<T>::mfma16(af[dy], bf, acc[j]);
+        acc[r][j] = LP<T>::mfma16(af[dy], bf, acc[r][j]);
       }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                                  // every wave is done reading the tile
+  float* v = reinterpret_cast<float*>(tile) + wave * (16 * VP);
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
     // D[row = 4 g + reg][col = p] -> V image [16 rows][48 columns] of this wave (pitch 52: rows 4 apart on distinct banks)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[(4 * g + i) * VP + 16 * j + p] = acc[j][i];
+      for (int i = 0; i < 4; ++i) v[(4 * g + i) * VP + 16 * j + p] = acc[r][j][i];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-private image: no barrier
     const int y = y0 + 2 * wave + r;
 #pragma unroll
