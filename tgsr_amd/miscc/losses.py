@@ -105,10 +105,40 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     return (unc_real + cond["real"]) / 2. + (unc_fake + cond["fake"] + cond["wrong"]) / 3.
 
 
+class _LazyLog:
+    """The log string of generator_loss, formatted when somebody looks at it: the reference builds it with `.item()` on
+    every term (losses.py:366-390) - three device synchronisations inside the generator step that nothing needs unless
+    the string is printed.  Behaves like the str it stands for under str(), format(), + and +=."""
+
+    def __init__(self, parts):
+        self._parts = parts                      # [(format, tensor, ...), ...]
+
+    def __str__(self):
+        return "".join(f % tuple(float(t) for t in ts) for f, *ts in self._parts)
+
+    __repr__ = __str__
+
+    def __format__(self, spec):
+        return format(str(self), spec)
+
+    def __add__(self, other):
+        return str(self) + str(other)
+
+    def __radd__(self, other):
+        return str(other) + str(self)
+
+    def __len__(self):
+        return len(str(self))
+
+    def __contains__(self, item):
+        return item in str(self)
+
+
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
                    class_ids, w=1, s=1, g=1):
     """losses.py:351-391: per-scale adversarial terms + the DAMSM words / sentence ranking loss on the last scale
-    (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log string) like the reference.  `image_encoder=None` (the reference
+    (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log) like the reference; the log is a _LazyLog: the same string, formatted
+    (and the device synchronised) only when it is looked at.  `image_encoder=None` (the reference
     always has one; its Inception-v3 weights are third-party and not shipped) leaves the ranking term out."""
     B = real_labels.size(0)
     total, parts = 0, []
@@ -119,7 +149,7 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
             adv = adv + _bce(netD.UNCOND_DNET(feat), real_labels)
         adv = g * adv
         total = total + adv
-        parts.append("g_loss%d: %.5f " % (k, adv.item()))
+        parts.append(("g_loss%d: %%.5f " % k, adv.detach()))
         if k == len(netsD) - 1 and image_encoder is not None:
             regions, code = image_encoder(img)
             w0, w1, _ = words_loss(regions, words_embs, match_labels, cap_lens, class_ids, B)
@@ -127,5 +157,5 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
             w_term = w * (w0 + w1) * cfg.TRAIN.SMOOTH.LAMBDA
             s_term = s * (s0 + s1) * cfg.TRAIN.SMOOTH.LAMBDA
             total = total + w_term + s_term
-            parts.append("w_loss: %.5f s_loss: %.5f " % (w_term.item(), s_term.item()))
-    return total, "".join(parts)
+            parts.append(("w_loss: %.5f s_loss: %.5f ", w_term.detach(), s_term.detach()))
+    return total, _LazyLog(parts)
