@@ -287,7 +287,11 @@ class ConvBnLeaky(torch.autograd.Function):
     tgsr_bn_train_fwd / _bwd(act = 2); the 3x3 convolution and its gradients are the generator's fp32 kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, momentum, eps, nbt=None):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, momentum, eps, nbt=None, groups=None):
+        """`groups`: sizes of consecutive slices of the batch that are normalised with their OWN batch statistics (and
+        update the running statistics one after the other, in order) - several forward passes of the module (real /
+        fake / mismatched images of discriminator_loss) as one convolution launch, one data-gradient launch and one
+        weight-gradient launch, numerically the passes run one by one."""
         L = _lib.lib()
         x = x.contiguous()
         if kind == "down":
@@ -298,16 +302,24 @@ class ConvBnLeaky(torch.autograd.Function):
             raw = ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), weight.shape[0], None, None)
         B, C, Ho, Wo = raw.shape
         HW, dev = Ho * Wo, x.device
-        nsplit = L.tgsr_bn_train_nsplit(B, C, HW)
-        ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
-        stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+        groups = (B,) if groups is None else tuple(int(g) for g in groups)
+        if sum(groups) != B or min(groups) < 1:
+            raise TgsrError("ConvBnLeaky: groups %s do not partition a batch of %d" % (groups, B))
+        stats = torch.empty(len(groups), 4, C, dtype=torch.float32, device=dev)
         out = torch.empty_like(raw)
-        rc = L.tgsr_bn_train_fwd(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum),
-                                 _p(running_mean), _p(running_var), 2, None, 0, _p(ws), _p(stats[0]), _p(stats[1]),
-                                 _p(stats[2]), _p(stats[3]), _p(out), C * HW, _p(nbt), _stream())
-        check(rc, "tgsr_bn_train_fwd")
+        o = 0
+        for gi, n in enumerate(groups):
+            nsplit = L.tgsr_bn_train_nsplit(n, C, HW)
+            ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
+            st = stats[gi]
+            rc = L.tgsr_bn_train_fwd(_p(raw[o:o + n]), n, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
+                                     float(momentum), _p(running_mean), _p(running_var), 2, None, 0, _p(ws), _p(st[0]),
+                                     _p(st[1]), _p(st[2]), _p(st[3]), _p(out[o:o + n]), C * HW, _p(nbt), _stream())
+            check(rc, "tgsr_bn_train_fwd")
+            o += n
         ctx.save_for_backward(x, weight, raw, stats)
         ctx.kind = kind
+        ctx.groups = groups
         ctx.bn_params = (gamma, beta)          # only to look up their gradient slots (parallel.grad_slot) in backward
         return out
 
@@ -318,15 +330,23 @@ class ConvBnLeaky(torch.autograd.Function):
         dout = dout.contiguous()
         B, C, Ho, Wo = raw.shape
         HW, dev = Ho * Wo, x.device
-        nsplit = L.tgsr_bn_train_nsplit(B, C, HW)
-        ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
-        sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
         draw = torch.empty_like(raw)
         gamma, beta = ctx.bn_params
         dgamma, dbeta = _grad_out(gamma, (C,), dev), _grad_out(beta, (C,), dev)
-        rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, C, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), 2,
-                                 _p(ws), _p(sums), _p(draw), _p(dgamma), _p(dbeta), _stream())
-        check(rc, "tgsr_bn_train_bwd")
+        o = 0
+        for gi, n in enumerate(ctx.groups):
+            nsplit = L.tgsr_bn_train_nsplit(n, C, HW)
+            ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
+            st = stats[gi]
+            dg, db = (dgamma, dbeta) if gi == 0 else (torch.empty(C, dtype=torch.float32, device=dev),
+                                                      torch.empty(C, dtype=torch.float32, device=dev))
+            rc = L.tgsr_bn_train_bwd(_p(dout[o:o + n]), _p(raw[o:o + n]), n, C, HW, _p(st[2]), _p(st[3]), _p(st[0]),
+                                     _p(st[1]), 2, _p(ws), _p(ws), _p(draw[o:o + n]), _p(dg), _p(db), _stream())
+            check(rc, "tgsr_bn_train_bwd")
+            if gi:                                           # the groups' contributions in order, like separate passes
+                dgamma += dg
+                dbeta += db
+            o += n
         dx = dw = None
         Cin, H, W = x.shape[1], x.shape[2], x.shape[3]
         if ctx.kind == "down":
@@ -353,13 +373,14 @@ class ConvBnLeaky(torch.autograd.Function):
                 wws = torch.empty(L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, C, H, W, 0), dtype=torch.float32, device=dev)
                 check(L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, C, 0, _p(wws), _p(dw), _stream()),
                       "tgsr_conv3x3_wgrad")
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def conv_bn_leaky_train(x, conv, bn, kind):
-    """Training-mode conv + BatchNorm + LeakyReLU(0.2) over the parameter-holder modules."""
+def conv_bn_leaky_train(x, conv, bn, kind, groups=None):
+    """Training-mode conv + BatchNorm + LeakyReLU(0.2) over the parameter-holder modules (`groups`: ConvBnLeaky)."""
     out = ConvBnLeaky.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                            bn.running_var if bn.track_running_stats else None, kind, bn.momentum, bn.eps, _nbt(bn))
+                            bn.running_var if bn.track_running_stats else None, kind, bn.momentum, bn.eps, _nbt(bn),
+                            groups)
     if bn.track_running_stats:
         torch.autograd.graph.increment_version(bn.running_mean)
         torch.autograd.graph.increment_version(bn.running_var)

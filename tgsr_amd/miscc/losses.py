@@ -93,8 +93,23 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
     """losses.py:290-316.  The reference ships no discriminator class; any module exposing `COND_DNET` /
     `UNCOND_DNET` like AttnGAN's D_NET* works: real / fake / wrong-caption terms, the wrong pair being the batch
     shifted by one (:302)."""
+    n = real_imgs.size(0)
+    if getattr(netD, "supports_groups", False) and n > 1:
+        # the build's D_NET*: the real and the fake pass as ONE batch whose two halves keep their own BatchNorm batch
+        # statistics (and update the running statistics in the reference's order: real, then fake) - one convolution,
+        # data-gradient and weight-gradient launch per layer instead of two, and every parameter receives one gradient;
+        # the three conditional heads (real, fake, mismatched) likewise.  Numerically the passes run one by one.
+        feats = netD(torch.cat((real_imgs, fake_imgs.detach())), groups=(n, n))
+        feat_real, feat_fake = feats[:n], feats[n:]
+        lc = netD.COND_DNET(torch.cat((feats, feat_real[:n - 1])), torch.cat((conditions, conditions, conditions[1:n])),
+                            groups=(n, n, n - 1))
+        cond = {"real": _bce(lc[:n], real_labels), "fake": _bce(lc[n:2 * n], fake_labels),
+                "wrong": _bce(lc[2 * n:], fake_labels[1:n])}
+        if netD.UNCOND_DNET is None:
+            return cond["real"] + (cond["fake"] + cond["wrong"]) / 2.
+        lu = netD.UNCOND_DNET(feats)
+        return (_bce(lu[:n], real_labels) + cond["real"]) / 2. + (_bce(lu[n:], fake_labels) + cond["fake"] + cond["wrong"]) / 3.
     feat_real, feat_fake = netD(real_imgs), netD(fake_imgs.detach())
-    n = feat_real.size(0)
     cond = {"real": _bce(netD.COND_DNET(feat_real, conditions), real_labels),
             "fake": _bce(netD.COND_DNET(feat_fake, conditions), fake_labels),
             "wrong": _bce(netD.COND_DNET(feat_real[:n - 1], conditions[1:n]), fake_labels[1:n])}

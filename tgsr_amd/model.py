@@ -161,12 +161,14 @@ class _D_NET(nn.Module):
         self.UNCOND_DNET = D_GET_LOGITS(ndf, nef, bcondition=False) if b_jcu else None
         self.COND_DNET = D_GET_LOGITS(ndf, nef, bcondition=True)
 
-    def forward(self, x_var):
-        x = self.img_code_s16(x_var)
+    supports_groups = True      # forward(x, groups=...): several passes as one batch with per-slice BatchNorm statistics
+
+    def forward(self, x_var, groups=None):
+        x = self.img_code_s16(x_var, groups)
         for m in self.extra:
-            x = m(x)
+            x = m(x, groups)
         for m in self.reduce:
-            x = m(x)
+            x = m(x, groups)
         return x                                                   # [B, 8 ndf, 4, 4]
 
 

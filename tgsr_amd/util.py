@@ -200,11 +200,12 @@ class _ConvBnLeaky(nn.Sequential):
         super().__init__(conv, nn.BatchNorm2d(out_planes), nn.LeakyReLU(0.2, inplace=True))
         self._kind = kind
 
-    def forward(self, x):
+    def forward(self, x, groups=None):
+        """groups: sizes of consecutive batch slices normalised with their own batch statistics (autograd.ConvBnLeaky)."""
         if not self.training:
             raise NotImplementedError("discriminator blocks run with batch-statistics BatchNorm only (training mode)")
         from .autograd import conv_bn_leaky_train
-        return conv_bn_leaky_train(x, self[0], self[1], self._kind)
+        return conv_bn_leaky_train(x, self[0], self[1], self._kind, groups)
 
 
 def downBlock(in_planes, out_planes):
@@ -228,8 +229,9 @@ class _EncodeBy16(nn.Module):
         self.down2 = downBlock(ndf * 2, ndf * 4)
         self.down3 = downBlock(ndf * 4, ndf * 8)
 
-    def forward(self, x):
-        return self.down3(self.down2(self.down1(C.conv4x4s2(x, self.conv0.weight, True))))
+    def forward(self, x, groups=None):
+        x = C.conv4x4s2(x, self.conv0.weight, True)
+        return self.down3(self.down2(self.down1(x, groups), groups), groups)
 
 
 def encode_image_by_16times(ndf):
@@ -249,11 +251,11 @@ class D_GET_LOGITS(nn.Module):
             self.jointConv = Block3x3_leakRelu(ndf * 8 + nef, ndf * 8)
         self.outlogits = nn.Sequential(nn.Conv2d(ndf * 8, 1, kernel_size=4, stride=4))
 
-    def forward(self, h_code, c_code=None):
+    def forward(self, h_code, c_code=None, groups=None):
         from .autograd import RowDot
         if self.bcondition and c_code is not None:
             c = c_code.view(-1, self.ef_dim, 1, 1).repeat(1, 1, 4, 4)
-            h_code = self.jointConv(torch.cat((h_code, c), 1))
+            h_code = self.jointConv(torch.cat((h_code, c), 1), groups)
         conv = self.outlogits[0]                                  # a 4x4 / stride 4 conv on a 4x4 map = one dot product
         return RowDot.apply(h_code.reshape(h_code.size(0), -1), conv.weight.reshape(-1), conv.bias)
 
