@@ -106,7 +106,7 @@ def test_committed_bench_lines_follow_the_contract():
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r02h_bench_*.json")))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r02i_bench_*.json")))
     assert len(files) >= 6, "round-2 bench lines missing"
     saw_cpu = saw_lp = saw_train = False
     for f in files:
@@ -134,5 +134,5 @@ def test_committed_bench_lines_follow_the_contract():
             c = d["cpu_baseline"]
             assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert saw_cpu and saw_lp and saw_train
-    two = json.loads(open(os.path.join(root, "profiles", "r02h_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
+    two = json.loads(open(os.path.join(root, "profiles", "r02i_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
     assert two["n_gpus"] == 2                       # `bench.py --gpus 2` launched its two ranks itself
