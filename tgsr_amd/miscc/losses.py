@@ -7,7 +7,10 @@ mask, the x gamma3 scale and the two cross entropies act on a [B, B] matrix and 
 Both are differentiable: words_loss through the HIP backward of the DAMSM kernel (tgsr_damsm_words_bwd, autograd.DamsmWords),
 sent_loss through torch autograd over its [B, B] matrix.
 """
+import contextlib
+
 import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -150,19 +153,36 @@ class _LazyLog:
 
 
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
-                   class_ids, w=1, s=1, g=1):
+                   class_ids, w=1, s=1, g=1, streams=None):
     """losses.py:351-391: per-scale adversarial terms + the DAMSM words / sentence ranking loss on the last scale
     (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log) like the reference; the log is a _LazyLog: the same string, formatted
     (and the device synchronised) only when it is looked at.  `image_encoder=None` (the reference
     always has one; its Inception-v3 weights are third-party and not shipped) leaves the ranking term out."""
     B = real_labels.size(0)
     total, parts = 0, []
+    advs = []
+    main = torch.cuda.current_stream(real_labels.device) if streams else None
     for k, (netD, img) in enumerate(zip(netsD, fake_imgs)):
-        feat = netD(img)
-        adv = _bce(netD.COND_DNET(feat, sent_emb), real_labels)
-        if netD.UNCOND_DNET is not None:
-            adv = adv + _bce(netD.UNCOND_DNET(feat), real_labels)
-        adv = g * adv
+        # `streams` (not a reference argument): one stream per discriminator - their forward passes, and through
+        # autograd's stream rule their backward passes, run side by side; the terms are added up on the calling stream
+        st = streams[k] if streams else None
+        if st is not None:
+            st.wait_stream(main)
+        with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+            if st is not None:
+                for t in (img, sent_emb, real_labels):
+                    t.record_stream(st)                    # allocated on the calling stream, read on this one
+            feat = netD(img)
+            adv = _bce(netD.COND_DNET(feat, sent_emb), real_labels)
+            if netD.UNCOND_DNET is not None:
+                adv = adv + _bce(netD.UNCOND_DNET(feat), real_labels)
+            adv = g * adv
+        advs.append(adv)
+    for k, (netD, img) in enumerate(zip(netsD, fake_imgs)):
+        adv = advs[k]
+        if streams:
+            main.wait_stream(streams[k])
+            adv.record_stream(main)
         total = total + adv
         parts.append(("g_loss%d: %%.5f " % k, adv.detach()))
         if k == len(netsD) - 1 and image_encoder is not None:

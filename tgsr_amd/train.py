@@ -118,7 +118,7 @@ class SRTrainer:
         B = sent_emb.shape[0]
         real_labels, _fake, match_labels = prepare_labels(B, self.device)
         adv, _log = losses.generator_loss(self.netsD, self.image_encoder, fine_im, real_labels, words_embs, sent_emb,
-                                          match_labels, cap_lens, class_ids)
+                                          match_labels, cap_lens, class_ids, streams=self._dstreams or None)
         return adv + losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
 
     @contextlib.contextmanager
