@@ -261,3 +261,34 @@ def test_full_size_gan_train_step_parity(face_weights):
             assert err < 1e-2, "GH %s: relative gradient error %g" % (k, err)
     finally:
         cfg_reset()
+
+
+@pytest.mark.parametrize("kind,Cin,Cout,H", [("down", 8, 16, 16), ("3x3", 256, 256, 4)])
+def test_grouped_batchnorm_statistics_equal_separate_passes(kind, Cin, Cout, H, cfg_d):
+    """ConvBnLeaky(groups=(n1, n2, n3)) - how discriminator_loss batches its real / fake / mismatched passes - normalises
+    every slice with its own batch statistics and updates the running statistics slice by slice: outputs, running
+    statistics and input gradients are BIT-identical to three separate passes through the block; the weight gradient is
+    one contraction over all slices instead of a sum of three (same value up to fp32 summation order)."""
+    import copy
+    from tgsr_amd import util
+    g = torch.Generator().manual_seed(3)
+    blk = (util.downBlock(Cin, Cout) if kind == "down" else util.Block3x3_leakRelu(Cin, Cout)).to(DEV).train()
+    ref = copy.deepcopy(blk)
+    sizes = (4, 4, 3)
+    xs = [torch.randn(n, Cin, H, H, generator=g).to(DEV).requires_grad_(True) for n in sizes]
+    outs = [ref(x) for x in xs]                                     # three passes, one after the other
+    dys = [torch.randn(*o.shape, generator=g).to(DEV) for o in outs]
+    torch.autograd.backward(outs, dys)
+    xc = torch.cat([x.detach() for x in xs]).requires_grad_(True)
+    out = blk(xc, groups=sizes)
+    out.backward(torch.cat(dys))
+    o = 0
+    for n, oref, x in zip(sizes, outs, xs):
+        assert torch.equal(out[o:o + n], oref)
+        assert torch.equal(xc.grad[o:o + n], x.grad)
+        o += n
+    assert torch.equal(blk[1].running_mean, ref[1].running_mean) and torch.equal(blk[1].running_var, ref[1].running_var)
+    assert int(blk[1].num_batches_tracked) == int(ref[1].num_batches_tracked) == 3
+    close(blk[0].weight.grad, ref[0].weight.grad, atol=2e-5 * float(ref[0].weight.grad.abs().max()), rtol=1e-4)
+    close(blk[1].weight.grad, ref[1].weight.grad, atol=1e-5, rtol=1e-5)
+    close(blk[1].bias.grad, ref[1].bias.grad, atol=1e-5, rtol=1e-5)
