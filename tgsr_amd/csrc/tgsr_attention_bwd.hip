@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256) void word_attention_bwd_kernel(AttnBwdArgs a) 
 using namespace tgsr;
 
 extern "C" int tgsr_word_attention_bwd_chunks(int Q) {
-  int n = (Q + 1023) / 1024;          // >= 8 pixel blocks per wave
+  // one pixel block (32 pixels) per wave and chunk where that is what fills the chip: at B = 16 the 32^2 / 64^2 / 128^2
+  // stages get 8 / 32 / 64 chunks = 128 / 512 / 1024 workgroups (with 8 blocks per wave they were 16 / 64 / 256
+  // workgroups of four latency-bound waves each: 0.41 ms per step for a 17 us matrix-pipe job)
+  int n = (Q + 127) / 128;
   return n < 1 ? 1 : (n > 64 ? 64 : n);
 }
 
