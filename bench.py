@@ -292,7 +292,7 @@ def bench_train(args, rank, world, dist, dev, weights):
         dist.destroy_process_group()
 
 
-def roofline_objects(agg, nprof, dtype, serial, steps):
+def roofline_objects(agg, nprof, dtype, serial, steps, batch=16):
     """`roofline` (dominant conv kernel), per-kernel table and the attention object from the HIP events recorded around
     every launch of the sampled steps.  Nothing here is a literal: HBM traffic and the MFMA-busy share come from the
     newest rocprofv3 table under profiles/ for this dtype (pmc_table), looked up by kernel name."""
@@ -306,9 +306,18 @@ def roofline_objects(agg, nprof, dtype, serial, steps):
     alg_tf, alg_gbs = fl / sec / 1e12, by / sec / 1e9
     exe_tf = alg_tf * EXECUTED_MAC_FRACTION[dom]               # what the MFMA pipe really issued
     traffic, busy = pmc_lookup(pmc, dom)
+    # the committed counter tables are taken at the default batch of 16: HBM bytes per launch scale with the batch
+    bscale = batch / 16.0
+    traffic = None if traffic is None else traffic * bscale
     mfma_frac, hbm_frac = exe_tf / peak_mfma, alg_gbs / PEAK_HBM_GBS
-    # the roofline that binds = the one the kernel sits closer to
-    if mfma_frac >= hbm_frac:
+    # the roofline that binds = the one the kernel sits closer to; the 2-byte path is priced against HBM (SURVEY.md 8d:
+    # "HBM roofline in bf16"), with the bytes the counters saw when a PMC table for this kernel is committed
+    cnt_gbs = None if traffic is None else traffic * n / sec / 1e9
+    if lp:
+        use = cnt_gbs if cnt_gbs is not None else alg_gbs
+        roof = {"bound": "hbm", "achieved": round(use, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(use / PEAK_HBM_GBS, 4), "bytes_from": "counters" if cnt_gbs is not None else "algorithmic"}
+    elif mfma_frac >= hbm_frac:
         roof = {"bound": "mfma", "achieved": round(exe_tf, 2), "peak": peak_mfma, "unit": "TFLOP/s",
                 "frac": round(mfma_frac, 4)}
     else:
@@ -323,13 +332,13 @@ def roofline_objects(agg, nprof, dtype, serial, steps):
         "hbm_frac_counter": None if traffic is None else round(traffic * n / sec / 1e9 / PEAK_HBM_GBS, 4),
         "traffic_over_algorithmic": None if traffic is None else round(traffic / (by / n), 3),
         "mfma_busy_frac_measured": None if busy is None else round(busy, 4),
-        "counters_from": pmc_file,
+        "counters_from": pmc_file, "counters_batch": 16,
         "timing": "HIP events around every launch of %d of the %d timed steps; those steps run single-stream so each "
                   "launch is timed alone%s" % (nprof, steps, "" if not serial else " (--serial: every step does)")})
     cp = [agg[k] for k in conv_kernels]
     cfl, csec, cby = sum(v[1] for v in cp), sum(v[3] for v in cp), sum(v[2] for v in cp)
     cex = sum(agg[k][1] * EXECUTED_MAC_FRACTION[k] for k in conv_kernels)
-    ctr = [(pmc_lookup(pmc, k)[0], agg[k][0]) for k in conv_kernels]
+    ctr = [(None if pmc_lookup(pmc, k)[0] is None else pmc_lookup(pmc, k)[0] * bscale, agg[k][0]) for k in conv_kernels]
     roof["conv_path"] = {"kernels": conv_kernels, "ms_per_step": round(csec / nprof * 1e3, 4),
                          "achieved_algorithmic_TFLOPs": round(cfl / csec / 1e12, 2),
                          "mfma_frac": round(cex / csec / 1e12 / peak_mfma, 4),
@@ -347,6 +356,7 @@ def roofline_objects(agg, nprof, dtype, serial, steps):
         # (AI ~ 7 FLOP/B), so both fractions are reported (flops = 4*B*Q*idf*T for the two GEMMs)
         n, fl, by, sec = agg[ak]
         tr, bz = pmc_lookup(pmc, ak)
+        tr = None if tr is None else tr * bscale
         att = {"kernel": ak, "bound": "hbm", "launches_per_step": n // nprof, "ms_per_step": round(sec / nprof * 1e3, 4),
                "mfma_util_pct": round(fl / sec / 1e12 / peak_mfma * 100, 2),
                "mfma_busy_pct_measured": None if bz is None else round(bz * 100, 2),
@@ -526,7 +536,7 @@ def main():
             a[1] += flops
             a[2] += nbytes
             a[3] += e0.elapsed_time(e1) * 1e-3
-        roof, kern, att = roofline_objects(agg, nprof, args.dtype, args.serial, args.steps) if nprof else (None, {}, None)
+        roof, kern, att = roofline_objects(agg, nprof, args.dtype, args.serial, args.steps, B) if nprof else (None, {}, None)
         dname = {"fp32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
         res = {"metric": "SR images/sec (32->256, batch 16 per GPU)", "value": round(world * B * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
