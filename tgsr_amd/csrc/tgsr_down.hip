@@ -326,6 +326,7 @@ static int dconv_fwd(int kind, const float* x, int B, int Cin, int H, int W, con
                      float* out, void* stream) {
   if (!x || !w || !out || !ws || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
   if (kind == 4 && ((H | W) & 1)) return TGSR_EUNSUPPORTED;
+  if ((int64_t)B * Cin * H * W >= (1ll << 31)) return TGSR_EUNSUPPORTED;        // 32-bit gather offsets
   const IgShape sh = ig_shape(kind, 0, B, Cin, H, W, Cout);
   IgArgs a = {};
   a.A = w; a.S = x; a.C = Cin; a.Hs = H; a.Ws = W;
@@ -341,6 +342,7 @@ static int dconv_dgrad(int kind, const float* dy, int B, int Cin, int H, int W, 
                        float* dx, void* stream) {
   if (!dy || !w || !ws || !dx || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
   if (kind == 4 && ((H | W) & 1)) return TGSR_EUNSUPPORTED;
+  if ((int64_t)B * Cout * H * W >= (1ll << 31)) return TGSR_EUNSUPPORTED;       // 32-bit gather offsets (dy is at most this)
   const IgShape sh = ig_shape(kind, 1, B, Cin, H, W, Cout);
   hipStream_t s = as_stream(stream);
   IgArgs a = {};
@@ -366,6 +368,7 @@ static int dconv_wgrad(int kind, const float* dy, const float* x, int B, int Cin
                        float* dw, void* stream) {
   if (!dy || !x || !ws || !dw || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return TGSR_EINVAL;
   if (kind == 4 && ((H | W) & 1)) return TGSR_EUNSUPPORTED;
+  if ((int64_t)B * Cin * H * W >= (1ll << 31)) return TGSR_EUNSUPPORTED;        // 32-bit gather offsets
   const IgShape sh = ig_shape(kind, 2, B, Cin, H, W, Cout);
   IgArgs a = {};
   a.A = dy; a.S = x; a.C = Cin; a.Hs = H; a.Ws = W;
