@@ -1,4 +1,6 @@
-"""Child process of tests/test_hip_dp.py: one data-parallel rank (gloo, every rank on cuda:0).  Not a test module."""
+"""Child process of tests/test_hip_dp.py: one data-parallel rank.  `gloo` (default): every rank on cuda:0 - the rehearsal
+a one-GPU box allows; `nccl` (argv[2]): one rank per device over RCCL, through tgsr_amd.parallel.init_distributed's nccl
+branch - what the driver's multi-GPU bench runs.  Not a test module."""
 import os
 import sys
 
@@ -17,23 +19,23 @@ def build_batch(B, lr=16):
     return cap, lens, LR, LRb, hr
 
 
-def make_trainer(correct_mask=True):
+def make_trainer(correct_mask=True, device="cuda:0", discriminators=False):
     from tgsr_amd.miscc.config import cfg, cfg_reset
     from tgsr_amd.train import SRTrainer
     cfg_reset()
-    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM = 32, 64
+    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.DF_DIM = 32, 64, 8
     torch.manual_seed(1234)                                   # identical initial weights on every rank
-    tr = SRTrainer(41, device="cuda:0")
+    tr = SRTrainer(41, device=device, discriminators=discriminators)
     for net in (tr.netGL.h_net1, tr.netGL.h_net2, tr.netGL.h_net3):
         net.att.correct_mask = correct_mask                   # per-sample masking: a shard's result must not depend on
     return tr                                                 # the local batch size
 
 
-def make_pipeline(tr):
+def make_pipeline(tr, device="cuda:0"):
     """Inference pipeline on a COPY of the trainer's initial weights - taken before any training forward, whose
     train-mode BatchNorm updates the running statistics with that rank's shard."""
     from tgsr_amd.trainer import SRPipeline
-    pipe = SRPipeline(41, device="cuda:0")
+    pipe = SRPipeline(41, device=device)
     pipe.netGL.load_state_dict(tr.netGL.state_dict())
     pipe.netGH.load_state_dict(tr.netGH.state_dict())
     pipe.text_encoder.load_state_dict(tr.text_encoder.state_dict())
@@ -44,9 +46,10 @@ def make_pipeline(tr):
 
 def shard_grads(tr, batch, lo, hi):
     cap, lens, LR, LRb, hr = batch
+    dev = tr.device
     tr._zero(tr.bucket)
-    loss, _, _ = tr.loss(cap[lo:hi].cuda(), lens[lo:hi].tolist(), LR[lo:hi].cuda(), LRb[lo:hi].cuda(),
-                         [h[lo:hi].cuda() for h in hr])
+    loss, _, _ = tr.loss(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev),
+                         [h[lo:hi].to(dev) for h in hr])
     loss.backward()
     tr.bucket.end_step()
     return loss.detach()
@@ -54,22 +57,40 @@ def shard_grads(tr, batch, lo, hi):
 
 def main():
     out = sys.argv[1]
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
-    from tgsr_amd.parallel import shard_bounds
+    backend = sys.argv[2] if len(sys.argv) > 2 else "gloo"
+    from tgsr_amd import parallel
+    if backend == "nccl":
+        rank, local_rank, world = parallel.init_distributed("nccl")    # sets the device, RCCL process group on it
+        dev = "cuda:%d" % local_rank
+        assert dist.get_backend() == "nccl" and torch.cuda.current_device() == local_rank
+    else:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        dev = "cuda:0"
     B = 4
     batch = build_batch(B)
-    tr = make_trainer()
-    pipe = make_pipeline(tr)
-    lo, hi = shard_bounds(B, rank, world)
+    tr = make_trainer(device=dev)
+    pipe = make_pipeline(tr, device=dev)
+    lo, hi = parallel.shard_bounds(B, rank, world)
     loss = shard_grads(tr, batch, lo, hi)
     tr.bucket.all_reduce_mean()                               # ONE collective over the flat bucket
-    cap, lens, LR, LRb, _ = batch                             # inference shard with per-sample masking
-    o = pipe(cap[lo:hi].cuda(), lens[lo:hi].tolist(), LR[lo:hi].cuda(), LRb[lo:hi].cuda())
+    cap, lens, LR, LRb, hr = batch                            # inference shard with per-sample masking
+    o = pipe(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev))
     torch.cuda.synchronize()
-    torch.save({"flat": tr.bucket.flat.cpu(), "loss": float(loss), "fine": o["fine"][2].cpu(), "lo": lo, "hi": hi},
-               "%s.rank%d.pt" % (out, rank))
+    res = {"flat": tr.bucket.flat.cpu(), "loss": float(loss), "fine": o["fine"][2].cpu(), "lo": lo, "hi": hi}
+    if backend == "nccl":
+        # the G/D alternation's collectives: each discriminator's bucket is all-reduced on that discriminator's own
+        # stream (train.py step_gan), then the generators' bucket on the main one - four RCCL all-reduces per step
+        tg = make_trainer(device=dev, discriminators=True)
+        errG, errsD = tg.step_gan(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev),
+                                  [h[lo:hi].to(dev) for h in hr])
+        torch.cuda.synchronize()
+        res["gan_flat"] = tg.bucket.flat.cpu()
+        res["gan_params_d"] = [torch.cat([p.detach().flatten() for p in b.params]).cpu() for b in tg.bucketsD]
+        res["gan_losses"] = [float(errG)] + [float(e) for e in errsD]
+        res["gan_params"] = torch.cat([p.detach().flatten() for p in tg.params]).cpu()
+    torch.save(res, "%s.rank%d.pt" % (out, rank))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -20,7 +20,8 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_gradients_and_sharded_inference(tmp_path):
+def _run_ranks(tmp_path, backend):
+    """Both ranks as child processes, started before this process has touched a device."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -29,11 +30,20 @@ def test_two_rank_gradients_and_sharded_inference(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out, backend], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    logs = [p.communicate(timeout=600)[0] for p in procs]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(logs)
-    r = [torch.load("%s.rank%d.pt" % (out, k)) for k in range(2)]
+    return [torch.load("%s.rank%d.pt" % (out, k)) for k in range(2)]
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_gradients_and_sharded_inference(tmp_path, backend):
+    """gloo: both ranks on cuda:0 (always runs).  nccl: one rank per device over RCCL - skipped on a one-GPU box, runs for
+    real wherever two devices are visible (torch.cuda.device_count() does not initialise the GPU on this image)."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank: %d visible" % torch.cuda.device_count())
+    r = _run_ranks(tmp_path, backend)
     assert torch.equal(r[0]["flat"], r[1]["flat"]), "ranks disagree after the all-reduce"
 
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -57,3 +67,12 @@ def test_two_rank_gradients_and_sharded_inference(tmp_path):
     for k in range(2):
         assert torch.allclose(full[r[k]["lo"]:r[k]["hi"]], r[k]["fine"], atol=1e-4, rtol=1e-4), \
             "sharded inference differs from the un-sharded rows"
+    if backend == "nccl":
+        # G/D alternation over RCCL: four all-reduces per step on four streams; after it every rank holds the same
+        # generator gradients and has taken the same Adam steps (the shards differ, so identical discriminator parameters
+        # after the step mean their gradients were all-reduced before it)
+        assert torch.equal(r[0]["gan_flat"], r[1]["gan_flat"]) and float(r[0]["gan_flat"].abs().max()) > 0
+        for a, b in zip(r[0]["gan_params_d"], r[1]["gan_params_d"]):
+            assert torch.equal(a, b)
+        assert torch.equal(r[0]["gan_params"], r[1]["gan_params"])
+        assert all(torch.isfinite(torch.tensor(r[k]["gan_losses"])).all() for k in range(2))

@@ -199,15 +199,35 @@ def test_generator_loss_adversarial_term(cfg_d):
         assert err < max(2e-4, 4 * err32), (err, err32)
 
 
+class _StandInTrunk(torch.nn.Module):
+    """Stand-in for CNN_ENCODER's frozen Inception-v3 trunk (third-party torchvision arithmetic, absent here - SURVEY.md
+    8c): any differentiable torch module image -> (features [B,768,17,17], pooled [B,2048]).  The SAME module (same
+    weights) runs on the CPU for the oracle side, so the comparison covers everything that is the build's: the HIP heads,
+    words_loss / sent_loss, the DAMSM backward kernel and the gradient's way back through both generators."""
+
+    def __init__(self):
+        super().__init__()
+        self.f = torch.nn.Conv2d(3, 768, 1)
+        self.p = torch.nn.Linear(3, 2048)
+
+    def forward(self, x):
+        return self.f(F.adaptive_avg_pool2d(x, 17)), self.p(x.mean((2, 3)))
+
+
 def test_full_size_gan_train_step_parity(face_weights):
     """BASELINE configs[2] at FULL size: CelebA x8, B = 16, shipped generator weights, DF_DIM 64 discriminators.  One
     G/D alternation of SRTrainer vs the oracle (torch autograd on the CPU): the three discriminator losses, the
-    generator loss, and a sample of parameter gradients of both generators (first / middle / last layers of each)."""
+    generator loss, and a sample of parameter gradients of both generators (first / middle / last layers of each) -
+    once as G + D + MSE + KL, and once more with generator_loss's DAMSM ranking term on the finest image switched on
+    (losses.py:375-389: words_loss + sent_loss x LAMBDA through an image encoder, with a class-id mask)."""
+    import copy
     from conftest import split_sd
     from tgsr_amd.miscc.config import cfg, cfg_reset
     from tgsr_amd.train import SRTrainer
+    from tgsr_amd.util import CNN_ENCODER
     cfg_reset()
     cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.DF_DIM = 32, 256, 64
+    cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.LAMBDA = 4.0, 5.0
     try:
         torch.manual_seed(0)
         tr = SRTrainer(41, device=DEV, discriminators=True)
@@ -216,8 +236,15 @@ def test_full_size_gan_train_step_parity(face_weights):
         tr.netGL.load_state_dict(sdL)
         tr.netGH.load_state_dict({k: v for k, v in sdH.items() if k != "a"})
         sdD = [_sd_cpu(d) for d in tr.netsD]
+        torch.manual_seed(3)
+        enc_cpu = CNN_ENCODER(256, trunk=_StandInTrunk()).eval()
+        for q in enc_cpu.parameters():
+            q.requires_grad = False
+        enc = copy.deepcopy(enc_cpu).to(DEV).eval()
         B = 16
         cap, lens, LR, LRb = O.synthetic_batch(B)
+        class_ids = np.arange(B)
+        class_ids[5] = class_ids[2]                      # one same-class pair: the -inf mask of losses.py:25-35 / 75-80
         g = torch.Generator().manual_seed(7)
         hr = [torch.rand(B, 3, s, s, generator=g) * 2 - 1 for s in (64, 128, 256)]
         # ---- oracle: the same alternation with torch autograd.  The discriminators are not updated between the two
@@ -233,32 +260,60 @@ def test_full_size_gan_train_step_parity(face_weights):
         rl, fl = torch.ones(B), torch.zeros(B)
         refD = [float(O.discriminator_loss(sd, hr[i], fine[i], sent, rl, fl)) for i, sd in enumerate(sdD)]
         refG = O.generator_adv_loss(sdD, fine, sent, rl) + O.mse(imgs, hr) + O.mse(fine, hr) + O.kl_loss(mu, logvar)
-        refG.backward()
+        refG.backward(retain_graph=True)
+        grads0 = {id(v): v.grad.clone() for sd in (rL, rH) for v in sd.values() if v.grad is not None}
+        # the ranking term alone (same graph): heads restated with stock torch ops on the CPU, oracle losses
+        feats, pooled = enc_cpu.trunk(fine[2])
+        regions = F.conv2d(feats, enc_cpu.emb_features.weight)
+        code = F.linear(pooled, enc_cpu.emb_cnn_code.weight, enc_cpu.emb_cnn_code.bias)
+        labels = torch.arange(B)
+        sm = cfg.TRAIN.SMOOTH
+        w0, w1, _ = O.words_loss(regions, words, labels, lens.tolist(), class_ids, B, sm.GAMMA1, sm.GAMMA2, sm.GAMMA3)
+        s0, s1 = O.sent_loss(code, sent, labels, class_ids, B, sm.GAMMA3)
+        refR = (w0 + w1) * sm.LAMBDA + (s0 + s1) * sm.LAMBDA
+        assert float(refR) > 1.0                          # a term that matters next to the others (~10)
+        refR.backward()                                   # accumulates onto the gradients of refG
         # ---- HIP
         for o in tr.optsD:
             for gq in o.param_groups:
                 gq["lr"] = 0.0
         for gq in tr.opt.param_groups:
             gq["lr"] = 0.0
-        errG, errsD = tr.step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), [h.to(DEV) for h in hr])
-        torch.cuda.synchronize()
-        for a, b in zip(errsD, refD):
-            assert abs(float(a) - b) < 1e-3 * max(1.0, abs(b)), (float(a), b)
-        assert abs(float(errG) - float(refG)) < 1e-3 * max(1.0, abs(float(refG))), (float(errG), float(refG))
-        sample = ["h_net1.im2f.0.weight", "h_net1.residual.0.block.0.weight", "h_net2.att.conv_context.weight",
-                  "h_net3.residual.1.block.3.weight", "h_net3.upsample.1.weight", "img_net3.img.0.weight",
-                  "h_net2.residual.0.block.1.weight"]
-        gl = dict(tr.netGL.named_parameters())
-        # gradients reach the generators through up to ten train-mode BatchNorms of the discriminators and 36 of their own:
-        # two fp32 implementations agree to ~1e-3 there (the discriminator tests above quantify it against fp64)
-        for k in sample:
-            err = float((gl[k].grad.cpu() - rL[k].grad).abs().max()) / (float(rL[k].grad.abs().max()) + 1e-12)
-            assert err < 1e-2, "GL %s: relative gradient error %g" % (k, err)
-        gh = dict(tr.netGH.named_parameters())
-        for k in ("convin.0.weight", "residual.3.block.0.weight", "upscale8x.1.weight", "conv_output.0.weight",
-                  "residual48.3.weight", "residual.5.block.4.bias"):
-            err = float((gh[k].grad.cpu() - rH[k].grad).abs().max()) / (float(rH[k].grad.abs().max()) + 1e-12)
-            assert err < 1e-2, "GH %s: relative gradient error %g" % (k, err)
+        sample_L = ["h_net1.im2f.0.weight", "h_net1.residual.0.block.0.weight", "h_net2.att.conv_context.weight",
+                    "h_net3.residual.1.block.3.weight", "h_net3.upsample.1.weight", "img_net3.img.0.weight",
+                    "h_net2.residual.0.block.1.weight"]
+        sample_H = ("convin.0.weight", "residual.3.block.0.weight", "upscale8x.1.weight", "conv_output.0.weight",
+                    "residual48.3.weight", "residual.5.block.4.bias")
+        args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), [h.to(DEV) for h in hr])
+        for leg in ("G+D+MSE+KL", "+DAMSM"):
+            if leg == "+DAMSM":
+                tr.image_encoder = enc                    # every learning rate is 0: the weights are those of leg one
+                want = float(refG) + float(refR)
+                ref_grad = lambda v: v.grad
+            else:
+                want = float(refG)
+                ref_grad = lambda v: grads0[id(v)]
+            errG, errsD = tr.step_gan(*args, class_ids=class_ids if leg == "+DAMSM" else None)
+            torch.cuda.synchronize()
+            for a, b in zip(errsD, refD):
+                assert abs(float(a) - b) < 1e-3 * max(1.0, abs(b)), (leg, float(a), b)
+            assert abs(float(errG) - want) < 1e-3 * max(1.0, abs(want)), (leg, float(errG), want)
+            gl = dict(tr.netGL.named_parameters())
+            # gradients reach the generators through up to ten train-mode BatchNorms of the discriminators and 36 of their
+            # own: two fp32 implementations agree to ~1e-3 there (the discriminator tests above quantify it against fp64)
+            for k in sample_L:
+                r = ref_grad(rL[k])
+                err = float((gl[k].grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-12)
+                assert err < 1e-2, "%s GL %s: relative gradient error %g" % (leg, k, err)
+            gh = dict(tr.netGH.named_parameters())
+            for k in sample_H:
+                r = ref_grad(rH[k])
+                err = float((gh[k].grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-12)
+                assert err < 1e-2, "%s GH %s: relative gradient error %g" % (leg, k, err)
+        # the ranking term really moved the sampled gradients (else leg two proves nothing beyond leg one)
+        moved = max(float((rH[k].grad - grads0[id(rH[k])]).abs().max()) / (float(grads0[id(rH[k])].abs().max()) + 1e-12)
+                    for k in sample_H)
+        assert moved > 5e-2, moved
     finally:
         cfg_reset()
 

@@ -678,3 +678,32 @@ def test_damsm_kernels_are_bitwise_reproducible():
         assert torch.equal(s, sims[0])
     for gi, gw in grads[1:]:
         assert torch.equal(gi, grads[0][0]) and torch.equal(gw, grads[0][1])
+
+
+def test_config3_birds_vocab_5450_batch4_vs_oracle(cfg_face):
+    """BASELINE configs[3] (eval_birdSR_attn2.yml: BRANCH_NUM 4, BASE_SIZE 32, GF_DIM 32, EMBEDDING_DIM 256): the CUB
+    vocabulary (n_words 5450, datasets.py:725) at the per-GPU batch of B=32 over 8 GPUs (4), full size, seeded random
+    weights of that architecture, against the CPU oracle at the stated 1e-4.  Exercises the 5450-row per-token gate table
+    of the text encoder (util.RNN_ENCODER -> ops.lstm_gate_table) and the small-batch kernel selection."""
+    from tgsr_amd.trainer import SRPipeline
+    n_words = 5450
+    sdE, sdL, sdH = O.random_state(n_words=n_words, seed=11)
+    cap, lens, LR, LRb = O.synthetic_batch(4, n_words=n_words, seed=31)
+    assert int(cap.max()) > 2000                       # tokens from the far end of the table, not just its head
+    ref = O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
+    p = SRPipeline(n_words, device=DEV).load_state_dicts(sdE, sdL, sdH)
+    assert tuple(p.text_encoder.encoder.weight.shape) == (n_words, 300)
+    r = p(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    assert tuple(p.text_encoder._table.shape) == (n_words, 2, 512)
+    close(r["words_emb"], ref["words_emb"], atol=1e-5)
+    close(r["sent_emb"], ref["sent_emb"], atol=1e-5)
+    for i in range(3):
+        close(r["fake"][i], ref["fake"][i], atol=ATOL256 if i == 2 else ATOL)
+        close(r["fine"][i], ref["fine"][i], atol=ATOL256 if i == 2 else ATOL)
+        close(r["att"][i], ref["att"][i], atol=2e-5)
+    # every token of the vocabulary: the table against the oracle's own input projection on a batch that walks the table
+    ids = torch.arange(1, n_words).reshape(-1, 1)[:5448].reshape(-1, 18)[::23][:16]          # 16 captions of 18 tokens
+    words, sent = O.rnn_encoder(sdE, ids, [18] * ids.shape[0])
+    w2, s2 = p.text_encoder(ids.to(DEV), [18] * ids.shape[0])
+    close(w2, words, atol=1e-5)
+    close(s2, sent, atol=1e-5)
