@@ -327,6 +327,14 @@ int tgsr_conv3x3_gemm_wgrad(const float* dy, const float* x, int B, int Cin, int
                             void* stream);
 int tgsr_leaky_relu(const float* x, const float* y_for_bwd, float* out, int64_t n, void* stream);
 
+/*
+ * GLU.forward (util.py:45-53) as a stand-alone op - inside the conv blocks it is the producing kernel's epilogue; the
+ * module itself is callable upstream (CA_NET, util.py:381).  x viewed as [outer][2][half] (the two channel halves of
+ * [B, 2C, ...]: outer = B, half = C * inner), dense fp32.  dy == NULL: out[outer][half] = x[.][0][.] * sigmoid(x[.][1][.]);
+ * dy [outer][half] != NULL: the backward, out = dx [outer][2][half].
+ */
+int tgsr_glu(const float* x, const float* dy, float* out, int64_t outer, int64_t half, void* stream);
+
 /* Backward of nn.Upsample(scale_factor=2, 'nearest'): out[bc][y][x] = sum of in[bc][2y..2y+1][2x..2x+1]. */
 int tgsr_sumpool2x2(const float* x, int64_t BC, int H, int W, float* out, void* stream);
 

@@ -27,6 +27,8 @@ def test_opcheck_conv_to3_and_conv4x4s2():
     xd = torch.randn(2, 8, 16, 16, generator=g).to(DEV).requires_grad_(True)
     wd = (torch.randn(16, 8, 4, 4, generator=g) / 11.0).to(DEV).requires_grad_(True)
     torch.library.opcheck(torch.ops.tgsr.conv4x4s2.default, (xd, wd, True), test_utils=utils)
+    torch.library.opcheck(torch.ops.tgsr.glu.default, (torch.randn(3, 8, 5, generator=g).to(DEV).requires_grad_(True),),
+                          test_utils=utils)
     torch.library.opcheck(torch.ops.tgsr.conv3x3_fused_out.default,
                           (torch.randn(1, 32, 8, 32, device=DEV), torch.zeros(32 * 32 * 9, device=DEV), 32, None, None,
                            False, False, None, torch.empty(1, 32, 8, 32, device=DEV)), test_utils=("test_schema", "test_faketensor"))

@@ -396,7 +396,7 @@ def test_cnn_encoder_heads(cfg_face):
     for B in (1, 5, 16):
         x = torch.zeros(B, 3, 64, 64, device=DEV)
         feats, code = enc(x)
-        f768, p2048 = enc.trunk(x)
+        f768, p2048 = enc.run_trunk(x)
         close(feats, F.conv2d(f768.cpu(), enc.emb_features.weight.detach().cpu()), atol=5e-5, rtol=1e-4)
         close(code, F.linear(p2048.cpu(), enc.emb_cnn_code.weight.detach().cpu(), enc.emb_cnn_code.bias.detach().cpu()),
               atol=1e-4, rtol=1e-4)
@@ -707,3 +707,76 @@ def test_config3_birds_vocab_5450_batch4_vs_oracle(cfg_face):
     w2, s2 = p.text_encoder(ids.to(DEV), [18] * ids.shape[0])
     close(w2, words, atol=1e-5)
     close(s2, sent, atol=1e-5)
+
+
+class _StubInception(torch.nn.Module):
+    """An object with the sixteen Inception-v3 block attributes CNN_ENCODER.define_module copies (util.py:282-298), each a
+    small conv with the stride / padding that gives the real blocks' spatial sizes (299 -> 149 -> 147 -> 147 | 73 -> 73 ->
+    71 | 35 ... -> 17 x 17 x 768 ... -> 8 x 8 x 2048).  torchvision is absent here and its arithmetic is third-party: the
+    stub is what lets the WALK (util.py:308-362) execute."""
+
+    def __init__(self):
+        super().__init__()
+        c = torch.nn.Conv2d
+        self.Conv2d_1a_3x3, self.Conv2d_2a_3x3, self.Conv2d_2b_3x3 = c(3, 4, 3, 2), c(4, 4, 3), c(4, 6, 3, 1, 1)
+        self.Conv2d_3b_1x1, self.Conv2d_4a_3x3 = c(6, 8, 1), c(8, 12, 3)
+        self.Mixed_5b, self.Mixed_5c, self.Mixed_5d = c(12, 16, 1), c(16, 16, 1), c(16, 16, 1)
+        self.Mixed_6a = c(16, 768, 3, 2)
+        self.Mixed_6b, self.Mixed_6c, self.Mixed_6d, self.Mixed_6e = (c(768, 768, 1, groups=768) for _ in range(4))
+        self.Mixed_7a, self.Mixed_7b, self.Mixed_7c = c(768, 64, 3, 2), c(64, 2048, 1), c(2048, 2048, 1, groups=2048)
+
+
+def test_cnn_encoder_trunk_walk_on_stub_inception(cfg_face):
+    """CNN_ENCODER built the reference's way (define_module over an Inception-like object): same state_dict key names,
+    frozen trunk, and forward == the reference's walk (util.py:308-368) restated here op by op on the CPU copy."""
+    import copy
+    from tgsr_amd import util
+    torch.manual_seed(5)
+    stub = _StubInception()
+    m = copy.deepcopy(stub)                                     # CPU copy for the restated walk
+    enc = util.CNN_ENCODER(256, inception=stub).to(DEV).eval()
+    keys = set(enc.state_dict())
+    assert {"Conv2d_1a_3x3.weight", "Mixed_6e.weight", "Mixed_7c.bias", "emb_features.weight", "emb_cnn_code.weight",
+            "emb_cnn_code.bias"} <= keys and not any(k.startswith("trunk.") for k in keys)
+    assert all(not p.requires_grad for p in enc.frozen_parameters()) and enc.emb_features.weight.requires_grad
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(3, 3, 256, 256, generator=g) * 2 - 1
+    with torch.no_grad():
+        feats, code = enc(x.to(DEV))
+        y = torch.nn.Upsample(size=(299, 299), mode='bilinear')(x)              # util.py:311
+        y = m.Conv2d_1a_3x3(y); y = m.Conv2d_2a_3x3(y); y = m.Conv2d_2b_3x3(y)  # :313-317
+        y = F.max_pool2d(y, kernel_size=3, stride=2)                            # :319
+        y = m.Conv2d_3b_1x1(y); y = m.Conv2d_4a_3x3(y)                          # :321-323
+        y = F.max_pool2d(y, kernel_size=3, stride=2)                            # :326
+        y = m.Mixed_5b(y); y = m.Mixed_5c(y); y = m.Mixed_5d(y)                 # :328-332
+        y = m.Mixed_6a(y); y = m.Mixed_6b(y); y = m.Mixed_6c(y); y = m.Mixed_6d(y); y = m.Mixed_6e(y)   # :335-343
+        features = y                                                            # :347
+        y = m.Mixed_7a(y); y = m.Mixed_7b(y); y = m.Mixed_7c(y)                 # :350-354
+        y = F.avg_pool2d(y, kernel_size=8).view(y.size(0), -1)                  # :356-360
+        ref_code = F.linear(y, enc.emb_cnn_code.weight.cpu(), enc.emb_cnn_code.bias.cpu())     # :363
+        ref_feats = F.conv2d(features, enc.emb_features.weight.cpu())            # :366
+    assert tuple(feats.shape) == (3, 256, 17, 17) and tuple(code.shape) == (3, 256)
+    close(feats, ref_feats, atol=2e-4, rtol=1e-3)
+    close(code, ref_code, atol=2e-4, rtol=1e-3)
+    with pytest.raises(ImportError):
+        util.CNN_ENCODER(256)                                   # no torchvision here: a loud error, not a silent stand-in
+
+
+@pytest.mark.parametrize("shape", [(4, 400), (2, 64, 9, 7), (3, 6, 5)])
+def test_glu_standalone_module_forward_backward(shape):
+    """util.GLU called on its own (the reference's CA_NET does, util.py:381): x[:, :C/2] * sigmoid(x[:, C/2:]) and its
+    gradient, vs torch."""
+    from tgsr_amd import util
+    g = torch.Generator().manual_seed(len(shape))
+    x = torch.randn(shape, generator=g, requires_grad=True)
+    nc = shape[1] // 2
+    ref = x[:, :nc] * torch.sigmoid(x[:, nc:])
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    out = util.GLU()(xd)
+    out.backward(dy.to(DEV))
+    close(out, ref, atol=1e-6, rtol=1e-6)
+    close(xd.grad, x.grad, atol=1e-6, rtol=1e-5)
+    with pytest.raises(AssertionError):
+        util.GLU()(torch.zeros(2, 3, device=DEV))

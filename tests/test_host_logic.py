@@ -137,3 +137,32 @@ def test_committed_bench_lines_follow_the_contract():
     assert saw_cpu and saw_lp and saw_train
     two = json.loads(open(os.path.join(root, "profiles", "r02i_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
     assert two["n_gpus"] == 2                       # `bench.py --gpus 2` launched its two ranks itself
+
+
+def test_get_caption_crops_like_the_reference():
+    """datasets.py:461-477: short captions are zero padded; a longer one keeps WORDS_NUM word positions drawn by
+    np.random.shuffle, in their original order - the same draw as the reference under the same numpy seed."""
+    import numpy as np
+    from tgsr_amd.datasets import get_caption
+    x, n = get_caption([5, 6, 7], 18)
+    assert n == 3 and x.tolist() == [5, 6, 7] + [0] * 15
+    cap = list(range(1, 31))
+    np.random.seed(100)
+    x, n = get_caption(cap, 18)
+    np.random.seed(100)                       # the reference's lines, verbatim in effect
+    ix = list(np.arange(30))
+    np.random.shuffle(ix)
+    want = np.asarray(cap)[np.sort(ix[:18])]
+    assert n == 18 and x.tolist() == want.tolist() and (np.diff(x) > 0).all() and x.tolist() != cap[:18]
+    x2, _ = get_caption(cap, 18, rng=np.random.RandomState(3))
+    x3, _ = get_caption(cap, 18, rng=np.random.RandomState(3))
+    assert x2.tolist() == x3.tolist()
+
+
+def test_lazy_log_is_opt_in_and_formats_like_the_reference():
+    import torch
+    from tgsr_amd.miscc.losses import _LazyLog
+    log = _LazyLog([("g_loss%d: %%.5f " % 0, torch.tensor(1.5)), ("w_loss: %.5f s_loss: %.5f ", torch.tensor(2.0), torch.tensor(3.0))])
+    text = "g_loss0: 1.50000 w_loss: 2.00000 s_loss: 3.00000 "
+    assert str(log) == text and log == text and "w_loss" in log and len(log) == len(text) and log[:7] == "g_loss0"
+    assert ("" + log) == text and (log + "x") == text + "x" and "%s" % log == text and log._parts is None

@@ -27,6 +27,20 @@ def _dgrad_weight(w: torch.Tensor) -> torch.Tensor:
 # one, for the duration of a step's backward, and joins it before anything reads the gradients; modules driven directly
 # (`loss.backward()` then `p.grad`) stay on one stream.
 WGRAD_SIDE = {}          # device index -> torch.cuda.Stream
+# (parameter, data_ptr of its bucket slot) of every weight gradient issued on a side stream: `check_adopted` verifies after
+# the join that autograd really took those tensors as `.grad` (had it cloned or added instead, that kernel would have run
+# on the main stream while the side stream was still writing the slot)
+_ADOPTED = []
+
+
+def check_adopted():
+    """Called once the side stream has been joined: every gradient computed there must BE the parameter's `.grad`."""
+    bad = [p for p, ptr in _ADOPTED if p.grad is None or p.grad.data_ptr() != ptr]
+    _ADOPTED.clear()
+    if bad:
+        raise TgsrError("%d weight gradients were computed on the side stream but autograd did not adopt them in place "
+                        "(it cloned or accumulated on the main stream while they were in flight): set TGSR_WGRAD_SIDE=0"
+                        % len(bad))
 
 
 def wgrad_stream(dev):
@@ -143,7 +157,11 @@ def _cba_backward(x, weight, raw, stats, gamma, beta, glu, upsample, dout, need_
     if need_dw:
         from . import util
         dw = _grad_out(weight, weight.shape, dev)
-        adopted = dw._base is not None                                # a view of the flat bucket (parallel.grad_slot)
+        # a view of the flat bucket (parallel.grad_slot) that autograd's AccumulateGrad will take as `.grad` without
+        # launching anything: only when no gradient sits there yet and no graph of the backward is being recorded
+        adopted = dw._base is not None and weight.grad is None and not torch.is_grad_enabled()
+        if adopted and wgrad_stream(dev) is not None:
+            _ADOPTED.append((weight, dw.data_ptr()))
 
         def wgrad():
             if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:

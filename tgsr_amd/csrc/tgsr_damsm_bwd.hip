@@ -309,12 +309,14 @@ extern "C" int tgsr_damsm_words_bwd(const float* words, const int32_t* cap_lens,
   a.gw_part = ws + (int64_t)B * B * 3 * 32 * S;
   a.gc_part = a.gw_part + (int64_t)B * B * ndf * 32;
   const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + (size_t)ndf * 33 * 2 + 128 + 4 * 128);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};   // the > 64 KB opt-in belongs to the DEVICE's code object: once per device, not per
+  int dev = 0;                          // process (one process driving two GPUs would otherwise fail on the second)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(damsm_pair_bwd_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return note_launch(hipGetLastError(), "hipFuncSetAttribute(damsm_pair_bwd_kernel)");
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(damsm_pair_bwd_kernel, dim3(B * B), dim3(256), lds, s, a);

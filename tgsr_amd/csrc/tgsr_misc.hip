@@ -62,6 +62,26 @@ __global__ void to_uint8_kernel(const float* __restrict__ x, uint8_t* __restrict
   }
 }
 
+// GLU (util.py:45-53): out[o][i] = x[o][0][i] * sigmoid(x[o][1][i]) over x viewed as [outer][2][half] (channel halves of
+// [B, 2C, ...]).  The fused conv kernels carry this in their epilogues; this is the module's stand-alone form (CA_NET
+// calls it on [B, 400], util.py:381).  dy != NULL: the backward, dx[o][0][i] = dy s, dx[o][1][i] = dy v s (1 - s).
+__global__ void glu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
+                           int64_t outer, int64_t half) {
+  const int64_t n = outer * half, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t o = i / half, r = i - o * half;
+    const float v = x[(2 * o) * half + r], g = x[(2 * o + 1) * half + r];
+    const float sg = 1.f / (1.f + expf(-g));
+    if (dy == nullptr) {
+      out[i] = v * sg;
+    } else {
+      const float d = dy[i];
+      out[(2 * o) * half + r] = d * sg;
+      out[(2 * o + 1) * half + r] = d * v * sg * (1.f - sg);
+    }
+  }
+}
+
 }  // namespace tgsr
 
 using namespace tgsr;
@@ -104,4 +124,12 @@ extern "C" int tgsr_to_uint8(const float* x, uint8_t* out, int64_t n, void* stre
   const int blocks = (int)((work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048);
   hipLaunchKernelGGL(to_uint8_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, out, n);
   return note_launch(hipGetLastError(), "to_uint8_kernel");
+}
+
+extern "C" int tgsr_glu(const float* x, const float* dy, float* out, int64_t outer, int64_t half, void* stream) {
+  if (!x || !out || outer < 1 || half < 1) return TGSR_EINVAL;
+  const int64_t n = outer * half;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(glu_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, out, outer, half);
+  return note_launch(hipGetLastError(), "glu_kernel");
 }

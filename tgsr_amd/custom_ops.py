@@ -193,3 +193,11 @@ def _conv4x4s2_backward(ctx, dy):
 
 
 torch.library.register_autograd("tgsr::conv4x4s2", _conv4x4s2_backward, setup_context=_conv4x4s2_setup, lib=_lib)
+
+
+# ------------------------------------------------------------------------------------------------ stand-alone GLU (differentiable)
+glu = _define("glu(Tensor x) -> Tensor", lambda x: ops.glu(x),
+              lambda x: x.new_empty((x.shape[0], x.shape[1] // 2) + tuple(x.shape[2:])))
+glu_bwd = _define("glu_bwd(Tensor dy, Tensor x) -> Tensor", lambda dy, x: ops.glu_bwd(dy, x), lambda dy, x: torch.empty_like(x))
+torch.library.register_autograd("tgsr::glu", lambda ctx, dy: glu_bwd(dy, ctx.saved_tensors[0]),
+                                setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0]), lib=_lib)

@@ -170,17 +170,35 @@ def prepare_datablur(data, cfg=None, device=None):
     return [real_imgs, captions, lens.to(dev), class_ids, keys, real_bic, real_blur, real_bicblur]
 
 
-def load_caption_pickle(path, words_num=18):
+def get_caption(sent_caption, words_num=18, rng=None):
+    """datasets.py:461-477: zero-pad a caption to `words_num` tokens; a LONGER caption keeps a random subset of
+    `words_num` word positions in their original order (np.random.shuffle of the positions, the first `words_num` of them,
+    sorted).  `rng`: None = numpy's global generator, exactly the reference's draw (seed it with np.random.seed like
+    test1.py:171 does); a np.random.RandomState / Generator for a private stream.  Returns (x int64 [words_num], x_len)."""
+    c = np.asarray(sent_caption).astype('int64')
+    x = np.zeros(words_num, dtype='int64')
+    n = len(c)
+    if n <= words_num:
+        x[:n] = c
+        return x, n
+    ix = list(np.arange(n))
+    (np.random if rng is None else rng).shuffle(ix)
+    ix = np.sort(ix[:words_num])
+    x[:] = c[ix]
+    return x, words_num
+
+
+def load_caption_pickle(path, words_num=18, rng=None):
     """The pickle test1.py:118-127 writes: `[captions (lists of word indices), ixtoword, wordtoix]`.  Returns
-    (captions int64 [N, words_num] zero padded / cropped like datasets.py get_caption, cap_lens int64 [N], ixtoword,
-    wordtoix)."""
+    (captions int64 [N, words_num], cap_lens int64 [N], ixtoword, wordtoix), every caption padded / cropped by
+    `get_caption` (datasets.py:461-477: captions longer than `words_num` keep a random ordered subset of their words)."""
     with open(path, "rb") as f:
         x = pickle.load(f)
     caps, ixtoword, wordtoix = x[0], x[-2], x[-1]
     out = torch.zeros(len(caps), words_num, dtype=torch.int64)
     lens = torch.zeros(len(caps), dtype=torch.int64)
     for i, c in enumerate(caps):
-        c = list(c)[:words_num]
-        out[i, :len(c)] = torch.tensor(c, dtype=torch.int64)
-        lens[i] = len(c)
+        row, n = get_caption(list(c), words_num, rng)
+        out[i] = torch.from_numpy(row)
+        lens[i] = n
     return out, lens, ixtoword, wordtoix

@@ -126,13 +126,21 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
 class _LazyLog:
     """The log string of generator_loss, formatted when somebody looks at it: the reference builds it with `.item()` on
     every term (losses.py:366-390) - three device synchronisations inside the generator step that nothing needs unless
-    the string is printed.  Behaves like the str it stands for under str(), format(), + and +=."""
+    the string is printed.  Behaves like the str it stands for under str(), format(), +, +=, len, in, slicing and ==; it
+    is NOT a str instance (a str subclass cannot fill its character buffer later, so C-level consumers - file.write,
+    ''.join - would silently see an empty string).  Only handed out on request: generator_loss(lazy_log=True), which
+    train.SRTrainer passes; the default return is the reference's plain str.  The loss tensors are released once the
+    text has been formatted."""
 
     def __init__(self, parts):
-        self._parts = parts                      # [(format, tensor, ...), ...]
+        self._parts = parts                      # [(format, tensor, ...), ...]; dropped once formatted
+        self._text = None
 
     def __str__(self):
-        return "".join(f % tuple(float(t) for t in ts) for f, *ts in self._parts)
+        if self._text is None:
+            self._text = "".join(f % tuple(float(t) for t in ts) for f, *ts in self._parts)
+            self._parts = None
+        return self._text
 
     __repr__ = __str__
 
@@ -151,12 +159,22 @@ class _LazyLog:
     def __contains__(self, item):
         return item in str(self)
 
+    def __getitem__(self, k):
+        return str(self)[k]
+
+    def __eq__(self, other):
+        return str(self) == other
+
+    def __hash__(self):
+        return hash(str(self))
+
 
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
-                   class_ids, w=1, s=1, g=1, streams=None):
+                   class_ids, w=1, s=1, g=1, streams=None, lazy_log=False):
     """losses.py:351-391: per-scale adversarial terms + the DAMSM words / sentence ranking loss on the last scale
-    (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log) like the reference; the log is a _LazyLog: the same string, formatted
-    (and the device synchronised) only when it is looked at.  `image_encoder=None` (the reference
+    (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log) like the reference: `log` is the same str; with `lazy_log=True` (not a
+    reference argument) a _LazyLog stands in for it - the same text, formatted (and the device synchronised) only when it
+    is looked at.  `image_encoder=None` (the reference
     always has one; its Inception-v3 weights are third-party and not shipped) leaves the ranking term out."""
     B = real_labels.size(0)
     total, parts = 0, []
@@ -193,4 +211,5 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
             s_term = s * (s0 + s1) * cfg.TRAIN.SMOOTH.LAMBDA
             total = total + w_term + s_term
             parts.append(("w_loss: %.5f s_loss: %.5f ", w_term.detach(), s_term.detach()))
-    return total, _LazyLog(parts)
+    log = _LazyLog(parts)
+    return total, (log if lazy_log else str(log))

@@ -588,6 +588,31 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+# ----------------------------------------------------------------------------------------- stand-alone GLU
+def glu(x: torch.Tensor) -> torch.Tensor:
+    """GLU.forward (util.py:45-53): x[:, :C/2] * sigmoid(x[:, C/2:]) for x [B, C, ...] with C even."""
+    _need_hip(x)
+    x = _f32(x, "x").contiguous()
+    if x.dim() < 2 or x.shape[1] % 2 != 0:
+        raise TgsrError("glu: channels dont divide 2! (shape %s)" % (tuple(x.shape),))
+    B, nc = x.shape[0], x.shape[1] // 2
+    out = torch.empty((B, nc) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    if out.numel():
+        check(_lib.lib().tgsr_glu(_p(x), None, _p(out), B, out.numel() // B, _stream()), "tgsr_glu")
+    return out
+
+
+def glu_bwd(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Backward of glu: dy [B, C/2, ...], x [B, C, ...] -> dx like x."""
+    _need_hip(dy, x)
+    x = _f32(x, "x").contiguous()
+    dy = _f32(dy, "dy").contiguous()
+    dx = torch.empty_like(x)
+    if dx.numel():
+        check(_lib.lib().tgsr_glu(_p(x), _p(dy), _p(dx), x.shape[0], dy.numel() // x.shape[0], _stream()), "tgsr_glu")
+    return dx
+
+
 # ----------------------------------------------------------------------------------------- image epilogue
 def to_uint8(img: torch.Tensor) -> torch.Tensor:
     """trainer_objective.py:153-155 on the device: round(clip((x + 1) * 127.5, 0, 255)) -> uint8, same shape.

@@ -117,6 +117,7 @@ class FlatGradBucket:
             if g is not None and g.data_ptr() != v.data_ptr():
                 v.copy_(g)
             p.grad = v
+            _SLOTS.pop(p.data_ptr(), None)       # the registry only holds buckets with a step in flight
         self.direct = False
 
     def pack(self):

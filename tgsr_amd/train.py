@@ -118,7 +118,7 @@ class SRTrainer:
         B = sent_emb.shape[0]
         real_labels, _fake, match_labels = prepare_labels(B, self.device)
         adv, _log = losses.generator_loss(self.netsD, self.image_encoder, fine_im, real_labels, words_embs, sent_emb,
-                                          match_labels, cap_lens, class_ids, streams=self._dstreams or None)
+                                          match_labels, cap_lens, class_ids, streams=self._dstreams or None, lazy_log=True)
         return adv + losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
 
     @contextlib.contextmanager
@@ -133,6 +133,11 @@ class SRTrainer:
         autograd.WGRAD_SIDE[idx] = self._wside
         try:
             yield
+        except BaseException:
+            autograd._ADOPTED.clear()
+            raise
+        else:
+            autograd.check_adopted()
         finally:
             autograd.WGRAD_SIDE.pop(idx, None)
             torch.cuda.current_stream(self.device).wait_stream(self._wside)
@@ -203,10 +208,12 @@ class SRTrainer:
         if self.netsD:
             return self.step_gan(captions, cap_lens, LR, LRb, hr_pyramid)[0]
         self._zero(self.bucket)
-        errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
-        with self._wgrad_side():
-            errG.backward()
-        self.bucket.end_step()
+        try:
+            errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
+            with self._wgrad_side():
+                errG.backward()
+        finally:
+            self.bucket.end_step()               # also after a failed step: `.grad` views restored, slots closed
         self.bucket.all_reduce_mean()
         self.opt.step()
         with torch.no_grad():
@@ -230,8 +237,8 @@ class DAMSMTrainer:
         self.image_encoder = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM,
                                          trunk=trunk if trunk is not None else torch.nn.Identity()).to(self.device)
         self.image_encoder.train()
-        for p in self.image_encoder.trunk.parameters():
-            p.requires_grad = False                                  # util.py:277-278
+        for p in self.image_encoder.frozen_parameters():
+            p.requires_grad = False                                  # util.py:274-275
         self.params = list(self.text_encoder.parameters()) + [p for p in self.image_encoder.parameters()
                                                               if p.requires_grad]
         self.bucket = FlatGradBucket(self.params).attach()
@@ -271,5 +278,5 @@ class DAMSMTrainer:
     def step(self, imgs, captions, cap_lens, class_ids=None):
         """pretrain_DAMSM.py:66-98 with the image through the (frozen) trunk."""
         with torch.no_grad():
-            features, pooled = self.image_encoder.trunk(imgs)
+            features, pooled = self.image_encoder.run_trunk(imgs)
         return self.step_features(features, pooled, captions, cap_lens, class_ids)

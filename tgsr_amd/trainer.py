@@ -222,10 +222,10 @@ class GraphedStep:
                 pipe.overlap = False
             with torch.cuda.graph(self.graph):
                 main = torch.cuda.current_stream(dev)
-                for k in range(self.lanes):
+                for st in branch:                        # fork EVERY branch before any lane's work is captured: a
+                    st.wait_stream(main)                 # wait recorded behind lane 0's kernels would make the branches
+                for k in range(self.lanes):              # depend on all of lane 0 (they would run after it, not beside it)
                     st = main if k == 0 else branch[k - 1]
-                    if k:
-                        st.wait_stream(main)             # fork: the branch joins the capture
                     with torch.cuda.stream(st):
                         if lpx is not None:
                             lpx.force_bufs = bufs[k]

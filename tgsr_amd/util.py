@@ -114,13 +114,17 @@ def invalidate_caches(module: nn.Module):
 
 # ------------------------------------------------------------------------------------------ blocks
 class GLU(nn.Module):
-    """util.py:45-53.  Only a marker inside the fused Sequentials below (its arithmetic is the conv epilogue)."""
+    """util.py:45-53: x[:, :C/2] * sigmoid(x[:, C/2:]).  Inside the fused Sequentials below it is a marker (its arithmetic
+    is the producing convolution's epilogue); called on its own - as CA_NET does upstream, util.py:381 - it is one HIP
+    launch (torch.ops.tgsr.glu, differentiable)."""
 
     def __init__(self):
         super(GLU, self).__init__()
 
     def forward(self, x):
-        raise NotImplementedError("GLU is fused into the producing convolution on the HIP path")
+        nc = x.size(1)
+        assert nc % 2 == 0, 'channels dont divide 2!'
+        return C.glu(x)
 
 
 def conv1x1(in_planes, out_planes, bias=False):
@@ -366,27 +370,72 @@ class RNN_ENCODER(nn.Module):
         return ops.bilstm(captions, cap_lens, self.encoder.weight, w_ih, w_hh, b_ih, b_hh)
 
 
+_INCEPTION_BLOCKS = ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3", "Conv2d_3b_1x1", "Conv2d_4a_3x3", "Mixed_5b", "Mixed_5c",
+                     "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b", "Mixed_7c")
+
+
 class CNN_ENCODER(nn.Module):
     """util.py:263-368.  The frozen Inception-v3 trunk is third-party torchvision arithmetic with downloaded weights
-    (util.py:271-275): it is NOT re-implemented here.  Pass `trunk` = a module mapping images [B,3,H,W] to
-    (region features [B,768,17,17], pooled code [B,2048]) - e.g. a torchvision Inception-v3 wrapped the way
-    util.py:308-362 walks it - or let the constructor build that wrapper when torchvision is importable.  The two
-    trainable heads (`emb_features`, `emb_cnn_code`; same state_dict keys, same uniform(-0.1, 0.1) init,
-    util.py:303-306) run on the HIP GEMM kernels."""
+    (util.py:271-275): its blocks are NOT re-implemented here.  Three ways to supply it:
+      * nothing: `torchvision.models.inception_v3()` is built like the reference does (raises where torchvision is absent);
+      * `inception=` any object exposing the sixteen block attributes the reference copies (util.py:282-298:
+        Conv2d_1a_3x3 ... Mixed_7c) - they are registered on this module under the reference's names, so the state_dict
+        keys (`Conv2d_1a_3x3.*`, ..., `emb_features.weight`, `emb_cnn_code.*`) equal the reference's image_encoder files,
+        and `forward` walks them exactly as util.py:308-362 does (bilinear resize to 299, two max-pools, features after
+        Mixed_6e, 8x8 average pool after Mixed_7c);
+      * `trunk=` a module images [B,3,H,W] -> (features [B,768,17,17], pooled [B,2048]) replacing the whole walk.
+    The two trainable heads (`emb_features`, `emb_cnn_code`; same uniform(-0.1, 0.1) init, util.py:303-306) run on the HIP
+    GEMM kernels."""
 
-    def __init__(self, nef, trunk=None):
+    def __init__(self, nef, trunk=None, inception=None):
         super(CNN_ENCODER, self).__init__()
         self.nef = nef if cfg.TRAIN.FLAG else 256          # util.py:266-269
-        if trunk is None:
-            trunk = _torchvision_inception_trunk()
         self.trunk = trunk
+        if trunk is None:
+            model = inception if inception is not None else _torchvision_inception()
+            for param in model.parameters():               # util.py:274-275
+                param.requires_grad = False
+            self.define_module(model)
+        else:
+            self._define_heads()
+        self.init_trainable_weights()
+
+    def define_module(self, model):
+        """util.py:281-301."""
+        for name in _INCEPTION_BLOCKS:
+            setattr(self, name, getattr(model, name))
+        self._define_heads()
+
+    def _define_heads(self):
         self.emb_features = conv1x1(768, self.nef)
         self.emb_cnn_code = nn.Linear(2048, self.nef)
-        self.init_trainable_weights()
 
     def init_trainable_weights(self):
         self.emb_features.weight.data.uniform_(-0.1, 0.1)
         self.emb_cnn_code.weight.data.uniform_(-0.1, 0.1)
+
+    def frozen_parameters(self):
+        """Everything but the two heads (the reference freezes the Inception parameters, util.py:274-275)."""
+        heads = {id(p) for m in (self.emb_features, self.emb_cnn_code) for p in m.parameters()}
+        return [p for p in self.parameters() if id(p) not in heads]
+
+    def run_trunk(self, x):
+        """images -> (features [B,768,17,17], pooled [B,2048]): util.py:308-362 up to (not including) the two heads.
+        Third-party blocks run as the torch modules they are; only the order / pooling / resize is the reference's."""
+        if self.trunk is not None:
+            return self.trunk(x)
+        import torch.nn.functional as F
+        x = F.interpolate(x, size=(299, 299), mode='bilinear', align_corners=False)   # nn.Upsample(size=(299, 299), 'bilinear')
+        x = self.Conv2d_2b_3x3(self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x)))              # 149 -> 147 -> 147
+        x = F.max_pool2d(x, kernel_size=3, stride=2)                                    # 73
+        x = self.Conv2d_4a_3x3(self.Conv2d_3b_1x1(x))                                   # 73 -> 71
+        x = F.max_pool2d(x, kernel_size=3, stride=2)                                    # 35
+        x = self.Mixed_5d(self.Mixed_5c(self.Mixed_5b(x)))
+        x = self.Mixed_6e(self.Mixed_6d(self.Mixed_6c(self.Mixed_6b(self.Mixed_6a(x)))))   # 17 x 17 x 768
+        features = x                                                                    # image region features
+        x = self.Mixed_7c(self.Mixed_7b(self.Mixed_7a(x)))                              # 8 x 8 x 2048
+        x = F.avg_pool2d(x, kernel_size=8)
+        return features, x.view(x.size(0), -1)
 
     def heads(self, features, pooled):
         """(features [B,768,17,17], pooled [B,2048]) -> (region features [B,nef,17,17], cnn_code [B,nef])."""
@@ -398,43 +447,20 @@ class CNN_ENCODER(nn.Module):
         return ops.conv1x1(features, self.emb_features.weight), cnn_code
 
     def forward(self, x):
-        features, pooled = self.trunk(x)
+        features, pooled = self.run_trunk(x)
         return self.heads(features, pooled)
 
 
-def _torchvision_inception_trunk():
+def _torchvision_inception():
+    """util.py:271-273: `models.inception_v3()` (the reference then loads the downloaded weights; there is no network
+    here, so the caller loads a state_dict)."""
     try:
         from torchvision import models
     except ImportError as e:
-        raise ImportError("CNN_ENCODER needs an Inception-v3 trunk: torchvision is not installed here; pass "
-                          "`trunk=` (images -> (features [B,768,17,17], pooled [B,2048]))") from e
-
-    class _Trunk(nn.Module):
-        """util.py:278-362: bilinear resize to 299, the Inception-v3 stem/Mixed blocks, features after Mixed_6e,
-        8x8 average pool after Mixed_7c.  Frozen (util.py:274-275)."""
-
-        def __init__(self):
-            super().__init__()
-            self.m = models.inception_v3(weights=None, aux_logits=True, init_weights=False)
-            for p in self.m.parameters():
-                p.requires_grad = False
-
-        def forward(self, x):
-            import torch.nn.functional as F
-            m = self.m
-            x = F.interpolate(x, size=(299, 299), mode='bilinear', align_corners=False)
-            x = m.Conv2d_2b_3x3(m.Conv2d_2a_3x3(m.Conv2d_1a_3x3(x)))
-            x = F.max_pool2d(x, kernel_size=3, stride=2)
-            x = m.Conv2d_4a_3x3(m.Conv2d_3b_1x1(x))
-            x = F.max_pool2d(x, kernel_size=3, stride=2)
-            x = m.Mixed_5d(m.Mixed_5c(m.Mixed_5b(x)))
-            x = m.Mixed_6e(m.Mixed_6d(m.Mixed_6c(m.Mixed_6b(m.Mixed_6a(x)))))
-            features = x
-            x = m.Mixed_7c(m.Mixed_7b(m.Mixed_7a(x)))
-            x = F.avg_pool2d(x, kernel_size=8)
-            return features, x.view(x.size(0), -1)
-
-    return _Trunk()
+        raise ImportError("CNN_ENCODER needs an Inception-v3: torchvision is not installed here; pass `inception=` (an "
+                          "object with the blocks Conv2d_1a_3x3 ... Mixed_7c) or `trunk=` (images -> (features "
+                          "[B,768,17,17], pooled [B,2048]))") from e
+    return models.inception_v3(weights=None, aux_logits=True, init_weights=False)
 
 
 class CA_NET(nn.Module):
@@ -448,11 +474,10 @@ class CA_NET(nn.Module):
         self.t_dim = cfg.TEXT.EMBEDDING_DIM
         self.c_dim = cfg.GAN.CONDITION_DIM
         self.fc = nn.Linear(self.t_dim, self.c_dim * 4, bias=True)
+        self.relu = GLU()
 
     def encode(self, text_embedding):
-        x = self.fc(text_embedding)
-        nc = x.size(1) // 2
-        x = x[:, :nc] * torch.sigmoid(x[:, nc:])
+        x = self.relu(self.fc(text_embedding))
         return x[:, :self.c_dim], x[:, self.c_dim:]
 
     def reparametrize(self, mu, logvar):

@@ -1,3 +1,6 @@
+// DIAGNOSTIC COPY of tgsr_amd/csrc/tgsr_lp_conv.hip as of round 2 with the LP_DBG timing-experiment switches and in-kernel
+// clock stamps (tools/lp_conv_experiments.sh, tools/lp_conv_clock.py).  Not part of the product; results of LP_DBG != 0
+// builds are wrong by construction.
 // Reduced-precision fused 3x3 convolution for the inference path (BASELINE.json configs[4]: "MFMA bf16 ... fused conv"):
 // conv3x3 (stride 1, zero pad 1, no bias) [+ nearest x2 in front] + BatchNorm(eval) affine + GLU | + residual, on
 // v_mfma_f32_32x32x16_{bf16,f16} with fp32 accumulation.  Replaces the same reference blocks as tgsr_conv3x3_fwd:
@@ -52,8 +55,27 @@ constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the
   return (CIN == 64 || (COUT / 32) * (TR / 4) * 16 >= 64) ? 2 : 3;
 }
 
-// (timing experiments - parts of this kernel compiled out, in-kernel clock stamps - live in a diagnostic copy of this file:
-// tools/diag/tgsr_lp_conv_dbg.hip, built by tools/lp_conv_experiments.sh; nothing of them is in the shipped kernel)
+#ifndef LP_DBG
+#define LP_DBG 0   // timing experiments only (tools/lp_conv_experiments.sh): bits switch parts of the kernel off
+#endif
+#if LP_DBG & 1024
+// diagnostic build only: shader-clock and 100 MHz wall stamps around the main loop of every workgroup (in-kernel clock =
+// d(s_memtime) / d(s_memrealtime) x 100 MHz, MI355X_MICROARCH.md DVFS item 6); never part of the shipped library
+__device__ unsigned long long g_lp_stamps[10 * 4096];  // [workgroup][4 shader-clock stamps, 4 wall stamps, HW_ID, XCC_ID]
+#define LP_STAMP(k)                                                                      \
+  do {                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {                                         \
+      g_lp_stamps[blockIdx.x * 10 + (k)] = __builtin_amdgcn_s_memtime();                 \
+      g_lp_stamps[blockIdx.x * 10 + 4 + (k)] = __builtin_amdgcn_s_memrealtime();         \
+      if ((k) == 0) {                                                                    \
+        g_lp_stamps[blockIdx.x * 10 + 8] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    \
+        g_lp_stamps[blockIdx.x * 10 + 9] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   \
+      }                                                                                  \
+    }                                                                                    \
+  } while (0)
+#else
+#define LP_STAMP(k) do { } while (0)
+#endif
 template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
 __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
   constexpr int NCB = COUT / 32, RW = TR / 4, TC = 34, NPIX = (TR + 2) * TC;
@@ -81,12 +103,17 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 
   const int tid = threadIdx.x, lane = tid & 63, c0 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  LP_STAMP(0);
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
   const int y0 = ty * TR, x0 = tx * 32;                         // output origin (unpadded coordinates)
+  if (LP_DBG & (128 | 256 | 512)) {   // timing experiment: half of the workgroups start ~3 us late (which half: 3 guesses
+    const int sel = (LP_DBG & 128) ? (blockIdx.x >> 3) & 1 : (LP_DBG & 256) ? (blockIdx.x >> 8) & 1 : blockIdx.x & 1;
+    if (sel) { __builtin_amdgcn_s_sleep(100); }                 // at how two co-residents of a CU are numbered)
+  }
 
   // ---- input tile: all lanes of the 4 waves copy 16-byte slots; slot S of the tile = pixel S / NSL, physical slot
   // S % NSL holding the pixel's logical slot (S % NSL) ^ swz(column)
@@ -97,7 +124,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 #pragma unroll
     for (int k = 0; k < (TILE_INSTR + 3) / 4; ++k) {
       const int ins = wave + 4 * k;
-      if (ins < TILE_INSTR) {                                   // wave-uniform
+      if (ins < TILE_INSTR && (!(LP_DBG & 16) || k == 0)) {     // wave-uniform
         const int S = ins * 64 + lane;
         int pix = S / NSL;
         const int ps = S % NSL;
@@ -135,6 +162,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   for (int dx = 0; dx < 3; ++dx)
     bbase[dx] = ((wave * RW) * TC + c0 + dx) * PB + ((h ^ lp_swz<CIN>(c0 + dx)) << 4);
 
+  LP_STAMP(1);
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     // my pieces of chunk ch (and, first time, of the input tile) have landed - the DMAs of chunk ch+1 may still be in
@@ -143,7 +171,7 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
     if (ch + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAVE_INSTR) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (ch + 2 < NCH) issue_w(ch + 2, (ch + 2) % NBUF);
+    if (ch + 2 < NCH && !(LP_DBG & 1)) issue_w(ch + 2, (ch + 2) % NBUF);
     const int dy = ch / NKG, kg = ch % NKG;                      // the pack is [dy][k16][dx][cb]: a chunk is contiguous
 #pragma unroll
     for (int kk = 0; kk < KC16; ++kk) {
@@ -154,18 +182,32 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
         u32x4 af[NCB], bf[RW];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
-          af[cb] = *reinterpret_cast<const u32x4*>(wb + (dx * NCB + cb) * 1024);
+          af[cb] = *reinterpret_cast<const u32x4*>((LP_DBG & 8) ? wbuf + lane * 16 + cb * 1024 : wb + (dx * NCB + cb) * 1024);
 #pragma unroll
         for (int pr = 0; pr < RW; ++pr)
-          bf[pr] = *reinterpret_cast<const u32x4*>(tile + (bbase[dx] ^ (k16 << 5)) + (pr + dy) * TC * PB);
+          bf[pr] = *reinterpret_cast<const u32x4*>((LP_DBG & 4) ? tile + bbase[0] + pr * TC * PB
+                                                                : tile + (bbase[dx] ^ (k16 << 5)) + (pr + dy) * TC * PB);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-          for (int pr = 0; pr < RW; ++pr) acc[cb][pr] = LP<T>::mfma32(af[cb], bf[pr], acc[cb][pr]);
+          for (int pr = 0; pr < RW; ++pr) {
+            if (LP_DBG & 64) {   // timing experiment: the same FLOPs as two 16x16x32 MFMAs (results meaningless)
+              f32x4w lo, hi2;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { lo[q] = acc[cb][pr][q]; hi2[q] = acc[cb][pr][4 + q]; }
+              lo = LP<T>::mfma16(af[cb], bf[pr], lo);
+              hi2 = LP<T>::mfma16(bf[pr], af[cb], hi2);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { acc[cb][pr][q] = lo[q]; acc[cb][pr][4 + q] = hi2[q]; }
+            } else {
+              acc[cb][pr] = LP<T>::mfma32(af[cb], bf[pr], acc[cb][pr]);
+            }
+          }
       }
     }
   }
 
+  LP_STAMP(2);
   // ---- epilogue: affine (+ GLU | + residual) in registers, then through LDS so that HBM sees whole lines.
   // The accumulator layout gives a lane 4 consecutive channels (8 bytes) of one pixel: stored directly that is 16
   // partial writes per 128-byte line (measured: WRITE_SIZE 2x the tensor).  Instead every wave stages its RW x 32
@@ -242,8 +284,9 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   for (int j = 0; j < STG_INSTR; ++j) {
     const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ (pw & (NCHK - 1));
     const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
-    *reinterpret_cast<u32x4*>(ob + (pw >> 5) * orow + (int64_t)(pw & 31) * (a.ocp * 2) + q * 16) = v;
+    if (!(LP_DBG & 2) || j == 0) *reinterpret_cast<u32x4*>(ob + (pw >> 5) * orow + (int64_t)(pw & 31) * (a.ocp * 2) + q * 16) = v;
   }
+  LP_STAMP(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -537,6 +580,12 @@ static int launch_lp_conv(const LpConvArgs& a, int Cin, int Cout, int epi, bool 
 }  // namespace tgsr
 
 using namespace tgsr;
+
+#if LP_DBG & 1024
+extern "C" int tgsr_debug_read_lp_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(tgsr::g_lp_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int64_t tgsr_lp_packed_conv3x3_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 9; }
 

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Timing decomposition of lp_conv3x3_kernel: builds variants of the library with parts of the kernel switched off
+# Timing decomposition of lp_conv3x3_kernel: builds variants of the library from the DIAGNOSTIC copy of the kernel source
+# (tools/diag/tgsr_lp_conv_dbg.hip; the shipped tgsr_amd/csrc/tgsr_lp_conv.hip carries none of this) with parts switched off
 # (-DLP_DBG bits: 1 no weight LDS-DMA after the prologue, 2 no output stores, 4 no B-fragment ds_reads, 8 no A-fragment
 # ds_reads, 16 no tile LDS-DMA, 64 the same FLOPs as 16x16x32 MFMAs, 128 | 256 | 512 a 3 us head start for half of
 # the workgroups) and, on a GPU box, times the generator's layer shapes with each.  Results are WRONG by
@@ -13,7 +14,7 @@ if [ "$1" = build ]; then
   mkdir -p tgsr_amd/lib/dbg
   for v in $VARIANTS; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DLP_DBG=$v \
-      -c tgsr_amd/csrc/tgsr_lp_conv.hip -o tgsr_amd/lib/dbg/lp_conv_$v.o &
+      -Itgsr_amd/csrc -c tools/diag/tgsr_lp_conv_dbg.hip -o tgsr_amd/lib/dbg/lp_conv_$v.o &
   done
   wait
   for v in $VARIANTS; do
