@@ -463,6 +463,22 @@ def generator_adv_loss(sds: Sequence[SD], fakes: Sequence[Tensor], sent_emb: Ten
     return total
 
 
+def generator_loss(sds: Sequence[SD], image_encoder, fakes: Sequence[Tensor], real_labels: Tensor, words_embs: Tensor,
+                   sent_emb: Tensor, match_labels: Tensor, cap_lens, class_ids, gamma1: float, gamma2: float,
+                   gamma3: float, lam: float, w: float = 1.0, s: float = 1.0, g: float = 1.0,
+                   training: bool = True) -> Tensor:
+    """losses.py:351-391 in full: the per-scale adversarial terms plus, on the LAST scale's image, the DAMSM ranking
+    term w (w_loss0 + w_loss1) LAMBDA + s (s_loss0 + s_loss1) LAMBDA through `image_encoder` (image -> (region features
+    [B,nef,17,17], cnn_code [B,nef])).  Pinned by tests/golden/gan_losses.npz (the reference's own function, run on
+    plain-torch discriminators)."""
+    total = generator_adv_loss(sds, fakes, sent_emb, real_labels, training, g)
+    B = real_labels.shape[0]
+    regions, code = image_encoder(fakes[len(sds) - 1])
+    w0, w1, _ = words_loss(regions, words_embs, match_labels, cap_lens, class_ids, B, gamma1, gamma2, gamma3)
+    s0, s1 = sent_loss(code, sent_emb, match_labels, class_ids, B, gamma3)
+    return total + w * (w0 + w1) * lam + s * (s0 + s1) * lam
+
+
 # --------------------------------------------------------------------------------------- synthetic workload
 def synthetic_batch(B: int, n_words: int = 41, seed: int = 100, lr: int = 32, width: int = 18,
                     fixed_len: Optional[int] = None):

@@ -347,3 +347,62 @@ def test_grouped_batchnorm_statistics_equal_separate_passes(kind, Cin, Cout, H, 
     close(blk[0].weight.grad, ref[0].weight.grad, atol=2e-5 * float(ref[0].weight.grad.abs().max()), rtol=1e-4)
     close(blk[1].weight.grad, ref[1].weight.grad, atol=1e-5, rtol=1e-5)
     close(blk[1].bias.grad, ref[1].bias.grad, atol=1e-5, rtol=1e-5)
+
+
+def test_gan_losses_vs_reference_run_fixture():
+    """The PRODUCT's discriminator_loss / generator_loss (HIP D_NET64 / D_NET128, HIP image-encoder heads, DAMSM kernels)
+    against tests/golden/gan_losses.npz = the reference's own loss functions (losses.py:290-316, 351-391) run on plain-torch
+    discriminators with the same parameters: values, discriminator parameter gradients, gradients reaching the fake images."""
+    from conftest import load_npz, split_sd
+    from tgsr_amd import model
+    from tgsr_amd.miscc import losses
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    g = load_npz("gan_losses.npz")
+    cfg_reset()
+    cfg.GAN.DF_DIM, cfg.TEXT.EMBEDDING_DIM = int(g["ndf"]), int(g["nef"])
+    sm = cfg.TRAIN.SMOOTH
+    sm.GAMMA1, sm.GAMMA2, sm.GAMMA3 = (float(v) for v in g["gamma"])
+    sm.LAMBDA = float(g["lambda"])
+    try:
+        T = lambda k: torch.from_numpy(np.asarray(g[k])).to(DEV)
+        img = lambda k: T(k).float() / 127.5 - 1.0
+        B = g["sent"].shape[0]
+        ds = [model.D_NET64(), model.D_NET128()]
+        for k, d in enumerate(ds):
+            d.load_state_dict(split_sd(g, "D%d." % k), strict=True)
+            d.to(DEV).train()
+        sent, words = T("sent"), T("words")
+        rl, fl, ml = torch.ones(B, device=DEV), torch.zeros(B, device=DEV), torch.arange(B, device=DEV)
+        for k, d in enumerate(ds):
+            err = losses.discriminator_loss(d, img("real%d.u8" % k), img("fake%d.u8" % k), sent, rl, fl)
+            err.backward()
+            assert abs(float(err) - float(g["errD%d" % k])) < 2e-5, (k, float(err), float(g["errD%d" % k]))
+            for n, p in d.named_parameters():
+                ref = g["gD%d.%s" % (k, n)]
+                scale = float(np.abs(ref).max()) + 1e-9
+                assert float((p.grad.cpu() - torch.from_numpy(ref)).abs().max()) / scale < 2e-3, (k, n)
+            d.zero_grad()
+
+        class Enc(torch.nn.Module):                   # the fixture's stub image encoder, on the GPU
+            def forward(self, x):
+                return (F.conv2d(F.adaptive_avg_pool2d(x, 17), T("enc.f.weight"), T("enc.f.bias")),
+                        F.linear(x.mean((2, 3)), T("enc.p.weight"), T("enc.p.bias")))
+
+        fakes = [img("fake%d.u8" % k).requires_grad_(True) for k in range(2)]
+        errG, log = losses.generator_loss(ds, Enc(), fakes, rl, words, sent, ml, g["cap_lens"].tolist(), g["class_ids"])
+        errG.backward()
+        assert abs(float(errG) - float(g["errG"])) < 1e-4 * abs(float(g["errG"]))
+        import re                                     # the reference's log string: same text, numbers to 4 decimals
+        num = r"-?\d+\.\d{5}"
+        ref_log = str(g["logs"])
+        assert isinstance(log, str) and re.sub(num, "#", log) == re.sub(num, "#", ref_log), (log, ref_log)
+        for a_, b_ in zip(re.findall(num, log), re.findall(num, ref_log)):
+            assert abs(float(a_) - float(b_)) < 2e-4 * max(1.0, abs(float(b_))), (log, ref_log)
+        for a, ref in ((fakes[0].grad, g["gG.fake0"]), (fakes[1].grad[:, :, ::4, ::4], g["gG.fake1.sub4"])):
+            scale = float(np.abs(ref).max())
+            assert float((a.cpu() - torch.from_numpy(ref)).abs().max()) / scale < 2e-3
+        err2, _ = losses.generator_loss(ds, Enc(), [f.detach() for f in fakes], rl, words, sent, ml, g["cap_lens"].tolist(),
+                                        None, w=0.5, s=2.0, g=3.0)
+        assert abs(float(err2) - float(g["errG.nocls.w05.s2.g3"])) < 1e-4 * abs(float(g["errG.nocls.w05.s2.g3"]))
+    finally:
+        cfg_reset()

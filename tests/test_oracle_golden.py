@@ -177,3 +177,54 @@ def test_x16_generator_weight_tied_stages():
         close(imgs[i], g["fake%d" % i], atol=5e-5)
         close(atts[i], g["att%d" % i], atol=1e-5)
     assert int(g["gh16_runs"]) == 0   # the shipped x16 NetG_highweight.forward raises (models16.py:178)
+
+
+def test_gan_loss_formulas_golden():
+    """oracle.discriminator_loss / generator_loss against the REFERENCE's own functions (losses.py:290-316, 351-391) run by
+    tests/golden/make_golden.py::gen_gan on plain-torch discriminators of the build-declared topology: loss values, every
+    discriminator parameter gradient, and the gradients reaching the fake images / sentence / word embeddings (the DAMSM
+    ranking term with a class mask rides along through a stub image encoder)."""
+    import torch.nn.functional as F
+    from conftest import load_npz
+    g = load_npz("gan_losses.npz")
+    B = g["sent"].shape[0]
+    img = lambda k: T(g[k]).float() / 127.5 - 1.0
+    real = [img("real0.u8"), img("real1.u8")]
+    sent, words = T(g["sent"]), T(g["words"])
+    lens, cls = g["cap_lens"].tolist(), g["class_ids"]
+    rl, fl, ml = torch.ones(B), torch.zeros(B), torch.arange(B)
+    g1, g2, g3 = (float(v) for v in g["gamma"])
+    sds = []
+    for k in range(2):
+        sd = split_sd(g, "D%d." % k)
+        sds.append({n: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in n else v)
+                    for n, v in sd.items()})
+    # ---- discriminator_loss: value + every parameter gradient
+    for k in range(2):
+        fake = img("fake%d.u8" % k)
+        err = O.discriminator_loss(sds[k], real[k], fake, sent, rl, fl)
+        close(err, g["errD%d" % k], atol=2e-6)
+        names = [n for n, v in sds[k].items() if v.requires_grad]
+        grads = torch.autograd.grad(err, [sds[k][n] for n in names])
+        assert len(names) == sum(1 for n in g if n.startswith("gD%d." % k))
+        for n, gr in zip(names, grads):
+            close(gr, g["gD%d.%s" % (k, n)], atol=2e-6, rtol=1e-4)
+    cond_only = {n: v for n, v in sds[0].items() if not n.startswith("UNCOND_DNET.")}
+    close(O.discriminator_loss(cond_only, real[0], img("fake0.u8"), sent, rl, fl), g["errD0.cond_only"], atol=2e-6)
+    # ---- generator_loss (adversarial + ranking term) and what it sends back
+    fakes = [img("fake%d.u8" % k).requires_grad_(True) for k in range(2)]
+    sent_r, words_r = sent.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    ew, eb, pw, pb = (T(g["enc." + n]) for n in ("f.weight", "f.bias", "p.weight", "p.bias"))
+    enc = lambda x: (F.conv2d(F.adaptive_avg_pool2d(x, 17), ew, eb), F.linear(x.mean((2, 3)), pw, pb))
+    sd_eval = [{n: v.detach() for n, v in sd.items()} for sd in sds]
+    errG = O.generator_loss(sd_eval, enc, fakes, rl, words_r, sent_r, ml, lens, cls, g1, g2, g3, float(g["lambda"]))
+    close(errG, g["errG"], atol=2e-5, rtol=1e-5)
+    gr = torch.autograd.grad(errG, fakes + [sent_r, words_r])
+    close(gr[0], g["gG.fake0"], atol=1e-7, rtol=1e-3)
+    close(gr[1][:, :, ::4, ::4], g["gG.fake1.sub4"], atol=1e-7, rtol=1e-3)
+    close(gr[2], g["gG.sent"], atol=2e-6, rtol=1e-4)
+    close(gr[3], g["gG.words"], atol=2e-6, rtol=1e-4)
+    err2 = O.generator_loss(sd_eval, enc, [f.detach() for f in fakes], rl, words, sent, ml, lens, None, g1, g2, g3,
+                            float(g["lambda"]), w=0.5, s=2.0, g=3.0)
+    close(err2, g["errG.nocls.w05.s2.g3"], atol=2e-5, rtol=1e-5)
+    assert str(g["logs"]).startswith("g_loss0: ")
