@@ -38,7 +38,11 @@ PEAK_HBM_GBS = 8000.0
 # share of the direct-form multiplies a kernel actually issues (Winograd F(2x2,3x3): 16/36; sub-pixel upBlock: 4/9;
 # up-sample-aware Winograd: 9 of the 16 positions of a 2x2 output tile = 9/36)
 EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "upconv_glu_mfma_kernel": 4.0 / 9.0,
-                         "upwino_glu_kernel": 9.0 / 36.0, "lp_conv3x3_kernel": 1.0, "lp_upconv_glu_kernel": 4.0 / 9.0}
+                         "upwino_glu_kernel": 9.0 / 36.0, "lp_conv3x3_kernel": 1.0, "lp_upconv_glu_kernel": 4.0 / 9.0,
+                         # training: weight gradients in the Winograd domain (16 | 9 positions per 2x2 outputs), the direct
+                         # 9-tap form, the image heads and the discriminators' implicit GEMM (every MAC issued)
+                         "wino_wgrad_kernel": 16.0 / 36.0, "upwino_wgrad_kernel": 9.0 / 36.0, "conv3x3_wgrad_kernel": 1.0,
+                         "dconv_igemm_kernel": 1.0}
 # bench name of a kernel -> prefix of its name in the rocprofv3 tables under profiles/
 PMC_NAME = {"upwino_glu_kernel": "upwino_kernel"}
 
@@ -365,6 +369,257 @@ def roofline_objects(agg, nprof, dtype, serial, steps, batch=16):
     return roof, kern, att
 
 
+# ------------------------------------------------------------------------------------------------ driver-timed extras
+def _all_ok(ok, dist, dev):
+    """Every rank agrees whether a section's set-up worked (a rank that failed must not leave the others in a barrier)."""
+    if dist is None:
+        return ok
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def _max_over_ranks(dt, dist, dev):
+    if dist is None:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _psnr(a, b, peak=2.0):
+    """10 log10(peak^2 / mse) of two device tensors (peak = the [-1, 1] image range, as oracle.tgsr_oracle_lp.psnr)."""
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return float("inf") if mse == 0 else 10.0 * float(np.log10(peak * peak / mse))
+
+
+def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
+    """BASELINE configs[4] inside the default run: the reduced-precision path replayed from a hipGraph, timed in this
+    process right after the fp32 region with the same K / W and the same fencing (barrier + synchronize, max over ranks).
+    One entry per (storage type, per-GPU batch): bf16 and f16 at batch 16, bf16 at batch 8 (configs[4]'s per-GPU batch:
+    64 over 8 GPUs) and at the saturating batch of 128; with N > 1 only the configs[4] entry.  Each entry carries the
+    whole-step HBM fraction on SURVEY 8d's compulsory bytes, the conv kernel's HBM (counter bytes) and executed-MFMA
+    fractions from HIP events around every launch of one eager step, and the PSNR of the finest image against the fp32
+    path of THIS run on the same inputs."""
+    from tgsr_amd import ops
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.trainer import SRPipeline
+    plan = [("bf16", 16), ("f16", 16), ("bf16", 8), ("bf16", 128)] if world == 1 else [("bf16", 8)]
+    out = {"launch": "hipgraph", "steps": args.steps, "warmup": args.warmup,
+           "psnr_reference": "fp32 path of this run, same inputs and weights (finest 256^2 image, peak 2.0); the 2-byte "
+                             "kernels themselves are checked against a CPU model of the same rounding points "
+                             "(oracle/tgsr_oracle_lp.py, derived from the pinned fp32 oracle) in tests/test_hip_lp.py",
+           "runs": []}
+    for dtype, B in plan:
+        entry = {"dtype": dtype, "batch_per_gpu": B}
+        pipe = None
+        try:
+            pipe = SRPipeline(41, device=dev, low="lr", overlap=True, dtype=dtype)
+            if weights is not None:
+                pipe.load_state_dicts(weights["E."], weights["GL."], weights["GH."])
+            else:
+                pipe.netGL.load_state_dict(fp32_pipe.netGL.state_dict())
+                pipe.netGH.load_state_dict(fp32_pipe.netGH.state_dict())
+                pipe.text_encoder.load_state_dict(fp32_pipe.text_encoder.state_dict())
+            cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
+            cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
+            ref = fp32_pipe(cap, lens, LR, LRb)["fine"][2]
+            got = pipe(cap, lens, LR, LRb)["fine"][2]
+            torch.cuda.synchronize()
+            entry["psnr_vs_fp32_dB"] = round(_psnr(got, ref), 2)
+            del ref, got
+            pipe.capture(cap, lens, LR, LRb)
+            for _ in range(args.warmup):
+                pipe.replay(cap, LR, LRb)
+            ok = True
+        except Exception as e:          # noqa: BLE001 - a failed extra must not take the headline line down
+            entry["error"] = "%s: %s" % (type(e).__name__, e)
+            ok = False
+        if not _all_ok(ok, dist, dev):
+            entry.setdefault("error", "set-up failed on another rank")
+            out["runs"].append(entry)
+            continue
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.replay(cap, LR, LRb)
+        fence()
+        dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
+        ips = world * B * args.steps / dt
+        mb_img = 173.9 / 2
+        entry.update({"value": round(ips, 2), "unit": "images/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
+                      "step_roofline": {"compulsory_MB_per_image": mb_img,
+                                        "hbm_frac": round(ips / world * mb_img * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
+                                        "algorithmic_TFLOPs": round(ips / world * 21.07e9 / 1e12, 1)}})
+        if rank == 0:
+            try:                         # one eager single-stream step with HIP events around every launch
+                prof = []
+                pipe.overlap = False
+                ops.profile = prof
+                pipe(cap, lens, LR, LRb)
+                ops.profile = None
+                torch.cuda.synchronize()
+                agg = {}
+                for name, flops, nbytes, e0, e1 in prof:
+                    a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+                    a[0] += 1
+                    a[1] += flops
+                    a[2] += nbytes
+                    a[3] += e0.elapsed_time(e1) * 1e-3
+                roof, _kern, att = roofline_objects(agg, 1, dtype, True, 1, B)
+                entry["conv_kernel"] = {k: roof[k] for k in ("kernel", "bound", "frac", "achieved", "unit", "bytes_from", "mfma_frac",
+                                                             "hbm_frac_algorithmic", "hbm_frac_counter", "avg_launch_us",
+                                                             "launches_per_step", "counters_from") if k in roof}
+                entry["conv_path"] = roof["conv_path"]
+                if att is not None:
+                    entry["attention"] = att
+            except Exception as e:      # noqa: BLE001
+                entry["conv_kernel"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                ops.profile = None
+        out["runs"].append(entry)
+        del pipe
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline_gan(weights, batch, budget_s=30.0):
+    """One G/D alternation on the CPU (oracle generators + the oracle's torch restatement of the build-declared
+    discriminators, DF_DIM 64, torch autograd): the three discriminator losses backward, then the generator loss
+    (adversarial + MSE + KL) backward - the arithmetic of SRTrainer.step_gan without the optimizer steps."""
+    from oracle import tgsr_oracle as O
+    from tgsr_amd import model
+    torch.set_num_threads(usable_cores())
+    sdE, sdL, sdH = O.random_state(seed=0) if weights is None else (weights["E."], weights["GL."], weights["GH."])
+    req = lambda sd: {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)   # noqa: E731
+                      for k, v in sd.items()}
+    sdL, sdH = req(sdL), req({k: v for k, v in sdH.items() if k != "a"})
+    torch.manual_seed(0)
+    sdD = [req({k: v.detach().clone() for k, v in d.state_dict().items()})
+           for d in (model.D_NET64(), model.D_NET128(), model.D_NET256())]
+    cap, lens, LR, LRb = O.synthetic_batch(batch)
+    g = torch.Generator().manual_seed(7)
+    hr = [torch.rand(batch, 3, s, s, generator=g) * 2 - 1 for s in (64, 128, 256)]
+    with torch.no_grad():
+        words, sent = O.rnn_encoder(sdE, cap, lens.tolist())
+    mask = (cap == 0)[:, :words.shape[2]]
+    rl, fl = torch.ones(batch), torch.zeros(batch)
+
+    def one():
+        imgs, _att, mu, logvar = O.g_sr_net_low(sdL, LR, sent, words, mask, training=True)
+        fine, _a, _one = O.netg_highweight(sdH, LR, imgs, LRb, "lr", training=True)
+        for i, sd in enumerate(sdD):
+            O.discriminator_loss(sd, hr[i], fine[i].detach(), sent, rl, fl).backward()
+        (O.generator_adv_loss(sdD, fine, sent, rl) + O.mse(imgs, hr) + O.mse(fine, hr) + O.kl_loss(mu, logvar)).backward()
+
+    ts, t_all = [], time.perf_counter()
+    while len(ts) < 3 and (not ts or (time.perf_counter() - t_all) < budget_s):
+        t0 = time.perf_counter()
+        one()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle generators (train-mode BN) + the torch restatement of D_NET64/128/256 (DF_DIM 64): three "
+                      "discriminator_loss backward passes, then generator_loss + MSE + KL backward, torch autograd (fp32), "
+                      "batch %d, median of %d runs, %.2f s/step (no warm-up run: the first step is in the sample)"
+                      % (batch, len(ts), med)}
+
+
+def train_object(args, rank, world, dist, dev, weights, fence):
+    """BASELINE configs[2] inside the default run: the generator train step (fwd + bwd + Adam + EMA on MSE + KL) and the
+    G/D alternation (three discriminators), each timed with the same fencing as the headline and priced by the MACs its
+    convolution kernels actually EXECUTE (per-launch direct-form FLOPs x the kernel's executed fraction - Winograd's
+    saving is not credited), over the whole step time against the fp32 MFMA peak."""
+    from tgsr_amd import ops
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.train import SRTrainer
+    from tgsr_amd.miscc.config import cfg
+    B = args.batch
+    out = {"batch_per_gpu": B, "runs": []}
+    for gan in (False, True):
+        steps = max(2, min(args.steps, 6 if gan else 10))
+        entry = {"workload": ("G/D alternation: 3 discriminator updates on (real, fake.detach()), then the generator update "
+                              "through them + MSE + KL (losses.py:290-374; D_NET64/128/256 build-declared, DF_DIM %d)"
+                              % cfg.GAN.DF_DIM) if gan else
+                 "generator train step: G_SR_NET_low + NetG_highweight fwd + bwd (train-mode BN), MSE + KL, Adam, EMA",
+                 "steps": steps, "warmup": 2}
+        tr = None
+        try:
+            tr = SRTrainer(41, device=dev, discriminators=gan)
+            if weights is not None:
+                tr.text_encoder.load_state_dict(weights["E."])
+                tr.netGL.load_state_dict(weights["GL."])
+                tr.netGH.load_state_dict({k: v for k, v in weights["GH."].items() if k != "a"})
+            cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
+            g = torch.Generator().manual_seed(7 + rank)
+            hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(dev) for s in (64, 128, 256)]
+            cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
+            for _ in range(2):
+                tr.step(cap, lens, LR, LRb, hr)
+            ok = True
+        except Exception as e:          # noqa: BLE001
+            entry["error"] = "%s: %s" % (type(e).__name__, e)
+            ok = False
+        if not _all_ok(ok, dist, dev):
+            entry.setdefault("error", "set-up failed on another rank")
+            out["runs"].append(entry)
+            continue
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.step(cap, lens, LR, LRb, hr)
+        fence()
+        dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
+        sec = dt / steps
+        entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4),
+                      "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
+        if rank == 0:
+            try:                         # one more step with HIP events around every convolution launch (single stream)
+                prof = []
+                wside, dstreams = tr._wside, tr._dstreams
+                tr._wside, tr._dstreams = None, []
+                ops.profile = prof
+                tr.step(cap, lens, LR, LRb, hr)
+                ops.profile = None
+                tr._wside, tr._dstreams = wside, dstreams
+                torch.cuda.synchronize()
+                agg = {}
+                for name, flops, _nb, e0, e1 in prof:
+                    a = agg.setdefault(name, [0, 0.0, 0.0])
+                    a[0] += 1
+                    a[1] += flops
+                    a[2] += e0.elapsed_time(e1) * 1e-3
+                conv = {k: v for k, v in agg.items() if k in EXECUTED_MAC_FRACTION}
+                alg = sum(v[1] for v in conv.values())
+                exe = sum(v[1] * EXECUTED_MAC_FRACTION[k] for k, v in conv.items())
+                ksec = sum(v[2] for v in conv.values())
+                entry["roofline"] = {
+                    "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "achieved": round(exe / sec / 1e12, 2), "frac": round(exe / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "achieved_algorithmic_TFLOPs": round(alg / sec / 1e12, 2),
+                    "conv_kernels_only": {"ms_per_step": round(ksec * 1e3, 3),
+                                          "executed_TFLOPs": round(exe / ksec / 1e12, 2),
+                                          "frac": round(exe / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                    "kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "executed_fraction": round(EXECUTED_MAC_FRACTION[k], 4),
+                                    "executed_TFLOPs": round(v[1] * EXECUTED_MAC_FRACTION[k] / v[2] / 1e12, 2)}
+                                for k, v in sorted(conv.items(), key=lambda kv: -kv[1][2])},
+                    "traffic": None,
+                    "note": "`achieved` / `frac`: MACs the convolution kernels of forward, data gradient and weight gradient "
+                            "really issue (direct-form FLOPs of every launch x the kernel's executed fraction), over the "
+                            "WHOLE step time (BatchNorm passes, losses, optimizer, EMA included); `conv_kernels_only`: the "
+                            "same MACs over the summed durations of those launches (HIP events, one single-stream step)"}
+                if world == 1 and not args.no_cpu_baseline:
+                    entry["cpu_baseline"] = (cpu_baseline_gan(weights, 2) if gan else cpu_baseline_train(weights, min(B, 4)))
+            except Exception as e:      # noqa: BLE001
+                entry["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                ops.profile = None
+        out["runs"].append(entry)
+        del tr
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -390,6 +645,10 @@ def main():
                          "that many steps; --steps must be a multiple)")
     ap.add_argument("--lanes", type=int, default=3,
                     help="inference: consecutive steps alternate between this many stream lanes (1 = one step at a time)")
+    ap.add_argument("--extras", default="lp,train",
+                    help="default run (fp32 inference, eager): also time, in this process after the headline region, the "
+                         "reduced-precision hipGraph configurations (`lp` object: BASELINE configs[4]) and the train steps "
+                         "(`train` object: configs[2]); '' or 'none' = headline only")
     ap.add_argument("--profile-every", type=int, default=20,
                     help="bracket every launch of every Nth timed step with HIP events for the roofline (0 = never); "
                          "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
@@ -527,6 +786,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, dt1 = float(t[0].item()), float(t[1].item())
 
+    extras = {}
+    want = [e for e in args.extras.replace("none", "").split(",") if e]
+    if want and args.dtype == "fp32" and not args.graph and not args.serial:
+        # driver-visible measurements of the other BASELINE configurations, same process, after the headline region
+        pipe.overlap = True
+        if "lp" in want:
+            extras["lp"] = lp_object(args, rank, world, dist, dev, weights, pipe, fence)
+        if "train" in want:
+            del lanes
+            pipe._side = None
+            torch.cuda.empty_cache()
+            extras["train"] = train_object(args, rank, world, dist, dev, weights, fence)
     if rank == 0:
         # per-kernel totals from the HIP events recorded around every launch of the sampled steps
         agg = {}
@@ -574,6 +845,7 @@ def main():
             res["attention"] = att
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(weights, B)
+        res.update(extras)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -469,6 +469,30 @@ int tgsr_lp_upconv_glu_fwd(int dtype, const void* x, int x_cpitch, int B, int Ci
                            void* stream);
 
 /*
+ * upBlock WITH the image head that reads its output, in one launch (the feature image of the last stage - consumed by
+ * nothing but its head: GET_IMAGE_G_noAct util.py:909-919 behind G_SR_NET_low.h_net3, conv_output model.py:224 behind
+ * NetG_highweight.upscale8x - then never goes to HBM).  Arguments of tgsr_lp_upconv_glu_fwd, plus:
+ *   out           may be NULL: the 32-channel feature image is not written;
+ *   head_wpack    tgsr_lp_pack_to3_weight of the head's [3][32][K][K] filter, head_k = K in {3, 5};
+ *   head_partial  tgsr_lp_head_partial_elems(B, 2H, 2W, K) floats: a workgroup tile (8 x 64 outputs) holds only its own
+ *                 pixels, so it writes the PARTIAL head sums of the (8 + 2P) x (64 + 2P) outputs they reach, layout
+ *                 [B][2H/8][2W/64][3][8 + 2P][64 + 2P], P = K/2.
+ * tgsr_lp_head_combine adds the <= 4 partials of every pixel in a fixed order (tile rows, then columns: reproducible, no
+ * float atomics) for up to 4 scales in ONE launch and finishes both generators' heads:
+ *   low[s]  = sum of partial_low[s] (3x3 heads)  [tanh when low_tanh: GET_IMAGE_G of models16, util.py:894-905]
+ *   high[s] = tanh(sum of partial_high[s] (5x5 heads)) + alpha * low[s]        (model.py:280, 288, 297)
+ * H[s], W[s] = image size of scale s (multiples of 8 / 64); partial_low[s] == NULL: low[s] is an input (already
+ * computed); partial_high[s] == NULL: high[s] is not produced.  low / high fp32 [B][3][H][W] dense.
+ */
+int64_t tgsr_lp_head_partial_elems(int B, int H, int W, int K);
+int tgsr_lp_upconv_glu_head_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                                int Cout, const float* scale, const float* shift, void* out, int out_cpitch, int out_coff,
+                                const void* head_wpack, int head_k, float* head_partial, void* stream);
+int tgsr_lp_head_combine(int nscales, int B, const int* H, const int* W, const float* const* partial_low,
+                         const float* const* partial_high, float* const* low, float* const* high, int low_tanh,
+                         float alpha, void* stream);
+
+/*
  * The two 3-channel stems on the fp32 LR image: conv3x3 3 -> 2C + BatchNorm(eval) affine + GLU, written as C channels
  * of an lp image (im2f util.py:741-744, convin model.py:228).  x [B][3][H][W] fp32 dense, w [2C][3][3][3] fp32 (torch
  * layout, NOT rounded: 27 MACs per output run on the VALU), scale / shift [2C].  C % 8 == 0.

@@ -163,6 +163,63 @@ def netg_highweight(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr"):
     return [ims2, ims4, head(out, SRb[2])]
 
 
+def g_sr_net_low16(sd, LR, sent_emb, words, mask, dtype, correct_mask=False):
+    """oracle.tgsr_oracle.g_sr_net_low16 (models16.py:5-39) with the lp path's rounding points: stages 2-4 through the
+    ONE `h_net2` module, four tanh heads through the ONE `img_net1` filter."""
+    mu, logvar = O.ca_net(sd, sent_emb, "ca_net.")
+    w_img = rnd(sd["img_net1.img.0.weight"], dtype)
+    imgs, atts = [], []
+    h = _stem(LR, sd, "h_net1.im2f.", dtype)
+    for k in range(4):
+        h, a = _stage(sd, "h_net1." if k == 0 else "h_net2.", h, words, mask, dtype, correct_mask)
+        imgs.append(torch.tanh(F.conv2d(h, w_img, None, 1, 1)))
+        atts.append(a)
+    return imgs, atts, mu, logvar
+
+
+def netg_highweight16(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr"):
+    """oracle.tgsr_oracle.netg_highweight16 (models16.py:97-179) with the lp path's rounding points."""
+    x = LRb if low == "lrblur" else (LR - LRb if low == "lr-lrblur" else LR)
+    out = _stem(x, sd, "convin.", dtype)
+    r = 0
+    while ("residual.%d.block.0.weight" % r) in sd:
+        out = _res_block(out, sd, "residual.%d." % r, dtype)
+        r += 1
+    w5, a = rnd(sd["conv_output.0.weight"], dtype), sd["a"]
+
+    def head(o, sr):
+        return torch.tanh(F.conv2d(o, w5, None, 1, 2)) + a * sr
+
+    def nosum(x, p):
+        s0, t0 = _fold(sd, p + "1.")
+        s1, t1 = _fold(sd, p + "4.")
+        y = conv_block(x, sd[p + "0.weight"], s0, t0, dtype, glu=True)
+        return conv_block(y, sd[p + "3.weight"], s1, t1, dtype)
+
+    out = _up_block(out, sd, "upscale2x.", dtype)
+    ims = [head(out, SRb[0])]
+    out = _up_block(nosum(out, "residual24."), sd, "upscale4x.", dtype)
+    ims.append(head(out, SRb[1]))
+    for k in (2, 3):
+        out = _up_block(nosum(out, "residual48."), sd, "upscale8x.", dtype)
+        ims.append(head(out, SRb[k]))
+    return ims
+
+
+def sr_forward16(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype=None, low="lr", correct_mask=False):
+    """The x16 caller wiring (trainer_objective.py:74-87 with BRANCH_NUM != 4); dtype None = the fp32 oracle."""
+    words, sent = O.rnn_encoder(sd_E, captions, cap_lens)
+    mask = (captions == 0)[:, :words.shape[2]]
+    if dtype is None:
+        imgs, atts, mu, logvar = O.g_sr_net_low16(sd_GL, LR, sent, words, mask, correct_mask=correct_mask)
+        fine = O.netg_highweight16(sd_GH, LR, imgs, LRb, low)[0]
+    else:
+        imgs, atts, mu, logvar = g_sr_net_low16(sd_GL, LR, sent, words, mask, dtype, correct_mask)
+        fine = netg_highweight16(sd_GH, LR, imgs, LRb, dtype, low)
+    return {"words_emb": words, "sent_emb": sent, "mask": mask, "fake": imgs, "att": atts, "mu": mu, "logvar": logvar,
+            "fine": fine}
+
+
 def sr_forward(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype, low="lr", correct_mask=False):
     """`oracle.tgsr_oracle.sr_forward` with the lp path's rounding points."""
     words, sent = O.rnn_encoder(sd_E, captions, cap_lens)

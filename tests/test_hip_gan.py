@@ -271,7 +271,7 @@ def test_full_size_gan_train_step_parity(face_weights):
         w0, w1, _ = O.words_loss(regions, words, labels, lens.tolist(), class_ids, B, sm.GAMMA1, sm.GAMMA2, sm.GAMMA3)
         s0, s1 = O.sent_loss(code, sent, labels, class_ids, B, sm.GAMMA3)
         refR = (w0 + w1) * sm.LAMBDA + (s0 + s1) * sm.LAMBDA
-        assert float(refR) > 1.0                          # a term that matters next to the others (~10)
+        assert float(refR.detach()) > 1.0                          # a term that matters next to the others (~10)
         refR.backward()                                   # accumulates onto the gradients of refG
         # ---- HIP
         for o in tr.optsD:

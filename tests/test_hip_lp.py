@@ -273,3 +273,189 @@ def test_hipgraph_with_parallel_lanes(name, cfg_face, face_weights):
     for k in range(3):
         assert torch.equal(out[k]["fine"][2], eager[2 - k])
     assert pipe.overlap                                          # the capture restored the two-stream setting
+
+
+def _x16_state(seed=5):
+    """Seeded x16 generator parameters with the reference's key names (models16 state_dict: tied tensors listed under every
+    alias, NetG_highweight with its trainable `a`), BatchNorm statistics randomised so eval-mode BN does something."""
+    from tgsr_amd import models16
+    from tgsr_amd.synthetic import random_init_
+    gl, gh = models16.G_SR_NET_low(), models16.NetG_highweight(weightmap=False, low="lr")
+    random_init_(gl, seed), random_init_(gh, seed + 1)
+    g = torch.Generator().manual_seed(seed)
+    for m in list(gl.modules()) + list(gh.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):
+            with torch.no_grad():
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.bias.shape, generator=g))
+    with torch.no_grad():
+        gh.a.fill_(0.4)
+    return ({k: v.detach().clone() for k, v in gl.state_dict().items()},
+            {k: v.detach().clone() for k, v in gh.state_dict().items()})
+
+
+def test_x16_pipeline_fp32_golden_and_full_size(cfg_face):
+    """SRPipeline(branch_num=5) selects the models16 generators exactly as trainer_objective.py:74-87 does.  (1) the
+    reference-captured x16 golden (nets16_small.npz: G_SR_NET_low, LR 8x8 -> 128^2) through the pipeline; (2) full size
+    (LR 32 -> 512^2, Q = 65 536 pixels in the 4th attention) against the fp32 oracle at the stated 1e-4, eager and
+    replayed from a hipGraph (the `.item()` of the trainable `a` stays off the captured path)."""
+    from conftest import load_npz, split_sd
+    from tgsr_amd.miscc.config import cfg
+    from tgsr_amd.trainer import SRPipeline
+    g = load_npz("nets16_small.npz")
+    cfg.TEXT.EMBEDDING_DIM = 64
+    cfg.TREE.BRANCH_NUM = 5
+    pipe = SRPipeline(41, device=DEV)                         # branch_num from cfg.TREE.BRANCH_NUM, like the reference
+    assert type(pipe.netGL).__module__.endswith("models16") and type(pipe.netGH).__module__.endswith("models16")
+    pipe.text_encoder.load_state_dict(split_sd(g, "E."))
+    pipe.netGL.load_state_dict(split_sd(g, "GL."), strict=False)       # tied aliases are stored once in the fixture
+    cap = torch.from_numpy(g["captions"]).to(DEV)
+    LR = torch.from_numpy(g["LR"]).to(DEV)
+    r = pipe(cap, g["cap_lens"].tolist(), LR, LR)
+    assert len(r["fake"]) == 4 and len(r["fine"]) == 4 and tuple(r["fine"][3].shape[-2:]) == (128, 128)
+    for i in range(4):
+        np.testing.assert_allclose(r["fake"][i].cpu().numpy(), g["fake%d" % i], atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(r["att"][i].cpu().numpy(), g["att%d" % i], atol=2e-5, rtol=1e-4)
+    # ---- full size vs the oracle
+    cfg.TEXT.EMBEDDING_DIM = 256
+    sdE, _, _ = O.random_state(seed=2)
+    sdL, sdH = _x16_state()
+    cap, lens, LR, LRb = O.synthetic_batch(2, seed=9)
+    ref = OL.sr_forward16(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
+    pipe = SRPipeline(41, device=DEV, branch_num=5).load_state_dicts(sdE, sdL, sdH)
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    out = pipe(*args)
+    assert tuple(out["fine"][3].shape) == (2, 3, 512, 512) and tuple(out["att"][3].shape[-2:]) == (256, 256)
+    for i in range(4):
+        np.testing.assert_allclose(out["fake"][i].cpu().numpy(), ref["fake"][i].numpy(), atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(out["fine"][i].cpu().numpy(), ref["fine"][i].numpy(), atol=1e-4, rtol=1e-4)
+        np.testing.assert_allclose(out["att"][i].cpu().numpy(), ref["att"][i].numpy(), atol=2e-5, rtol=1e-4)
+    eager = [f.clone() for f in out["fine"]]
+    pipe.capture(*args)
+    rep = pipe.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(rep["fine"], eager):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+def test_x16_lp_pipeline_full_size(name, td, ulp, cfg_face):
+    """The reduced-precision executor over the weight-tied x16 stages (4th attention at 256^2, tanh heads, the 16x stage
+    through residual48 / upscale8x again): within 1 dB of what the CPU model of the same rounding points predicts against
+    fp32, far closer to that model than the model is to fp32, and bit-identical when replayed from a hipGraph."""
+    from tgsr_amd.trainer import SRPipeline
+    sdE, _, _ = O.random_state(seed=2)
+    sdL, sdH = _x16_state()
+    cap, lens, LR, LRb = O.synthetic_batch(2, seed=9)
+    with torch.no_grad():
+        ref32 = OL.sr_forward16(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
+        model = OL.sr_forward16(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb, td)
+    pipe = SRPipeline(41, device=DEV, dtype=name, branch_num=5).load_state_dicts(sdE, sdL, sdH)
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    out = pipe(*args)
+    torch.cuda.synchronize()
+    for k in ("fake", "fine"):
+        for i in range(4):
+            got = out[k][i].cpu()
+            p32, pm, pmodel = OL.psnr(got, ref32[k][i]), OL.psnr(got, model[k][i]), OL.psnr(model[k][i], ref32[k][i])
+            assert abs(p32 - pmodel) < 1.0, "%s %s[%d]: %.2f dB vs fp32, the CPU model predicts %.2f" % (name, k, i, p32, pmodel)
+            assert pm > pmodel + 3.0, "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
+    for i in range(4):
+        assert OL.psnr(out["att"][i].cpu(), model["att"][i], peak=1.0) > 45.0
+    eager = [f.clone() for f in out["fine"]]
+    pipe.capture(*args)
+    rep = pipe.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(rep["fine"], eager):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("B,Cin,Hi,Wi", [(2, 64, 4, 32), (1, 32, 8, 64), (3, 64, 16, 32), (5, 32, 12, 96)])
+def test_lp_upconv_with_fused_heads(B, Cin, Hi, Wi, name, td, ulp):
+    """tgsr_lp_upconv_glu_head_fwd + tgsr_lp_head_combine (the image heads computed inside the producing upBlock, per-tile
+    partial sums, one combine launch for both generators) against the unfused kernels on the same values: the feature
+    image bit for bit, the head images to fp32 summation order - single tiles, several tile rows / columns, with and
+    without writing the feature image, GL's head with and without tanh (x16 / x8), reproducible bit for bit."""
+    import torch.nn.functional as F
+    from tgsr_amd import lp
+    g = torch.Generator().manual_seed(B * 11 + Cin + Wi)
+    x = OL.rnd(torch.randn(B, Cin, Hi, Wi, generator=g), td)
+    w = torch.randn(64, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    scale, shift = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    w3 = torch.randn(3, 32, 3, 3, generator=g) / (3 * 32 ** 0.5)
+    w5 = torch.randn(3, 32, 5, 5, generator=g) / (5 * 32 ** 0.5)
+    xi = lp.from_nchw(x.to(DEV), name, cpitch=Cin)
+    wp = lp.pack_upconv_weight(w.to(DEV), name)
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    p3, p5 = lp.pack_to3_weight(w3.to(DEV), name), lp.pack_to3_weight(w5.to(DEV), name)
+    Ho, Wo = 2 * Hi, 2 * Wi
+    # ---- unfused: the feature image, then the two heads on it (the high one adds alpha * low)
+    h = lp.new_image(B, Ho, Wo, 32, name, DEV)
+    lp.upconv_glu(xi, wp, Cin, 64, sc, sh, out=h)
+    for low_tanh in (False, True):
+        low_ref = lp.conv_to3(h, p3, 3, tanh_axpy=low_tanh)
+        high_ref = lp.conv_to3(h, p5, 5, tanh_axpy=True, addend=low_ref, alpha=0.4)
+        # ---- fused: one launch per "generator" (here both read the same upBlock), feature image written once / never
+        h2, part3 = lp.upconv_glu_head(xi, wp, Cin, 64, sc, sh, p3, 3)
+        none, part5 = lp.upconv_glu_head(xi, wp, Cin, 64, sc, sh, p5, 5, write_out=False)
+        assert none is None and torch.equal(h2, h), "the feature image of the fused launch differs"
+        low = torch.full((B, 3, Ho, Wo), float("nan"), device=DEV)
+        high = torch.full((B, 3, Ho, Wo), float("nan"), device=DEV)
+        lp.head_combine(B, [(Ho, Wo)], [part3], [part5], [low], [high], low_tanh, 0.4)
+        np.testing.assert_allclose(low.cpu().numpy(), low_ref.cpu().numpy(), atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(high.cpu().numpy(), high_ref.cpu().numpy(), atol=2e-5, rtol=1e-5)
+        # an already computed low image as the combine's input (partial_low = None), and against the CPU arithmetic
+        high2 = torch.empty_like(high)
+        lp.head_combine(B, [(Ho, Wo)], [None], [part5], [low], [high2], low_tanh, 0.4)
+        assert torch.equal(high2, high)
+        hc = lp.to_nchw(h, 32, 0).cpu()
+        ref3 = F.conv2d(hc, OL.rnd(w3, td), None, 1, 1)
+        np.testing.assert_allclose(low.cpu().numpy(), (torch.tanh(ref3) if low_tanh else ref3).numpy(), atol=2e-5, rtol=1e-5)
+        # reproducible: same partial sums, same images, bit for bit
+        _, part3b = lp.upconv_glu_head(xi, wp, Cin, 64, sc, sh, p3, 3)
+        lowb, highb = torch.empty_like(low), torch.empty_like(high)
+        lp.head_combine(B, [(Ho, Wo)], [part3b], [part5], [lowb], [highb], low_tanh, 0.4)
+        assert torch.equal(part3b, part3) and torch.equal(lowb, low) and torch.equal(highb, high)
+
+
+def test_lp_head_combine_several_scales_in_one_launch():
+    """Three scales of both generators finished by ONE tgsr_lp_head_combine launch == scale by scale."""
+    from tgsr_amd import lp
+    g = torch.Generator().manual_seed(8)
+    B, name = 2, "bf16"
+    sizes, pl, ph = [], [], []
+    for Hi, Wi in ((4, 32), (8, 64), (16, 128)):
+        x = lp.from_nchw(torch.randn(B, 32, Hi, Wi, generator=g).to(DEV), name, cpitch=32)
+        wp = lp.pack_upconv_weight((torch.randn(64, 32, 3, 3, generator=g) / 17.0).to(DEV), name)
+        p3 = lp.pack_to3_weight((torch.randn(3, 32, 3, 3, generator=g) / 17.0).to(DEV), name)
+        p5 = lp.pack_to3_weight((torch.randn(3, 32, 5, 5, generator=g) / 28.0).to(DEV), name)
+        pl.append(lp.upconv_glu_head(x, wp, 32, 64, None, None, p3, 3, write_out=False)[1])
+        ph.append(lp.upconv_glu_head(x, wp, 32, 64, None, None, p5, 5, write_out=False)[1])
+        sizes.append((2 * Hi, 2 * Wi))
+    mk = lambda: [torch.empty(B, 3, H, W, device=DEV) for H, W in sizes]      # noqa: E731
+    low, high, low1, high1 = mk(), mk(), mk(), mk()
+    lp.head_combine(B, sizes, pl, ph, low, high, False, 0.5)
+    for k in range(3):
+        lp.head_combine(B, [sizes[k]], [pl[k]], [ph[k]], [low1[k]], [high1[k]], False, 0.5)
+        assert torch.equal(low[k], low1[k]) and torch.equal(high[k], high1[k])
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_lp_pipeline_fused_heads_equal_standalone_heads(name, cfg_face, face_weights, monkeypatch):
+    """The whole pipeline with the heads fused into their upBlocks (default) against TGSR_LP_FUSE_HEADS=0 (six stand-alone
+    head launches): same stored activations, so the images differ only by fp32 summation order."""
+    from tgsr_amd import lp_pipeline
+    cap, lens, LR, LRb = O.synthetic_batch(3)
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    assert lp_pipeline.FUSE_HEADS
+    fused = _pipe(cfg_face, face_weights, name)(*args)
+    monkeypatch.setattr(lp_pipeline, "FUSE_HEADS", False)
+    plain = _pipe(cfg_face, face_weights, name)(*args)
+    torch.cuda.synchronize()
+    for k in ("fake", "fine"):
+        for i in range(3):
+            np.testing.assert_allclose(fused[k][i].cpu().numpy(), plain[k][i].cpu().numpy(), atol=3e-5, rtol=1e-5)
+    for i in range(3):
+        assert torch.equal(fused["att"][i], plain["att"][i])

@@ -702,7 +702,7 @@ def test_config3_birds_vocab_5450_batch4_vs_oracle(cfg_face):
         close(r["fine"][i], ref["fine"][i], atol=ATOL256 if i == 2 else ATOL)
         close(r["att"][i], ref["att"][i], atol=2e-5)
     # every token of the vocabulary: the table against the oracle's own input projection on a batch that walks the table
-    ids = torch.arange(1, n_words).reshape(-1, 1)[:5448].reshape(-1, 18)[::23][:16]          # 16 captions of 18 tokens
+    ids = torch.arange(1, 1 + 302 * 18).reshape(302, 18)[::19][:16].contiguous()        # 16 captions of 18 tokens, ids up to 5149
     words, sent = O.rnn_encoder(sdE, ids, [18] * ids.shape[0])
     w2, s2 = p.text_encoder(ids.to(DEV), [18] * ids.shape[0])
     close(w2, words, atol=1e-5)

@@ -94,6 +94,9 @@ SIGNATURES = {
     "tgsr_lp_packed_upconv_elems": (_i64, [_i, _i]),
     "tgsr_lp_pack_upconv_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_upconv_glu_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "tgsr_lp_head_partial_elems": (_i64, [_i, _i, _i, _i]),
+    "tgsr_lp_upconv_glu_head_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "tgsr_lp_head_combine": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp]),
     "tgsr_lp_stem_fwd": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_pack_to3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_conv_to3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),

@@ -164,23 +164,30 @@ def _cba_backward(x, weight, raw, stats, gamma, beta, glu, upsample, dout, need_
             _ADOPTED.append((weight, dw.data_ptr()))
 
         def wgrad():
+            e0 = ops._ev() if ops.profile is not None else None
             if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
                 # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
                 # up-sampled grid)
+                kname = "upwino_wgrad_kernel"
                 wws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
                 rc = L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
                 check(rc, "tgsr_upwino_wgrad")
             elif (not upsample) and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
                 # plain conv: 16 Winograd positions per 2x2 output tile (2.25x fewer multiplies than 9 taps per pixel)
+                kname = "wino_wgrad_kernel"
                 wws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
                 rc = L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
                 check(rc, "tgsr_wino_wgrad")
             else:
+                kname = "conv3x3_wgrad_kernel"
                 n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
                 wws = torch.empty(n, dtype=torch.float32, device=dev)
                 rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0,
                                           _p(wws), _p(dw), _stream())
                 check(rc, "tgsr_conv3x3_wgrad")
+            if ops.profile is not None:      # direct-form FLOPs of the weight gradient: one MAC per (output pixel, tap, ci, co)
+                ops.profile.append((kname, 2.0 * B * HW * Cout * Cin * 9, 4.0 * (B * Cin * H * W + B * Cout * HW + Cout * Cin * 9),
+                                    e0, ops._ev()))
         on_wgrad_stream(dev, (draw, x), wgrad, adopted)
     return dx, dw, dgamma, dbeta
 

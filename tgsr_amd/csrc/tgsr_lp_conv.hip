@@ -35,9 +35,11 @@ struct LpConvArgs {
   const float* shift;
   const char* res;
   int rcp, rco;
-  char* out;
+  char* out;           // may be null for the head-fused upBlock (the feature image is then never written)
   int ocp, oco;
   int tiles_x, tiles_y;
+  const char* hw;      // head fusion (lp_upconv_glu_kernel<.., HK>): image-head filter, lp_pack_to3 layout [HK][lane 64][8]
+  float* hpart;        // per-tile partial sums of the head [B][tiles_y][tiles_x][3][8 + 2P][64 + 2P]
 };
 
 constexpr int kEpiAffine = 0, kEpiGlu = 1, kEpiRes = 2;
@@ -257,7 +259,15 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 // low-res halo tile once by swizzled LDS-DMA, the phase weights streamed in 16-KB chunks [k16][column group][8 combos]
 // (column group 0 = the outer columns dx = -1 (b = 0) and +1 (b = 1), 1 = the centre column feeding both b), double
 // buffered, one barrier per chunk; an A fragment feeds 2 MFMAs, a B fragment 2-4.
-template <class T, int CIN>
+//
+// HK = 3 | 5: the image head that reads this upBlock's output (GET_IMAGE_G_noAct util.py:909-919, HK = 3; conv_output
+// model.py:224, HK = 5) is computed here too, from the output tile while it sits in LDS: V[(c, dx)][row][x'] =
+// sum_{dy, ci} w[c][ci][dy][dx] h[ci][row + dy - P][x'] on MFMA 16x16x32 (the (output channel, kernel column) pairs are
+// the rows of the A fragment, as in lp_to3_kernel), then the HK-term shift-sum over dx.  A tile only holds its own 8 x 64
+// pixels, so it produces PARTIAL sums for the (8 + 2P) x (64 + 2P) outputs its pixels reach; lp_head_combine_kernel adds
+// the <= 4 partials of every pixel in a fixed order (no float atomics) and applies tanh / + a SRb.  With a.out == null the
+// 32-channel feature image - which only the head would read - never goes to HBM.
+template <class T, int CIN, int HK>
 __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
   constexpr int TRL = 4, TC = 34, NPIX = (TRL + 2) * TC, PB = CIN * 2, NSL = CIN / 8, COUT = 64;
   constexpr int TILE_SLOTS = NPIX * NSL, TILE_INSTR = (TILE_SLOTS + 63) / 64, TILE_BYTES = TILE_INSTR * 1024;
@@ -398,19 +408,143 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
         u32x2 pk;
         pk[0] = LP<T>::pack2(o[0], o[1]);
         pk[1] = LP<T>::pack2(o[2], o[3]);
-        *reinterpret_cast<u32x2*>(stg + pw * OB + ((rg ^ (pw & (NCHK - 1))) << 4) + 8 * h) = pk;
+        *reinterpret_cast<u32x2*>(stg + pw * OB + ((rg ^ ((pw >> 1) & (NCHK - 1))) << 4) + 8 * h) = pk;
       }
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int64_t orow = (int64_t)(a.W + 2) * a.ocp * 2;
-  char* ob = a.out + ((int64_t)b * (a.H + 2) + 2 * (y0 + 2 * rp) + ph + 1) * orow + (int64_t)(2 * x0 + 1) * (a.ocp * 2) +
-             a.oco * 2;
+  if (HK == 0 || a.out != nullptr) {
+    const int64_t orow = (int64_t)(a.W + 2) * a.ocp * 2;
+    char* ob = a.out + ((int64_t)b * (a.H + 2) + 2 * (y0 + 2 * rp) + ph + 1) * orow + (int64_t)(2 * x0 + 1) * (a.ocp * 2) +
+               a.oco * 2;
 #pragma unroll
-  for (int j = 0; j < STG_INSTR; ++j) {
-    const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ (pw & (NCHK - 1));
-    const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
-    *reinterpret_cast<u32x4*>(ob + (pw >> 6) * (2 * orow) + (int64_t)(pw & 63) * (a.ocp * 2) + q * 16) = v;
+    for (int j = 0; j < STG_INSTR; ++j) {
+      const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ ((pw >> 1) & (NCHK - 1));
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
+      *reinterpret_cast<u32x4*>(ob + (pw >> 6) * (2 * orow) + (int64_t)(pw & 63) * (a.ocp * 2) + q * 16) = v;
+    }
+  }
+  if constexpr (HK > 0) {
+    // ---- fused image head on the tile in LDS: output row R (0..7) of the tile lives in the staging region of wave
+    // (R >> 2) * 2 + (R & 1), half rr = (R >> 1) & 1, as [64 pixels][64 bytes] with the 16-byte chunk of channels 8 g ..
+    // at physical chunk g ^ ((pixel >> 1) & 3): the B fragment of 16 neighbouring pixels x 4 channel groups is one
+    // conflict-free ds_read_b128
+    constexpr int P = HK / 2, NR = 8 + 2 * P, NX = 64 + 2 * P, VP = 68;
+    static_assert(4 * STG_WAVE + 4 * 16 * VP * 4 + COUT * 8 <= TILE_BYTES + NBUF * CHUNK_BYTES, "V images fit behind the tile");
+    const int p = lane & 15, g = lane >> 4;
+    u32x4 hf[HK];
+#pragma unroll
+    for (int k = 0; k < HK; ++k) hf[k] = *reinterpret_cast<const u32x4*>(a.hw + (k * 64 + lane) * 16);
+    __builtin_amdgcn_s_barrier();                                // every wave's rows are staged (own lgkmcnt(0) above)
+    float* v = reinterpret_cast<float*>(smem + 4 * STG_WAVE) + wave * (16 * VP);
+    float* pb = a.hpart + ((int64_t)(b * a.tiles_y + ty) * a.tiles_x + tx) * (3 * NR * NX);
+#pragma unroll 1
+    for (int yo = wave - P; yo < 8 + P; yo += 4) {               // this wave's output rows (tile-local, -P .. 7 + P)
+      f32x4w acc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < HK; ++dy) {
+        const int R = yo + dy - P;                               // source row: wave-uniform
+        if ((unsigned)R < 8u) {
+          const char* rb = smem + ((R >> 2) * 2 + (R & 1)) * STG_WAVE + ((R >> 1) & 1) * (64 * OB);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int xq = 16 * j + p;
+            const u32x4 bf = *reinterpret_cast<const u32x4*>(rb + xq * OB + ((g ^ ((xq >> 1) & 3)) << 4));
+            acc[j] = LP<T>::mfma16(hf[dy], bf, acc[j]);
+          }
+        }
+      }
+      // D[row = 4 g + i][col = p] -> V image [16 rows (c, dx)][64 columns] of this wave, then the shift-sum over dx
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[(4 * g + i) * VP + 16 * j + p] = acc[j][i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private image: no barrier
+      for (int o = lane; o < 3 * NX; o += 64) {
+        const int c = o / NX, xi = o - c * NX;                   // output column x = xi - P (tile-local)
+        float sum = 0.f;
+#pragma unroll
+        for (int dx = 0; dx < HK; ++dx) {
+          const int xs = xi + dx - 2 * P;                        // source column x + dx - P
+          if ((unsigned)xs < 64u) sum += v[(c * HK + dx) * VP + xs];
+        }
+        pb[(c * NR + yo + P) * NX + xi] = sum;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the V image is rewritten for the next row
+    }
+  }
+}
+
+// Sum of the per-tile partial sums the head-fused upBlocks wrote, for up to 4 scales at once and both generators:
+//   low[s]  = act_low(sum of G_SR_NET_low's 3x3 partials)                (GET_IMAGE_G_noAct: none; GET_IMAGE_G x16: tanh)
+//   high[s] = tanh(sum of NetG_highweight's 5x5 partials) + alpha * low[s]   (model.py:280, 288, 297)
+// A pixel receives at most 2 x 2 partials (tile rows ty, columns tx ascending: a fixed order).  thread = one pixel of
+// one scale, all 3 channels of both images.
+struct LpCombineScale {
+  const float* pl;     // [B][ty][tx][3][10][66] or null
+  const float* ph;     // [B][ty][tx][3][12][68] or null
+  float* low;          // [B][3][H][W]
+  float* high;         // [B][3][H][W] or null
+  int H, W, tiles_x, tiles_y;
+  int64_t first;       // index of this scale's first pixel in the launch's flat pixel range
+};
+struct LpCombineArgs {
+  LpCombineScale s[4];
+  int nscales, B, low_tanh;
+  float alpha;
+  int64_t total;
+};
+
+template <int P>
+__device__ __forceinline__ void head_gather(const float* part, int b, int y, int x, int tiles_y, int tiles_x, float (&o)[3]) {
+  constexpr int NR = 8 + 2 * P, NX = 64 + 2 * P;
+  o[0] = o[1] = o[2] = 0.f;
+  const int ty0 = (y - P) >= 0 ? (y - P) >> 3 : 0, ty1 = min((y + P) >> 3, tiles_y - 1);
+  const int tx0 = (x - P) >= 0 ? (x - P) >> 6 : 0, tx1 = min((x + P) >> 6, tiles_x - 1);
+  for (int ty = ty0; ty <= ty1; ++ty)
+    for (int tx = tx0; tx <= tx1; ++tx) {
+      const float* pb = part + ((int64_t)(b * tiles_y + ty) * tiles_x + tx) * (3 * NR * NX) + (y - 8 * ty + P) * NX +
+                        (x - 64 * tx + P);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) o[c] += pb[c * NR * NX];
+    }
+}
+
+__global__ __launch_bounds__(256) void lp_head_combine_kernel(LpCombineArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.total) return;
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q)
+    if (q < a.nscales && i >= a.s[q].first) k = q;
+  const LpCombineScale& sc = a.s[k];
+  int64_t t = i - sc.first;
+  const int x = (int)(t % sc.W);
+  t /= sc.W;
+  const int y = (int)(t % sc.H);
+  const int b = (int)(t / sc.H);
+  const int64_t HW = (int64_t)sc.H * sc.W, oi = (int64_t)b * 3 * HW + (int64_t)y * sc.W + x;
+  float lo[3] = {0.f, 0.f, 0.f};
+  if (sc.pl) {
+    head_gather<1>(sc.pl, b, y, x, sc.tiles_y, sc.tiles_x, lo);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (a.low_tanh) lo[c] = tanhf(lo[c]);
+      sc.low[oi + c * HW] = lo[c];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lo[c] = sc.low[oi + c * HW];
+  }
+  if (sc.ph) {
+    float hi[3];
+    head_gather<2>(sc.ph, b, y, x, sc.tiles_y, sc.tiles_x, hi);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sc.high[oi + c * HW] = tanhf(hi[c]) + a.alpha * lo[c];
   }
 }
 
@@ -580,6 +714,7 @@ extern "C" int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B
   a.res = static_cast<const char*>(residual); a.rcp = res_cpitch; a.rco = res_coff;
   a.out = static_cast<char*>(out); a.ocp = out_cpitch; a.oco = out_coff;
   a.tiles_x = a.tiles_y = 0;
+  a.hw = nullptr; a.hpart = nullptr;
   const int epi = epilogue == TGSR_EPI_AFFINE_GLU ? kEpiGlu : (residual ? kEpiRes : kEpiAffine);
   if (dtype == TGSR_DT_BF16) return launch_lp_conv<BF16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
   return launch_lp_conv<F16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
@@ -602,31 +737,88 @@ extern "C" int tgsr_lp_pack_upconv_weight(int dtype, const float* w, void* wpack
   return note_launch(hipGetLastError(), "lp_pack_upconv_kernel");
 }
 
-extern "C" int tgsr_lp_upconv_glu_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
-                                      int Cout, const float* scale, const float* shift, void* out, int out_cpitch,
-                                      int out_coff, void* stream) {
-  if (!x || !wpack || !out || B < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+template <class T, int HK>
+static void launch_lp_upconv(const LpConvArgs& a, int Cin, dim3 grid, hipStream_t s) {
+  if (Cin == 64) hipLaunchKernelGGL((lp_upconv_glu_kernel<T, 64, HK>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((lp_upconv_glu_kernel<T, 32, HK>), grid, dim3(256), 0, s, a);
+}
+
+static int lp_upconv_launch(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack, int Cout,
+                            const float* scale, const float* shift, void* out, int out_cpitch, int out_coff,
+                            const void* head_wpack, int head_k, float* head_partial, void* stream) {
+  if (!x || !wpack || B < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  if (!out && !head_partial) return TGSR_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
   if (dtype != TGSR_DT_BF16 && dtype != TGSR_DT_F16) return TGSR_EINVAL;
+  if (head_partial && (!head_wpack || (head_k != 3 && head_k != 5))) return TGSR_EINVAL;
   if (Cout != 64 || (Cin != 32 && Cin != 64) || W % 32 != 0 || H % 4 != 0) return TGSR_EUNSUPPORTED;   // H, W: LOW-res size
-  if (x_cpitch < Cin || x_cpitch % 8 != 0 || out_cpitch % 8 != 0 || out_coff % 8 != 0 || out_coff + 32 > out_cpitch ||
-      (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wpack) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+  if (x_cpitch < Cin || x_cpitch % 8 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wpack) & 15) ||
+      (reinterpret_cast<uintptr_t>(head_wpack) & 15))
     return TGSR_EUNSUPPORTED;
-  if ((int64_t)(2 * H + 2) * (2 * W + 2) * out_cpitch * 2 >= (1ll << 31)) return TGSR_EUNSUPPORTED;
+  if (out && (out_cpitch % 8 != 0 || out_coff % 8 != 0 || out_coff + 32 > out_cpitch || (reinterpret_cast<uintptr_t>(out) & 15) ||
+              (int64_t)(2 * H + 2) * (2 * W + 2) * out_cpitch * 2 >= (1ll << 31)))
+    return TGSR_EUNSUPPORTED;
   LpConvArgs a;
   a.x = static_cast<const char*>(x); a.xcp = x_cpitch; a.B = B; a.H = 2 * H; a.W = 2 * W; a.Hi = H; a.Wi = W;
   a.wpack = static_cast<const char*>(wpack); a.scale = scale; a.shift = shift; a.res = nullptr; a.rcp = a.rco = 0;
   a.out = static_cast<char*>(out); a.ocp = out_cpitch; a.oco = out_coff; a.tiles_x = W / 32; a.tiles_y = H / 4;
+  a.hw = static_cast<const char*>(head_wpack); a.hpart = head_partial;
   const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y));
   hipStream_t s = as_stream(stream);
+  const int hk = head_partial ? head_k : 0;
   if (dtype == TGSR_DT_BF16) {
-    if (Cin == 64) hipLaunchKernelGGL((lp_upconv_glu_kernel<BF16, 64>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((lp_upconv_glu_kernel<BF16, 32>), grid, dim3(256), 0, s, a);
+    if (hk == 0) launch_lp_upconv<BF16, 0>(a, Cin, grid, s);
+    else if (hk == 3) launch_lp_upconv<BF16, 3>(a, Cin, grid, s);
+    else launch_lp_upconv<BF16, 5>(a, Cin, grid, s);
   } else {
-    if (Cin == 64) hipLaunchKernelGGL((lp_upconv_glu_kernel<F16, 64>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((lp_upconv_glu_kernel<F16, 32>), grid, dim3(256), 0, s, a);
+    if (hk == 0) launch_lp_upconv<F16, 0>(a, Cin, grid, s);
+    else if (hk == 3) launch_lp_upconv<F16, 3>(a, Cin, grid, s);
+    else launch_lp_upconv<F16, 5>(a, Cin, grid, s);
   }
   return note_launch(hipGetLastError(), "lp_upconv_glu_kernel");
+}
+
+extern "C" int tgsr_lp_upconv_glu_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                                      int Cout, const float* scale, const float* shift, void* out, int out_cpitch,
+                                      int out_coff, void* stream) {
+  if (!out) return TGSR_EINVAL;
+  return lp_upconv_launch(dtype, x, x_cpitch, B, Cin, H, W, wpack, Cout, scale, shift, out, out_cpitch, out_coff, nullptr, 0,
+                          nullptr, stream);
+}
+
+extern "C" int64_t tgsr_lp_head_partial_elems(int B, int H, int W, int K) {
+  const int P = K / 2;                                   // H, W: size of the head's image (the upBlock's OUTPUT)
+  return (int64_t)B * (H / 8) * (W / 64) * 3 * (8 + 2 * P) * (64 + 2 * P);
+}
+
+extern "C" int tgsr_lp_upconv_glu_head_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W,
+                                           const void* wpack, int Cout, const float* scale, const float* shift, void* out,
+                                           int out_cpitch, int out_coff, const void* head_wpack, int head_k,
+                                           float* head_partial, void* stream) {
+  if (!head_partial) return TGSR_EINVAL;
+  return lp_upconv_launch(dtype, x, x_cpitch, B, Cin, H, W, wpack, Cout, scale, shift, out, out_cpitch, out_coff, head_wpack,
+                          head_k, head_partial, stream);
+}
+
+extern "C" int tgsr_lp_head_combine(int nscales, int B, const int* H, const int* W, const float* const* partial_low,
+                                    const float* const* partial_high, float* const* low, float* const* high, int low_tanh,
+                                    float alpha, void* stream) {
+  if (nscales < 1 || nscales > 4 || B < 1 || !H || !W || !partial_low || !partial_high || !low || !high) return TGSR_EINVAL;
+  LpCombineArgs a;
+  a.nscales = nscales; a.B = B; a.low_tanh = low_tanh; a.alpha = alpha;
+  int64_t total = 0;
+  for (int k = 0; k < nscales; ++k) {
+    if (H[k] < 8 || W[k] < 64 || H[k] % 8 != 0 || W[k] % 64 != 0) return TGSR_EUNSUPPORTED;
+    if (!low[k] || (partial_high[k] && !high[k])) return TGSR_EINVAL;
+    a.s[k].pl = partial_low[k]; a.s[k].ph = partial_high[k]; a.s[k].low = low[k]; a.s[k].high = high[k];
+    a.s[k].H = H[k]; a.s[k].W = W[k]; a.s[k].tiles_x = W[k] / 64; a.s[k].tiles_y = H[k] / 8; a.s[k].first = total;
+    total += (int64_t)B * H[k] * W[k];
+  }
+  for (int k = nscales; k < 4; ++k) a.s[k] = a.s[0];
+  a.total = total;
+  if (total >= (1ll << 31) * 256) return TGSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(lp_head_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), a);
+  return note_launch(hipGetLastError(), "lp_head_combine_kernel");
 }
 
 extern "C" int tgsr_lp_from_nchw(int dtype, const float* x, void* out, int B, int C, int H, int W, int cpitch, int coff,

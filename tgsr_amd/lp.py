@@ -239,3 +239,83 @@ def upconv_glu(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale,
         nbytes = 2 * (B * cin * Hi * Wi + B * co * 4 * Hi * Wi + cout * cin * 16)
         ops.profile.append(("lp_upconv_glu_kernel", 2.0 * B * 4 * Hi * Wi * cout * cin * 9, nbytes, e0, ops._ev()))
     return out
+
+
+def head_partial_elems(B: int, H: int, W: int, K: int) -> int:
+    return int(_lib.lib().tgsr_lp_head_partial_elems(B, H, W, K))
+
+
+def head_fusable(cin: int, cout: int, Hi: int, Wi: int) -> bool:
+    """Shapes tgsr_lp_upconv_glu_head_fwd + tgsr_lp_head_combine take: the sub-pixel upBlock kernel's, and an output
+    image whose size is a multiple of the 8 x 64 workgroup tile (always true for Hi % 4 == 0, Wi % 32 == 0)."""
+    return upconv_supported(cin, cout, Hi, Wi)
+
+
+def upconv_glu_head(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, shift, head_wpack: torch.Tensor,
+                    K: int, partial: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                    out_coff: int = 0, write_out: bool = True):
+    """upBlock + the image head reading it, one launch: returns (out lp image or None, partial head sums fp32).  With
+    write_out=False the 32-channel feature image is not written at all (its only consumer is the head)."""
+    _need_hip(x, wpack, scale, shift, head_wpack, partial, out)
+    B, Hi, Wi, xcp = _img(x, "x")
+    L = _lib.lib()
+    n = L.tgsr_lp_head_partial_elems(B, 2 * Hi, 2 * Wi, K)
+    if partial is None:
+        partial = torch.empty(n, dtype=torch.float32, device=x.device)
+    if partial.numel() != n or partial.dtype != torch.float32 or head_wpack.dtype != x.dtype or wpack.dtype != x.dtype:
+        raise TgsrError("lp.upconv_glu_head: partial buffer / dtypes do not match")
+    ocp = 0
+    if write_out:
+        if out is None:
+            out = new_image(B, 2 * Hi, 2 * Wi, out_coff + cout // 2, x.dtype, x.device)
+        ob, oh, ow, ocp = _img(out, "out")
+        if (ob, oh, ow) != (B, 2 * Hi, 2 * Wi) or out.dtype != x.dtype:
+            raise TgsrError("lp.upconv_glu_head: out %s" % (tuple(out.shape),))
+    else:
+        out = None
+    if cin > xcp or wpack.numel() != L.tgsr_lp_packed_upconv_elems(cout, cin) or head_wpack.numel() != K * 512:
+        raise TgsrError("lp.upconv_glu_head: filter packs do not fit (%d input channels, %d / %d values)"
+                        % (xcp, wpack.numel(), head_wpack.numel()))
+    from . import ops
+    e0 = ops._ev() if ops.profile is not None else None
+    rc = L.tgsr_lp_upconv_glu_head_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift), _p(out),
+                                       ocp, out_coff, _p(head_wpack), K, _p(partial), _stream())
+    check(rc, "tgsr_lp_upconv_glu_head_fwd")
+    if ops.profile is not None:
+        co = cout // 2
+        nbytes = 2 * (B * cin * Hi * Wi + (B * co * 4 * Hi * Wi if write_out else 0) + cout * cin * 16) + 4 * n
+        flops = 2.0 * B * 4 * Hi * Wi * (cout * cin * 9 + 3 * co * K * K)
+        ops.profile.append(("lp_upconv_glu_kernel", flops, nbytes, e0, ops._ev()))
+    return out, partial
+
+
+def head_combine(B: int, sizes, partial_low, partial_high, low, high, low_tanh: bool, alpha: float):
+    """tgsr_lp_head_combine over len(sizes) <= 4 scales: sizes[s] = (H, W); partial_low / partial_high / low / high lists
+    (entries may be None as the header describes).  One launch."""
+    n = len(sizes)
+    ts = [t for lst in (partial_low, partial_high, low, high) for t in lst if t is not None]
+    _need_hip(*ts)
+    L = _lib.lib()
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TgsrError("lp.head_combine: fp32 contiguous tensors only")
+    for k, (H, W) in enumerate(sizes):
+        for t in (low[k], high[k]):
+            if t is not None and tuple(t.shape) != (B, 3, H, W):
+                raise TgsrError("lp.head_combine: image %s, expected %s" % (tuple(t.shape), (B, 3, H, W)))
+        if partial_low[k] is not None and partial_low[k].numel() != L.tgsr_lp_head_partial_elems(B, H, W, 3):
+            raise TgsrError("lp.head_combine: partial_low[%d] has %d values" % (k, partial_low[k].numel()))
+        if partial_high[k] is not None and partial_high[k].numel() != L.tgsr_lp_head_partial_elems(B, H, W, 5):
+            raise TgsrError("lp.head_combine: partial_high[%d] has %d values" % (k, partial_high[k].numel()))
+    arr_i = ctypes.c_int * n
+    arr_p = ctypes.c_void_p * n
+    ptr = lambda lst: arr_p(*[None if t is None else t.data_ptr() for t in lst])      # noqa: E731
+    from . import ops
+    e0 = ops._ev() if ops.profile is not None else None
+    rc = L.tgsr_lp_head_combine(n, B, arr_i(*[s[0] for s in sizes]), arr_i(*[s[1] for s in sizes]), ptr(partial_low),
+                                ptr(partial_high), ptr(low), ptr(high), 1 if low_tanh else 0, float(alpha), _stream())
+    check(rc, "tgsr_lp_head_combine")
+    if ops.profile is not None:
+        nbytes = 4 * sum(t.numel() for t in ts)
+        ops.profile.append(("lp_head_combine_kernel", 0.0, nbytes, e0, ops._ev()))
+    return low, high

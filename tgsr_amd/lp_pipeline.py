@@ -1,6 +1,7 @@
-"""Reduced-precision executor of the x8 inference path (BASELINE.json configs[4]: bf16 storage, MFMA bf16 attention +
+"""Reduced-precision executor of the inference path (BASELINE.json configs[4]: bf16 storage, MFMA bf16 attention +
 fused conv, hipGraph-capturable): G_SR_NET_low.forward (model.py:48-78) and NetG_highweight.forward (model.py:264-298)
-of an `SRPipeline`'s modules, run on lp images (tgsr_amd.lp) instead of fp32 NCHW tensors.
+of an `SRPipeline`'s modules - or their x16 counterparts (models16.py:5-39, 97-179: weight-tied stages 2-4, tanh heads,
+a fourth stage through `residual48` / `upscale8x` again) - run on lp images (tgsr_amd.lp) instead of fp32 NCHW tensors.
 
 Same parameters (read from the fp32 drop-in modules, packed once per weight version), same call order and argument
 wiring, same return values (fp32 images and attention maps) - only the storage / MFMA operand type of the activations
@@ -18,6 +19,10 @@ from .util import _ver
 # upBlocks by sub-pixel decomposition (tgsr_lp_upconv_glu_fwd: 2.25x fewer MFMAs); TGSR_LP_SUBPIXEL=0 keeps the direct
 # 9-tap form on the up-sampled grid (tgsr_lp_conv3x3_fwd(upsample=1)) for A/B runs
 SUBPIXEL = os.environ.get("TGSR_LP_SUBPIXEL", "1") != "0"
+# image heads computed inside the upBlock that produces their input (tgsr_lp_upconv_glu_head_fwd: per-tile partial sums)
+# and finished for all scales of both generators by ONE tgsr_lp_head_combine launch; the last stage's 256^2 feature
+# images then never go to HBM.  TGSR_LP_FUSE_HEADS=0 keeps the six stand-alone head launches (tgsr_lp_conv_to3_fwd).
+FUSE_HEADS = os.environ.get("TGSR_LP_FUSE_HEADS", "1") != "0"
 
 
 class _Conv:
@@ -48,6 +53,14 @@ class _UpConv:
             return lp.upconv_glu(x, self.wsub, self.cin, self.cout, self.scale, self.shift, out=out)
         return lp.conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, glu=True, upsample=True, out=out)
 
+    def fusable(self, x):
+        return FUSE_HEADS and self.sub and lp.head_fusable(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2)
+
+    def with_head(self, x, head_wpack, K, partial, out):
+        """upBlock + its image head's partial sums in one launch; out None: the feature image is not written."""
+        return lp.upconv_glu_head(x, self.wsub, self.cin, self.cout, self.scale, self.shift, head_wpack, K, partial=partial,
+                                  out=out, write_out=out is not None)
+
 
 class _Stem:
     def __init__(self, seq):                      # _ConvBnGlu: [conv3x3(3, 2C), BatchNorm2d, GLU]
@@ -66,6 +79,7 @@ class LpExecutor:
         self.key = None
         self.bufs = {}
         self.force_bufs = None       # set by a hipGraph capture: the buffer set the captured step is bound to
+        self._bufs_of_step = None    # the buffer set of the step in flight (its pending fused heads)
 
     # ------------------------------------------------------------------ weights
     def _params_key(self):
@@ -83,15 +97,32 @@ class LpExecutor:
         def res(rb):
             return (_Conv(rb.block[0], rb.block[1], dt), _Conv(rb.block[3], rb.block[4], dt))
 
+        # x16 (models16): ONE NEXT_STAGE_G object serves stages 2-4 and ONE image head all four (models16.py:13-14); the
+        # 16x stage of NetG_highweight re-uses residual48 / upscale8x (:172-173).  A module is packed once however many
+        # stages use it.
+        self.x16 = hasattr(GL, "h_net4")
+        nst = 4 if self.x16 else 3
+        memo = {}
+
+        def once(mod, build):
+            if id(mod) not in memo:
+                memo[id(mod)] = build(mod)
+            return memo[id(mod)]
+
         self.gl_stem = _Stem(GL.h_net1.im2f)
         self.gl_stage = []
-        for st, img in ((GL.h_net1, GL.img_net1), (GL.h_net2, GL.img_net2), (GL.h_net3, GL.img_net3)):
-            self.gl_stage.append({"res": [res(rb) for rb in st.residual], "up": _UpConv(st.upsample[1], st.upsample[2], dt),
-                                  "head": lp.pack_to3_weight(img.img[0].weight, dt), "att": st.att})
+        for k in range(1, nst + 1):
+            st, img = getattr(GL, "h_net%d" % k), getattr(GL, "img_net%d" % k)
+            self.gl_stage.append({"res": once(st.residual, lambda m: [res(rb) for rb in m]),
+                                  "up": once(st.upsample, lambda m: _UpConv(m[1], m[2], dt)),
+                                  "head": once(img, lambda m: lp.pack_to3_weight(m.img[0].weight, dt)), "att": st.att})
+        self.gl_head_tanh = self.x16                       # GET_IMAGE_G (util.py:894-905) vs GET_IMAGE_G_noAct (:909-919)
         self.gh_stem = _Stem(GH.convin)
         self.gh_res = [res(rb) for rb in GH.residual]
-        self.gh_up = [_UpConv(u[1], u[2], dt) for u in (GH.upscale2x, GH.upscale4x, GH.upscale8x)]
-        self.gh_mid = [(_Conv(m[0], m[1], dt), _Conv(m[3], m[4], dt)) for m in (GH.residual24, GH.residual48)]
+        ups = [GH.upscale2x, GH.upscale4x, GH.upscale8x] + ([GH.upscale8x] if self.x16 else [])
+        mids = [GH.residual24, GH.residual48] + ([GH.residual48] if self.x16 else [])
+        self.gh_up = [once(u, lambda m: _UpConv(m[1], m[2], dt)) for u in ups]
+        self.gh_mid = [once(m_, lambda m: (_Conv(m[0], m[1], dt), _Conv(m[3], m[4], dt))) for m_ in mids]
         self.gh_head = lp.pack_to3_weight(GH.conv_output[0].weight, dt)
         self.key = key
 
@@ -100,11 +131,15 @@ class LpExecutor:
         """One set of zero-bordered activation images for a batch of B LR images of H x W."""
         def im(s, c):
             return lp.new_image(B, H * s, W * s, c, self.dtype, dev)
-        return {"gl": [{"wide": im(s, 64), "tmp": im(s, 64), "a": im(s, 64), "b": im(s, 64)} for s in (1, 2, 4)],
-                "h3": im(8, 32),
+        n = len(self.gl_stage)
+        return {"gl": [{"wide": im(1 << k, 64), "tmp": im(1 << k, 64), "a": im(1 << k, 64), "b": im(1 << k, 64)}
+                       for k in range(n)],
+                "h3": im(1 << n, 32),                                   # the last stage's 32-channel output
                 "gh": {"x": im(1, 32), "y": im(1, 32), "t": im(1, 32)},
-                "u": [im(2, 32), im(4, 32), im(8, 32)],
-                "m": [{"t": im(2, 32), "v": im(2, 32)}, {"t": im(4, 32), "v": im(4, 32)}]}
+                "u": [im(2 << k, 32) for k in range(n)],
+                "m": [{"t": im(2 << k, 32), "v": im(2 << k, 32)} for k in range(n - 1)],
+                # per-tile partial sums of the fused image heads (fp32; allocated on first use)
+                "pl": [None] * n, "ph": [None] * n, "pend": None}
 
     def _buffers(self, B, H, W, dev):
         """The buffer set of the calling stream (concurrent lanes must not share activations); allocated on first use."""
@@ -122,8 +157,14 @@ class LpExecutor:
         GL = self.netGL
         c_code, mu, logvar = GL.ca_net(sent_emb) if ca is None else ca
         T = word_embs.size(2)
-        srcs = ops.word_project(word_embs, [st["att"].conv_context.weight for st in self.gl_stage])
-        fake, atts = [], []
+        atts_m = []
+        for st in self.gl_stage:                                               # distinct attention modules (x16: two)
+            if all(st["att"] is not m for m in atts_m):
+                atts_m.append(st["att"])
+        proj = ops.word_project(word_embs, [m.conv_context.weight for m in atts_m])
+        srcs = [proj[[i for i, m in enumerate(atts_m) if m is st["att"]][0]] for st in self.gl_stage]
+        last = len(self.gl_stage) - 1
+        fake, atts, pend = [], [], []
         wide = bufs["gl"][0]["wide"]
         self.gl_stem(LR, out=wide)                                             # im2f -> channels [0, 32)
         for k, st in enumerate(self.gl_stage):
@@ -134,9 +175,21 @@ class LpExecutor:
                 c0(x, glu=True, out=bb["tmp"])
                 c1(bb["tmp"], residual=x, out=o)
                 x = o
-            nxt = bufs["gl"][k + 1]["wide"] if k < 2 else bufs["h3"]
-            st["up"](x, out=nxt)                                               # upBlock -> channels [0, 32) of the next stage
-            fake.append(lp.conv_to3(nxt, st["head"], 3))
+            nxt = bufs["gl"][k + 1]["wide"] if k < last else bufs["h3"]
+            if st["up"].fusable(x):
+                # upBlock + the partial sums of its 3x3 head; the last stage's feature image is read by nothing else
+                B, Ho, Wo = x.shape[0], 2 * (x.shape[1] - 2), 2 * (x.shape[2] - 2)
+                if bufs["pl"][k] is None:
+                    bufs["pl"][k] = torch.empty(lp.head_partial_elems(B, Ho, Wo, 3), dtype=torch.float32, device=x.device)
+                st["up"].with_head(x, st["head"], 3, bufs["pl"][k], nxt if k < last else None)
+                fake.append(torch.empty(B, 3, Ho, Wo, dtype=torch.float32, device=x.device))
+                pend.append(bufs["pl"][k])
+            else:
+                st["up"](x, out=nxt)                                           # upBlock -> channels [0, 32) of the next stage
+                fake.append(lp.conv_to3(nxt, st["head"], 3, tanh_axpy=self.gl_head_tanh))
+                pend.append(None)
+        # images whose partial sums are still to be combined (high_heads does it, for both generators in one launch)
+        bufs["pend"] = (fake, pend)
         return fake, atts, mu, logvar
 
     def high_trunk(self, bufs, LR, LRb):
@@ -151,17 +204,60 @@ class LpExecutor:
             c1(g["t"], residual=cur, out=other)
             cur, other = other, cur
         feats = []
-        for k in range(3):
+        for k in range(len(self.gh_up)):
             if k > 0:
                 m, (c0, c1) = bufs["m"][k - 1], self.gh_mid[k - 1]
                 c0(cur, glu=True, out=m["t"])
                 c1(m["t"], out=m["v"])
                 cur = m["v"]
-            self.gh_up[k](cur, out=bufs["u"][k])
+            nlast = len(self.gh_up) - 1
+            if self.gh_up[k].fusable(cur):
+                B, Ho, Wo = cur.shape[0], 2 * (cur.shape[1] - 2), 2 * (cur.shape[2] - 2)
+                if bufs["ph"][k] is None:
+                    bufs["ph"][k] = torch.empty(lp.head_partial_elems(B, Ho, Wo, 5), dtype=torch.float32, device=cur.device)
+                self.gh_up[k].with_head(cur, self.gh_head, 5, bufs["ph"][k], bufs["u"][k] if k < nlast else None)
+                feats.append(_Partial(bufs["ph"][k], B, Ho, Wo))
+            else:
+                self.gh_up[k](cur, out=bufs["u"][k])
+                feats.append(bufs["u"][k])
             cur = bufs["u"][k]
-            feats.append(cur)
+        self._bufs_of_step = bufs
         return feats
 
     def high_heads(self, feats, SRb):
-        return [lp.conv_to3(f, self.gh_head, 5, tanh_axpy=True, addend=sr, alpha=self.netGH._a)
-                for f, sr in zip(feats, SRb)]
+        """NetG_highweight's heads: `tanh(conv5x5(out_k)) + a * SRb_k`.  Scales whose heads were computed inside their
+        upBlocks (partial sums) are finished here - with G_SR_NET_low's pending 3x3 heads - by one combine launch."""
+        alpha = self.netGH.alpha() if self.x16 else self.netGH._a      # x16: `a` is a parameter (models16.py:126)
+        fake, pend = self._bufs_of_step["pend"] if self._bufs_of_step is not None else (list(SRb), [None] * len(SRb))
+        fine, sizes, pl, ph, lo, hi = [], [], [], [], [], []
+        for k, (f, sr) in enumerate(zip(feats, SRb)):
+            fused_h = isinstance(f, _Partial)
+            pk = pend[k] if k < len(pend) and fake[k] is sr else None
+            if not fused_h:
+                if pk is not None:          # the low image must exist before an unfused 5x5 head can add it: combine it alone
+                    lp.head_combine(sr.shape[0], [tuple(sr.shape[2:])], [pk], [None], [sr], [None], self.gl_head_tanh, alpha)
+                    pk = None
+                fine.append(lp.conv_to3(f, self.gh_head, 5, tanh_axpy=True, addend=sr, alpha=alpha))
+            else:
+                fine.append(torch.empty(f.B, 3, f.H, f.W, dtype=torch.float32, device=sr.device))
+            if fused_h or pk is not None:
+                sizes.append(tuple(sr.shape[2:]))
+                pl.append(pk)
+                ph.append(f.t if fused_h else None)
+                lo.append(sr)
+                hi.append(fine[-1] if fused_h else None)
+        if sizes:
+            lp.head_combine(SRb[0].shape[0], sizes, pl, ph, lo, hi, self.gl_head_tanh, alpha)
+        if self._bufs_of_step is not None:
+            self._bufs_of_step["pend"] = None
+        return fine
+
+
+class _Partial:
+    """A NetG_highweight head whose per-tile partial sums an upBlock has written (LpExecutor.high_trunk)."""
+
+    def __init__(self, t, B, H, W):
+        self.t, self.B, self.H, self.W = t, B, H, W
+
+    def record_stream(self, stream):        # SRPipeline tags the trunk's outputs for the allocator
+        self.t.record_stream(stream)

@@ -31,15 +31,21 @@ class G_SR_NET_low(nn.Module):
         self.h_net4 = self.h_net3 = self.h_net2 = NEXT_STAGE_G(ngf, nef, ncf)
         self.img_net4 = self.img_net3 = self.img_net2 = self.img_net1 = GET_IMAGE_G(ngf)
 
-    def forward(self, LR, sent_emb, word_embs, mask):
+    def forward(self, LR, sent_emb, word_embs, mask, ca=None):
+        """ca: optional precomputed `self.ca_net(sent_emb)` (SRPipeline runs it beside the trunk, like the x8 model)."""
         fake_imgs, att_maps = [], []
-        c_code, mu, logvar = self.ca_net(sent_emb)
-        h_code, att = self.h_net1(None, LR, word_embs, mask, wide_out=True)
+        c_code, mu, logvar = self.ca_net(sent_emb) if ca is None else ca
+        src1 = src2 = None
+        if not self.training:
+            # two distinct conv_context projections (h_net1's and the tied stages'): one launch for both
+            src1, src2 = ops.word_project(word_embs, [self.h_net1.att.conv_context.weight,
+                                                      self.h_net2.att.conv_context.weight])
+        h_code, att = self.h_net1(None, LR, word_embs, mask, wide_out=True, src=src1)
         fake_imgs.append(self.img_net1(h_code))
         att_maps.append(att)
         for k, (stage, head) in enumerate(((self.h_net2, self.img_net2), (self.h_net3, self.img_net3),
                                            (self.h_net4, self.img_net4))):
-            h_code, att = stage(h_code, None, word_embs, mask, wide_out=(k < 2))
+            h_code, att = stage(h_code, None, word_embs, mask, wide_out=(k < 2), src=src2)
             fake_imgs.append(head(h_code))
             att_maps.append(att)
         return fake_imgs, att_maps, mu, logvar
@@ -74,29 +80,39 @@ class NetG_highweight(nn.Module):
         if self.training:
             from .autograd import ConvTo3
             return ConvTo3.apply(out, self.conv_output[0].weight, SRb, True, self.a)   # d/da = sum(dy * SRb)
-        key = (self.a.data_ptr(), self.a._version)
-        if self._a_host[0] != key:
-            self._a_host = (key, float(self.a.item()))
-        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=self._a_host[1])
+        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=self.alpha())
 
-    def forward(self, LR, SRb, LRb):
-        SRb2, SRb4, SRb8, SRb16 = SRb[0], SRb[1], SRb[2], SRb[3]
+    def trunk(self, LR, LRb):
+        """Everything that does not need the low-frequency images (see model.NetG_highweight.trunk): the four feature
+        maps the heads read."""
         if self.low == 'lrblur':
             x = LRb
         elif self.low == 'lr-lrblur':
             x = LR - LRb
         else:
             x = LR
-        out = self.residual(self.convin(x))
-        out = self.upscale2x(out)
-        ims2 = self._head(out, SRb2)
-        out = self.upscale4x(self.residual24(out))
-        ims4 = self._head(out, SRb4)
-        out = self.upscale8x(self.residual48(out))
-        ims8 = self._head(out, SRb8)
-        out = self.upscale8x(self.residual48(out))   # models16.py:172-173: the 16x stage re-uses the 8x modules
-        ims16 = self._head(out, SRb16)               # models16.py:178 says SRb8 (shape error as shipped)
+        out2 = self.upscale2x(self.residual(self.convin(x)))
+        out4 = self.upscale4x(self.residual24(out2))
+        out8 = self.upscale8x(self.residual48(out4))
+        out16 = self.upscale8x(self.residual48(out8))   # models16.py:172-173: the 16x stage re-uses the 8x modules
+        return out2, out4, out8, out16
+
+    def heads(self, feats, SRb):
+        """ims_k = one * tanh(conv5x5(out_k)) + a * SRb_k; the 16x head adds SRb16 (models16.py:178 says SRb8: a shape
+        error as shipped)."""
+        return [self._head(f, sr) for f, sr in zip(feats, SRb[:4])]
+
+    def forward(self, LR, SRb, LRb):
+        ims = self.heads(self.trunk(LR, LRb), SRb)
         one = self._one.get(LR.device)
         if one is None:
             one = self._one[LR.device] = LR.new_ones(1)
-        return [ims2, ims4, ims8, ims16], self.a, one
+        return ims, self.a, one
+
+    def alpha(self):
+        """Host value of `a` for the inference kernels: one D2H copy per weight version, none per step (and none inside
+        a hipGraph capture once a warm-up step has run)."""
+        key = (self.a.data_ptr(), self.a._version)
+        if self._a_host[0] != key:
+            self._a_host = (key, float(self.a.item()))
+        return self._a_host[1]

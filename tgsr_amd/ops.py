@@ -645,12 +645,22 @@ def _dconv_fwd(kind, x, w, leaky):
     Ho, Wo = (H // 2, W // 2) if kind == 4 else (H, W)
     out = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
     ws = torch.empty(ws_elems(0, B, Cin, H, W, Cout), dtype=torch.float32, device=x.device)
+    e0 = _ev() if profile is not None else None
     if kind == 4:
         check(fwd(_p(x), B, Cin, H, W, _p(w), Cout, 1 if leaky else 0, _p(ws), _p(out), _stream()), name + "_fwd")
     else:
         assert not leaky
         check(fwd(_p(x), B, Cin, H, W, _p(w), Cout, _p(ws), _p(out), _stream()), name + "_fwd")
+    _dconv_profile(e0, kind, B, Cin, H, W, Cout, Ho, Wo)
     return out
+
+
+def _dconv_profile(e0, kind, B, Cin, H, W, Cout, Ho, Wo):
+    """bench.py's per-launch hook for the discriminators' implicit-GEMM kernel (forward / data / weight gradient alike:
+    2 B Ho Wo Cout Cin K^2 FLOPs, every one of them issued - no Winograd saving here)."""
+    if profile is not None:
+        profile.append(("dconv_igemm_kernel", 2.0 * B * Ho * Wo * Cout * Cin * kind * kind,
+                        4.0 * (B * Cin * H * W + B * Cout * Ho * Wo + Cout * Cin * kind * kind), e0, _ev()))
 
 
 def _dconv_dgrad(kind, dy, w, H, W):
@@ -661,7 +671,9 @@ def _dconv_dgrad(kind, dy, w, H, W):
     ws_elems, _, dgrad, _, name = _dconv(kind)
     dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dy.device)
     ws = torch.empty(ws_elems(1, B, Cin, H, W, Cout), dtype=torch.float32, device=dy.device)
+    e0 = _ev() if profile is not None else None
     check(dgrad(_p(dy), B, Cin, H, W, _p(w), Cout, _p(ws), _p(dx), _stream()), name + "_dgrad")
+    _dconv_profile(e0, kind, B, Cin, H, W, Cout, dy.shape[2], dy.shape[3])
     return dx
 
 
@@ -674,7 +686,9 @@ def _dconv_wgrad(kind, dy, x, out=None):
     ws_elems, _, _, wgrad, name = _dconv(kind)
     ws = torch.empty(ws_elems(2, B, Cin, H, W, Cout), dtype=torch.float32, device=x.device)
     dw = out if out is not None else torch.empty(Cout, Cin, kind, kind, dtype=torch.float32, device=x.device)
+    e0 = _ev() if profile is not None else None
     check(wgrad(_p(dy), _p(x), B, Cin, H, W, Cout, _p(ws), _p(dw), _stream()), name + "_wgrad")
+    _dconv_profile(e0, kind, B, Cin, H, W, Cout, dy.shape[2], dy.shape[3])
     return dw
 
 

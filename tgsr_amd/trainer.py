@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from .miscc.config import cfg
-from .model import G_SR_NET_low, NetG_highweight, RNN_ENCODER
+from .model import RNN_ENCODER
 
 
 def sort_by_caption_length(captions, cap_lens, *per_sample):
@@ -34,14 +34,21 @@ def to_uint8(img):
 
 
 class SRPipeline:
-    """The three networks of the shipped x8 path, built like trainer_objective.py:62-99."""
+    """The three networks of the SR path, built like trainer_objective.py:62-99: TREE.BRANCH_NUM == 4 selects the x8
+    generators of model.py, anything else the x16 ones of models16.py (trainer_objective.py:74-87)."""
 
-    def __init__(self, n_words, device="cuda", low="lr", overlap=True, dtype="fp32"):
+    def __init__(self, n_words, device="cuda", low="lr", overlap=True, dtype="fp32", branch_num=None):
         """dtype: "fp32" (the parity path: fp32 NCHW kernels) or "bf16" / "f16" (BASELINE configs[4]: the two generators
         run on reduced-precision channels-last images through tgsr_amd.lp_pipeline.LpExecutor; inputs, the text encoder
-        and every returned tensor stay fp32)."""
+        and every returned tensor stay fp32).  branch_num: None = cfg.TREE.BRANCH_NUM, read at construction like the
+        reference does."""
         self.dtype = dtype
         self._lp = None
+        self.branch_num = int(cfg.TREE.BRANCH_NUM if branch_num is None else branch_num)
+        if self.branch_num == 4:                                        # trainer_objective.py:74-87
+            from .model import G_SR_NET_low, NetG_highweight
+        else:
+            from .models16 import G_SR_NET_low, NetG_highweight
         self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM)
         self.netGL = G_SR_NET_low()
         self.netGH = NetG_highweight(weightmap=False, low=low)
@@ -58,13 +65,16 @@ class SRPipeline:
             self._lp = LpExecutor(self.netGL, self.netGH, dtype)
 
     def load_state_dicts(self, sd_E=None, sd_GL=None, sd_GH=None):
-        """strict for E and GL; GH tolerates only a missing `a` (never saved by the reference, model.py:246-248)."""
+        """strict for E and GL; the x8 GH tolerates only a missing `a` (never saved by the reference, model.py:246-248);
+        the x16 GH registers `a` as a parameter (models16.py:126) and loads it."""
         if sd_E is not None:
             self.text_encoder.load_state_dict(sd_E, strict=True)
         if sd_GL is not None:
             self.netGL.load_state_dict(sd_GL, strict=True)
         if sd_GH is not None:
-            self.netGH.load_state_dict({k: v for k, v in sd_GH.items() if k != "a"}, strict=True)
+            if self.branch_num == 4:
+                sd_GH = {k: v for k, v in sd_GH.items() if k != "a"}
+            self.netGH.load_state_dict(sd_GH, strict=True)
         return self
 
     # ------------------------------------------------------------------ throughput: stream lanes
