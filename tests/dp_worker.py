@@ -35,7 +35,7 @@ def make_pipeline(tr, device="cuda:0"):
     """Inference pipeline on a COPY of the trainer's initial weights - taken before any training forward, whose
     train-mode BatchNorm updates the running statistics with that rank's shard."""
     from tgsr_amd.trainer import SRPipeline
-    pipe = SRPipeline(41, device=device)
+    pipe = SRPipeline(41, device=device, branch_num=4)
     pipe.netGL.load_state_dict(tr.netGL.state_dict())
     pipe.netGH.load_state_dict(tr.netGH.state_dict())
     pipe.text_encoder.load_state_dict(tr.text_encoder.state_dict())

@@ -56,7 +56,7 @@ def test_pyramid_feeds_the_pipeline(face_weights):
     hr = torch.from_numpy(z["crop_u8"]).to(DEV)[None].repeat(2, 1, 1, 1)
     imgs, bic, imgsblur, bicblur = GpuImagePyramid((32, 64, 128, 256), device=DEV)(hr)
     cap, lens, _LR, _LRb = O.synthetic_batch(2)
-    pipe = SRPipeline(41, device=DEV).load_state_dicts(split_sd(face_weights, "E."), split_sd(face_weights, "GL."),
+    pipe = SRPipeline(41, device=DEV, branch_num=4).load_state_dicts(split_sd(face_weights, "E."), split_sd(face_weights, "GL."),
                                                        split_sd(face_weights, "GH."))
     out = pipe(cap.to(DEV), lens.tolist(), imgs[0], imgsblur[0])
     ref = O.sr_forward(split_sd(face_weights, "E."), split_sd(face_weights, "GL."), split_sd(face_weights, "GH."), cap,

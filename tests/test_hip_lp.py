@@ -188,6 +188,7 @@ def cfg_face():
     cfg_reset()
     cfg.GAN.GF_DIM = 32
     cfg.TEXT.EMBEDDING_DIM = 256
+    cfg.TREE.BRANCH_NUM = 4                  # cfg/eval_*SR_attn2.yml: the x8 generators (trainer_objective.py:74-87)
     yield cfg
     cfg_reset()
 

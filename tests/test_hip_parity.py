@@ -44,6 +44,7 @@ def cfg_small():
     cfg_reset()
     cfg.GAN.GF_DIM = 32
     cfg.TEXT.EMBEDDING_DIM = 64
+    cfg.TREE.BRANCH_NUM = 4
     yield cfg
     cfg_reset()
 
@@ -54,6 +55,7 @@ def cfg_face():
     cfg_reset()
     cfg.GAN.GF_DIM = 32
     cfg.TEXT.EMBEDDING_DIM = 256
+    cfg.TREE.BRANCH_NUM = 4                  # cfg/eval_*SR_attn2.yml: the x8 generators (trainer_objective.py:74-87)
     yield cfg
     cfg_reset()
 

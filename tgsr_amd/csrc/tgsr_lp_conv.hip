@@ -286,6 +286,11 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
   const int y0 = ty * TRL, x0 = tx * 32;                         // low-res origin (unpadded)
+  u32x4 hf[HK > 0 ? HK : 1];                                     // the head's A fragments: fetched now, used after the epilogue
+  if constexpr (HK > 0) {
+#pragma unroll
+    for (int k = 0; k < HK; ++k) hf[k] = *reinterpret_cast<const u32x4*>(a.hw + (k * 64 + lane) * 16);
+  }
   {
     const int64_t rowb = (int64_t)(a.Wi + 2) * a.xcp * 2;
     const char* xb = a.x + (int64_t)b * (a.Hi + 2) * rowb;
@@ -428,15 +433,18 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
     // ---- fused image head on the tile in LDS: output row R (0..7) of the tile lives in the staging region of wave
     // (R >> 2) * 2 + (R & 1), half rr = (R >> 1) & 1, as [64 pixels][64 bytes] with the 16-byte chunk of channels 8 g ..
     // at physical chunk g ^ ((pixel >> 1) & 3): the B fragment of 16 neighbouring pixels x 4 channel groups is one
-    // conflict-free ds_read_b128
-    constexpr int P = HK / 2, NR = 8 + 2 * P, NX = 64 + 2 * P, VP = 68;
+    // conflict-free ds_read_b128.  V image of a wave: [16 rows (c, dx)][VP], column x' + 2P, zero outside [0, 64): the
+    // shift-sum out[c][x] = sum_dx V[(c, dx)][x + dx - P] then needs no bounds test.
+    constexpr int P = HK / 2, NR = 8 + 2 * P, NX = 64 + 2 * P, VP = 76;   // VP >= 64 + 4P; rows 4 apart 16 banks apart
     static_assert(4 * STG_WAVE + 4 * 16 * VP * 4 + COUT * 8 <= TILE_BYTES + NBUF * CHUNK_BYTES, "V images fit behind the tile");
     const int p = lane & 15, g = lane >> 4;
-    u32x4 hf[HK];
-#pragma unroll
-    for (int k = 0; k < HK; ++k) hf[k] = *reinterpret_cast<const u32x4*>(a.hw + (k * 64 + lane) * 16);
-    __builtin_amdgcn_s_barrier();                                // every wave's rows are staged (own lgkmcnt(0) above)
     float* v = reinterpret_cast<float*>(smem + 4 * STG_WAVE) + wave * (16 * VP);
+    for (int o = lane; o < 16 * 4 * P; o += 64) {                // the 2P zero columns on either side, once
+      const int r = o / (4 * P), q = o - r * (4 * P);
+      v[r * VP + (q < 2 * P ? q : 64 + q)] = 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                // every wave's rows are staged (own lgkmcnt(0) above)
     float* pb = a.hpart + ((int64_t)(b * a.tiles_y + ty) * a.tiles_x + tx) * (3 * NR * NX);
 #pragma unroll 1
     for (int yo = wave - P; yo < 8 + P; yo += 4) {               // this wave's output rows (tile-local, -P .. 7 + P)
@@ -458,21 +466,25 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
           }
         }
       }
-      // D[row = 4 g + i][col = p] -> V image [16 rows (c, dx)][64 columns] of this wave, then the shift-sum over dx
+      // D[row = 4 g + i][col = p] -> V image, then the shift-sum over dx: lane = output column xi (and xi + 64)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[(4 * g + i) * VP + 16 * j + p] = acc[j][i];
+        for (int i = 0; i < 4; ++i) v[(4 * g + i) * VP + 2 * P + 16 * j + p] = acc[j][i];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private image: no barrier
-      for (int o = lane; o < 3 * NX; o += 64) {
-        const int c = o / NX, xi = o - c * NX;                   // output column x = xi - P (tile-local)
-        float sum = 0.f;
+      float* prow = pb + (yo + P) * NX;
 #pragma unroll
-        for (int dx = 0; dx < HK; ++dx) {
-          const int xs = xi + dx - 2 * P;                        // source column x + dx - P
-          if ((unsigned)xs < 64u) sum += v[(c * HK + dx) * VP + xs];
+      for (int rnd = 0; rnd < 2; ++rnd) {
+        const int xi = lane + 64 * rnd;                          // output column x = xi - P (tile-local)
+        if (xi < NX) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            float sum = 0.f;
+#pragma unroll
+            for (int dx = 0; dx < HK; ++dx) sum += v[(c * HK + dx) * VP + xi + dx];   // V column (x + dx - P) + 2P
+            prow[c * (NR * NX) + xi] = sum;
+          }
         }
-        pb[(c * NR + yo + P) * NX + xi] = sum;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the V image is rewritten for the next row
     }
@@ -498,6 +510,9 @@ struct LpCombineArgs {
   float alpha;
   int64_t total;
 };
+
+// tanh(v) = 1 - 2 / (exp(2v) + 1): absolute error ~1e-7, saturates cleanly (the fp32 heads' form, tgsr_conv_to3.hip)
+__device__ __forceinline__ float lp_fast_tanh(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v) + 1.f); }
 
 template <int P>
 __device__ __forceinline__ void head_gather(const float* part, int b, int y, int x, int tiles_y, int tiles_x, float (&o)[3]) {
@@ -533,7 +548,7 @@ __global__ __launch_bounds__(256) void lp_head_combine_kernel(LpCombineArgs a) {
     head_gather<1>(sc.pl, b, y, x, sc.tiles_y, sc.tiles_x, lo);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      if (a.low_tanh) lo[c] = tanhf(lo[c]);
+      if (a.low_tanh) lo[c] = lp_fast_tanh(lo[c]);
       sc.low[oi + c * HW] = lo[c];
     }
   } else {
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(256) void lp_head_combine_kernel(LpCombineArgs a) {
     float hi[3];
     head_gather<2>(sc.ph, b, y, x, sc.tiles_y, sc.tiles_x, hi);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) sc.high[oi + c * HW] = tanhf(hi[c]) + a.alpha * lo[c];
+    for (int c = 0; c < 3; ++c) sc.high[oi + c * HW] = lp_fast_tanh(hi[c]) + a.alpha * lo[c];
   }
 }
 

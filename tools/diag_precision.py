@@ -14,7 +14,7 @@ cap, lens = torch.from_numpy(g["captions"]), g["cap_lens"].tolist()
 LR, LRb = torch.from_numpy(g["LR"]), torch.from_numpy(g["LRb"])
 r64 = O.sr_forward(sd("E.", torch.float64), sd("GL.", torch.float64), sd("GH.", torch.float64), cap, lens, LR.double(), LRb.double())
 cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 256
-p = SRPipeline(41, device="cuda").load_state_dicts(sd("E."), sd("GL."), sd("GH."))
+p = SRPipeline(41, device="cuda", branch_num=4).load_state_dicts(sd("E."), sd("GL."), sd("GH."))
 r = p(cap.cuda(), lens, LR.cuda(), LRb.cuda())
 for k in ("fake", "fine"):
     for i in range(3):

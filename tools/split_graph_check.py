@@ -10,7 +10,7 @@ cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM = 32, 256
 from tgsr_amd.synthetic import synthetic_batch
 from tgsr_amd.trainer import SRPipeline, caption_mask
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-pipe = SRPipeline(41, device="cuda", dtype="bf16")
+pipe = SRPipeline(41, device="cuda", dtype="bf16", branch_num=4)
 cap, lens, LR, LRb = synthetic_batch(B, seed=100)
 cap, LR, LRb, lens = cap.cuda(), LR.cuda(), LRb.cuda(), lens.tolist()
 with torch.no_grad():

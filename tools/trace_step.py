@@ -15,7 +15,7 @@ cfg.TEXT.EMBEDDING_DIM = 256
 cfg.TREE.BRANCH_NUM = 4
 cfg.TREE.BASE_SIZE = 32
 dev = torch.device("cuda:0")
-pipe = SRPipeline(41, device=dev, low="lr", overlap=False)
+pipe = SRPipeline(41, device=dev, low="lr", overlap=False, branch_num=4)
 w = bench.load_weights()
 if w is not None:
     pipe.load_state_dicts(w["E."], w["GL."], w["GH."])
