@@ -88,3 +88,110 @@ def test_filter_packed_for_another_channel_count_raises():
     xi = lp.from_nchw(x[:, :64].contiguous(), "bf16")
     with pytest.raises(TgsrError):
         lp.conv3x3(xi, lp.pack_conv3x3_weight(w, "bf16"), 64, 64, None, None)
+
+
+def test_opcheck_training_text_damsm_and_lp_operators():
+    """Every `torch.ops.tgsr.*` entry point of the training / text / DAMSM / reduced-precision paths: schema (declared
+    mutations are the only ones) and fake kernel (shapes, dtypes) through torch.library.opcheck; the differentiable ones
+    also their autograd registration."""
+    from tgsr_amd import lp
+    T = torch.ops.tgsr
+    g = torch.Generator().manual_seed(0)
+    R = lambda *s: torch.randn(*s, generator=g).to(DEV)                 # noqa: E731
+    basic = ("test_schema", "test_faketensor")
+    full = basic + ("test_autograd_registration",)
+    B, Cc, H, W = 2, 64, 8, 16
+    raw = R(B, Cc, H, W)
+    gam, bet, rm, rv = R(Cc), R(Cc), torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    chk = torch.library.opcheck
+    chk(T.bn_train_fwd.default, (raw, gam, bet, 1e-5, 0.1, rm, rv, 1, None, nbt), test_utils=basic)
+    out, stats = T.bn_train_fwd(raw, gam, bet, 1e-5, 0.1, rm, rv, 1, None, nbt)
+    chk(T.bn_train_fwd_out.default, (raw, gam, bet, 1e-5, 0.1, rm, rv, 2, nbt, torch.empty_like(raw), torch.empty(4, Cc, device=DEV)),
+        test_utils=basic)
+    chk(T.bn_train_bwd.default, (R(B, Cc // 2, H, W), raw, stats, 1, torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV), None),
+        test_utils=basic)
+    x32 = R(B, 32, H, W)
+    for up in (False, True):
+        dr = R(B, Cc, H * (2 if up else 1), W * (2 if up else 1))
+        chk(T.conv3x3_wgrad.default, (dr, x32, up, True, torch.empty(Cc, 32, 3, 3, device=DEV)), test_utils=basic)
+    chk(T.conv3x3_wgrad.default, (R(B, 3, H, W), x32, False, True, torch.empty(3, 32, 3, 3, device=DEV)), test_utils=basic)
+    chk(T.sumpool2x2.default, (raw,), test_utils=basic)
+    w33 = R(Cc, 32, 3, 3) / 17.0
+    chk(T.pack_conv3x3_weight.default, (w33, False), test_utils=basic)
+    chk(T.pack_conv3x3_weight.default, (w33, True), test_utils=basic)
+    chk(T.pack_wino_weight.default, (w33, True, False), test_utils=basic)
+    chk(T.pack_wino_weight.default, (w33, False, True), test_utils=basic)
+    chk(T.pack_upwino_weight.default, (w33, False), test_utils=basic)
+    chk(T.upwino.default, (x32, T.pack_upwino_weight(w33, False), Cc, None, None, False), test_utils=basic)
+    xg, wg = R(2, 256, 4, 4), R(256, 256, 3, 3) / 48.0
+    chk(T.conv3x3_gemm.default, (xg, wg), test_utils=basic)
+    chk(T.conv3x3_gemm_dgrad.default, (xg, wg), test_utils=basic)
+    chk(T.conv3x3_gemm_wgrad_out.default, (xg, xg, torch.empty_like(wg)), test_utils=basic)
+    chk(T.conv4x4s2_wgrad_out.default, (R(2, 16, 4, 4), R(2, 8, 8, 8), torch.empty(16, 8, 4, 4, device=DEV)), test_utils=basic)
+    # word attention backward, projections
+    h, words, wc = R(2, 32, 8, 8), R(2, 48, 7), R(32, 48, 1, 1)
+    src = T.word_project(words, [wc])[0]
+    mask = torch.zeros(2, 7, dtype=torch.bool, device=DEV)
+    chk(T.word_project.default, (words, [wc, wc]), test_utils=basic)
+    chk(T.word_attention_bwd.default, (h, src, mask, False, 7, R(2, 32, 8, 8)), test_utils=basic)
+    # differentiable GEMM / dot heads
+    chk(T.rowdot.default, (R(3, 512).requires_grad_(True), R(512).requires_grad_(True), R(1).requires_grad_(True)), test_utils=full)
+    chk(T.rowdot_bwd.default, (R(3), R(3, 512), R(512), True, True), test_utils=basic)
+    chk(T.linear.default, (R(4, 64).requires_grad_(True), R(32, 64).requires_grad_(True), R(32).requires_grad_(True)), test_utils=full)
+    chk(T.conv1x1.default, (R(2, 64, 5, 5).requires_grad_(True), R(32, 64, 1, 1).requires_grad_(True)), test_utils=full)
+    # text encoder
+    Hh, ntok = 32, 20
+    emb, w_ih, w_hh = R(ntok, 24) * 0.1, R(2, 4 * Hh, 24) * 0.2, R(2, 4 * Hh, Hh) * 0.2
+    b_ih, b_hh = R(2, 4 * Hh) * 0.1, R(2, 4 * Hh) * 0.1
+    cap = torch.randint(1, ntok, (3, 6), generator=g).to(DEV)
+    lens = [6, 4, 2]
+    chk(T.lstm_gate_table.default, (emb, w_ih, b_ih, b_hh), test_utils=basic)
+    chk(T.bilstm_table.default, (cap, lens, T.lstm_gate_table(emb, w_ih, b_ih, b_hh), w_hh), test_utils=basic)
+    xe = R(3, 6, 24)
+    chk(T.bilstm_train.default, (xe, w_ih, w_hh, b_ih, b_hh, lens), test_utils=basic)
+    wds, sent, acts = T.bilstm_train(xe, w_ih, w_hh, b_ih, b_hh, lens)
+    chk(T.bilstm_bwd.default, (lens, w_hh, acts, wds, torch.randn_like(wds), torch.randn_like(sent)), test_utils=basic)
+    # DAMSM
+    feats, wemb = R(3, 64, 5, 5), R(3, 64, 6)
+    chk(T.damsm_words.default, (feats, wemb, lens, 4.0, 5.0), test_utils=basic)
+    chk(T.damsm_words_bwd.default, (feats, wemb, lens, 4.0, 5.0, R(3, 3)), test_utils=basic)
+    chk(T.func_attention.default, (wemb, feats, 4.0), test_utils=basic)
+    chk(T.ca_net.default, (R(3, 64), R(40, 64), R(40), 10, R(3, 10)), test_utils=basic)
+    chk(T.ca_net.default, (R(3, 64), R(40, 64), R(40), 10, None), test_utils=basic)
+    chk(T.to_uint8.default, (R(2, 3, 8, 8),), test_utils=basic)
+    # reduced-precision path (lp images)
+    xi = lp.from_nchw(R(2, 64, 8, 32), "bf16", cpitch=64)
+    wp = lp.pack_conv3x3_weight(R(64, 64, 3, 3) / 24.0, "bf16")
+    sc, sh = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    chk(T.lp_conv3x3.default, (xi, wp, 64, 64, sc, sh, True, False, None, 0, lp.new_image(2, 8, 32, 64, "bf16", DEV), 32), test_utils=basic)
+    chk(T.lp_conv3x3.default, (xi, wp, 64, 64, sc, sh, False, False, xi, 0, lp.new_image(2, 8, 32, 64, "bf16", DEV), 0), test_utils=basic)
+    wu = lp.pack_upconv_weight(R(64, 64, 3, 3) / 24.0, "bf16")
+    chk(T.lp_upconv_glu.default, (xi, wu, 64, 64, sc, sh, lp.new_image(2, 16, 64, 32, "bf16", DEV), 0), test_utils=basic)
+    p3 = lp.pack_to3_weight(R(3, 32, 3, 3) / 17.0, "bf16")
+    p5 = lp.pack_to3_weight(R(3, 32, 5, 5) / 28.0, "bf16")
+    part3 = torch.empty(lp.head_partial_elems(2, 16, 64, 3), device=DEV)
+    part5 = torch.empty(lp.head_partial_elems(2, 16, 64, 5), device=DEV)
+    chk(T.lp_upconv_glu_head.default, (xi, wu, 64, 64, sc, sh, p3, 3, part3, lp.new_image(2, 16, 64, 32, "bf16", DEV), 0), test_utils=basic)
+    chk(T.lp_upconv_glu_head.default, (xi, wu, 64, 64, sc, sh, p5, 5, part5, None, 0), test_utils=basic)
+    T.lp_upconv_glu_head(xi, wu, 64, 64, sc, sh, p3, 3, part3, None, 0)
+    T.lp_upconv_glu_head(xi, wu, 64, 64, sc, sh, p5, 5, part5, None, 0)
+    low, high = torch.empty(2, 3, 16, 64, device=DEV), torch.empty(2, 3, 16, 64, device=DEV)
+    chk(T.lp_head_combine.default, ([16], [64], [part3], [part5], [low], [high], False, 0.5), test_utils=basic)
+    chk(T.lp_stem.default, (R(2, 3, 8, 32), R(64, 3, 3, 3) / 5.0, sc, sh, lp.new_image(2, 8, 32, 64, "bf16", DEV), 0), test_utils=basic)
+    h32 = lp.from_nchw(R(2, 32, 8, 32), "bf16", cpitch=64)
+    chk(T.lp_conv_to3.default, (h32, p5, 5, True, R(2, 3, 8, 32), 0.5), test_utils=basic)
+    chk(T.lp_word_attention.default, (h32, R(2, 32, 32), None, 7, False, 32), test_utils=basic)
+
+
+def test_only_the_tensor_wrappers_touch_the_c_abi():
+    """`_lib.lib()` (the ctypes handle of libtgsr_hip.so) is used by tgsr_amd/ops.py and tgsr_amd/lp.py only: modules,
+    autograd formulas, losses, trainers and the lp executor go through torch.ops.tgsr.* (which sit on those wrappers)."""
+    import glob
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tgsr_amd")
+    for path in glob.glob(os.path.join(root, "**", "*.py"), recursive=True):
+        if os.path.basename(path) in ("ops.py", "lp.py", "_lib.py"):
+            continue
+        src = open(path).read()
+        assert "_lib.lib()" not in src and "lib()." not in src, path

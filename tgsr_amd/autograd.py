@@ -8,13 +8,11 @@ The reference trains through torch autograd over nn.Conv2d / nn.BatchNorm2d(trai
         backward: tgsr_bn_train_bwd (GLU', BN') -> data gradient = the same conv kernels on flipped/transposed
                   weights (+ tgsr_sumpool2x2 through the up-sample) and tgsr_conv3x3_wgrad
 """
-import contextlib
-
 import torch
 
-from . import _lib, ops
-from ._lib import TgsrError, check
-from .ops import _p, _stream
+from . import custom_ops as C
+from . import ops
+from ._lib import TgsrError
 
 
 def _dgrad_weight(w: torch.Tensor) -> torch.Tensor:
@@ -87,55 +85,29 @@ def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgr
     from . import util
     Cout = weight.shape[1] if dgrad else weight.shape[0]
     if util.WINOGRAD and not upsample and util._wino_pays(x, Cout, None, None):
-        return ops.conv3x3_wino(x, ops.pack_wino_weight(weight, glu=False, dgrad=dgrad), Cout, None, None, residual=residual)
+        return C.conv3x3_wino(x, C.pack_wino_weight(weight, False, dgrad), Cout, None, None, False, residual)
     if util.WINOGRAD and upsample and ops.upwino_supported(x, Cout):
         assert not dgrad and residual is None
-        return ops.upwino_glu(x, ops.pack_upwino_weight(weight, glu=False), Cout, None, None, glu=False)
-    return ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight, dgrad=dgrad), Cout, None, None, glu=False, upsample=upsample,
-                             residual=residual)
+        return C.upwino(x, C.pack_upwino_weight(weight, False), Cout, None, None, False)
+    return C.conv3x3_fused(x, C.pack_conv3x3_weight(weight, dgrad), Cout, None, None, False, upsample, residual)
 
 
 def _cba_forward(x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps, nbt):
     """conv3x3 (raw) -> BatchNorm batch statistics -> normalise (+ GLU | + residual).  Returns (out, raw, stats)."""
-    L = _lib.lib()
-    B, Cin, H, W = x.shape
-    Cout = weight.shape[0]
     raw = _conv_raw(x, weight.detach(), upsample)
-    Ho, Wo = raw.shape[2], raw.shape[3]
-    HW = Ho * Wo
-    dev = x.device
-    nsplit = L.tgsr_bn_train_nsplit(B, Cout, HW)
-    ws = torch.empty(Cout * nsplit * 4, dtype=torch.float32, device=dev)
-    stats = torch.empty(4, Cout, dtype=torch.float32, device=dev)      # mean, invstd, scale, shift
-    co = Cout // 2 if glu else Cout
-    out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=dev)
-    res = None if residual is None else residual.contiguous()
-    rc = L.tgsr_bn_train_fwd(_p(raw), B, Cout, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
-                             float(momentum), _p(running_mean), _p(running_var), 1 if glu else 0, _p(res),
-                             0 if res is None else co * HW, _p(ws), _p(stats[0]), _p(stats[1]), _p(stats[2]),
-                             _p(stats[3]), _p(out), co * HW, _p(nbt), _stream())
-    check(rc, "tgsr_bn_train_fwd")
+    out, stats = C.bn_train_fwd(raw, gamma.detach(), beta.detach(), float(eps), float(momentum), running_mean, running_var,
+                                1 if glu else 0, residual, nbt)
     return out, raw, stats
 
 
 def _cba_backward(x, weight, raw, stats, gamma, beta, glu, upsample, dout, need_dx, need_dw, dx_addend=None):
     """Backward of _cba_forward: (dx, dw, dgamma, dbeta).  `dx_addend` (the gradient arriving at x through a skip
     connection) is added in the data-gradient conv's epilogue instead of by a separate elementwise kernel."""
-    L = _lib.lib()
-    dout = dout.contiguous()
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
-    Ho, Wo = raw.shape[2], raw.shape[3]
-    HW = Ho * Wo
     dev = x.device
-    co = Cout // 2 if glu else Cout
-    nsplit = L.tgsr_bn_train_nsplit(B, co, HW)
-    ws = torch.empty(co * nsplit * 4, dtype=torch.float32, device=dev)
-    draw = torch.empty_like(raw)
     dgamma, dbeta = _grad_out(gamma, (Cout,), dev), _grad_out(beta, (Cout,), dev)
-    rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, Cout, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]),
-                             1 if glu else 0, _p(ws), _p(ws), _p(draw), _p(dgamma), _p(dbeta), _stream())
-    check(rc, "tgsr_bn_train_bwd")
+    draw = C.bn_train_bwd(dout.contiguous(), raw, stats, 1 if glu else 0, dgamma, dbeta, None)
     dx = dw = None
     if need_dx:
         cpad = (Cin + 31) // 32 * 32                                  # the kernel tiles 32 output channels
@@ -148,8 +120,7 @@ def _cba_backward(x, weight, raw, stats, gamma, beta, glu, upsample, dout, need_
         else:
             dxu = _conv_raw(draw, weight.detach(), dgrad=True, residual=None if upsample else dx_addend)
         if upsample:
-            dx = torch.empty(B, Cin, H, W, dtype=torch.float32, device=dev)
-            check(L.tgsr_sumpool2x2(_p(dxu), B * Cin, H, W, _p(dx), _stream()), "tgsr_sumpool2x2")
+            dx = C.sumpool2x2(dxu)
             if dx_addend is not None:
                 dx = dx + dx_addend
         else:
@@ -162,33 +133,9 @@ def _cba_backward(x, weight, raw, stats, gamma, beta, glu, upsample, dout, need_
         adopted = dw._base is not None and weight.grad is None and not torch.is_grad_enabled()
         if adopted and wgrad_stream(dev) is not None:
             _ADOPTED.append((weight, dw.data_ptr()))
-
-        def wgrad():
-            e0 = ops._ev() if ops.profile is not None else None
-            if upsample and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
-                # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the
-                # up-sampled grid)
-                kname = "upwino_wgrad_kernel"
-                wws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
-                rc = L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
-                check(rc, "tgsr_upwino_wgrad")
-            elif (not upsample) and util.WINOGRAD and Cout % 64 == 0 and Cin % 32 == 0:
-                # plain conv: 16 Winograd positions per 2x2 output tile (2.25x fewer multiplies than 9 taps per pixel)
-                kname = "wino_wgrad_kernel"
-                wws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
-                rc = L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(wws), _p(dw), _stream())
-                check(rc, "tgsr_wino_wgrad")
-            else:
-                kname = "conv3x3_wgrad_kernel"
-                n = L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0)
-                wws = torch.empty(n, dtype=torch.float32, device=dev)
-                rc = L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0,
-                                          _p(wws), _p(dw), _stream())
-                check(rc, "tgsr_conv3x3_wgrad")
-            if ops.profile is not None:      # direct-form FLOPs of the weight gradient: one MAC per (output pixel, tap, ci, co)
-                ops.profile.append((kname, 2.0 * B * HW * Cout * Cin * 9, 4.0 * (B * Cin * H * W + B * Cout * HW + Cout * Cin * 9),
-                                    e0, ops._ev()))
-        on_wgrad_stream(dev, (draw, x), wgrad, adopted)
+        # upBlock: 9 Winograd positions on the low-resolution pixels (4x fewer multiplies than 9 taps on the up-sampled
+        # grid); plain conv: 16 positions per 2x2 output tile (2.25x fewer); else the direct 9-tap form (ops.conv3x3_wgrad)
+        on_wgrad_stream(dev, (draw, x), lambda: C.conv3x3_wgrad(draw, x, upsample, util.WINOGRAD, dw), adopted)
     return dx, dw, dgamma, dbeta
 
 
@@ -293,23 +240,24 @@ class DownConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, leaky):
-        out = ops.conv4x4s2(x, weight, leaky=leaky)
+        out = C.conv4x4s2(x, weight.detach(), leaky)
         ctx.save_for_backward(x, weight, out if leaky else None)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, out = ctx.saved_tensors
-        g = dy.contiguous() if out is None else ops.leaky_relu_bwd(dy, out)
-        dx = ops.conv4x4s2_dgrad(g, weight, x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
-        dw = ops.conv4x4s2_wgrad(g, x) if ctx.needs_input_grad[1] else None
+        g = dy.contiguous() if out is None else C.leaky_relu_bwd(dy.contiguous(), out)
+        dx = C.conv4x4s2_dgrad(g, weight.detach(), x.shape[2], x.shape[3]) if ctx.needs_input_grad[0] else None
+        dw = C.conv4x4s2_wgrad(g, x.contiguous()) if ctx.needs_input_grad[1] else None
         return dx, dw, None
 
 
 class ConvBnLeaky(torch.autograd.Function):
     """conv -> BatchNorm2d(batch statistics) -> LeakyReLU(0.2) with `kind` = "down" (conv4x4 stride 2: downBlock,
     util.py:92-98) or "3x3" (the discriminators' Block3x3_leakRelu).  BatchNorm + activation forward / backward =
-    tgsr_bn_train_fwd / _bwd(act = 2); the 3x3 convolution and its gradients are the generator's fp32 kernels."""
+    tgsr::bn_train_fwd_out / tgsr::bn_train_bwd (act = 2); the 3x3 convolution and its gradients are the generator's
+    fp32 kernels."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, momentum, eps, nbt=None, groups=None):
@@ -317,30 +265,23 @@ class ConvBnLeaky(torch.autograd.Function):
         update the running statistics one after the other, in order) - several forward passes of the module (real /
         fake / mismatched images of discriminator_loss) as one convolution launch, one data-gradient launch and one
         weight-gradient launch, numerically the passes run one by one."""
-        L = _lib.lib()
         x = x.contiguous()
         if kind == "down":
-            raw = ops.conv4x4s2(x, weight)
+            raw = C.conv4x4s2(x, weight.detach(), False)
         elif ops.conv3x3_gemm_pays(x.shape[1], weight.shape[0], x.shape[2], x.shape[3]):
-            raw = ops.conv3x3_gemm(x, weight)                 # many channels on 4x4 pixels: the implicit-GEMM form
+            raw = C.conv3x3_gemm(x, weight.detach())          # many channels on 4x4 pixels: the implicit-GEMM form
         else:
-            raw = ops.conv3x3_fused(x, ops.pack_conv3x3_weight(weight), weight.shape[0], None, None)
-        B, C, Ho, Wo = raw.shape
-        HW, dev = Ho * Wo, x.device
+            raw = C.conv3x3_fused(x, C.pack_conv3x3_weight(weight.detach(), False), weight.shape[0], None, None, False, False, None)
+        B, Cc = raw.shape[0], raw.shape[1]
         groups = (B,) if groups is None else tuple(int(g) for g in groups)
         if sum(groups) != B or min(groups) < 1:
             raise TgsrError("ConvBnLeaky: groups %s do not partition a batch of %d" % (groups, B))
-        stats = torch.empty(len(groups), 4, C, dtype=torch.float32, device=dev)
+        stats = torch.empty(len(groups), 4, Cc, dtype=torch.float32, device=x.device)
         out = torch.empty_like(raw)
         o = 0
         for gi, n in enumerate(groups):
-            nsplit = L.tgsr_bn_train_nsplit(n, C, HW)
-            ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
-            st = stats[gi]
-            rc = L.tgsr_bn_train_fwd(_p(raw[o:o + n]), n, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
-                                     float(momentum), _p(running_mean), _p(running_var), 2, None, 0, _p(ws), _p(st[0]),
-                                     _p(st[1]), _p(st[2]), _p(st[3]), _p(out[o:o + n]), C * HW, _p(nbt), _stream())
-            check(rc, "tgsr_bn_train_fwd")
+            C.bn_train_fwd_out(raw[o:o + n], gamma.detach(), beta.detach(), float(eps), float(momentum), running_mean, running_var,
+                               2, nbt, out[o:o + n], stats[gi])
             o += n
         ctx.save_for_backward(x, weight, raw, stats)
         ctx.kind = kind
@@ -350,54 +291,49 @@ class ConvBnLeaky(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        L = _lib.lib()
         x, weight, raw, stats = ctx.saved_tensors
         dout = dout.contiguous()
-        B, C, Ho, Wo = raw.shape
-        HW, dev = Ho * Wo, x.device
+        B, Cc = raw.shape[0], raw.shape[1]
+        dev = x.device
         draw = torch.empty_like(raw)
         gamma, beta = ctx.bn_params
-        dgamma, dbeta = _grad_out(gamma, (C,), dev), _grad_out(beta, (C,), dev)
+        dgamma, dbeta = _grad_out(gamma, (Cc,), dev), _grad_out(beta, (Cc,), dev)
         o = 0
         for gi, n in enumerate(ctx.groups):
-            nsplit = L.tgsr_bn_train_nsplit(n, C, HW)
-            ws = torch.empty(C * nsplit * 4, dtype=torch.float32, device=dev)
-            st = stats[gi]
-            dg, db = (dgamma, dbeta) if gi == 0 else (torch.empty(C, dtype=torch.float32, device=dev),
-                                                      torch.empty(C, dtype=torch.float32, device=dev))
-            rc = L.tgsr_bn_train_bwd(_p(dout[o:o + n]), _p(raw[o:o + n]), n, C, HW, _p(st[2]), _p(st[3]), _p(st[0]),
-                                     _p(st[1]), 2, _p(ws), _p(ws), _p(draw[o:o + n]), _p(dg), _p(db), _stream())
-            check(rc, "tgsr_bn_train_bwd")
+            dg, db = (dgamma, dbeta) if gi == 0 else (torch.empty(Cc, dtype=torch.float32, device=dev),
+                                                      torch.empty(Cc, dtype=torch.float32, device=dev))
+            C.bn_train_bwd(dout[o:o + n], raw[o:o + n], stats[gi], 2, dg, db, draw[o:o + n])
             if gi:                                           # the groups' contributions in order, like separate passes
                 dgamma += dg
                 dbeta += db
             o += n
         dx = dw = None
         Cin, H, W = x.shape[1], x.shape[2], x.shape[3]
+        w = weight.detach()
         if ctx.kind == "down":
             if ctx.needs_input_grad[0]:
-                dx = ops.conv4x4s2_dgrad(draw, weight, H, W)
+                dx = C.conv4x4s2_dgrad(draw, w, H, W)
             if ctx.needs_input_grad[1]:
-                dw = ops.conv4x4s2_wgrad(draw, x, out=_grad_out(weight, weight.shape, dev))
-        elif ops.conv3x3_gemm_pays(Cin, C, H, W):
+                dw = _grad_out(weight, weight.shape, dev)
+                C.conv4x4s2_wgrad_out(draw, x, dw)
+        elif ops.conv3x3_gemm_pays(Cin, Cc, H, W):
             if ctx.needs_input_grad[0]:
-                dx = ops.conv3x3_gemm_dgrad(draw, weight)
+                dx = C.conv3x3_gemm_dgrad(draw, w)
             if ctx.needs_input_grad[1]:
-                dw = ops.conv3x3_gemm_wgrad(draw, x, out=_grad_out(weight, weight.shape, dev))
+                dw = _grad_out(weight, weight.shape, dev)
+                C.conv3x3_gemm_wgrad_out(draw, x, dw)
         else:
             if ctx.needs_input_grad[0]:
-                wT = _dgrad_weight(weight.detach())
+                wT = _dgrad_weight(w)
                 cpad = (Cin + 31) // 32 * 32
                 if cpad != Cin:
-                    wT = torch.cat((wT, wT.new_zeros(cpad - Cin, C, 3, 3)), 0)
-                dx = ops.conv3x3_fused(draw, ops.pack_conv3x3_weight(wT), cpad, None, None)
+                    wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cc, 3, 3)), 0)
+                dx = C.conv3x3_fused(draw, C.pack_conv3x3_weight(wT, False), cpad, None, None, False, False, None)
                 if cpad != Cin:
                     dx = dx[:, :Cin].contiguous()
             if ctx.needs_input_grad[1]:
                 dw = torch.empty_like(weight)
-                wws = torch.empty(L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, C, H, W, 0), dtype=torch.float32, device=dev)
-                check(L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, C, 0, _p(wws), _p(dw), _stream()),
-                      "tgsr_conv3x3_wgrad")
+                C.conv3x3_wgrad(draw, x, False, False, dw)
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -413,51 +349,44 @@ def conv_bn_leaky_train(x, conv, bn, kind, groups=None):
 
 
 class ConvTo3(torch.autograd.Function):
-    """KxK conv to 3 channels [+ tanh + alpha * addend] (the image heads), forward and backward on HIP."""
+    """KxK conv to 3 channels [+ tanh + alpha * addend] (the image heads) with `alpha` possibly a trainable 1-element
+    tensor (models16.NetG_highweight's `a`, models16.py:126): tgsr::conv_to3 / tgsr::conv_to3_bwd + d/da = sum(dy * addend)."""
 
     @staticmethod
     def forward(ctx, x, weight, addend, tanh_axpy, alpha):
-        """alpha: python float, or a 1-element tensor (models16.NetG_highweight's trainable `a`, models16.py:126)."""
         ctx.alpha_is_tensor = torch.is_tensor(alpha)
         alpha_f = float(alpha.detach().item()) if ctx.alpha_is_tensor else float(alpha)
         if addend is not None:
             addend = addend.contiguous()     # backward hands the saved tensor's raw pointer to the kernel as dense NCHW
-        out = ops.conv_to3(x, weight, tanh_axpy=tanh_axpy, addend=addend, alpha=alpha_f)
+        with torch.no_grad():
+            out = C.conv_to3(x, weight.detach(), tanh_axpy, addend, alpha_f)
         ctx.save_for_backward(x, weight, out if tanh_axpy else None, addend)
         ctx.cfg = (tanh_axpy, alpha_f)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        L = _lib.lib()
         x, weight, out, addend = ctx.saved_tensors
         tanh_axpy, alpha = ctx.cfg
         dy = dy.contiguous()
-        x = x.contiguous()
-        B, Cin, H, W = x.shape
-        K = weight.shape[2]
-        dev = x.device
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dx = torch.empty_like(x) if need_dx else None
-        dw = torch.empty_like(weight) if need_dw else None
-        ws = torch.empty(L.tgsr_conv_to3_bwd_ws_elems(B, Cin, H, W, K), dtype=torch.float32, device=dev) if need_dw else None
-        w = weight.detach().contiguous()
-        rc = L.tgsr_conv_to3_bwd(_p(dy), _p(out), _p(addend), alpha, _p(x), Cin * H * W, _p(w), B, Cin, H, W, K,
-                                 _lib.ACT_TANH_AXPY if tanh_axpy else _lib.ACT_NONE, _p(dx), _p(ws), _p(dw), _stream())
-        check(rc, "tgsr_conv_to3_bwd")
+        dx = dw = None
+        if need_dx or need_dw:
+            dx, dw = C.conv_to3_bwd(dy, out, addend, alpha, x.contiguous(), weight.detach(), tanh_axpy, need_dx, need_dw)
         dadd = dy * alpha if (addend is not None and ctx.needs_input_grad[2]) else None
         dalpha = None
         if ctx.alpha_is_tensor and ctx.needs_input_grad[4] and addend is not None:
             dalpha = (dy * addend).sum().reshape(1)              # out = tanh(conv) + alpha * addend
-        return dx, dw, dadd, None, dalpha
+        return (dx if need_dx else None), (dw if need_dw else None), dadd, None, dalpha
 
 
 class WordAttention(torch.autograd.Function):
-    """GlobalAttentionGeneral.forward with a HIP backward for h and conv_context.weight (and words when needed)."""
+    """GlobalAttentionGeneral.forward with a HIP backward for h and conv_context.weight (and words when needed):
+    tgsr::word_attention / tgsr::word_attention_bwd."""
 
     @staticmethod
     def forward(ctx, h, words, w_ctx, mask, correct_mask):
-        c_code, attn = ops.word_attention(h, words, w_ctx, mask, correct_mask)
+        c_code, attn = C.word_attention(h, words, w_ctx.detach(), mask, correct_mask, None)
         ctx.save_for_backward(h, words, w_ctx, mask)
         ctx.correct_mask = correct_mask
         ctx.mark_non_differentiable(attn)
@@ -465,38 +394,26 @@ class WordAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dc, _dattn):
-        L = _lib.lib()
         h, words, w_ctx, mask = ctx.saved_tensors
-        h = h.contiguous()
-        dc = dc.contiguous()
-        B, idf, ih, iw = h.shape
+        B, idf = h.shape[0], h.shape[1]
         cdf, T = words.shape[1], words.shape[2]
-        Q = ih * iw
-        dev = h.device
         w2 = w_ctx.detach().reshape(idf, cdf)
-        src = torch.zeros(B, idf, 32, dtype=torch.float32, device=dev)
+        src = torch.zeros(B, idf, 32, dtype=torch.float32, device=h.device)
         src[:, :, :T] = torch.matmul(w2, words.detach())               # tiny [idf,cdf] x [B,cdf,T] (library GEMM)
-        nch = L.tgsr_word_attention_bwd_chunks(Q)
-        part = torch.empty(B, nch, idf, 32, dtype=torch.float32, device=dev)
-        dh = torch.empty_like(h)
-        m8 = None if mask is None else ops._mask_u8(mask)
-        rc = L.tgsr_word_attention_bwd(_p(h), idf * Q, _p(src), _p(m8), 1 if ctx.correct_mask else 0, B, idf, T, Q,
-                                       _p(dc), _p(dh), _p(part), _stream())
-        check(rc, "tgsr_word_attention_bwd")
-        dsrc = part.sum(1)[:, :, :T]                                      # [B, idf, T]
+        dh, dsrc = C.word_attention_bwd(h.contiguous(), src, mask, ctx.correct_mask, T, dc.contiguous())
         dwords = torch.matmul(w2.t(), dsrc) if ctx.needs_input_grad[1] else None
         dw = torch.einsum("bit,bct->ic", dsrc, words.detach()).reshape(w_ctx.shape) if ctx.needs_input_grad[2] else None
         return dh, dwords, dw, None, None
 
 
 class DamsmWords(torch.autograd.Function):
-    """sim[j][i] of words_loss (losses.py:73-113) with its HIP backward (tgsr_damsm_words_bwd): differentiable w.r.t.
-    the image region features and the word embeddings; the diagonal attention maps are returned without gradient,
-    as the reference only plots them."""
+    """sim[j][i] of words_loss (losses.py:73-113) with its HIP backward: tgsr::damsm_words / tgsr::damsm_words_bwd.
+    Differentiable w.r.t. the image region features and the word embeddings; the diagonal attention maps are returned
+    without gradient, as the reference only plots them."""
 
     @staticmethod
     def forward(ctx, img_features, words_emb, lens, gamma1, gamma2):
-        sim, att = ops.damsm_words_similarity(img_features, words_emb, lens, gamma1, gamma2, need_att=True)
+        sim, att = C.damsm_words(img_features, words_emb, list(lens), float(gamma1), float(gamma2))
         ctx.save_for_backward(img_features, words_emb)
         ctx.meta = (list(lens), float(gamma1), float(gamma2))
         ctx.mark_non_differentiable(att)
@@ -506,23 +423,18 @@ class DamsmWords(torch.autograd.Function):
     def backward(ctx, grad_sim, _grad_att):
         img_features, words_emb = ctx.saved_tensors
         lens, gamma1, gamma2 = ctx.meta
-        g_img, g_words = ops.damsm_words_bwd(img_features, words_emb, lens, gamma1, gamma2, grad_sim)
+        g_img, g_words = C.damsm_words_bwd(img_features.detach(), words_emb.detach(), lens, gamma1, gamma2, grad_sim)
         return g_img, g_words, None, None, None
 
 
-def _gemm_nt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a [M,K] @ b[N,K]^T on the HIP GEMM kernel (tgsr_linear_fwd)."""
-    return ops.linear(a.contiguous(), b.contiguous(), None)
-
-
 class BiLSTM(torch.autograd.Function):
-    """RNN_ENCODER's bidirectional LSTM (util.py:233-260) in training mode: forward = tgsr_bilstm_train_fwd on the
-    embedded (and dropped-out) inputs, backward = tgsr_bilstm_bwd (BPTT, one workgroup per sample and direction) plus
-    four GEMMs for dW_ih, dW_hh and dx.  w_* are the two directions stacked: [2,4H,ninput], [2,4H,H], [2,4H]."""
+    """RNN_ENCODER's bidirectional LSTM (util.py:233-260) in training mode: forward = tgsr::bilstm_train on the embedded
+    (and dropped-out) inputs, backward = tgsr::bilstm_bwd (BPTT, one workgroup per sample and direction) plus four GEMMs
+    (tgsr::linear) for dW_ih, dW_hh and dx.  w_* are the two directions stacked: [2,4H,ninput], [2,4H,H], [2,4H]."""
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, lens):
-        words, sent, acts = ops.bilstm_train_fwd(x, lens, w_ih, w_hh, b_ih, b_hh)
+        words, sent, acts = C.bilstm_train(x, w_ih.detach(), w_hh.detach(), b_ih.detach(), b_hh.detach(), list(lens))
         ctx.save_for_backward(x, w_ih, w_hh, acts, words)
         ctx.lens = list(lens)
         return words, sent
@@ -534,84 +446,40 @@ class BiLSTM(torch.autograd.Function):
         H = w_hh.shape[2]
         if d_words is None:
             d_words = torch.zeros_like(words)
-        dgates, hprev, dbias = ops.bilstm_bwd(ctx.lens, w_hh, acts, words, d_words, d_sent)
+        dgates, hprev, dbias = C.bilstm_bwd(ctx.lens, w_hh.detach(), acts, words, d_words.contiguous(),
+                                            None if d_sent is None else d_sent.contiguous())
+        gemm = C._gemm_nt
         g2 = dgates.reshape(B * Tmax, 8 * H)
         x2 = x.detach().reshape(B * Tmax, K)
-        dw_ih = _gemm_nt(g2.t(), x2.t()).reshape(2, 4 * H, K)                        # dgates^T x
-        dx = _gemm_nt(g2, w_ih.detach().reshape(8 * H, K).t()).reshape(B, Tmax, K)   # dgates W_ih
-        dw_hh = torch.stack([_gemm_nt(dgates[:, :, d].reshape(B * Tmax, 4 * H).t(),
-                                      hprev[:, :, d].reshape(B * Tmax, H).t()) for d in range(2)])
+        dw_ih = gemm(g2.t(), x2.t()).reshape(2, 4 * H, K)                        # dgates^T x
+        dx = gemm(g2, w_ih.detach().reshape(8 * H, K).t()).reshape(B, Tmax, K)   # dgates W_ih
+        dw_hh = torch.stack([gemm(dgates[:, :, d].reshape(B * Tmax, 4 * H).t(), hprev[:, :, d].reshape(B * Tmax, H).t())
+                             for d in range(2)])
         return dx, dw_ih, dw_hh, dbias, dbias.clone(), None
 
 
-class LinearFn(torch.autograd.Function):
-    """y = x W^T + b with all three GEMMs on the HIP kernel (CNN_ENCODER.emb_cnn_code, util.py:301,364)."""
+class LinearFn:
+    """y = x W^T + b with all three GEMMs on the HIP kernel (CNN_ENCODER.emb_cnn_code, util.py:301,364): the differentiable
+    operator tgsr::linear (autograd registered on the op itself)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        return ops.linear(x, w, bias)
+    def apply(x, w, bias):
+        return C.linear(x, w, bias)
+
+
+class RowDot:
+    """out[b] = <x[b, :], w> + bias: the discriminators' logit heads (a 4x4 / stride-4 conv of a 4x4 map to one channel):
+    the differentiable operator tgsr::rowdot."""
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = _gemm_nt(dy, w.detach().t()) if ctx.needs_input_grad[0] else None          # [B,N] @ W [N,K]
-        dw = _gemm_nt(dy.t(), x.detach().t()) if ctx.needs_input_grad[1] else None      # dy^T x
-        return dx, dw, (dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+    def apply(x, w, bias):
+        return C.rowdot(x.contiguous(), w, bias)
 
 
-class RowDot(torch.autograd.Function):
-    """out[b] = <x[b, :], w> + bias: the discriminators' logit heads (a 4x4 / stride-4 conv of a 4x4 map to one
-    channel), tgsr_rowdot_fwd / _bwd."""
+class Conv1x1Fn:
+    """1x1 convolution without bias (CNN_ENCODER.emb_features, util.py:300,367): the differentiable operator tgsr::conv1x1
+    (dx = the same kernel on the transposed weight, dw = one GEMM over all positions)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
-        L = _lib.lib()
-        x = x.contiguous()
-        w = w.detach().contiguous().view(-1)
-        B, K = x.shape
-        out = torch.empty(B, dtype=torch.float32, device=x.device)
-        check(L.tgsr_rowdot_fwd(_p(x), _p(w), _p(None if bias is None else bias.detach()), _p(out), B, K, _stream()),
-              "tgsr_rowdot_fwd")
-        ctx.save_for_backward(x, w)
-        ctx.wshape = None
-        return out
-
-    @staticmethod
-    def backward(ctx, dy):
-        L = _lib.lib()
-        x, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        B, K = x.shape
-        ndx, ndw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dx = torch.empty_like(x) if ndx else None
-        dw = torch.empty(K, dtype=torch.float32, device=x.device) if ndw else None
-        if ndx or ndw:
-            check(L.tgsr_rowdot_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), B, K, _stream()), "tgsr_rowdot_bwd")
-        return dx, dw, (dy.sum().reshape(1) if ctx.needs_input_grad[2] else None)
-
-
-class Conv1x1Fn(torch.autograd.Function):
-    """1x1 convolution without bias (CNN_ENCODER.emb_features, util.py:300,367): forward tgsr_conv1x1_fwd, backward as
-    the same kernel on the transposed weight (dx) and one GEMM over all positions (dw)."""
-
-    @staticmethod
-    def forward(ctx, x, w):
-        ctx.save_for_backward(x, w)
-        return ops.conv1x1(x, w)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        Cout, Cin = w.shape[0], w.shape[1]
-        dy = dy.contiguous()
-        dx = dw = None
-        if ctx.needs_input_grad[0]:                                    # (the frozen trunk's features need none)
-            dx = ops.conv1x1(dy, w.detach().reshape(Cout, Cin).t().contiguous())
-        if ctx.needs_input_grad[1]:
-            dy2 = dy.permute(1, 0, 2, 3).reshape(Cout, -1)             # [Cout, B*S]
-            x2 = x.detach().permute(1, 0, 2, 3).reshape(Cin, -1)       # [Cin,  B*S]
-            dw = _gemm_nt(dy2, x2).reshape(w.shape)
-        return dx, dw
+    def apply(x, w):
+        return C.conv1x1(x, w)

@@ -133,9 +133,15 @@ __global__ __launch_bounds__(16 * TH * KS) void conv_to3_kernel(To3Args a) {
 #pragma unroll
           for (int ky = 0; ky < K; ++ky) {
             const float* row = cur + (c * TR + tyi + ky) * PITCH + 4 * txi;
-            const float4 v0 = *reinterpret_cast<const float4*>(row);
-            const float4 v1 = *reinterpret_cast<const float4*>(row + 4);
-            const float4 v2 = *reinterpret_cast<const float4*>(row + 8);
+            float4 v0 = *reinterpret_cast<const float4*>(row);
+            float4 v1 = *reinterpret_cast<const float4*>(row + 4);
+            float4 v2 = *reinterpret_cast<const float4*>(row + 8);
+            // Keep the three reads whole ds_read_b128s: of v0 / v2 only one (K = 3) or two (K = 5) components are used, and
+            // hipcc then narrows them to ds_read_b32 / _b64 at a 4-word lane stride - 8 distinct banks for 32 lanes, a 4-way
+            // conflict on every one of them (what SQ_LDS_BANK_CONFLICT = 72 % of this kernel's LDS cycles really was); a
+            // whole b128 of a row is conflict free (lane mapping above) and costs 4 LDS cycles instead of 8.
+            asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w));
+            asm volatile("" : "+v"(v2.x), "+v"(v2.y), "+v"(v2.z), "+v"(v2.w));
             const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
             // pixel p (column x0 + 4*txi + p) tap kx reads LDS column 4*txi + 4 + p + kx - P
 #pragma unroll

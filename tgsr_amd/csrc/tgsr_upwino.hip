@@ -33,7 +33,7 @@ struct UpwArgs {
   const float* x;
   int64_t xbs;
   int B, Cin, H, W;        // low-resolution input
-  const float* upack;      // [stage][group][ A: [3 i][4 ci][2 halves][16][4] | B: [3 i][4 ci][2 halves][16][2] ]
+  const float* upack;      // [stage][group][ A: [3 i][4 ci][2 halves][16][4] | B: [3 i][2 halves][4 ci][16][2] ]
   int Cout;
   const float* scale;
   const float* shift;
@@ -43,11 +43,15 @@ struct UpwArgs {
 };
 
 constexpr int kUCK = 4;                                   // input channels per stage
-constexpr int kUTC = 24, kUTR = 4, kUPLANE = kUTR * kUTC; // raw tile: 4 low-res rows x (16 + 8) columns per channel
+constexpr int kUTC = 24, kUTR = 4;                        // raw tile: 4 low-res rows x (16 + 8) columns per channel
+// channel planes 112 words apart (96 used + 16 pad): a ds_read_b32 serves lanes 0-31 = channels lg, lg + 1 x 16 tiles in
+// one cycle only if the two channels sit 16 banks apart (112 = 16 mod 32); at 96 = 0 mod 32 every raw read of the
+// input transform was a 2-way conflict (profiles/r02i_fp32_pmc.csv: 19 % of this kernel's LDS cycles)
+constexpr int kUPLANE = kUTR * kUTC + 16;
 constexpr int kUA = 3 * kUCK * 2 * 16 * 4;                // 1536 floats: (j0cb0, j0cb1, j1cb0, j1cb1) per (i, ci, half, l)
 constexpr int kUB = 3 * kUCK * 2 * 16 * 2;                // 768 floats: (j2cb0, j2cb1)
 constexpr int kUU = kUA + kUB;                            // 2304 floats of U per stage = 9 DMA pieces
-constexpr int kURawN = kUCK * kUPLANE;                    // 384 floats of raw input per stage
+constexpr int kURawN = kUCK * kUPLANE;                    // 448 floats of raw input per stage (64 of them padding)
 constexpr int kURaw = 512;                                // = 2 DMA pieces (waves 0 and 1)
 constexpr int kUV = 3 * kUCK * 16 * 4;                    // V image of one tile row: 768 floats
 constexpr int kUNB = 2;                                    // U buffers: the next stage's U is fetched during this one
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256, 4) void upwino_kernel(UpwArgs a) {
     const int rem = e - c * kUPLANE;
     const int r = rem / kUTC, j = rem - r * kUTC;
     const int gy = y0 - 1 + r, gx = x0 - 4 + j;
-    const bool ok = e < kURawN && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // W % 4 == 0
+    const bool ok = e < kURawN && r < kUTR && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // W % 4 == 0
     if (ok) {
       rptr = xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx);
       rstep = (int)(kUCK * HW);
@@ -194,7 +198,9 @@ __global__ __launch_bounds__(256, 4) void upwino_kernel(UpwArgs a) {
   __syncthreads();
 
   const int ualane = ((lg * 2 + h) * 16 + l15) * 4;       // A part: [i][ci = lg][h][l15][4]
-  const int ublane = kUA + ((lg * 2 + h) * 16 + l15) * 2; // B part: [i][ci = lg][h][l15][2]
+  // B part: [i][h][ci = lg][l15][2] - the two channels of a 32-lane ds_read_b64 group 32 words apart = all 64 banks (with
+  // the half inside the channel, [ci][h], they were 64 words apart: the same banks, a 2-way conflict on every read)
+  const int ublane = kUA + ((h * kUCK + lg) * 16 + l15) * 2;
   const int vlane = (lg * 16 + l15) * 4;                  // V: [i][ci = lg][l15][4]
 
   int b3 = 0;                                             // st % 3
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(256, 4) void upwino_kernel(UpwArgs a) {
 }
 
 // upack[stage][group][ A | B ]:  A [3 i][4 ci][2 halves][16 l][4] = (U[i][0] cb0, U[i][0] cb1, U[i][1] cb0, U[i][1] cb1),
-// B [3 i][4 ci][2 halves][16 l][2] = (U[i][2] cb0, U[i][2] cb1);  U = G' g G'^T with G' = [[1,0,0],[1,1,1],[0,0,1]];
+// B [3 i][2 halves][4 ci][16 l][2] = (U[i][2] cb0, U[i][2] cb1);  U = G' g G'^T with G' = [[1,0,0],[1,1,1],[0,0,1]];
 // cb 0 = value channel grp*32 + half*16 + l, cb 1 = its gate Cout/2 + grp*32 + half*16 + l.
 __global__ void pack_upwino_weight_kernel(const float* __restrict__ wt, float* __restrict__ up, int Cout, int Cin,
                                           int glu, int64_t total) {
@@ -324,7 +330,7 @@ __global__ void pack_upwino_weight_kernel(const float* __restrict__ wt, float* _
       j = q >> 1; cb = q & 1;
     } else {
       const int f = e - kUA;
-      cb = f & 1; l = (f >> 1) & 15; hh = (f >> 5) & 1; ci = (f >> 6) & 3; i = f >> 8;
+      cb = f & 1; l = (f >> 1) & 15; ci = (f >> 5) & 3; hh = (f >> 7) & 1; i = f >> 8;
       j = 2;
     }
     const int co = glu ? (cb ? (Cout >> 1) : 0) + grp * 32 + hh * 16 + l : grp * 64 + hh * 32 + cb * 16 + l;

@@ -23,10 +23,17 @@ _lib = torch.library.Library("tgsr", "DEF")
 _T = torch.Tensor
 
 
+def _refuse_cpu(name):
+    def kernel(*args, **kwargs):
+        raise ops.TgsrError("torch.ops.tgsr.%s got CPU tensors: tgsr_amd ops run only on HIP tensors; there is no CPU fallback" % name)
+    return kernel
+
+
 def _define(schema, fn, fake=None):
     name = schema.split("(")[0]
     _lib.define(schema)
     _lib.impl(name, fn, "CUDA")
+    _lib.impl(name, _refuse_cpu(name), "CPU")        # a loud refusal (the same TgsrError the ctypes wrappers raise), not a fallback
     if fake is not None:
         torch.library.register_fake("tgsr::" + name, fake, lib=_lib)
     return getattr(torch.ops.tgsr, name).default
@@ -113,6 +120,10 @@ word_attention_out = _define("word_attention_out(Tensor h, Tensor words, Tensor 
                              h.new_empty(h.shape[0], words.shape[2], h.shape[2], h.shape[3]))
 
 
+word_project = _define("word_project(Tensor words, Tensor[] w_ctxs) -> Tensor[]", lambda words, ws: ops.word_project(words, list(ws)),
+                       lambda words, ws: [words.new_empty(words.shape[0], ws[0].shape[0], 32) for _ in ws])
+
+
 # ------------------------------------------------------------------------------------------------ image heads (differentiable)
 def _conv_to3(x, w, tanh_axpy, addend, alpha):
     return ops.conv_to3(x, w, tanh_axpy=tanh_axpy, addend=addend, alpha=alpha)
@@ -120,22 +131,8 @@ def _conv_to3(x, w, tanh_axpy, addend, alpha):
 
 def _conv_to3_bwd(dy, out, addend, alpha, x, w, tanh_axpy, need_dx, need_dw):
     """(dx, dw) of conv_to3; a gradient that is not needed comes back as an empty tensor."""
-    from . import _lib as L
-    from ._lib import check
-    from .ops import _p, _stream
-    lib = L.lib()
-    dy, x, w = dy.contiguous(), x.contiguous(), w.contiguous()
-    addend = None if addend is None else addend.contiguous()     # the kernel reads it as dense NCHW
-    B, Cin, H, W = x.shape
-    K = w.shape[2]
-    dx = torch.empty_like(x) if need_dx else x.new_empty(0)
-    dw = torch.empty_like(w) if need_dw else x.new_empty(0)
-    ws = x.new_empty(lib.tgsr_conv_to3_bwd_ws_elems(B, Cin, H, W, K)) if need_dw else None
-    rc = lib.tgsr_conv_to3_bwd(_p(dy), _p(out), _p(addend), float(alpha), _p(x), Cin * H * W, _p(w), B, Cin, H, W, K,
-                               L.ACT_TANH_AXPY if tanh_axpy else L.ACT_NONE, _p(dx) if need_dx else None, _p(ws),
-                               _p(dw) if need_dw else None, _stream())
-    check(rc, "tgsr_conv_to3_bwd")
-    return dx, dw
+    dx, dw = ops.conv_to3_bwd(dy, out, addend, alpha, x, w, tanh_axpy, need_dx, need_dw)
+    return (dx if dx is not None else x.new_empty(0)), (dw if dw is not None else x.new_empty(0))
 
 
 conv_to3 = _define("conv_to3(Tensor x, Tensor w, bool tanh_axpy, Tensor? addend, float alpha) -> Tensor", _conv_to3,
@@ -201,3 +198,223 @@ glu = _define("glu(Tensor x) -> Tensor", lambda x: ops.glu(x),
 glu_bwd = _define("glu_bwd(Tensor dy, Tensor x) -> Tensor", lambda dy, x: ops.glu_bwd(dy, x), lambda dy, x: torch.empty_like(x))
 torch.library.register_autograd("tgsr::glu", lambda ctx, dy: glu_bwd(dy, ctx.saved_tensors[0]),
                                 setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0]), lib=_lib)
+
+
+# ================================================================================================ training primitives
+# The blocks of tgsr_amd.autograd (ConvBnAct, ResBlockFn, ConvBnLeaky) are formulas over these operators; gradient
+# tensors that must land in a given place (a slot of the flat gradient bucket, parallel.grad_slot) are mutable arguments.
+def _bn_train_fwd(raw, gamma, beta, eps, momentum, running_mean, running_var, act, residual, nbt):
+    return ops.bn_train_fwd(raw, gamma, beta, eps, momentum, running_mean, running_var, act, residual, nbt)
+
+
+bn_train_fwd = _define("bn_train_fwd(Tensor raw, Tensor gamma, Tensor beta, float eps, float momentum, Tensor(a!)? running_mean, "
+                       "Tensor(b!)? running_var, int act, Tensor? residual, Tensor(c!)? num_batches_tracked) -> (Tensor, Tensor)",
+                       _bn_train_fwd,
+                       lambda raw, g, b, eps, mom, rm, rv, act, res, nbt:
+                       (raw.new_empty(raw.shape[0], raw.shape[1] // 2 if act == 1 else raw.shape[1], raw.shape[2], raw.shape[3]),
+                        raw.new_empty(4, raw.shape[1])))
+bn_train_fwd_out = _define("bn_train_fwd_out(Tensor raw, Tensor gamma, Tensor beta, float eps, float momentum, "
+                           "Tensor(a!)? running_mean, Tensor(b!)? running_var, int act, Tensor(c!)? num_batches_tracked, "
+                           "Tensor(d!) out, Tensor(e!) stats) -> ()",
+                           lambda raw, g, b, eps, mom, rm, rv, act, nbt, out, stats:
+                           (ops.bn_train_fwd(raw, g, b, eps, mom, rm, rv, act, None, nbt, out=out, stats=stats), None)[1],
+                           lambda *a: None)
+bn_train_bwd = _define("bn_train_bwd(Tensor dout, Tensor raw, Tensor stats, int act, Tensor(a!) dgamma, Tensor(b!) dbeta, "
+                       "Tensor(c!)? draw) -> Tensor",
+                       lambda dout, raw, stats, act, dg, db, draw: ops.bn_train_bwd(dout, raw, stats, act, dg, db, draw)[0]
+                       if draw is None else (ops.bn_train_bwd(dout, raw, stats, act, dg, db, draw), raw.new_empty(0))[1],
+                       lambda dout, raw, stats, act, dg, db, draw: torch.empty_like(raw) if draw is None else raw.new_empty(0))
+conv3x3_wgrad = _define("conv3x3_wgrad(Tensor draw, Tensor x, bool upsample, bool winograd, Tensor(a!) dw) -> ()",
+                        lambda draw, x, up, wino, dw: (ops.conv3x3_wgrad(draw, x, up, wino, out=dw), None)[1], lambda *a: None)
+sumpool2x2 = _define("sumpool2x2(Tensor x) -> Tensor", lambda x: ops.sumpool2x2(x),
+                     lambda x: x.new_empty(x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2))
+conv3x3_gemm = _define("conv3x3_gemm(Tensor x, Tensor w) -> Tensor", lambda x, w: ops.conv3x3_gemm(x, w),
+                       lambda x, w: x.new_empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3]))
+conv3x3_gemm_dgrad = _define("conv3x3_gemm_dgrad(Tensor dy, Tensor w) -> Tensor", lambda dy, w: ops.conv3x3_gemm_dgrad(dy, w),
+                             lambda dy, w: dy.new_empty(dy.shape[0], w.shape[1], dy.shape[2], dy.shape[3]))
+conv3x3_gemm_wgrad_out = _define("conv3x3_gemm_wgrad_out(Tensor dy, Tensor x, Tensor(a!) dw) -> ()",
+                                 lambda dy, x, dw: (ops.conv3x3_gemm_wgrad(dy, x, out=dw), None)[1], lambda *a: None)
+conv4x4s2_wgrad_out = _define("conv4x4s2_wgrad_out(Tensor dy, Tensor x, Tensor(a!) dw) -> ()",
+                              lambda dy, x, dw: (ops.conv4x4s2_wgrad(dy, x, out=dw), None)[1], lambda *a: None)
+pack_conv3x3_weight = _define("pack_conv3x3_weight(Tensor w, bool dgrad) -> Tensor", lambda w, d: ops.pack_conv3x3_weight(w, dgrad=d),
+                              lambda w, d: w.new_empty(((w.shape[0 if d else 1] + 3) // 4) * 36 * w.shape[1 if d else 0]))
+pack_wino_weight = _define("pack_wino_weight(Tensor w, bool glu, bool dgrad) -> Tensor",
+                           lambda w, g, d: ops.pack_wino_weight(w, glu=g, dgrad=d),
+                           lambda w, g, d: w.new_empty(((w.shape[0 if d else 1] + 3) // 4) * 64 * w.shape[1 if d else 0]))
+pack_upwino_weight = _define("pack_upwino_weight(Tensor w, bool glu) -> Tensor", lambda w, g: ops.pack_upwino_weight(w, glu=g),
+                             lambda w, g: w.new_empty(((w.shape[1] + 3) // 4) * (w.shape[0] // 64) * 2304))
+upwino = _define("upwino(Tensor x, Tensor upack, int cout, Tensor? scale, Tensor? shift, bool glu) -> Tensor",
+                 lambda x, p, cout, s, t, glu: ops.upwino_glu(x, p, cout, s, t, glu=glu),
+                 lambda x, p, cout, s, t, glu: x.new_empty(x.shape[0], cout // 2 if glu else cout, 2 * x.shape[2], 2 * x.shape[3]))
+
+
+# ------------------------------------------------------------------------------------------------ word attention backward
+word_attention_bwd = _define("word_attention_bwd(Tensor h, Tensor src, Tensor? mask, bool correct_mask, int T, Tensor dc) -> "
+                             "(Tensor, Tensor)",
+                             lambda h, src, mask, cm, T, dc: ops.word_attention_bwd(h, src, mask, cm, T, dc),
+                             lambda h, src, mask, cm, T, dc: (torch.empty_like(h), h.new_empty(h.shape[0], h.shape[1], T)))
+
+
+# ------------------------------------------------------------------------------------------------ logit heads (row dot)
+rowdot = _define("rowdot(Tensor x, Tensor w, Tensor? bias) -> Tensor", lambda x, w, b: ops.rowdot(x, w, b),
+                 lambda x, w, b: x.new_empty(x.shape[0]))
+
+
+def _rowdot_bwd(dy, x, w, need_dx, need_dw):
+    dx, dw = ops.rowdot_bwd(dy, x, w, need_dx, need_dw)
+    return (dx if dx is not None else x.new_empty(0)), (dw if dw is not None else x.new_empty(0))
+
+
+rowdot_bwd = _define("rowdot_bwd(Tensor dy, Tensor x, Tensor w, bool need_dx, bool need_dw) -> (Tensor, Tensor)", _rowdot_bwd,
+                     lambda dy, x, w, ndx, ndw: (torch.empty_like(x) if ndx else x.new_empty(0),
+                                                 x.new_empty(x.shape[1]) if ndw else x.new_empty(0)))
+
+
+def _rowdot_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    ndx, ndw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    dx = dw = None
+    if ndx or ndw:
+        dx, dw = rowdot_bwd(dy, x, w, ndx, ndw)
+    return (dx if ndx else None), (dw.reshape(w.shape) if ndw else None), (dy.sum().reshape(1) if ctx.needs_input_grad[2] else None)
+
+
+torch.library.register_autograd("tgsr::rowdot", _rowdot_backward,
+                                setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1]), lib=_lib)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM heads (differentiable)
+linear = _define("linear(Tensor x, Tensor w, Tensor? bias) -> Tensor", lambda x, w, b: ops.linear(x, w, b),
+                 lambda x, w, b: x.new_empty(x.shape[0], w.shape[0]))
+conv1x1 = _define("conv1x1(Tensor x, Tensor w) -> Tensor", lambda x, w: ops.conv1x1(x, w),
+                  lambda x, w: x.new_empty(x.shape[0], w.shape[0], x.shape[2], x.shape[3]))
+
+
+def _gemm_nt(a, b):
+    """a [M,K] @ b[N,K]^T on the HIP GEMM kernel."""
+    return linear(a.contiguous(), b.contiguous(), None)
+
+
+def _linear_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    dy = dy.contiguous()
+    dx = _gemm_nt(dy, w.detach().t()) if ctx.needs_input_grad[0] else None          # [B,N] @ W [N,K]
+    dw = _gemm_nt(dy.t(), x.detach().t()) if ctx.needs_input_grad[1] else None      # dy^T x
+    return dx, dw, (dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+
+
+def _linear_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+    ctx.has_bias = inputs[2] is not None
+
+
+torch.library.register_autograd("tgsr::linear", _linear_backward, setup_context=_linear_setup, lib=_lib)
+
+
+def _conv1x1_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    Cout, Cin = w.shape[0], w.shape[1]
+    dy = dy.contiguous()
+    dx = dw = None
+    if ctx.needs_input_grad[0]:                                    # (the frozen trunk's features need none)
+        dx = conv1x1(dy, w.detach().reshape(Cout, Cin).t().contiguous())
+    if ctx.needs_input_grad[1]:
+        dy2 = dy.permute(1, 0, 2, 3).reshape(Cout, -1)             # [Cout, B*S]
+        x2 = x.detach().permute(1, 0, 2, 3).reshape(Cin, -1)       # [Cin,  B*S]
+        dw = _gemm_nt(dy2, x2).reshape(w.shape)
+    return dx, dw
+
+
+torch.library.register_autograd("tgsr::conv1x1", _conv1x1_backward,
+                                setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[0], inputs[1]), lib=_lib)
+
+
+# ------------------------------------------------------------------------------------------------ text encoder
+bilstm_table = _define("bilstm_table(Tensor captions, int[] cap_lens, Tensor table, Tensor w_hh) -> (Tensor, Tensor)",
+                       lambda c, lens, table, w_hh: ops.bilstm_table(c, list(lens), table, w_hh),
+                       lambda c, lens, table, w_hh: (table.new_empty(c.shape[0], 2 * w_hh.shape[2], max(lens)),
+                                                     table.new_empty(c.shape[0], 2 * w_hh.shape[2])))
+lstm_gate_table = _define("lstm_gate_table(Tensor emb, Tensor w_ih, Tensor b_ih, Tensor b_hh) -> Tensor",
+                          lambda e, w, bi, bh: ops.lstm_gate_table(e, w, bi, bh),
+                          lambda e, w, bi, bh: e.new_empty(e.shape[0], 2, w.shape[1]))
+bilstm_train = _define("bilstm_train(Tensor x, Tensor w_ih, Tensor w_hh, Tensor b_ih, Tensor b_hh, int[] cap_lens) -> "
+                       "(Tensor, Tensor, Tensor)",
+                       lambda x, wi, wh, bi, bh, lens: ops.bilstm_train_fwd(x, list(lens), wi, wh, bi, bh),
+                       lambda x, wi, wh, bi, bh, lens: (x.new_empty(x.shape[0], 2 * wh.shape[2], x.shape[1]),
+                                                        x.new_empty(x.shape[0], 2 * wh.shape[2]),
+                                                        x.new_empty(x.shape[0], x.shape[1], 2, 5, wh.shape[2])))
+bilstm_bwd = _define("bilstm_bwd(int[] cap_lens, Tensor w_hh, Tensor acts, Tensor words, Tensor d_words, Tensor? d_sent) -> "
+                     "(Tensor, Tensor, Tensor)",
+                     lambda lens, wh, acts, words, dw, ds: ops.bilstm_bwd(list(lens), wh, acts, words, dw, ds),
+                     lambda lens, wh, acts, words, dw, ds: (acts.new_empty(acts.shape[0], acts.shape[1], 2, 4 * acts.shape[4]),
+                                                            acts.new_empty(acts.shape[0], acts.shape[1], 2, acts.shape[4]),
+                                                            acts.new_empty(2, 4 * acts.shape[4])))
+
+
+# ------------------------------------------------------------------------------------------------ DAMSM
+damsm_words = _define("damsm_words(Tensor img_features, Tensor words_emb, int[] cap_lens, float gamma1, float gamma2) -> "
+                      "(Tensor, Tensor)",
+                      lambda f, w, lens, g1, g2: ops.damsm_words_similarity(f, w, list(lens), g1, g2, need_att=True),
+                      lambda f, w, lens, g1, g2: (f.new_empty(f.shape[0], f.shape[0]),
+                                                  f.new_empty(f.shape[0], w.shape[2], f.shape[2], f.shape[3])))
+damsm_words_bwd = _define("damsm_words_bwd(Tensor img_features, Tensor words_emb, int[] cap_lens, float gamma1, float gamma2, "
+                          "Tensor grad_sim) -> (Tensor, Tensor)",
+                          lambda f, w, lens, g1, g2, gs: ops.damsm_words_bwd(f, w, list(lens), g1, g2, gs),
+                          lambda f, w, lens, g1, g2, gs: (torch.empty_like(f), torch.empty_like(w)))
+func_attention = _define("func_attention(Tensor query, Tensor context, float gamma1) -> (Tensor, Tensor)",
+                         lambda q, c, g1: ops.func_attention(q, c, g1),
+                         lambda q, c, g1: (torch.empty_like(q), q.new_empty(q.shape[0], q.shape[2], c.shape[2], c.shape[3])))
+
+
+# ------------------------------------------------------------------------------------------------ CA_NET (inference)
+def _ca_net(sent_emb, w, b, ncf, eps):
+    c, mu, logvar = ops.ca_net(sent_emb, w, b, ncf, eps)
+    return (c if c is not None else mu.new_empty(0)), mu, logvar
+
+
+ca_net = _define("ca_net(Tensor sent_emb, Tensor w, Tensor b, int ncf, Tensor? eps) -> (Tensor, Tensor, Tensor)", _ca_net,
+                 lambda s_, w, b, ncf, eps: (s_.new_empty(s_.shape[0], ncf) if eps is not None else s_.new_empty(0),
+                                             s_.new_empty(s_.shape[0], ncf), s_.new_empty(s_.shape[0], ncf)))
+to_uint8 = _define("to_uint8(Tensor img) -> Tensor", lambda x: ops.to_uint8(x), lambda x: torch.empty_like(x, dtype=torch.uint8))
+
+
+# ================================================================================================ reduced-precision path
+# (lp images are mutable arguments: every kernel writes a channel slice of a caller-owned zero-bordered image)
+def _lp():
+    from . import lp
+    return lp
+
+
+lp_conv3x3 = _define("lp_conv3x3(Tensor x, Tensor wpack, int cin, int cout, Tensor? scale, Tensor? shift, bool glu, bool upsample, "
+                     "Tensor? residual, int res_coff, Tensor(a!) out, int out_coff) -> ()",
+                     lambda x, wp, cin, cout, s, t, glu, up, res, rco, out, oco:
+                     (_lp().conv3x3(x, wp, cin, cout, s, t, glu=glu, upsample=up, residual=res, res_coff=rco, out=out, out_coff=oco),
+                      None)[1], lambda *a: None)
+lp_upconv_glu = _define("lp_upconv_glu(Tensor x, Tensor wpack, int cin, int cout, Tensor? scale, Tensor? shift, Tensor(a!) out, "
+                        "int out_coff) -> ()",
+                        lambda x, wp, cin, cout, s, t, out, oco: (_lp().upconv_glu(x, wp, cin, cout, s, t, out=out, out_coff=oco), None)[1],
+                        lambda *a: None)
+lp_upconv_glu_head = _define("lp_upconv_glu_head(Tensor x, Tensor wpack, int cin, int cout, Tensor? scale, Tensor? shift, "
+                             "Tensor head_wpack, int K, Tensor(a!) partial, Tensor(b!)? out, int out_coff) -> ()",
+                             lambda x, wp, cin, cout, s, t, hw, K, part, out, oco:
+                             (_lp().upconv_glu_head(x, wp, cin, cout, s, t, hw, K, partial=part, out=out, out_coff=oco,
+                                                    write_out=out is not None), None)[1], lambda *a: None)
+lp_stem = _define("lp_stem(Tensor x, Tensor w, Tensor scale, Tensor shift, Tensor(a!) out, int out_coff) -> ()",
+                  lambda x, w, s, t, out, oco: (_lp().stem(x, w, s, t, out=out, out_coff=oco), None)[1], lambda *a: None)
+lp_conv_to3 = _define("lp_conv_to3(Tensor x, Tensor wpack, int K, bool tanh_axpy, Tensor? addend, float alpha) -> Tensor",
+                      lambda x, wp, K, act, add, alpha: _lp().conv_to3(x, wp, K, tanh_axpy=act, addend=add, alpha=alpha),
+                      lambda x, wp, K, act, add, alpha: x.new_empty(x.shape[0], 3, x.shape[1] - 2, x.shape[2] - 2, dtype=torch.float32))
+lp_word_attention = _define("lp_word_attention(Tensor(a!) h_img, Tensor src, Tensor? mask, int T, bool correct_mask, int c_coff) -> Tensor",
+                            lambda h, src, mask, T, cm, cco: _lp().word_attention(h, src, mask, T, correct_mask=cm, c_coff=cco),
+                            lambda h, src, mask, T, cm, cco: h.new_empty(h.shape[0], T, h.shape[1] - 2, h.shape[2] - 2, dtype=torch.float32))
+
+
+def _lp_head_combine(sizes_h, sizes_w, partial_low, partial_high, low, high, low_tanh, alpha):
+    n = len(sizes_h)
+    none = lambda t: None if (t is None or t.numel() == 0) else t          # noqa: E731  (an empty tensor stands for "absent")
+    _lp().head_combine(low[0].shape[0], list(zip(sizes_h, sizes_w)), [none(t) for t in partial_low[:n]],
+                       [none(t) for t in partial_high[:n]], list(low[:n]), [none(t) for t in high[:n]], low_tanh, alpha)
+
+
+lp_head_combine = _define("lp_head_combine(int[] H, int[] W, Tensor[] partial_low, Tensor[] partial_high, Tensor(a!)[] low, "
+                          "Tensor(b!)[] high, bool low_tanh, float alpha) -> ()", _lp_head_combine, lambda *a: None)

@@ -16,9 +16,8 @@ import pickle
 import numpy as np
 import torch
 
-from . import _lib
-from ._lib import TgsrError, check
-from .ops import _need_hip, _p, _stream
+from . import ops
+from ._lib import TgsrError
 
 _PB = 32 - 8 - 2       # Pillow's PRECISION_BITS
 
@@ -83,44 +82,19 @@ class GpuImagePyramid:
 
     def resize(self, x: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
         """PIL `resize((out_w, out_h), BILINEAR)` of planar uint8 images [..., H, W]."""
-        _need_hip(x)
-        if x.dtype != torch.uint8:
-            raise TgsrError("resize: uint8 images expected, got %s" % x.dtype)
-        x = x.contiguous()
         H, W = x.shape[-2], x.shape[-1]
-        N = x.numel() // (H * W)
-        out = torch.empty(x.shape[:-2] + (out_h, out_w), dtype=torch.uint8, device=x.device)
-        hb = hk = vb = vk = None
-        hks = vks = 0
-        if out_w != W:
-            hb, hk, hks = self._table(W, out_w)
-        if out_h != H:
-            vb, vk, vks = self._table(H, out_h)
-        tmp = torch.empty(N * H * out_w, dtype=torch.uint8, device=x.device) if (hb is not None and vb is not None) else None
-        check(_lib.lib().tgsr_resize_bilinear_u8(_p(x), N, H, W, out_h, out_w, _p(hb), _p(hk), hks, _p(vb), _p(vk), vks,
-                                                 _p(tmp), _p(out), _stream()), "tgsr_resize_bilinear_u8")
-        return out
+        return ops.resize_bilinear_u8(x, out_h, out_w, self._table(W, out_w) if out_w != W else None,
+                                      self._table(H, out_h) if out_h != H else None)
 
     def gaussian_blur(self, x: torch.Tensor) -> torch.Tensor:
         """PIL `filter(ImageFilter.GaussianBlur(radius))` of planar uint8 images [..., H, W]."""
-        _need_hip(x)
-        x = x.contiguous()
-        H, W = x.shape[-2], x.shape[-1]
-        N = x.numel() // (H * W)
-        out, tmp = torch.empty_like(x), torch.empty_like(x)
         r, ww, fw = self.blur
-        check(_lib.lib().tgsr_gaussian_blur_u8(_p(x), N, H, W, r, ww, fw, 3, _p(tmp), _p(out), _stream()),
-              "tgsr_gaussian_blur_u8")
-        return out
+        return ops.gaussian_blur_u8(x, r, ww, fw, 3)
 
     @staticmethod
     def normalize(x: torch.Tensor) -> torch.Tensor:
         """ToTensor + Normalize((0.5,)*3, (0.5,)*3) (datasets.py:286-288)."""
-        _need_hip(x)
-        x = x.contiguous()
-        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-        check(_lib.lib().tgsr_u8_normalize(_p(x), _p(out), x.numel(), _stream()), "tgsr_u8_normalize")
-        return out
+        return ops.u8_normalize(x)
 
     def __call__(self, hr_u8: torch.Tensor, u8: bool = False):
         S = self.sizes[-1]

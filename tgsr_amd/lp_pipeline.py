@@ -13,6 +13,7 @@ import os
 
 import torch
 
+from . import custom_ops as C
 from . import lp, ops
 from .util import _ver
 
@@ -34,8 +35,8 @@ class _Conv:
         self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
     def __call__(self, x, glu=False, upsample=False, residual=None, out=None, out_coff=0):
-        return lp.conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, glu=glu, upsample=upsample,
-                          residual=residual, out=out, out_coff=out_coff)
+        C.lp_conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, glu, upsample, residual, 0, out, out_coff)
+        return out
 
 
 class _UpConv:
@@ -50,16 +51,18 @@ class _UpConv:
 
     def __call__(self, x, out):
         if self.sub and lp.upconv_supported(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2):
-            return lp.upconv_glu(x, self.wsub, self.cin, self.cout, self.scale, self.shift, out=out)
-        return lp.conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, glu=True, upsample=True, out=out)
+            C.lp_upconv_glu(x, self.wsub, self.cin, self.cout, self.scale, self.shift, out, 0)
+        else:
+            C.lp_conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, True, True, None, 0, out, 0)
+        return out
 
     def fusable(self, x):
         return FUSE_HEADS and self.sub and lp.head_fusable(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2)
 
     def with_head(self, x, head_wpack, K, partial, out):
         """upBlock + its image head's partial sums in one launch; out None: the feature image is not written."""
-        return lp.upconv_glu_head(x, self.wsub, self.cin, self.cout, self.scale, self.shift, head_wpack, K, partial=partial,
-                                  out=out, write_out=out is not None)
+        C.lp_upconv_glu_head(x, self.wsub, self.cin, self.cout, self.scale, self.shift, head_wpack, K, partial, out, 0)
+        return out, partial
 
 
 class _Stem:
@@ -69,7 +72,8 @@ class _Stem:
         self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
     def __call__(self, x, out, out_coff=0):
-        return lp.stem(x, self.w, self.scale, self.shift, out=out, out_coff=out_coff)
+        C.lp_stem(x, self.w, self.scale, self.shift, out, out_coff)
+        return out
 
 
 class LpExecutor:
@@ -161,7 +165,7 @@ class LpExecutor:
         for st in self.gl_stage:                                               # distinct attention modules (x16: two)
             if all(st["att"] is not m for m in atts_m):
                 atts_m.append(st["att"])
-        proj = ops.word_project(word_embs, [m.conv_context.weight for m in atts_m])
+        proj = C.word_project(word_embs, [m.conv_context.weight.detach() for m in atts_m])
         srcs = [proj[[i for i, m in enumerate(atts_m) if m is st["att"]][0]] for st in self.gl_stage]
         last = len(self.gl_stage) - 1
         fake, atts, pend = [], [], []
@@ -169,7 +173,7 @@ class LpExecutor:
         self.gl_stem(LR, out=wide)                                             # im2f -> channels [0, 32)
         for k, st in enumerate(self.gl_stage):
             bb = bufs["gl"][k]
-            atts.append(lp.word_attention(bb["wide"], srcs[k], mask, T, correct_mask=st["att"].correct_mask))
+            atts.append(C.lp_word_attention(bb["wide"], srcs[k], mask, T, st["att"].correct_mask, 32))
             x = bb["wide"]
             for (c0, c1), o in zip(st["res"], (bb["a"], bb["b"])):             # R_NUM = 2 ResBlocks (util.py:110-130)
                 c0(x, glu=True, out=bb["tmp"])
@@ -186,7 +190,7 @@ class LpExecutor:
                 pend.append(bufs["pl"][k])
             else:
                 st["up"](x, out=nxt)                                           # upBlock -> channels [0, 32) of the next stage
-                fake.append(lp.conv_to3(nxt, st["head"], 3, tanh_axpy=self.gl_head_tanh))
+                fake.append(C.lp_conv_to3(nxt, st["head"], 3, self.gl_head_tanh, None, 0.0))
                 pend.append(None)
         # images whose partial sums are still to be combined (high_heads does it, for both generators in one launch)
         bufs["pend"] = (fake, pend)
@@ -235,9 +239,9 @@ class LpExecutor:
             pk = pend[k] if k < len(pend) and fake[k] is sr else None
             if not fused_h:
                 if pk is not None:          # the low image must exist before an unfused 5x5 head can add it: combine it alone
-                    lp.head_combine(sr.shape[0], [tuple(sr.shape[2:])], [pk], [None], [sr], [None], self.gl_head_tanh, alpha)
+                    _combine([tuple(sr.shape[2:])], [pk], [None], [sr], [None], self.gl_head_tanh, alpha)
                     pk = None
-                fine.append(lp.conv_to3(f, self.gh_head, 5, tanh_axpy=True, addend=sr, alpha=alpha))
+                fine.append(C.lp_conv_to3(f, self.gh_head, 5, True, sr, float(alpha)))
             else:
                 fine.append(torch.empty(f.B, 3, f.H, f.W, dtype=torch.float32, device=sr.device))
             if fused_h or pk is not None:
@@ -247,10 +251,18 @@ class LpExecutor:
                 lo.append(sr)
                 hi.append(fine[-1] if fused_h else None)
         if sizes:
-            lp.head_combine(SRb[0].shape[0], sizes, pl, ph, lo, hi, self.gl_head_tanh, alpha)
+            _combine(sizes, pl, ph, lo, hi, self.gl_head_tanh, alpha)
         if self._bufs_of_step is not None:
             self._bufs_of_step["pend"] = None
         return fine
+
+
+def _combine(sizes, pl, ph, lo, hi, low_tanh, alpha):
+    """torch.ops.tgsr.lp_head_combine (tensor lists cannot hold None: an empty tensor stands for an absent entry)."""
+    e = lo[0].new_empty(0)
+    C.lp_head_combine([s[0] for s in sizes], [s[1] for s in sizes], [e if t is None else t for t in pl],
+                      [e if t is None else t for t in ph], list(lo), [e if t is None else t for t in hi], bool(low_tanh),
+                      float(alpha))
 
 
 class _Partial:

@@ -14,12 +14,12 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .. import ops
+from .. import custom_ops as C
 from .config import cfg
 
 
 def _func_attention(query, context, gamma1):
-    return ops.func_attention(query, context, gamma1)
+    return C.func_attention(query, context, float(gamma1))
 
 
 def cosine_similarity(x1, x2, dim=1, eps=1e-8):
@@ -67,8 +67,8 @@ def words_loss(img_features, words_emb, labels, cap_lens, class_ids, batch_size)
         from ..autograd import DamsmWords
         sim, att = DamsmWords.apply(img_features, words_emb, lens, cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.GAMMA2)
     else:
-        sim, att = ops.damsm_words_similarity(img_features, words_emb, lens, cfg.TRAIN.SMOOTH.GAMMA1,
-                                              cfg.TRAIN.SMOOTH.GAMMA2, need_att=True)
+        sim, att = C.damsm_words(img_features, words_emb, [int(v) for v in lens], float(cfg.TRAIN.SMOOTH.GAMMA1),
+                                 float(cfg.TRAIN.SMOOTH.GAMMA2))
     att_maps = [att[i:i + 1, :lens[i]].contiguous() for i in range(batch_size)]
     similarities = sim * cfg.TRAIN.SMOOTH.GAMMA3
     masks = _class_masks(class_ids, batch_size, sim.device)

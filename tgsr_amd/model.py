@@ -58,7 +58,7 @@ class G_SR_NET_low(nn.Module):
         if not self.training:
             # the three stages attend to the same words: their conv_context projections go out as one launch
             atts = [self.h_net1.att, self.h_net2.att, self.h_net3.att]
-            srcs = ops.word_project(word_embs, [a.conv_context.weight for a in atts])
+            srcs = C.word_project(word_embs, [a.conv_context.weight.detach() for a in atts])
         h_code1, att0 = self.h_net1(None, LR, word_embs, mask, wide_out=True, src=srcs[0])
         fake_imgs.append(self.img_net1(h_code1))
         att_maps.append(att0)

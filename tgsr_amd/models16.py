@@ -11,6 +11,7 @@ One deviation, because the shipped line cannot execute: models16.py:178 adds the
 import torch
 import torch.nn as nn
 
+from . import custom_ops as C
 from . import ops
 from .miscc.config import cfg
 from .model import *  # noqa: F401,F403  (the reference does `from model import *`)
@@ -38,8 +39,8 @@ class G_SR_NET_low(nn.Module):
         src1 = src2 = None
         if not self.training:
             # two distinct conv_context projections (h_net1's and the tied stages'): one launch for both
-            src1, src2 = ops.word_project(word_embs, [self.h_net1.att.conv_context.weight,
-                                                      self.h_net2.att.conv_context.weight])
+            src1, src2 = C.word_project(word_embs, [self.h_net1.att.conv_context.weight.detach(),
+                                                    self.h_net2.att.conv_context.weight.detach()])
         h_code, att = self.h_net1(None, LR, word_embs, mask, wide_out=True, src=src1)
         fake_imgs.append(self.img_net1(h_code))
         att_maps.append(att)
@@ -80,7 +81,7 @@ class NetG_highweight(nn.Module):
         if self.training:
             from .autograd import ConvTo3
             return ConvTo3.apply(out, self.conv_output[0].weight, SRb, True, self.a)   # d/da = sum(dy * SRb)
-        return ops.conv_to3(out, self.conv_output[0].weight, tanh_axpy=True, addend=SRb, alpha=self.alpha())
+        return C.conv_to3(out, self.conv_output[0].weight.detach(), True, SRb, self.alpha())
 
     def trunk(self, LR, LRb):
         """Everything that does not need the low-frequency images (see model.NetG_highweight.trunk): the four feature

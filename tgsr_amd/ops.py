@@ -588,6 +588,222 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+# ----------------------------------------------------------------------------------------- training path primitives
+def bn_train_fwd(raw: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, momentum: float,
+                 running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], act: int = 0,
+                 residual: Optional[torch.Tensor] = None, nbt: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+    """nn.BatchNorm2d(train) on the raw conv output [B,C,H,W] + act (0 none [+ residual], 1 GLU, 2 LeakyReLU(0.2)):
+    batch statistics, running statistics / num_batches_tracked updated in place through their pointers.  Returns
+    (out, stats [4, C] = mean, invstd, scale, shift).  `out` / `stats` may be given (slices of larger tensors)."""
+    _need_hip(raw, gamma, beta, running_mean, running_var, residual, nbt, out, stats)
+    L = _lib.lib()
+    B, C, Ho, Wo = raw.shape
+    HW, dev = Ho * Wo, raw.device
+    raw = _f32(raw, "raw")
+    if not raw.is_contiguous():
+        raise TgsrError("bn_train_fwd: raw must be contiguous")
+    co = C // 2 if act == 1 else C
+    if out is None:
+        out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=dev)
+    if stats is None:
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+    res = None if residual is None else residual.contiguous()
+    ws = torch.empty(C * L.tgsr_bn_train_nsplit(B, C, HW) * 4, dtype=torch.float32, device=dev)
+    rc = L.tgsr_bn_train_fwd(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum),
+                             _p(running_mean), _p(running_var), int(act), _p(res), 0 if res is None else co * HW, _p(ws),
+                             _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(out), co * HW, _p(nbt), _stream())
+    check(rc, "tgsr_bn_train_fwd")
+    return out, stats
+
+
+def bn_train_bwd(dout: torch.Tensor, raw: torch.Tensor, stats: torch.Tensor, act: int, dgamma: Optional[torch.Tensor] = None,
+                 dbeta: Optional[torch.Tensor] = None, draw: Optional[torch.Tensor] = None):
+    """Backward of bn_train_fwd: (draw like raw, dgamma [C], dbeta [C]); the three may be given (gradient slots of a flat
+    bucket, slices of a batched tensor)."""
+    _need_hip(dout, raw, stats, dgamma, dbeta, draw)
+    L = _lib.lib()
+    B, C, Ho, Wo = raw.shape
+    HW, dev = Ho * Wo, raw.device
+    dout = _f32(dout, "dout").contiguous()
+    co = C // 2 if act == 1 else C
+    if draw is None:
+        draw = torch.empty_like(raw)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    if dbeta is None:
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    ws = torch.empty(co * L.tgsr_bn_train_nsplit(B, co, HW) * 4, dtype=torch.float32, device=dev)
+    rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, C, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), int(act),
+                             _p(ws), _p(ws), _p(draw), _p(dgamma), _p(dbeta), _stream())
+    check(rc, "tgsr_bn_train_bwd")
+    return draw, dgamma, dbeta
+
+
+def sumpool2x2(x: torch.Tensor) -> torch.Tensor:
+    """Backward of nn.Upsample(x2, nearest): [B,C,2H,2W] -> [B,C,H,W], each output the sum of its 2x2 block."""
+    _need_hip(x)
+    x = _f32(x, "x").contiguous()
+    B, C, H2, W2 = x.shape
+    out = torch.empty(B, C, H2 // 2, W2 // 2, dtype=torch.float32, device=x.device)
+    check(_lib.lib().tgsr_sumpool2x2(_p(x), B * C, H2 // 2, W2 // 2, _p(out), _stream()), "tgsr_sumpool2x2")
+    return out
+
+
+def conv3x3_wgrad_kind(Cin: int, Cout: int, upsample: bool, winograd: bool = True) -> str:
+    """Which weight-gradient kernel serves a conv3x3 layer: "upwino" (9 Winograd positions on the low-resolution pixels of
+    an upBlock), "wino" (16 positions per 2x2 output tile) where Cout % 64 == 0 and Cin % 32 == 0, else "direct"."""
+    if winograd and Cout % 64 == 0 and Cin % 32 == 0:
+        return "upwino" if upsample else "wino"
+    return "direct"
+
+
+def conv3x3_wgrad(draw: torch.Tensor, x: torch.Tensor, upsample: bool = False, winograd: bool = True,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight gradient [Cout,Cin,3,3] of conv3x3(upsample ? nearest_x2(x) : x): draw [B,Cout,Ho,Wo] (gradient at the raw
+    conv output), x [B,Cin,H,W]; per-workgroup partial slabs summed in a fixed order (reproducible).  `out`: where to
+    write it (a gradient slot)."""
+    _need_hip(draw, x, out)
+    L = _lib.lib()
+    draw = _f32(draw, "draw").contiguous()
+    x = _f32(x, "x").contiguous()
+    B, Cin, H, W = x.shape
+    Cout, HW, dev = draw.shape[1], draw.shape[2] * draw.shape[3], x.device
+    dw = out if out is not None else torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=dev)
+    kind = conv3x3_wgrad_kind(Cin, Cout, upsample, winograd)
+    e0 = _ev() if profile is not None else None
+    if kind == "upwino":
+        ws = torch.empty(L.tgsr_upwino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
+        check(L.tgsr_upwino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(ws), _p(dw), _stream()), "tgsr_upwino_wgrad")
+    elif kind == "wino":
+        ws = torch.empty(L.tgsr_wino_wgrad_ws_elems(B, Cin, Cout, H, W), dtype=torch.float32, device=dev)
+        check(L.tgsr_wino_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, _p(ws), _p(dw), _stream()), "tgsr_wino_wgrad")
+    else:
+        ws = torch.empty(L.tgsr_conv3x3_wgrad_ws_elems(B, Cin, Cout, H, W, 1 if upsample else 0), dtype=torch.float32, device=dev)
+        check(L.tgsr_conv3x3_wgrad(_p(draw), _p(x), Cin * H * W, B, Cin, H, W, Cout, 1 if upsample else 0, _p(ws), _p(dw),
+                                   _stream()), "tgsr_conv3x3_wgrad")
+    if profile is not None:      # direct-form FLOPs of the weight gradient: one MAC per (output pixel, tap, ci, co)
+        profile.append(({"upwino": "upwino_wgrad_kernel", "wino": "wino_wgrad_kernel", "direct": "conv3x3_wgrad_kernel"}[kind],
+                        2.0 * B * HW * Cout * Cin * 9, 4.0 * (B * Cin * H * W + B * Cout * HW + Cout * Cin * 9), e0, _ev()))
+    return dw
+
+
+def conv_to3_bwd(dy: torch.Tensor, out: Optional[torch.Tensor], addend: Optional[torch.Tensor], alpha: float, x: torch.Tensor,
+                 w: torch.Tensor, tanh_axpy: bool, need_dx: bool = True, need_dw: bool = True):
+    """(dx, dw) of conv_to3 (None for a gradient that is not needed); `out` = the forward output (tanh heads)."""
+    _need_hip(dy, out, addend, x, w)
+    L = _lib.lib()
+    dy, x, w = _f32(dy, "dy").contiguous(), _f32(x, "x").contiguous(), _f32(w.detach(), "w").contiguous()
+    addend = None if addend is None else addend.contiguous()     # the kernel reads it as dense NCHW
+    B, Cin, H, W = x.shape
+    K = w.shape[2]
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty_like(w) if need_dw else None
+    ws = x.new_empty(L.tgsr_conv_to3_bwd_ws_elems(B, Cin, H, W, K)) if need_dw else None
+    rc = L.tgsr_conv_to3_bwd(_p(dy), _p(out), _p(addend), float(alpha), _p(x), Cin * H * W, _p(w), B, Cin, H, W, K,
+                             _lib.ACT_TANH_AXPY if tanh_axpy else _lib.ACT_NONE, _p(dx), _p(ws), _p(dw), _stream())
+    check(rc, "tgsr_conv_to3_bwd")
+    return dx, dw
+
+
+def word_attention_bwd(h: torch.Tensor, src: torch.Tensor, mask: Optional[torch.Tensor], correct_mask: bool, T: int,
+                       dc: torch.Tensor):
+    """Backward of word_attention wrt h and the projected words: h [B,idf,ih,iw], src [B,idf,32] (zero padded past T),
+    dc [B,idf,ih,iw] -> (dh like h, dsrc [B,idf,T]); P is recomputed, the per-chunk partial sums of d(src) are added in a
+    fixed order."""
+    _need_hip(h, src, mask, dc)
+    L = _lib.lib()
+    h, dc = _f32(h, "h").contiguous(), _f32(dc, "dc").contiguous()
+    B, idf, ih, iw = h.shape
+    Q = ih * iw
+    part = torch.empty(B, L.tgsr_word_attention_bwd_chunks(Q), idf, 32, dtype=torch.float32, device=h.device)
+    dh = torch.empty_like(h)
+    m8 = None if mask is None else _mask_u8(mask)
+    rc = L.tgsr_word_attention_bwd(_p(h), idf * Q, _p(src.contiguous()), _p(m8), 1 if correct_mask else 0, B, idf, T, Q,
+                                   _p(dc), _p(dh), _p(part), _stream())
+    check(rc, "tgsr_word_attention_bwd")
+    return dh, part.sum(1)[:, :, :T]
+
+
+def rowdot(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """out[b] = <x[b, :], w> + bias (the discriminators' logit heads: a 4x4 / stride-4 conv of a 4x4 map to one channel)."""
+    _need_hip(x, w, bias)
+    x = _f32(x, "x").contiguous()
+    w = _f32(w.detach(), "w").contiguous().view(-1)
+    B, K = x.shape
+    out = torch.empty(B, dtype=torch.float32, device=x.device)
+    check(_lib.lib().tgsr_rowdot_fwd(_p(x), _p(w), _p(None if bias is None else bias.detach()), _p(out), B, K, _stream()),
+          "tgsr_rowdot_fwd")
+    return out
+
+
+def rowdot_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, need_dx: bool = True, need_dw: bool = True):
+    """(dx [B,K], dw [K]) of rowdot (None where not needed)."""
+    _need_hip(dy, x, w)
+    dy, x = _f32(dy, "dy").contiguous(), _f32(x, "x").contiguous()
+    w = _f32(w.detach(), "w").contiguous().view(-1)
+    B, K = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dw = torch.empty(K, dtype=torch.float32, device=x.device) if need_dw else None
+    if need_dx or need_dw:
+        check(_lib.lib().tgsr_rowdot_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), B, K, _stream()), "tgsr_rowdot_bwd")
+    return dx, dw
+
+
+def ca_net(sent_emb: torch.Tensor, w: torch.Tensor, b: torch.Tensor, ncf: int, eps: Optional[torch.Tensor]):
+    """CA_NET.forward (util.py:372-400) in one launch: (c_code or None, mu, logvar); eps [B,ncf] = the standard normals of
+    the re-parametrisation (None: c_code is not produced - the x8 / x16 generators discard it, model.py:51-52)."""
+    _need_hip(sent_emb, w, b, eps)
+    x = _f32(sent_emb, "sent_emb").contiguous()
+    w, b = _f32(w.detach(), "w").contiguous(), _f32(b.detach(), "b").contiguous()
+    B, tdim = x.shape
+    mu = torch.empty(B, ncf, dtype=torch.float32, device=x.device)
+    logvar = torch.empty_like(mu)
+    c_code = torch.empty_like(mu) if eps is not None else None
+    check(_lib.lib().tgsr_ca_net_fwd(_p(x), _p(w), _p(b), _p(eps), B, tdim, ncf, _p(c_code), _p(mu), _p(logvar), _stream()),
+          "tgsr_ca_net_fwd")
+    return c_code, mu, logvar
+
+
+# ----------------------------------------------------------------------------------------- image pyramid (uint8)
+def resize_bilinear_u8(x: torch.Tensor, out_h: int, out_w: int, htab, vtab) -> torch.Tensor:
+    """Pillow's `resize(BILINEAR)` of planar uint8 images [..., H, W]; htab / vtab = (bounds, coefficients, ksize) device
+    tables of the horizontal / vertical pass, or None when that size does not change."""
+    _need_hip(x)
+    if x.dtype != torch.uint8:
+        raise TgsrError("resize: uint8 images expected, got %s" % x.dtype)
+    x = x.contiguous()
+    H, W = x.shape[-2], x.shape[-1]
+    N = x.numel() // (H * W)
+    out = torch.empty(x.shape[:-2] + (out_h, out_w), dtype=torch.uint8, device=x.device)
+    hb, hk, hks = htab if htab is not None else (None, None, 0)
+    vb, vk, vks = vtab if vtab is not None else (None, None, 0)
+    tmp = torch.empty(N * H * out_w, dtype=torch.uint8, device=x.device) if (hb is not None and vb is not None) else None
+    check(_lib.lib().tgsr_resize_bilinear_u8(_p(x), N, H, W, out_h, out_w, _p(hb), _p(hk), hks, _p(vb), _p(vk), vks, _p(tmp),
+                                             _p(out), _stream()), "tgsr_resize_bilinear_u8")
+    return out
+
+
+def gaussian_blur_u8(x: torch.Tensor, r: int, ww: int, fw: int, passes: int = 3) -> torch.Tensor:
+    """Pillow's GaussianBlur (extended box blur, `passes` per axis) of planar uint8 images [..., H, W]."""
+    _need_hip(x)
+    x = x.contiguous()
+    H, W = x.shape[-2], x.shape[-1]
+    out, tmp = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.lib().tgsr_gaussian_blur_u8(_p(x), x.numel() // (H * W), H, W, r, ww, fw, passes, _p(tmp), _p(out), _stream()),
+          "tgsr_gaussian_blur_u8")
+    return out
+
+
+def u8_normalize(x: torch.Tensor) -> torch.Tensor:
+    """ToTensor + Normalize((0.5,)*3, (0.5,)*3) (datasets.py:286-288): uint8 -> float32 in [-1, 1]."""
+    _need_hip(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib.lib().tgsr_u8_normalize(_p(x), _p(out), x.numel(), _stream()), "tgsr_u8_normalize")
+    return out
+
+
 # ----------------------------------------------------------------------------------------- stand-alone GLU
 def glu(x: torch.Tensor) -> torch.Tensor:
     """GLU.forward (util.py:45-53): x[:, :C/2] * sigmoid(x[:, C/2:]) for x [B, C, ...] with C even."""

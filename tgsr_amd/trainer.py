@@ -27,8 +27,8 @@ def to_uint8(img):
     converted on the GPU (tgsr_to_uint8, byte-identical) so that 4x fewer bytes cross PCIe; host tensors use the
     reference's numpy expression."""
     if img.is_cuda:
-        from . import ops
-        return ops.to_uint8(img).cpu().numpy()
+        from . import custom_ops as C
+        return C.to_uint8(img.detach()).cpu().numpy()
     a = img.detach().cpu().numpy()
     return np.round(np.maximum(0, np.minimum(255, (a + 1.0) * 127.5))).astype(np.uint8)
 

@@ -364,9 +364,10 @@ class RNN_ENCODER(nn.Module):
             # per weight version with the same GEMM kernel (bit-identical), then ONE recurrence launch per batch
             key = (self._key, _ver(self.encoder.weight))
             if key != self._table_key:
-                self._table = ops.lstm_gate_table(self.encoder.weight, w_ih, b_ih, b_hh)
+                self._table = C.lstm_gate_table(self.encoder.weight.detach(), w_ih, b_ih, b_hh)
                 self._table_key = key
-            return ops.bilstm_table(captions, cap_lens, self._table, w_hh)
+            lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+            return C.bilstm_table(captions, lens, self._table, w_hh)
         return ops.bilstm(captions, cap_lens, self.encoder.weight, w_ih, w_hh, b_ih, b_hh)
 
 
@@ -439,12 +440,9 @@ class CNN_ENCODER(nn.Module):
 
     def heads(self, features, pooled):
         """(features [B,768,17,17], pooled [B,2048]) -> (region features [B,nef,17,17], cnn_code [B,nef])."""
-        if torch.is_grad_enabled() and (self.emb_cnn_code.weight.requires_grad or features.requires_grad):
-            from .autograd import Conv1x1Fn, LinearFn
-            return (Conv1x1Fn.apply(features, self.emb_features.weight),
-                    LinearFn.apply(pooled, self.emb_cnn_code.weight, self.emb_cnn_code.bias))
-        cnn_code = ops.linear(pooled, self.emb_cnn_code.weight, self.emb_cnn_code.bias)
-        return ops.conv1x1(features, self.emb_features.weight), cnn_code
+        # torch.ops.tgsr.conv1x1 / linear: HIP GEMM kernels, differentiable (their backward GEMMs are the same kernel)
+        return (C.conv1x1(features, self.emb_features.weight),
+                C.linear(pooled, self.emb_cnn_code.weight, self.emb_cnn_code.bias))
 
     def forward(self, x):
         features, pooled = self.run_trunk(x)
@@ -489,22 +487,14 @@ class CA_NET(nn.Module):
         if not self.training and not torch.is_grad_enabled():
             # inference: the Linear, the GLU and the re-parametrisation in one HIP launch (tgsr_ca_net_fwd); the normals
             # still come from torch's generator, as many as the reference draws
-            from . import _lib
-            from .ops import _need_hip, _p, _stream
-            x = text_embedding.contiguous()
-            w, b = self.fc.weight.detach().contiguous(), self.fc.bias.detach().contiguous()
-            _need_hip(x, w, b)
-            B = x.shape[0]
-            mu = torch.empty(B, self.c_dim, dtype=torch.float32, device=x.device)
-            logvar = torch.empty_like(mu)
-            c_code = eps = None
-            if not (x.is_cuda and torch.cuda.is_current_stream_capturing()):
+            eps = None
+            if not (text_embedding.is_cuda and torch.cuda.is_current_stream_capturing()):
                 # inside a hipGraph capture the draw is skipped (c_code is None): a captured normal_() makes every replay
                 # fill two philox-state tensors first, and the x8 / x16 generators discard c_code anyway (model.py:51-52)
-                c_code = torch.empty_like(mu)
-                eps = torch.empty_like(mu).normal_()
-            _lib.check(_lib.lib().tgsr_ca_net_fwd(_p(x), _p(w), _p(b), _p(eps), B, self.t_dim, self.c_dim, _p(c_code), _p(mu),
-                                                  _p(logvar), _stream()), "tgsr_ca_net_fwd")
+                eps = torch.empty(text_embedding.shape[0], self.c_dim, dtype=torch.float32, device=text_embedding.device).normal_()
+            c_code, mu, logvar = C.ca_net(text_embedding, self.fc.weight.detach(), self.fc.bias.detach(), self.c_dim, eps)
+            if eps is None:
+                c_code = None
             return c_code, mu, logvar
         mu, logvar = self.encode(text_embedding)
         return self.reparametrize(mu, logvar), mu, logvar
