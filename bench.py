@@ -229,68 +229,31 @@ def bench_damsm(args, rank, world, dist, dev):
 
 
 def bench_train(args, rank, world, dist, dev, weights):
-    """Generator training step: text-enc (frozen) + G_SR_NET_low + NetG_highweight forward in train-mode BN, MSE + KL
-    loss, HIP backward, one flat-bucket gradient all-reduce (N > 1), Adam, EMA.  Synthetic HR targets U(-1, 1)."""
-    from tgsr_amd.synthetic import synthetic_batch
-    from tgsr_amd.train import SRTrainer
-    tr = SRTrainer(41, device=dev, discriminators=args.gan)
-    if weights is not None:
-        tr.text_encoder.load_state_dict(weights["E."])
-        tr.netGL.load_state_dict(weights["GL."])
-        tr.netGH.load_state_dict({k: v for k, v in weights["GH."].items() if k != "a"})
-    B = args.batch
-    cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
-    g = torch.Generator().manual_seed(7 + rank)
-    hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(dev) for s in (64, 128, 256)]
-    cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
-    for _ in range(args.warmup):
-        tr.step(cap, lens, LR, LRb, hr)
-
+    """`--mode train`: the generator training step (text-enc frozen + G_SR_NET_low + NetG_highweight forward in train-mode
+    BN, MSE + KL, HIP backward, one flat-bucket gradient all-reduce (N > 1), Adam, EMA), or with `--gan` the G/D
+    alternation with three discriminators.  Synthetic HR targets U(-1, 1).  The roofline object prices the step by the MACs
+    its convolution kernels actually execute (train_object), and both forms carry a CPU baseline."""
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = tr.step(cap, lens, LR, LRb, hr)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    e = _train_run(args, rank, world, dist, dev, weights, fence, args.gan, args.steps, args.warmup)
     if rank == 0:
+        if "error" in e:
+            raise SystemExit("train bench failed: " + e["error"])
+        B = args.batch
         print(json.dumps({
             "metric": ("SR G/D alternation train images/sec (32->256, batch 16 per GPU, 3 discriminators + generators, Adam)"
                        if args.gan else "SR generator train images/sec (32->256, batch 16 per GPU, fwd+bwd+Adam)"),
-            "value": round(world * B * args.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic inputs and HR targets",
-            "config": {"workload": ("CelebA x8 G/D alternation (losses.py:290-374 with D_NET64/128/256 as DESIGN.md 3.9 declares "
-                                    "them: three discriminator updates on (real, fake.detach()), then the generator update "
-                                    "through them + MSE + KL), batch=16 per GPU" if args.gan else
-                                    "CelebA x8 generator train step (G_SR_NET_low + NetG_highweight, train-mode BN, MSE+KL, "
-                                    "Adam; no discriminator / DAMSM terms), batch=16 per GPU"),
-                       "batch_per_gpu": B, "parallelism": "dp%d" % world, "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)},
-            "final_loss": round(float(loss), 5),
-            # whole-step figure: the conv kernels of forward, data gradient and weight gradient are ~3x the forward's
-            # direct-form FLOPs (36 conv launches, 20.5 GFLOP per image); `achieved` counts those algorithmic FLOPs over
-            # the WHOLE step time (BatchNorm statistics, optimizer and EMA included), so it is a lower bound of what the
-            # MFMA kernels reach and includes the Winograd saving in the numerator
-            "roofline": {"bound": "mfma", "kernel": "train step: conv forward + dgrad + wgrad kernels over the whole step",
-                         "achieved": round(3 * CONV_GFLOP_PER_IMAGE * B * args.steps / dt / 1e3, 2),
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(3 * CONV_GFLOP_PER_IMAGE * B * args.steps / dt / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
-                         "traffic": None,
-                         "note": "algorithmic (direct-form) FLOPs / step time; per-kernel shares: profiles/*train*kernel_stats*"
-                                 + ("; --gan: the numerator still counts the GENERATOR convolutions only (the discriminators' "
-                                    "4x4 stride-2 convolutions add work that is not credited)" if args.gan else "")},
-            **({"cpu_baseline": cpu_baseline_train(weights, min(B, 4))}
-               if world == 1 and not args.no_cpu_baseline and not args.gan else {}),
-        }), flush=True)
+            "value": e["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic inputs and HR targets",
+            "config": {"workload": "CelebA x8 " + e["workload"] + ", batch=%d per GPU" % B, "batch_per_gpu": B,
+                       "parallelism": "dp%d" % world, "grad_bucket_MB": e["grad_bucket_MB"]},
+            "final_loss": e["final_loss"], "roofline": e.get("roofline"),
+            **({"cpu_baseline": e["cpu_baseline"]} if "cpu_baseline" in e else {})}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -537,87 +500,95 @@ def train_object(args, rank, world, dist, dev, weights, fence):
     B = args.batch
     out = {"batch_per_gpu": B, "runs": []}
     for gan in (False, True):
-        steps = max(2, min(args.steps, 6 if gan else 10))
-        entry = {"workload": ("G/D alternation: 3 discriminator updates on (real, fake.detach()), then the generator update "
-                              "through them + MSE + KL (losses.py:290-374; D_NET64/128/256 build-declared, DF_DIM %d)"
-                              % cfg.GAN.DF_DIM) if gan else
-                 "generator train step: G_SR_NET_low + NetG_highweight fwd + bwd (train-mode BN), MSE + KL, Adam, EMA",
-                 "steps": steps, "warmup": 2}
-        tr = None
-        try:
-            tr = SRTrainer(41, device=dev, discriminators=gan)
-            if weights is not None:
-                tr.text_encoder.load_state_dict(weights["E."])
-                tr.netGL.load_state_dict(weights["GL."])
-                tr.netGH.load_state_dict({k: v for k, v in weights["GH."].items() if k != "a"})
-            cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
-            g = torch.Generator().manual_seed(7 + rank)
-            hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(dev) for s in (64, 128, 256)]
-            cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
-            for _ in range(2):
-                tr.step(cap, lens, LR, LRb, hr)
-            ok = True
-        except Exception as e:          # noqa: BLE001
-            entry["error"] = "%s: %s" % (type(e).__name__, e)
-            ok = False
-        if not _all_ok(ok, dist, dev):
-            entry.setdefault("error", "set-up failed on another rank")
-            out["runs"].append(entry)
-            continue
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = tr.step(cap, lens, LR, LRb, hr)
-        fence()
-        dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
-        sec = dt / steps
-        entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4),
-                      "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
-        if rank == 0:
-            try:                         # one more step with HIP events around every convolution launch (single stream)
-                prof = []
-                wside, dstreams = tr._wside, tr._dstreams
-                tr._wside, tr._dstreams = None, []
-                ops.profile = prof
-                tr.step(cap, lens, LR, LRb, hr)
-                ops.profile = None
-                tr._wside, tr._dstreams = wside, dstreams
-                torch.cuda.synchronize()
-                agg = {}
-                for name, flops, _nb, e0, e1 in prof:
-                    a = agg.setdefault(name, [0, 0.0, 0.0])
-                    a[0] += 1
-                    a[1] += flops
-                    a[2] += e0.elapsed_time(e1) * 1e-3
-                conv = {k: v for k, v in agg.items() if k in EXECUTED_MAC_FRACTION}
-                alg = sum(v[1] for v in conv.values())
-                exe = sum(v[1] * EXECUTED_MAC_FRACTION[k] for k, v in conv.items())
-                ksec = sum(v[2] for v in conv.values())
-                entry["roofline"] = {
-                    "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "achieved": round(exe / sec / 1e12, 2), "frac": round(exe / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "achieved_algorithmic_TFLOPs": round(alg / sec / 1e12, 2),
-                    "conv_kernels_only": {"ms_per_step": round(ksec * 1e3, 3),
-                                          "executed_TFLOPs": round(exe / ksec / 1e12, 2),
-                                          "frac": round(exe / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
-                    "kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "executed_fraction": round(EXECUTED_MAC_FRACTION[k], 4),
-                                    "executed_TFLOPs": round(v[1] * EXECUTED_MAC_FRACTION[k] / v[2] / 1e12, 2)}
-                                for k, v in sorted(conv.items(), key=lambda kv: -kv[1][2])},
-                    "traffic": None,
-                    "note": "`achieved` / `frac`: MACs the convolution kernels of forward, data gradient and weight gradient "
-                            "really issue (direct-form FLOPs of every launch x the kernel's executed fraction), over the "
-                            "WHOLE step time (BatchNorm passes, losses, optimizer, EMA included); `conv_kernels_only`: the "
-                            "same MACs over the summed durations of those launches (HIP events, one single-stream step)"}
-                if world == 1 and not args.no_cpu_baseline:
-                    entry["cpu_baseline"] = (cpu_baseline_gan(weights, 2) if gan else cpu_baseline_train(weights, min(B, 4)))
-            except Exception as e:      # noqa: BLE001
-                entry["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            finally:
-                ops.profile = None
-        out["runs"].append(entry)
-        del tr
-        torch.cuda.empty_cache()
+        out["runs"].append(_train_run(args, rank, world, dist, dev, weights, fence, gan, max(2, min(args.steps, 10)), 3))
     return out
+
+
+def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup):
+    """One timed train configuration (see train_object): returns its entry dict."""
+    from tgsr_amd import ops
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.train import SRTrainer
+    from tgsr_amd.miscc.config import cfg
+    B = args.batch
+    entry = {"workload": ("G/D alternation: 3 discriminator updates on (real, fake.detach()), then the generator update "
+                          "through them + MSE + KL (losses.py:290-374; D_NET64/128/256 build-declared, DF_DIM %d)"
+                          % cfg.GAN.DF_DIM) if gan else
+             "generator train step: G_SR_NET_low + NetG_highweight fwd + bwd (train-mode BN), MSE + KL, Adam, EMA",
+             "steps": steps, "warmup": warmup}
+    tr = None
+    try:
+        tr = SRTrainer(41, device=dev, discriminators=gan)
+        if weights is not None:
+            tr.text_encoder.load_state_dict(weights["E."])
+            tr.netGL.load_state_dict(weights["GL."])
+            tr.netGH.load_state_dict({k: v for k, v in weights["GH."].items() if k != "a"})
+        cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
+        g = torch.Generator().manual_seed(7 + rank)
+        hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(dev) for s in (64, 128, 256)]
+        cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
+        for _ in range(warmup):
+            tr.step(cap, lens, LR, LRb, hr)
+        ok = True
+    except Exception as e:          # noqa: BLE001
+        entry["error"] = "%s: %s" % (type(e).__name__, e)
+        ok = False
+    if not _all_ok(ok, dist, dev):
+        entry.setdefault("error", "set-up failed on another rank")
+        return entry
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(cap, lens, LR, LRb, hr)
+    fence()
+    dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
+    sec = dt / steps
+    entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4),
+                  "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
+    if rank == 0:
+        try:                         # one more step with HIP events around every convolution launch (single stream)
+            prof = []
+            wside, dstreams = tr._wside, tr._dstreams
+            tr._wside, tr._dstreams = None, []
+            ops.profile = prof
+            tr.step(cap, lens, LR, LRb, hr)
+            ops.profile = None
+            tr._wside, tr._dstreams = wside, dstreams
+            torch.cuda.synchronize()
+            agg = {}
+            for name, flops, _nb, e0, e1 in prof:
+                a = agg.setdefault(name, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += flops
+                a[2] += e0.elapsed_time(e1) * 1e-3
+            conv = {k: v for k, v in agg.items() if k in EXECUTED_MAC_FRACTION}
+            alg = sum(v[1] for v in conv.values())
+            exe = sum(v[1] * EXECUTED_MAC_FRACTION[k] for k, v in conv.items())
+            ksec = sum(v[2] for v in conv.values())
+            entry["roofline"] = {
+                "bound": "mfma", "unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS,
+                "achieved": round(exe / sec / 1e12, 2), "frac": round(exe / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "achieved_algorithmic_TFLOPs": round(alg / sec / 1e12, 2),
+                "conv_kernels_only": {"ms_per_step": round(ksec * 1e3, 3),
+                                      "executed_TFLOPs": round(exe / ksec / 1e12, 2),
+                                      "frac": round(exe / ksec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)},
+                "kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "executed_fraction": round(EXECUTED_MAC_FRACTION[k], 4),
+                                "executed_TFLOPs": round(v[1] * EXECUTED_MAC_FRACTION[k] / v[2] / 1e12, 2)}
+                            for k, v in sorted(conv.items(), key=lambda kv: -kv[1][2])},
+                "traffic": None,
+                "note": "`achieved` / `frac`: MACs the convolution kernels of forward, data gradient and weight gradient "
+                        "really issue (direct-form FLOPs of every launch x the kernel's executed fraction), over the "
+                        "WHOLE step time (BatchNorm passes, losses, optimizer, EMA included); `conv_kernels_only`: the "
+                        "same MACs over the summed durations of those launches (HIP events, one single-stream step)"}
+            if world == 1 and not args.no_cpu_baseline:
+                entry["cpu_baseline"] = (cpu_baseline_gan(weights, 2) if gan else cpu_baseline_train(weights, min(B, 4)))
+        except Exception as e:      # noqa: BLE001
+            entry["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            ops.profile = None
+    del tr
+    torch.cuda.empty_cache()
+    return entry
 
 
 def main():

@@ -115,7 +115,7 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     for up in (False, True):
         dr = R(B, Cc, H * (2 if up else 1), W * (2 if up else 1))
         chk(T.conv3x3_wgrad.default, (dr, x32, up, True, torch.empty(Cc, 32, 3, 3, device=DEV)), test_utils=basic)
-    chk(T.conv3x3_wgrad.default, (R(B, 3, H, W), x32, False, True, torch.empty(3, 32, 3, 3, device=DEV)), test_utils=basic)
+    chk(T.conv3x3_wgrad.default, (R(B, 32, H, W), R(B, 3, H, W), False, True, torch.empty(32, 3, 3, 3, device=DEV)), test_utils=basic)
     chk(T.sumpool2x2.default, (raw,), test_utils=basic)
     w33 = R(Cc, 32, 3, 3) / 17.0
     chk(T.pack_conv3x3_weight.default, (w33, False), test_utils=basic)

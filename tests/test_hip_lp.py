@@ -363,7 +363,8 @@ def test_x16_lp_pipeline_full_size(name, td, ulp, cfg_face):
             assert abs(p32 - pmodel) < 1.0, "%s %s[%d]: %.2f dB vs fp32, the CPU model predicts %.2f" % (name, k, i, p32, pmodel)
             # closer to the model than the model is to fp32 - by 1.5 dB here (the x8 test asks 3): through four weight-tied
             # stages two implementations of the same roundings pick different neighbours of a rounding tie more often
-            assert pm > pmodel + 1.5, "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
+            # (above ~85 dB both distances are fp32 summation-order noise on these small-valued images)
+            assert pm > min(pmodel + 1.5, 85.0), "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
     for i in range(4):
         assert OL.psnr(out["att"][i].cpu(), model["att"][i], peak=1.0) > 45.0
     eager = [f.clone() for f in out["fine"]]

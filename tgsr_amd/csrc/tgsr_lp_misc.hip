@@ -23,50 +23,78 @@ struct LpStemArgs {
   int B, H, W, C, ocp, oco;
 };
 
-// thread = (pixel, group of 8 output channels): 8 value + 8 gate channels x 27 MACs, one 16-byte store.  The channel
-// group is blockIdx.y, i.e. uniform over the wave: the 16 x 27 weights of a group come in through scalar loads.
+// Workgroup = one row segment of 32 pixels x ALL output channels: thread = (pixel, group of 8 output channels: 8 value +
+// 8 gate channels x 27 MACs, one 16-byte store).  The 3 x 3 x 34 input halo, the whole filter (2C x 27 floats, 6.9 KB for
+// C = 32) and the BatchNorm affine go through LDS once per workgroup with coalesced loads; before, every thread fetched
+// its 27 inputs itself, eight times over (once per channel group), and the 16 x 27 weights of its group through ~50
+// dependent scalar loads: 11 us for 2 MFLOP per image at the head of the step's critical chain (profiles/r02i_bf16_
+// kernel_stats.csv), now bound by one load round trip.
 template <class T>
 __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
-  const int64_t total = (int64_t)a.B * a.H * a.W;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int g = blockIdx.y;
-  int64_t t = i;
-  const int x = (int)(t % a.W);
-  t /= a.W;
-  const int y = (int)(t % a.H);
-  const int b = (int)(t / a.H);
+  // [2C][28] weights | [2C] scale | [2C] shift | [3][3][34] input, sized for C <= 64.  STATIC on purpose: with a dynamic
+  // (`extern __shared__`) size this kernel, captured into a hipGraph whose other branch runs the second stem at the same
+  // time, intermittently produced different values on replay (ROCm 7.2; eager launches and single-branch graphs never
+  // did: tools/graph_dbg_lp.py) - no other kernel of the captured step uses dynamic LDS.
+  __shared__ __attribute__((aligned(16))) float stem_s[2 * 64 * 28 + 4 * 64 + 3 * 3 * 34];
+  const int C2 = 2 * a.C, NG = a.C / 8;                                // NG channel groups, 32 * NG threads do the arithmetic
+  float* ws = stem_s;
+  float* sc = ws + C2 * 28;
+  float* sh = sc + C2;
+  float* in_s = sh + C2;
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tilesx = (a.W + 31) / 32;
+  const int tx = t % tilesx;
+  t /= tilesx;
+  const int y = t % a.H, b = t / a.H, x0 = tx * 32;
+  for (int i = tid; i < C2 * 27; i += 256) ws[(i / 27) * 28 + i % 27] = a.w[i];
+  for (int i = tid; i < C2; i += 256) {
+    sc[i] = a.scale[i];
+    sh[i] = a.shift[i];
+  }
+  for (int i = tid; i < 3 * 3 * 34; i += 256) {
+    const int c = i / 102, r = (i / 34) % 3, j = i % 34;
+    const int yy = y + r - 1, xx = x0 + j - 1;
+    in_s[i] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) ? a.x[(((int64_t)b * 3 + c) * a.H + yy) * a.W + xx] : 0.f;
+  }
+  __syncthreads();
+  const int px = tid & 31, g = tid >> 5;
+  if (g >= NG || x0 + px >= a.W) return;
   float in[27];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int yy = y + dy - 1, xx = x + dx - 1;
-        in[c * 9 + dy * 3 + dx] = ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
-                                      ? a.x[(((int64_t)b * 3 + c) * a.H + yy) * a.W + xx] : 0.f;
-      }
+      for (int dx = 0; dx < 3; ++dx) in[c * 9 + dy * 3 + dx] = in_s[(c * 3 + dy) * 34 + px + dx];
   float o[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int cv = g * 8 + q, cg = a.C + cv;
-    const float* wv = a.w + cv * 27;
-    const float* wg = a.w + cg * 27;
+    const float* wv = ws + cv * 28;                                    // rows of 28 floats: 16-byte aligned, read as float4
+    const float* wg = ws + cg * 28;
     float v = 0.f, gt = 0.f;
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      v = fmaf(wv[k], in[k], v);
-      gt = fmaf(wg[k], in[k], gt);
+    for (int k4 = 0; k4 < 7; ++k4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(wv + 4 * k4);
+      const float4 g4 = *reinterpret_cast<const float4*>(wg + 4 * k4);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (4 * k4 + j < 27) {
+          v = fmaf(av[j], in[4 * k4 + j], v);
+          gt = fmaf(gv[j], in[4 * k4 + j], gt);
+        }
+      }
     }
-    v = v * a.scale[cv] + a.shift[cv];
-    gt = gt * a.scale[cg] + a.shift[cg];
+    v = v * sc[cv] + sh[cv];
+    gt = gt * sc[cg] + sh[cg];
     o[q] = v * sigmoidf_fast(gt);
   }
   u32x4 pk;
 #pragma unroll
   for (int q = 0; q < 4; ++q) pk[q] = LP<T>::pack2(o[2 * q], o[2 * q + 1]);
-  unsigned short* op = a.out + (((int64_t)b * (a.H + 2) + y + 1) * (a.W + 2) + x + 1) * a.ocp + a.oco + g * 8;
+  unsigned short* op = a.out + (((int64_t)b * (a.H + 2) + y + 1) * (a.W + 2) + x0 + px + 1) * a.ocp + a.oco + g * 8;
   *reinterpret_cast<u32x4*>(op) = pk;
 }
 
@@ -315,8 +343,8 @@ extern "C" int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, 
   LpStemArgs a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.out = static_cast<unsigned short*>(out);
   a.B = B; a.H = H; a.W = W; a.C = C; a.ocp = out_cpitch; a.oco = out_coff;
-  const int64_t total = (int64_t)B * H * W;
-  const dim3 grid((unsigned)((total + 255) / 256), (unsigned)(C / 8));
+  if (C > 64) return TGSR_EUNSUPPORTED;                      // 8 channel groups of 8 per 256-thread workgroup
+  const dim3 grid((unsigned)((int64_t)B * H * ((W + 31) / 32)));
   if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL(lp_stem_kernel<BF16>, grid, dim3(256), 0, as_stream(stream), a);
   else if (dtype == TGSR_DT_F16) hipLaunchKernelGGL(lp_stem_kernel<F16>, grid, dim3(256), 0, as_stream(stream), a);
   else return TGSR_EINVAL;

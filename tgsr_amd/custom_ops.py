@@ -121,7 +121,7 @@ word_attention_out = _define("word_attention_out(Tensor h, Tensor words, Tensor 
 
 
 word_project = _define("word_project(Tensor words, Tensor[] w_ctxs) -> Tensor[]", lambda words, ws: ops.word_project(words, list(ws)),
-                       lambda words, ws: [words.new_empty(words.shape[0], ws[0].shape[0], 32) for _ in ws])
+                       lambda words, ws: list(words.new_empty(len(ws), words.shape[0], ws[0].shape[0], 32).unbind(0)))
 
 
 # ------------------------------------------------------------------------------------------------ image heads (differentiable)

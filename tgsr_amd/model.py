@@ -11,6 +11,7 @@ from torch.autograd import Variable      # re-exported: the reference's model.py
                                          # util.py:1-11) and its callers import `Variable, torch, cfg` FROM `model`
                                          # (trainer_objective.py:8)
 
+from . import custom_ops as C
 from . import ops
 from .miscc.config import cfg
 from .util import (CA_NET, CNN_ENCODER, D_GET_LOGITS, GET_IMAGE_G, GET_IMAGE_G_noAct, GLU, INIT_STAGE_GImgup, NEXT_STAGE_G,
