@@ -236,12 +236,14 @@ def test_lp_pipeline_hipgraph_and_determinism(name, cfg_face, face_weights):
     assert torch.equal(a["fine"][2], b["fine"][2]), "two eager runs differ"
     serial = _pipe(cfg_face, face_weights, name, overlap=False)(*args)
     assert torch.equal(a["fine"][2], serial["fine"][2]), "two-stream run differs from the single-stream one"
-    pipe.capture(*args)
-    g = pipe.replay()
-    torch.cuda.synchronize()
-    for k in ("fake", "fine", "att"):
-        for i in range(3):
-            assert torch.equal(g[k][i], a[k][i]), "hipGraph replay differs from eager (%s[%d])" % (k, i)
+    for trial in range(4):             # several captures x replays: the two branches of the graph really overlap on replay,
+        pipe.capture(*args)            # which is where a kernel that misbehaves beside another one shows (lp_stem_kernel did)
+        for rep in range(3):
+            g = pipe.replay()
+            torch.cuda.synchronize()
+            for k in ("fake", "fine", "att"):
+                for i in range(3):
+                    assert torch.equal(g[k][i], a[k][i]), "hipGraph replay %d/%d differs from eager (%s[%d])" % (trial, rep, k, i)
     # new inputs through the captured step
     cap2, lens2, LR2, LRb2 = O.synthetic_batch(B, seed=7)
     if lens2.tolist() == lens.tolist():

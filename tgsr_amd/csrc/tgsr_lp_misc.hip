@@ -31,10 +31,7 @@ struct LpStemArgs {
 // kernel_stats.csv), now bound by one load round trip.
 template <class T>
 __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
-  // [2C][28] weights | [2C] scale | [2C] shift | [3][3][34] input, sized for C <= 64.  STATIC on purpose: with a dynamic
-  // (`extern __shared__`) size this kernel, captured into a hipGraph whose other branch runs the second stem at the same
-  // time, intermittently produced different values on replay (ROCm 7.2; eager launches and single-branch graphs never
-  // did: tools/graph_dbg_lp.py) - no other kernel of the captured step uses dynamic LDS.
+  // [2C][28] weights | [2C] scale | [2C] shift | [3][3][34] input, sized for C <= 64
   __shared__ __attribute__((aligned(16))) float stem_s[2 * 64 * 28 + 4 * 64 + 3 * 3 * 34];
   const int C2 = 2 * a.C, NG = a.C / 8;                                // NG channel groups, 32 * NG threads do the arithmetic
   float* ws = stem_s;
@@ -67,6 +64,13 @@ __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) in[c * 9 + dy * 3 + dx] = in_s[(c * 3 + dy) * 34 + px + dx];
+#pragma unroll
+  // The 27 inputs stay in registers.  Left alone, hipcc (100 VGPRs) re-reads parts of in_s late in the channel loop with
+  // unaligned ds_read_b96 / ds_read2_b32 - and those late re-reads intermittently returned other values (lanes 48-63, the
+  // later channels of a group) when the step was replayed from a hipGraph whose second branch ran LDS-DMA convolutions at
+  // the same time (20-70 % of the replays; never eagerly, never in a one-branch graph, never with this pin: tools/
+  // graph_dbg_lp.py, tools/stem_race_check.py).  Not root-caused; the reads right behind the barrier are the only ones left.
+  for (int k = 0; k < 27; ++k) asm volatile("" : "+v"(in[k]));
   float o[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {

@@ -7,6 +7,17 @@ from tgsr_amd.miscc.config import cfg, cfg_reset
 from conftest import load_npz, split_sd
 from tgsr_amd.trainer import SRPipeline
 cfg_reset(); cfg.GAN.GF_DIM=32; cfg.TEXT.EMBEDDING_DIM=256; cfg.TREE.BRANCH_NUM=4
+if os.environ.get("NO_TORCH_OPS"):            # bisect: the executor calls the ctypes wrappers directly, as before the routing
+    from tgsr_amd import custom_ops as C, lp, ops
+    C.lp_conv3x3 = lambda x, wp, cin, cout, s, t, glu, up, res, rco, out, oco: lp.conv3x3(x, wp, cin, cout, s, t, glu=glu, upsample=up, residual=res, res_coff=rco, out=out, out_coff=oco) and None
+    C.lp_upconv_glu = lambda x, wp, cin, cout, s, t, out, oco: lp.upconv_glu(x, wp, cin, cout, s, t, out=out, out_coff=oco) and None
+    C.lp_upconv_glu_head = lambda x, wp, cin, cout, s, t, hw, K, part, out, oco: lp.upconv_glu_head(x, wp, cin, cout, s, t, hw, K, partial=part, out=out, out_coff=oco, write_out=out is not None) and None
+    C.lp_stem = lambda x, w, s, t, out, oco: lp.stem(x, w, s, t, out=out, out_coff=oco) and None
+    C.lp_word_attention = lambda h, src, mask, T, cm, cco: lp.word_attention(h, src, mask, T, correct_mask=cm, c_coff=cco)
+    C.word_project = lambda words, ws: ops.word_project(words, list(ws))
+    C.bilstm_table = lambda c, lens, table, w_hh: ops.bilstm_table(c, list(lens), table, w_hh)
+    _ca = C.ca_net
+    C.ca_net = lambda se, w, b, ncf, eps: ops.ca_net(se, w, b, ncf, eps)
 fw = load_npz("face_S8_weights.npz")
 overlap = os.environ.get("OVERLAP", "1") == "1"
 dtype = os.environ.get("DTYPE", "bf16")
@@ -18,6 +29,17 @@ def snap(o):
     for k in ("words_emb", "sent_emb", "mu", "mask"):
         d[k] = [o[k].clone().float()]
     return d
+from tgsr_amd import lp_pipeline
+SNAP = {}
+_orig_stem_call = lp_pipeline._Stem.__call__
+def _stem_call(self, x, out, out_coff=0):
+    r = _orig_stem_call(self, x, out, out_coff)
+    if out.shape[-1] == 64:                      # the GL stem: copy its output right behind it, on the same stream
+        if "buf" not in SNAP or SNAP["buf"].shape != out[..., :32].shape:
+            SNAP["buf"] = torch.empty_like(out[..., :32])
+        SNAP["buf"].copy_(out[..., :32])
+    return r
+lp_pipeline._Stem.__call__ = _stem_call
 bad = 0
 for trial in range(int(os.environ.get("TRIALS", "6"))):
     pipe = SRPipeline(41, device="cuda", dtype=dtype, overlap=overlap).load_state_dicts(split_sd(fw,"E."), split_sd(fw,"GL."), split_sd(fw,"GH."))
@@ -26,9 +48,25 @@ for trial in range(int(os.environ.get("TRIALS", "6"))):
     torch.cuda.synchronize()
     a = snap(a)
     pipe.capture(*args)
-    for rep in range(2):
+    gb = pipe._graphed.bufs[0] if dtype != "fp32" else None
+    ref_int = None
+    for rep in range(3):
         g = snap(pipe.replay()); torch.cuda.synchronize()
         diff = {k: [round(float((x-y).abs().max()), 5) for x, y in zip(g[k], a[k])] for k in a}
+        if gb is not None:       # intermediates of this replay: stage-1 stem output / attention output, GH stem output
+            cur = {"gl_stem_right_after": SNAP["buf"].float().clone(), "gl_stem": gb["gl"][0]["wide"][..., :32].float().clone(), "gl_c": gb["gl"][0]["wide"][..., 32:].float().clone(),
+                   "gh_stem": gb["gh"]["x"].float().clone(), "gl_res_a": gb["gl"][0]["a"].float().clone()}
+            if ref_int is None and not any(v for vs in diff.values() for v in vs):
+                ref_int = cur
+            elif ref_int is not None:
+                diff.update({k: [round(float((cur[k] - ref_int[k]).abs().max()), 5)] for k in cur})
+                nz = ((cur["gl_stem"] - ref_int["gl_stem"]).abs() > 0).nonzero()
+                if len(nz):
+                    print("   gl_stem wrong elements:", len(nz), "of", cur["gl_stem"].numel(), "b", sorted(set(nz[:, 0].tolist())),
+                          "rows", sorted(set(nz[:, 1].tolist()))[:40], "cols", sorted(set(nz[:, 2].tolist()))[:40],
+                          "ch", sorted(set(nz[:, 3].tolist())))
+                    print("   values wrong/right:", cur["gl_stem"][tuple(nz[0])].item(), ref_int["gl_stem"][tuple(nz[0])].item(),
+                          cur["gl_stem"][tuple(nz[-1])].item(), ref_int["gl_stem"][tuple(nz[-1])].item())
         if any(v for vs in diff.values() for v in vs):
             bad += 1
             print("trial", trial, "replay", rep, diff, flush=True)
