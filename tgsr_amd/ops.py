@@ -722,7 +722,7 @@ def word_attention_bwd(h: torch.Tensor, src: torch.Tensor, mask: Optional[torch.
     rc = L.tgsr_word_attention_bwd(_p(h), idf * Q, _p(src.contiguous()), _p(m8), 1 if correct_mask else 0, B, idf, T, Q,
                                    _p(dc), _p(dh), _p(part), _stream())
     check(rc, "tgsr_word_attention_bwd")
-    return dh, part.sum(1)[:, :, :T]
+    return dh, part.sum(1)[:, :, :T].contiguous()
 
 
 def rowdot(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
