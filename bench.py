@@ -567,16 +567,25 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
     sec = dt / steps
     entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4),
                   "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
-    if rank == 0:
-        try:                         # one more step with HIP events around every convolution launch (single stream)
-            prof = []
-            wside, dstreams = tr._wside, tr._dstreams
-            tr._wside, tr._dstreams = None, []
-            ops.profile = prof
-            tr.step(cap, lens, LR, LRb, hr)
-            ops.profile = None
-            tr._wside, tr._dstreams = wside, dstreams
-            torch.cuda.synchronize()
+    # one more step with HIP events around every convolution launch (single stream).  EVERY rank takes it - the step
+    # all-reduces the gradient bucket, a collective rank 0 alone would leave unmatched; only rank 0 records and reports.
+    prof = []
+    perr = None
+    try:
+        wside, dstreams = tr._wside, tr._dstreams
+        tr._wside, tr._dstreams = None, []
+        ops.profile = prof if rank == 0 else None
+        tr.step(cap, lens, LR, LRb, hr)
+        torch.cuda.synchronize()
+    except Exception as e:          # noqa: BLE001
+        perr = "%s: %s" % (type(e).__name__, e)
+    finally:
+        ops.profile = None
+        tr._wside, tr._dstreams = wside, dstreams
+    if rank == 0 and perr is not None:
+        entry["roofline"] = {"error": perr}
+    elif rank == 0:
+        try:
             agg = {}
             for name, flops, _nb, e0, e1 in prof:
                 a = agg.setdefault(name, [0, 0.0, 0.0])

@@ -264,6 +264,25 @@ int tgsr_ca_net_fwd(const float* sent_emb, const float* w, const float* bias, co
                     float* c_code, float* mu, float* logvar, void* stream);
 int tgsr_rowdot_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, int B, int K, void* stream);
 
+/*
+ * The text tail of an inference step in ONE launch (trainer_objective.py:134-146 between the text encoder and the
+ * generator): the conv_context projections of tgsr_word_project_fwd (src_out [nsets][B][idf][32]), CA_NET's mu / logvar
+ * [B][ncf] of tgsr_ca_net_fwd (same arithmetic; c_code is not produced - the x8 / x16 generators discard it,
+ * model.py:51-52) and mask[B][T] = (captions[b][t] == 0) as bytes 0 / 1 (trainer_objective.py:136-140; torch.bool storage).
+ * captions int64 [B][width], width >= T.  tdim % 16 == 0 (sent_emb / ca_w 16-byte aligned when tdim % 64 == 0); other
+ * limits as tgsr_word_project_fwd.
+ */
+int tgsr_text_tail_fwd(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf, int T,
+                       float* src_out, const float* sent_emb, const float* ca_w, const float* ca_b, int tdim, int ncf,
+                       float* mu, float* logvar, const int64_t* captions, int width, uint8_t* mask, void* stream);
+
+/*
+ * n <= 16 dense device-to-device copies in one launch: dst / src / nbytes are HOST arrays; sizes and addresses must be
+ * multiples of 4 bytes.  (GraphedStep.replay: the new inputs of every lane go into the captured step's static buffers
+ * with one launch instead of three hipMemcpyAsync per lane.)
+ */
+int tgsr_multi_copy(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Training path (BatchNorm2d batch statistics + backward).  The reference trains through torch autograd over
  * nn.Conv2d / nn.BatchNorm2d(train) / GLU / nn.Upsample (util.py:74-80, 110-130); these entry points are the

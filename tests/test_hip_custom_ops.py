@@ -159,6 +159,10 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     chk(T.func_attention.default, (wemb, feats, 4.0), test_utils=basic)
     chk(T.ca_net.default, (R(3, 64), R(40, 64), R(40), 10, R(3, 10)), test_utils=basic)
     chk(T.ca_net.default, (R(3, 64), R(40, 64), R(40), 10, None), test_utils=basic)
+    cap = torch.randint(0, 9, (3, 12), generator=g).to(DEV)
+    chk(T.text_tail.default, (R(3, 48, 9), [R(32, 48), R(32, 48)], R(3, 64), R(40, 64), R(40), 10, cap), test_utils=basic)
+    chk(T.multi_copy.default, ([torch.empty(5, 7, device=DEV), torch.empty(3, dtype=torch.int64, device=DEV)],
+                               [R(5, 7), cap[0, :3].contiguous()]), test_utils=basic)
     chk(T.to_uint8.default, (R(2, 3, 8, 8),), test_utils=basic)
     # reduced-precision path (lp images)
     xi = lp.from_nchw(R(2, 64, 8, 32), "bf16", cpitch=64)

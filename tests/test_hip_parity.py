@@ -664,6 +664,53 @@ def test_ca_net_fused_inference_kernel():
         cfg_reset()
 
 
+@pytest.mark.parametrize("B,T_,tdim,ncf,nsets", [(16, 18, 256, 100, 3), (3, 5, 64, 6, 2), (20, 32, 48, 9, 1), (1, 1, 16, 1, 4)])
+def test_text_tail_equals_its_parts(B, T_, tdim, ncf, nsets):
+    """tgsr_text_tail_fwd = word_project + CA_NET (mu, logvar) + the caption mask in one launch: bit-identical to the
+    stand-alone launches (same device code), and CA_NET's MFMA form agrees with the torch formulation of util.py:372-400
+    for every K split (tdim % 64 == 0: float4 operands; % 16: scalar) and ragged sample / channel blocks."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + T_)
+    cdf, idf = 40, 32
+    words = torch.randn(B, cdf, T_, generator=g).to(DEV)
+    ws = [torch.randn(idf, cdf, generator=g).to(DEV) for _ in range(nsets)]
+    sent = torch.randn(B, tdim, generator=g).to(DEV)
+    w, b = (torch.randn(4 * ncf, tdim, generator=g) * 0.1).to(DEV), torch.randn(4 * ncf, generator=g).to(DEV)
+    cap = torch.randint(0, 4, (B, T_ + 3), generator=g).to(DEV)
+    src, mu, lv, m8 = ops.text_tail(words, ws, sent, w, b, ncf, cap)
+    ref = ops.word_project(words, ws)
+    for k in range(nsets):
+        assert torch.equal(src[k], ref[k])
+    _, mu1, lv1 = ops.ca_net(sent, w, b, ncf, None)
+    assert torch.equal(mu, mu1) and torch.equal(lv, lv1)
+    y = torch.nn.functional.linear(sent.double().cpu(), w.double().cpu(), b.double().cpu())
+    y = y[:, :2 * ncf] * torch.sigmoid(y[:, 2 * ncf:])
+    close(mu.cpu().double(), y[:, :ncf], atol=1e-5, rtol=1e-5)
+    close(lv.cpu().double(), y[:, ncf:], atol=1e-5, rtol=1e-5)
+    assert m8.dtype == torch.uint8 and torch.equal(m8.view(torch.bool), cap[:, :T_] == 0)
+    eps = torch.randn(B, ncf, generator=g).to(DEV)
+    c, mu2, lv2 = ops.ca_net(sent, w, b, ncf, eps)
+    assert torch.equal(mu2, mu1)
+    close(c, eps * torch.exp(0.5 * lv2) + mu2, atol=1e-5, rtol=1e-5)
+
+
+def test_multi_copy_one_launch():
+    """tgsr_multi_copy: dense buffers of different types and sizes (16-byte and 4-byte paths, one segment per blockIdx.y)."""
+    from tgsr_amd import ops
+    from tgsr_amd._lib import TgsrError
+    g = torch.Generator().manual_seed(1)
+    srcs = [torch.randn(16, 3, 32, 32, generator=g).to(DEV), torch.randint(0, 99, (16, 18), generator=g).to(DEV),
+            torch.randn(1000003, generator=g).to(DEV)[1:8], torch.randn(5, generator=g).to(DEV),
+            torch.randn(300001, generator=g).to(DEV)[1:]]
+    dsts = [torch.zeros_like(s_) for s_ in srcs]
+    dsts[4] = torch.zeros(300004, device=DEV)[3:-1]
+    ops.multi_copy(dsts, srcs)
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d, s_)
+    with pytest.raises(TgsrError):
+        ops.multi_copy([torch.zeros(3, device=DEV)], [torch.zeros(4, device=DEV)])
+
+
 def test_damsm_kernels_are_bitwise_reproducible():
     """No float atomics anywhere in the library: the DAMSM similarity and its backward give bit-identical results run
     after run (the four waves' partial sums of a workgroup meet in a fixed order)."""

@@ -70,6 +70,8 @@ SIGNATURES = {
     "tgsr_conv3x3_gemm_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tgsr_leaky_relu": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "tgsr_glu": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "tgsr_text_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "tgsr_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "tgsr_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "tgsr_gaussian_blur_u8": (_i, [_vp, _i, _i, _i, _i, ctypes.c_uint32, ctypes.c_uint32, _i, _vp, _vp, _vp]),

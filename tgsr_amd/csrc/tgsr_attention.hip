@@ -12,6 +12,7 @@
 // The kernel is HBM-bound ((2*idf + T) * 4 bytes per pixel against 4*idf*T flops): one pass over h, one write of
 // c_code and attn, versus bmm + masked_fill + softmax + 2 transposes + bmm in the reference.
 #include "tgsr_common.h"
+#include "tgsr_text_blocks.h"
 
 namespace tgsr {
 
@@ -46,49 +47,10 @@ __global__ __launch_bounds__(256) void word_project_kernel(const float* __restri
   src[((int64_t)b * idf + i) * 32 + t] = acc;
 }
 
-// The same projection on the MFMA units for up to 4 weight sets in ONE launch (the generator stages attend to the same
-// words through different conv_context weights): grid (B, nsets, idf / 32), 4 waves, each a quarter of the channel
-// pairs of src[i][t] = sum_c W[i][c] words[c][t] (A = W, lane = i; B = words, lane = t), summed through LDS.
-struct ProjArgs {
-  const float* words;
-  const float* w[4];
-  float* out;            // [nsets][B][idf][32]
-  int B, idf, cdf, T;
-};
-
+// word_project_block (tgsr_text_blocks.h): grid (B, nsets, idf / 32).
 __global__ __launch_bounds__(256) void word_project_mfma_kernel(ProjArgs a) {
-  __shared__ float red[4][16][64];
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5, wave = tid >> 6;
-  const int b = blockIdx.x, set = blockIdx.y, ib = blockIdx.z;
-  const float* wr = a.w[set] + (int64_t)(ib * 32 + l31) * a.cdf;
-  const float* wb = a.words + (int64_t)b * a.cdf * a.T;
-  const bool tok = l31 < a.T;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int nk = (a.cdf + 1) >> 1;
-  for (int ks = wave; ks < nk; ks += 32) {               // 8 k-steps of this wave per trip: their loads go out together
-    float av[8], bv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = 2 * (ks + 4 * j) + hh;
-      const bool ok = ks + 4 * j < nk && c < a.cdf;
-      av[j] = ok ? wr[c] : 0.f;
-      bv[j] = ok && tok ? wb[c * a.T + l31] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-  __syncthreads();
-  float* ob = a.out + ((int64_t)(set * a.B + b) * a.idf + ib * 32) * 32;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int o = tid + 256 * j, r = o >> 6, ln = o & 63;
-    const float v = red[0][r][ln] + red[1][r][ln] + red[2][r][ln] + red[3][r][ln];
-    ob[acc_row(r, ln >> 5) * 32 + (ln & 31)] = v;
-  }
+  __shared__ float red[kProjRedFloats];
+  word_project_block(a, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
 
 struct AttnArgs {

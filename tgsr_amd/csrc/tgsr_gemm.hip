@@ -5,6 +5,7 @@
 // pitch 65), MFMA "B" = activations (lane = n): NN reads them straight from HBM (n contiguous), NT stages a
 // [32 n][64 k] tile per wave.  Output strides are free, so both NCHW planes and [B][nef] rows are written directly.
 #include "tgsr_common.h"
+#include "tgsr_text_blocks.h"
 
 namespace tgsr {
 
@@ -156,6 +157,12 @@ __global__ __launch_bounds__(256) void ca_net_kernel(const float* __restrict__ s
   }
 }
 
+// ca_net_block (tgsr_text_blocks.h): grid (ceil(ncf / 4), ceil(B / 16)).
+__global__ __launch_bounds__(256) void ca_net_mfma_kernel(CaArgs a) {
+  __shared__ float red[kCaRedFloats];
+  ca_net_block(a, blockIdx.x, blockIdx.y, red);
+}
+
 static int gemm_launch(const GemmArgs& a, bool nt, int batch, hipStream_t s) {
   dim3 grid((a.N + 127) / 128, (a.M + 31) / 32, batch);
   if (nt) hipLaunchKernelGGL(gemm_bias_kernel<true>, grid, dim3(256), 0, s, a);
@@ -179,6 +186,13 @@ extern "C" int tgsr_conv1x1_fwd(const float* x, int B, int Cin, int S, const flo
 extern "C" int tgsr_ca_net_fwd(const float* sent_emb, const float* w, const float* bias, const float* eps, int B, int tdim,
                                int ncf, float* c_code, float* mu, float* logvar, void* stream) {
   if (!sent_emb || !w || !bias || !mu || !logvar || B < 1 || tdim < 1 || ncf < 1 || (c_code && !eps)) return TGSR_EINVAL;
+  if ((tdim & 15) == 0 && ((tdim & 63) != 0 || ((reinterpret_cast<uintptr_t>(sent_emb) | reinterpret_cast<uintptr_t>(w)) & 15) == 0)) {
+    CaArgs a;
+    a.sent = sent_emb; a.w = w; a.bias = bias; a.eps = eps; a.c_code = c_code; a.mu = mu; a.logvar = logvar;
+    a.B = B; a.tdim = tdim; a.ncf = ncf;
+    hipLaunchKernelGGL(ca_net_mfma_kernel, dim3((ncf + 3) / 4, (B + 15) / 16), dim3(256), 0, as_stream(stream), a);
+    return note_launch(hipGetLastError(), "ca_net_mfma_kernel");
+  }
   if ((size_t)(tdim + 4 * ncf) * sizeof(float) > 60 * 1024) return TGSR_EUNSUPPORTED;
   hipLaunchKernelGGL(ca_net_kernel, dim3(B, 2), dim3(256), (size_t)(tdim + 4 * ncf + 8) * sizeof(float), as_stream(stream),
                      sent_emb, w, bias, eps, tdim, ncf, c_code, mu, logvar);

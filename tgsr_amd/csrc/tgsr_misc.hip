@@ -82,6 +82,29 @@ __global__ void glu_kernel(const float* __restrict__ x, const float* __restrict_
   }
 }
 
+// Up to 16 dense device buffers copied in ONE launch (the static inputs of a captured step: 3 per lane).  blockIdx.y =
+// segment; 16-byte words when every pointer and size of the segment allows, 4-byte words otherwise.
+struct MultiCopyArgs {
+  void* dst[16];
+  const void* src[16];
+  uint32_t bytes[16];
+};
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopyArgs a) {
+  const int sgm = blockIdx.y;
+  const uint32_t nb = a.bytes[sgm];
+  const uintptr_t both = reinterpret_cast<uintptr_t>(a.dst[sgm]) | reinterpret_cast<uintptr_t>(a.src[sgm]) | nb;
+  if ((both & 15) == 0) {
+    const uint4* s = static_cast<const uint4*>(a.src[sgm]);
+    uint4* d = static_cast<uint4*>(a.dst[sgm]);
+    for (uint32_t o = blockIdx.x * 256 + threadIdx.x; o < (nb >> 4); o += gridDim.x * 256) d[o] = s[o];
+  } else {
+    const uint32_t* s = static_cast<const uint32_t*>(a.src[sgm]);
+    uint32_t* d = static_cast<uint32_t*>(a.dst[sgm]);
+    for (uint32_t o = blockIdx.x * 256 + threadIdx.x; o < (nb >> 2); o += gridDim.x * 256) d[o] = s[o];
+  }
+}
+
 }  // namespace tgsr
 
 using namespace tgsr;
@@ -132,4 +155,26 @@ extern "C" int tgsr_glu(const float* x, const float* dy, float* out, int64_t out
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(glu_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, out, outer, half);
   return note_launch(hipGetLastError(), "glu_kernel");
+}
+
+extern "C" int tgsr_multi_copy(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream) {
+  if (n < 1 || !dst || !src || !nbytes) return TGSR_EINVAL;
+  if (n > 16) return TGSR_EUNSUPPORTED;
+  MultiCopyArgs a;
+  uint32_t most = 0;
+  for (int i = 0; i < 16; ++i) {
+    a.dst[i] = nullptr; a.src[i] = nullptr; a.bytes[i] = 0;
+    if (i >= n) continue;
+    if (!dst[i] || !src[i] || nbytes[i] < 0) return TGSR_EINVAL;
+    if (nbytes[i] > 0x7fffffff || (nbytes[i] & 3) ||
+        ((reinterpret_cast<uintptr_t>(dst[i]) | reinterpret_cast<uintptr_t>(src[i])) & 3))
+      return TGSR_EUNSUPPORTED;
+    a.dst[i] = dst[i]; a.src[i] = src[i]; a.bytes[i] = (uint32_t)nbytes[i];
+    most = a.bytes[i] > most ? a.bytes[i] : most;
+  }
+  if (most == 0) return TGSR_OK;
+  const uint32_t words = (most + 15) / 16;
+  const int bx = (int)((words + 255) / 256 < 64 ? (words + 255) / 256 : 64);
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, n), dim3(256), 0, as_stream(stream), a);
+  return note_launch(hipGetLastError(), "multi_copy_kernel");
 }

@@ -375,6 +375,15 @@ def _ca_net(sent_emb, w, b, ncf, eps):
 ca_net = _define("ca_net(Tensor sent_emb, Tensor w, Tensor b, int ncf, Tensor? eps) -> (Tensor, Tensor, Tensor)", _ca_net,
                  lambda s_, w, b, ncf, eps: (s_.new_empty(s_.shape[0], ncf) if eps is not None else s_.new_empty(0),
                                              s_.new_empty(s_.shape[0], ncf), s_.new_empty(s_.shape[0], ncf)))
+text_tail = _define("text_tail(Tensor words, Tensor[] w_ctxs, Tensor sent_emb, Tensor ca_w, Tensor ca_b, int ncf, Tensor captions) "
+                    "-> (Tensor, Tensor, Tensor, Tensor)",
+                    lambda words, ws, sent, cw, cb, ncf, cap: ops.text_tail(words, list(ws), sent, cw, cb, ncf, cap),
+                    lambda words, ws, sent, cw, cb, ncf, cap:
+                    (words.new_empty(len(ws), words.shape[0], ws[0].shape[0], 32), words.new_empty(words.shape[0], ncf),
+                     words.new_empty(words.shape[0], ncf),
+                     words.new_empty(words.shape[0], words.shape[2], dtype=torch.uint8)))
+multi_copy = _define("multi_copy(Tensor(a!)[] dsts, Tensor[] srcs) -> ()",
+                     lambda dsts, srcs: ops.multi_copy(list(dsts), list(srcs)), lambda dsts, srcs: None)
 to_uint8 = _define("to_uint8(Tensor img) -> Tensor", lambda x: ops.to_uint8(x), lambda x: torch.empty_like(x, dtype=torch.uint8))
 
 

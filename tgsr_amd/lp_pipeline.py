@@ -156,16 +156,14 @@ class LpExecutor:
         return b
 
     # ------------------------------------------------------------------ the two generators
-    def low(self, bufs, LR, sent_emb, word_embs, mask, ca=None):
+    def low(self, bufs, LR, sent_emb, word_embs, mask, ca=None, proj=None):
         """G_SR_NET_low.forward (model.py:48-78) -> (fake_imgs, att_maps, mu, logvar, [h image of each stage])."""
         GL = self.netGL
         c_code, mu, logvar = GL.ca_net(sent_emb) if ca is None else ca
         T = word_embs.size(2)
-        atts_m = []
-        for st in self.gl_stage:                                               # distinct attention modules (x16: two)
-            if all(st["att"] is not m for m in atts_m):
-                atts_m.append(st["att"])
-        proj = C.word_project(word_embs, [m.conv_context.weight.detach() for m in atts_m])
+        atts_m = GL.attention_modules()                                        # distinct attention modules (x16: two)
+        if proj is None:
+            proj = C.word_project(word_embs, [m.conv_context.weight.detach() for m in atts_m])
         srcs = [proj[[i for i, m in enumerate(atts_m) if m is st["att"]][0]] for st in self.gl_stage]
         last = len(self.gl_stage) - 1
         fake, atts, pend = [], [], []

@@ -50,16 +50,22 @@ class G_SR_NET_low(nn.Module):
         self.img_net2 = GET_IMAGE_G_noAct(ngf)
         self.img_net3 = GET_IMAGE_G_noAct(ngf)
 
-    def forward(self, LR, sent_emb, word_embs, mask, outmiddle=False, ca=None):
-        """ca: optional precomputed `self.ca_net(sent_emb)` (SRPipeline runs that chain of tiny launches on its
-        second stream: nothing downstream reads c_code, model.py:51-52, only mu / logvar are returned)."""
+    def attention_modules(self):
+        """The distinct GlobalAttentionGeneral modules in stage order: `proj` of forward() holds their word projections."""
+        return [self.h_net1.att, self.h_net2.att, self.h_net3.att]
+
+    def forward(self, LR, sent_emb, word_embs, mask, outmiddle=False, ca=None, proj=None):
+        """ca: optional precomputed `self.ca_net(sent_emb)` (nothing downstream reads c_code, model.py:51-52, only mu /
+        logvar are returned); proj: optional precomputed conv_context projections of `attention_modules()` (SRPipeline
+        computes both, and the mask, in one launch: ops.text_tail)."""
         fake_imgs, att_maps = [], []
         c_code, mu, logvar = self.ca_net(sent_emb) if ca is None else ca   # c_code unused downstream (model.py:51-52)
         srcs = [None, None, None]
-        if not self.training:
+        if proj is not None:
+            srcs = proj
+        elif not self.training:
             # the three stages attend to the same words: their conv_context projections go out as one launch
-            atts = [self.h_net1.att, self.h_net2.att, self.h_net3.att]
-            srcs = C.word_project(word_embs, [a.conv_context.weight.detach() for a in atts])
+            srcs = C.word_project(word_embs, [a.conv_context.weight.detach() for a in self.attention_modules()])
         h_code1, att0 = self.h_net1(None, LR, word_embs, mask, wide_out=True, src=srcs[0])
         fake_imgs.append(self.img_net1(h_code1))
         att_maps.append(att0)

@@ -32,15 +32,21 @@ class G_SR_NET_low(nn.Module):
         self.h_net4 = self.h_net3 = self.h_net2 = NEXT_STAGE_G(ngf, nef, ncf)
         self.img_net4 = self.img_net3 = self.img_net2 = self.img_net1 = GET_IMAGE_G(ngf)
 
-    def forward(self, LR, sent_emb, word_embs, mask, ca=None):
-        """ca: optional precomputed `self.ca_net(sent_emb)` (SRPipeline runs it beside the trunk, like the x8 model)."""
+    def attention_modules(self):
+        """The distinct GlobalAttentionGeneral modules in stage order (h_net1's and the tied stages')."""
+        return [self.h_net1.att, self.h_net2.att]
+
+    def forward(self, LR, sent_emb, word_embs, mask, ca=None, proj=None):
+        """ca / proj: optional precomputed `self.ca_net(sent_emb)` and conv_context projections of `attention_modules()`
+        (SRPipeline computes them, and the mask, in one launch - like the x8 model)."""
         fake_imgs, att_maps = [], []
         c_code, mu, logvar = self.ca_net(sent_emb) if ca is None else ca
         src1 = src2 = None
-        if not self.training:
+        if proj is not None:
+            src1, src2 = proj
+        elif not self.training:
             # two distinct conv_context projections (h_net1's and the tied stages'): one launch for both
-            src1, src2 = C.word_project(word_embs, [self.h_net1.att.conv_context.weight.detach(),
-                                                    self.h_net2.att.conv_context.weight.detach()])
+            src1, src2 = C.word_project(word_embs, [a.conv_context.weight.detach() for a in self.attention_modules()])
         h_code, att = self.h_net1(None, LR, word_embs, mask, wide_out=True, src=src1)
         fake_imgs.append(self.img_net1(h_code))
         att_maps.append(att)

@@ -327,6 +327,8 @@ def _mask_u8(mask: torch.Tensor) -> torch.Tensor:
     """bool -> uint8 once per mask tensor (the three generator stages share one mask)."""
     if mask.dtype == torch.uint8 and mask.is_contiguous():
         return mask
+    if mask.dtype == torch.bool and mask.is_contiguous():
+        return mask.view(torch.uint8)                    # torch.bool storage is one byte 0 / 1: no cast kernel
     key = (mask.data_ptr(), mask._version, tuple(mask.shape), mask.dtype)
     if _MASK_CACHE[0] != key or _MASK_CACHE[1] is not mask:
         _MASK_CACHE[0], _MASK_CACHE[1], _MASK_CACHE[2] = key, mask, mask.to(torch.uint8).contiguous()
@@ -763,6 +765,54 @@ def ca_net(sent_emb: torch.Tensor, w: torch.Tensor, b: torch.Tensor, ncf: int, e
     check(_lib.lib().tgsr_ca_net_fwd(_p(x), _p(w), _p(b), _p(eps), B, tdim, ncf, _p(c_code), _p(mu), _p(logvar), _stream()),
           "tgsr_ca_net_fwd")
     return c_code, mu, logvar
+
+
+def text_tail(words: torch.Tensor, w_ctxs, sent_emb: torch.Tensor, ca_w: torch.Tensor, ca_b: torch.Tensor, ncf: int,
+              captions: torch.Tensor):
+    """What an inference step needs between the text encoder and the generator, in one launch (tgsr_text_tail_fwd):
+    word_project(words, w_ctxs), CA_NET's (mu, logvar) and mask = (captions[:, :T] == 0).
+    Returns (src [nsets,B,idf,32], mu, logvar, mask uint8 [B,T] - `.view(torch.bool)` is the reference's mask)."""
+    import ctypes
+    _need_hip(words, sent_emb, ca_w, ca_b, captions, *w_ctxs)
+    words = _f32(words, "words").contiguous()
+    B, cdf, T = words.shape
+    n = len(w_ctxs)
+    idf = w_ctxs[0].shape[0]
+    ws = [_f32(w.detach(), "w_ctx").reshape(idf, cdf).contiguous() for w in w_ctxs]
+    x = _f32(sent_emb, "sent_emb").contiguous()
+    w, b = _f32(ca_w.detach(), "ca_w").contiguous(), _f32(ca_b.detach(), "ca_b").contiguous()
+    if captions.dtype != torch.int64 or captions.dim() != 2 or captions.shape[0] != B or captions.shape[1] < T:
+        raise TgsrError("text_tail: captions %s %s for words %s" % (tuple(captions.shape), captions.dtype, tuple(words.shape)))
+    captions = captions.contiguous()
+    if x.shape[0] != B or w.shape != (4 * ncf, x.shape[1]):
+        raise TgsrError("text_tail: sent_emb %s / fc weight %s" % (tuple(x.shape), tuple(w.shape)))
+    out = torch.empty(n, B, idf, 32, dtype=torch.float32, device=words.device)
+    mu = torch.empty(B, ncf, dtype=torch.float32, device=words.device)
+    logvar = torch.empty_like(mu)
+    mask = torch.empty(B, T, dtype=torch.uint8, device=words.device)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ws])
+    check(_lib.lib().tgsr_text_tail_fwd(_p(words), ptrs, n, B, idf, cdf, T, _p(out), _p(x), _p(w), _p(b), x.shape[1], ncf,
+                                        _p(mu), _p(logvar), _p(captions), captions.shape[1], _p(mask), _stream()),
+          "tgsr_text_tail_fwd")
+    return out, mu, logvar, mask
+
+
+def multi_copy(dsts, srcs) -> None:
+    """dst[i].copy_(src[i]) for up to 16 dense same-shape, same-dtype device tensors in one launch (tgsr_multi_copy)."""
+    import ctypes
+    n = len(dsts)
+    if n == 0:
+        return
+    if n != len(srcs) or n > 16:
+        raise TgsrError("multi_copy: %d destinations, %d sources" % (n, len(srcs)))
+    _need_hip(*dsts, *srcs)
+    for d, s_ in zip(dsts, srcs):
+        if d.shape != s_.shape or d.dtype != s_.dtype or not d.is_contiguous() or not s_.is_contiguous():
+            raise TgsrError("multi_copy: %s %s <- %s %s" % (tuple(d.shape), d.dtype, tuple(s_.shape), s_.dtype))
+    dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    sp = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+    nb = (ctypes.c_int64 * n)(*[d.numel() * d.element_size() for d in dsts])
+    check(_lib.lib().tgsr_multi_copy(n, dp, sp, nb, _stream()), "tgsr_multi_copy")
 
 
 # ----------------------------------------------------------------------------------------- image pyramid (uint8)

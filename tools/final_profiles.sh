@@ -3,17 +3,19 @@
 # bench lines (default fp32, bf16 graph, f16 graph, bf16 eager lanes, bf16 B=8 graph, train) + rocprofv3 stats / PMC of
 # the fp32 and bf16 paths.  Everything lands in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 set -e
-TAG=${1:-r02z}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
 python3 bench.py > $OUT/${TAG}_bench_fp32.json 2> $OUT/${TAG}_bench_fp32.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --extras none > $OUT/${TAG}_bench_fp32_driver_flags.json 2> $OUT/${TAG}_bench_fp32_driver_flags.err
+python3 bench.py --eager --no-cpu-baseline --extras none > $OUT/${TAG}_bench_fp32_eager_lanes3.json 2> $OUT/${TAG}_bench_fp32_eager.err
 echo "fp32 done"
 python3 bench.py --dtype bf16 --graph > $OUT/${TAG}_bench_bf16_graph.json 2> $OUT/${TAG}_bench_bf16_graph.err
 echo "bf16 graph done"
 python3 bench.py --dtype f16 --graph --no-cpu-baseline > $OUT/${TAG}_bench_f16_graph.json 2> $OUT/${TAG}_bench_f16_graph.err
-python3 bench.py --dtype bf16 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_lanes.json 2> $OUT/${TAG}_bench_bf16_lanes.err
+python3 bench.py --dtype bf16 --eager --no-cpu-baseline > $OUT/${TAG}_bench_bf16_eager_lanes3.json 2> $OUT/${TAG}_bench_bf16_eager.err
 python3 bench.py --dtype bf16 --graph --batch 8 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b8.json 2> $OUT/${TAG}_bench_bf16_graph_b8.err
 python3 bench.py --dtype bf16 --graph --batch 64 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b64.json 2> $OUT/${TAG}_bench_bf16_graph_b64.err
 python3 bench.py --dtype bf16 --graph --graph-lanes 4 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_lanes4.json 2> $OUT/${TAG}_bench_bf16_graph_lanes4.err
@@ -28,8 +30,8 @@ bash tools/profile_stats.sh ${TAG}_train_gan --mode train --gan --steps 4 --warm
 rm -f $OUT/${TAG}_train_stats.log $OUT/${TAG}_train_gan_stats.log
 echo "train profiles done"
 TGSR_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_rehearsal_2ranks.json 2> $OUT/${TAG}_bench_rehearsal.err || echo "rehearsal failed"
-bash tools/profile_pmc.sh ${TAG}_fp32 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial
-bash tools/profile_pmc.sh ${TAG}_bf16 --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial
+bash tools/profile_pmc.sh ${TAG}_fp32 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial --extras none
+bash tools/profile_pmc.sh ${TAG}_bf16 --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial --extras none
 for f in $OUT/${TAG}_bench_*.json; do python3 -c "
 import json,sys
 try:
