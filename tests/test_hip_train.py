@@ -221,6 +221,46 @@ def test_side_stream_weight_gradients_change_nothing(monkeypatch):
         cfg_reset()
 
 
+def test_pack_cache_changes_nothing_over_steps(monkeypatch):
+    """SRTrainer re-packs the generators' conv weights behind the optimizer on a stream of its own (autograd.PackCache)
+    instead of in front of every convolution.  Four optimisation steps with and without the cache, same initial weights
+    and batches: bit-identical losses and parameters (a pack served one step late, or rewritten while a kernel of the
+    previous backward still reads it, would show up here); an in-place write outside the optimizer re-packs on the spot."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.synthetic import synthetic_batch
+    from tgsr_amd.train import SRTrainer
+    cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 256
+    try:
+        B = 4
+        a = SRTrainer(41, device=DEV)
+        assert a._packs is not None
+        monkeypatch.setenv("TGSR_PACK_CACHE", "0")
+        b = SRTrainer(41, device=DEV)
+        assert b._packs is None
+        for m, n in ((a.text_encoder, b.text_encoder), (a.netGL, b.netGL), (a.netGH, b.netGH)):
+            n.load_state_dict(m.state_dict())
+        losses_ = [[], []]
+        for k, t in enumerate((a, b)):
+            for it in range(4):
+                cap, lens, LR, LRb = synthetic_batch(B, seed=3 + it)
+                gen = torch.Generator().manual_seed(21 + it)
+                hr = [(torch.rand(B, 3, s, s, generator=gen) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+                torch.manual_seed(5 + it)
+                if it == 2:                              # a write behind the cache's back: version counter moves
+                    with torch.no_grad():
+                        t.netGH.convin[0].weight.mul_(1.01)
+                        t.netGL.h_net1.upsample[1].weight.add_(0.001)
+                losses_[k].append(float(t.step(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)))
+        torch.cuda.synchronize()
+        assert losses_[0] == losses_[1], losses_
+        assert len(a._packs.entries) > 40
+        for (n, p), (_, q) in zip(list(a.netGL.named_parameters()) + list(a.netGH.named_parameters()),
+                                  list(b.netGL.named_parameters()) + list(b.netGH.named_parameters())):
+            assert torch.equal(p, q), n
+    finally:
+        cfg_reset()
+
+
 def test_train_step_decreases_loss_and_updates_running_stats(nets_small):
     from conftest import split_sd
     from tgsr_amd.miscc.config import cfg, cfg_reset

@@ -75,21 +75,89 @@ def _grad_out(param, shape, dev):
     return slot if slot is not None else torch.empty(tuple(shape), dtype=torch.float32, device=dev)
 
 
+class PackCache:
+    """The packed forms (Winograd U, direct-kernel stream order, up-sample-aware Winograd taps; forward and data-gradient
+    variants) of the generator's conv weights across training steps.  The parameters change once per step, in the
+    optimizer: `repack()` - called right after it - rewrites every pack seen so far IN PLACE on a stream of its own, so the
+    ~70 pack launches of a step (4-5 us each, each in front of the conv that needs it) leave the critical stream and run
+    under the EMA update and the text encoder of the next step.  `get` serves a pack while the weight's version counter
+    still equals the one it was made from (a load_state_dict or any other in-place write makes it re-pack on the spot)."""
+
+    def __init__(self):
+        self.entries = {}            # (data_ptr, shape, kind) -> [weight alias, kind, packed, version]
+        self.stream = None
+        self.event = None
+
+    @staticmethod
+    def _pack(weight, kind, out):
+        if kind == "wino":
+            return ops.pack_wino_weight(weight, False, False, out=out)
+        if kind == "wino_dgrad":
+            return ops.pack_wino_weight(weight, False, True, out=out)
+        if kind == "upwino":
+            return ops.pack_upwino_weight(weight, False, out=out)
+        return ops.pack_conv3x3_weight(weight, kind == "direct_dgrad", out=out)
+
+    def get(self, weight, kind):
+        if self.event is not None:                       # first use after a repack: this stream waits for it once
+            torch.cuda.current_stream(weight.device).wait_event(self.event)
+            self.event = None
+        key = (weight.data_ptr(), tuple(weight.shape), kind)
+        e = self.entries.get(key)
+        if e is not None and e[3] == weight._version:
+            return e[2]
+        out = self._pack(weight, kind, e[2] if e is not None else None)
+        self.entries[key] = [weight.detach(), kind, out, weight._version]
+        return out
+
+    def repack(self):
+        """Re-derive every cached pack from the current weights on the pack stream (ordered behind everything queued on
+        the current stream: the optimizer step, and the previous backward's reads of the old packs)."""
+        if not self.entries:
+            return
+        dev = next(iter(self.entries.values()))[0].device
+        with torch.cuda.device(dev):
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=dev)
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self.stream), torch.no_grad():
+                for e in self.entries.values():
+                    if e[3] != e[0]._version:
+                        self._pack(e[0], e[1], e[2])
+                        e[3] = e[0]._version
+            self.event = torch.cuda.Event()
+            self.event.record(self.stream)
+
+
+_PACKS = None        # the PackCache of the trainer whose step is running (train.SRTrainer sets it), else packs are per call
+
+
+def _packed(weight, kind):
+    if _PACKS is not None and weight.is_cuda and not torch.cuda.is_current_stream_capturing():
+        return _PACKS.get(weight, kind)
+    if kind in ("wino", "wino_dgrad"):
+        return C.pack_wino_weight(weight, False, kind == "wino_dgrad")
+    if kind == "upwino":
+        return C.pack_upwino_weight(weight, False)
+    return C.pack_conv3x3_weight(weight, kind == "direct_dgrad")
+
+
 def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgrad: bool = False,
               residual: torch.Tensor = None) -> torch.Tensor:
     """conv3x3 without affine / activation (what BatchNorm's batch statistics are taken of, and the data gradient):
     the Winograd kernel where it applies (no up-sampling, Cout % 64 == 0, Cin % 4 == 0), else the direct kernel.
-    The weights change every step, so they are packed per call (a few microseconds).  `dgrad`: `weight` is the forward
+    The weights change every step: they are packed per call (a few microseconds each), or - inside a trainer's step -
+    served from its PackCache, which re-packs them all behind the optimizer on a stream of its own.  `dgrad`: `weight` is the forward
     layer's [Cin_of_x... = weight.shape[0]] filter and the conv applied is its transpose (pack kernels read it
     transposed and flipped: no flip / transpose / copy kernels)."""
     from . import util
     Cout = weight.shape[1] if dgrad else weight.shape[0]
     if util.WINOGRAD and not upsample and util._wino_pays(x, Cout, None, None):
-        return C.conv3x3_wino(x, C.pack_wino_weight(weight, False, dgrad), Cout, None, None, False, residual)
+        return C.conv3x3_wino(x, _packed(weight, "wino_dgrad" if dgrad else "wino"), Cout, None, None, False, residual)
     if util.WINOGRAD and upsample and ops.upwino_supported(x, Cout):
         assert not dgrad and residual is None
-        return C.upwino(x, C.pack_upwino_weight(weight, False), Cout, None, None, False)
-    return C.conv3x3_fused(x, C.pack_conv3x3_weight(weight, dgrad), Cout, None, None, False, upsample, residual)
+        return C.upwino(x, _packed(weight, "upwino"), Cout, None, None, False)
+    return C.conv3x3_fused(x, _packed(weight, "direct_dgrad" if dgrad else "direct"), Cout, None, None, False, upsample, residual)
 
 
 def _cba_forward(x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps, nbt):

@@ -92,7 +92,7 @@ def _check_pack(what: str, kind: str, pack: torch.Tensor, cout: int, cin: int):
                                                                               cout, cin, cin))
 
 
-def pack_conv3x3_weight(w: torch.Tensor, dgrad: bool = False) -> torch.Tensor:
+def pack_conv3x3_weight(w: torch.Tensor, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[Cout,Cin,3,3] -> the [ceil(Cin/4)][9][4][Cout] stream order of tgsr_conv3x3_fwd.  `dgrad`: w is the forward
     conv's weight and the pack is of its data-gradient conv (in/out swapped, taps flipped) - no flip/transpose copies."""
     _need_hip(w)
@@ -102,7 +102,7 @@ def pack_conv3x3_weight(w: torch.Tensor, dgrad: bool = False) -> torch.Tensor:
     if dgrad:
         Cout, Cin = Cin, Cout
     L = _lib.lib()
-    out = torch.empty(L.tgsr_packed_weight_elems(Cout, Cin, 3), dtype=torch.float32, device=w.device)
+    out = _pack_out(out, L.tgsr_packed_weight_elems(Cout, Cin, 3), w.device)
     if dgrad:
         check(L.tgsr_pack_conv_weight_dgrad(_p(w), _p(out), Cout, Cin, 3, _stream()), "tgsr_pack_conv_weight_dgrad")
     else:
@@ -157,7 +157,16 @@ def conv3x3_fused(x: torch.Tensor, wpack: torch.Tensor, cout: int, scale: Option
     return out
 
 
-def pack_wino_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False) -> torch.Tensor:
+def _pack_out(out, n, dev):
+    """A pack's destination: fresh, or the caller's persistent buffer (autograd.PackCache re-packs in place)."""
+    if out is None:
+        return torch.empty(n, dtype=torch.float32, device=dev)
+    if out.numel() != n or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
+        raise TgsrError("pack: out %s %s does not hold %d floats" % (tuple(out.shape), out.dtype, n))
+    return out
+
+
+def pack_wino_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[Cout,Cin,3,3] -> Winograd F(2x2,3x3) transformed weights [ceil(Cin/8)][Cout/64][16 pos][8][64]; `glu` must
     match the epilogue the pack is used with (it groups value channels with their gate channels).  `dgrad`: w is the
     forward conv's weight, the pack is of its data-gradient conv (see pack_conv3x3_weight)."""
@@ -167,7 +176,7 @@ def pack_wino_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False) ->
     if dgrad:
         Cout, Cin = Cin, Cout
     L = _lib.lib()
-    out = torch.empty(L.tgsr_packed_wino_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
+    out = _pack_out(out, L.tgsr_packed_wino_weight_elems(Cout, Cin), w.device)
     if dgrad:
         assert not glu
         check(L.tgsr_pack_wino_weight_dgrad(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_wino_weight_dgrad")
@@ -249,14 +258,14 @@ def upconv3x3_glu(x: torch.Tensor, wpack_up: torch.Tensor, cout: int, scale, shi
     return out
 
 
-def pack_upwino_weight(w: torch.Tensor, glu: bool = True) -> torch.Tensor:
+def pack_upwino_weight(w: torch.Tensor, glu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[Cout,Cin,3,3] -> the 9 tap-sum positions of the up-sample-aware Winograd form (tgsr_upwino_glu_fwd; glu=False:
     the layout of tgsr_upwino_fwd)."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
     L = _lib.lib()
-    out = torch.empty(L.tgsr_packed_upwino_weight_elems(Cout, Cin), dtype=torch.float32, device=w.device)
+    out = _pack_out(out, L.tgsr_packed_upwino_weight_elems(Cout, Cin), w.device)
     check(L.tgsr_pack_upwino_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_upwino_weight")
     return out
 

@@ -50,6 +50,8 @@ class SRTrainer:
         # the generators' weight gradients run on a side stream beside the data-gradient chain while a step's backward
         # is in flight (12.7 -> 11.7 ms per step at B=16: the small layers' weight-gradient kernels and the slab sums
         # fill a fraction of the CUs); TGSR_WGRAD_SIDE=0 keeps everything on one stream
+        from . import autograd as _ag
+        self._packs = _ag.PackCache() if (self.device.type == "cuda" and os.environ.get("TGSR_PACK_CACHE", "1") != "0") else None
         self._wside = torch.cuda.Stream(device=self.device) \
             if self.device.type == "cuda" and os.environ.get("TGSR_WGRAD_SIDE", "1") != "0" else None
         self.image_encoder = image_encoder
@@ -122,6 +124,16 @@ class SRTrainer:
         return adv + losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
 
     @contextlib.contextmanager
+    def _use_packs(self):
+        """Scope in which the conv blocks take their packed weights from this trainer's autograd.PackCache."""
+        from . import autograd
+        prev, autograd._PACKS = autograd._PACKS, self._packs
+        try:
+            yield
+        finally:
+            autograd._PACKS = prev
+
+    @contextlib.contextmanager
     def _wgrad_side(self):
         """Scope in which autograd.ConvBnAct issues its weight gradients on this trainer's side stream; the stream is
         joined on exit, before anything reads the gradients."""
@@ -146,7 +158,8 @@ class SRTrainer:
         """One G/D alternation: forward the generators once; update every discriminator on (real, fake.detach());
         then update the generators through the UPDATED discriminators on the same fake images.  Returns
         (errG, [errD_i]) as detached tensors."""
-        fake_imgL, fine_im, mu, logvar, words_embs, sent_emb = self.forward_G(captions, cap_lens, LR, LRb)
+        with self._use_packs():
+            fake_imgL, fine_im, mu, logvar, words_embs, sent_emb = self.forward_G(captions, cap_lens, LR, LRb)
         for b in self.bucketsD:
             self._zero(b)
         if self._dstreams:
@@ -186,7 +199,7 @@ class SRTrainer:
                 p.requires_grad_(False)
         try:
             errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
-            with self._wgrad_side():
+            with self._use_packs(), self._wgrad_side():
                 errG.backward()
         finally:
             for b in self.bucketsD:
@@ -197,6 +210,8 @@ class SRTrainer:
             b.end_step()
         self.bucket.all_reduce_mean()
         self.opt.step()
+        if self._packs is not None:
+            self._packs.repack()
         with torch.no_grad():
             torch._foreach_mul_(self.avg_param_G, self.ema_decay)
             torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
@@ -209,13 +224,16 @@ class SRTrainer:
             return self.step_gan(captions, cap_lens, LR, LRb, hr_pyramid)[0]
         self._zero(self.bucket)
         try:
-            errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
-            with self._wgrad_side():
-                errG.backward()
+            with self._use_packs():
+                errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
+                with self._wgrad_side():
+                    errG.backward()
         finally:
             self.bucket.end_step()               # also after a failed step: `.grad` views restored, slots closed
         self.bucket.all_reduce_mean()
         self.opt.step()
+        if self._packs is not None:
+            self._packs.repack()                 # next step's packed weights, off the critical stream
         with torch.no_grad():
             torch._foreach_mul_(self.avg_param_G, self.ema_decay)
             torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
