@@ -307,6 +307,22 @@ int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma
                       float* out, int64_t out_bstride, int64_t* num_batches_tracked, void* stream);
 
 /*
+ * The statistics pass folded into the producing convolution.  tgsr_wino_conv3x3_stats_fwd = tgsr_wino_conv3x3_fwd with the
+ * plain epilogue (no affine, no residual: the raw output BatchNorm's batch statistics are taken of) that also writes
+ * stat_partial [Cout][nslots][2]: one (sum, sum of squares) pair per channel and wave tile, nslots =
+ * tgsr_wino_stats_nslots(B, H, W, Cout).  tgsr_bn_train_fwd_from_stats = tgsr_bn_train_fwd without its pass over the raw
+ * tensor: it combines those pairs (double precision, fixed order) instead.
+ */
+int tgsr_wino_stats_nslots(int B, int H, int W, int Cout);
+int tgsr_wino_conv3x3_stats_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                                int Cout, float* out, int64_t out_bstride, float* stat_partial, void* stream);
+int tgsr_bn_train_fwd_from_stats(const float* raw, int B, int C, int HW, const float* gamma, const float* beta, float eps,
+                                 float momentum, float* running_mean, float* running_var, int glu, const float* residual,
+                                 int64_t res_bstride, const float* stat_partial, int nslots, float* mean, float* invstd,
+                                 float* scale, float* shift, float* out, int64_t out_bstride, int64_t* num_batches_tracked,
+                                 void* stream);
+
+/*
  * Backward of the above: dout [B][C or C/2][HW] dense -> draw [B][C][HW] (gradient wrt the raw conv output),
  * dgamma, dbeta [C].  The gradient wrt a residual input is dout itself.  sums_ws: no longer used (the apply pass combines
  * the partials itself); any non-NULL pointer, e.g. partial_ws.

@@ -107,6 +107,10 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     chk = torch.library.opcheck
     chk(T.bn_train_fwd.default, (raw, gam, bet, 1e-5, 0.1, rm, rv, 1, None, nbt), test_utils=basic)
     out, stats = T.bn_train_fwd(raw, gam, bet, 1e-5, 0.1, rm, rv, 1, None, nbt)
+    upw = T.pack_wino_weight(R(Cc, Cc, 3, 3), False, False)
+    chk(T.conv3x3_wino_stats.default, (raw, upw, Cc), test_utils=basic)
+    _, sp = T.conv3x3_wino_stats(raw, upw, Cc)
+    chk(T.bn_train_fwd_from_stats.default, (raw, gam, bet, 1e-5, 0.1, rm, rv, 1, None, nbt, sp), test_utils=basic)
     chk(T.bn_train_fwd_out.default, (raw, gam, bet, 1e-5, 0.1, rm, rv, 2, nbt, torch.empty_like(raw), torch.empty(4, Cc, device=DEV)),
         test_utils=basic)
     chk(T.bn_train_bwd.default, (R(B, Cc // 2, H, W), raw, stats, 1, torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV), None),

@@ -221,6 +221,37 @@ def test_side_stream_weight_gradients_change_nothing(monkeypatch):
         cfg_reset()
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 32, 16, 32, 64), (3, 64, 12, 40, 128), (1, 32, 32, 32, 32), (2, 8, 6, 4, 96)])
+def test_batch_statistics_in_the_conv_epilogue(B, Cin, H, W, Cout):
+    """tgsr_wino_conv3x3_stats_fwd: the same raw output as the plain Winograd convolution (bit for bit) plus one
+    (sum, sum of squares) pair per channel and wave tile - ragged tiles contribute only their in-image pixels;
+    tgsr_bn_train_fwd_from_stats on them = tgsr_bn_train_fwd with its own statistics pass (tolerance: the order of the
+    fp32 partial sums differs), running statistics and num_batches_tracked included."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).to(DEV)
+    up = ops.pack_wino_weight(w, False, False)
+    ref = ops.conv3x3_wino(x, up, Cout, None, None, False, None)
+    out, part = ops.conv3x3_wino_stats(x, up, Cout)
+    assert torch.equal(out, ref) and part.shape[0] == Cout and part.shape[2] == 2
+    s = part.double().sum(1)
+    close(s[:, 0], ref.double().sum((0, 2, 3)), atol=1e-3, rtol=1e-5)
+    close(s[:, 1], (ref.double() ** 2).sum((0, 2, 3)), atol=1e-3, rtol=1e-5)
+    if H * W % 4 == 0:
+        for act in (0, 1):
+            gam, bet = torch.rand(Cout, generator=g).to(DEV) + 0.5, torch.randn(Cout, generator=g).to(DEV)
+            res = []
+            for sp in (None, part):
+                rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+                nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+                y, st = ops.bn_train_fwd(ref, gam, bet, 1e-5, 0.1, rm, rv, act, None, nbt, stat_partial=sp)
+                res.append((y, st, rm, rv, nbt))
+            for a_, b_ in zip(res[0][:4], res[1][:4]):
+                close(a_, b_, atol=2e-5, rtol=2e-5)
+            assert int(res[1][4]) == 1
+
+
 def test_pack_cache_changes_nothing_over_steps(monkeypatch):
     """SRTrainer re-packs the generators' conv weights behind the optimizer on a stream of its own (autograd.PackCache)
     instead of in front of every convolution.  Four optimisation steps with and without the cache, same initial weights

@@ -70,6 +70,10 @@ SIGNATURES = {
     "tgsr_conv3x3_gemm_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tgsr_leaky_relu": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "tgsr_glu": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "tgsr_wino_stats_nslots": (_i, [_i, _i, _i, _i]),
+    "tgsr_wino_conv3x3_stats_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp]),
+    "tgsr_bn_train_fwd_from_stats": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp,
+                                          _vp, _i64, _vp, _vp]),
     "tgsr_text_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "tgsr_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),

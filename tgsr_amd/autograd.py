@@ -129,6 +129,8 @@ class PackCache:
             self.event.record(self.stream)
 
 
+import os as _os
+BN_STATS_IN_CONV = _os.environ.get("TGSR_BN_STATS_IN_CONV", "1") != "0"
 _PACKS = None        # the PackCache of the trainer whose step is running (train.SRTrainer sets it), else packs are per call
 
 
@@ -162,7 +164,15 @@ def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgr
 
 def _cba_forward(x, weight, gamma, beta, running_mean, running_var, residual, glu, upsample, momentum, eps, nbt):
     """conv3x3 (raw) -> BatchNorm batch statistics -> normalise (+ GLU | + residual).  Returns (out, raw, stats)."""
-    raw = _conv_raw(x, weight.detach(), upsample)
+    from . import util
+    w = weight.detach()
+    if BN_STATS_IN_CONV and util.WINOGRAD and not upsample and util._wino_pays(x, w.shape[0], None, None):
+        # BatchNorm's statistics pass rides the convolution's epilogue: one (sum, sumsq) pair per channel and wave tile
+        raw, part = C.conv3x3_wino_stats(x, _packed(w, "wino"), w.shape[0])
+        out, stats = C.bn_train_fwd_from_stats(raw, gamma.detach(), beta.detach(), float(eps), float(momentum), running_mean,
+                                               running_var, 1 if glu else 0, residual, nbt, part)
+        return out, raw, stats
+    raw = _conv_raw(x, w, upsample)
     out, stats = C.bn_train_fwd(raw, gamma.detach(), beta.detach(), float(eps), float(momentum), running_mean, running_var,
                                 1 if glu else 0, residual, nbt)
     return out, raw, stats

@@ -130,14 +130,45 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// channel ch: (scale, shift) from the statistics partials; slice-0 workgroups publish the statistics
+// channel ch: (scale, shift) from the statistics partials; slice-0 workgroups publish the statistics.
+// Up to 64 partials (the statistics kernel's splits): lanes of wave 0, as before.  More (a convolution's epilogue wrote one
+// pair per wave tile, tgsr_wino_conv3x3_stats_fwd: 4096 per channel at 128^2): every thread of the workgroup sums its
+// strided share with the loads in flight together, the 256 thread sums meet in LDS - a fixed order either way, so every
+// workgroup of the channel gets the same bits.
 __device__ __forceinline__ void bn_channel_affine(const float* __restrict__ partial, int nsplit, int ch, double count,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                   float momentum, float* running_mean, float* running_var, float* mean,
                                                   float* invstd, float* scale, float* shift, bool publish, float* bc) {
+  __shared__ double wide_s[kBnThreads], wide_q[kBnThreads];
+  const bool wide = nsplit > 64;
+  if (wide) {
+    double s = 0.0, q = 0.0;
+    const float2* pp = reinterpret_cast<const float2*>(partial + (int64_t)ch * nsplit * 2);
+    int k = threadIdx.x;
+    for (; k + 3 * kBnThreads < nsplit; k += 4 * kBnThreads) {
+      const float2 v0 = pp[k], v1 = pp[k + kBnThreads], v2 = pp[k + 2 * kBnThreads], v3 = pp[k + 3 * kBnThreads];
+      s += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; k < nsplit; k += kBnThreads) {
+      const float2 v = pp[k];
+      s += (double)v.x;
+      q += (double)v.y;
+    }
+    __syncthreads();                       // (a previous call's readers of wide_* are done)
+    wide_s[threadIdx.x] = s;
+    wide_q[threadIdx.x] = q;
+    __syncthreads();
+  }
   if (threadIdx.x < 64) {
     double s = 0.0, q = 0.0;
-    if ((int)threadIdx.x < nsplit) {
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < kBnThreads / 64; ++j) {
+        s += wide_s[threadIdx.x + 64 * j];
+        q += wide_q[threadIdx.x + 64 * j];
+      }
+    } else if ((int)threadIdx.x < nsplit) {
       s = partial[((int64_t)ch * nsplit + threadIdx.x) * 2];
       q = partial[((int64_t)ch * nsplit + threadIdx.x) * 2 + 1];
     }
@@ -320,11 +351,10 @@ extern "C" int tgsr_bn_train_nsplit(int B, int C, int HW) {
   return n < 1 ? 1 : (n > 64 ? 64 : n);
 }
 
-extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma, const float* beta,
-                                 float eps, float momentum, float* running_mean, float* running_var, int glu,
-                                 const float* residual, int64_t res_bstride, float* partial_ws, float* mean,
-                                 float* invstd, float* scale, float* shift, float* out, int64_t out_bstride,
-                                 int64_t* num_batches_tracked, void* stream) {
+static int bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, int glu, const float* residual,
+                        int64_t res_bstride, float* partial_ws, int given_nsplit, float* mean, float* invstd, float* scale,
+                        float* shift, float* out, int64_t out_bstride, int64_t* num_batches_tracked, void* stream) {
   if (!raw || !gamma || !beta || !partial_ws || !mean || !invstd || !scale || !shift || !out) return TGSR_EINVAL;
   if (glu < 0 || glu > 2) return TGSR_EINVAL;             // `glu` is the activation selector: 0 none, 1 GLU, 2 LeakyReLU(0.2)
   const int leaky = glu == 2 ? 1 : 0;
@@ -333,9 +363,12 @@ extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const f
   if ((HW & 3) != 0) return TGSR_EUNSUPPORTED;
   if ((running_mean == nullptr) != (running_var == nullptr)) return TGSR_EINVAL;
   hipStream_t s = as_stream(stream);
-  const int nsplit = tgsr_bn_train_nsplit(B, C, HW);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, nsplit), dim3(kBnThreads), 0, s, raw, (int64_t)C * HW, B, HW,
-                     partial_ws, nsplit);
+  // given_nsplit > 0: partial_ws already holds that many (sum, sumsq) pairs per channel (a convolution's epilogue wrote
+  // them): the statistics pass over the raw tensor is not launched
+  const int nsplit = given_nsplit > 0 ? given_nsplit : tgsr_bn_train_nsplit(B, C, HW);
+  if (given_nsplit <= 0)
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, nsplit), dim3(kBnThreads), 0, s, raw, (int64_t)C * HW, B, HW,
+                       partial_ws, nsplit);
   const int Co = glu ? C / 2 : C;
   const int ns2 = tgsr_bn_train_nsplit(B, Co, HW);
   long long* nbt = reinterpret_cast<long long*>(num_batches_tracked);
@@ -348,6 +381,26 @@ extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const f
                        gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, nbt, residual,
                        res_bstride, out, out_bstride, leaky, ns2);
   return note_launch(hipGetLastError(), "bn_train_fwd");
+}
+
+extern "C" int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, int glu,
+                                 const float* residual, int64_t res_bstride, float* partial_ws, float* mean,
+                                 float* invstd, float* scale, float* shift, float* out, int64_t out_bstride,
+                                 int64_t* num_batches_tracked, void* stream) {
+  return bn_train_fwd(raw, B, C, HW, gamma, beta, eps, momentum, running_mean, running_var, glu, residual, res_bstride,
+                      partial_ws, 0, mean, invstd, scale, shift, out, out_bstride, num_batches_tracked, stream);
+}
+
+extern "C" int tgsr_bn_train_fwd_from_stats(const float* raw, int B, int C, int HW, const float* gamma, const float* beta,
+                                            float eps, float momentum, float* running_mean, float* running_var, int glu,
+                                            const float* residual, int64_t res_bstride, const float* stat_partial,
+                                            int nslots, float* mean, float* invstd, float* scale, float* shift, float* out,
+                                            int64_t out_bstride, int64_t* num_batches_tracked, void* stream) {
+  if (nslots < 1) return TGSR_EINVAL;
+  return bn_train_fwd(raw, B, C, HW, gamma, beta, eps, momentum, running_mean, running_var, glu, residual, res_bstride,
+                      const_cast<float*>(stat_partial), nslots, mean, invstd, scale, shift, out, out_bstride,
+                      num_batches_tracked, stream);
 }
 
 extern "C" int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW, const float* scale,

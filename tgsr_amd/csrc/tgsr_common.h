@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels of libtgsr_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "../../include/tgsr_hip.h"
@@ -26,6 +27,17 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// Experiment knob: TGSR_WGRAD_SPLIT_PCT scales how many partial slabs the split weight-gradient kernels produce
+// (100 = the launchers' own choice).
+inline int wgrad_split_pct() {
+  static int pct = [] {
+    const char* e = getenv("TGSR_WGRAD_SPLIT_PCT");
+    const int v = e ? atoi(e) : 100;
+    return v < 1 ? 100 : v;
+  }();
+  return pct;
 }
 
 }  // namespace tgsr

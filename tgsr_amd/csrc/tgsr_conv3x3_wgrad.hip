@@ -160,6 +160,7 @@ static void wgrad_plan(int B, int Cin, int Cout, int Ho, int Wo, int* ncob, int*
   // one partial slab per workgroup: ~256 CUs x 8 waves of workgroups in flight keeps the chip full while the slabs
   // (nslots x |dW|) stay ~75 MB for every layer shape
   int want = 2048 / (*ncob * *ncib) / *groups;
+  want = want * wgrad_split_pct() / 100;
   if (want < 1) want = 1;
   if (want > *ntiles) want = *ntiles;
   *tiles_per_wg = (*ntiles + want - 1) / want;

@@ -189,6 +189,7 @@ static void wwgrad_plan(int B, int Cin, int Cout, int H, int W, int* nci, int* g
   *chunks_x = ((W + 1) / 2 + kWWT - 1) / kWWT;
   *nchunks = B * *tiles_y * *chunks_x;
   int want = 256 / *groups;                  // one 8-wave workgroup per CU: fewer, longer K walks keep the slabs small
+  want = want * wgrad_split_pct() / 100;
   if (want < 1) want = 1;
   if (want > *nchunks) want = *nchunks;
   *cpw = (*nchunks + want - 1) / want;

@@ -48,6 +48,8 @@ struct WinoArgs {
   float* out;
   int64_t obs;
   int tiles_x, tiles_y, nstages, ngroups;
+  float* stat;            // STATS: [Cout][nslots][2] per-wave (sum, sum of squares) of the outputs, else unused
+  int nslots;
 };
 
 // Geometry.  MFMA 16x16x4 with ALL 16 transformed positions live: a wave owns 16 tiles (one tile row = 2 x 32 output
@@ -86,8 +88,9 @@ struct WinoGeo {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <bool GLU, int NH>
+template <bool GLU, int NH, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
+  static_assert(!(GLU && STATS), "batch statistics are taken of the raw (plain-epilogue) convolution output");
   using Geo = WinoGeo<NH>;
   constexpr int kWPLANE = Geo::PLANE, kWU = Geo::U, kWUK = Geo::UK, kWRawN = Geo::RAWN, kWRaw = Geo::RAW;
   __shared__ __attribute__((aligned(16))) float smem[Geo::SMEM];
@@ -355,6 +358,7 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
       y[1][dx] = rr[1][dx] - rr[2][dx] - rr[3][dx];
     }
   };
+  float ssum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, ssq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (ox < a.W) {
     if (GLU) {
 #pragma unroll
@@ -388,7 +392,33 @@ __global__ __launch_bounds__(256, 2) void wino_conv3x3_kernel(WinoArgs a) {
             const float o0 = yv[dy][0] * sv + tv + rres[cb][i][dy].x, o1 = yv[dy][1] * sv + tv + rres[cb][i][dy].y;
             *reinterpret_cast<float2*>(ob + (int64_t)(grp * (32 * NH) + lc) * HWo + (int64_t)(oy + dy) * a.W + ox) =
                 make_float2(o0, o1);
+            if (STATS) {
+              ssum[cb][i] += o0 + o1;
+              ssq[cb][i] += o0 * o0 + o1 * o1;
+            }
           }
+        }
+      }
+    }
+  }
+  if (STATS) {
+    // BatchNorm's batch statistics ride the epilogue: this wave's 2 x 32 outputs of each of its 32 channels are summed
+    // over the 16 tiles (lanes l15 of a lane group; out-of-image lanes hold zeros) and leave as ONE (sum, sumsq) pair per
+    // channel and wave - slot = (sample, tile row, 32-column chunk); the normalise pass combines the slots in a fixed order
+    const int slot = ((b * a.tiles_y + ty) * a.tiles_x + tx) * Geo::ROWS + w;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = ssum[cb][i], q = ssq[cb][i];
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+          s += __shfl_xor(s, o);
+          q += __shfl_xor(q, o);
+        }
+        if (l15 == 0) {
+          const int c = grp * (32 * NH) + h * 32 + cb * 16 + 4 * lg + i;
+          *reinterpret_cast<float2*>(a.stat + ((int64_t)c * a.nslots + slot) * 2) = make_float2(s, q);
         }
       }
     }
@@ -465,10 +495,23 @@ extern "C" int tgsr_pack_wino_weight_dgrad(const float* w, float* upack, int Cou
   return pack_wino_weight(w, upack, Cout, Cin, 0, 1, stream);
 }
 
-extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W,
-                                     const float* upack, int Cout, const float* scale, const float* shift,
-                                     const float* residual, int64_t res_bstride, float* out, int64_t out_bstride,
-                                     int epilogue, void* stream) {
+static void wino_geometry(int B, int Cin, int H, int W, int Cout, WinoArgs& a) {
+  const int nh = Cout % 64 == 0 ? 2 : 1;                 // cout halves per workgroup: 64- or 32-channel groups
+  a.tiles_x = (W + 31) / 32; a.tiles_y = nh == 2 ? (H + 3) / 4 : (H + 7) / 8; a.nstages = (Cin + kWCK - 1) / kWCK;
+  a.ngroups = Cout / (32 * nh);
+  a.nslots = B * a.tiles_y * a.tiles_x * (nh == 2 ? 2 : 4);
+}
+
+extern "C" int tgsr_wino_stats_nslots(int B, int H, int W, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cout < 1 || Cout % 32 != 0) return 0;
+  WinoArgs a;
+  wino_geometry(B, 4, H, W, Cout, a);
+  return a.nslots;
+}
+
+static int wino_conv3x3(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
+                        const float* scale, const float* shift, const float* residual, int64_t res_bstride, float* out,
+                        int64_t out_bstride, int epilogue, float* stat, void* stream) {
   if (!x || !upack || !out || B < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return TGSR_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
   const bool glu = epilogue == TGSR_EPI_AFFINE_GLU;
@@ -482,9 +525,10 @@ extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, i
   WinoArgs a;
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
   a.scale = scale; a.shift = shift; a.res = residual; a.rbs = res_bstride; a.out = out; a.obs = out_bstride;
-  const int nh = Cout % 64 == 0 ? 2 : 1;                 // cout halves per workgroup: 64- or 32-channel groups
-  a.tiles_x = (W + 31) / 32; a.tiles_y = nh == 2 ? (H + 3) / 4 : (H + 7) / 8; a.nstages = (Cin + kWCK - 1) / kWCK;
-  a.ngroups = Cout / (32 * nh);
+  const int nh = Cout % 64 == 0 ? 2 : 1;
+  wino_geometry(B, Cin, H, W, Cout, a);
+  a.stat = stat;
+  if (stat && (glu || residual || scale)) return TGSR_EINVAL;     // statistics are of the raw convolution output
   dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.ngroups));
   size_t dyn = 0;
 #ifdef TGSR_WINO_STAMPS
@@ -492,10 +536,28 @@ extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, i
 #endif
   if (nh == 2) {
     if (glu) hipLaunchKernelGGL((wino_conv3x3_kernel<true, 2>), grid, dim3(256), dyn, as_stream(stream), a);
+    else if (stat) hipLaunchKernelGGL((wino_conv3x3_kernel<false, 2, true>), grid, dim3(256), dyn, as_stream(stream), a);
     else hipLaunchKernelGGL((wino_conv3x3_kernel<false, 2>), grid, dim3(256), dyn, as_stream(stream), a);
   } else {
     if (glu) hipLaunchKernelGGL((wino_conv3x3_kernel<true, 1>), grid, dim3(256), dyn, as_stream(stream), a);
+    else if (stat) hipLaunchKernelGGL((wino_conv3x3_kernel<false, 1, true>), grid, dim3(256), dyn, as_stream(stream), a);
     else hipLaunchKernelGGL((wino_conv3x3_kernel<false, 1>), grid, dim3(256), dyn, as_stream(stream), a);
   }
   return note_launch(hipGetLastError(), "wino_conv3x3_kernel");
+}
+
+extern "C" int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W,
+                                     const float* upack, int Cout, const float* scale, const float* shift,
+                                     const float* residual, int64_t res_bstride, float* out, int64_t out_bstride,
+                                     int epilogue, void* stream) {
+  return wino_conv3x3(x, x_bstride, B, Cin, H, W, upack, Cout, scale, shift, residual, res_bstride, out, out_bstride,
+                      epilogue, nullptr, stream);
+}
+
+extern "C" int tgsr_wino_conv3x3_stats_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W,
+                                           const float* upack, int Cout, float* out, int64_t out_bstride,
+                                           float* stat_partial, void* stream) {
+  if (!stat_partial) return TGSR_EINVAL;
+  return wino_conv3x3(x, x_bstride, B, Cin, H, W, upack, Cout, nullptr, nullptr, nullptr, 0, out, out_bstride,
+                      TGSR_EPI_AFFINE, stat_partial, stream);
 }

@@ -74,6 +74,13 @@ def _conv3x3_wino_out(x, upack, cout, scale, shift, glu, residual, out):
     ops.conv3x3_wino(x, upack, cout, scale, shift, glu=glu, residual=residual, out=out)
 
 
+def _wino_stats_fake(x, upack, cout):
+    n = ops.wino_stats_nslots(x.shape[0], x.shape[2], x.shape[3], cout)
+    return x.new_empty(x.shape[0], cout, x.shape[2], x.shape[3]), x.new_empty(cout, n, 2)
+
+
+conv3x3_wino_stats = _define("conv3x3_wino_stats(Tensor x, Tensor upack, int cout) -> (Tensor, Tensor)",
+                             lambda x, upack, cout: ops.conv3x3_wino_stats(x, upack, cout), _wino_stats_fake)
 conv3x3_wino = _define("conv3x3_wino(Tensor x, Tensor upack, int cout, Tensor? scale, Tensor? shift, bool glu, "
                        "Tensor? residual) -> Tensor", _conv3x3_wino,
                        lambda x, upack, cout, scale, shift, glu, residual:
@@ -213,6 +220,13 @@ bn_train_fwd = _define("bn_train_fwd(Tensor raw, Tensor gamma, Tensor beta, floa
                        lambda raw, g, b, eps, mom, rm, rv, act, res, nbt:
                        (raw.new_empty(raw.shape[0], raw.shape[1] // 2 if act == 1 else raw.shape[1], raw.shape[2], raw.shape[3]),
                         raw.new_empty(4, raw.shape[1])))
+bn_train_fwd_from_stats = _define(
+    "bn_train_fwd_from_stats(Tensor raw, Tensor gamma, Tensor beta, float eps, float momentum, Tensor(a!)? running_mean, "
+    "Tensor(b!)? running_var, int act, Tensor? residual, Tensor(c!)? num_batches_tracked, Tensor stat_partial) -> (Tensor, Tensor)",
+    lambda raw, g, b, eps, mom, rm, rv, act, res, nbt, sp: ops.bn_train_fwd(raw, g, b, eps, mom, rm, rv, act, res, nbt, stat_partial=sp),
+    lambda raw, g, b, eps, mom, rm, rv, act, res, nbt, sp:
+    (raw.new_empty(raw.shape[0], raw.shape[1] // 2 if act == 1 else raw.shape[1], raw.shape[2], raw.shape[3]),
+     raw.new_empty(4, raw.shape[1])))
 bn_train_fwd_out = _define("bn_train_fwd_out(Tensor raw, Tensor gamma, Tensor beta, float eps, float momentum, "
                            "Tensor(a!)? running_mean, Tensor(b!)? running_var, int act, Tensor(c!)? num_batches_tracked, "
                            "Tensor(d!) out, Tensor(e!) stats) -> ()",

@@ -224,6 +224,33 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
     return out
 
 
+def wino_stats_nslots(B: int, H: int, W: int, cout: int) -> int:
+    """Partial-sum pairs per channel conv3x3_wino_stats writes for this shape (0: unsupported)."""
+    return int(_lib.lib().tgsr_wino_stats_nslots(int(B), int(H), int(W), int(cout)))
+
+
+def conv3x3_wino_stats(x: torch.Tensor, upack: torch.Tensor, cout: int):
+    """The raw Winograd convolution (no affine, no residual) whose epilogue also leaves BatchNorm's batch statistics as
+    partial sums: returns (out [B,cout,H,W], stat_partial [cout, nslots, 2]) for bn_train_fwd(..., stat_partial=...)."""
+    _need_hip(x, upack)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    B, Cin, H, W = x.shape
+    _check_pack("conv3x3_wino_stats", "wino", upack, cout, Cin)
+    L = _lib.lib()
+    nslots = L.tgsr_wino_stats_nslots(B, H, W, cout)
+    if nslots < 1:
+        raise TgsrError("conv3x3_wino_stats: unsupported shape %s -> %d channels" % (tuple(x.shape), cout))
+    out = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
+    part = torch.empty(cout, nslots, 2, dtype=torch.float32, device=x.device)
+    e0 = _ev() if profile is not None else None
+    check(L.tgsr_wino_conv3x3_stats_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(out), cout * H * W, _p(part), _stream()),
+          "tgsr_wino_conv3x3_stats_fwd")
+    if profile is not None:
+        profile.append(("wino_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9,
+                        4 * (B * Cin * H * W + B * cout * H * W + cout * Cin * 9), e0, _ev()))
+    return out, part
+
+
 def pack_upconv_weight(w: torch.Tensor) -> torch.Tensor:
     """[Cout,Cin,3,3] -> [ceil(Cin/4)][4 phases][4 taps][4][Cout] with the sub-pixel tap sums (tgsr_upconv3x3_glu_fwd)."""
     _need_hip(w)
@@ -603,11 +630,14 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 def bn_train_fwd(raw: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, momentum: float,
                  running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], act: int = 0,
                  residual: Optional[torch.Tensor] = None, nbt: Optional[torch.Tensor] = None,
-                 out: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None):
+                 out: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
+                 stat_partial: Optional[torch.Tensor] = None):
     """nn.BatchNorm2d(train) on the raw conv output [B,C,H,W] + act (0 none [+ residual], 1 GLU, 2 LeakyReLU(0.2)):
     batch statistics, running statistics / num_batches_tracked updated in place through their pointers.  Returns
-    (out, stats [4, C] = mean, invstd, scale, shift).  `out` / `stats` may be given (slices of larger tensors)."""
-    _need_hip(raw, gamma, beta, running_mean, running_var, residual, nbt, out, stats)
+    (out, stats [4, C] = mean, invstd, scale, shift).  `out` / `stats` may be given (slices of larger tensors).
+    `stat_partial` [C, nslots, 2]: the (sum, sumsq) pairs conv3x3_wino_stats left - the pass over `raw` that would compute
+    them is then skipped."""
+    _need_hip(raw, gamma, beta, running_mean, running_var, residual, nbt, out, stats, stat_partial)
     L = _lib.lib()
     B, C, Ho, Wo = raw.shape
     HW, dev = Ho * Wo, raw.device
@@ -620,6 +650,17 @@ def bn_train_fwd(raw: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
     if stats is None:
         stats = torch.empty(4, C, dtype=torch.float32, device=dev)
     res = None if residual is None else residual.contiguous()
+    if stat_partial is not None:
+        if (stat_partial.dim() != 3 or stat_partial.shape[0] != C or stat_partial.shape[2] != 2 or
+                stat_partial.dtype != torch.float32 or not stat_partial.is_contiguous()):
+            raise TgsrError("bn_train_fwd: stat_partial %s for %d channels" % (tuple(stat_partial.shape), C))
+        rc = L.tgsr_bn_train_fwd_from_stats(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
+                                            float(momentum), _p(running_mean), _p(running_var), int(act), _p(res),
+                                            0 if res is None else co * HW, _p(stat_partial), stat_partial.shape[1],
+                                            _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(out), co * HW, _p(nbt),
+                                            _stream())
+        check(rc, "tgsr_bn_train_fwd_from_stats")
+        return out, stats
     ws = torch.empty(C * L.tgsr_bn_train_nsplit(B, C, HW) * 4, dtype=torch.float32, device=dev)
     rc = L.tgsr_bn_train_fwd(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum),
                              _p(running_mean), _p(running_var), int(act), _p(res), 0 if res is None else co * HW, _p(ws),
