@@ -68,7 +68,8 @@ template <int NI>  // idf = 32 * NI
 __global__ __launch_bounds__(256) void word_attention_kernel(AttnArgs a) {
   constexpr int IDF = 32 * NI;
   __shared__ float src_s[IDF * 32];   // [i][t]  (GEMM1 A operand: lanes = t, conflict-free)
-  __shared__ float srcT_s[32 * IDF];  // [t][i]  (GEMM2 A operand: lanes = i, conflict-free)
+  constexpr int TP = IDF + 1;         // row pitch of srcT: the transposing store below walks a column (bank = t + i: conflict free)
+  __shared__ float srcT_s[32 * TP];   // [t][i]  (GEMM2 A operand: lanes = i, conflict-free)
   __shared__ unsigned mbits_s[256];   // packed mask rows (bit t = masked), up to 256 rows cached
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void word_attention_kernel(AttnArgs a) {
   for (int o = tid; o < IDF * 32; o += 256) {
     const float v = sb[o];
     src_s[o] = v;
-    srcT_s[(o & 31) * IDF + (o >> 5)] = v;
+    srcT_s[(o & 31) * TP + (o >> 5)] = v;
   }
   const int nrows = a.mask ? (a.B < 256 ? a.B : 256) : 0;
   for (int r = tid; r < nrows; r += 256) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void word_attention_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         if (acc_row(r, 0) < a.T) {   // wave-uniform; words >= T have P = 0 anyway
-          const float av = srcT_s[acc_row(r, hh) * IDF + blk * 32 + l31];
+          const float av = srcT_s[acc_row(r, hh) * TP + blk * 32 + l31];
           c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, s[r], c, 0, 0, 0);
         }
       }
