@@ -12,6 +12,24 @@
 
 namespace tgsr {
 
+#ifdef TGSR_LSTM_STAMPS
+// diagnostic build (tools/lstm_stamps.py): s_memtime of thread 0 of every workgroup at the phases of every step
+__device__ unsigned long long g_lstamps[64 * 128];
+#define TGSR_LSTAMP(k)                                                                                    \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && (k) < 126) {                                                                  \
+      const int bid_ = blockIdx.y * gridDim.x + blockIdx.x;                                               \
+      if (bid_ < 64) {                                                                                    \
+        g_lstamps[bid_ * 128 + (k)] = __builtin_amdgcn_s_memtime();                                       \
+        if ((k) == 0) g_lstamps[bid_ * 128 + 126] = __builtin_amdgcn_s_memrealtime();                     \
+        g_lstamps[bid_ * 128 + 127] = __builtin_amdgcn_s_memrealtime();                                   \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+#else
+#define TGSR_LSTAMP(k)
+#endif
+
 // C[m][n] = sum_k A[row(m)][k] * Bm[n][k] + bias0[n] + bias1[n];  A rows gathered through idx (token ids).
 // Tile: 4 waves, wave w -> columns [n0 + 32w, +32), rows [m0, m0+32).  K chunks of 64 through LDS (pitch 65).
 __global__ __launch_bounds__(256) void lstm_input_gates_kernel(const int64_t* __restrict__ captions, int width,
@@ -140,6 +158,136 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
   if (j < H) sent_emb[(int64_t)b * 2 * H + d * H + j] = hcur;
 }
 
+// The recurrence as shipped for H = 128: KS * H threads, thread t = (unit j = t / KS, K slice q = t % KS) owns ALL FOUR gate
+// rows of unit j over 1/KS of the K = H products, as (i, f) and (g, o) weight pairs feeding v_pk_fma_f32 with h[k] selected
+// for both halves.  What the stamps of the one-row kernel above say about a step (tools/lstm_stamps.py, 2.4 GHz, 4 400 cycles):
+// its 128 FMAs are not the cost - (a) the step's gate pre-activations were a global load behind a scalar caption load at the
+// head of the FMA chain (~1.2 us of exposed latency per step), (b) every wave re-read all of h as 32 broadcast ds_read_b128,
+// 1 KB of returned data each: 2 048 cycles per step on the CU's one LDS pipe, (c) two barriers and the g_s round trip between
+// the mat-vec and the gate math.  Here: (a) all steps' pre-activations are staged in LDS during the prologue (TP steps x 4H
+// floats, 48 KB), (b) a wave reads 1/KS of h per lane - a quarter of the LDS traffic, (c) the KS partial sums of a unit's
+// four gates meet by DPP quad_perm adds between neighbouring lanes (a __shfl_xor is a ds_bpermute: an LDS round trip per
+// value), so the gate math needs no LDS exchange; h is double-buffered and a step has ONE barrier.
+// Measured per launch (B = 16, T = 18, rocprofv3): one row per thread 29.4-31.0 us (also with the pre-activations staged, also
+// with two rows per thread: each removes one of (a)-(c) and leaves the others); KS = 2 (256 weight registers, some in AGPRs,
+// one wave per SIMD) 25.1 us; KS = 4 (128 weight registers, two waves per SIMD hide each other's LDS and transcendental
+// latencies) 20.2 us.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float lane_xor1(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float lane_xor2(float x) {   // quad_perm [2,3,0,1]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false));
+}
+
+template <int H, int TP, int KS>
+__global__ __launch_bounds__(KS * H) void lstm_recurrent2_kernel(const float* __restrict__ gates,
+                                                                const int32_t* __restrict__ cap_lens, int Tmax,
+                                                                const float* __restrict__ w_hh,
+                                                                float* __restrict__ words_emb, float* __restrict__ sent_emb,
+                                                                const int64_t* __restrict__ captions, int width, int ntoken,
+                                                                float* __restrict__ acts) {
+  static_assert(KS == 2 || KS == 4, "K split over 2 or 4 neighbouring lanes");
+  constexpr int HK = H / KS, NT = KS * H;
+  __shared__ __attribute__((aligned(16))) float h_s[2][H];
+  __shared__ float gpre_s[TP * 4 * H];                         // [step s][4H], in the order the recurrence consumes them
+  const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
+  const int j = tid / KS, q = tid & (KS - 1);
+  TGSR_LSTAMP(0);
+  int len = cap_lens[b];
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  __shared__ int row_s[TP];
+  if (tid < len) {                                             // the gate-table row of every step (caption token, or position)
+    const int t = d == 0 ? tid : len - 1 - tid;
+    int64_t row = (int64_t)b * Tmax + t;
+    if (captions) {
+      const int64_t v = captions[(int64_t)b * width + t];
+      row = (v < 0 || v >= ntoken) ? 0 : v;
+    }
+    row_s[tid] = (int)row;
+  }
+  __syncthreads();
+#pragma unroll 6
+  for (int s = 0; s < len; ++s) {                              // independent loads: in flight together, and with the weights below
+    const float* gp = gates + ((int64_t)row_s[s] * 2 + d) * 4 * H;
+#pragma unroll
+    for (int e = tid; e < 4 * H; e += NT) gpre_s[s * 4 * H + e] = gp[e];
+  }
+  f32x2 wa[HK], wb[HK];                                        // (w_i, w_f)[k], (w_g, w_o)[k] for k in this thread's half
+  {
+    const float* base = w_hh + ((int64_t)d * 4 * H + j) * H + q * HK;
+    const float4* wi = reinterpret_cast<const float4*>(base);
+    const float4* wf = reinterpret_cast<const float4*>(base + (int64_t)H * H);
+    const float4* wg = reinterpret_cast<const float4*>(base + (int64_t)2 * H * H);
+    const float4* wo = reinterpret_cast<const float4*>(base + (int64_t)3 * H * H);
+#pragma unroll
+    for (int k = 0; k < HK / 4; ++k) {
+      const float4 vi = wi[k], vf = wf[k], vg = wg[k], vo = wo[k];
+      wa[4 * k] = f32x2{vi.x, vf.x}; wa[4 * k + 1] = f32x2{vi.y, vf.y}; wa[4 * k + 2] = f32x2{vi.z, vf.z}; wa[4 * k + 3] = f32x2{vi.w, vf.w};
+      wb[4 * k] = f32x2{vg.x, vo.x}; wb[4 * k + 1] = f32x2{vg.y, vo.y}; wb[4 * k + 2] = f32x2{vg.z, vo.z}; wb[4 * k + 3] = f32x2{vg.w, vo.w};
+    }
+  }
+  float c = 0.f, hcur = 0.f;
+  if (tid < H) h_s[0][tid] = 0.f;
+  float* wout = words_emb + ((int64_t)b * 2 * H + d * H + j) * Tmax;
+  if (q == 0)
+    for (int t = len; t < Tmax; ++t) wout[t] = 0.f;
+  __syncthreads();
+  TGSR_LSTAMP(1);
+  for (int s = 0; s < len; ++s) {
+    const int t = d == 0 ? s : len - 1 - s;
+    const float* hb = h_s[s & 1] + q * HK;
+    const float* gq = gpre_s + s * 4 * H + j;                  // issued ahead of the h reads: back before the FMAs are done
+    const float q0 = gq[0], q1 = gq[H], q2 = gq[2 * H], q3 = gq[3 * H];
+    f32x2 a0 = f32x2{0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;     // two chains per row pair
+#pragma unroll
+    for (int k = 0; k < HK / 4; ++k) {
+      const float4 hv = *reinterpret_cast<const float4*>(hb + 4 * k);
+      a0 = __builtin_elementwise_fma(wa[4 * k], f32x2{hv.x, hv.x}, a0);
+      b0 = __builtin_elementwise_fma(wb[4 * k], f32x2{hv.x, hv.x}, b0);
+      a1 = __builtin_elementwise_fma(wa[4 * k + 1], f32x2{hv.y, hv.y}, a1);
+      b1 = __builtin_elementwise_fma(wb[4 * k + 1], f32x2{hv.y, hv.y}, b1);
+      a0 = __builtin_elementwise_fma(wa[4 * k + 2], f32x2{hv.z, hv.z}, a0);
+      b0 = __builtin_elementwise_fma(wb[4 * k + 2], f32x2{hv.z, hv.z}, b0);
+      a1 = __builtin_elementwise_fma(wa[4 * k + 3], f32x2{hv.w, hv.w}, a1);
+      b1 = __builtin_elementwise_fma(wb[4 * k + 3], f32x2{hv.w, hv.w}, b1);
+    }
+    f32x2 pa = a0 + a1, pb = b0 + b1;
+    TGSR_LSTAMP(2 + 3 * s);
+    // the other half of K sits in the neighbouring lane (fixed order: lower half + upper half, so both lanes get the same bits)
+    // (DPP quad_perm moves - __shfl_xor is a ds_bpermute: an LDS round trip per value; the order of the adds is the same on
+    // every lane of a unit: (k quarter 0 + 1) + (2 + 3))
+    float v4[4] = {pa.x, pa.y, pb.x, pb.y};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float o = lane_xor1(v4[e]);
+      v4[e] = (q & 1) ? o + v4[e] : v4[e] + o;
+      if (KS == 4) {
+        const float o2 = lane_xor2(v4[e]);
+        v4[e] = (q & 2) ? o2 + v4[e] : v4[e] + o2;
+      }
+    }
+    const float si = v4[0] + q0, sf = v4[1] + q1, sg = v4[2] + q2, so = v4[3] + q3;
+    const float ig = fsig_(si), fg = fsig_(sf), gg = ftanh_(sg), og = fsig_(so);
+    c = fg * c + ig * gg;
+    hcur = og * ftanh_(c);
+    if (q == 0) {
+      h_s[(s + 1) & 1][j] = hcur;
+      wout[t] = hcur;
+      if (acts) {   // training: gate activations and cell state of this step, [B][Tmax][2][5][H]
+        float* ap = acts + (((int64_t)b * Tmax + t) * 2 + d) * 5 * H + j;
+        ap[0] = ig; ap[H] = fg; ap[2 * H] = gg; ap[3 * H] = og; ap[4 * H] = c;
+      }
+    }
+    TGSR_LSTAMP(3 + 3 * s);
+    __syncthreads();
+    TGSR_LSTAMP(4 + 3 * s);
+  }
+  if (q == 0) sent_emb[(int64_t)b * 2 * H + d * H + j] = hcur;
+}
+
 // Any H (<= 256): w_hh streamed from L2 every step; correctness path for configurations the register kernel
 // does not cover.
 __global__ void lstm_recurrent_generic_kernel(const float* __restrict__ gates, const int32_t* __restrict__ cap_lens,
@@ -262,11 +410,21 @@ __global__ void lstm_colsum_kernel(const float* __restrict__ parts, int n, int m
 
 using namespace tgsr;
 
+#ifdef TGSR_LSTM_STAMPS
+extern "C" int tgsr_debug_read_lstamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(tgsr::g_lstamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -3;
+}
+#endif
+
 static int launch_recurrent(const float* gates, const int32_t* cap_lens, int B, int Tmax, const float* w_hh, int H,
                             float* words_emb, float* sent_emb, const int64_t* captions, int width, int ntoken,
                             hipStream_t s, float* acts = nullptr) {
   dim3 grid(B, 2);
-  if (H == 128)
+  static const bool one_row = getenv("TGSR_LSTM_ONE_ROW") != nullptr;       // A/B switch (tools)
+  if (H == 128 && !one_row && Tmax <= 24)
+    hipLaunchKernelGGL((lstm_recurrent2_kernel<128, 24, 4>), grid, dim3(512), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
+                       sent_emb, captions, width, ntoken, acts);
+  else if (H == 128)
     hipLaunchKernelGGL(lstm_recurrent_kernel<128>, grid, dim3(512), 0, s, gates, cap_lens, Tmax, w_hh, words_emb,
                        sent_emb, captions, width, ntoken, acts);
   else if (H == 64)
