@@ -1,0 +1,96 @@
+"""GPU: a kernel's result must not depend on what runs beside it.
+
+Every inference kernel of the path is launched on one stream while an MFMA-heavy neighbour loops on a second stream, and
+its output is compared bit for bit with the one it gives alone.  The case this pins: packed fp32 instructions
+(v_pk_fma_f32 ...) whose registers are reloaded right behind them read the NEW contents when the matrix pipe is busy with
+another wave's MFMAs (tools/lds_neighbour_check.py) - the LSTM recurrence and the lp stem gave
+different results under a hipGraph's concurrency until their packed instructions were removed."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _neighbours(g, B=16):
+    from tgsr_amd import lp, ops
+    R = lambda *sh: torch.randn(*sh, generator=g).to(DEV)            # noqa: E731
+    dt = "bf16"
+    out = {}
+    x = lp.from_nchw(R(B, 64, 64, 64), dt)
+    wp = lp.pack_upconv_weight(R(64, 64, 3, 3) * 0.1, dt)
+    sc, sh = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    o = lp.new_image(B, 128, 128, 32, dt, DEV)
+    out["lp upBlock 64 @64->128"] = lambda: lp.upconv_glu(x, wp, 64, 64, sc, sh, out=o)
+    x2 = lp.from_nchw(R(B, 32, 32, 32), dt)
+    wp2 = lp.pack_upconv_weight(R(64, 32, 3, 3) * 0.1, dt)
+    o2 = lp.new_image(B, 64, 64, 32, dt, DEV)
+    out["lp upBlock 32 @32->64"] = lambda: lp.upconv_glu(x2, wp2, 32, 64, sc, sh, out=o2)
+    x3 = lp.from_nchw(R(B, 64, 128, 128), dt)
+    wp3 = lp.pack_conv3x3_weight(R(128, 64, 3, 3) * 0.1, dt)
+    sc3, sh3 = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    o3 = lp.new_image(B, 128, 128, 64, dt, DEV)
+    out["lp conv 64->128 glu @128^2"] = lambda: lp.conv3x3(x3, wp3, 64, 128, sc3, sh3, glu=True, out=o3)
+    xf = R(B, 64, 64, 64)
+    upf = ops.pack_wino_weight(R(128, 64, 3, 3) * 0.1, True, False)
+    out["fp32 wino 64->128 glu @64^2"] = lambda: ops.conv3x3_wino(xf, upf, 128, sc3, sh3, True, None)
+    return out
+
+
+def _victims(g, B=16):
+    from tgsr_amd import lp, ops
+    R = lambda *sh: torch.randn(*sh, generator=g).to(DEV)            # noqa: E731
+    dt = "bf16"
+    v = {}
+    T, H, ntok = 18, 128, 41
+    cap = torch.randint(1, ntok, (B, T), generator=g).to(DEV)
+    table, w_hh = R(ntok, 2, 4 * H) * 0.5, R(2, 4 * H, H) * 0.08
+    v["bilstm_table (H = 128)"] = lambda: torch.cat([t.flatten() for t in ops.bilstm_table(cap, [T] * B, table, w_hh)])
+    words, sent = R(B, 256, T), R(B, 256)
+    ws = [R(32, 256) for _ in range(3)]
+    caw, cab = R(400, 256) * 0.1, R(400)
+    v["text_tail"] = lambda: torch.cat([t.flatten().float() for t in ops.text_tail(words, ws, sent, caw, cab, 100, cap)])
+    img = R(B, 3, 32, 32)
+    wst, scs, shs = R(64, 3, 3, 3) * 0.2, torch.rand(64, generator=g).to(DEV) + 0.5, R(64) * 0.1
+    v["lp stem"] = lambda: lp.stem(img, wst, scs, shs, dtype=dt).float().flatten()
+    himg = lp.from_nchw(R(B, 32, 32, 32), dt, cpitch=64)
+    src = R(B, 32, 32)
+    v["lp word attention @32^2"] = lambda: torch.cat([lp.word_attention(himg, src, None, T).flatten(), himg.float().flatten()])
+    xs = lp.from_nchw(R(B, 32, 32, 32), dt)
+    wps = lp.pack_conv3x3_weight(R(64, 32, 3, 3) * 0.1, dt)
+    sc64, sh64 = torch.rand(64, generator=g).to(DEV) + 0.5, R(64) * 0.1
+    v["lp conv 32->64 glu @32^2"] = lambda: lp.conv3x3(xs, wps, 32, 64, sc64, sh64, glu=True).float().flatten()
+    xw = R(B, 32, 32, 32)
+    upw = ops.pack_wino_weight(R(64, 32, 3, 3) * 0.1, True, False)
+    v["fp32 wino 32->64 glu @32^2"] = lambda: ops.conv3x3_wino(xw, upw, 64, sc64, sh64, True, None).flatten()
+    hf, wf, wc = R(B, 32, 32, 32), R(B, 256, T), R(32, 256)
+    v["fp32 word attention @32^2"] = lambda: torch.cat([t.flatten() for t in ops.word_attention(hf, wf, wc, None)])
+    xh, wh = R(B, 32, 64, 64), R(3, 32, 3, 3) * 0.1
+    v["fp32 conv_to3 3x3 @64^2"] = lambda: ops.conv_to3(xh, wh).flatten()
+    return v
+
+
+def test_results_do_not_depend_on_the_neighbour_kernel():
+    g = torch.Generator().manual_seed(11)
+    victims, neighbours = _victims(g), _neighbours(g)
+    side = torch.cuda.Stream()
+    bad = []
+    for vn, vf in victims.items():
+        ref = vf().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(vf(), ref), "%s is not reproducible on its own" % vn
+        for nn, nf in neighbours.items():
+            torch.cuda.synchronize()
+            for it in range(12):
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        nf()
+                out = vf()
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        nf()
+                torch.cuda.synchronize()
+                if not torch.equal(out, ref):
+                    bad.append((vn, nn, it, float((out - ref).abs().max())))
+                    break
+    assert not bad, "results changed beside another kernel: %s" % bad

@@ -67,6 +67,14 @@ for trial in range(int(os.environ.get("TRIALS", "6"))):
                           "ch", sorted(set(nz[:, 3].tolist())))
                     print("   values wrong/right:", cur["gl_stem"][tuple(nz[0])].item(), ref_int["gl_stem"][tuple(nz[0])].item(),
                           cur["gl_stem"][tuple(nz[-1])].item(), ref_int["gl_stem"][tuple(nz[-1])].item())
+        if diff["words_emb"][0] > 0:
+            dz = ((g["words_emb"][0] - a["words_emb"][0]).abs() > 0).nonzero()
+            H2 = g["words_emb"][0].shape[1] // 2
+            print("   words_emb wrong:", len(dz), "of", g["words_emb"][0].numel(), "samples", sorted(set(dz[:, 0].tolist())),
+                  "dirs", sorted(set((dz[:, 1] // H2).tolist())), "units", sorted(set((dz[:, 1] % H2).tolist()))[:48],
+                  "t", sorted(set(dz[:, 2].tolist())), "lens", lens.tolist())
+            ds_ = ((g["sent_emb"][0] - a["sent_emb"][0]).abs() > 0).nonzero()
+            print("   sent_emb wrong:", len(ds_), "samples", sorted(set(ds_[:, 0].tolist())), "dirs", sorted(set((ds_[:, 1] // H2).tolist())))
         if any(v for vs in diff.values() for v in vs):
             bad += 1
             print("trial", trial, "replay", rep, diff, flush=True)
