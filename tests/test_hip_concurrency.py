@@ -94,3 +94,55 @@ def test_results_do_not_depend_on_the_neighbour_kernel():
                     bad.append((vn, nn, it, float((out - ref).abs().max())))
                     break
     assert not bad, "results changed beside another kernel: %s" % bad
+
+
+def test_training_kernels_beside_mfma_neighbours():
+    """The training-only translation units keep the compiler's packed fp32 math (14 % of a train step, csrc/Makefile); their
+    kernels run beside the MFMA-bound weight gradients of the side stream.  Same check for them: bit-identical results with a
+    matrix-pipe-bound neighbour on the other stream."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    R = lambda *sh: torch.randn(*sh, generator=g).to(DEV)            # noqa: E731
+    B, C, HW = 8, 64, 64
+    raw, gam, bet = R(B, C, HW, HW), torch.rand(C, generator=g).to(DEV) + 0.5, R(C) * 0.1
+    dout = R(B, C // 2, HW, HW)
+
+    def bn():
+        rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y, st = ops.bn_train_fwd(raw, gam, bet, 1e-5, 0.1, rm, rv, 1, None, None)
+        draw, dg, db = ops.bn_train_bwd(dout, raw, st, 1)
+        return torch.cat([t.flatten() for t in (y, st, rm, rv, draw, dg, db)])
+    x3, w3, dy3 = R(B, 32, 64, 64), R(3, 32, 5, 5) * 0.1, R(B, 3, 64, 64)
+    out3 = ops.conv_to3(x3, w3, tanh_axpy=True, addend=R(B, 3, 64, 64), alpha=0.5)
+
+    def to3_bwd():
+        dx, dw = ops.conv_to3_bwd(dy3, out3, None, 0.5, x3, w3, True, True, True)
+        return torch.cat([dx.flatten(), dw.flatten()])
+    xs_, dys_ = R(B, 64, 64, 64), R(B, 64, 64, 64)
+
+    def wgrad():
+        dw = torch.empty(64, 64, 3, 3, device=DEV)
+        ops.conv3x3_wgrad(dys_, xs_, False, True, out=dw)
+        return dw.flatten()
+    victims = {"BatchNorm train fwd + bwd": bn, "conv_to3 backward": to3_bwd, "Winograd weight gradient": wgrad}
+    neighbours = _neighbours(g, B=16)
+    side = torch.cuda.Stream()
+    bad = []
+    for vn, vf in victims.items():
+        ref = vf().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(vf(), ref), "%s is not reproducible on its own" % vn
+        for nn, nf in neighbours.items():
+            for it in range(10):
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        nf()
+                out = vf()
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        nf()
+                torch.cuda.synchronize()
+                if not torch.equal(out, ref):
+                    bad.append((vn, nn, it, float((out - ref).abs().max())))
+                    break
+    assert not bad, "results changed beside another kernel: %s" % bad

@@ -64,13 +64,10 @@ __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) in[c * 9 + dy * 3 + dx] = in_s[(c * 3 + dy) * 34 + px + dx];
-#pragma unroll
-  // The 27 inputs stay in registers.  Left alone, hipcc (100 VGPRs) re-reads parts of in_s late in the channel loop with
-  // unaligned ds_read_b96 / ds_read2_b32 - and those late re-reads intermittently returned other values (lanes 48-63, the
-  // later channels of a group) when the step was replayed from a hipGraph whose second branch ran LDS-DMA convolutions at
-  // the same time (20-70 % of the replays; never eagerly, never in a one-branch graph, never with this pin: tools/
-  // graph_dbg_lp.py, tools/stem_race_check.py).  Not root-caused; the reads right behind the barrier are the only ones left.
-  for (int k = 0; k < 27; ++k) asm volatile("" : "+v"(in[k]));
+  // (Round 3 history: built with the SLP vectorizer this loop became v_pk_fma_f32 fed by late re-reads of in_s into the same
+  // registers, and the kernel intermittently computed other values - lanes 48-63, the later channels - whenever a hipGraph ran
+  // MFMA-bound convolutions beside it.  That was the packed-fp32 hazard of DESIGN.md 3.13, not a property of this kernel: the
+  // library's inference kernels are built without packed fp32 instructions now, tests/test_hip_concurrency.py watches it.)
   float o[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
