@@ -106,8 +106,8 @@ def test_committed_bench_lines_follow_the_contract():
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r02i_bench_*.json")))
-    assert len(files) >= 6, "round-2 bench lines missing"
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r03_bench_*.json")))
+    assert len(files) >= 10, "round-3 bench lines missing"
     saw_cpu = saw_lp = saw_train = False
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
@@ -119,8 +119,9 @@ def test_committed_bench_lines_follow_the_contract():
         per_gpu = d["config"].get("batch_per_gpu", 16)
         assert abs(d["value"] - per_gpu * d["n_gpus"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
         r = d["roofline"]
-        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in r, (f, k)
+        assert "kernel" in r or "kernels" in r, f        # the dominant kernel, or (train lines) the per-kernel table of the step
         assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
         if "train" in os.path.basename(f):
             saw_train = True
@@ -135,8 +136,21 @@ def test_committed_bench_lines_follow_the_contract():
             c = d["cpu_baseline"]
             assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert saw_cpu and saw_lp and saw_train
-    two = json.loads(open(os.path.join(root, "profiles", "r02i_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
+    two = json.loads(open(os.path.join(root, "profiles", "r03_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
     assert two["n_gpus"] == 2                       # `bench.py --gpus 2` launched its two ranks itself
+    assert "lp" in two and "train" in two and "error" not in json.dumps(two["train"])   # the extras survive N > 1 (all-reduce matched)
+    # the default line (what the driver times): fp32 stays the headline, configs[4] and the train step ride along
+    d = json.loads(open(os.path.join(root, "profiles", "r03_bench_fp32.json")).read().strip().splitlines()[-1])
+    assert d["dtype"] == "f32" and d["config"]["launch"] == "hipgraph" and d["config"]["graph_lanes"] == 4
+    runs = {(r["dtype"], r["batch_per_gpu"]): r for r in d["lp"]["runs"]}
+    assert set(runs) == {("bf16", 16), ("f16", 16), ("bf16", 8), ("bf16", 128)}
+    for r in runs.values():
+        assert r["value"] > 0 and r["psnr_vs_fp32_dB"] > 40 and 0 < r["step_roofline"]["hbm_frac"] < 1
+        assert r["conv_kernel"]["bound"] == "hbm" and "mfma_frac" in r["conv_kernel"]
+    assert runs[("bf16", 16)]["value"] >= 30000         # the driver-timed batch-16 bf16 line
+    tr = d["train"]["runs"]
+    assert len(tr) == 2 and all(0 < t["roofline"]["frac"] < 1 and "executed_fraction" in json.dumps(t["roofline"]) for t in tr)
+    assert all("cpu_baseline" in t for t in tr)
 
 
 def test_get_caption_crops_like_the_reference():
