@@ -67,6 +67,26 @@ def _victims(g, B=16):
     v["fp32 word attention @32^2"] = lambda: torch.cat([t.flatten() for t in ops.word_attention(hf, wf, wc, None)])
     xh, wh = R(B, 32, 64, 64), R(3, 32, 3, 3) * 0.1
     v["fp32 conv_to3 3x3 @64^2"] = lambda: ops.conv_to3(xh, wh).flatten()
+    wh5, addend = R(3, 32, 5, 5) * 0.1, R(B, 3, 64, 64)
+    v["fp32 conv_to3 5x5 tanh @64^2"] = lambda: ops.conv_to3(xh, wh5, tanh_axpy=True, addend=addend, alpha=0.5).flatten()
+    xu = R(B, 64, 32, 32)
+    upu = ops.pack_upwino_weight(R(128, 64, 3, 3) * 0.1, True)
+    sc128, sh128 = torch.rand(128, generator=g).to(DEV) + 0.5, R(128) * 0.1
+    v["fp32 upBlock (upwino) 64 @32->64"] = lambda: ops.upwino_glu(xu, upu, 128, sc128, sh128).flatten()
+    # lp upBlock with its fused 3x3 head + the combine of the partial sums
+    xl = lp.from_nchw(R(B, 64, 32, 32), dt)
+    wpu = lp.pack_upconv_weight(R(64, 64, 3, 3) * 0.1, dt)
+    hwp = lp.pack_to3_weight(R(3, 32, 3, 3) * 0.1, dt)
+
+    def up_head():
+        out, part = lp.upconv_glu_head(xl, wpu, 64, 64, sc64, sh64, hwp, 3)
+        low = torch.empty(B, 3, 64, 64, device=DEV)
+        lp.head_combine(B, [(64, 64)], [part], [None], [low], [None], True, 0.5)
+        return torch.cat([out.float().flatten(), low.flatten()])
+    v["lp upBlock + fused head + combine @32->64"] = up_head
+    xt = lp.from_nchw(R(B, 32, 64, 64), dt)
+    wt3 = lp.pack_to3_weight(R(3, 32, 5, 5) * 0.1, dt)
+    v["lp conv_to3 5x5 tanh @64^2"] = lambda: lp.conv_to3(xt, wt3, 5, True, addend, 0.5).flatten()
     return v
 
 
