@@ -117,9 +117,8 @@ def test_results_do_not_depend_on_the_neighbour_kernel():
 
 
 def test_training_kernels_beside_mfma_neighbours():
-    """The training-only translation units keep the compiler's packed fp32 math (14 % of a train step, csrc/Makefile); their
-    kernels run beside the MFMA-bound weight gradients of the side stream.  Same check for them: bit-identical results with a
-    matrix-pipe-bound neighbour on the other stream."""
+    """The training kernels run beside the MFMA-bound weight gradients of the side stream (and the discriminators' streams).
+    Same check for them: bit-identical results with a matrix-pipe-bound neighbour on the other stream."""
     from tgsr_amd import ops
     g = torch.Generator().manual_seed(5)
     R = lambda *sh: torch.randn(*sh, generator=g).to(DEV)            # noqa: E731

@@ -61,7 +61,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __res
   }
 }
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each), as the inference epilogues: the IEEE division expands to ~10 instructions, and the GLU
+// passes of BatchNorm's forward / backward are VALU-bound (the step lost 14 % without packed math, csrc/Makefile)
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 // Backward, pass 1.  grid (Co, nsplit).  For output channel c: GLU -> BN channels c (value) and c+Co (gate).
 // partial[c][s] = (sum dz_v, sum dz_v*xhat_v, sum dz_g, sum dz_g*xhat_g)   (non-GLU: the last two are 0)
