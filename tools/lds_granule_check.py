@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: do two workgroups' LDS allocations overlap when the kernel's LDS size is not a multiple of some granule?
 Workgroups of one canary kernel (tools/diag/lds_canary.hip) share CUs; each keeps writing its own pattern into its whole
-allocation and then checks it.  For every size tried: number of words that came back with foreign content and their range."""
+allocation and then checks it (build: see tools/lds_neighbour_check.py).  For every size tried: number of words that came back with foreign content and their range."""
 import ctypes, os
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,7 +2,11 @@
 """Diagnostic: does a kernel's result change when ANOTHER kernel runs beside it on the same CUs?
 The LSTM recurrence (its per-step inputs live in LDS for the whole launch) is replayed on one stream while a candidate
 neighbour kernel loops on a second stream; every output is compared with the one the recurrence gives alone.
-    python3 tools/lds_neighbour_check.py [iterations]"""
+    python3 tools/lds_neighbour_check.py [iterations]          (ONLY=upconv,glu selects neighbours, NO_CANARY=1 skips the canaries)
+The canaries (LDS contents, registers, packed FMAs on registers, packed FMAs fed from LDS, plain LDS write/barrier/read) live in
+tools/diag/lds_canary.hip:
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -shared -o tgsr_amd/lib/diag/liblds_canary.so tools/diag/lds_canary.hip
+What it found is DESIGN.md section 3.13: v_pk_fma_f32 fed from ds_read_b128 gives other results beside MFMA-bound kernels."""
 import sys, os
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
