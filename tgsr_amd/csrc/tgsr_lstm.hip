@@ -202,21 +202,19 @@ __global__ __launch_bounds__(KS * H) void lstm_recurrent2_kernel(const float* __
   TGSR_LSTAMP(0);
   int len = cap_lens[b];
   len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  // Load order of the prologue: the caption tokens (one per thread, the head of a dependent chain), then the 32 float4 of weights
+  // per thread, which stay in flight while the chain continues - caption -> gate-table rows staged in LDS.  The prologue is
+  // 7.7 us of the kernel's 20 either way (stamps): what it waits for is the weight loads' address pattern - a lane's 128 bytes
+  // of a row are 128 bytes away from its neighbour's, so every one of the 32 load instructions touches 64 cache lines.  A
+  // per-weight-version pack in lane order (like the gate table) would make them 1-KB runs; not built (5 us of a 520 us step).
+  int64_t row_of_step = 0;
   if (tid < len) {                                             // the gate-table row of every step (caption token, or position)
     const int t = d == 0 ? tid : len - 1 - tid;
-    int64_t row = (int64_t)b * Tmax + t;
+    row_of_step = (int64_t)b * Tmax + t;
     if (captions) {
       const int64_t v = captions[(int64_t)b * width + t];
-      row = (v < 0 || v >= ntoken) ? 0 : v;
+      row_of_step = (v < 0 || v >= ntoken) ? 0 : v;
     }
-    row_s[tid] = (int)row;
-  }
-  __syncthreads();
-#pragma unroll 6
-  for (int s = 0; s < len; ++s) {                              // independent loads: in flight together, and with the weights below
-    const float* gp = gates + ((int64_t)row_s[s] * 2 + d) * 4 * H;
-#pragma unroll
-    for (int e = tid; e < 4 * H; e += NT) gpre_s[s * 4 * H + e] = gp[e];
   }
   // SCALAR registers and v_fma_f32 on purpose - see the note on packed fp32 instructions above
   float wi[HK], wf[HK], wg[HK], wo[HK];                        // rows i, f, g, o of unit j, this thread's K slice
@@ -234,6 +232,14 @@ __global__ __launch_bounds__(KS * H) void lstm_recurrent2_kernel(const float* __
       wg[4 * k] = vg.x; wg[4 * k + 1] = vg.y; wg[4 * k + 2] = vg.z; wg[4 * k + 3] = vg.w;
       wo[4 * k] = vo.x; wo[4 * k + 1] = vo.y; wo[4 * k + 2] = vo.z; wo[4 * k + 3] = vo.w;
     }
+  }
+  if (tid < len) row_s[tid] = (int)row_of_step;
+  __syncthreads();
+#pragma unroll 6
+  for (int s = 0; s < len; ++s) {                              // independent loads: in flight together, and with the weights below
+    const float* gp = gates + ((int64_t)row_s[s] * 2 + d) * 4 * H;
+#pragma unroll
+    for (int e = tid; e < 4 * H; e += NT) gpre_s[s * 4 * H + e] = gp[e];
   }
   float c = 0.f, hcur = 0.f;
   if (tid < H) h_s[0][tid] = 0.f;
