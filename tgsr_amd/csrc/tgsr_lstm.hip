@@ -177,6 +177,9 @@ __global__ __launch_bounds__(4 * H) void lstm_recurrent_kernel(const float* __re
 // does not know it.  tools/lds_neighbour_check.py reproduces it in 40 lines (packed FMAs fed from ds_read_b128 against
 // v_fma_f32 on the same data: 0 mismatches alone, 40 000 beside lp_upconv_glu_kernel; with every load in registers of its own:
 // 0 again), tests/test_hip_concurrency.py keeps it out.
+// Per launch (B = 16, T = 18, rocprofv3): one row per thread 29.4-31.0 us; this kernel 20.2 us; with the K slices interleaved so
+// that the prologue's weight loads coalesce (below) 14.7 us.  (One activation per lane + a DPP broadcast round the quad instead
+// of four per lane: 15.0 - the quarter-rate transcendentals are not what a step waits for.)
 __device__ __forceinline__ float lane_xor1(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
 }
@@ -204,9 +207,10 @@ __global__ __launch_bounds__(KS * H) void lstm_recurrent2_kernel(const float* __
   len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
   // Load order of the prologue: the caption tokens (one per thread, the head of a dependent chain), then the 32 float4 of weights
   // per thread, which stay in flight while the chain continues - caption -> gate-table rows staged in LDS.  The prologue is
-  // 7.7 us of the kernel's 20 either way (stamps): what it waits for is the weight loads' address pattern - a lane's 128 bytes
+  // 7.7 us of the kernel's 20 whatever the order (stamps): what it waited for was the weight loads' address pattern - a lane's 128 bytes
   // of a row are 128 bytes away from its neighbour's, so every one of the 32 load instructions touches 64 cache lines.  A
-  // per-weight-version pack in lane order (like the gate table) would make them 1-KB runs; not built (5 us of a 520 us step).
+  // per-weight-version pack in lane order (like the gate table) would make them 1-KB runs; short of that the K slices are
+  // interleaved (below): the four lanes of a unit read 64 contiguous bytes per instruction - 16 lines instead of 64.
   int64_t row_of_step = 0;
   if (tid < len) {                                             // the gate-table row of every step (caption token, or position)
     const int t = d == 0 ? tid : len - 1 - tid;
@@ -219,14 +223,17 @@ __global__ __launch_bounds__(KS * H) void lstm_recurrent2_kernel(const float* __
   // SCALAR registers and v_fma_f32 on purpose - see the note on packed fp32 instructions above
   float wi[HK], wf[HK], wg[HK], wo[HK];                        // rows i, f, g, o of unit j, this thread's K slice
   {
-    const float* base = w_hh + ((int64_t)d * 4 * H + j) * H + q * HK;
-    const float4* pi = reinterpret_cast<const float4*>(base);
-    const float4* pf = reinterpret_cast<const float4*>(base + (int64_t)H * H);
-    const float4* pg = reinterpret_cast<const float4*>(base + (int64_t)2 * H * H);
-    const float4* po = reinterpret_cast<const float4*>(base + (int64_t)3 * H * H);
+    // K slice of lane q = the float4 pieces q, q + KS, q + 2 KS ... of the row: the KS lanes of a unit read 16 KS contiguous
+    // bytes per load instruction (a contiguous H / KS run per lane put every lane on a cache line of its own: 64 lines per
+    // instruction, and the prologue was 7.7 of the kernel's 20 us; now 2.9)
+    const float* base = w_hh + ((int64_t)d * 4 * H + j) * H;
+    const float4* pi = reinterpret_cast<const float4*>(base) + q;
+    const float4* pf = reinterpret_cast<const float4*>(base + (int64_t)H * H) + q;
+    const float4* pg = reinterpret_cast<const float4*>(base + (int64_t)2 * H * H) + q;
+    const float4* po = reinterpret_cast<const float4*>(base + (int64_t)3 * H * H) + q;
 #pragma unroll
     for (int k = 0; k < HK / 4; ++k) {
-      const float4 vi = pi[k], vf = pf[k], vg = pg[k], vo = po[k];
+      const float4 vi = pi[KS * k], vf = pf[KS * k], vg = pg[KS * k], vo = po[KS * k];
       wi[4 * k] = vi.x; wi[4 * k + 1] = vi.y; wi[4 * k + 2] = vi.z; wi[4 * k + 3] = vi.w;
       wf[4 * k] = vf.x; wf[4 * k + 1] = vf.y; wf[4 * k + 2] = vf.z; wf[4 * k + 3] = vf.w;
       wg[4 * k] = vg.x; wg[4 * k + 1] = vg.y; wg[4 * k + 2] = vg.z; wg[4 * k + 3] = vg.w;
@@ -250,13 +257,13 @@ __global__ __launch_bounds__(KS * H) void lstm_recurrent2_kernel(const float* __
   TGSR_LSTAMP(1);
   for (int s = 0; s < len; ++s) {
     const int t = d == 0 ? s : len - 1 - s;
-    const float* hb = h_s[s & 1] + q * HK;
+    const float* hb = h_s[s & 1] + 4 * q;                      // this lane's pieces of h: 4 (q + KS k), as its weights
     const float* gq = gpre_s + s * 4 * H + j;
     const float q0 = gq[0], q1 = gq[H], q2 = gq[2 * H], q3 = gq[3 * H];   // issued ahead of the h reads
     float ai0 = 0.f, af0 = 0.f, ag0 = 0.f, ao0 = 0.f, ai1 = 0.f, af1 = 0.f, ag1 = 0.f, ao1 = 0.f;   // two chains per row
 #pragma unroll
     for (int k = 0; k < HK / 4; ++k) {
-      const float4 hv = *reinterpret_cast<const float4*>(hb + 4 * k);
+      const float4 hv = *reinterpret_cast<const float4*>(hb + 4 * KS * k);
       ai0 = fmaf(wi[4 * k], hv.x, ai0); af0 = fmaf(wf[4 * k], hv.x, af0); ag0 = fmaf(wg[4 * k], hv.x, ag0); ao0 = fmaf(wo[4 * k], hv.x, ao0);
       ai1 = fmaf(wi[4 * k + 1], hv.y, ai1); af1 = fmaf(wf[4 * k + 1], hv.y, af1); ag1 = fmaf(wg[4 * k + 1], hv.y, ag1); ao1 = fmaf(wo[4 * k + 1], hv.y, ao1);
       ai0 = fmaf(wi[4 * k + 2], hv.z, ai0); af0 = fmaf(wf[4 * k + 2], hv.z, af0); ag0 = fmaf(wg[4 * k + 2], hv.z, ag0); ao0 = fmaf(wo[4 * k + 2], hv.z, ao0);
