@@ -89,6 +89,31 @@ def maybe_spawn(args):
     sys.exit(subprocess.run(cmd).returncode)
 
 
+def batch_pool(B, rank, dev, n=8):
+    """`n` different synthetic batches (captions, caption LENGTHS, images: seeds 100 + rank + 1000 i), resident in HBM
+    before any timed region starts.  Every timed step runs on the next batch of the pool - a hipGraph replay copies it
+    into the graph's static inputs inside the timed loop (one copy launch) - so no figure is the rate of one length vector
+    (Q7: T_max and the mask follow each batch, util.py:250-253, trainer_objective.py:136-140)."""
+    from tgsr_amd.synthetic import synthetic_batch
+    pool = []
+    for i in range(n):
+        cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank + 1000 * i)
+        pool.append({"cap": cap.to(dev), "lens": lens.tolist(), "lens_dev": lens.to(torch.int32).to(dev),
+                     "LR": LR.to(dev), "LRb": LRb.to(dev), "T": int(lens.max())})
+    return pool
+
+
+def replay_on(step, pool, k, lanes=1):
+    """Replay a captured step (SRPipeline / GraphedStep) on the pool's next batch(es): new captions, lengths and images
+    go into the static inputs by the replay's one copy launch; lengths stay on the device (nothing crosses PCIe)."""
+    if lanes == 1:
+        b = pool[k % len(pool)]
+        return step.replay(b["cap"], b["lens_dev"], b["LR"], b["LRb"], num_words=b["T"])
+    bs = [pool[(k * lanes + j) % len(pool)] for j in range(lanes)]
+    return step.replay([b["cap"] for b in bs], [b["lens_dev"] for b in bs], [b["LR"] for b in bs],
+                       [b["LRb"] for b in bs], num_words=[b["T"] for b in bs])
+
+
 def load_weights():
     """Shipped x8 face checkpoint (committed as a data fixture) when present, else None -> seeded random init."""
     p = os.path.join(ROOT, "tests", "golden", "face_S8_weights.npz")
@@ -120,27 +145,37 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(weights, batch, budget_s=20.0):
-    """The oracle (CPU restatement of the reference, plain PyTorch/oneDNN) on this host's cores, bounded sample."""
+def cpu_baseline(weights, batch, budget_s=20.0, x16_pipe=None):
+    """The oracle (CPU restatement of the reference, plain PyTorch/oneDNN) on this host's cores, bounded sample.
+    x16_pipe: the x16 SRPipeline whose (random-init) parameters the x16 oracle runs on (--branch-num != 4)."""
     from oracle import tgsr_oracle as O
     torch.set_num_threads(usable_cores())
-    if weights is None:
+    name = "oracle.sr_forward"
+    if x16_pipe is not None:
+        from oracle import tgsr_oracle_lp as OL
+        cpu = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}          # noqa: E731
+        sdE, sdL, sdH = cpu(x16_pipe.text_encoder), cpu(x16_pipe.netGL), cpu(x16_pipe.netGH)
+        fwd = lambda *a: OL.sr_forward16(*a, dtype=None)                                   # noqa: E731  (None = fp32 oracle)
+        name, batch = "oracle sr_forward16 (models16)", min(batch, 4)
+    elif weights is None:
         sdE, sdL, sdH = O.random_state(seed=0)
+        fwd = O.sr_forward
     else:
         sdE, sdL, sdH = weights["E."], weights["GL."], weights["GH."]
+        fwd = O.sr_forward
     cap, lens, LR, LRb = O.synthetic_batch(batch)
     with torch.no_grad():
-        O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)       # warm-up
+        fwd(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)       # warm-up
         ts = []
         t_all = time.perf_counter()
         while len(ts) < 5 and (time.perf_counter() - t_all) < budget_s:
             t0 = time.perf_counter()
-            O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
+            fwd(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
             ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
     return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle.sr_forward (CPU PyTorch restatement, fp32, eval BN), batch %d, warm-up 1 + median of %d "
-                      "runs, %.2f s/batch" % (batch, len(ts), med)}
+            "sample": "%s (CPU PyTorch restatement, fp32, eval BN), batch %d, warm-up 1 + median of %d "
+                      "runs, %.2f s/batch" % (name, batch, len(ts), med)}
 
 
 CONV_GFLOP_PER_IMAGE = 20.5     # direct-form FLOPs of the 36 conv3x3 launches of one forward (DESIGN.md section 3.1)
@@ -384,16 +419,22 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
                 pipe.netGL.load_state_dict(fp32_pipe.netGL.state_dict())
                 pipe.netGH.load_state_dict(fp32_pipe.netGH.state_dict())
                 pipe.text_encoder.load_state_dict(fp32_pipe.text_encoder.state_dict())
-            cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
-            cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
+            pool = batch_pool(B, rank, dev)
+            cap, lens, LR, LRb = (pool[0][k] for k in ("cap", "lens", "LR", "LRb"))
             ref = fp32_pipe(cap, lens, LR, LRb)["fine"][2]
             got = pipe(cap, lens, LR, LRb)["fine"][2]
             torch.cuda.synchronize()
             entry["psnr_vs_fp32_dB"] = round(_psnr(got, ref), 2)
             del ref, got
             pipe.capture(cap, lens, LR, LRb)
-            for _ in range(args.warmup):
-                pipe.replay(cap, LR, LRb)
+            for k in range(args.warmup):
+                replay_on(pipe, pool, k)
+            # the captured step on a batch with OTHER caption lengths == the eager step on that batch, bit for bit
+            b = pool[3]
+            g = replay_on(pipe, pool, 3)["fine"][2].clone()
+            e = pipe(b["cap"], b["lens"], b["LR"], b["LRb"])["fine"][2]
+            entry["replay_equals_eager_on_new_lengths"] = bool(torch.equal(g, e))
+            del g, e
             ok = True
         except Exception as e:          # noqa: BLE001 - a failed extra must not take the headline line down
             entry["error"] = "%s: %s" % (type(e).__name__, e)
@@ -404,8 +445,8 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
             continue
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.replay(cap, LR, LRb)
+        for k in range(args.steps):
+            replay_on(pipe, pool, k)             # a different batch (captions, lengths, images) every step
         fence()
         dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
         ips = world * B * args.steps / dt
@@ -419,8 +460,8 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
             try:
                 from tgsr_amd.trainer import GraphedStep
                 multi = GraphedStep(pipe, cap, lens, LR, LRb, lanes=4)
-                for _ in range(max(1, args.warmup // 4)):
-                    multi.replay()
+                for k in range(max(1, args.warmup // 4)):
+                    replay_on(multi, pool, k, 4)
                 ok4 = True
             except Exception as e:      # noqa: BLE001
                 entry["graph_lanes4"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -428,8 +469,8 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
             if _all_ok(ok4, dist, dev):
                 fence()
                 t0 = time.perf_counter()
-                for _ in range(args.steps // 4):
-                    multi.replay()
+                for k in range(args.steps // 4):
+                    replay_on(multi, pool, k, 4)  # four different batches per replay, other ones every replay
                 fence()
                 dt4 = _max_over_ranks(time.perf_counter() - t0, dist, dev)
                 ips4 = world * B * args.steps / dt4
@@ -560,19 +601,20 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
         return entry
     fence()
     t0 = time.perf_counter()
+    loss = float("nan")
     for _ in range(steps):
         loss = tr.step(cap, lens, LR, LRb, hr)
     fence()
     dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
-    sec = dt / steps
+    sec = dt / max(1, steps)
     entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4),
                   "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
     # one more step with HIP events around every convolution launch (single stream).  EVERY rank takes it - the step
     # all-reduces the gradient bucket, a collective rank 0 alone would leave unmatched; only rank 0 records and reports.
     prof = []
     perr = None
+    wside, dstreams = tr._wside, tr._dstreams
     try:
-        wside, dstreams = tr._wside, tr._dstreams
         tr._wside, tr._dstreams = None, []
         ops.profile = prof if rank == 0 else None
         tr.step(cap, lens, LR, LRb, hr)
@@ -582,6 +624,8 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
     finally:
         ops.profile = None
         tr._wside, tr._dstreams = wside, dstreams
+    if not _all_ok(perr is None, dist, dev):       # a rank whose profiled step failed may have skipped a collective
+        perr = perr or "the profiled step failed on another rank"
     if rank == 0 and perr is not None:
         entry["roofline"] = {"error": perr}
     elif rank == 0:
@@ -656,6 +700,10 @@ def main():
                     help="default run (fp32 inference, eager): also time, in this process after the headline region, the "
                          "reduced-precision hipGraph configurations (`lp` object: BASELINE configs[4]) and the train steps "
                          "(`train` object: configs[2]); '' or 'none' = headline only")
+    ap.add_argument("--branch-num", type=int, default=4,
+                    help="cfg.TREE.BRANCH_NUM: 4 = the x8 generators of model.py (BASELINE configs, the default); anything "
+                         "else = the x16 generators of models16.py (trainer_objective.py:74-87: 32 -> 512, weight-tied stages, "
+                         "a fourth attention at 256^2 = 65 536 pixels), seeded random-init weights (no x16 checkpoint ships)")
     ap.add_argument("--profile-every", type=int, default=20,
                     help="bracket every launch of every Nth timed step with HIP events for the roofline (0 = never); "
                          "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
@@ -697,10 +745,15 @@ def main():
     cfg_reset()
     cfg.GAN.GF_DIM = 32
     cfg.TEXT.EMBEDDING_DIM = 256
-    cfg.TREE.BRANCH_NUM = 4
+    cfg.TREE.BRANCH_NUM = args.branch_num
     cfg.TREE.BASE_SIZE = 32
+    x16 = args.branch_num != 4
 
-    weights = load_weights()
+    weights = None if x16 else load_weights()
+    if x16:
+        args.extras = "none"           # the lp / train objects are BASELINE's x8 configurations
+        if args.mode != "infer":
+            raise SystemExit("--branch-num applies to the inference bench")
     if args.mode == "train":
         return bench_train(args, rank, world, dist, dev, weights)
     if args.mode == "damsm":
@@ -714,9 +767,8 @@ def main():
             random_init_(m, seed=i)
         wdesc = "seeded random-init weights"
     B = args.batch
-    cap, lens, LR, LRb = synthetic_batch(B, seed=100 + rank)
-    cap, LR, LRb = cap.to(dev), LR.to(dev), LRb.to(dev)
-    lens = lens.tolist()
+    pool = batch_pool(B, rank, dev)
+    cap, lens, LR, LRb = (pool[0][k] for k in ("cap", "lens", "LR", "LRb"))
 
     glanes = max(1, args.graph_lanes) if args.graph else 1
     if args.graph:      # BASELINE config 5: the step replayed from a captured hipGraph (identical results)
@@ -728,8 +780,16 @@ def main():
         from tgsr_amd.trainer import GraphedStep
         multi = GraphedStep(pipe, cap, lens, LR, LRb, lanes=glanes)   # `glanes` independent batches in one graph
 
+    nstep = [0]
+
     def step(eager=False):
-        return pipe(cap, lens, LR, LRb) if eager or not args.graph else pipe.replay(cap, LR, LRb)
+        """One step on the NEXT batch of the pool (other captions, caption lengths and images than the step before)."""
+        k = nstep[0]
+        nstep[0] += 1
+        if eager or not args.graph:
+            b = pool[k % len(pool)]
+            return pipe(b["cap"], b["lens"], b["LR"], b["LRb"])
+        return replay_on(pipe, pool, k)
 
     for _ in range(args.warmup):
         step()
@@ -757,9 +817,9 @@ def main():
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps // glanes):
-        if multi is not None:               # one replay = `glanes` steps; the per-launch sampling happens in the one-lane
-            multi.replay()                  # pass below (a replay of several lanes has no single step to sample)
-            continue
+        if multi is not None:               # one replay = `glanes` steps on `glanes` different batches, other ones every
+            replay_on(multi, pool, k, glanes)   # replay; the per-launch sampling happens in the one-lane pass below (a
+            continue                        # replay of several lanes has no single step to sample)
         # sampled steps are counted from the END of the run: the last step drains the lanes anyway
         sample = args.profile_every > 0 and (args.steps - 1 - k) % args.profile_every == 0
         ops.profile = prof if sample else None
@@ -822,42 +882,60 @@ def main():
             a[3] += e0.elapsed_time(e1) * 1e-3
         roof, kern, att = roofline_objects(agg, nprof, args.dtype, args.serial, args.steps, B) if nprof else (None, {}, None)
         dname = {"fp32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
-        res = {"metric": "SR images/sec (32->256, batch 16 per GPU)", "value": round(world * B * args.steps / dt, 2),
+        res = {"metric": "SR images/sec (32->%d, batch %d per GPU)" % (512 if x16 else 256, B),
+               "value": round(world * B * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": dname, "data": "synthetic inputs (seed 100); " + wdesc,
+               "vs_baseline": None, "dtype": dname, "data": "synthetic inputs (%d batches, seeds 100 + 1000 i); " % len(pool) + wdesc,
                "value_one_lane": round(world * B * args.steps / dt1, 2),
                "ms_per_step_one_lane": round(dt1 / args.steps * 1e3, 4),
-               "config": {"workload": "CelebA face x8 (32->256) batch=%d per GPU, text-enc + G_SR_NET_low + "
+               "config": {"workload": ("CelebA face x16 (32->512, models16.py: TREE.BRANCH_NUM=%d) batch=%d per GPU, text-enc + "
+                                       "G_SR_NET_low + NetG_highweight forward, eval BN (the reference's default branch, "
+                                       "config.py:28; not a BASELINE config)" % (args.branch_num, B)) if x16 else
+                                      "CelebA face x8 (32->256) batch=%d per GPU, text-enc + G_SR_NET_low + "
                                       "NetG_highweight forward, eval BN (BASELINE configs[%d])" %
                                       (B, 1 if args.dtype == "fp32" else 4),
-                          "batch_per_gpu": B, "lr": 32, "sr": 256, "n_words": 41, "parallelism": "dp%d" % world,
+                          "batch_per_gpu": B, "lr": 32, "sr": 512 if x16 else 256, "n_words": 41, "parallelism": "dp%d" % world,
                           "streams": 1 if args.serial else 2, "launch": "hipgraph" if args.graph else "eager",
                           "lanes": nlanes, **({"graph_lanes": glanes} if glanes > 1 else {}), "storage": "fp32 NCHW" if args.dtype == "fp32" else
                           "%s channels-last (zero-bordered), fp32 accumulate; inputs / outputs fp32" % args.dtype,
                           "sampled_steps": nprof,
-                          "note": "`value` covers all %d steps incl. the %d event-sampled single-stream one(s) "
-                                  "(~1 %% of the mean at the default K); `value_one_lane` = the same K steps issued one "
-                                  "at a time, measured right after" % (args.steps, nprof) +
-                                  ("; --graph-lanes %d: a replay runs %d independent batches of %d as parallel branches of "
-                                   "one hipGraph, the timed region is %d replays with no sampling - the event-sampled "
-                                   "steps are part of the one-lane pass instead" % (glanes, glanes, B, args.steps // glanes)
-                                   if glanes > 1 else "")},
+                          "batches": "%d different resident synthetic batches (captions, caption lengths, images) cycled "
+                                     "through the steps: every timed step - every lane of a hipGraph replay - runs on another "
+                                     "batch than the one before; a replay copies it into the graph's static inputs inside the "
+                                     "timed loop (one copy launch); the captured step is independent of the caption lengths"
+                                     % len(pool),
+                          **({"images_in_flight": B * glanes} if glanes > 1 else {}),
+                          "note": ("`value`: %d replays of ONE hipGraph holding %d independent batches of %d as parallel "
+                                   "branches (%d images in flight), no sampling inside; `value_one_lane`: the same K steps "
+                                   "issued one at a time (the strict batch-%d figure), measured right after, incl. the %d "
+                                   "event-sampled single-stream step(s)" % (args.steps // glanes, glanes, B, B * glanes, B, nprof))
+                                  if glanes > 1 else
+                                  ("`value` covers all %d steps incl. the %d event-sampled single-stream one(s) (~1 %% of "
+                                   "the mean at the default K); `value_one_lane` = the same K steps issued one at a time, "
+                                   "measured right after" % (args.steps, nprof))},
                "roofline": roof, "kernels": kern}
         # the whole step against SURVEY.md 8(d)'s compulsory conv-path bytes (173.9 MB per image at the reference's layer
         # boundaries in fp32, half of that with 2-byte storage) and 21.07 GFLOP per image: the "fraction of the HBM
         # roofline" BASELINE.json's north_star speaks of, per GPU
         mb_img = 173.9 if args.dtype == "fp32" else 173.9 / 2
+        gflop_img = 21.07
+        if x16 and nprof:
+            # no SURVEY figure exists for the x16 generators: the per-launch accounting of the sampled step(s) stands in
+            # (every launch's algorithmic bytes / FLOPs, summed; the same accounting gives 2 782 MB per x8 step at batch 16
+            # = SURVEY's 173.9 MB per image)
+            mb_img = sum(v[2] for v in agg.values()) / nprof / B / 1e6
+            gflop_img = sum(v[1] for v in agg.values()) / nprof / B / 1e9
         res["step_roofline"] = {
-            "compulsory_MB_per_image": mb_img, "GFLOP_per_image": 21.07,
+            "compulsory_MB_per_image": round(mb_img, 2), "GFLOP_per_image": round(gflop_img, 3),
             "hbm_frac": round(res["value"] / world * mb_img * 1e6 / (PEAK_HBM_GBS * 1e9), 4),
-            "algorithmic_TFLOPs": round(res["value"] / world * 21.07e9 / 1e12, 1),   # direct-form FLOPs (Winograd /
+            "algorithmic_TFLOPs": round(res["value"] / world * gflop_img * 1e9 / 1e12, 1),   # direct-form FLOPs (Winograd /
             "mfma_peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS if args.dtype == "fp32" else PEAK_LP_MFMA_TFLOPS,   # sub-pixel forms execute fewer)
             "hbm_frac_one_lane": round(res["value_one_lane"] / world * mb_img * 1e6 / (PEAK_HBM_GBS * 1e9), 4)}
         if att is not None:
             res["attention"] = att
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(weights, B)
+            res["cpu_baseline"] = cpu_baseline(weights, B, x16_pipe=pipe if x16 else None)
         res.update(extras)
         print(json.dumps(res), flush=True)
     if dist is not None:

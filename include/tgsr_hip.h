@@ -471,6 +471,12 @@ int tgsr_lp_from_nchw(int dtype, const float* x, void* out, int B, int C, int H,
 int tgsr_lp_to_nchw(int dtype, const void* x, float* out, int B, int C, int H, int W, int cpitch, int coff,
                     void* stream);
 
+/* An lp image (any shape; the whole buffer incl. its zero border, n_elems % 8 == 0, 16-byte aligned) from one 2-byte type
+ * to the other: TGSR_DT_F16 -> TGSR_DT_BF16 (one round-to-nearest-even) or back (exact while |x| < 65504).  Used where a
+ * section of a generator runs with f16 operands inside the bf16 configuration (NetG_highweight's 32x32 trunk: the six
+ * chained ResBlocks of model.py:258-262 are where 8-bit mantissas cost the finest image 7 dB). */
+int tgsr_lp_convert(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n_elems, void* stream);
+
 /* conv weight [Cout][Cin][3][3] (fp32, torch layout) -> MFMA fragment order
  * [kernel row 3][Cin/16][kernel column 3][Cout/32][lane 64][8], rounded to `dtype`
  * (tgsr_lp_packed_conv3x3_elems 2-byte elements).  Cout % 32 == 0, Cin % 16 == 0. */

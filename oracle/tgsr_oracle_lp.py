@@ -15,10 +15,13 @@ can be stated independently of any kernel:
     projected words are rounded to `dtype` once; the attention maps returned to the caller are the fp32 softmax;
   * the six image heads return fp32 images (no rounding of the outputs).
 
-Measured with this model on the shipped face checkpoint (B=4, seed 100), PSNR of the finest SR image against the fp32
-oracle (peak 2.0): bf16 45.0 dB, f16 62.3 dB.  Rounding ONLY the weights to bf16, or ONLY the conv operands, each gives
-48.3-48.6 dB with everything else (storage, accumulation) in fp32: the bf16 figure is the price of 8-bit-mantissa
-operands on this network, not of storage or of a kernel, and cannot reach the 50 dB SURVEY.md 8c hoped for.
+Measured with this model on the shipped face checkpoint (B=2..16, seeds 100 / 7), PSNR of the finest SR image against
+the fp32 oracle (peak 2.0): uniform bf16 46.9-47.4 dB, f16 64.7-65.5 dB.  Where the bf16 loss comes from (layer groups
+switched to f16 one at a time, everything else bf16): all of G_SR_NET_low in f16 gains 0.4 dB; NetG_highweight's 64^2 ..
+256^2 layers and heads in f16 gain 0.2 dB; NetG_highweight's 32^2 TRUNK alone (convin + six chained ResBlocks, 1.2 % of
+the MACs) in f16 gives 53.6-53.8 dB - six residual additions rounded to 8-bit mantissas in a row are the loss.  The bf16
+configuration therefore runs that section in f16 (`trunk_dtype_of`; the product's counterpart is
+tgsr_amd.lp_pipeline.F16_TRUNK) and meets the >= 50 dB SURVEY.md 8c states for it.
 """
 from __future__ import annotations
 
@@ -137,13 +140,25 @@ def g_sr_net_low(sd, LR, sent_emb, words, mask, dtype, correct_mask=False):
     return imgs, atts, mu, logvar
 
 
-def netg_highweight(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr"):
-    x = LRb if low == "lrblur" else (LR - LRb if low == "lr-lrblur" else LR)
-    out = _stem(x, sd, "convin.", dtype)
+def trunk_dtype_of(dtype):
+    """The bf16 configuration runs NetG_highweight's 32x32 trunk (convin + the chained ResBlocks, model.py:258-262) with
+    f16 operands and storage (tgsr_amd/lp_pipeline.py: F16_TRUNK); its output is rounded once to bf16 for the up-scales."""
+    return torch.float16 if dtype == torch.bfloat16 else dtype
+
+
+def _gh_trunk(sd, x, dtype, trunk_dtype):
+    td = trunk_dtype_of(dtype) if trunk_dtype is None else trunk_dtype
+    out = _stem(x, sd, "convin.", td)
     r = 0
     while ("residual.%d.block.0.weight" % r) in sd:
-        out = _res_block(out, sd, "residual.%d." % r, dtype)
+        out = _res_block(out, sd, "residual.%d." % r, td)
         r += 1
+    return out if td == dtype else rnd(out, dtype)            # tgsr_lp_convert
+
+
+def netg_highweight(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr", trunk_dtype=None):
+    x = LRb if low == "lrblur" else (LR - LRb if low == "lr-lrblur" else LR)
+    out = _gh_trunk(sd, x, dtype, trunk_dtype)
     w5 = rnd(sd["conv_output.0.weight"], dtype)
 
     def head(o, sr):
@@ -177,14 +192,10 @@ def g_sr_net_low16(sd, LR, sent_emb, words, mask, dtype, correct_mask=False):
     return imgs, atts, mu, logvar
 
 
-def netg_highweight16(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr"):
+def netg_highweight16(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr", trunk_dtype=None):
     """oracle.tgsr_oracle.netg_highweight16 (models16.py:97-179) with the lp path's rounding points."""
     x = LRb if low == "lrblur" else (LR - LRb if low == "lr-lrblur" else LR)
-    out = _stem(x, sd, "convin.", dtype)
-    r = 0
-    while ("residual.%d.block.0.weight" % r) in sd:
-        out = _res_block(out, sd, "residual.%d." % r, dtype)
-        r += 1
+    out = _gh_trunk(sd, x, dtype, trunk_dtype)
     w5, a = rnd(sd["conv_output.0.weight"], dtype), sd["a"]
 
     def head(o, sr):
@@ -206,7 +217,8 @@ def netg_highweight16(sd, LR, SRb: Sequence[Tensor], LRb, dtype, low="lr"):
     return ims
 
 
-def sr_forward16(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype=None, low="lr", correct_mask=False):
+def sr_forward16(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype=None, low="lr", correct_mask=False,
+                 trunk_dtype=None):
     """The x16 caller wiring (trainer_objective.py:74-87 with BRANCH_NUM != 4); dtype None = the fp32 oracle."""
     words, sent = O.rnn_encoder(sd_E, captions, cap_lens)
     mask = (captions == 0)[:, :words.shape[2]]
@@ -215,17 +227,18 @@ def sr_forward16(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype=None, lo
         fine = O.netg_highweight16(sd_GH, LR, imgs, LRb, low)[0]
     else:
         imgs, atts, mu, logvar = g_sr_net_low16(sd_GL, LR, sent, words, mask, dtype, correct_mask)
-        fine = netg_highweight16(sd_GH, LR, imgs, LRb, dtype, low)
+        fine = netg_highweight16(sd_GH, LR, imgs, LRb, dtype, low, trunk_dtype)
     return {"words_emb": words, "sent_emb": sent, "mask": mask, "fake": imgs, "att": atts, "mu": mu, "logvar": logvar,
             "fine": fine}
 
 
-def sr_forward(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype, low="lr", correct_mask=False):
-    """`oracle.tgsr_oracle.sr_forward` with the lp path's rounding points."""
+def sr_forward(sd_E, sd_GL, sd_GH, captions, cap_lens, LR, LRb, dtype, low="lr", correct_mask=False, trunk_dtype=None):
+    """`oracle.tgsr_oracle.sr_forward` with the lp path's rounding points (trunk_dtype None: the shipped choice,
+    trunk_dtype_of(dtype); pass `dtype` itself for the uniform-type model)."""
     words, sent = O.rnn_encoder(sd_E, captions, cap_lens)
     mask = (captions == 0)[:, :words.shape[2]]
     imgs, atts, mu, logvar = g_sr_net_low(sd_GL, LR, sent, words, mask, dtype, correct_mask)
-    fine = netg_highweight(sd_GH, LR, imgs, LRb, dtype, low)
+    fine = netg_highweight(sd_GH, LR, imgs, LRb, dtype, low, trunk_dtype)
     return {"words_emb": words, "sent_emb": sent, "mask": mask, "fake": imgs, "att": atts, "mu": mu, "logvar": logvar,
             "fine": fine}
 

@@ -44,6 +44,23 @@ def _worker(rank, world, port, q):
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))   # wrote in place
     bucket.all_reduce_mean()
     err = max(float((p.grad - q_.grad).abs().max()) for p, q_ in zip(model.parameters(), ref.parameters()))
+    # --- BatchNorm running statistics ride the same all-reduce: identical on every rank afterwards (= the mean over ranks)
+    bnm = torch.nn.Sequential(torch.nn.Conv2d(2, 4, 1), torch.nn.BatchNorm2d(4))
+    torch.manual_seed(1)
+    xb = torch.randn(8, 2, 3, 3) * 2 + 1
+    bb = parallel.FlatGradBucket(bnm.parameters(), buffers=bnm.buffers()).attach()
+    assert len(bb.buffers) == 2 and bb.flat.numel() == bb.numel and bb.flat_all.numel() == bb.numel + 8
+    bnm(xb[lo:hi]).square().mean().backward()
+    mine = [bnm[1].running_mean.clone(), bnm[1].running_var.clone()]
+    both = [torch.zeros(2, 4), torch.zeros(2, 4)]
+    for k in range(2):
+        gathered = [torch.empty(4) for _ in range(world)]
+        dist.all_gather(gathered, mine[k])
+        both[k] = torch.stack(gathered).mean(0)
+    bb.all_reduce_mean()
+    berr = max(float((bnm[1].running_mean - both[0]).abs().max()), float((bnm[1].running_var - both[1]).abs().max()))
+    assert berr < 1e-6 and int(bnm[1].num_batches_tracked) == 1
+    assert float((mine[0] - bnm[1].running_mean).abs().max()) > 1e-4     # the shards' statistics did differ
     # --- async form + gather
     bucket2 = parallel.FlatGradBucket(model.parameters())
     h = bucket2.all_reduce_mean(async_op=True)

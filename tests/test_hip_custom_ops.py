@@ -152,6 +152,8 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     lens = [6, 4, 2]
     chk(T.lstm_gate_table.default, (emb, w_ih, b_ih, b_hh), test_utils=basic)
     chk(T.bilstm_table.default, (cap, lens, T.lstm_gate_table(emb, w_ih, b_ih, b_hh), w_hh), test_utils=basic)
+    chk(T.bilstm_table_static.default, (cap, torch.tensor(lens, dtype=torch.int32, device=DEV),
+                                        T.lstm_gate_table(emb, w_ih, b_ih, b_hh), w_hh), test_utils=basic)
     xe = R(3, 6, 24)
     chk(T.bilstm_train.default, (xe, w_ih, w_hh, b_ih, b_hh, lens), test_utils=basic)
     wds, sent, acts = T.bilstm_train(xe, w_ih, w_hh, b_ih, b_hh, lens)

@@ -193,11 +193,50 @@ def cfg_face():
     cfg_reset()
 
 
-# PSNR (peak 2.0) of the finest SR image against the fp32 oracle, shipped face checkpoint.  The CPU model of the same
-# rounding points gives bf16 45.0 dB / f16 62.3 dB (oracle/tgsr_oracle_lp.py: bf16 operands alone cost 48.3 dB, so the
-# 50 dB SURVEY.md 8c hoped for is out of reach for ANY bf16-operand implementation of this network); the kernels must
-# land within 1 dB of the model and above these floors.
-PSNR_FLOOR = {"bf16": 43.5, "f16": 60.0}
+# PSNR (peak 2.0) of the finest SR image against the fp32 oracle, shipped face checkpoint.  SURVEY.md 8c states >= 50 dB for
+# the bf16 configuration.  The CPU model of the same rounding points (oracle/tgsr_oracle_lp.py) gives 53.6-53.8 dB for the
+# bf16 configuration as shipped (NetG_highweight's 32^2 trunk with f16 operands, everything else bf16; uniform bf16: 46.9)
+# and 64.7-65.5 dB for f16; the kernels must land within 1 dB of the model and above these floors.
+PSNR_FLOOR = {"bf16": 50.0, "f16": 60.0}
+
+
+def test_lp_convert_between_the_two_types():
+    """tgsr_lp_convert: f16 image -> bf16 (one round-to-nearest-even per element, = torch's conversion) and back (exact),
+    zero border included."""
+    from tgsr_amd import lp
+    g = torch.Generator().manual_seed(4)
+    x = lp.from_nchw((torch.randn(3, 32, 8, 32, generator=g) * 3).to(DEV), torch.float16)
+    out = lp.new_image(3, 8, 32, 32, torch.bfloat16, DEV)
+    lp.convert(x, out)
+    assert torch.equal(out, x.to(torch.bfloat16))
+    back = lp.new_image(3, 8, 32, 32, torch.float16, DEV)
+    lp.convert(out, back)
+    assert torch.equal(back, out.to(torch.float16))
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, :, 0].abs().max()) == 0        # the border stays zero
+    with pytest.raises(Exception):
+        lp.convert(x, lp.new_image(3, 8, 32, 32, torch.float16, DEV))                            # same type: refused
+
+
+def test_bf16_configuration_runs_the_32x32_trunk_in_f16(cfg_face, face_weights, monkeypatch):
+    """The shipped bf16 configuration (f16 operands in NetG_highweight's 32^2 trunk) against the uniform-bf16 one
+    (TGSR_LP_BF16_TRUNK=bf16): each within 1 dB of ITS CPU model, and the shipped one >= 50 dB from the fp32 oracle where
+    uniform bf16 stays below (what SURVEY.md 8c's bar is about)."""
+    from conftest import split_sd
+    from tgsr_amd import lp_pipeline
+    sdE, sdL, sdH = (split_sd(face_weights, k) for k in ("E.", "GL.", "GH."))
+    cap, lens, LR, LRb = O.synthetic_batch(4)
+    with torch.no_grad():
+        ref32 = O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)["fine"][2]
+        m_mixed = OL.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb, torch.bfloat16)["fine"][2]
+        m_plain = OL.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb, torch.bfloat16, trunk_dtype=torch.bfloat16)["fine"][2]
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    mixed = _pipe(cfg_face, face_weights, "bf16")(*args)["fine"][2].cpu()
+    monkeypatch.setattr(lp_pipeline, "F16_TRUNK", False)
+    plain = _pipe(cfg_face, face_weights, "bf16")(*args)["fine"][2].cpu()
+    p_mixed, p_plain = OL.psnr(mixed, ref32), OL.psnr(plain, ref32)
+    assert abs(p_mixed - OL.psnr(m_mixed, ref32)) < 1.0 and abs(p_plain - OL.psnr(m_plain, ref32)) < 1.0
+    assert p_mixed >= 50.0 and p_plain < 49.0 and p_mixed > p_plain + 4.0, (p_mixed, p_plain)
+    assert OL.psnr(mixed, m_mixed) > OL.psnr(m_mixed, ref32) + 3.0
 
 
 @pytest.mark.parametrize("name,td,ulp", DTYPES)
@@ -244,13 +283,33 @@ def test_lp_pipeline_hipgraph_and_determinism(name, cfg_face, face_weights):
             for k in ("fake", "fine", "att"):
                 for i in range(3):
                     assert torch.equal(g[k][i], a[k][i]), "hipGraph replay %d/%d differs from eager (%s[%d])" % (trial, rep, k, i)
-    # new inputs through the captured step
-    cap2, lens2, LR2, LRb2 = O.synthetic_batch(B, seed=7)
-    if lens2.tolist() == lens.tolist():
-        g2 = pipe.replay(cap2.to(DEV), LR2.to(DEV), LRb2.to(DEV))
-        e2 = pipe(cap2.to(DEV), lens2.tolist(), LR2.to(DEV), LRb2.to(DEV))
+    # NEW BATCHES through the captured step - other captions, other LENGTHS (Q7: T_max and the mask follow each batch,
+    # util.py:250-253, trainer_objective.py:136-140), other images: every output bit-equal to the eager step on that batch,
+    # in the reference's T_max-sized shapes
+    seen = set()
+    for seed in (7, 8, 9, 10, 11, 12):
+        cap2, lens2, LR2, LRb2 = O.synthetic_batch(B, seed=seed)
+        if seed == 12:                                            # the extremes: one-word captions ... the full width
+            lens2 = torch.tensor([18, 9, 2, 1])
+            cap2 = torch.zeros(B, 18, dtype=torch.int64)
+            for i, n in enumerate(lens2.tolist()):
+                cap2[i, :n] = torch.randint(1, 41, (n,), generator=torch.Generator().manual_seed(i))
+        seen.add(tuple(lens2.tolist()))
+        a2 = (cap2.to(DEV), lens2.tolist(), LR2.to(DEV), LRb2.to(DEV))
+        g2 = pipe.replay(*a2)
         torch.cuda.synchronize()
-        assert torch.equal(g2["fine"][2], e2["fine"][2])
+        g2 = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in g2.items()}
+        e2 = pipe(*a2)
+        torch.cuda.synchronize()
+        T = max(lens2.tolist())
+        assert g2["words_emb"].shape == e2["words_emb"].shape == (B, 256, T) and g2["mask"].shape == (B, T)
+        for k in ("words_emb", "sent_emb", "mask", "mu", "logvar"):
+            assert torch.equal(g2[k], e2[k]), "replay on batch %d: %s differs from eager" % (seed, k)
+        for k in ("fake", "fine", "att"):
+            for i in range(3):
+                assert g2[k][i].shape == e2[k][i].shape
+                assert torch.equal(g2[k][i], e2[k][i]), "replay on batch %d: %s[%d] differs from eager" % (seed, k, i)
+    assert len(seen) >= 5, "the synthetic batches should differ in their caption lengths"
 
 
 @pytest.mark.parametrize("name", ["bf16", "fp32"])
@@ -267,14 +326,29 @@ def test_hipgraph_with_parallel_lanes(name, cfg_face, face_weights):
     LRbs = [(torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).to(DEV) for _ in range(3)]
     eager = [pipe(capd, lens, LRs[k], LRbs[k])["fine"][2].clone() for k in range(3)]
     step = GraphedStep(pipe, capd, lens, LRs[0], LRbs[0], lanes=3)
-    out = step.replay([capd] * 3, LRs, LRbs)
+    out = step.replay([capd] * 3, None, LRs, LRbs)
     torch.cuda.synchronize()
     for k in range(3):
         assert torch.equal(out[k]["fine"][2], eager[k]), "lane %d differs from the eager step" % k
-    out = step.replay(None, LRs[::-1], LRbs[::-1])               # lanes swapped: same graph, new inputs
+    out = step.replay(None, None, LRs[::-1], LRbs[::-1])         # lanes swapped: same graph, new inputs
     torch.cuda.synchronize()
     for k in range(3):
         assert torch.equal(out[k]["fine"][2], eager[2 - k])
+    # every lane a batch of its own: other captions and other caption lengths per lane (device-side lengths + num_words, the
+    # form bench.py's timed loop uses: nothing crosses PCIe)
+    batches = [O.synthetic_batch(B, seed=20 + k) for k in range(3)]
+    assert len({tuple(b[1].tolist()) for b in batches}) > 1
+    dev = [(b[0].to(DEV), b[1].to(torch.int32).to(DEV), b[2].to(DEV), b[3].to(DEV)) for b in batches]
+    out = step.replay([d[0] for d in dev], [d[1] for d in dev], [d[2] for d in dev], [d[3] for d in dev],
+                      num_words=[int(b[1].max()) for b in batches])
+    torch.cuda.synchronize()
+    out = [{k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in o.items()} for o in out]
+    for k, b in enumerate(batches):
+        e = pipe(b[0].to(DEV), b[1].tolist(), b[2].to(DEV), b[3].to(DEV))
+        torch.cuda.synchronize()
+        assert torch.equal(out[k]["words_emb"], e["words_emb"]) and torch.equal(out[k]["mask"], e["mask"])
+        for i in range(3):
+            assert torch.equal(out[k]["fine"][i], e["fine"][i]) and torch.equal(out[k]["att"][i], e["att"][i]), (k, i)
     assert pipe.overlap                                          # the capture restored the two-stream setting
 
 

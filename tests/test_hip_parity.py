@@ -542,14 +542,61 @@ def test_pipeline_hipgraph_replay_matches_eager():
     cap, LR, LRb, lens = cap.to(DEV), LR.to(DEV), LRb.to(DEV), lens.tolist()
     eager = [f.clone() for f in pipe(cap, lens, LR, LRb)["fine"]]
     pipe.capture(cap, lens, LR, LRb)
-    out = pipe.replay(cap, LR, LRb)
+    out = pipe.replay(cap, lens, LR, LRb)
     for a, b in zip(out["fine"], eager):
         assert torch.equal(a, b)
     _, _, LR2, LRb2 = synthetic_batch(3, seed=8)
-    out2 = [f.clone() for f in pipe.replay(cap, LR2.to(DEV), LRb2.to(DEV))["fine"]]
+    out2 = [f.clone() for f in pipe.replay(cap, None, LR2.to(DEV), LRb2.to(DEV))["fine"]]
     eager2 = pipe(cap, lens, LR2.to(DEV), LRb2.to(DEV))["fine"]
     for a, b in zip(out2, eager2):
         assert torch.equal(a, b)
+    cfg_reset()
+
+
+def test_captured_step_is_independent_of_caption_lengths():
+    """Q7 (util.py:250-253, trainer_objective.py:136-140): T_max and the mask follow each batch's captions.  ONE capture,
+    then six batches with six different length vectors (new captions, lengths, images) through the same hipGraph: every
+    output in the reference's T_max-sized shape, within the stated fp32 tolerance of the CPU oracle on that batch
+    (which runs the reference's per-batch T_max formulation, mask quirk Q1 included) and bit-equal to the eager step."""
+    from oracle import tgsr_oracle as O
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.trainer import SRPipeline
+    cfg_reset()
+    cfg.GAN.GF_DIM = 32
+    cfg.TEXT.EMBEDDING_DIM = 256
+    cfg.TREE.BRANCH_NUM = 4
+    cfg.TREE.BASE_SIZE = 32
+    B = 3
+    sdE, sdL, sdH = O.random_state(seed=3)
+    pipe = SRPipeline(41, device=DEV, branch_num=4).load_state_dicts(sdE, sdL, sdH)
+    cap, lens, LR, LRb = O.synthetic_batch(B, lr=16)
+    pipe.capture(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    seen = set()
+    for seed, forced in ((21, None), (22, None), (23, None), (24, [18, 18, 18]), (25, [18, 2, 1]), (26, [1, 1, 1])):
+        cap, lens, LR, LRb = O.synthetic_batch(B, seed=seed, lr=16)
+        if forced is not None:
+            lens = torch.tensor(forced)
+            cap = torch.zeros(B, 18, dtype=torch.int64)
+            for i, n in enumerate(forced):
+                cap[i, :n] = torch.randint(1, 41, (n,), generator=torch.Generator().manual_seed(seed * 7 + i))
+        seen.add(tuple(lens.tolist()))
+        a = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+        got = pipe.replay(*a)
+        torch.cuda.synchronize()
+        got = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in got.items()}
+        eager = pipe(*a)
+        ref = O.sr_forward(sdE, sdL, sdH, cap, lens.tolist(), LR, LRb)
+        T = max(lens.tolist())
+        assert got["words_emb"].shape == (B, 256, T) and got["mask"].shape == (B, T)
+        np.testing.assert_allclose(got["words_emb"].cpu().numpy(), ref["words_emb"].numpy(), atol=1e-5, rtol=1e-5)
+        for i in range(3):
+            assert got["att"][i].shape == ref["att"][i].shape
+            np.testing.assert_allclose(got["att"][i].cpu().numpy(), ref["att"][i].numpy(), atol=1e-4, rtol=1e-4)
+            np.testing.assert_allclose(got["fake"][i].cpu().numpy(), ref["fake"][i].numpy(), atol=1e-4, rtol=1e-4)
+            np.testing.assert_allclose(got["fine"][i].cpu().numpy(), ref["fine"][i].numpy(), atol=1e-4, rtol=1e-4)
+            assert torch.equal(got["fine"][i], eager["fine"][i]) and torch.equal(got["att"][i], eager["att"][i])
+        assert torch.equal(got["words_emb"], eager["words_emb"]) and torch.equal(got["mask"], eager["mask"])
+    assert len(seen) == 6
     cfg_reset()
 
 

@@ -415,6 +415,60 @@ def test_damsm_trainer_epoch_protocol():
     cfg_reset()
 
 
+def test_damsm_trainer_evaluate_snapshot_resume(tmp_path):
+    """pretrain_DAMSM.py:133-163 (evaluate: eval mode, <= 51 batches, sums divided by the last step index), :286-291
+    (snapshots) and :172-186 (resume: both encoders + the epoch parsed from the file name) against the oracle's losses."""
+    from oracle import tgsr_oracle as O
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.train import DAMSMTrainer
+    cfg_reset()
+    cfg.TEXT.WORDS_NUM = 10
+    cfg.TRAIN.FLAG = True
+    cfg.TRAIN.SNAPSHOT_INTERVAL = 5
+    tr = DAMSMTrainer(40, device=DEV, lr=2e-3)
+    g = torch.Generator().manual_seed(11)
+    B, lens = 4, [10, 7, 4, 2]
+
+    def batch():
+        cap = torch.zeros(B, 10, dtype=torch.int64)
+        for b, n in enumerate(lens):
+            cap[b, :n] = torch.randint(1, 40, (n,), generator=g)
+        return (torch.randn(B, 768, 17, 17, generator=g).to(DEV), torch.randn(B, 2048, generator=g).to(DEV), cap.to(DEV),
+                lens, None)
+    val = [batch() for _ in range(3)]
+    tr.step_features(*val[0][:4])
+    s_loss, w_loss = tr.evaluate_features(val)
+    assert not tr.text_encoder.training and not tr.image_encoder.training          # left in eval mode, like the reference
+    # the same three batches through the oracle's restatement of the encoders' heads and the two losses
+    sdE = {k: v.detach().cpu() for k, v in tr.text_encoder.state_dict().items()}
+    ie = tr.image_encoder
+    s_ref = w_ref = 0.0
+    for feats, pooled, cap, ln, _cls in val:
+        wf = F.conv2d(feats.cpu(), ie.emb_features.weight.detach().cpu())
+        sc = F.linear(pooled.cpu(), ie.emb_cnn_code.weight.detach().cpu(), ie.emb_cnn_code.bias.detach().cpu())
+        we, se = O.rnn_encoder(sdE, cap.cpu(), ln)
+        sm = cfg.TRAIN.SMOOTH
+        w0, w1, _ = O.words_loss(wf, we, torch.arange(B), ln, None, B, sm.GAMMA1, sm.GAMMA2, sm.GAMMA3)
+        s0, s1 = O.sent_loss(sc, se, torch.arange(B), None, B, sm.GAMMA3)
+        w_ref += float(w0 + w1)
+        s_ref += float(s0 + s1)
+    assert abs(s_loss - s_ref / 2) < 2e-4 * max(1.0, abs(s_ref)) and abs(w_loss - w_ref / 2) < 2e-4 * max(1.0, abs(w_ref))
+    assert tr.evaluate_features(val[:1]) == (float("inf"), float("inf"))          # one batch: divided by step index 0
+    assert tr.snapshot_due(10, 600) and tr.snapshot_due(600, 600) and not tr.snapshot_due(7, 600)
+    pi, pt = tr.snapshot(str(tmp_path), 10)
+    assert pt.endswith("text_encoder10.pth") and pi.endswith("image_encoder10.pth")
+    tr2 = DAMSMTrainer(40, device=DEV, lr=2e-3)
+    assert tr2.resume(pt) == 11 and tr2.text_encoder.training
+    for a, b in zip(tr.text_encoder.state_dict().values(), tr2.text_encoder.state_dict().values()):
+        assert torch.equal(a, b)
+    for a, b in zip(tr.image_encoder.state_dict().values(), tr2.image_encoder.state_dict().values()):
+        assert torch.equal(a, b)
+    s2, w2 = tr2.evaluate_features(val)
+    assert s2 == s_loss and w2 == w_loss                                          # same parameters, same kernels: same bits
+    assert tr2.resume('') == 0
+    cfg_reset()
+
+
 def test_sr_trainer_with_damsm_term():
     """SRTrainer with an image encoder: the DAMSM ranking term (generator_loss, losses.py:375-386) reaches the
     generators through the HIP DAMSM backward; one step runs and changes the result of the pixel-only loss."""

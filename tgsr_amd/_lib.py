@@ -94,6 +94,7 @@ SIGNATURES = {
     # reduced-precision inference path (lp images: zero-bordered channels-last bf16 / f16)
     "tgsr_lp_from_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tgsr_lp_to_nchw": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "tgsr_lp_convert": (_i, [_i, _vp, _i, _vp, _i64, _vp]),
     "tgsr_lp_packed_conv3x3_elems": (_i64, [_i, _i]),
     "tgsr_lp_pack_conv3x3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_conv3x3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),

@@ -32,7 +32,8 @@ _ADOPTED = []
 
 
 def check_adopted():
-    """Called once the side stream has been joined: every gradient computed there must BE the parameter's `.grad`."""
+    """Called AFTER the side stream has been joined (SRTrainer._wgrad_side): every gradient computed there must BE the
+    parameter's `.grad`.  It detects after the fact - a failure invalidates the step's gradients (the caller zeroes the bucket)."""
     bad = [p for p, ptr in _ADOPTED if p.grad is None or p.grad.data_ptr() != ptr]
     _ADOPTED.clear()
     if bad:
@@ -476,11 +477,18 @@ class WordAttention(torch.autograd.Function):
         B, idf = h.shape[0], h.shape[1]
         cdf, T = words.shape[1], words.shape[2]
         w2 = w_ctx.detach().reshape(idf, cdf)
-        src = torch.zeros(B, idf, 32, dtype=torch.float32, device=h.device)
-        src[:, :, :T] = torch.matmul(w2, words.detach())               # tiny [idf,cdf] x [B,cdf,T] (library GEMM)
+        # the 1x1 word projection (GlobalAttention.py:100-102) and its two gradients on the library's own MFMA kernels
+        # (tgsr::word_project: [B, idf, 32] zero padded past T; tgsr::linear = gemm_bias_kernel) - no rocBLAS / Tensile
+        # kernel on the training path
+        src = C.word_project(words.detach().contiguous(), [w_ctx.detach()])[0]
         dh, dsrc = C.word_attention_bwd(h.contiguous(), src, mask, ctx.correct_mask, T, dc.contiguous())
-        dwords = torch.matmul(w2.t(), dsrc) if ctx.needs_input_grad[1] else None
-        dw = torch.einsum("bit,bct->ic", dsrc, words.detach()).reshape(w_ctx.shape) if ctx.needs_input_grad[2] else None
+        dwords = dw = None
+        if ctx.needs_input_grad[1]:      # dwords[b] = W^T dsrc[b]: rows (b, t) x W [idf, cdf]
+            dwt = C.linear(dsrc.permute(0, 2, 1).reshape(B * T, idf).contiguous(), w2.t().contiguous(), None)
+            dwords = dwt.reshape(B, T, cdf).permute(0, 2, 1).contiguous()
+        if ctx.needs_input_grad[2]:      # dW[i][c] = sum_{b,t} dsrc[b][i][t] words[b][c][t]
+            dw = C.linear(dsrc.permute(1, 0, 2).reshape(idf, B * T).contiguous(),
+                          words.detach().permute(1, 0, 2).reshape(cdf, B * T).contiguous(), None).reshape(w_ctx.shape)
         return dh, dwords, dw, None, None
 
 

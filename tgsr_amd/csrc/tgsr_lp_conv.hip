@@ -657,6 +657,20 @@ __global__ void lp_to_nchw_kernel(const unsigned short* __restrict__ x, float* _
   }
 }
 
+// lp image of one 2-byte type -> the same image in the other (bf16 <-> f16): 8 elements per thread, the whole buffer incl.
+// the zero border (0 -> 0).  One rounding (to nearest even) where the target has fewer bits.  The one place of the bf16
+// configuration that needs it: NetG_highweight's 32^2 trunk runs with f16 operands, its output feeds bf16 layers.
+template <class TS, class TD>
+__global__ __launch_bounds__(256) void lp_convert_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const u32x4 v = src[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = LP<TD>::pack2(LP<TS>::lo(v[j]), LP<TS>::hi(v[j]));
+    dst[i] = o;
+  }
+}
+
 template <class T, int CIN, int COUT, int EPI, bool UP>
 static int launch_lp_conv_tr(const LpConvArgs& a0, hipStream_t s) {
   LpConvArgs a = a0;
@@ -863,6 +877,22 @@ extern "C" int tgsr_lp_from_nchw(int dtype, const float* x, void* out, int B, in
   else
     return TGSR_EINVAL;
   return note_launch(hipGetLastError(), "lp_from_nchw_kernel");
+}
+
+extern "C" int tgsr_lp_convert(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n_elems, void* stream) {
+  if (!src || !dst || n_elems < 8 || (n_elems & 7) || src_dtype == dst_dtype) return TGSR_EINVAL;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) != 0) return TGSR_EINVAL;
+  const int64_t n8 = n_elems >> 3;
+  const int blocks = (int)((n8 + 255) / 256 < 2048 ? (n8 + 255) / 256 : 2048);
+  const u32x4* sp = static_cast<const u32x4*>(src);
+  u32x4* dp = static_cast<u32x4*>(dst);
+  if (src_dtype == TGSR_DT_F16 && dst_dtype == TGSR_DT_BF16)
+    hipLaunchKernelGGL((lp_convert_kernel<F16, BF16>), dim3(blocks), dim3(256), 0, as_stream(stream), sp, dp, n8);
+  else if (src_dtype == TGSR_DT_BF16 && dst_dtype == TGSR_DT_F16)
+    hipLaunchKernelGGL((lp_convert_kernel<BF16, F16>), dim3(blocks), dim3(256), 0, as_stream(stream), sp, dp, n8);
+  else
+    return TGSR_EINVAL;
+  return note_launch(hipGetLastError(), "lp_convert_kernel");
 }
 
 extern "C" int tgsr_lp_to_nchw(int dtype, const void* x, float* out, int B, int C, int H, int W, int cpitch, int coff,

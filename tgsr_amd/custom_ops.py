@@ -348,6 +348,11 @@ bilstm_table = _define("bilstm_table(Tensor captions, int[] cap_lens, Tensor tab
                        lambda c, lens, table, w_hh: ops.bilstm_table(c, list(lens), table, w_hh),
                        lambda c, lens, table, w_hh: (table.new_empty(c.shape[0], 2 * w_hh.shape[2], max(lens)),
                                                      table.new_empty(c.shape[0], 2 * w_hh.shape[2])))
+# lengths read from a device int32 tensor: no argument of the launch depends on their values (hipGraph replay on new batches)
+bilstm_table_static = _define("bilstm_table_static(Tensor captions, Tensor cap_lens, Tensor table, Tensor w_hh) -> (Tensor, Tensor)",
+                              lambda c, lens, table, w_hh: ops.bilstm_table(c, lens, table, w_hh),
+                              lambda c, lens, table, w_hh: (table.new_empty(c.shape[0], 2 * w_hh.shape[2], c.shape[1]),
+                                                            table.new_empty(c.shape[0], 2 * w_hh.shape[2])))
 lstm_gate_table = _define("lstm_gate_table(Tensor emb, Tensor w_ih, Tensor b_ih, Tensor b_hh) -> Tensor",
                           lambda e, w, bi, bh: ops.lstm_gate_table(e, w, bi, bh),
                           lambda e, w, bi, bh: e.new_empty(e.shape[0], 2, w.shape[1]))
@@ -424,6 +429,8 @@ lp_upconv_glu_head = _define("lp_upconv_glu_head(Tensor x, Tensor wpack, int cin
                                                     write_out=out is not None), None)[1], lambda *a: None)
 lp_stem = _define("lp_stem(Tensor x, Tensor w, Tensor scale, Tensor shift, Tensor(a!) out, int out_coff) -> ()",
                   lambda x, w, s, t, out, oco: (_lp().stem(x, w, s, t, out=out, out_coff=oco), None)[1], lambda *a: None)
+lp_convert = _define("lp_convert(Tensor src, Tensor(a!) out) -> ()", lambda src, out: (_lp().convert(src, out), None)[1],
+                     lambda *a: None)
 lp_conv_to3 = _define("lp_conv_to3(Tensor x, Tensor wpack, int K, bool tanh_axpy, Tensor? addend, float alpha) -> Tensor",
                       lambda x, wp, K, act, add, alpha: _lp().conv_to3(x, wp, K, tanh_axpy=act, addend=add, alpha=alpha),
                       lambda x, wp, K, act, add, alpha: x.new_empty(x.shape[0], 3, x.shape[1] - 2, x.shape[2] - 2, dtype=torch.float32))

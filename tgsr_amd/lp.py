@@ -66,6 +66,19 @@ def to_nchw(img: torch.Tensor, C: Optional[int] = None, coff: int = 0) -> torch.
     return out
 
 
+def convert(src: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """An lp image in the other 2-byte type (f16 -> bf16: one rounding; bf16 -> f16: exact in range): the whole buffer,
+    zero border included (tgsr_lp_convert)."""
+    _need_hip(src, out)
+    _img(src, "src")
+    _img(out, "out")
+    if src.shape != out.shape or src.dtype == out.dtype or src.numel() % 8:
+        raise TgsrError("lp.convert: %s %s -> %s %s" % (tuple(src.shape), src.dtype, tuple(out.shape), out.dtype))
+    check(_lib.lib().tgsr_lp_convert(DT[src.dtype], _p(src), DT[out.dtype], _p(out), src.numel(), _stream()),
+          "tgsr_lp_convert")
+    return out
+
+
 def pack_conv3x3_weight(w: torch.Tensor, dtype) -> torch.Tensor:
     """[Cout,Cin,3,3] fp32 -> MFMA fragment order, rounded to `dtype` (tgsr_lp_pack_conv3x3_weight)."""
     _need_hip(w)

@@ -24,6 +24,18 @@ SUBPIXEL = os.environ.get("TGSR_LP_SUBPIXEL", "1") != "0"
 # and finished for all scales of both generators by ONE tgsr_lp_head_combine launch; the last stage's 256^2 feature
 # images then never go to HBM.  TGSR_LP_FUSE_HEADS=0 keeps the six stand-alone head launches (tgsr_lp_conv_to3_fwd).
 FUSE_HEADS = os.environ.get("TGSR_LP_FUSE_HEADS", "1") != "0"
+# the bf16 configuration runs NetG_highweight's 32^2 trunk (convin + the six ResBlocks of model.py:258-262, 1.2 % of the
+# step's MACs) with f16 operands and storage: six chained residual additions rounded to 8-bit mantissas are where bf16 loses
+# the finest image 7 dB (46.9 -> 53.7 dB against fp32 on the CPU model of the shipped checkpoint with ONLY this section in
+# f16, oracle/tgsr_oracle_lp.py; everything else - all of G_SR_NET_low, every 64^2..256^2 layer, the heads - stays bf16).
+# One tgsr_lp_convert launch (a 1.2 MB image at batch 16) hands the trunk's output to the bf16 up-scales.
+# TGSR_LP_BF16_TRUNK=bf16 keeps the trunk in bf16 (A/B).
+F16_TRUNK = os.environ.get("TGSR_LP_BF16_TRUNK", "f16") != "bf16"
+
+
+def trunk_dtype_of(dtype):
+    """Storage / operand type of NetG_highweight's 32^2 trunk for a pipeline of `dtype`."""
+    return torch.float16 if (dtype == torch.bfloat16 and F16_TRUNK) else dtype
 
 
 class _Conv:
@@ -83,7 +95,6 @@ class LpExecutor:
         self.key = None
         self.bufs = {}
         self.force_bufs = None       # set by a hipGraph capture: the buffer set the captured step is bound to
-        self._bufs_of_step = None    # the buffer set of the step in flight (its pending fused heads)
 
     # ------------------------------------------------------------------ weights
     def _params_key(self):
@@ -98,8 +109,9 @@ class LpExecutor:
         if GL.training or GH.training:
             raise RuntimeError("the reduced-precision path is inference only: call .eval() on the generators")
 
-        def res(rb):
+        def res(rb, dt=dt):
             return (_Conv(rb.block[0], rb.block[1], dt), _Conv(rb.block[3], rb.block[4], dt))
+        self.trunk_dtype = trunk_dtype_of(dt)
 
         # x16 (models16): ONE NEXT_STAGE_G object serves stages 2-4 and ONE image head all four (models16.py:13-14); the
         # 16x stage of NetG_highweight re-uses residual48 / upscale8x (:172-173).  A module is packed once however many
@@ -122,7 +134,7 @@ class LpExecutor:
                                   "head": once(img, lambda m: lp.pack_to3_weight(m.img[0].weight, dt)), "att": st.att})
         self.gl_head_tanh = self.x16                       # GET_IMAGE_G (util.py:894-905) vs GET_IMAGE_G_noAct (:909-919)
         self.gh_stem = _Stem(GH.convin)
-        self.gh_res = [res(rb) for rb in GH.residual]
+        self.gh_res = [res(rb, self.trunk_dtype) for rb in GH.residual]
         ups = [GH.upscale2x, GH.upscale4x, GH.upscale8x] + ([GH.upscale8x] if self.x16 else [])
         mids = [GH.residual24, GH.residual48] + ([GH.residual48] if self.x16 else [])
         self.gh_up = [once(u, lambda m: _UpConv(m[1], m[2], dt)) for u in ups]
@@ -133,17 +145,19 @@ class LpExecutor:
     # ------------------------------------------------------------------ activation buffers
     def alloc(self, B, H, W, dev):
         """One set of zero-bordered activation images for a batch of B LR images of H x W."""
-        def im(s, c):
-            return lp.new_image(B, H * s, W * s, c, self.dtype, dev)
+        def im(s, c, dt=None):
+            return lp.new_image(B, H * s, W * s, c, dt or self.dtype, dev)
         n = len(self.gl_stage)
+        td = self.trunk_dtype
         return {"gl": [{"wide": im(1 << k, 64), "tmp": im(1 << k, 64), "a": im(1 << k, 64), "b": im(1 << k, 64)}
                        for k in range(n)],
                 "h3": im(1 << n, 32),                                   # the last stage's 32-channel output
-                "gh": {"x": im(1, 32), "y": im(1, 32), "t": im(1, 32)},
+                "gh": {"x": im(1, 32, td), "y": im(1, 32, td), "t": im(1, 32, td),
+                       "c": im(1, 32) if td != self.dtype else None},      # the trunk's output in the pipeline's type
                 "u": [im(2 << k, 32) for k in range(n)],
                 "m": [{"t": im(2 << k, 32), "v": im(2 << k, 32)} for k in range(n - 1)],
                 # per-tile partial sums of the fused image heads (fp32; allocated on first use)
-                "pl": [None] * n, "ph": [None] * n, "pend": None}
+                "pl": [None] * n, "ph": [None] * n}
 
     def _buffers(self, B, H, W, dev):
         """The buffer set of the calling stream (concurrent lanes must not share activations); allocated on first use."""
@@ -156,8 +170,14 @@ class LpExecutor:
         return b
 
     # ------------------------------------------------------------------ the two generators
-    def low(self, bufs, LR, sent_emb, word_embs, mask, ca=None, proj=None):
-        """G_SR_NET_low.forward (model.py:48-78) -> (fake_imgs, att_maps, mu, logvar, [h image of each stage])."""
+    def low(self, bufs, LR, sent_emb, word_embs, mask, ca=None, proj=None, defer_heads=False):
+        """G_SR_NET_low.forward (model.py:48-78) -> (fake_imgs, att_maps, mu, logvar).
+
+        Image heads computed inside their upBlocks leave per-tile partial sums.  By default they are combined before this
+        returns: the images are finished.  `defer_heads=True` (SRPipeline: NetG_highweight's heads follow and one combine
+        launch then finishes both generators' images) returns a fifth value, the list of pending partial-sum tensors (None
+        where an image is already complete), and the corresponding `fake_imgs` entries are NOT WRITTEN YET: pass that list
+        to `high_heads(feats, fake_imgs, pend)`, which fills them."""
         GL = self.netGL
         c_code, mu, logvar = GL.ca_net(sent_emb) if ca is None else ca
         T = word_embs.size(2)
@@ -190,8 +210,12 @@ class LpExecutor:
                 st["up"](x, out=nxt)                                           # upBlock -> channels [0, 32) of the next stage
                 fake.append(C.lp_conv_to3(nxt, st["head"], 3, self.gl_head_tanh, None, 0.0))
                 pend.append(None)
-        # images whose partial sums are still to be combined (high_heads does it, for both generators in one launch)
-        bufs["pend"] = (fake, pend)
+        if defer_heads:
+            return fake, atts, mu, logvar, pend
+        todo = [k for k, p in enumerate(pend) if p is not None]
+        if todo:
+            _combine([tuple(fake[k].shape[2:]) for k in todo], [pend[k] for k in todo], [None] * len(todo),
+                     [fake[k] for k in todo], [None] * len(todo), self.gl_head_tanh, 0.0)
         return fake, atts, mu, logvar
 
     def high_trunk(self, bufs, LR, LRb):
@@ -205,6 +229,9 @@ class LpExecutor:
             c0(cur, glu=True, out=g["t"])
             c1(g["t"], residual=cur, out=other)
             cur, other = other, cur
+        if g["c"] is not None:
+            C.lp_convert(cur, g["c"])              # f16 trunk -> the bf16 up-scales (one rounding per element)
+            cur = g["c"]
         feats = []
         for k in range(len(self.gh_up)):
             if k > 0:
@@ -223,18 +250,21 @@ class LpExecutor:
                 self.gh_up[k](cur, out=bufs["u"][k])
                 feats.append(bufs["u"][k])
             cur = bufs["u"][k]
-        self._bufs_of_step = bufs
         return feats
 
-    def high_heads(self, feats, SRb):
+    def high_heads(self, feats, SRb, pend=None):
         """NetG_highweight's heads: `tanh(conv5x5(out_k)) + a * SRb_k`.  Scales whose heads were computed inside their
-        upBlocks (partial sums) are finished here - with G_SR_NET_low's pending 3x3 heads - by one combine launch."""
+        upBlocks (partial sums) are finished here by one combine launch - together with the low-frequency images `SRb`
+        whose partial sums `low(..., defer_heads=True)` handed back as `pend` (pend[k] is None / pend is None: SRb[k] is a
+        finished image)."""
         alpha = self.netGH.alpha() if self.x16 else self.netGH._a      # x16: `a` is a parameter (models16.py:126)
-        fake, pend = self._bufs_of_step["pend"] if self._bufs_of_step is not None else (list(SRb), [None] * len(SRb))
+        pend = [None] * len(SRb) if pend is None else list(pend)
+        if len(pend) != len(SRb):
+            raise ValueError("high_heads: %d pending entries for %d low-frequency images" % (len(pend), len(SRb)))
         fine, sizes, pl, ph, lo, hi = [], [], [], [], [], []
         for k, (f, sr) in enumerate(zip(feats, SRb)):
             fused_h = isinstance(f, _Partial)
-            pk = pend[k] if k < len(pend) and fake[k] is sr else None
+            pk = pend[k]
             if not fused_h:
                 if pk is not None:          # the low image must exist before an unfused 5x5 head can add it: combine it alone
                     _combine([tuple(sr.shape[2:])], [pk], [None], [sr], [None], self.gl_head_tanh, alpha)
@@ -250,8 +280,6 @@ class LpExecutor:
                 hi.append(fine[-1] if fused_h else None)
         if sizes:
             _combine(sizes, pl, ph, lo, hi, self.gl_head_tanh, alpha)
-        if self._bufs_of_step is not None:
-            self._bufs_of_step["pend"] = None
         return fine
 
 

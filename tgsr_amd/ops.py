@@ -520,18 +520,32 @@ def lstm_gate_table(emb, w_ih, b_ih, b_hh):
 
 
 def bilstm_table(captions, cap_lens, table, w_hh):
-    """The BiLSTM recurrence over a per-token gate table (one launch).  Returns (words_emb, sent_emb)."""
+    """The BiLSTM recurrence over a per-token gate table (one launch).  Returns (words_emb, sent_emb).
+
+    cap_lens on the HOST (list / CPU tensor): words_emb is [B, 2H, max(cap_lens)] like the reference's
+    pad_packed_sequence output (util.py:250-253).  cap_lens as a DEVICE int32 tensor [B]: the lengths are read by the
+    kernel only - nothing of the launch (shapes, grid, arguments) depends on their values, so the step can be captured
+    once and replayed on any batch; words_emb is then [B, 2H, captions.size(1)] with zeros behind each caption, and the
+    caller crops to the batch's longest caption on its side (SRPipeline / GraphedStep do)."""
     _need_hip(captions, table, w_hh)
-    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
     B, width = captions.shape
-    if len(lens) != B or min(lens) < 1 or max(lens) > width:
-        raise TgsrError("bilstm: cap_lens %s invalid for captions %s" % (lens, tuple(captions.shape)))
-    Tmax, H, dev = max(lens), w_hh.shape[2], table.device
+    H, dev = w_hh.shape[2], table.device
+    if torch.is_tensor(cap_lens) and cap_lens.is_cuda:
+        if cap_lens.dtype != torch.int32 or cap_lens.numel() != B or not cap_lens.is_contiguous():
+            raise TgsrError("bilstm: device cap_lens must be a contiguous int32 [%d] tensor, got %s %s"
+                            % (B, cap_lens.dtype, tuple(cap_lens.shape)))
+        _need_hip(cap_lens)
+        Tmax, lens_d = width, cap_lens
+    else:
+        lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+        if len(lens) != B or min(lens) < 1 or max(lens) > width:
+            raise TgsrError("bilstm: cap_lens %s invalid for captions %s" % (lens, tuple(captions.shape)))
+        Tmax, lens_d = max(lens), _lens_on_device(tuple(lens), dev)
     captions = captions.to(torch.int64).contiguous()
     words = torch.empty(B, 2 * H, Tmax, dtype=torch.float32, device=dev)
     sent = torch.empty(B, 2 * H, dtype=torch.float32, device=dev)
     w = _f32(w_hh.detach(), "w_hh").contiguous()
-    rc = _lib.lib().tgsr_bilstm_table_fwd(_p(captions), width, _p(_lens_on_device(tuple(lens), dev)), B, Tmax, _p(table),
+    rc = _lib.lib().tgsr_bilstm_table_fwd(_p(captions), width, _p(lens_d), B, Tmax, _p(table),
                                           table.shape[0], _p(w), H, _p(words), _p(sent), _stream())
     check(rc, "tgsr_bilstm_table_fwd")
     return words, sent

@@ -7,7 +7,14 @@ The path shards by image:
     `gather_images` exists only for reporting / saving;
   * training: ONE all-reduce per step over a flat fp32 bucket holding every gradient (G: 1 191 313 params =
     4.77 MB - far below the size where bucketing into several collectives pays on 7 x 153 GB/s xGMI links), then
-    x 1/world.  BatchNorm statistics stay per shard (the DistributedDataParallel convention).
+    x 1/world.  BatchNorm NORMALISES with per-shard batch statistics (the DistributedDataParallel convention; SyncBN
+    would be 36 latency-bound collectives per forward).  The RUNNING statistics every rank accumulates from its own
+    shards would drift apart - DDP avoids that by broadcasting rank 0's buffers before each forward - so here they ride
+    the gradient bucket: FlatGradBucket(params, buffers=...) appends running_mean / running_var to the flat buffer, the
+    step's ONE all-reduce averages them with the gradients and they are copied back: every rank holds the same
+    buffers after every step (a checkpoint is the same file whichever rank writes it; rank 0 does), each the mean over
+    ranks of the per-shard running statistics - for the mean that is the running mean of the global batch, for the
+    variance the running average of the per-shard variances, i.e. of the quantity this policy normalises with.
 """
 import os
 from typing import Iterable, List, Sequence
@@ -77,18 +84,27 @@ def grad_slot(param: torch.Tensor):
 class FlatGradBucket:
     """All gradients of `params` in one flat fp32 buffer; `all_reduce_mean()` = one collective per step."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], buffers: Iterable[torch.Tensor] = ()):
+        """buffers: module buffers to keep identical across ranks (BatchNorm running_mean / running_var; integer buffers
+        such as num_batches_tracked advance in lockstep and are skipped): they travel in the tail of the flat buffer
+        and come back as the mean over ranks with every all_reduce_mean() - no collective of their own."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGradBucket: no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.buffers: List[torch.Tensor] = [b for b in buffers if b.is_floating_point() and b.dtype == dt]
+        self.flat_all = torch.zeros(self.numel + sum(b.numel() for b in self.buffers), dtype=dt, device=dev)
+        self.flat = self.flat_all[:self.numel]                 # the gradients (what begin_step zeroes, what is clipped)
         self.views, self.offsets, off = [], [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             self.offsets.append((off, p.numel()))
             off += p.numel()
+        self.buf_views = []
+        for b in self.buffers:
+            self.buf_views.append(self.flat_all[off:off + b.numel()].view_as(b))
+            off += b.numel()
         self.direct = False
         self.filled = [False] * len(self.params)
 
@@ -138,18 +154,27 @@ class FlatGradBucket:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
         world = dist.get_world_size()
+        if self.buffers:
+            with torch.no_grad():
+                torch._foreach_copy_(self.buf_views, self.buffers)      # this step's running statistics -> the tail
+
+        def finish():
+            self.flat_all.div_(world)
+            self.unpack()
+            if self.buffers:
+                with torch.no_grad():
+                    torch._foreach_copy_(self.buffers, self.buf_views)  # the same values on every rank (bumps versions:
+                                                                        # eval-mode packs derived from them are rebuilt)
         if async_op:
-            work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+            work = dist.all_reduce(self.flat_all, op=dist.ReduceOp.SUM, async_op=True)
 
             class _Done:
                 def wait(_s):
                     work.wait()
-                    self.flat.div_(world)
-                    self.unpack()
+                    finish()
             return _Done()
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(world)
-        self.unpack()
+        dist.all_reduce(self.flat_all, op=dist.ReduceOp.SUM)
+        finish()
         return None
 
 

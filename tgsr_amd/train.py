@@ -61,7 +61,8 @@ class SRTrainer:
         self.netGL = G_SR_NET_low().to(self.device).train()
         self.netGH = NetG_highweight(weightmap=False, low=low).to(self.device).train()
         self.params = list(self.netGL.parameters()) + list(self.netGH.parameters())
-        self.bucket = FlatGradBucket(self.params).attach()
+        # (BatchNorm's running statistics ride the gradient bucket's all-reduce: identical on every rank, parallel.py)
+        self.bucket = FlatGradBucket(self.params, buffers=list(self.netGL.buffers()) + list(self.netGH.buffers())).attach()
         self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999))
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
@@ -72,7 +73,7 @@ class SRTrainer:
                 [model.D_NET64(), model.D_NET128(), model.D_NET256()]
             for d in self.netsD:
                 d.to(self.device).train()
-                self.bucketsD.append(FlatGradBucket(d.parameters()).attach())
+                self.bucketsD.append(FlatGradBucket(d.parameters(), buffers=d.buffers()).attach())
                 self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
                                                    betas=(0.5, 0.999)))
         self._dstreams = [torch.cuda.Stream(device=self.device) for _ in self.netsD] \
@@ -143,16 +144,23 @@ class SRTrainer:
             return
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         autograd.WGRAD_SIDE[idx] = self._wside
+        ok = False
         try:
             yield
-        except BaseException:
-            autograd._ADOPTED.clear()
-            raise
-        else:
-            autograd.check_adopted()
+            ok = True
         finally:
             autograd.WGRAD_SIDE.pop(idx, None)
-            torch.cuda.current_stream(self.device).wait_stream(self._wside)
+            torch.cuda.current_stream(self.device).wait_stream(self._wside)      # the join comes first ...
+            if not ok:
+                autograd._ADOPTED.clear()
+        # ... then the check that autograd adopted every side-stream gradient in place.  A failure means the step's gradients
+        # are INVALID (an accumulation kernel read a slot the side stream was still writing): the bucket is zeroed so that
+        # nothing downstream (all-reduce, optimizer) can consume them, and the error propagates - the caller skips the step.
+        try:
+            autograd.check_adopted()
+        except Exception:
+            self.bucket.flat.zero_()
+            raise
 
     def step_gan(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """One G/D alternation: forward the generators once; update every discriminator on (real, fake.detach());
@@ -264,8 +272,82 @@ class DAMSMTrainer:
         self.start_epoch()
 
     def start_epoch(self):
-        """pretrain_DAMSM.py:270: the optimizer (and its moments) is rebuilt every epoch."""
+        """pretrain_DAMSM.py:270: the optimizer (and its moments) is rebuilt every epoch; train() puts both encoders back
+        in training mode (:49-50; evaluate() leaves them in eval mode)."""
+        self.text_encoder.train()
+        self.image_encoder.train()
         self.opt = torch.optim.Adam(self.params, lr=self.lr, betas=(0.5, 0.999))
+
+    # ------------------------------------------------------------------ validation, snapshots, resume
+    @torch.no_grad()
+    def evaluate_features(self, batches):
+        """pretrain_DAMSM.py:133-163 on trunk outputs: `batches` yields (features, pooled, captions, cap_lens, class_ids);
+        both encoders in eval mode (and left there, as in the reference), at most 51 batches (`if step == 50: break`),
+        returns (s_cur_loss, w_cur_loss) = the summed sentence / word losses divided by the LAST STEP INDEX - the
+        reference's `s_total_loss[0] / step` (:160-161), not by the number of batches: N batches (N <= 50) are divided by
+        N - 1, a single batch by 0 (inf), 51 or more by 50.  Kept as is: the numbers it prints are the ones a user of
+        the reference compares against."""
+        self.text_encoder.eval()
+        self.image_encoder.eval()
+        s_total = torch.zeros((), dtype=torch.float32, device=self.device)
+        w_total = torch.zeros((), dtype=torch.float32, device=self.device)
+        step = -1
+        for step, (features, pooled, captions, cap_lens, class_ids) in enumerate(batches):
+            B = captions.shape[0]
+            labels = torch.arange(B, device=self.device)
+            words_features, sent_code = self.image_encoder.heads(features, pooled)
+            words_emb, sent_emb = self.text_encoder(captions, cap_lens, self.text_encoder.init_hidden(B))
+            w0, w1, _att = losses.words_loss(words_features, words_emb, labels, cap_lens, class_ids, B)
+            s0, s1 = losses.sent_loss(sent_code, sent_emb, labels, class_ids, B)
+            w_total += (w0 + w1).detach()
+            s_total += (s0 + s1).detach()
+            if step == 50:
+                break
+        if step < 0:
+            raise ValueError("evaluate: no validation batch (the reference only evaluates when len(dataloader_val) > 0)")
+        s, w = float(s_total), float(w_total)
+        return (s / step, w / step) if step > 0 else (float("inf") * (1 if s >= 0 else -1), float("inf") * (1 if w >= 0 else -1))
+
+    @torch.no_grad()
+    def evaluate(self, batches):
+        """pretrain_DAMSM.py:133-163 with the images through the (frozen) trunk: `batches` yields
+        (imgs, captions, cap_lens, class_ids) - imgs = the data loader's real_imgs[-1]."""
+        def through_trunk():
+            for imgs, captions, cap_lens, class_ids in batches:
+                features, pooled = self.image_encoder.run_trunk(imgs)
+                yield features, pooled, captions, cap_lens, class_ids
+        return self.evaluate_features(through_trunk())
+
+    def snapshot_due(self, epoch, max_epoch=None):
+        """pretrain_DAMSM.py:286-287."""
+        max_epoch = cfg.TRAIN.MAX_EPOCH if max_epoch is None else max_epoch
+        return epoch % cfg.TRAIN.SNAPSHOT_INTERVAL == 0 or epoch == max_epoch
+
+    def snapshot(self, model_dir, epoch):
+        """pretrain_DAMSM.py:288-291: `image_encoder%d.pth` / `text_encoder%d.pth` state_dicts (no optimizer state: the
+        reference rebuilds Adam every epoch anyway).  Under data parallelism call it on rank 0 (parameters are identical
+        on every rank after the all-reduced step)."""
+        import os
+        os.makedirs(model_dir, exist_ok=True)
+        pi, pt = "%s/image_encoder%d.pth" % (model_dir, epoch), "%s/text_encoder%d.pth" % (model_dir, epoch)
+        torch.save(self.image_encoder.state_dict(), pi)
+        torch.save(self.text_encoder.state_dict(), pt)
+        return pi, pt
+
+    def resume(self, net_e=None):
+        """pretrain_DAMSM.py:172-186: load `cfg.TRAIN.NET_E` (a text_encoder snapshot), the image encoder from the same
+        name with 'text_encoder' -> 'image_encoder', and take the epoch to continue from out of the file name
+        (`istart = rfind('_') + 8`: the digits behind 'text_encoder').  Returns start_epoch = that epoch + 1; the learning
+        rate restarts at ENCODER_LR as in the reference (the decayed value is not saved)."""
+        net_e = cfg.TRAIN.NET_E if net_e is None else net_e
+        if net_e == '':
+            return 0
+        self.text_encoder.load_state_dict(torch.load(net_e, map_location=self.device))
+        self.image_encoder.load_state_dict(torch.load(net_e.replace('text_encoder', 'image_encoder'),
+                                                      map_location=self.device))
+        istart, iend = net_e.rfind('_') + 8, net_e.rfind('.')
+        self.start_epoch()
+        return int(net_e[istart:iend]) + 1
 
     def end_epoch(self):
         """pretrain_DAMSM.py:283-284."""

@@ -34,6 +34,24 @@ def to_uint8(img):
     return np.round(np.maximum(0, np.minimum(255, (a + 1.0) * 127.5))).astype(np.uint8)
 
 
+def crop_words(out, num_words):
+    """Views of a step's outputs cropped to `num_words` caption columns: what the reference's T_max-sized tensors hold
+    (util.py:250-253: words_emb [B, nef, T_max]; trainer_objective.py:136-140: mask [B, T_max]; attention maps
+    [B, T_max, r, r]).  The columns cut off are zero (words_emb, attention weights) or masked."""
+    T = int(num_words)
+    if out["words_emb"].size(2) == T:
+        return out
+    res = dict(out)
+    res["words_emb"] = out["words_emb"][:, :, :T]
+    res["mask"] = out["mask"][:, :T]
+    res["att"] = [a[:, :T] for a in out["att"]]
+    return res
+
+
+def _host_lens(cap_lens):
+    return [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+
+
 class SRPipeline:
     """The three networks of the SR path, built like trainer_objective.py:62-99: TREE.BRANCH_NUM == 4 selects the x8
     generators of model.py, anything else the x16 ones of models16.py (trainer_objective.py:74-87)."""
@@ -97,25 +115,27 @@ class SRPipeline:
     def capture(self, captions, cap_lens, LR, LRb, warmup=3, lanes=1):
         """Capture one forward (both streams, ~60 launches) into a hipGraph bound to static input buffers (`lanes` > 1:
         that many independent batches as parallel branches of the graph, see GraphedStep).
-        `replay(captions, LR, LRb)` then copies new inputs in and relaunches the whole step with one call.  The
-        caption lengths (hence T_max and the mask shape) are part of the captured step: a batch with other lengths
-        needs its own capture, like the reference's cudnn.benchmark re-tunes per shape."""
+        `replay(captions, cap_lens, LR, LRb)` then copies a new batch in and relaunches the whole step with one call.
+        The captured step does not depend on the caption lengths (Q7: util.py:250-253, trainer_objective.py:136-140 make
+        T_max and the mask follow each batch): inside the graph the text runs at the full caption width
+        (cfg.TEXT.WORDS_NUM columns), lengths and mask are device buffers, and the outputs are cropped to the batch's
+        longest caption on the host side of the boundary.  Only the shapes (batch, caption width, LR size) are fixed."""
         self._graphed = GraphedStep(self, captions, cap_lens, LR, LRb, warmup=warmup, lanes=lanes)
-        return self._graphed.out
+        return self._graphed.cropped()
 
     @torch.no_grad()
-    def replay(self, captions=None, LR=None, LRb=None):
-        """Relaunch the captured step (on new inputs when given: same shapes, same caption lengths).  The returned
-        tensors are the graph's static outputs: consume them before the next replay."""
-        return self._graphed.replay(captions, LR, LRb)
+    def replay(self, captions=None, cap_lens=None, LR=None, LRb=None, num_words=None):
+        """Relaunch the captured step, on a new batch when given (same shapes; ANY caption lengths).  The returned
+        tensors are views of the graph's static outputs: consume them before the next replay."""
+        return self._graphed.replay(captions, cap_lens, LR, LRb, num_words=num_words)
 
     @torch.no_grad()
     def capture_lanes(self, n, captions, cap_lens, LR, LRb):
         """n independent captured steps, each with its own static buffers and its own stream, for
         `lanes[k % n].replay(...)`: one host call per step (0.17 ms of host time instead of the ~1.3 ms of ~60 eager
         launches).  Measured on ROCm 7.2 the replays of different graphs do NOT overlap the way eager lanes do
-        (B=16: 1.70-1.75 ms per step against 1.57 ms with three eager lanes, tools/two_lane_check.py), so bench.py
-        keeps eager lanes; this is the option for a host that cannot keep up with the enqueue rate."""
+        (B=16: 1.70-1.75 ms per step against 1.57 ms with three eager lanes), so bench.py uses ONE graph of several
+        lanes (GraphedStep(lanes=...)); this is the option for a host that cannot keep up with the enqueue rate."""
         return [GraphedStep(self, captions, cap_lens, LR, LRb, stream=torch.cuda.Stream(device=self.device))
                 for _ in range(n)]
 
@@ -129,14 +149,23 @@ class SRPipeline:
             self._lp.key = None
 
     @torch.no_grad()
-    def __call__(self, captions, cap_lens, LR, LRb):
+    def __call__(self, captions, cap_lens, LR, LRb, num_words=None):
         """trainer_objective.py:134-146.  Returns the same tensors the reference loop produces.  Runs under the
-        pipeline's device (the kernels launch on the CURRENT device's stream; ops refuse tensors that live elsewhere)."""
+        pipeline's device (the kernels launch on the CURRENT device's stream; ops refuse tensors that live elsewhere).
+
+        cap_lens on the host (list / CPU tensor, what the reference's callers hold: util.py:239) -> words_emb, mask and the
+        attention maps have T_max = max(cap_lens) columns, like the reference's.  cap_lens as a DEVICE tensor -> the
+        length-independent form a hipGraph capture needs: no launch argument depends on the lengths' values, the text runs
+        at the full caption width with zeros / mask bits behind every caption (bit-identical images: a padded column is
+        masked for every sample, its softmax weight is exactly 0), and the outputs are cropped to `num_words` columns when
+        the caller says how long the batch's longest caption is (None: left at the full width)."""
         if self.device.type == "cuda" and self.device.index is not None and \
                 self.device.index != torch.cuda.current_device():
             with torch.cuda.device(self.device):
-                return self._forward(captions, cap_lens, LR, LRb)
-        return self._forward(captions, cap_lens, LR, LRb)
+                out = self._forward(captions, cap_lens, LR, LRb)
+        else:
+            out = self._forward(captions, cap_lens, LR, LRb)
+        return crop_words(out, num_words) if num_words is not None else out
 
     def _text_tail(self, words_embs, sent_emb, captions):
         """(word projections, CA_NET outputs, mask) for G_SR_NET_low: ONE launch (ops.text_tail) where the shapes allow -
@@ -148,8 +177,10 @@ class SRPipeline:
         atts = GL.attention_modules() if hasattr(GL, "attention_modules") else None
         fc = GL.ca_net.fc
         T = words_embs.size(2)
+        idf = atts[0].conv_context.out_channels if atts else 0
         if (atts is None or GL.training or not words_embs.is_cuda or len(atts) > 4 or T > 32 or fc.in_features % 16
-                or captions.dtype != torch.int64 or captions.size(1) < T):
+                or captions.dtype != torch.int64 or captions.size(1) < T or idf < 32 or idf % 32
+                or any(a.conv_context.out_channels != idf for a in atts)):
             return None, GL.ca_net(sent_emb), caption_mask(captions, T)
         src, mu, logvar, m8 = C.text_tail(words_embs, [a.conv_context.weight.detach() for a in atts], sent_emb,
                                           fc.weight.detach(), fc.bias.detach(), GL.ca_net.c_dim, captions)
@@ -166,7 +197,8 @@ class SRPipeline:
             ex.refresh()
             bufs = ex._buffers(LR.shape[0], LR.shape[2], LR.shape[3], LR.device)
             trunk = lambda: ex.high_trunk(bufs, LR, LRb)                                                    # noqa: E731
-            low = lambda sent, words, mask, ca, proj: ex.low(bufs, LR, sent, words, mask, ca=ca, proj=proj)  # noqa: E731
+            low = lambda sent, words, mask, ca, proj: ex.low(bufs, LR, sent, words, mask, ca=ca, proj=proj,  # noqa: E731
+                                                             defer_heads=True)
             heads = ex.high_heads
         else:
             trunk = lambda: self.netGH.trunk(LR, LRb)                                                        # noqa: E731
@@ -185,7 +217,9 @@ class SRPipeline:
                 feats = trunk()
         words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
         proj, ca, mask = self._text_tail(words_embs, sent_emb, captions)
-        fake_imgL, attention_maps, mu, logvar = low(sent_emb, words_embs, mask, ca, proj)
+        res = low(sent_emb, words_embs, mask, ca, proj)
+        fake_imgL, attention_maps, mu, logvar = res[:4]
+        pend = res[4:]       # lp path: (partial sums of the low-frequency heads still to be combined,) - heads() finishes them
         if side is not None:
             main.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
@@ -193,7 +227,7 @@ class SRPipeline:
                     f.record_stream(main)                # allocated on the side stream, consumed on the main one
         else:
             feats = trunk()
-        fine_im = heads(feats, fake_imgL)
+        fine_im = heads(feats, fake_imgL, *pend)
         return {"words_emb": words_embs, "sent_emb": sent_emb, "mask": mask, "fake": fake_imgL,
                 "att": attention_maps, "mu": mu, "logvar": logvar, "fine": fine_im}
 
@@ -202,18 +236,36 @@ class GraphedStep:
     """One captured inference step of an SRPipeline: a hipGraph + the static input / output tensors it is bound to.
     With `stream` the replay (and the copy of new inputs) runs on that stream.
 
+    The graph is independent of the caption lengths: captions [B, W], lengths (int32 [B]), LR and LRb are static DEVICE
+    buffers refreshed by one copy launch per replay; inside the graph the text runs at the full width W (the recurrence
+    reads each sample's length from memory and stops there, the word projection / attention see zero words behind a
+    caption and a mask bit for every padded column, so the softmax weights of those columns are exactly 0); `replay`
+    crops words_emb / mask / attention maps to the new batch's longest caption, which is what the reference's per-batch
+    T_max produces (util.py:250-253, trainer_objective.py:136-140).
+
     `lanes` > 1 captures that many INDEPENDENT batches (each with its own static inputs, outputs and activation buffers)
     as parallel branches of the one graph: a replay then runs `lanes` steps whose kernels interleave on the device the
     way eager stream lanes do, without the host cost of ~60 launches per step and without relying on separate graph
     launches overlapping (measured: they do not).  `inputs` / `out` are then lists of length `lanes`."""
+
+    _RING = 8      # pinned staging buffers for host-side length lists (a replay may be enqueued before the previous copy ran)
 
     @torch.no_grad()
     def __init__(self, pipe, captions, cap_lens, LR, LRb, stream=None, warmup=3, lanes=1):
         dev = LR.device
         self.stream = stream
         self.lanes = max(1, int(lanes))
-        sets = [(captions.clone(), LR.clone(), LRb.clone()) for _ in range(self.lanes)]
-        self.lens = list(cap_lens)
+        if torch.is_tensor(cap_lens) and cap_lens.is_cuda:
+            lens0 = cap_lens.to(torch.int32)
+            self.num_words = [captions.size(1)] * self.lanes        # unknown on the host: no crop until a replay says
+        else:
+            host = _host_lens(cap_lens)
+            lens0 = torch.tensor(host, dtype=torch.int32).to(dev)
+            self.num_words = [max(host)] * self.lanes
+        sets = [(captions.to(torch.int64).clone(), lens0.clone(), LR.clone(), LRb.clone()) for _ in range(self.lanes)]
+        self._pin = [torch.empty(captions.size(0), dtype=torch.int32).pin_memory() for _ in range(self._RING)]
+        self._pin_ev = [None] * self._RING
+        self._pin_next = 0
         lpx = getattr(pipe, "_lp", None)
         bufs = None
         if lpx is not None:                              # reduced-precision path: every lane is bound to its own set of
@@ -227,7 +279,7 @@ class GraphedStep:
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):                   # weight packs, caches and the allocator warm up outside the graph
                 for _ in range(warmup):
-                    pipe(sets[0][0], self.lens, sets[0][1], sets[0][2])
+                    pipe(*sets[0])
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
@@ -247,7 +299,7 @@ class GraphedStep:
                     with torch.cuda.stream(st):
                         if lpx is not None:
                             lpx.force_bufs = bufs[k]
-                        outs.append(pipe(sets[k][0], self.lens, sets[k][1], sets[k][2]))
+                        outs.append(pipe(*sets[k]))      # lengths = the device tensor: the length-independent form
                 for st in branch:
                     main.wait_stream(st)                 # join
         finally:
@@ -258,24 +310,70 @@ class GraphedStep:
         self.inputs = sets[0] if self.lanes == 1 else sets
         self.out = outs[0] if self.lanes == 1 else outs
 
+    def cropped(self):
+        """The static outputs, cropped to the longest caption of the batch each lane last ran."""
+        if self.lanes == 1:
+            return crop_words(self.out, self.num_words[0])
+        return [crop_words(o, t) for o, t in zip(self.out, self.num_words)]
+
     @torch.no_grad()
-    def replay(self, captions=None, LR=None, LRb=None):
-        """Copy new inputs (same shapes, same caption lengths) into the static buffers and relaunch the step.  Returns
-        the static outputs: consume them (on `stream`, or after synchronising it) before this lane's next replay.
-        With `lanes` > 1 each argument is a list of `lanes` tensors (or None: keep the buffers' contents)."""
+    def replay(self, captions=None, cap_lens=None, LR=None, LRb=None, num_words=None):
+        """Copy a new batch (same shapes, any caption lengths) into the static buffers and relaunch the step.  Returns
+        views of the static outputs cropped to the batch's longest caption: consume them (on `stream`, or after
+        synchronising it) before this lane's next replay.
+
+        cap_lens: host list / CPU tensor (staged through pinned memory; T_max = its maximum), or a device int32 / int64
+        tensor (copied on the device; pass `num_words` = the batch's longest caption to have the outputs cropped, else they
+        keep the width they had), or None (captions unchanged).  With `lanes` > 1 each argument is a list of `lanes`
+        entries (or None: keep the buffers' contents)."""
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
-                return self._go(captions, LR, LRb)
-        return self._go(captions, LR, LRb)
+                return self._go(captions, cap_lens, LR, LRb, num_words)
+        return self._go(captions, cap_lens, LR, LRb, num_words)
 
-    def _go(self, captions, LR, LRb):
-        pairs = []
+    def _stage_lens(self, host):
+        """A host-side length list -> a pinned int32 buffer of the ring (waits for the copy that last used that buffer)."""
+        i = self._pin_next
+        self._pin_next = (i + 1) % self._RING
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        pin = self._pin[i]
+        if len(host) != pin.numel():
+            raise ValueError("replay: %d caption lengths for a captured batch of %d" % (len(host), pin.numel()))
+        pin.copy_(torch.tensor(host, dtype=torch.int32))
+        return i, pin
+
+    def _go(self, captions, cap_lens, LR, LRb, num_words):
+        pairs, h2d = [], []
         sets = [self.inputs] if self.lanes == 1 else self.inputs
+        one = self.lanes == 1
         for k, dsts in enumerate(sets):
-            for dst, src in zip(dsts, (captions, LR, LRb)):
-                src = src if (self.lanes == 1 or src is None) else src[k]
+            ln = cap_lens if (one or cap_lens is None) else cap_lens[k]
+            nw = num_words if (one or num_words is None or isinstance(num_words, int)) else num_words[k]
+            if ln is not None:
+                if torch.is_tensor(ln) and ln.is_cuda:
+                    if ln.dtype != torch.int32:
+                        ln = ln.to(torch.int32)
+                    if nw is not None:
+                        self.num_words[k] = int(nw)
+                else:
+                    host = _host_lens(ln)
+                    if min(host) < 1 or max(host) > dsts[0].size(1):
+                        raise ValueError("replay: caption lengths %s outside [1, %d]" % (host, dsts[0].size(1)))
+                    self.num_words[k] = max(host) if nw is None else int(nw)
+                    h2d.append((dsts[1], host))
+                    ln = None
+            elif nw is not None:
+                self.num_words[k] = int(nw)
+            lane = lambda a: a if (one or a is None) else a[k]                 # noqa: E731
+            for dst, src in zip(dsts, (lane(captions), ln, lane(LR), lane(LRb))):
                 if src is not None and src is not dst:
                     pairs.append((dst, src))
+        for dst, host in h2d:
+            i, pin = self._stage_lens(host)
+            dst.copy_(pin, non_blocking=True)
+            ev = self._pin_ev[i] = self._pin_ev[i] or torch.cuda.Event()
+            ev.record()
         fast = [(d, s_) for d, s_ in pairs
                 if s_.is_cuda and s_.dtype == d.dtype and s_.shape == d.shape and s_.is_contiguous() and s_.device == d.device]
         if len(fast) == len(pairs):
@@ -285,4 +383,4 @@ class GraphedStep:
             for dst, src in pairs:
                 dst.copy_(src, non_blocking=True)
         self.graph.replay()
-        return self.out
+        return self.cropped()

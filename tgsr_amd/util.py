@@ -366,6 +366,11 @@ class RNN_ENCODER(nn.Module):
             if key != self._table_key:
                 self._table = C.lstm_gate_table(self.encoder.weight.detach(), w_ih, b_ih, b_hh)
                 self._table_key = key
+            if torch.is_tensor(cap_lens) and cap_lens.is_cuda:
+                # lengths stay on the device (a captured step replayed on new batches): words_emb comes back at the full
+                # caption width, zero behind each caption; the caller crops to the batch's longest caption (util.py:250-253)
+                lens_d = cap_lens if cap_lens.dtype == torch.int32 else cap_lens.to(torch.int32)
+                return C.bilstm_table_static(captions, lens_d.contiguous(), self._table, w_hh)
             lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
             return C.bilstm_table(captions, lens, self._table, w_hh)
         return ops.bilstm(captions, cap_lens, self.encoder.weight, w_ih, w_hh, b_ih, b_hh)
