@@ -277,6 +277,21 @@ int tgsr_text_tail_fwd(const float* words, const float* const* w_ctx, int nsets,
                        float* mu, float* logvar, const int64_t* captions, int width, uint8_t* mask, void* stream);
 
 /*
+ * tgsr_text_tail_fwd that ALSO leaves what the reduced-precision generators need to attend to the words inside the kernels
+ * that produce h (tgsr_lp_stem_att_fwd, tgsr_lp_upconv_glu_att_fwd): `att_pack`, tgsr_lp_att_pack_bytes(nsets, B) bytes,
+ * 16-byte aligned =
+ *     [nsets][B][4 fragments][64 lanes][8] elements of `lp_dtype`: the projections src_out rounded once and laid out as
+ *         the MFMA 32x32x16 A fragments of the scores GEMM (0, 1) and the context GEMM (2, 3);
+ *     [B] uint32: bit t = (captions[b][t] == 0), t < T.
+ * idf must be 32 (the generators' ngf).  src_out / mu / logvar / mask as tgsr_text_tail_fwd, bit-identical.
+ */
+int64_t tgsr_lp_att_pack_bytes(int nsets, int B);
+int tgsr_text_tail_lp_fwd(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf, int T,
+                          float* src_out, const float* sent_emb, const float* ca_w, const float* ca_b, int tdim, int ncf,
+                          float* mu, float* logvar, const int64_t* captions, int width, uint8_t* mask, int lp_dtype,
+                          void* att_pack, void* stream);
+
+/*
  * n <= 16 dense device-to-device copies in one launch: dst / src / nbytes are HOST arrays; sizes and addresses must be
  * multiples of 4 bytes.  (GraphedStep.replay: the new inputs of every lane go into the captured step's static buffers
  * with one launch instead of three hipMemcpyAsync per lane.)
@@ -540,6 +555,26 @@ int tgsr_lp_head_combine(int nscales, int B, const int* H, const int* W, const f
  */
 int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
                      const float* shift, void* out, int out_cpitch, int out_coff, void* stream);
+
+/*
+ * Word attention fused into the kernel that PRODUCES h (GlobalAttention.py:87-130 called at util.py:768-771 on im2f's output
+ * and at util.py:814-817 on the previous stage's upBlock output; c_code[:, q] depends only on h[:, q] and the words):
+ *   tgsr_lp_stem_att_fwd        = tgsr_lp_stem_fwd (C = 32, W % 32 == 0) + the first stage's attention;
+ *   tgsr_lp_upconv_glu_att_fwd  = tgsr_lp_upconv_glu_fwd (head_partial NULL) / tgsr_lp_upconv_glu_head_fwd (head_k = 3)
+ *                                 of a 64 -> 64 upBlock + the NEXT stage's attention on its output.
+ * Same arithmetic as tgsr_lp_word_attention_fwd on the stored h (one shared device function: bit-identical results):
+ * c_code -> channels [c_coff, c_coff + 32) of the same pixels of `out` (must not overlap [out_coff, out_coff + 32)),
+ * attn [B][T][H_out * W_out] fp32 or NULL.  att_pack / att_nsets: what tgsr_text_tail_lp_fwd wrote for this batch; att_set:
+ * which projection this stage attends through; use_mask 0: no mask; mask_mode as tgsr_word_attention_fwd.
+ * The stand-alone attention launches - and their re-read of h - leave G_SR_NET_low's dependent chain.
+ */
+int tgsr_lp_stem_att_fwd(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
+                         const float* shift, void* out, int out_cpitch, int out_coff, const void* att_pack, int att_nsets,
+                         int att_set, int use_mask, int mask_mode, int T, int c_coff, float* attn, void* stream);
+int tgsr_lp_upconv_glu_att_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack,
+                               int Cout, const float* scale, const float* shift, void* out, int out_cpitch, int out_coff,
+                               const void* head_wpack, int head_k, float* head_partial, const void* att_pack, int att_nsets,
+                               int att_set, int use_mask, int mask_mode, int T, int c_coff, float* attn, void* stream);
 
 /*
  * The image heads on an lp image (tgsr_conv_to3_fwd's reference sites: GET_IMAGE_G_noAct util.py:913-915; conv_output

@@ -84,6 +84,35 @@ def _victims(g, B=16):
         lp.head_combine(B, [(64, 64)], [part], [None], [low], [None], True, 0.5)
         return torch.cat([out.float().flatten(), low.flatten()])
     v["lp upBlock + fused head + combine @32->64"] = up_head
+    # the producers that attend to the words in their epilogue (text tail with the attention pack, stem, upBlock), and the
+    # f16 -> bf16 hand-over of NetG_highweight's trunk
+    capz = cap.clone()
+    capz[:, 9:] = 0
+    tail = ops.text_tail(words, ws, sent, caw, cab, 100, capz, lp_dtype=torch.bfloat16)
+    v["text_tail + attention pack"] = lambda: torch.cat([t.flatten().float() for t in
+                                                         ops.text_tail(words, ws, sent, caw, cab, 100, capz, lp_dtype=torch.bfloat16)])
+    pack = tail[4]
+
+    def stem_att():
+        out = lp.new_image(B, 32, 32, 64, dt, DEV)
+        attn = torch.empty(B, T, 32, 32, device=DEV)
+        lp.stem(img, wst, scs, shs, out=out, att=lp.AttFuse(pack, 3, 0, T, True, False, 32, attn))
+        return torch.cat([out.float().flatten(), attn.flatten()])
+    v["lp stem + fused attention"] = stem_att
+
+    def up_att():
+        out = lp.new_image(B, 64, 64, 64, dt, DEV)
+        attn = torch.empty(B, T, 64, 64, device=DEV)
+        _, part = lp.upconv_glu_head(xl, wpu, 64, 64, sc64, sh64, hwp, 3, out=out, att=lp.AttFuse(pack, 3, 1, T, True, False, 32, attn))
+        return torch.cat([out.float().flatten(), attn.flatten(), part.flatten()])
+    v["lp upBlock + fused head + fused attention @32->64"] = up_att
+    x16 = lp.from_nchw(R(B, 32, 32, 32), "f16")
+
+    def conv_():
+        o = lp.new_image(B, 32, 32, 32, dt, DEV)
+        lp.convert(x16, o)
+        return o.float().flatten()
+    v["lp convert f16 -> bf16"] = conv_
     xt = lp.from_nchw(R(B, 32, 64, 64), dt)
     wt3 = lp.pack_to3_weight(R(3, 32, 5, 5) * 0.1, dt)
     v["lp conv_to3 5x5 tanh @64^2"] = lambda: lp.conv_to3(xt, wt3, 5, True, addend, 0.5).flatten()

@@ -175,6 +175,135 @@ def test_lp_word_attention(B, H, W, T, correct, name, td, ulp):
     assert torch.equal(lp.to_nchw(img, 32, 0).cpu(), h), "h channels must be untouched"
 
 
+def _attention_inputs(B, T, seed, nsets=2, ca_dim=64, ncf=10):
+    """words, two conv_context weights, a sentence code + CA_NET's Linear, zero-padded captions of random lengths."""
+    g = torch.Generator().manual_seed(seed)
+    words = torch.randn(B, 48, T, generator=g)
+    ws = [torch.randn(32, 48, 1, 1, generator=g) / 48 ** 0.5 for _ in range(nsets)]
+    sent, caw, cab = torch.randn(B, ca_dim, generator=g), torch.randn(4 * ncf, ca_dim, generator=g) / 8, torch.randn(4 * ncf, generator=g)
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    cap = torch.zeros(B, T + 2, dtype=torch.int64)
+    for b in range(B):
+        cap[b, :int(lens[b])] = torch.randint(1, 40, (int(lens[b]),), generator=g)
+    return words, ws, sent, caw, cab, ncf, cap
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+def test_text_tail_lp_pack(name, td, ulp):
+    """tgsr_text_tail_lp_fwd: the four outputs of tgsr_text_tail_fwd bit for bit + `att_pack` = the projections rounded once
+    to the storage type in the MFMA fragment order the attention consumes (fragments 0, 1: row = word, k = channel;
+    2, 3: row = channel, k = word in the accumulator's order) + the packed mask rows."""
+    from tgsr_amd import ops
+    B, T = 5, 11
+    words, ws, sent, caw, cab, ncf, cap = _attention_inputs(B, T, 3)
+    d = lambda t: t.to(DEV)                                                                     # noqa: E731
+    base = ops.text_tail(d(words), [d(w) for w in ws], d(sent), d(caw), d(cab), ncf, d(cap))
+    got = ops.text_tail(d(words), [d(w) for w in ws], d(sent), d(caw), d(cab), ncf, d(cap), lp_dtype=td)
+    for a, b in zip(base, got[:4]):
+        assert torch.equal(a, b)
+    pack = got[4].cpu()
+    src = got[0].cpu()                                                                           # [nsets, B, 32, 32]
+    frag = pack[:2 * B * 4096].view(td).reshape(2, B, 4, 64, 8).float()
+    q = src.to(td).float()
+    f, l, j = torch.meshgrid(torch.arange(4), torch.arange(64), torch.arange(8), indexing="ij")
+    lr, lh = l % 32, l // 32
+    i1, t1 = 16 * f + 8 * lh + j, lr                                                             # fragments 0, 1 (f < 2)
+    i2, t2 = lr, 16 * (f - 2) + 8 * (j // 4) + 4 * lh + (j % 4)                                  # fragments 2, 3
+    ii, tt = torch.where(f < 2, i1, i2), torch.where(f < 2, t1, t2)
+    assert torch.equal(frag, q[:, :, ii, tt])
+    bits = pack[2 * B * 4096:].view(torch.int32)
+    want = ((cap[:, :T] == 0).long() << torch.arange(T)).sum(1).to(torch.int32)
+    assert torch.equal(bits, want)
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("B,H,W,T,correct,use_mask", [(3, 8, 32, 7, False, True), (2, 32, 32, 18, False, True),
+                                                      (5, 4, 64, 12, True, True), (16, 32, 32, 14, False, True),
+                                                      (2, 8, 32, 5, False, False)])
+def test_lp_stem_with_fused_attention(B, H, W, T, correct, use_mask, name, td, ulp):
+    """tgsr_lp_stem_att_fwd == tgsr_lp_stem_fwd followed by tgsr_lp_word_attention_fwd, bit for bit (h, c_code, attention
+    maps), incl. the reference's mask quirk (row b*Q + q is masked with mask[(b*Q + q) % B]) at B = 16."""
+    from tgsr_amd import lp, ops
+    g = torch.Generator().manual_seed(B + T)
+    x = (torch.rand(B, 3, H, W, generator=g) * 2 - 1).to(DEV)
+    w = (torch.randn(64, 3, 3, 3, generator=g) / 5.0).to(DEV)
+    scale, shift = (1 + 0.1 * torch.randn(64, generator=g)).to(DEV), (0.1 * torch.randn(64, generator=g)).to(DEV)
+    words, ws, sent, caw, cab, ncf, cap = _attention_inputs(B, T, 7 + T)
+    d = lambda t: t.to(DEV)                                                                     # noqa: E731
+    src, _mu, _lv, m8, pack = ops.text_tail(d(words), [d(v) for v in ws], d(sent), d(caw), d(cab), ncf, d(cap), lp_dtype=td)
+    mask = m8.view(torch.bool) if use_mask else None
+    ref = lp.new_image(B, H, W, 64, name, DEV)
+    lp.stem(x, w, scale, shift, out=ref, out_coff=0)
+    a_ref = lp.word_attention(ref, src[1].contiguous(), mask, T, correct_mask=correct)
+    out = lp.new_image(B, H, W, 64, name, DEV)
+    attn = torch.full((B, T, H, W), -1.0, device=DEV)
+    lp.stem(x, w, scale, shift, out=out, out_coff=0, att=lp.AttFuse(pack, 2, 1, T, use_mask, correct, 32, attn))
+    assert torch.equal(out, ref), "h / c_code differ from stem + stand-alone attention"
+    assert torch.equal(attn, a_ref)
+    assert float(out[:, 0].abs().max()) == 0 and float(out[:, :, 0].abs().max()) == 0          # the border stays zero
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("head", [True, False])
+@pytest.mark.parametrize("B,Hi,Wi,T,correct", [(2, 4, 32, 9, False), (3, 16, 32, 18, False), (16, 32, 32, 13, False),
+                                               (2, 8, 64, 6, True)])
+def test_lp_upconv_with_fused_attention(B, Hi, Wi, T, correct, head, name, td, ulp):
+    """tgsr_lp_upconv_glu_att_fwd (with and without the fused 3x3 head) == the upBlock followed by the stand-alone attention
+    on its output, bit for bit: feature channels, c_code channels, attention maps, head partial sums."""
+    from tgsr_amd import lp, ops
+    g = torch.Generator().manual_seed(B * 7 + T)
+    x = lp.from_nchw(torch.randn(B, 64, Hi, Wi, generator=g).to(DEV), name, cpitch=64)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(DEV)
+    scale, shift = (1 + 0.1 * torch.randn(64, generator=g)).to(DEV), (0.1 * torch.randn(64, generator=g)).to(DEV)
+    wsub = lp.pack_upconv_weight(w, name)
+    hw = lp.pack_to3_weight((torch.randn(3, 32, 3, 3, generator=g) / 17.0).to(DEV), name)
+    words, ws, sent, caw, cab, ncf, cap = _attention_inputs(B, T, 11 + T)
+    d = lambda t: t.to(DEV)                                                                     # noqa: E731
+    src, _mu, _lv, m8, pack = ops.text_tail(d(words), [d(v) for v in ws], d(sent), d(caw), d(cab), ncf, d(cap), lp_dtype=td)
+    mask = m8.view(torch.bool)
+    Ho, Wo = 2 * Hi, 2 * Wi
+    ref = lp.new_image(B, Ho, Wo, 64, name, DEV)
+    out = lp.new_image(B, Ho, Wo, 64, name, DEV)
+    attn = torch.full((B, T, Ho, Wo), -1.0, device=DEV)
+    att = lp.AttFuse(pack, 2, 0, T, True, correct, 32, attn)
+    if head:
+        _, p_ref = lp.upconv_glu_head(x, wsub, 64, 64, scale, shift, hw, 3, out=ref)
+        _, p_got = lp.upconv_glu_head(x, wsub, 64, 64, scale, shift, hw, 3, out=out, att=att)
+        assert torch.equal(p_got, p_ref)
+    else:
+        lp.upconv_glu(x, wsub, 64, 64, scale, shift, out=ref)
+        lp.upconv_glu(x, wsub, 64, 64, scale, shift, out=out, att=att)
+    a_ref = lp.word_attention(ref, src[0].contiguous(), mask, T, correct_mask=correct)
+    assert torch.equal(out, ref), "feature / c_code channels differ from upBlock + stand-alone attention"
+    assert torch.equal(attn, a_ref)
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_lp_pipeline_fused_attention_equals_standalone(name, cfg_face, face_weights):
+    """The whole reduced-precision step with the attention of every stage inside the kernel that produces its h
+    (TGSR_LP_FUSE_ATT, the default) against the stand-alone attention launches: every output bit-identical, eager and
+    replayed from a hipGraph."""
+    B = 3
+    cap, lens, LR, LRb = O.synthetic_batch(B, seed=31)
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    fused = _pipe(cfg_face, face_weights, name)
+    plain = _pipe(cfg_face, face_weights, name)
+    plain._lp.fuse_attention = False
+    assert fused._lp.fuse_attention
+    a, b = fused(*args), plain(*args)
+    torch.cuda.synchronize()
+    for k in ("fake", "fine", "att"):
+        for i in range(3):
+            assert torch.equal(a[k][i], b[k][i]), "%s[%d]: fused attention differs from the stand-alone launches" % (k, i)
+    fused.capture(*args)
+    r = fused.replay(*args)
+    torch.cuda.synchronize()
+    for k in ("fake", "fine", "att"):
+        for i in range(3):
+            assert torch.equal(r[k][i], b[k][i])
+
+
 def _pipe(cfg_face, face_weights, dtype, overlap=True):
     from conftest import split_sd
     from tgsr_amd.trainer import SRPipeline
@@ -256,7 +385,11 @@ def test_lp_pipeline_full_size(B, name, td, ulp, cfg_face, face_weights):
             got = out[k][i].cpu()
             p32, pm, pmodel = OL.psnr(got, ref32[k][i]), OL.psnr(got, model[k][i]), OL.psnr(model[k][i], ref32[k][i])
             assert abs(p32 - pmodel) < 1.0, "%s %s[%d]: %.2f dB vs fp32, the CPU model predicts %.2f" % (name, k, i, p32, pmodel)
-            assert pm > pmodel + 3.0, "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
+            # closer to the model than the model is to fp32: by 3 dB for f16; by 2 dB for the bf16 configuration, whose f16
+            # trunk moved the MODEL 7 dB closer to fp32 while the distance between two implementations of the same roundings
+            # stays what the bf16 layers' rounding ties make it (~58 dB)
+            assert pm > pmodel + (3.0 if name == "f16" else 2.0), \
+                "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
     assert OL.psnr(out["fine"][2].cpu(), ref32["fine"][2]) >= PSNR_FLOOR[name]
     for i in range(3):   # attention maps are the fp32 softmax of lp scores
         assert OL.psnr(out["att"][i].cpu(), model["att"][i], peak=1.0) > 45.0
@@ -440,7 +573,8 @@ def test_x16_lp_pipeline_full_size(name, td, ulp, cfg_face):
             # closer to the model than the model is to fp32 - by 1.5 dB here (the x8 test asks 3): through four weight-tied
             # stages two implementations of the same roundings pick different neighbours of a rounding tie more often
             # (above ~85 dB both distances are fp32 summation-order noise on these small-valued images)
-            assert pm > min(pmodel + 1.5, 85.0), "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
+            assert pm > min(pmodel + (1.5 if name == "f16" else 1.0), 85.0), \
+                "%s %s[%d]: only %.2f dB against the CPU model of the same roundings" % (name, k, i, pm)
     for i in range(4):
         assert OL.psnr(out["att"][i].cpu(), model["att"][i], peak=1.0) > 45.0
     eager = [f.clone() for f in out["fine"]]

@@ -80,4 +80,89 @@ __device__ __forceinline__ void lds_dma16(const void* g, void* lds_wave_base) {
 // GLU epilogue (64 gates per lane) half of the kernel's VALU work
 __device__ __forceinline__ float sigmoidf_fast(float g) { return __builtin_amdgcn_rcpf(1.f + __expf(-g)); }
 
+// What a kernel needs to attend to the words for the pixels it has just produced (GlobalAttentionGeneral.forward,
+// GlobalAttention.py:87-130, fused into the epilogue of the kernel that computes h: util.py:768-771, 814-817).
+struct LpAttFuse {
+  const char* frag;        // [B][4 fragments][64 lanes][8] of T: the projected words as MFMA A fragments (tgsr_text_tail_lp_fwd)
+  const uint32_t* mbits;   // [B] packed mask rows (bit t = masked) or null
+  float* attn;             // [B][T][H*W] fp32 or null
+  int T, mask_mode, coff;  // words (<= 32); 0 = the reference's mask quirk, 1 = per-sample; first channel of c_code in `out`
+};
+
+// One 32-pixel tile of the word attention on MFMA 32x32x16 - THE arithmetic of the reduced-precision attention, shared by the
+// stand-alone kernel (lp_word_attention_kernel) and the producers that attend in their epilogue (lp_stem_kernel,
+// lp_upconv_glu_kernel), so every route gives the same bits.  Lane = (pixel l31, half hh):
+//   S[t][q] = sum_i src[i][t] h[i][q]   (fa[0], fa[1]; b0 / b1 = channels 8 hh .. and 16 + 8 hh .. of the lane's pixel)
+//   mask (bit t of mb), softmax over the 32 word rows: 16 in this lane, 16 in lane ^ 32
+//   C[i][q] = sum_t src[i][t] P[t][q]   (fa[2], fa[3]; P rounded to T and consumed from the accumulator registers)
+// attn_q = &attn[b][0][q] or null (row stride Q); cp = address of channel `coff` of the lane's pixel in the output image.
+template <class T>
+__device__ __forceinline__ void lp_attend_tile(const u32x4 (&fa)[4], u32x4 b0, u32x4 b1, unsigned mb, int Tw, int hh,
+                                               float* __restrict__ attn_q, int64_t Q, char* __restrict__ cp) {
+  f32x16v s;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = 0.f;
+  s = LP<T>::mfma32(fa[0], b0, s);
+  s = LP<T>::mfma32(fa[1], b1, s);
+  const unsigned valid = (Tw >= 32 ? 0xffffffffu : ((1u << Tw) - 1u)) & ~mb;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = acc_row(i, hh);
+    if (!((valid >> t) & 1u)) s[i] = -INFINITY;
+    mx = fmaxf(mx, s[i]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s[i] = __expf(s[i] - mx);
+    sum += s[i];
+  }
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] *= inv;
+  if (attn_q) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = acc_row(i, hh);
+      if (t < Tw) attn_q[(int64_t)t * Q] = s[i];
+    }
+  }
+  // weighted context: B operand of k-step ks = registers 8 ks .. 8 ks + 7 of P, rounded to T (their word order is the one
+  // the context GEMM's A fragments were packed in)
+  u32x4 p0, p1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p0[j] = LP<T>::pack2(s[2 * j], s[2 * j + 1]);
+    p1[j] = LP<T>::pack2(s[8 + 2 * j], s[8 + 2 * j + 1]);
+  }
+  f32x16v c;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c[i] = 0.f;
+  c = LP<T>::mfma32(fa[2], p0, c);
+  c = LP<T>::mfma32(fa[3], p1, c);
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    u32x2 pk;
+    pk[0] = LP<T>::pack2(c[4 * rg], c[4 * rg + 1]);
+    pk[1] = LP<T>::pack2(c[4 * rg + 2], c[4 * rg + 3]);
+    *reinterpret_cast<u32x2*>(cp + (8 * rg + 4 * hh) * 2) = pk;
+  }
+}
+
+// `att_pack` (tgsr_text_tail_lp_fwd) -> the fused-attention arguments of one stage
+static inline int lp_att_fuse(const void* att_pack, int att_nsets, int att_set, int B, int use_mask, int mask_mode, int T, int c_coff,
+                       float* attn, LpAttFuse* f) {
+  if (!att_pack || att_nsets < 1 || att_set < 0 || att_set >= att_nsets || (reinterpret_cast<uintptr_t>(att_pack) & 15))
+    return TGSR_EINVAL;
+  const char* p = static_cast<const char*>(att_pack);
+  f->frag = p + (size_t)att_set * B * 4096;
+  f->mbits = use_mask ? reinterpret_cast<const uint32_t*>(p + (size_t)att_nsets * B * 4096) : nullptr;
+  f->attn = attn; f->T = T; f->mask_mode = mask_mode; f->coff = c_coff;
+  return TGSR_OK;
+}
+
+
 }  // namespace tgsr

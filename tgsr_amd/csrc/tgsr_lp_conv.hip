@@ -40,6 +40,7 @@ struct LpConvArgs {
   int tiles_x, tiles_y;
   const char* hw;      // head fusion (lp_upconv_glu_kernel<.., HK>): image-head filter, lp_pack_to3 layout [HK][lane 64][8]
   float* hpart;        // per-tile partial sums of the head [B][tiles_y][tiles_x][3][8 + 2P][64 + 2P]
+  LpAttFuse att;       // lp_upconv_glu_kernel<.., ATT = true>: the next stage's word attention on the tile just produced
 };
 
 constexpr int kEpiAffine = 0, kEpiGlu = 1, kEpiRes = 2;
@@ -267,7 +268,13 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
 // pixels, so it produces PARTIAL sums for the (8 + 2P) x (64 + 2P) outputs its pixels reach; lp_head_combine_kernel adds
 // the <= 4 partials of every pixel in a fixed order (no float atomics) and applies tanh / + a SRb.  With a.out == null the
 // 32-channel feature image - which only the head would read - never goes to HBM.
-template <class T, int CIN, int HK>
+//
+// ATT: NEXT_STAGE_G.forward opens with `c_code, att = self.att(h_code, word_embs)` on exactly the tensor this kernel writes
+// (util.py:814-817; c_code[:, q] depends on h[:, q] and the words only), so each wave attends to the words for its own
+// 2 x 64 pixels while they sit in its staging region (lp_attend_tile: B fragments = two ds_read_b128 of the staged pixel):
+// c_code goes to channels [att.coff, att.coff + 32) of the same pixels of `out`, the attention map to att.attn.  The
+// stand-alone attention launch of the next stage - and its re-read of h - disappear from G_SR_NET_low's dependent chain.
+template <class T, int CIN, int HK, bool ATT = false>
 __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
   constexpr int TRL = 4, TC = 34, NPIX = (TRL + 2) * TC, PB = CIN * 2, NSL = CIN / 8, COUT = 64;
   constexpr int TILE_SLOTS = NPIX * NSL, TILE_INSTR = (TILE_SLOTS + 63) / 64, TILE_BYTES = TILE_INSTR * 1024;
@@ -290,6 +297,11 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
   if constexpr (HK > 0) {
 #pragma unroll
     for (int k = 0; k < HK; ++k) hf[k] = *reinterpret_cast<const u32x4*>(a.hw + (k * 64 + lane) * 16);
+  }
+  u32x4 fa[4];                                                   // the attention's A fragments (this sample's projected words)
+  if constexpr (ATT) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fa[f] = *reinterpret_cast<const u32x4*>(a.att.frag + (int64_t)b * 4096 + (f * 64 + lane) * 16);
   }
   {
     const int64_t rowb = (int64_t)(a.Wi + 2) * a.xcp * 2;
@@ -427,6 +439,26 @@ __global__ __launch_bounds__(256, 2) void lp_upconv_glu_kernel(LpConvArgs a) {
       const int S = j * 64 + lane, pw = S / NCHK, q = (S % NCHK) ^ ((pw >> 1) & (NCHK - 1));
       const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
       *reinterpret_cast<u32x4*>(ob + (pw >> 6) * (2 * orow) + (int64_t)(pw & 63) * (a.ocp * 2) + q * 16) = v;
+    }
+  }
+  if constexpr (ATT) {
+    // ---- the next stage's word attention on this wave's own 2 rows x 64 pixels (staged above; own lgkmcnt(0) passed)
+    const int64_t Q = (int64_t)a.H * a.W;
+    const int64_t orow = (int64_t)(a.W + 2) * a.ocp * 2;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * (y0 + 2 * rp + rr) + ph;
+#pragma unroll
+      for (int seg = 0; seg < 2; ++seg) {
+        const int pw = rr * 64 + seg * 32 + c0, col = 2 * x0 + seg * 32 + c0, sw = (pw >> 1) & (NCHK - 1);
+        const u32x4 b0 = *reinterpret_cast<const u32x4*>(stg + pw * OB + ((h ^ sw) << 4));          // channels 8 h ..
+        const u32x4 b1 = *reinterpret_cast<const u32x4*>(stg + pw * OB + (((2 + h) ^ sw) << 4));    // channels 16 + 8 h ..
+        const int64_t q = (int64_t)row * a.W + col;
+        unsigned mb = 0;
+        if (a.att.mbits) mb = a.att.mbits[a.att.mask_mode ? b : (int)(((int64_t)b * Q + q) % a.B)];   // GlobalAttention.py:111
+        char* cp = a.out + ((int64_t)b * (a.H + 2) + row + 1) * orow + (int64_t)(col + 1) * (a.ocp * 2) + a.att.coff * 2;
+        lp_attend_tile<T>(fa, b0, b1, mb, a.att.T, h, a.att.attn ? a.att.attn + (int64_t)b * a.att.T * Q + q : nullptr, Q, cp);
+      }
     }
   }
   if constexpr (HK > 0) {
@@ -785,9 +817,15 @@ static void launch_lp_upconv(const LpConvArgs& a, int Cin, dim3 grid, hipStream_
   else hipLaunchKernelGGL((lp_upconv_glu_kernel<T, 32, HK>), grid, dim3(256), 0, s, a);
 }
 
+template <class T, int HK>
+static void launch_lp_upconv_att(const LpConvArgs& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((lp_upconv_glu_kernel<T, 64, HK, true>), grid, dim3(256), 0, s, a);
+}
+
 static int lp_upconv_launch(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W, const void* wpack, int Cout,
                             const float* scale, const float* shift, void* out, int out_cpitch, int out_coff,
-                            const void* head_wpack, int head_k, float* head_partial, void* stream) {
+                            const void* head_wpack, int head_k, float* head_partial, void* stream,
+                            const LpAttFuse* att = nullptr) {
   if (!x || !wpack || B < 1 || H < 1 || W < 1) return TGSR_EINVAL;
   if (!out && !head_partial) return TGSR_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
@@ -808,6 +846,22 @@ static int lp_upconv_launch(int dtype, const void* x, int x_cpitch, int B, int C
   const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y));
   hipStream_t s = as_stream(stream);
   const int hk = head_partial ? head_k : 0;
+  a.att = LpAttFuse{nullptr, nullptr, nullptr, 0, 0, 0};
+  if (att) {
+    // the attended tensor is G_SR_NET_low's 32-channel h_code: a 64 -> 64 (GLU: 32) upBlock whose image is written
+    if (!out || Cin != 64 || (hk != 0 && hk != 3) || att->T < 1 || att->T > 32 || att->coff % 4 != 0 ||
+        att->coff + 32 > out_cpitch || (att->coff < out_coff + 32 && out_coff < att->coff + 32))
+      return TGSR_EUNSUPPORTED;
+    a.att = *att;
+    if (dtype == TGSR_DT_BF16) {
+      if (hk == 0) launch_lp_upconv_att<BF16, 0>(a, grid, s);
+      else launch_lp_upconv_att<BF16, 3>(a, grid, s);
+    } else {
+      if (hk == 0) launch_lp_upconv_att<F16, 0>(a, grid, s);
+      else launch_lp_upconv_att<F16, 3>(a, grid, s);
+    }
+    return note_launch(hipGetLastError(), "lp_upconv_glu_kernel");
+  }
   if (dtype == TGSR_DT_BF16) {
     if (hk == 0) launch_lp_upconv<BF16, 0>(a, Cin, grid, s);
     else if (hk == 3) launch_lp_upconv<BF16, 3>(a, Cin, grid, s);
@@ -840,6 +894,18 @@ extern "C" int tgsr_lp_upconv_glu_head_fwd(int dtype, const void* x, int x_cpitc
   if (!head_partial) return TGSR_EINVAL;
   return lp_upconv_launch(dtype, x, x_cpitch, B, Cin, H, W, wpack, Cout, scale, shift, out, out_cpitch, out_coff, head_wpack,
                           head_k, head_partial, stream);
+}
+
+extern "C" int tgsr_lp_upconv_glu_att_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, int H, int W,
+                                          const void* wpack, int Cout, const float* scale, const float* shift, void* out,
+                                          int out_cpitch, int out_coff, const void* head_wpack, int head_k,
+                                          float* head_partial, const void* att_pack, int att_nsets, int att_set, int use_mask,
+                                          int mask_mode, int T, int c_coff, float* attn, void* stream) {
+  LpAttFuse f;
+  const int rc = lp_att_fuse(att_pack, att_nsets, att_set, B, use_mask, mask_mode, T, c_coff, attn, &f);
+  if (rc) return rc;
+  return lp_upconv_launch(dtype, x, x_cpitch, B, Cin, H, W, wpack, Cout, scale, shift, out, out_cpitch, out_coff,
+                          head_partial ? head_wpack : nullptr, head_k, head_partial, stream, &f);
 }
 
 extern "C" int tgsr_lp_head_combine(int nscales, int B, const int* H, const int* W, const float* const* partial_low,

@@ -21,6 +21,7 @@ struct LpStemArgs {
   const float* shift;
   unsigned short* out;   // lp image
   int B, H, W, C, ocp, oco;
+  LpAttFuse att;         // ATT: attend to the words in the epilogue (INIT_STAGE_GImgup: im2f -> att, util.py:768-771)
 };
 
 // Workgroup = one row segment of 32 pixels x ALL output channels: thread = (pixel, group of 8 output channels: 8 value +
@@ -29,10 +30,15 @@ struct LpStemArgs {
 // its 27 inputs itself, eight times over (once per channel group), and the 16 x 27 weights of its group through ~50
 // dependent scalar loads: 11 us for 2 MFLOP per image at the head of the step's critical chain (profiles/r02i_bf16_
 // kernel_stats.csv), now bound by one load round trip.
-template <class T>
+// ATT (C = 32): the 32 pixels x 32 channels the workgroup has just produced are also staged in LDS and wave 0 attends to the
+// words for them (lp_attend_tile): c_code goes to channels [att.coff, att.coff + 32) of the same pixels of `out`, the
+// attention map to att.attn - the stand-alone attention launch of the 32 x 32 stage and its re-read of h are gone.
+template <class T, bool ATT>
 __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
   // [2C][28] weights | [2C] scale | [2C] shift | [3][3][34] input, sized for C <= 64
   __shared__ __attribute__((aligned(16))) float stem_s[2 * 64 * 28 + 4 * 64 + 3 * 3 * 34];
+  constexpr int HP = 80;                                               // bytes per staged pixel (64 + 16 pad)
+  __shared__ __attribute__((aligned(16))) char h_s[ATT ? 32 * HP : 16];
   const int C2 = 2 * a.C, NG = a.C / 8;                                // NG channel groups, 32 * NG threads do the arithmetic
   float* ws = stem_s;
   float* sc = ws + C2 * 28;
@@ -44,6 +50,14 @@ __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
   const int tx = t % tilesx;
   t /= tilesx;
   const int y = t % a.H, b = t / a.H, x0 = tx * 32;
+  u32x4 fa[4];
+  if constexpr (ATT) {
+    if (tid < 64) {                                                    // wave 0's A fragments: in flight under the convolution
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        fa[f] = *reinterpret_cast<const u32x4*>(a.att.frag + (int64_t)b * 4096 + (f * 64 + tid) * 16);
+    }
+  }
   for (int i = tid; i < C2 * 27; i += 256) ws[(i / 27) * 28 + i % 27] = a.w[i];
   for (int i = tid; i < C2; i += 256) {
     sc[i] = a.scale[i];
@@ -56,7 +70,9 @@ __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
   }
   __syncthreads();
   const int px = tid & 31, g = tid >> 5;
-  if (g >= NG || x0 + px >= a.W) return;
+  const bool active = g < NG && x0 + px < a.W;
+  if (!ATT && !active) return;
+  if (active) {
   float in[27];
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -97,6 +113,21 @@ __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
   for (int q = 0; q < 4; ++q) pk[q] = LP<T>::pack2(o[2 * q], o[2 * q + 1]);
   unsigned short* op = a.out + (((int64_t)b * (a.H + 2) + y + 1) * (a.W + 2) + x0 + px + 1) * a.ocp + a.oco + g * 8;
   *reinterpret_cast<u32x4*>(op) = pk;
+  if constexpr (ATT) *reinterpret_cast<u32x4*>(h_s + px * HP + g * 16) = pk;
+  }
+  if constexpr (ATT) {
+    __syncthreads();
+    if (tid >= 64) return;
+    const int l31 = tid & 31, hh = tid >> 5;
+    const int64_t Q = (int64_t)a.H * a.W;
+    const int64_t q = (int64_t)y * a.W + x0 + l31;
+    const u32x4 b0 = *reinterpret_cast<const u32x4*>(h_s + l31 * HP + hh * 16);
+    const u32x4 b1 = *reinterpret_cast<const u32x4*>(h_s + l31 * HP + 32 + hh * 16);
+    unsigned mb = 0;
+    if (a.att.mbits) mb = a.att.mbits[a.att.mask_mode ? b : (int)(((int64_t)b * Q + q) % a.B)];   // GlobalAttention.py:111
+    char* cp = reinterpret_cast<char*>(a.out + (((int64_t)b * (a.H + 2) + y + 1) * (a.W + 2) + x0 + l31 + 1) * a.ocp + a.att.coff);
+    lp_attend_tile<T>(fa, b0, b1, mb, a.att.T, hh, a.att.attn ? a.att.attn + (int64_t)b * a.att.T * Q + q : nullptr, Q, cp);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------ heads
@@ -265,12 +296,6 @@ __global__ __launch_bounds__(256) void lp_word_attention_kernel(LpAttnArgs a) {
     const char* hp = hb + (y + 1) * hrow + (int64_t)(x + 1) * (a.hcp * 2) + hh * 16;
     const u32x4 b0 = *reinterpret_cast<const u32x4*>(hp);          // channels 8 hh .. (k-step 0)
     const u32x4 b1 = *reinterpret_cast<const u32x4*>(hp + 32);     // channels 16 + 8 hh ..
-    f32x16v s;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] = 0.f;
-    s = LP<T>::mfma32(fa[0], b0, s);
-    s = LP<T>::mfma32(fa[1], b1, s);
-
     unsigned mb = 0;
     if (a.mask) {
       const int mrow = a.mask_mode ? b : (int)(((int64_t)b * Q + q) % a.B);   // GlobalAttention.py:111 mask.repeat(queryL,1)
@@ -280,54 +305,8 @@ __global__ __launch_bounds__(256) void lp_word_attention_kernel(LpAttnArgs a) {
         for (int t = 0; t < a.T; ++t) mb |= (a.mask[mrow * a.T + t] ? 1u : 0u) << t;
       }
     }
-    const unsigned valid = (a.T >= 32 ? 0xffffffffu : ((1u << a.T) - 1u)) & ~mb;
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = acc_row(i, hh);
-      if (!((valid >> t) & 1u)) s[i] = -INFINITY;
-      mx = fmaxf(mx, s[i]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      s[i] = __expf(s[i] - mx);
-      sum += s[i];
-    }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[i] *= inv;
-    if (a.attn) {
-      float* __restrict__ ab = a.attn + (int64_t)b * a.T * Q + q;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int t = acc_row(i, hh);
-        if (t < a.T) ab[(int64_t)t * Q] = s[i];
-      }
-    }
-    // weighted context: B operand of k-step ks = registers 8 ks .. 8 ks + 7 of P, rounded to T (their word order is
-    // the one the GEMM2 A fragments were packed in)
-    u32x4 p0, p1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      p0[j] = LP<T>::pack2(s[2 * j], s[2 * j + 1]);
-      p1[j] = LP<T>::pack2(s[8 + 2 * j], s[8 + 2 * j + 1]);
-    }
-    f32x16v c;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = 0.f;
-    c = LP<T>::mfma32(fa[2], p0, c);
-    c = LP<T>::mfma32(fa[3], p1, c);
     char* cp = cb + (y + 1) * crow + (int64_t)(x + 1) * (a.ccp * 2) + a.cco * 2;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      u32x2 pk;
-      pk[0] = LP<T>::pack2(c[4 * rg], c[4 * rg + 1]);
-      pk[1] = LP<T>::pack2(c[4 * rg + 2], c[4 * rg + 3]);
-      *reinterpret_cast<u32x2*>(cp + (8 * rg + 4 * hh) * 2) = pk;
-    }
+    lp_attend_tile<T>(fa, b0, b1, mb, a.T, hh, a.attn ? a.attn + (int64_t)b * a.T * Q + q : nullptr, Q, cp);
   }
 }
 
@@ -335,8 +314,8 @@ __global__ __launch_bounds__(256) void lp_word_attention_kernel(LpAttnArgs a) {
 
 using namespace tgsr;
 
-extern "C" int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
-                                const float* shift, void* out, int out_cpitch, int out_coff, void* stream) {
+static int lp_stem_launch(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
+                          const float* shift, void* out, int out_cpitch, int out_coff, const LpAttFuse* att, void* stream) {
   if (!x || !w || !scale || !shift || !out || B < 1 || H < 1 || W < 1 || C < 8) return TGSR_EINVAL;
   if (C % 8 != 0 || out_cpitch % 8 != 0 || out_coff % 8 != 0 || out_coff + C > out_cpitch ||
       (reinterpret_cast<uintptr_t>(out) & 15))
@@ -346,10 +325,36 @@ extern "C" int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, 
   a.B = B; a.H = H; a.W = W; a.C = C; a.ocp = out_cpitch; a.oco = out_coff;
   if (C > 64) return TGSR_EUNSUPPORTED;                      // 8 channel groups of 8 per 256-thread workgroup
   const dim3 grid((unsigned)((int64_t)B * H * ((W + 31) / 32)));
-  if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL(lp_stem_kernel<BF16>, grid, dim3(256), 0, as_stream(stream), a);
-  else if (dtype == TGSR_DT_F16) hipLaunchKernelGGL(lp_stem_kernel<F16>, grid, dim3(256), 0, as_stream(stream), a);
+  if (att) {
+    if (C != 32 || W % 32 != 0 || att->T < 1 || att->T > 32 || att->coff % 4 != 0 || att->coff + 32 > out_cpitch ||
+        (att->coff < out_coff + C && out_coff < att->coff + 32))
+      return TGSR_EUNSUPPORTED;
+    a.att = *att;
+    if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL((lp_stem_kernel<BF16, true>), grid, dim3(256), 0, as_stream(stream), a);
+    else if (dtype == TGSR_DT_F16) hipLaunchKernelGGL((lp_stem_kernel<F16, true>), grid, dim3(256), 0, as_stream(stream), a);
+    else return TGSR_EINVAL;
+    return note_launch(hipGetLastError(), "lp_stem_kernel");
+  }
+  a.att = LpAttFuse{nullptr, nullptr, nullptr, 0, 0, 0};
+  if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL((lp_stem_kernel<BF16, false>), grid, dim3(256), 0, as_stream(stream), a);
+  else if (dtype == TGSR_DT_F16) hipLaunchKernelGGL((lp_stem_kernel<F16, false>), grid, dim3(256), 0, as_stream(stream), a);
   else return TGSR_EINVAL;
   return note_launch(hipGetLastError(), "lp_stem_kernel");
+}
+
+extern "C" int tgsr_lp_stem_fwd(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
+                                const float* shift, void* out, int out_cpitch, int out_coff, void* stream) {
+  return lp_stem_launch(dtype, x, B, H, W, w, C, scale, shift, out, out_cpitch, out_coff, nullptr, stream);
+}
+
+extern "C" int tgsr_lp_stem_att_fwd(int dtype, const float* x, int B, int H, int W, const float* w, int C, const float* scale,
+                                    const float* shift, void* out, int out_cpitch, int out_coff, const void* att_pack,
+                                    int att_nsets, int att_set, int use_mask, int mask_mode, int T, int c_coff, float* attn,
+                                    void* stream) {
+  LpAttFuse f;
+  const int rc = lp_att_fuse(att_pack, att_nsets, att_set, B, use_mask, mask_mode, T, c_coff, attn, &f);
+  if (rc) return rc;
+  return lp_stem_launch(dtype, x, B, H, W, w, C, scale, shift, out, out_cpitch, out_coff, &f, stream);
 }
 
 extern "C" int tgsr_lp_pack_to3_weight(int dtype, const float* w, void* wpack, int Cin, int K, void* stream) {

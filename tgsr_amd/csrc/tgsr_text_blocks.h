@@ -15,7 +15,18 @@ struct ProjArgs {
   const float* w[4];
   float* out;            // [nsets][B][idf][32]
   int B, idf, cdf, T;
+  // optional (idf == 32 only): the same projections rounded to a 2-byte type and laid out as the four MFMA 32x32x16 A
+  // fragments the reduced-precision attention consumes ([nsets][B][4 fragments][64 lanes][8], tgsr_lp_misc.hip): fragments
+  // 0, 1 = scores GEMM (row = word t, k = channel 16 f + 8 (lane >> 5) + j), 2, 3 = context GEMM (row = channel, k = word
+  // 16 (f - 2) + 8 (j >> 2) + 4 (lane >> 5) + (j & 3): the order the softmax leaves in the accumulator registers).  A
+  // kernel that attends in its epilogue (lp_stem_kernel, lp_upconv_glu_kernel) loads them with one 16-byte load per lane.
+  unsigned short* frag = nullptr;
+  int frag_dt = 0;       // TGSR_DT_BF16 | TGSR_DT_F16
 };
+
+__device__ __forceinline__ unsigned short lp_round_one(float v, int dt) {
+  return dt == TGSR_DT_BF16 ? __builtin_bit_cast(unsigned short, (__bf16)v) : __builtin_bit_cast(unsigned short, (_Float16)v);
+}
 
 constexpr int kProjRedFloats = 4 * 16 * 64;
 
@@ -50,6 +61,13 @@ __device__ __forceinline__ void word_project_block(const ProjArgs& a, int b, int
     const int o = tid + 256 * j, r = o >> 6, ln = o & 63;
     const float v = red[0][r][ln] + red[1][r][ln] + red[2][r][ln] + red[3][r][ln];
     ob[acc_row(r, ln >> 5) * 32 + (ln & 31)] = v;
+    if (a.frag) {                                             // idf == 32 (checked by the launcher): ib == 0
+      const int i = acc_row(r, ln >> 5), t = ln & 31;
+      unsigned short* fb = a.frag + (int64_t)(set * a.B + b) * (4 * 64 * 8);
+      const unsigned short q = lp_round_one(v, a.frag_dt);
+      fb[(((i >> 4) * 64 + ((i >> 3) & 1) * 32 + t) << 3) + (i & 7)] = q;
+      fb[(((2 + (t >> 4)) * 64 + ((t >> 2) & 1) * 32 + i) << 3) + 4 * ((t >> 3) & 1) + (t & 3)] = q;
+    }
   }
 }
 

@@ -16,6 +16,7 @@ struct TextTailArgs {
   CaArgs c;
   const int64_t* captions;   // [B][width]
   uint8_t* mask;             // [B][T]
+  uint32_t* mbits;           // [B] or null: bit t = (captions[b][t] == 0), t < T  (the packed form the fused attention reads)
   int width, nsets, nib, nproj, nca_i, nca;
 };
 
@@ -38,16 +39,22 @@ __global__ __launch_bounds__(256) void text_tail_kernel(TextTailArgs a) {
     const int b = o / a.p.T, t = o - b * a.p.T;
     a.mask[o] = a.captions[(int64_t)b * a.width + t] == 0 ? 1 : 0;
   }
+  if (a.mbits)
+    for (int b = threadIdx.x; b < a.p.B; b += 256) {
+      uint32_t m = 0;
+      for (int t = 0; t < a.p.T; ++t) m |= (a.captions[(int64_t)b * a.width + t] == 0 ? 1u : 0u) << t;
+      a.mbits[b] = m;
+    }
 }
 
 }  // namespace tgsr
 
 using namespace tgsr;
 
-extern "C" int tgsr_text_tail_fwd(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf, int T,
-                                  float* src_out, const float* sent_emb, const float* ca_w, const float* ca_b, int tdim,
-                                  int ncf, float* mu, float* logvar, const int64_t* captions, int width, uint8_t* mask,
-                                  void* stream) {
+static int text_tail_launch(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf, int T,
+                            float* src_out, const float* sent_emb, const float* ca_w, const float* ca_b, int tdim,
+                            int ncf, float* mu, float* logvar, const int64_t* captions, int width, uint8_t* mask,
+                            int lp_dtype, void* att_pack, void* stream) {
   if (!words || !w_ctx || !src_out || !sent_emb || !ca_w || !ca_b || !mu || !logvar || !captions || !mask || nsets < 1 ||
       B < 1 || cdf < 1 || T < 1 || tdim < 1 || ncf < 1 || width < T)
     return TGSR_EINVAL;
@@ -63,8 +70,35 @@ extern "C" int tgsr_text_tail_fwd(const float* words, const float* const* w_ctx,
   a.c.sent = sent_emb; a.c.w = ca_w; a.c.bias = ca_b; a.c.eps = nullptr; a.c.c_code = nullptr; a.c.mu = mu;
   a.c.logvar = logvar; a.c.B = B; a.c.tdim = tdim; a.c.ncf = ncf;
   a.captions = captions; a.mask = mask; a.width = width;
+  a.mbits = nullptr;
+  if (att_pack) {
+    if (idf != 32 || (lp_dtype != TGSR_DT_BF16 && lp_dtype != TGSR_DT_F16) || (reinterpret_cast<uintptr_t>(att_pack) & 15))
+      return TGSR_EUNSUPPORTED;
+    a.p.frag = static_cast<unsigned short*>(att_pack);
+    a.p.frag_dt = lp_dtype;
+    a.mbits = reinterpret_cast<uint32_t*>(static_cast<char*>(att_pack) + (size_t)nsets * B * 4096);
+  }
   a.nsets = nsets; a.nib = idf / 32; a.nproj = B * nsets * a.nib;
   a.nca_i = (ncf + 3) / 4; a.nca = a.nca_i * ((B + 15) / 16);
   hipLaunchKernelGGL(text_tail_kernel, dim3(a.nproj + a.nca + 1), dim3(256), 0, as_stream(stream), a);
   return note_launch(hipGetLastError(), "text_tail_kernel");
+}
+
+extern "C" int tgsr_text_tail_fwd(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf, int T,
+                                  float* src_out, const float* sent_emb, const float* ca_w, const float* ca_b, int tdim,
+                                  int ncf, float* mu, float* logvar, const int64_t* captions, int width, uint8_t* mask,
+                                  void* stream) {
+  return text_tail_launch(words, w_ctx, nsets, B, idf, cdf, T, src_out, sent_emb, ca_w, ca_b, tdim, ncf, mu, logvar, captions,
+                          width, mask, 0, nullptr, stream);
+}
+
+extern "C" int64_t tgsr_lp_att_pack_bytes(int nsets, int B) { return (int64_t)nsets * B * 4096 + 4 * (int64_t)B; }
+
+extern "C" int tgsr_text_tail_lp_fwd(const float* words, const float* const* w_ctx, int nsets, int B, int idf, int cdf, int T,
+                                     float* src_out, const float* sent_emb, const float* ca_w, const float* ca_b, int tdim,
+                                     int ncf, float* mu, float* logvar, const int64_t* captions, int width, uint8_t* mask,
+                                     int lp_dtype, void* att_pack, void* stream) {
+  if (!att_pack) return TGSR_EINVAL;
+  return text_tail_launch(words, w_ctx, nsets, B, idf, cdf, T, src_out, sent_emb, ca_w, ca_b, tdim, ncf, mu, logvar, captions,
+                          width, mask, lp_dtype, att_pack, stream);
 }

@@ -401,6 +401,17 @@ text_tail = _define("text_tail(Tensor words, Tensor[] w_ctxs, Tensor sent_emb, T
                     (words.new_empty(len(ws), words.shape[0], ws[0].shape[0], 32), words.new_empty(words.shape[0], ncf),
                      words.new_empty(words.shape[0], ncf),
                      words.new_empty(words.shape[0], words.shape[2], dtype=torch.uint8)))
+# ... and, for the reduced-precision generators, the `att_pack` their attention-fused kernels read (bool bf16: else f16)
+text_tail_lp = _define("text_tail_lp(Tensor words, Tensor[] w_ctxs, Tensor sent_emb, Tensor ca_w, Tensor ca_b, int ncf, "
+                       "Tensor captions, bool bf16) -> (Tensor, Tensor, Tensor, Tensor, Tensor)",
+                       lambda words, ws, sent, cw, cb, ncf, cap, bf16:
+                       ops.text_tail(words, list(ws), sent, cw, cb, ncf, cap,
+                                     lp_dtype=torch.bfloat16 if bf16 else torch.float16),
+                       lambda words, ws, sent, cw, cb, ncf, cap, bf16:
+                       (words.new_empty(len(ws), words.shape[0], ws[0].shape[0], 32), words.new_empty(words.shape[0], ncf),
+                        words.new_empty(words.shape[0], ncf),
+                        words.new_empty(words.shape[0], words.shape[2], dtype=torch.uint8),
+                        words.new_empty(len(ws) * words.shape[0] * 4096 + 4 * words.shape[0], dtype=torch.uint8)))
 multi_copy = _define("multi_copy(Tensor(a!)[] dsts, Tensor[] srcs) -> ()",
                      lambda dsts, srcs: ops.multi_copy(list(dsts), list(srcs)), lambda dsts, srcs: None)
 to_uint8 = _define("to_uint8(Tensor img) -> Tensor", lambda x: ops.to_uint8(x), lambda x: torch.empty_like(x, dtype=torch.uint8))
@@ -429,6 +440,33 @@ lp_upconv_glu_head = _define("lp_upconv_glu_head(Tensor x, Tensor wpack, int cin
                                                     write_out=out is not None), None)[1], lambda *a: None)
 lp_stem = _define("lp_stem(Tensor x, Tensor w, Tensor scale, Tensor shift, Tensor(a!) out, int out_coff) -> ()",
                   lambda x, w, s, t, out, oco: (_lp().stem(x, w, s, t, out=out, out_coff=oco), None)[1], lambda *a: None)
+
+
+
+def _att(pack, nsets, index, T, use_mask, correct_mask, c_coff, attn):
+    return _lp().AttFuse(pack, nsets, index, T, use_mask, correct_mask, c_coff, attn)
+
+
+# the producers of h that also attend to the words for the pixels they have just computed (GlobalAttention.py:87-130 at
+# util.py:768-771 / 814-817): att_pack = text_tail_lp's fifth output, index = which projection the stage attends through
+_ATT_SCHEMA = "Tensor att_pack, int nsets, int index, int T, bool use_mask, bool correct_mask, int c_coff"
+lp_stem_att = _define("lp_stem_att(Tensor x, Tensor w, Tensor scale, Tensor shift, Tensor(a!) out, int out_coff, " + _ATT_SCHEMA +
+                      ", Tensor(b!)? attn) -> ()",
+                      lambda x, w, s, t, out, oco, pack, ns, ix, T, um, cm, cco, attn:
+                      (_lp().stem(x, w, s, t, out=out, out_coff=oco, att=_att(pack, ns, ix, T, um, cm, cco, attn)), None)[1],
+                      lambda *a: None)
+lp_upconv_glu_att = _define("lp_upconv_glu_att(Tensor x, Tensor wpack, int cin, int cout, Tensor? scale, Tensor? shift, "
+                            "Tensor(a!) out, int out_coff, " + _ATT_SCHEMA + ", Tensor(b!)? attn) -> ()",
+                            lambda x, wp, cin, cout, s, t, out, oco, pack, ns, ix, T, um, cm, cco, attn:
+                            (_lp().upconv_glu(x, wp, cin, cout, s, t, out=out, out_coff=oco,
+                                              att=_att(pack, ns, ix, T, um, cm, cco, attn)), None)[1], lambda *a: None)
+lp_upconv_glu_head_att = _define("lp_upconv_glu_head_att(Tensor x, Tensor wpack, int cin, int cout, Tensor? scale, Tensor? shift, "
+                                 "Tensor head_wpack, int K, Tensor(a!) partial, Tensor(b!) out, int out_coff, " + _ATT_SCHEMA +
+                                 ", Tensor(c!)? attn) -> ()",
+                                 lambda x, wp, cin, cout, s, t, hw, K, part, out, oco, pack, ns, ix, T, um, cm, cco, attn:
+                                 (_lp().upconv_glu_head(x, wp, cin, cout, s, t, hw, K, partial=part, out=out, out_coff=oco,
+                                                        att=_att(pack, ns, ix, T, um, cm, cco, attn)), None)[1],
+                                 lambda *a: None)
 lp_convert = _define("lp_convert(Tensor src, Tensor(a!) out) -> ()", lambda src, out: (_lp().convert(src, out), None)[1],
                      lambda *a: None)
 lp_conv_to3 = _define("lp_conv_to3(Tensor x, Tensor wpack, int K, bool tanh_axpy, Tensor? addend, float alpha) -> Tensor",

@@ -127,10 +127,43 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, sh
     return out
 
 
+class AttFuse:
+    """Arguments of a word attention fused into the kernel that produces h (tgsr_lp_stem_att_fwd,
+    tgsr_lp_upconv_glu_att_fwd): pack / nsets = ops.text_tail(..., lp_dtype)'s att_pack of this batch, `index` = which
+    projection the stage attends through, T words, use_mask / correct_mask as lp.word_attention, c_coff = first channel of
+    c_code in the producer's output image, attn = fp32 [B, T, H, W] attention maps to fill (or None)."""
+
+    def __init__(self, pack, nsets, index, T, use_mask, correct_mask, c_coff, attn):
+        self.pack, self.nsets, self.index, self.T = pack, int(nsets), int(index), int(T)
+        self.use_mask, self.correct_mask, self.c_coff, self.attn = bool(use_mask), bool(correct_mask), int(c_coff), attn
+
+    def check(self, B, H, W, dtype):
+        if self.pack.dtype != torch.uint8 or self.pack.numel() != _lib.lib().tgsr_lp_att_pack_bytes(self.nsets, B):
+            raise TgsrError("fused attention: att_pack of %d bytes does not fit %d projections of a batch of %d"
+                            % (self.pack.numel(), self.nsets, B))
+        if self.attn is not None and (tuple(self.attn.shape) != (B, self.T, H, W) or self.attn.dtype != torch.float32 or
+                                      not self.attn.is_contiguous()):
+            raise TgsrError("fused attention: attn %s, expected %s" % (tuple(self.attn.shape), (B, self.T, H, W)))
+
+    def args(self):
+        return (_p(self.pack), self.nsets, self.index, 1 if self.use_mask else 0, 1 if self.correct_mask else 0, self.T,
+                self.c_coff, _p(self.attn))
+
+
+def _att_profile(att, B, H, W, e0):
+    """The fused attention is accounted under its own name (zero-duration marker: its time is inside the producer's)."""
+    from . import ops
+    if ops.profile is not None and att is not None:
+        nbytes = B * H * W * (2 * 32 + (4 * att.T if att.attn is not None else 0))       # h comes from LDS: c_code + attn only
+        ops.profile.append(("lp_attention_fused", 4.0 * B * H * W * 32 * att.T, nbytes, e0, e0))
+
+
 def stem(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, dtype=None,
-         out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cpitch: Optional[int] = None) -> torch.Tensor:
-    """conv3x3 3 -> 2C + affine + GLU from the fp32 NCHW image into C channels of an lp image (tgsr_lp_stem_fwd)."""
-    _need_hip(x, w, scale, shift, out)
+         out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cpitch: Optional[int] = None,
+         att: Optional[AttFuse] = None) -> torch.Tensor:
+    """conv3x3 3 -> 2C + affine + GLU from the fp32 NCHW image into C channels of an lp image (tgsr_lp_stem_fwd);
+    att: + the first stage's word attention on those channels in the same launch (tgsr_lp_stem_att_fwd)."""
+    _need_hip(x, w, scale, shift, out, *(() if att is None else (att.pack, att.attn)))
     x = x.contiguous()
     w = w.detach().contiguous()
     if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or tuple(w.shape[1:]) != (3, 3, 3):
@@ -142,6 +175,14 @@ def stem(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Ten
     ob, oh, ow, ocp = _img(out, "out")
     if (ob, oh, ow) != (B, H, W):
         raise TgsrError("lp.stem: out %s" % (tuple(out.shape),))
+    if att is not None:
+        att.check(B, H, W, out.dtype)
+        from . import ops
+        e0 = ops._ev() if ops.profile is not None else None
+        check(_lib.lib().tgsr_lp_stem_att_fwd(DT[out.dtype], _p(x), B, H, W, _p(w), C, _p(scale), _p(shift), _p(out), ocp,
+                                              out_coff, *att.args(), _stream()), "tgsr_lp_stem_att_fwd")
+        _att_profile(att, B, H, W, e0)
+        return out
     check(_lib.lib().tgsr_lp_stem_fwd(DT[out.dtype], _p(x), B, H, W, _p(w), C, _p(scale), _p(shift), _p(out), ocp,
                                       out_coff, _stream()), "tgsr_lp_stem_fwd")
     return out
@@ -230,9 +271,11 @@ def upconv_supported(cin: int, cout: int, Hi: int, Wi: int) -> bool:
 
 
 def upconv_glu(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, shift,
-               out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cpitch: Optional[int] = None) -> torch.Tensor:
-    """upBlock (Upsample x2 -> conv3x3 -> affine -> GLU) on lp images by sub-pixel decomposition, one launch."""
-    _need_hip(x, wpack, scale, shift, out)
+               out: Optional[torch.Tensor] = None, out_coff: int = 0, out_cpitch: Optional[int] = None,
+               att: Optional[AttFuse] = None) -> torch.Tensor:
+    """upBlock (Upsample x2 -> conv3x3 -> affine -> GLU) on lp images by sub-pixel decomposition, one launch;
+    att: + the NEXT stage's word attention on the output tile (tgsr_lp_upconv_glu_att_fwd)."""
+    _need_hip(x, wpack, scale, shift, out, *(() if att is None else (att.pack, att.attn)))
     B, Hi, Wi, xcp = _img(x, "x")
     co = cout // 2
     if out is None:
@@ -245,12 +288,19 @@ def upconv_glu(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale,
                         % (cout, cin, xcp, wpack.numel()))
     from . import ops
     e0 = ops._ev() if ops.profile is not None else None
-    rc = _lib.lib().tgsr_lp_upconv_glu_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift),
-                                           _p(out), ocp, out_coff, _stream())
-    check(rc, "tgsr_lp_upconv_glu_fwd")
+    if att is not None:
+        att.check(B, 2 * Hi, 2 * Wi, x.dtype)
+        rc = _lib.lib().tgsr_lp_upconv_glu_att_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale),
+                                                   _p(shift), _p(out), ocp, out_coff, None, 0, None, *att.args(), _stream())
+        check(rc, "tgsr_lp_upconv_glu_att_fwd")
+    else:
+        rc = _lib.lib().tgsr_lp_upconv_glu_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift),
+                                               _p(out), ocp, out_coff, _stream())
+        check(rc, "tgsr_lp_upconv_glu_fwd")
     if ops.profile is not None:
         nbytes = 2 * (B * cin * Hi * Wi + B * co * 4 * Hi * Wi + cout * cin * 16)
         ops.profile.append(("lp_upconv_glu_kernel", 2.0 * B * 4 * Hi * Wi * cout * cin * 9, nbytes, e0, ops._ev()))
+        _att_profile(att, B, 2 * Hi, 2 * Wi, e0)
     return out
 
 
@@ -266,10 +316,11 @@ def head_fusable(cin: int, cout: int, Hi: int, Wi: int) -> bool:
 
 def upconv_glu_head(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, shift, head_wpack: torch.Tensor,
                     K: int, partial: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                    out_coff: int = 0, write_out: bool = True):
+                    out_coff: int = 0, write_out: bool = True, att: Optional[AttFuse] = None):
     """upBlock + the image head reading it, one launch: returns (out lp image or None, partial head sums fp32).  With
-    write_out=False the 32-channel feature image is not written at all (its only consumer is the head)."""
-    _need_hip(x, wpack, scale, shift, head_wpack, partial, out)
+    write_out=False the 32-channel feature image is not written at all (its only consumer is the head).
+    att (K == 3, the image is written): + the NEXT stage's word attention on the output tile, same launch."""
+    _need_hip(x, wpack, scale, shift, head_wpack, partial, out, *(() if att is None else (att.pack, att.attn)))
     B, Hi, Wi, xcp = _img(x, "x")
     L = _lib.lib()
     n = L.tgsr_lp_head_partial_elems(B, 2 * Hi, 2 * Wi, K)
@@ -291,14 +342,23 @@ def upconv_glu_head(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, s
                         % (xcp, wpack.numel(), head_wpack.numel()))
     from . import ops
     e0 = ops._ev() if ops.profile is not None else None
-    rc = L.tgsr_lp_upconv_glu_head_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift), _p(out),
-                                       ocp, out_coff, _p(head_wpack), K, _p(partial), _stream())
-    check(rc, "tgsr_lp_upconv_glu_head_fwd")
+    if att is not None:
+        if not write_out or K != 3:
+            raise TgsrError("lp.upconv_glu_head: a fused attention needs the feature image written and the 3x3 head")
+        att.check(B, 2 * Hi, 2 * Wi, x.dtype)
+        rc = L.tgsr_lp_upconv_glu_att_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift),
+                                          _p(out), ocp, out_coff, _p(head_wpack), K, _p(partial), *att.args(), _stream())
+        check(rc, "tgsr_lp_upconv_glu_att_fwd")
+    else:
+        rc = L.tgsr_lp_upconv_glu_head_fwd(DT[x.dtype], _p(x), xcp, B, cin, Hi, Wi, _p(wpack), cout, _p(scale), _p(shift),
+                                           _p(out), ocp, out_coff, _p(head_wpack), K, _p(partial), _stream())
+        check(rc, "tgsr_lp_upconv_glu_head_fwd")
     if ops.profile is not None:
         co = cout // 2
         nbytes = 2 * (B * cin * Hi * Wi + (B * co * 4 * Hi * Wi if write_out else 0) + cout * cin * 16) + 4 * n
         flops = 2.0 * B * 4 * Hi * Wi * (cout * cin * 9 + 3 * co * K * K)
         ops.profile.append(("lp_upconv_glu_kernel", flops, nbytes, e0, ops._ev()))
+        _att_profile(att, B, 2 * Hi, 2 * Wi, e0)
     return out, partial
 
 

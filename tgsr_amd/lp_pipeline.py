@@ -31,6 +31,10 @@ FUSE_HEADS = os.environ.get("TGSR_LP_FUSE_HEADS", "1") != "0"
 # One tgsr_lp_convert launch (a 1.2 MB image at batch 16) hands the trunk's output to the bf16 up-scales.
 # TGSR_LP_BF16_TRUNK=bf16 keeps the trunk in bf16 (A/B).
 F16_TRUNK = os.environ.get("TGSR_LP_BF16_TRUNK", "f16") != "bf16"
+# the word attention of every stage computed in the epilogue of the kernel that produces its h (lp_stem_kernel for stage 1,
+# the previous stage's lp_upconv_glu_kernel for the others; same device function as the stand-alone kernel: same bits):
+# three launches - and the re-read of h - leave G_SR_NET_low's dependent chain.  TGSR_LP_FUSE_ATT=0: stand-alone launches.
+FUSE_ATT = os.environ.get("TGSR_LP_FUSE_ATT", "1") != "0"
 
 
 def trunk_dtype_of(dtype):
@@ -61,19 +65,29 @@ class _UpConv:
         self.wpack = lp.pack_conv3x3_weight(conv.weight, dtype)
         self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
-    def __call__(self, x, out):
-        if self.sub and lp.upconv_supported(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2):
+    def __call__(self, x, out, att=None):
+        if att is not None:
+            C.lp_upconv_glu_att(x, self.wsub, self.cin, self.cout, self.scale, self.shift, out, 0, *att)
+        elif self.sub and lp.upconv_supported(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2):
             C.lp_upconv_glu(x, self.wsub, self.cin, self.cout, self.scale, self.shift, out, 0)
         else:
             C.lp_conv3x3(x, self.wpack, self.cin, self.cout, self.scale, self.shift, True, True, None, 0, out, 0)
         return out
 
+    def att_fusable(self, x):
+        """The next stage's attention can ride this upBlock's epilogue: the sub-pixel kernel at 64 input channels."""
+        return self.sub and self.cin == 64 and lp.upconv_supported(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2)
+
     def fusable(self, x):
         return FUSE_HEADS and self.sub and lp.head_fusable(self.cin, self.cout, x.shape[1] - 2, x.shape[2] - 2)
 
-    def with_head(self, x, head_wpack, K, partial, out):
+    def with_head(self, x, head_wpack, K, partial, out, att=None):
         """upBlock + its image head's partial sums in one launch; out None: the feature image is not written."""
-        C.lp_upconv_glu_head(x, self.wsub, self.cin, self.cout, self.scale, self.shift, head_wpack, K, partial, out, 0)
+        if att is not None:
+            C.lp_upconv_glu_head_att(x, self.wsub, self.cin, self.cout, self.scale, self.shift, head_wpack, K, partial, out, 0,
+                                     *att)
+        else:
+            C.lp_upconv_glu_head(x, self.wsub, self.cin, self.cout, self.scale, self.shift, head_wpack, K, partial, out, 0)
         return out, partial
 
 
@@ -83,8 +97,12 @@ class _Stem:
         self.w = conv.weight.detach().contiguous()
         self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
-    def __call__(self, x, out, out_coff=0):
-        C.lp_stem(x, self.w, self.scale, self.shift, out, out_coff)
+    def __call__(self, x, out, out_coff=0, att=None):
+        """att = (att_pack, nsets, index, T, use_mask, correct_mask, c_coff, attn): + the first stage's word attention."""
+        if att is not None:
+            C.lp_stem_att(x, self.w, self.scale, self.shift, out, out_coff, *att)
+        else:
+            C.lp_stem(x, self.w, self.scale, self.shift, out, out_coff)
         return out
 
 
@@ -95,6 +113,7 @@ class LpExecutor:
         self.key = None
         self.bufs = {}
         self.force_bufs = None       # set by a hipGraph capture: the buffer set the captured step is bound to
+        self.fuse_attention = FUSE_ATT
 
     # ------------------------------------------------------------------ weights
     def _params_key(self):
@@ -184,30 +203,46 @@ class LpExecutor:
         atts_m = GL.attention_modules()                                        # distinct attention modules (x16: two)
         if proj is None:
             proj = C.word_project(word_embs, [m.conv_context.weight.detach() for m in atts_m])
-        srcs = [proj[[i for i, m in enumerate(atts_m) if m is st["att"]][0]] for st in self.gl_stage]
+        set_of = [[i for i, m in enumerate(atts_m) if m is st["att"]][0] for st in self.gl_stage]
+        srcs = [proj[i] for i in set_of]
         last = len(self.gl_stage) - 1
         fake, atts, pend = [], [], []
         wide = bufs["gl"][0]["wide"]
-        self.gl_stem(LR, out=wide)                                             # im2f -> channels [0, 32)
+        B, H0, W0 = LR.shape[0], LR.shape[2], LR.shape[3]
+        # The attention of stage k rides the kernel that produces its h when the step brought the attention pack
+        # (SRPipeline._text_tail -> proj.att_pack) and the shapes allow: att_args(k, attn) = the producer's extra arguments
+        pack = getattr(proj, "att_pack", None) if self.fuse_attention else None
+
+        def att_args(k):
+            H, W = H0 << k, W0 << k
+            atts.append(torch.empty(B, T, H, W, dtype=torch.float32, device=LR.device))
+            return (pack, len(atts_m), set_of[k], T, mask is not None, bool(self.gl_stage[k]["att"].correct_mask), 32, atts[-1])
+
+        fused_next = pack is not None and W0 % 32 == 0                         # stage 0: inside the stem
+        self.gl_stem(LR, out=wide, att=att_args(0) if fused_next else None)    # im2f -> channels [0, 32) (+ c_code -> [32, 64))
         for k, st in enumerate(self.gl_stage):
             bb = bufs["gl"][k]
-            atts.append(C.lp_word_attention(bb["wide"], srcs[k], mask, T, st["att"].correct_mask, 32))
+            if not fused_next:
+                atts.append(C.lp_word_attention(bb["wide"], srcs[k], mask, T, st["att"].correct_mask, 32))
             x = bb["wide"]
             for (c0, c1), o in zip(st["res"], (bb["a"], bb["b"])):             # R_NUM = 2 ResBlocks (util.py:110-130)
                 c0(x, glu=True, out=bb["tmp"])
                 c1(bb["tmp"], residual=x, out=o)
                 x = o
             nxt = bufs["gl"][k + 1]["wide"] if k < last else bufs["h3"]
+            # the NEXT stage's attention inside this upBlock (its output is that stage's h)
+            fused_next = pack is not None and k < last and st["up"].att_fusable(x)
             if st["up"].fusable(x):
                 # upBlock + the partial sums of its 3x3 head; the last stage's feature image is read by nothing else
-                B, Ho, Wo = x.shape[0], 2 * (x.shape[1] - 2), 2 * (x.shape[2] - 2)
+                Ho, Wo = 2 * (x.shape[1] - 2), 2 * (x.shape[2] - 2)
                 if bufs["pl"][k] is None:
                     bufs["pl"][k] = torch.empty(lp.head_partial_elems(B, Ho, Wo, 3), dtype=torch.float32, device=x.device)
-                st["up"].with_head(x, st["head"], 3, bufs["pl"][k], nxt if k < last else None)
+                st["up"].with_head(x, st["head"], 3, bufs["pl"][k], nxt if k < last else None,
+                                   att=att_args(k + 1) if fused_next else None)
                 fake.append(torch.empty(B, 3, Ho, Wo, dtype=torch.float32, device=x.device))
                 pend.append(bufs["pl"][k])
             else:
-                st["up"](x, out=nxt)                                           # upBlock -> channels [0, 32) of the next stage
+                st["up"](x, out=nxt, att=att_args(k + 1) if fused_next else None)   # upBlock -> channels [0, 32) of the next stage
                 fake.append(C.lp_conv_to3(nxt, st["head"], 3, self.gl_head_tanh, None, 0.0))
                 pend.append(None)
         if defer_heads:

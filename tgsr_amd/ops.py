@@ -832,10 +832,13 @@ def ca_net(sent_emb: torch.Tensor, w: torch.Tensor, b: torch.Tensor, ncf: int, e
 
 
 def text_tail(words: torch.Tensor, w_ctxs, sent_emb: torch.Tensor, ca_w: torch.Tensor, ca_b: torch.Tensor, ncf: int,
-              captions: torch.Tensor):
+              captions: torch.Tensor, lp_dtype=None):
     """What an inference step needs between the text encoder and the generator, in one launch (tgsr_text_tail_fwd):
     word_project(words, w_ctxs), CA_NET's (mu, logvar) and mask = (captions[:, :T] == 0).
-    Returns (src [nsets,B,idf,32], mu, logvar, mask uint8 [B,T] - `.view(torch.bool)` is the reference's mask)."""
+    Returns (src [nsets,B,idf,32], mu, logvar, mask uint8 [B,T] - `.view(torch.bool)` is the reference's mask).
+    lp_dtype (torch.bfloat16 | torch.float16; idf == 32): a fifth value, the uint8 buffer `att_pack` of
+    tgsr_text_tail_lp_fwd - the projections as MFMA A fragments of that type + the packed mask rows, which the
+    reduced-precision kernels that attend in their epilogue read (lp.stem / lp.upconv_glu_head with att=...)."""
     import ctypes
     _need_hip(words, sent_emb, ca_w, ca_b, captions, *w_ctxs)
     words = _f32(words, "words").contiguous()
@@ -855,6 +858,14 @@ def text_tail(words: torch.Tensor, w_ctxs, sent_emb: torch.Tensor, ca_w: torch.T
     logvar = torch.empty_like(mu)
     mask = torch.empty(B, T, dtype=torch.uint8, device=words.device)
     ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ws])
+    if lp_dtype is not None:
+        L = _lib.lib()
+        dt = {torch.bfloat16: _lib.DT_BF16, torch.float16: _lib.DT_F16}[lp_dtype]
+        pack = torch.empty(L.tgsr_lp_att_pack_bytes(n, B), dtype=torch.uint8, device=words.device)
+        check(L.tgsr_text_tail_lp_fwd(_p(words), ptrs, n, B, idf, cdf, T, _p(out), _p(x), _p(w), _p(b), x.shape[1], ncf,
+                                      _p(mu), _p(logvar), _p(captions), captions.shape[1], _p(mask), dt, _p(pack), _stream()),
+              "tgsr_text_tail_lp_fwd")
+        return out, mu, logvar, mask, pack
     check(_lib.lib().tgsr_text_tail_fwd(_p(words), ptrs, n, B, idf, cdf, T, _p(out), _p(x), _p(w), _p(b), x.shape[1], ncf,
                                         _p(mu), _p(logvar), _p(captions), captions.shape[1], _p(mask), _stream()),
           "tgsr_text_tail_fwd")

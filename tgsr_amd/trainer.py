@@ -8,6 +8,7 @@ import torch
 
 from .miscc.config import cfg
 from . import custom_ops as C
+from . import ops
 from .model import RNN_ENCODER
 
 
@@ -46,6 +47,15 @@ def crop_words(out, num_words):
     res["mask"] = out["mask"][:, :T]
     res["att"] = [a[:, :T] for a in out["att"]]
     return res
+
+
+class _ProjWithPack(list):
+    """The word projections of a step (a list, one [B, idf, 32] tensor per attention module) that also carry the
+    reduced-precision attention pack of tgsr_text_tail_lp_fwd (`.att_pack`) for LpExecutor.low."""
+
+    def __init__(self, proj, att_pack):
+        super().__init__(proj)
+        self.att_pack = att_pack
 
 
 def _host_lens(cap_lens):
@@ -182,11 +192,22 @@ class SRPipeline:
                 or captions.dtype != torch.int64 or captions.size(1) < T or idf < 32 or idf % 32
                 or any(a.conv_context.out_channels != idf for a in atts)):
             return None, GL.ca_net(sent_emb), caption_mask(captions, T)
-        src, mu, logvar, m8 = C.text_tail(words_embs, [a.conv_context.weight.detach() for a in atts], sent_emb,
-                                          fc.weight.detach(), fc.bias.detach(), GL.ca_net.c_dim, captions)
+        ws = [a.conv_context.weight.detach() for a in atts]
+        pack = None
+        if self._lp is not None and self._lp.fuse_attention and idf == 32:
+            # the reduced-precision generators attend inside the kernels that produce h: the projections also leave as the
+            # MFMA fragments (and the mask as the packed rows) those kernels read
+            src, mu, logvar, m8, pack = C.text_tail_lp(words_embs, ws, sent_emb, fc.weight.detach(), fc.bias.detach(),
+                                                       GL.ca_net.c_dim, captions, self._lp.dtype == torch.bfloat16)
+        else:
+            src, mu, logvar, m8 = C.text_tail(words_embs, ws, sent_emb, fc.weight.detach(), fc.bias.detach(),
+                                              GL.ca_net.c_dim, captions)
         if not torch.cuda.is_current_stream_capturing():
             torch.empty(sent_emb.shape[0], GL.ca_net.c_dim, dtype=torch.float32, device=sent_emb.device).normal_()
-        return list(src.unbind(0)), (None, mu, logvar), m8.view(torch.bool)
+        proj = list(src.unbind(0))
+        if pack is not None:
+            proj = _ProjWithPack(proj, pack)
+        return proj, (None, mu, logvar), m8.view(torch.bool)
 
     def _forward(self, captions, cap_lens, LR, LRb):
         # (the reference passes init_hidden()'s zero state, trainer_objective.py:134; the HIP recurrence starts from zero
@@ -248,8 +269,6 @@ class GraphedStep:
     way eager stream lanes do, without the host cost of ~60 launches per step and without relying on separate graph
     launches overlapping (measured: they do not).  `inputs` / `out` are then lists of length `lanes`."""
 
-    _RING = 8      # pinned staging buffers for host-side length lists (a replay may be enqueued before the previous copy ran)
-
     @torch.no_grad()
     def __init__(self, pipe, captions, cap_lens, LR, LRb, stream=None, warmup=3, lanes=1):
         dev = LR.device
@@ -263,9 +282,6 @@ class GraphedStep:
             lens0 = torch.tensor(host, dtype=torch.int32).to(dev)
             self.num_words = [max(host)] * self.lanes
         sets = [(captions.to(torch.int64).clone(), lens0.clone(), LR.clone(), LRb.clone()) for _ in range(self.lanes)]
-        self._pin = [torch.empty(captions.size(0), dtype=torch.int32).pin_memory() for _ in range(self._RING)]
-        self._pin_ev = [None] * self._RING
-        self._pin_next = 0
         lpx = getattr(pipe, "_lp", None)
         bufs = None
         if lpx is not None:                              # reduced-precision path: every lane is bound to its own set of
@@ -322,7 +338,7 @@ class GraphedStep:
         views of the static outputs cropped to the batch's longest caption: consume them (on `stream`, or after
         synchronising it) before this lane's next replay.
 
-        cap_lens: host list / CPU tensor (staged through pinned memory; T_max = its maximum), or a device int32 / int64
+        cap_lens: host list / CPU tensor (T_max = its maximum; its device copy is cached per length vector), or a device int32 / int64
         tensor (copied on the device; pass `num_words` = the batch's longest caption to have the outputs cropped, else they
         keep the width they had), or None (captions unchanged).  With `lanes` > 1 each argument is a list of `lanes`
         entries (or None: keep the buffers' contents)."""
@@ -331,20 +347,8 @@ class GraphedStep:
                 return self._go(captions, cap_lens, LR, LRb, num_words)
         return self._go(captions, cap_lens, LR, LRb, num_words)
 
-    def _stage_lens(self, host):
-        """A host-side length list -> a pinned int32 buffer of the ring (waits for the copy that last used that buffer)."""
-        i = self._pin_next
-        self._pin_next = (i + 1) % self._RING
-        if self._pin_ev[i] is not None:
-            self._pin_ev[i].synchronize()
-        pin = self._pin[i]
-        if len(host) != pin.numel():
-            raise ValueError("replay: %d caption lengths for a captured batch of %d" % (len(host), pin.numel()))
-        pin.copy_(torch.tensor(host, dtype=torch.int32))
-        return i, pin
-
     def _go(self, captions, cap_lens, LR, LRb, num_words):
-        pairs, h2d = [], []
+        pairs = []
         sets = [self.inputs] if self.lanes == 1 else self.inputs
         one = self.lanes == 1
         for k, dsts in enumerate(sets):
@@ -360,20 +364,19 @@ class GraphedStep:
                     host = _host_lens(ln)
                     if min(host) < 1 or max(host) > dsts[0].size(1):
                         raise ValueError("replay: caption lengths %s outside [1, %d]" % (host, dsts[0].size(1)))
+                    if len(host) != dsts[1].numel():
+                        raise ValueError("replay: %d caption lengths for a captured batch of %d" % (len(host), dsts[1].numel()))
                     self.num_words[k] = max(host) if nw is None else int(nw)
-                    h2d.append((dsts[1], host))
-                    ln = None
+                    # a device copy of this length vector, cached per vector (ops._lens_on_device: one small blocking H2D
+                    # copy the first time a vector is seen, none afterwards); it goes into the static buffer with the
+                    # other inputs by the replay's one copy launch
+                    ln = ops._lens_on_device(tuple(host), dsts[1].device)
             elif nw is not None:
                 self.num_words[k] = int(nw)
             lane = lambda a: a if (one or a is None) else a[k]                 # noqa: E731
             for dst, src in zip(dsts, (lane(captions), ln, lane(LR), lane(LRb))):
                 if src is not None and src is not dst:
                     pairs.append((dst, src))
-        for dst, host in h2d:
-            i, pin = self._stage_lens(host)
-            dst.copy_(pin, non_blocking=True)
-            ev = self._pin_ev[i] = self._pin_ev[i] or torch.cuda.Event()
-            ev.record()
         fast = [(d, s_) for d, s_ in pairs
                 if s_.is_cuda and s_.dtype == d.dtype and s_.shape == d.shape and s_.is_contiguous() and s_.device == d.device]
         if len(fast) == len(pairs):
