@@ -350,7 +350,13 @@ def roofline_objects(agg, nprof, dtype, serial, steps, batch=16):
                                               round(sum(t * c for t, c in ctr) / csec / 1e9 / PEAK_HBM_GBS, 4))}
     kern = {k: {"launches_per_step": v[0] // nprof, "ms_per_step": round(v[3] / nprof * 1e3, 4),
                 "TFLOPs": round(v[1] / v[3] / 1e12, 2), "GBs_algorithmic": round(v[2] / v[3] / 1e9, 1)}
-            for k, v in agg.items()}
+            for k, v in agg.items() if v[3] > 0}
+    if "lp_attention_fused" in agg:      # zero-duration marker: the attention runs inside the kernels that produce h
+        v = agg["lp_attention_fused"]
+        kern["lp_attention_fused"] = {"launches_per_step": 0, "fused_into": ["lp_stem_kernel", "lp_upconv_glu_kernel"],
+                                      "stages_per_step": v[0] // nprof, "GFLOP_per_step": round(v[1] / nprof / 1e9, 3),
+                                      "MB_per_step": round(v[2] / nprof / 1e6, 2),
+                                      "note": "no launch of its own: its time is part of the producers' (h comes from LDS)"}
     att = None
     ak = "lp_word_attention_kernel" if lp else "word_attention_kernel"
     if ak in agg:
@@ -497,6 +503,25 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
                                                              "hbm_frac_algorithmic", "hbm_frac_counter", "avg_launch_us",
                                                              "launches_per_step", "counters_from") if k in roof}
                 entry["conv_path"] = roof["conv_path"]
+                if att is None and pipe._lp.fuse_attention:
+                    # the attention runs inside the producers of h: one more step with the stand-alone launches (same bits)
+                    prof2 = []
+                    pipe._lp.fuse_attention, ops.profile = False, prof2
+                    try:
+                        pipe(cap, lens, LR, LRb)
+                        torch.cuda.synchronize()
+                    finally:
+                        pipe._lp.fuse_attention, ops.profile = True, None
+                    agg2 = {}
+                    for name, flops, nbytes, e0, e1 in prof2:
+                        a = agg2.setdefault(name, [0, 0.0, 0.0, 0.0])
+                        a[0] += 1
+                        a[1] += flops
+                        a[2] += nbytes
+                        a[3] += e0.elapsed_time(e1) * 1e-3
+                    att = roofline_objects(agg2, 1, dtype, True, 1, B)[2]
+                    if att is not None:
+                        att["measured_with"] = "stand-alone attention launches (one extra step); the timed steps fuse it into the producers of h"
                 if att is not None:
                     entry["attention"] = att
             except Exception as e:      # noqa: BLE001
@@ -881,6 +906,31 @@ def main():
             a[2] += nbytes
             a[3] += e0.elapsed_time(e1) * 1e-3
         roof, kern, att = roofline_objects(agg, nprof, args.dtype, args.serial, args.steps, B) if nprof else (None, {}, None)
+        if att is None and nprof and getattr(pipe, "_lp", None) is not None and pipe._lp.fuse_attention:
+            # BASELINE's metric asks for the attention GEMM's MFMA utilisation: in the default route it has no launch of its own,
+            # so ONE extra eager step with the stand-alone attention launches (same arithmetic, same bits) is event-timed
+            try:
+                prof2 = []
+                pipe._lp.fuse_attention, pipe.overlap, ops.profile = False, False, prof2
+                b0 = pool[0]
+                pipe(b0["cap"], b0["lens"], b0["LR"], b0["LRb"])
+                torch.cuda.synchronize()
+                agg2 = {}
+                for name, flops, nbytes, e0, e1 in prof2:
+                    a = agg2.setdefault(name, [0, 0.0, 0.0, 0.0])
+                    a[0] += 1
+                    a[1] += flops
+                    a[2] += nbytes
+                    a[3] += e0.elapsed_time(e1) * 1e-3
+                att = roofline_objects(agg2, 1, args.dtype, True, 1, B)[2]
+                if att is not None:
+                    att["measured_with"] = ("stand-alone attention launches (TGSR_LP_FUSE_ATT=0), one extra step outside the "
+                                            "timed region; the timed steps compute the same arithmetic inside lp_stem_kernel / "
+                                            "lp_upconv_glu_kernel, where it costs no launch and no re-read of h")
+            except Exception as e:       # noqa: BLE001
+                att = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                pipe._lp.fuse_attention, pipe.overlap, ops.profile = True, not args.serial, None
         dname = {"fp32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
         res = {"metric": "SR images/sec (32->%d, batch %d per GPU)" % (512 if x16 else 256, B),
                "value": round(world * B * args.steps / dt, 2),

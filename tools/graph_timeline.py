@@ -5,7 +5,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
 # steps are delimited by the text encoder's recurrent kernel (once per step)
-marks = [i for i, e in enumerate(ev) if "lstm_recurrent_kernel" in e[2]]
+marks = [i for i, e in enumerate(ev) if "lstm_recurrent" in e[2]]
 if len(marks) < 4:
     sys.exit("not enough steps in the trace")
 for a, b in zip(marks[-4:-1], marks[-3:]):
