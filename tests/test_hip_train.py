@@ -30,6 +30,8 @@ CASES = [
     (16, 64, 32, 32, 128, True, False, False),
     (2, 32, 13, 20, 64, True, False, False),     # Winograd-domain wgrad: odd height (partial tiles), 32-channel input
     (1, 64, 5, 40, 64, False, False, True),      # ... several chunks per tile row
+    (3, 32, 11, 24, 32, False, False, True),     # Winograd-domain wgrad of a 32 -> 32 layer (NetG_highweight's ResBlocks), ragged
+    (2, 64, 8, 40, 32, False, False, False),     # ... 64 -> 32: two ci blocks, one co block
 ]
 
 

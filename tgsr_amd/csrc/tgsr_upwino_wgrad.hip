@@ -48,24 +48,85 @@ __global__ __launch_bounds__(128 * NCI) void upwino_wgrad_kernel(UpWgradArgs a) 
 
   const int c_lo = blockIdx.x * a.chunks_per_wg;
   const int c_hi = c_lo + a.chunks_per_wg < a.nchunks ? c_lo + a.chunks_per_wg : a.nchunks;
-  for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+  // Software pipeline (round 4, as tgsr_wino_wgrad.hip): the raw values of the NEXT chunk - the 2x2 output gradients of a
+  // thread's dM items, the 3x3 neighbourhoods of its V items - are fetched into registers right before the MFMAs of the
+  // current chunk, so their latency runs under the matrix work instead of opening every chunk.
+  constexpr int ND = NCO * kUWT / NT, NV = NCIN * kUWT / NT;
+  static_assert(ND * NT == NCO * kUWT && NV * NT == NCIN * kUWT, "items divide evenly");
+  float gd[ND][4], xd[NV][9];
+  // Branch-free (see tgsr_wino_wgrad.hip): unconditional loads from clamped addresses, out-of-image values zeroed by a select;
+  // the row is wave-uniform, only the ends of an image row need a per-lane select.
+  int dpx[ND], vpx[NV];
+  const float* gplane[ND];
+  const float* xplane[NV];
+#pragma unroll
+  for (int n = 0; n < ND; ++n) {
+    const int item = tid + n * NT, c = item / kUWT;
+    dpx[n] = item - c * kUWT;
+    gplane[n] = a.g + (int64_t)(co0 + c < a.Cout ? co0 + c : 0) * HWo;
+  }
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const int item = tid + n * NT, c = item / kUWT;
+    vpx[n] = item - c * kUWT;
+    xplane[n] = a.x + (int64_t)(ci0 + c < a.Cin ? ci0 + c : 0) * HW;
+  }
+  const int Hm1 = a.H - 1, Wm1 = a.W - 1;
+  // validity of the fetched values, applied at transform time (a select here would make the wave wait for its loads at once)
+  unsigned dok[ND], vcm[NV], vrm = 0;
+  auto fetch = [&](int chunk) {
     int t = chunk;
     const int cx = t % a.chunks_x;
     t /= a.chunks_x;
     const int y = t % a.H;
     const int b = t / a.H;
     const int x0 = cx * kUWT;
-    __syncthreads();                          // the previous chunk's MFMAs are done with the LDS images
-    // dM: item = (co, px); dY = 2x2 output gradients of low-res pixel (y, x0 + px)
-    for (int item = tid; item < NCO * kUWT; item += NT) {
-      const int c = item / kUWT, px = item - c * kUWT;
-      const int x = x0 + px;
-      float d00 = 0.f, d01 = 0.f, d10 = 0.f, d11 = 0.f;
-      if (x < a.W && co0 + c < a.Cout) {
-        const float* gp = a.g + ((int64_t)b * a.Cout + co0 + c) * HWo + (int64_t)(2 * y) * Wo + 2 * x;
-        const float2 r0 = *reinterpret_cast<const float2*>(gp), r1 = *reinterpret_cast<const float2*>(gp + Wo);
-        d00 = r0.x; d01 = r0.y; d10 = r1.x; d11 = r1.y;
+    const int64_t gb = (int64_t)b * a.Cout * HWo, xb = (int64_t)b * a.xbs;
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {           // dM item = (co, px): the 2x2 output gradients of low-res pixel (y, x0 + px)
+      const int item = tid + n * NT, c = item / kUWT;
+      const int x = x0 + dpx[n];
+      dok[n] = (x < a.W && co0 + c < a.Cout) ? 1u : 0u;
+      const float* gp = gplane[n] + gb + (int64_t)(2 * y) * Wo + 2 * (x < Wm1 ? x : Wm1);   // 8-byte aligned: Wo, 2x even
+      const float2 r0 = *reinterpret_cast<const float2*>(gp), r1 = *reinterpret_cast<const float2*>(gp + Wo);
+      gd[n][0] = r0.x; gd[n][1] = r0.y; gd[n][2] = r1.x; gd[n][3] = r1.y;
+    }
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {           // V item = (ci, px): the 3x3 neighbourhood of the low-res input
+      const int item = tid + n * NT, c = item / kUWT;
+      const int x = x0 + vpx[n];
+      const bool cok = x < a.W && ci0 + c < a.Cin;
+      int gxc[3];
+      vcm[n] = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int gx = x - 1 + q;
+        vcm[n] |= ((cok && (unsigned)gx < (unsigned)a.W) ? 1u : 0u) << q;
+        gxc[q] = gx < 0 ? 0 : (gx < Wm1 ? gx : Wm1);
       }
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        const int gy = y - 1 + rr;
+        const float* rowp = xplane[n] + xb + (int64_t)(gy < 0 ? 0 : (gy < Hm1 ? gy : Hm1)) * a.W;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xd[n][3 * rr + q] = rowp[gxc[q]];
+      }
+    }
+    vrm = 0;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) vrm |= ((unsigned)(y - 1 + rr) < (unsigned)a.H ? 1u : 0u) << rr;
+  };
+  if (c_lo < c_hi) fetch(c_lo);
+  // (barriers as s_waitcnt lgkmcnt(0) + s_barrier: the release fence of __syncthreads() waits for vmcnt(0) on gfx9 - loads and
+  // stores share the counter - which would park every wave on its own prefetch)
+  for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();             // the previous chunk's MFMAs are done with the LDS images
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      const int item = tid + n * NT, c = item / kUWT, px = item - c * kUWT;
+      const float d00 = dok[n] ? gd[n][0] : 0.f, d01 = dok[n] ? gd[n][1] : 0.f, d10 = dok[n] ? gd[n][2] : 0.f,
+                  d11 = dok[n] ? gd[n][3] : 0.f;
       // rows of A' dY: (d0), (d0 + d1), (-d1);  then the same along the columns
       const float r[3][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {-d10, -d11}};
       float* mp = m_s + c * kUWP + px;
@@ -76,26 +137,17 @@ __global__ __launch_bounds__(128 * NCI) void upwino_wgrad_kernel(UpWgradArgs a) 
         mp[(i * 3 + 2) * NCO * kUWP] = -r[i][1];
       }
     }
-    // V: item = (ci, px); d = 3x3 neighbourhood of the low-res input
-    for (int item = tid; item < NCIN * kUWT; item += NT) {
-      const int c = item / kUWT, px = item - c * kUWT;
-      const int x = x0 + px;
-      float d[3][3];
-      const bool cok = x < a.W && ci0 + c < a.Cin;
-      const float* xp = a.x + (int64_t)b * a.xbs + (int64_t)(ci0 + c) * HW;
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
+    for (int n = 0; n < NV; ++n) {
+      const int item = tid + n * NT, c = item / kUWT, px = item - c * kUWT;
+      float d[9], tr[3][3];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int gy = y - 1 + rr, gx = x - 1 + q;
-          d[rr][q] = (cok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? xp[(int64_t)gy * a.W + gx] : 0.f;
-        }
-      float tr[3][3];
+      for (int e = 0; e < 9; ++e) d[e] = (((vrm >> (e / 3)) & 1u) && ((vcm[n] >> (e % 3)) & 1u)) ? xd[n][e] : 0.f;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        tr[0][q] = d[0][q] - d[1][q];
-        tr[1][q] = d[1][q];
-        tr[2][q] = d[1][q] - d[2][q];
+        tr[0][q] = d[q] - d[3 + q];
+        tr[1][q] = d[3 + q];
+        tr[2][q] = d[3 + q] - d[6 + q];
       }
       float* vp = v_s + c * kUWP + px;
 #pragma unroll
@@ -105,7 +157,9 @@ __global__ __launch_bounds__(128 * NCI) void upwino_wgrad_kernel(UpWgradArgs a) 
         vp[(i * 3 + 2) * NCIN * kUWP] = tr[i][1] - tr[i][2];
       }
     }
-    __syncthreads();
+    if (chunk + 1 < c_hi) fetch(chunk + 1);   // in flight under this chunk's MFMAs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     const float* mw = m_s + (cob * 32 + l31) * kUWP + hh;
     const float* vw = v_s + (cib * 32 + l31) * kUWP + hh;
 #pragma unroll

@@ -5,7 +5,7 @@
 // and dW = G^T dU G afterwards: 16 products per tile and channel pair instead of 36 (9 taps x 4 pixels) - 2.25x fewer
 // multiplies than tgsr_conv3x3_wgrad.hip.  fp32 throughout; the transforms only add / subtract, G holds {0, 1, +-1/2}.
 //
-// GEMM view per position: M = co, N = ci, K = tiles.  Workgroup = 2 co blocks x NCI ci blocks x 2 position halves of
+// GEMM view per position: M = co, N = ci, K = tiles.  Workgroup = NCOB co blocks x NCI ci blocks x 2 position halves of
 // waves, wave = (32 co, 32 ci, 8 positions) = 8 MFMA 32x32x2 accumulators (128 VGPRs); it walks over chunks of 8
 // consecutive tiles of one tile row: every thread transforms one (co, tile) item of dM and one (ci, tile) item of V
 // straight from global memory into LDS images [p][channel][8 tiles] (pitch 9), then 8 x 4 MFMAs per wave consume the
@@ -26,14 +26,25 @@ struct WinoWgradArgs {
 
 constexpr int kWWT = 8, kWWP = kWWT + 1;    // tiles per chunk, LDS pitch
 
-template <int NCI>
-__global__ __launch_bounds__(256 * NCI) void wino_wgrad_kernel(WinoWgradArgs a) {
-  constexpr int NT = 256 * NCI, NCO = 64, NCIN = 32 * NCI;
-  __shared__ float m_s[16 * NCO * kWWP];     // dM [p][co][tile]
-  __shared__ float v_s[16 * NCIN * kWWP];    // V  [p][ci][tile]
+// NCOB = 32-channel co blocks per workgroup (2: Cout % 64 == 0; 1: the 32-channel layers of NetG_highweight - model.py:258-262
+// ResBlock(32), residual24 / 48 - which the direct-form kernel of tgsr_conv3x3_wgrad.hip served at 9 TFLOP/s), NCI = ci blocks.
+// Waves = NCOB x 2 position halves x NCI.
+//
+// Software pipeline (round 4): a chunk's raw values (the 2x2 output gradients of a thread's dM items, the 4x4 input patches
+// of its V items: up to 8 + 32 registers) are fetched one chunk AHEAD, right before the MFMAs of the current chunk, so that
+// their latency runs under the matrix work.  Before, every chunk began with those loads exposed (~2 us of a ~7 us chunk on
+// the 128^2 layers: the kernel sat at 0.24 of the fp32 MFMA peak with its MFMA phases 93 % dense).
+template <int NCI, int NCOB>
+__global__ __launch_bounds__(128 * NCI * NCOB) void wino_wgrad_kernel(WinoWgradArgs a) {
+  constexpr int NT = 128 * NCI * NCOB, NCO = 32 * NCOB, NCIN = 32 * NCI;
+  constexpr int ND = NCO * kWWT / NT, NV = NCIN * kWWT / NT;      // dM / V items per thread (1 or 2)
+  static_assert(ND * NT == NCO * kWWT && NV * NT == NCIN * kWWT, "items divide evenly");
+  constexpr int NBUF = (NCI == 2 && NCOB == 2) ? 2 : 1;   // 8-wave workgroups double-buffer (below); 144 of the CU's 160 KB
+  __shared__ float m_s[NBUF * 16 * NCO * kWWP];     // dM [buffer][p][co][tile]
+  __shared__ float v_s[NBUF * 16 * NCIN * kWWP];    // V  [buffer][p][ci][tile]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cob = wave & 1, ph = (wave >> 1) & 1, cib = wave >> 2;        // co block, position half, ci block
+  const int cob = wave % NCOB, ph = (wave / NCOB) & 1, cib = wave / (2 * NCOB);   // co block, position half, ci block
   const int grp = blockIdx.y;
   const int co0 = (grp / a.cgroups_i) * NCO, ci0 = (grp % a.cgroups_i) * NCIN;
   const int64_t HW = (int64_t)a.H * a.W;
@@ -46,31 +57,88 @@ __global__ __launch_bounds__(256 * NCI) void wino_wgrad_kernel(WinoWgradArgs a) 
 
   const int c_lo = blockIdx.x * a.chunks_per_wg;
   const int c_hi = c_lo + a.chunks_per_wg < a.nchunks ? c_lo + a.chunks_per_wg : a.nchunks;
-  for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+  float gd[ND][4], xd[NV][16];
+  // Branch-free fetch: every load is unconditional from a CLAMPED address, out-of-image values are zeroed by a select.  The
+  // first version wrote `in range ? load : 0` per element: hipcc made each of the 20 loads of a thread its own exec-masked
+  // branch with 64-bit address arithmetic - ~1 200 VALU instructions per wave and chunk, 4.8 k cycles against the 2 k of the
+  // chunk's MFMAs (the kernel's real bound: 0.24-0.37 of the MFMA peak however the phases were overlapped).  Row validity is
+  // wave-uniform (a chunk is one tile row), only the first / last column of an image row needs a per-lane select.
+  int dtl[ND], vtl[NV];
+  const float* gplane[ND];
+  const float* xplane[NV];
+#pragma unroll
+  for (int n = 0; n < ND; ++n) {
+    const int item = tid + n * NT, c = item / kWWT;
+    dtl[n] = item - c * kWWT;
+    gplane[n] = a.g + (int64_t)(co0 + c) * HW;               // Cout % 32 == 0, Cin % 32 == 0 (launcher): every channel exists
+  }
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const int item = tid + n * NT, c = item / kWWT;
+    vtl[n] = item - c * kWWT;
+    xplane[n] = a.x + (int64_t)(ci0 + c) * HW;
+  }
+  const int Hm1 = a.H - 1, Wm1 = a.W - 1;
+  // validity of the fetched values (applied by transform(): a select at fetch time would make the wave wait for its loads
+  // right there instead of under the MFMAs): per-lane column bits, wave-uniform row bits
+  unsigned dcm[ND], vcm[NV], drm = 0, vrm = 0;
+  auto fetch = [&](int chunk) {
     int t = chunk;
     const int cx = t % a.chunks_x;
     t /= a.chunks_x;
     const int ty = t % a.tiles_y;
     const int b = t / a.tiles_y;
     const int y0 = 2 * ty, tx0 = cx * kWWT;
-    __syncthreads();                          // the previous chunk's MFMAs are done with the LDS images
-    // dM: item = (co, tile); dY = the tile's 2x2 output gradients (zero outside the image)
-    for (int item = tid; item < NCO * kWWT; item += NT) {
-      const int c = item / kWWT, tl = item - c * kWWT;
-      const int x = 2 * (tx0 + tl);
-      float d[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-      if (co0 + c < a.Cout) {
-        const float* gp = a.g + ((int64_t)b * a.Cout + co0 + c) * HW;
+    const int64_t gb = (int64_t)b * a.Cout * HW, xb = (int64_t)b * a.xbs;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+    for (int n = 0; n < ND; ++n) {           // dM item = (co, tile): the tile's 2x2 output gradients (zero outside the image)
+      const int x = 2 * (tx0 + dtl[n]);
+      const int xc0 = x < Wm1 ? x : Wm1, xc1 = x + 1 < Wm1 ? x + 1 : Wm1;
+      dcm[n] = (x < a.W ? 1u : 0u) | (x + 1 < a.W ? 2u : 0u);
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-            if (y0 + r < a.H && x + q < a.W) d[r][q] = gp[(int64_t)(y0 + r) * a.W + x + q];
+      for (int r = 0; r < 2; ++r) {
+        const int gy = y0 + r;
+        const float* rowp = gplane[n] + gb + (int64_t)(gy < a.H ? gy : Hm1) * a.W;
+        gd[n][2 * r] = rowp[xc0];
+        gd[n][2 * r + 1] = rowp[xc1];
       }
+    }
+    drm = 1u | (y0 + 1 < a.H ? 2u : 0u);
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {           // V item = (ci, tile): its 4x4 input patch (rows y0-1 .. y0+2, cols x-1 .. x+2)
+      const int x = 2 * (tx0 + vtl[n]);
+      int gxc[4];
+      vcm[n] = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gx = x - 1 + q;
+        vcm[n] |= ((unsigned)gx < (unsigned)a.W ? 1u : 0u) << q;
+        gxc[q] = gx < 0 ? 0 : (gx < Wm1 ? gx : Wm1);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int gy = y0 - 1 + rr;
+        const float* rowp = xplane[n] + xb + (int64_t)(gy < 0 ? 0 : (gy < Hm1 ? gy : Hm1)) * a.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xd[n][4 * rr + q] = rowp[gxc[q]];
+      }
+    }
+    vrm = 0;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) vrm |= ((unsigned)(y0 - 1 + rr) < (unsigned)a.H ? 1u : 0u) << rr;
+  };
+  // registers (the fetched raw values) -> the transformed LDS images of buffer `buf`
+  auto transform = [&](int buf) {
+    float* mb = m_s + buf * (16 * NCO * kWWP);
+    float* vb = v_s + buf * (16 * NCIN * kWWP);
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {
+      const int item = tid + n * NT, c = item / kWWT, tl = item - c * kWWT;
+      const float d00 = (dcm[n] & 1u) ? gd[n][0] : 0.f, d01 = (dcm[n] & 2u) ? gd[n][1] : 0.f;
+      const float d10 = ((drm & 2u) && (dcm[n] & 1u)) ? gd[n][2] : 0.f, d11 = ((drm & 2u) && (dcm[n] & 2u)) ? gd[n][3] : 0.f;
       // A dY: rows (d0), (d0 + d1), (d0 - d1), (-d1); then the same along the columns
-      const float r4[4][2] = {{d[0][0], d[0][1]}, {d[0][0] + d[1][0], d[0][1] + d[1][1]},
-                              {d[0][0] - d[1][0], d[0][1] - d[1][1]}, {-d[1][0], -d[1][1]}};
-      float* mp = m_s + c * kWWP + tl;
+      const float r4[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
+      float* mp = mb + c * kWWP + tl;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         mp[(i * 4 + 0) * NCO * kWWP] = r4[i][0];
@@ -79,29 +147,20 @@ __global__ __launch_bounds__(256 * NCI) void wino_wgrad_kernel(WinoWgradArgs a) 
         mp[(i * 4 + 3) * NCO * kWWP] = -r4[i][1];
       }
     }
-    // V: item = (ci, tile); d = the tile's 4x4 input patch (rows y0-1 .. y0+2, cols x-1 .. x+2)
-    for (int item = tid; item < NCIN * kWWT; item += NT) {
-      const int c = item / kWWT, tl = item - c * kWWT;
-      const int x = 2 * (tx0 + tl);
-      float d[4][4];
-      const bool cok = ci0 + c < a.Cin;
-      const float* xp = a.x + (int64_t)b * a.xbs + (int64_t)(ci0 + c) * HW;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr)
+    for (int n = 0; n < NV; ++n) {
+      const int item = tid + n * NT, c = item / kWWT, tl = item - c * kWWT;
+      float d[16], tr[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int gy = y0 - 1 + rr, gx = x - 1 + q;
-          d[rr][q] = (cok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) ? xp[(int64_t)gy * a.W + gx] : 0.f;
-        }
-      float tr[4][4];
+      for (int e = 0; e < 16; ++e) d[e] = (((vrm >> (e >> 2)) & 1u) && ((vcm[n] >> (e & 3)) & 1u)) ? xd[n][e] : 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        tr[0][q] = d[0][q] - d[2][q];
-        tr[1][q] = d[1][q] + d[2][q];
-        tr[2][q] = d[2][q] - d[1][q];
-        tr[3][q] = d[1][q] - d[3][q];
+        tr[0][q] = d[q] - d[8 + q];
+        tr[1][q] = d[4 + q] + d[8 + q];
+        tr[2][q] = d[8 + q] - d[4 + q];
+        tr[3][q] = d[4 + q] - d[12 + q];
       }
-      float* vp = v_s + c * kWWP + tl;
+      float* vp = vb + c * kWWP + tl;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         vp[(i * 4 + 0) * NCIN * kWWP] = tr[i][0] - tr[i][2];
@@ -110,26 +169,74 @@ __global__ __launch_bounds__(256 * NCI) void wino_wgrad_kernel(WinoWgradArgs a) 
         vp[(i * 4 + 3) * NCIN * kWWP] = tr[i][1] - tr[i][3];
       }
     }
-    __syncthreads();
-    const float* mw = m_s + (ph * 8 * NCO + cob * 32 + l31) * kWWP + hh;
-    const float* vw = v_s + (ph * 8 * NCIN + cib * 32 + l31) * kWWP + hh;
+  };
+  auto mfmas = [&](int buf) {
+    const float* mw = m_s + buf * (16 * NCO * kWWP) + (ph * 8 * NCO + cob * 32 + l31) * kWWP + hh;
+    const float* vw = v_s + buf * (16 * NCIN * kWWP) + (ph * 8 * NCIN + cib * 32 + l31) * kWWP + hh;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
 #pragma unroll
       for (int k = 0; k < kWWT / 2; ++k)
         acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(mw[p * NCO * kWWP + 2 * k], vw[p * NCIN * kWWP + 2 * k], acc[p], 0, 0, 0);
     }
+  };
+  // (barriers as s_waitcnt lgkmcnt(0) + s_barrier: __syncthreads()' release fence waits for vmcnt(0) on gfx9 - loads and
+  // stores share the counter - which would park every wave on its own prefetch)
+  auto barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  if constexpr (NBUF == 2) {
+    // Two LDS image sets: chunk k's MFMAs read one while chunk k + 1 is transformed into the other, ONE barrier per chunk - and
+    // the two waves that share a SIMD take the two halves of an iteration in OPPOSITE order, so that one transforms (VALU, LDS stores) while the other multiplies: an fp32 MFMA and the same wave's
+    // other instructions do not overlap on gfx950, two waves' do.  Single-buffered, every wave of the
+    // workgroup - the only one a CU holds at 72 KB of LDS per set and 176 registers - transformed, then multiplied, in step:
+    // 4.6 us per chunk on the 128^2 layers against 1.95 us of matrix work.
+    //   Which waves share a SIMD is the dispatcher's business: every wave publishes its SIMD id (HW_ID[5:4]) and takes the
+    //   parity of its rank among the workgroup's waves on the same SIMD.
+    __shared__ int simd_of[2 * NCOB * NCI];
+    const int simd = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3u);
+    if (lane == 0) simd_of[wave] = simd;
+    __syncthreads();
+    int rank = 0;
+    for (int w = 0; w < wave; ++w) rank += simd_of[w] == simd ? 1 : 0;
+    const bool mfma_first = rank & 1;
+    if (c_lo < c_hi) {
+      fetch(c_lo);
+      transform(0);
+      if (c_lo + 1 < c_hi) fetch(c_lo + 1);
+      barrier();
+    }
+    for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+      const int buf = (chunk - c_lo) & 1;
+      const bool more = chunk + 1 < c_hi;                       // workgroup-uniform
+      if (mfma_first) mfmas(buf);
+      if (more) {
+        transform(buf ^ 1);
+        if (chunk + 2 < c_hi) fetch(chunk + 2);
+      }
+      if (!mfma_first) mfmas(buf);
+      barrier();
+    }
+  } else {
+    if (c_lo < c_hi) fetch(c_lo);
+    for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+      barrier();                                // the previous chunk's MFMAs are done with the LDS images
+      transform(0);
+      if (chunk + 1 < c_hi) fetch(chunk + 1);   // in flight under this chunk's MFMAs
+      barrier();
+      mfmas(0);
+    }
   }
-  // one slab per workgroup: partial[slot][p][co][ci]; lane = ci (coalesced), register rows = co
-  float* ps = a.partial + (int64_t)blockIdx.x * 16 * a.Cout * a.Cin;
-  const int ci = ci0 + cib * 32 + l31;
+  // one slab per workgroup: partial[slot][p][co][ci]; lane = ci (coalesced), register rows = co.  Every (co, ci) of the
+  // workgroup's blocks exists (Cout % 32 == 0, Cin % 32 == 0): unconditional stores off one base pointer.
+  const int64_t CC = (int64_t)a.Cout * a.Cin;
+  float* ps = a.partial + (int64_t)blockIdx.x * 16 * CC + (int64_t)(ph * 8) * CC + (int64_t)(co0 + cob * 32 + 4 * hh) * a.Cin +
+              ci0 + cib * 32 + l31;
 #pragma unroll
   for (int p = 0; p < 8; ++p)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int co = co0 + cob * 32 + acc_row(i, hh);
-      if (co < a.Cout && ci < a.Cin) ps[((int64_t)(ph * 8 + p) * a.Cout + co) * a.Cin + ci] = acc[p][i];
-    }
+    for (int i = 0; i < 16; ++i) ps[p * CC + (int64_t)((i & 3) + 8 * (i >> 2)) * a.Cin] = acc[p][i];   // acc_row(i, hh) - 4 hh
 }
 
 // dU[p][co][ci] = sum_slot partial (fixed order), then dW = G^T dU G with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -198,7 +305,8 @@ static void wwgrad_plan(int B, int Cin, int Cout, int H, int W, int* nci, int* g
                         int* nchunks, int* tiles_y, int* chunks_x) {
   *nci = (Cin % 64 == 0) ? 2 : 1;
   *gi = Cin / (32 * *nci);
-  *groups = (Cout / 64) * *gi;
+  const int ncob = (Cout % 64 == 0) ? 2 : 1;
+  *groups = (Cout / (32 * ncob)) * *gi;
   *tiles_y = (H + 1) / 2;
   *chunks_x = ((W + 1) / 2 + kWWT - 1) / kWWT;
   *nchunks = B * *tiles_y * *chunks_x;
@@ -219,7 +327,7 @@ extern "C" int64_t tgsr_wino_wgrad_ws_elems(int B, int Cin, int Cout, int H, int
 extern "C" int tgsr_wino_wgrad(const float* grad_out, const float* x, int64_t x_bstride, int B, int Cin, int H, int W,
                                int Cout, float* ws, float* dw, void* stream) {
   if (!grad_out || !x || !ws || !dw || B < 1 || Cin < 1 || Cout < 1 || H < 1 || W < 1) return TGSR_EINVAL;
-  if (Cout % 64 != 0 || Cin % 32 != 0) return TGSR_EUNSUPPORTED;
+  if (Cout % 32 != 0 || Cin % 32 != 0) return TGSR_EUNSUPPORTED;
   WinoWgradArgs a;
   a.g = grad_out; a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
   int nci, groups, gi, nslots, cpw, nchunks;
@@ -227,8 +335,11 @@ extern "C" int tgsr_wino_wgrad(const float* grad_out, const float* x, int64_t x_
   a.nchunks = nchunks; a.chunks_per_wg = cpw; a.cgroups_i = gi; a.partial = ws;
   hipStream_t s = as_stream(stream);
   dim3 grid(nslots, groups);
-  if (nci == 2) hipLaunchKernelGGL(wino_wgrad_kernel<2>, grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL(wino_wgrad_kernel<1>, grid, dim3(256), 0, s, a);
+  const bool co64 = Cout % 64 == 0;
+  if (nci == 2 && co64) hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), grid, dim3(512), 0, s, a);
+  else if (nci == 2) hipLaunchKernelGGL((wino_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a);
+  else if (co64) hipLaunchKernelGGL((wino_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((wino_wgrad_kernel<1, 1>), grid, dim3(128), 0, s, a);
   int rc = note_launch(hipGetLastError(), "wino_wgrad_kernel");
   if (rc) return rc;
   const int64_t n = (int64_t)Cout * Cin;

@@ -718,8 +718,8 @@ def sumpool2x2(x: torch.Tensor) -> torch.Tensor:
 
 def conv3x3_wgrad_kind(Cin: int, Cout: int, upsample: bool, winograd: bool = True) -> str:
     """Which weight-gradient kernel serves a conv3x3 layer: "upwino" (9 Winograd positions on the low-resolution pixels of
-    an upBlock), "wino" (16 positions per 2x2 output tile) where Cout % 64 == 0 and Cin % 32 == 0, else "direct"."""
-    if winograd and Cout % 64 == 0 and Cin % 32 == 0:
+    an upBlock), "wino" (16 positions per 2x2 output tile) where Cout % 32 == 0 and Cin % 32 == 0, else "direct"."""
+    if winograd and Cout % 32 == 0 and Cin % 32 == 0:
         return "upwino" if upsample else "wino"
     return "direct"
 
