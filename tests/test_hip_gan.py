@@ -214,6 +214,14 @@ class _StandInTrunk(torch.nn.Module):
         return self.f(F.adaptive_avg_pool2d(x, 17)), self.p(x.mean((2, 3)))
 
 
+# Relative error bound on the generator gradients of the full-size G/D step (max |diff| / max |ref| per tensor).  Measured
+# (round 4, printed by the test): HIP vs the fp64 oracle 2.6e-3, the CPU fp32 oracle itself vs fp64 1.8e-3, HIP vs the fp32
+# oracle 2.7e-3 - gradients reach the generators through up to ten train-mode BatchNorms of the discriminators and 36 of
+# their own, and ANY fp32 evaluation of this step sits ~2e-3 from the fp64 one.  The bound is 4x the measured worst case, and
+# the HIP path may be at most 3x as far from fp64 as the CPU fp32 oracle is.
+GD_GRAD_TOL = 1e-2
+
+
 def test_full_size_gan_train_step_parity(face_weights):
     """BASELINE configs[2] at FULL size: CelebA x8, B = 16, shipped generator weights, DF_DIM 64 discriminators.  One
     G/D alternation of SRTrainer vs the oracle (torch autograd on the CPU): the three discriminator losses, the
@@ -262,6 +270,18 @@ def test_full_size_gan_train_step_parity(face_weights):
         refG = O.generator_adv_loss(sdD, fine, sent, rl) + O.mse(imgs, hr) + O.mse(fine, hr) + O.kl_loss(mu, logvar)
         refG.backward(retain_graph=True)
         grads0 = {id(v): v.grad.clone() for sd in (rL, rH) for v in sd.values() if v.grad is not None}
+        # the same leg in fp64 (the oracle on double tensors): what the two fp32 implementations are each measured against
+        dbl = lambda sd: {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else
+                              (v.double() if v.is_floating_point() else v)) for k, v in sd.items()}
+        dL, dH = dbl(sdL), dbl({k: v for k, v in sdH.items() if k != "a"})
+        dD = [{k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()} for sd in sdD]
+        i64, _a64, mu64, lv64 = O.g_sr_net_low(dL, LR.double(), sent.double(), words.double(), mask, training=True)
+        f64, _a2, _o2 = O.netg_highweight(dH, LR.double(), i64, LRb.double(), "lr", training=True)
+        hr64 = [h.double() for h in hr]
+        ref64 = (O.generator_adv_loss(dD, f64, sent.double(), rl.double()) + O.mse(i64, hr64) + O.mse(f64, hr64) +
+                 O.kl_loss(mu64, lv64))
+        ref64.backward()
+        del i64, f64
         # the ranking term alone (same graph): heads restated with stock torch ops on the CPU, oracle losses
         feats, pooled = enc_cpu.trunk(fine[2])
         regions = F.conv2d(feats, enc_cpu.emb_features.weight)
@@ -301,15 +321,23 @@ def test_full_size_gan_train_step_parity(face_weights):
             gl = dict(tr.netGL.named_parameters())
             # gradients reach the generators through up to ten train-mode BatchNorms of the discriminators and 36 of their
             # own: two fp32 implementations agree to ~1e-3 there (the discriminator tests above quantify it against fp64)
-            for k in sample_L:
-                r = ref_grad(rL[k])
-                err = float((gl[k].grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-12)
-                assert err < 1e-2, "%s GL %s: relative gradient error %g" % (leg, k, err)
             gh = dict(tr.netGH.named_parameters())
-            for k in sample_H:
-                r = ref_grad(rH[k])
-                err = float((gh[k].grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-12)
-                assert err < 1e-2, "%s GH %s: relative gradient error %g" % (leg, k, err)
+            worst = {"hip_vs_fp32": 0.0, "hip_vs_fp64": 0.0, "fp32_vs_fp64": 0.0}
+            for names, got, r32, r64 in ((sample_L, gl, rL, dL), (sample_H, gh, rH, dH)):
+                for k in names:
+                    r = ref_grad(r32[k])
+                    err = float((got[k].grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-12)
+                    worst["hip_vs_fp32"] = max(worst["hip_vs_fp32"], err)
+                    assert err < GD_GRAD_TOL, "%s %s: relative gradient error %g against the fp32 oracle" % (leg, k, err)
+                    if leg == "G+D+MSE+KL":          # the fp64 reference covers this leg
+                        t = r64[k].grad
+                        e64 = float((got[k].grad.cpu().double() - t).abs().max()) / (float(t.abs().max()) + 1e-300)
+                        o64 = float((r.double() - t).abs().max()) / (float(t.abs().max()) + 1e-300)
+                        worst["hip_vs_fp64"], worst["fp32_vs_fp64"] = max(worst["hip_vs_fp64"], e64), max(worst["fp32_vs_fp64"], o64)
+                        assert e64 < GD_GRAD_TOL, "%s %s: relative gradient error %g against the fp64 oracle" % (leg, k, e64)
+            print("G/D step gradients (%s), worst relative error over the sampled tensors: %s" % (leg, worst))
+            if leg == "G+D+MSE+KL":
+                assert worst["hip_vs_fp64"] < 3.0 * worst["fp32_vs_fp64"] + 1e-4, worst
         # the ranking term really moved the sampled gradients (else leg two proves nothing beyond leg one)
         moved = max(float((rH[k].grad - grads0[id(rH[k])]).abs().max()) / (float(grads0[id(rH[k])].abs().max()) + 1e-12)
                     for k in sample_H)

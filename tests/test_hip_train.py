@@ -179,7 +179,7 @@ def test_generators_train_mode_golden_and_gradients(nets_small):
                 denom = float(r.abs().max()) + 1e-6
                 err = float((p.grad.cpu() - r).abs().max()) / denom
                 worst = max(worst, err)
-                assert err < 5e-3, (k, err, denom)
+                assert err < 2e-4, (k, err, denom)       # measured worst over all 225 tensors: 1.6e-5 (round 4); bound ~10x
         print("worst relative parameter-gradient error", worst)
     finally:
         cfg_reset()
@@ -563,6 +563,7 @@ def test_models16_train_mode_gradients():
                                 return b_ + k[len(a_):]
             return k
 
+        worst16 = 0.0
         for net, ref in ((gl, pL), (gh, pH)):
             for k0, p in net.named_parameters():
                 k = ref_key(k0, ref)
@@ -572,8 +573,10 @@ def test_models16_train_mode_gradients():
                 r = ref[k].grad
                 assert p.grad is not None, k
                 err = float((p.grad.cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-6)
+                worst16 = max(worst16, err)
                 assert err < 5e-3, (k, err)
                 seen.add(k)
+        print("x16: worst relative parameter-gradient error", worst16)
         assert "a" in seen and any(k.startswith("h_net2.") for k in seen) and "img_net1.img.0.weight" in seen
     finally:
         cfg_reset()

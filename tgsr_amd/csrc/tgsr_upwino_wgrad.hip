@@ -238,6 +238,7 @@ static void upwgrad_plan(int B, int Cin, int Cout, int H, int W, int* nci, int* 
   *groups = (Cout / 64) * *gi;
   *nchunks = B * H * ((W + kUWT - 1) / kUWT);
   int want = 512 / *groups;                  // two workgroups per CU in flight; fewer, longer K walks keep the slabs small
+  if (*nchunks <= 1024 && want >= 64) want /= 2;   // the 32 x 32 upBlocks are slab-bound (tools/exp_wgrad.py: 54 -> 41 us, 46 -> 42)
   want = want * wgrad_split_pct() / 100;
   if (want < 1) want = 1;
   if (want > *nchunks) want = *nchunks;

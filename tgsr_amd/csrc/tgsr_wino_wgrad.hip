@@ -311,6 +311,9 @@ static void wwgrad_plan(int B, int Cin, int Cout, int H, int W, int* nci, int* g
   *chunks_x = ((W + 1) / 2 + kWWT - 1) / kWWT;
   *nchunks = B * *tiles_y * *chunks_x;
   int want = 256 / *groups;                  // one 8-wave workgroup per CU: fewer, longer K walks keep the slabs small
+  // the 32 x 32 layers (<= 512 chunks at batch 16) are slab-bound - 2-4 chunks of work per workgroup against a 64-KB..512-KB
+  // slab written and re-read: half the split measured 5-20 % faster there, slower everywhere else (tools/exp_wgrad.py)
+  if (*nchunks <= 512 && want >= 64) want /= 2;
   want = want * wgrad_split_pct() / 100;
   if (want < 1) want = 1;
   if (want > *nchunks) want = *nchunks;
