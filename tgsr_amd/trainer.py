@@ -2,6 +2,8 @@
 and prepare_datablur, datasets.py:71-109): batch preparation, the text-enc -> G_SR_NET_low -> NetG_highweight
 wiring and the uint8 epilogue.  Orchestration only; all arithmetic is in the modules' HIP kernels.
 """
+import os
+
 import numpy as np
 
 import torch
@@ -33,6 +35,10 @@ def to_uint8(img):
         return C.to_uint8(img.detach()).cpu().numpy()
     a = img.detach().cpu().numpy()
     return np.round(np.maximum(0, np.minimum(255, (a + 1.0) * 127.5))).astype(np.uint8)
+
+
+# where NetG_highweight's stream forks off: behind the text tail (1) or at the start of the step (0, the round-3 order)
+GH_AFTER_TEXT = os.environ.get("TGSR_GH_AFTER_TEXT", "1") != "0"
 
 
 def crop_words(out, num_words):
@@ -226,18 +232,29 @@ class SRPipeline:
             low = lambda sent, words, mask, ca, proj: self.netGL(LR, sent, words, mask, ca=ca, proj=proj)    # noqa: E731
             heads = self.netGH.heads
         feats = side = None
-        if self.overlap and LR.is_cuda:
-            main = torch.cuda.current_stream(LR.device)
+
+        def fork_trunk():
+            nonlocal feats, side
+            main_ = torch.cuda.current_stream(LR.device)
             if self._side is None:
                 self._side = {}
-            side = self._side.get(main.cuda_stream)      # one side stream per calling stream (callers may alternate
+            side = self._side.get(main_.cuda_stream)     # one side stream per calling stream (callers may alternate
             if side is None:                             # lanes to overlap consecutive steps)
-                side = self._side[main.cuda_stream] = torch.cuda.Stream(device=LR.device)
-            side.wait_stream(main)                       # LR / LRb are ready on the main stream
+                side = self._side[main_.cuda_stream] = torch.cuda.Stream(device=LR.device)
+            side.wait_stream(main_)                      # LR / LRb are ready on the main stream
             with torch.cuda.stream(side):                # the trunk needs neither the text encoder nor G_SR_NET_low
                 feats = trunk()
+            return main_
+
+        main = None
+        if self.overlap and LR.is_cuda and not GH_AFTER_TEXT:
+            main = fork_trunk()
         words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
         proj, ca, mask = self._text_tail(words_embs, sent_emb, captions)
+        if self.overlap and LR.is_cuda and GH_AFTER_TEXT:
+            # NetG_highweight's branch has slack (G_SR_NET_low's dependent chain is the step): forked BEHIND the text tail, the
+            # recurrence and the tail - the head of that chain - run without its kernels competing for the CUs
+            main = fork_trunk()
         res = low(sent_emb, words_embs, mask, ca, proj)
         fake_imgL, attention_maps, mu, logvar = res[:4]
         pend = res[4:]       # lp path: (partial sums of the low-frequency heads still to be combined,) - heads() finishes them
