@@ -37,8 +37,10 @@ def to_uint8(img):
     return np.round(np.maximum(0, np.minimum(255, (a + 1.0) * 127.5))).astype(np.uint8)
 
 
-# where NetG_highweight's stream forks off: behind the text tail (1) or at the start of the step (0, the round-3 order)
-GH_AFTER_TEXT = os.environ.get("TGSR_GH_AFTER_TEXT", "1") != "0"
+# where NetG_highweight's stream forks off: at the start of the step (0, the default) or behind the text tail (1).  Measured
+# neutral (round 4, hipGraph replays: bf16 31.3 k vs 31.3 k images/s, fp32 10.26 k vs 10.36 k): the step is G_SR_NET_low's
+# dependent chain either way, the other branch's kernels competing with the recurrence / text tail do not bound it.
+GH_AFTER_TEXT = os.environ.get("TGSR_GH_AFTER_TEXT", "0") == "1"
 
 
 def crop_words(out, num_words):
