@@ -3,11 +3,13 @@
 # bench lines (default fp32, bf16 graph, f16 graph, bf16 eager lanes, bf16 B=8 graph, train) + rocprofv3 stats / PMC of
 # the fp32 and bf16 paths.  Everything lands in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
+PART=${2:-all}      # all | bench | prof
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd $ROOT
+if [ "$PART" != "prof" ]; then
 python3 bench.py > $OUT/${TAG}_bench_fp32.json 2> $OUT/${TAG}_bench_fp32.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --extras none > $OUT/${TAG}_bench_fp32_driver_flags.json 2> $OUT/${TAG}_bench_fp32_driver_flags.err
 python3 bench.py --eager --no-cpu-baseline --extras none > $OUT/${TAG}_bench_fp32_eager_lanes3.json 2> $OUT/${TAG}_bench_fp32_eager.err
@@ -25,13 +27,20 @@ echo "lp variants done"
 python3 bench.py --mode train --steps 10 > $OUT/${TAG}_bench_train.json 2> $OUT/${TAG}_bench_train.err
 python3 bench.py --mode train --gan --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_train_gan.json 2> $OUT/${TAG}_bench_train_gan.err
 echo "train done"
+python3 bench.py --branch-num 5 --steps 12 --warmup 3 > $OUT/${TAG}_bench_x16_fp32.json 2> $OUT/${TAG}_bench_x16_fp32.err
+python3 bench.py --branch-num 5 --dtype f16 --graph --steps 12 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_x16_f16_graph.json 2> $OUT/${TAG}_bench_x16_f16.err
+python3 bench.py --branch-num 5 --dtype bf16 --graph --steps 12 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_x16_bf16_graph.json 2> $OUT/${TAG}_bench_x16_bf16.err
+echo "x16 done"
+TGSR_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_rehearsal_2ranks.json 2> $OUT/${TAG}_bench_rehearsal.err || echo "rehearsal failed"
+fi
+if [ "$PART" != "bench" ]; then
 bash tools/profile_stats.sh ${TAG}_train --mode train --steps 8 --warmup 2 --no-cpu-baseline
 bash tools/profile_stats.sh ${TAG}_train_gan --mode train --gan --steps 4 --warmup 2 --no-cpu-baseline
 rm -f $OUT/${TAG}_train_stats.log $OUT/${TAG}_train_gan_stats.log
 echo "train profiles done"
-TGSR_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_rehearsal_2ranks.json 2> $OUT/${TAG}_bench_rehearsal.err || echo "rehearsal failed"
 bash tools/profile_pmc.sh ${TAG}_fp32 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial --extras none
 bash tools/profile_pmc.sh ${TAG}_bf16 --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial --extras none
+fi
 for f in $OUT/${TAG}_bench_*.json; do python3 -c "
 import json,sys
 try:
