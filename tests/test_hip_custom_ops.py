@@ -192,6 +192,18 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     h32 = lp.from_nchw(R(2, 32, 8, 32), "bf16", cpitch=64)
     chk(T.lp_conv_to3.default, (h32, p5, 5, True, R(2, 3, 8, 32), 0.5), test_utils=basic)
     chk(T.lp_word_attention.default, (h32, R(2, 32, 32), None, 7, False, 32), test_utils=basic)
+    # the attention pack of the text tail and the producers of h that attend in their epilogue; the f16 <-> bf16 hand-over
+    tail = (R(2, 48, 9), [R(32, 48), R(32, 48)], R(2, 64), R(40, 64), R(40), 10, cap[:2].contiguous(), True)
+    chk(T.text_tail_lp.default, tail, test_utils=basic)
+    pack = T.text_tail_lp(*tail)[4]
+    att = (pack, 2, 1, 9, True, False, 32)
+    chk(T.lp_stem_att.default, (R(2, 3, 8, 32), R(64, 3, 3, 3) / 5.0, sc, sh, lp.new_image(2, 8, 32, 64, "bf16", DEV), 0) + att +
+        (torch.empty(2, 9, 8, 32, device=DEV),), test_utils=basic)
+    chk(T.lp_upconv_glu_att.default, (xi, wu, 64, 64, sc, sh, lp.new_image(2, 16, 64, 64, "bf16", DEV), 0) + att +
+        (torch.empty(2, 9, 16, 64, device=DEV),), test_utils=basic)
+    chk(T.lp_upconv_glu_head_att.default, (xi, wu, 64, 64, sc, sh, p3, 3, part3, lp.new_image(2, 16, 64, 64, "bf16", DEV), 0) + att +
+        (None,), test_utils=basic)
+    chk(T.lp_convert.default, (lp.from_nchw(R(2, 32, 8, 32), "f16"), lp.new_image(2, 8, 32, 32, "bf16", DEV)), test_utils=basic)
 
 
 def test_only_the_tensor_wrappers_touch_the_c_abi():
