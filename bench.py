@@ -294,13 +294,14 @@ def bench_train(args, rank, world, dist, dev, weights):
         dist.destroy_process_group()
 
 
-def roofline_objects(agg, nprof, dtype, serial, steps, batch=16):
+def roofline_objects(agg, nprof, dtype, serial, steps, batch=16, counters=True):
     """`roofline` (dominant conv kernel), per-kernel table and the attention object from the HIP events recorded around
     every launch of the sampled steps.  Nothing here is a literal: HBM traffic and the MFMA-busy share come from the
     newest rocprofv3 table under profiles/ for this dtype (pmc_table), looked up by kernel name."""
     lp = dtype != "fp32"
     peak_mfma = PEAK_LP_MFMA_TFLOPS if lp else PEAK_FP32_MFMA_TFLOPS
-    pmc_file, pmc = pmc_table(dtype)
+    # (counters=False: the committed counter tables were taken on the x8 generators' layer mix - not applied to the x16 line)
+    pmc_file, pmc = pmc_table(dtype) if counters else (None, {})
     conv_kernels = [k for k in ("lp_conv3x3_kernel", "lp_upconv_glu_kernel", "wino_conv3x3_kernel", "upwino_glu_kernel", "conv3x3_mfma_kernel",
                                 "upconv_glu_mfma_kernel") if k in agg]
     dom = max(conv_kernels, key=lambda k: agg[k][3])
@@ -905,7 +906,7 @@ def main():
             a[1] += flops
             a[2] += nbytes
             a[3] += e0.elapsed_time(e1) * 1e-3
-        roof, kern, att = roofline_objects(agg, nprof, args.dtype, args.serial, args.steps, B) if nprof else (None, {}, None)
+        roof, kern, att = roofline_objects(agg, nprof, args.dtype, args.serial, args.steps, B, counters=not x16) if nprof else (None, {}, None)
         if att is None and nprof and getattr(pipe, "_lp", None) is not None and pipe._lp.fuse_attention:
             # BASELINE's metric asks for the attention GEMM's MFMA utilisation: in the default route it has no launch of its own,
             # so ONE extra eager step with the stand-alone attention launches (same arithmetic, same bits) is event-timed
@@ -922,7 +923,7 @@ def main():
                     a[1] += flops
                     a[2] += nbytes
                     a[3] += e0.elapsed_time(e1) * 1e-3
-                att = roofline_objects(agg2, 1, args.dtype, True, 1, B)[2]
+                att = roofline_objects(agg2, 1, args.dtype, True, 1, B, counters=not x16)[2]
                 if att is not None:
                     att["measured_with"] = ("stand-alone attention launches (TGSR_LP_FUSE_ATT=0), one extra step outside the "
                                             "timed region; the timed steps compute the same arithmetic inside lp_stem_kernel / "
