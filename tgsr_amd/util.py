@@ -468,8 +468,8 @@ def _torchvision_inception():
 
 class CA_NET(nn.Module):
     """util.py:372-400.  One 256->400 Linear + GLU + re-parametrisation on [B,256].  Inference (eval mode under
-    no_grad): one HIP launch (tgsr_ca_net_fwd).  Training: torch ops (a library GEMM and pointwise kernels - the KL
-    term differentiates through them).  `c_code` is sampled to keep the reference's RNG consumption (util.py:388-396)
+    no_grad): one HIP launch (tgsr_ca_net_fwd).  Training: tgsr::linear (the library's MFMA GEMM, differentiable) + torch
+    pointwise ops - the KL term differentiates through them.  `c_code` is sampled to keep the reference's RNG consumption (util.py:388-396)
     and discarded by the x8 caller."""
 
     def __init__(self):
@@ -480,7 +480,13 @@ class CA_NET(nn.Module):
         self.relu = GLU()
 
     def encode(self, text_embedding):
-        x = self.relu(self.fc(text_embedding))
+        # the Linear on the library's own MFMA GEMM (tgsr::linear = gemm_bias_kernel, with its autograd formula: dW and dx are
+        # the same kernel) when the tensors live on the GPU - no rocBLAS / Tensile kernel on the training path
+        if text_embedding.is_cuda and text_embedding.dtype == torch.float32:
+            y = C.linear(text_embedding, self.fc.weight, self.fc.bias)
+        else:
+            y = self.fc(text_embedding)
+        x = self.relu(y)
         return x[:, :self.c_dim], x[:, self.c_dim:]
 
     def reparametrize(self, mu, logvar):
