@@ -239,6 +239,156 @@ __global__ __launch_bounds__(128 * NCI * NCOB) void wino_wgrad_kernel(WinoWgradA
     for (int i = 0; i < 16; ++i) ps[p * CC + (int64_t)((i & 3) + 8 * (i >> 2)) * a.Cin] = acc[p][i];   // acc_row(i, hh) - 4 hh
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The 64 co x 64 ci instance with the raw rows STAGED THROUGH LDS by LDS-DMA (round 4, W % 4 == 0, 16-byte aligned tensors).
+// In-kernel stamps of the register-fetch kernel above (per wave and 8-tile chunk, 64 -> 128 @128^2): MFMA phase 2 180 cycles
+// (2 048 of matrix work: dense), barrier 730, transform 2 250 - and 2 650 cycles just ISSUING the chunk's 20 scattered dword
+// loads per thread: 160 wave-level load instructions per chunk and CU, each touching 8-16 cache lines for 64 useful dwords,
+// back up in the vector-memory pipe while the wave sits at the issue.  The prefetched values had always arrived (vmcnt wait:
+// ~0) - it was never latency.  Here a chunk's input is 32 DMA instructions per workgroup instead of 160 loads:
+//   X  tile [4 rows][64 ci][24 cols]  (cols 2 tx0 - 4 .. 2 tx0 + 19: six aligned 16-byte pieces per (row, channel))
+//   dY tile [2 rows][64 co][16 cols]  (four pieces per (row, channel))
+// 2 048 pieces, 4 per thread, each wholly inside the image or fetched from a zero block (no bounds handling, no selects
+// afterwards); raw tiles double-buffered (2 x 32 KB) so chunk k + 1 is in flight while chunk k is transformed and multiplied;
+// the transformed images stay single-buffered (72 KB): two barriers per chunk, 136 KB of LDS.
+typedef __attribute__((address_space(3))) void* lds_ptrg_t;
+__device__ __attribute__((aligned(16))) float g_wgrad_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+constexpr int kWGXC = 24;                               // X tile columns
+constexpr int kWGX = 4 * 64 * kWGXC;                    // 6144 floats
+constexpr int kWGY = 2 * 64 * 16;                       // 2048 floats
+constexpr int kWGRaw = kWGX + kWGY;                     // 8192 floats = 32 KB = 32 DMA instructions of 1 KB
+
+__global__ __launch_bounds__(512) void wino_wgrad_dma_kernel(WinoWgradArgs a) {
+  constexpr int NCO = 64, NCIN = 64;
+  __shared__ __attribute__((aligned(16))) float raw_s[2 * kWGRaw];
+  __shared__ float m_s[16 * NCO * kWWP];      // dM [p][co][tile]
+  __shared__ float v_s[16 * NCIN * kWWP];     // V  [p][ci][tile]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cob = wave & 1, ph = (wave >> 1) & 1, cib = wave >> 2;        // co block, position half, ci block
+  const int grp = blockIdx.y;
+  const int co0 = (grp / a.cgroups_i) * NCO, ci0 = (grp % a.cgroups_i) * NCIN;
+  const int64_t HW = (int64_t)a.H * a.W;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+
+  const int c_lo = blockIdx.x * a.chunks_per_wg;
+  const int c_hi = c_lo + a.chunks_per_wg < a.nchunks ? c_lo + a.chunks_per_wg : a.nchunks;
+
+  // DMA plan: instruction q (0..31) of a chunk is issued by wave q & 7 as its (q >> 3)-th; lane l of instruction q copies piece
+  // P = 64 q + l.  X pieces P < 1536: (row = P / 384, ci = (P % 384) / 6, j = P % 6); dY pieces P - 1536: (row = / 256, co = (% 256)
+  // / 4, j = % 4).  The LDS image of a chunk is simply the pieces in order: X [row][ci][24], dY [row][co][16].
+  int prow[4], pcol[4];                       // image row offset (relative to y0) and first column (relative to 2 tx0) of a piece
+  const float* pbase[4];                      // channel plane of the piece (batch 0)
+  int pisx[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int P = 64 * (wave + 8 * k) + lane;
+    if (P < 1536) {
+      const int row = P / 384, r = P - row * 384, ci = r / 6, j = r - ci * 6;
+      prow[k] = row - 1; pcol[k] = 4 * j - 4; pisx[k] = 1;
+      pbase[k] = a.x + (int64_t)(ci0 + ci) * HW;
+    } else {
+      const int Q = P - 1536, row = Q >> 8, r = Q & 255, co = r >> 2, j = r & 3;
+      prow[k] = row; pcol[k] = 4 * j; pisx[k] = 0;
+      pbase[k] = a.g + (int64_t)(co0 + co) * HW;
+    }
+  }
+  const int64_t gbs = (int64_t)a.Cout * HW;
+  auto issue = [&](int chunk, int buf) {
+    int t = chunk;
+    const int cx = t % a.chunks_x;
+    t /= a.chunks_x;
+    const int ty = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int y0 = 2 * ty, xo = 2 * cx * kWWT;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int gy = y0 + prow[k], gx = xo + pcol[k];
+      const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;          // W % 4 == 0: a piece is all in or all out
+      const float* src = ok ? pbase[k] + (int64_t)b * (pisx[k] ? a.xbs : gbs) + (int64_t)gy * a.W + gx : g_wgrad_zero;
+      const unsigned l = __builtin_amdgcn_readfirstlane(
+          (unsigned)(size_t)(lds_ptrg_t)(raw_s + buf * kWGRaw + (wave + 8 * k) * 256));
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory");
+    }
+  };
+  // transform items: thread = (channel c = tid >> 3, tile tl = tid & 7) of dM and of V
+  const int tc = tid >> 3, tl = tid & 7;
+  if (c_lo < c_hi) issue(c_lo, 0);
+  for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+    const int buf = (chunk - c_lo) & 1;
+    if (chunk + 1 < c_hi) {
+      issue(chunk + 1, buf ^ 1);              // raw[buf ^ 1] was consumed by the transform of chunk - 1 (two barriers ago)
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // this wave's pieces of `chunk` landed; the 4 just issued fly on
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();             // every wave's pieces landed AND the previous chunk's MFMAs are done with the images
+    {
+      const float* xr = raw_s + buf * kWGRaw + tc * kWGXC + 2 * tl + 3;          // row 0, column x - 1 of this item's 4x4 patch
+      const float* yr = raw_s + buf * kWGRaw + kWGX + tc * 16 + 2 * tl;
+      const float2 g0 = *reinterpret_cast<const float2*>(yr), g1 = *reinterpret_cast<const float2*>(yr + 64 * 16);
+      // A dY: rows (d0), (d0 + d1), (d0 - d1), (-d1); then the same along the columns
+      const float r4[4][2] = {{g0.x, g0.y}, {g0.x + g1.x, g0.y + g1.y}, {g0.x - g1.x, g0.y - g1.y}, {-g1.x, -g1.y}};
+      float* mp = m_s + tc * kWWP + tl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        mp[(i * 4 + 0) * NCO * kWWP] = r4[i][0];
+        mp[(i * 4 + 1) * NCO * kWWP] = r4[i][0] + r4[i][1];
+        mp[(i * 4 + 2) * NCO * kWWP] = r4[i][0] - r4[i][1];
+        mp[(i * 4 + 3) * NCO * kWWP] = -r4[i][1];
+      }
+      float d[4][4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float* rp = xr + rr * (64 * kWGXC);
+        d[rr][0] = rp[0];
+        const float2 mid = *reinterpret_cast<const float2*>(rp + 1);            // columns x, x + 1: 8-byte aligned (2 tl + 4)
+        d[rr][1] = mid.x; d[rr][2] = mid.y;
+        d[rr][3] = rp[3];
+      }
+      float tr[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        tr[0][q] = d[0][q] - d[2][q];
+        tr[1][q] = d[1][q] + d[2][q];
+        tr[2][q] = d[2][q] - d[1][q];
+        tr[3][q] = d[1][q] - d[3][q];
+      }
+      float* vp = v_s + tc * kWWP + tl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vp[(i * 4 + 0) * NCIN * kWWP] = tr[i][0] - tr[i][2];
+        vp[(i * 4 + 1) * NCIN * kWWP] = tr[i][1] + tr[i][2];
+        vp[(i * 4 + 2) * NCIN * kWWP] = tr[i][2] - tr[i][1];
+        vp[(i * 4 + 3) * NCIN * kWWP] = tr[i][1] - tr[i][3];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float* mw = m_s + (ph * 8 * NCO + cob * 32 + l31) * kWWP + hh;
+    const float* vw = v_s + (ph * 8 * NCIN + cib * 32 + l31) * kWWP + hh;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+#pragma unroll
+      for (int k = 0; k < kWWT / 2; ++k)
+        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(mw[p * NCO * kWWP + 2 * k], vw[p * NCIN * kWWP + 2 * k], acc[p], 0, 0, 0);
+    }
+  }
+  const int64_t CC = (int64_t)a.Cout * a.Cin;
+  float* ps = a.partial + (int64_t)blockIdx.x * 16 * CC + (int64_t)(ph * 8) * CC + (int64_t)(co0 + cob * 32 + 4 * hh) * a.Cin +
+              ci0 + cib * 32 + l31;
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ps[p * CC + (int64_t)((i & 3) + 8 * (i >> 2)) * a.Cin] = acc[p][i];
+}
+
 // dU[p][co][ci] = sum_slot partial (fixed order), then dW = G^T dU G with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int Cout,
                                                                 int Cin, float* __restrict__ dw) {
@@ -339,7 +489,12 @@ extern "C" int tgsr_wino_wgrad(const float* grad_out, const float* x, int64_t x_
   hipStream_t s = as_stream(stream);
   dim3 grid(nslots, groups);
   const bool co64 = Cout % 64 == 0;
-  if (nci == 2 && co64) hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), grid, dim3(512), 0, s, a);
+  // the DMA-staged instance: aligned planes and rows (TGSR_WGRAD_DMA=0 keeps the register-fetch kernel for A/B runs)
+  static const bool dma_on = [] { const char* e = getenv("TGSR_WGRAD_DMA"); return !(e && e[0] == '0'); }();
+  const bool dma_ok = dma_on && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
+                      x_bstride % 4 == 0;
+  if (nci == 2 && co64 && dma_ok) hipLaunchKernelGGL(wino_wgrad_dma_kernel, grid, dim3(512), 0, s, a);
+  else if (nci == 2 && co64) hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), grid, dim3(512), 0, s, a);
   else if (nci == 2) hipLaunchKernelGGL((wino_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a);
   else if (co64) hipLaunchKernelGGL((wino_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((wino_wgrad_kernel<1, 1>), grid, dim3(128), 0, s, a);
