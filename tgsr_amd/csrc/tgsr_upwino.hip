@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256, 4) void upwino_kernel(UpwArgs a) {
         for (int dy = 0; dy < 2; ++dy) {
           const float o0 = (yv[dy][0] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][0] * sg + tg)));
           const float o1 = (yv[dy][1] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[dy][1] * sg + tg)));
+#ifdef TGSR_UPW_NOSTORE   // diagnostic build (tools/upw_store_cost.py): the epilogue's arithmetic without its stores (a.B is never negative)
+          if (a.B < 0)
+#endif
           *reinterpret_cast<float2*>(ob + (int64_t)c * HWo + (int64_t)(oy + dy) * Wo + ox) = make_float2(o0, o1);
         }
       }

@@ -24,7 +24,7 @@ from .miscc.config import cfg
 from .miscc.utils import copy_G_params, load_params  # noqa: F401  (miscc/utils.py:467-474: the generator EMA helpers)
 from .model import CNN_ENCODER, G_SR_NET_low, NetG_highweight, RNN_ENCODER
 from .parallel import FlatGradBucket
-from .trainer import caption_mask
+from .trainer import caption_mask, distinct_streams
 
 
 def prepare_labels(batch_size, device):
@@ -52,7 +52,9 @@ class SRTrainer:
         # fill a fraction of the CUs); TGSR_WGRAD_SIDE=0 keeps everything on one stream
         from . import autograd as _ag
         self._packs = _ag.PackCache() if (self.device.type == "cuda" and os.environ.get("TGSR_PACK_CACHE", "1") != "0") else None
-        self._wside = torch.cuda.Stream(device=self.device) \
+        # (distinct_streams: torch hands out pool streams round robin - two "new" streams can be the same hip stream)
+        cur = [torch.cuda.current_stream(self.device).cuda_stream] if self.device.type == "cuda" else []
+        self._wside = distinct_streams(1, self.device, avoid=cur)[0] \
             if self.device.type == "cuda" and os.environ.get("TGSR_WGRAD_SIDE", "1") != "0" else None
         self.image_encoder = image_encoder
         self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM).to(self.device).eval()
@@ -76,8 +78,9 @@ class SRTrainer:
                 self.bucketsD.append(FlatGradBucket(d.parameters(), buffers=d.buffers()).attach())
                 self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
                                                    betas=(0.5, 0.999)))
-        self._dstreams = [torch.cuda.Stream(device=self.device) for _ in self.netsD] \
-            if self.device.type == "cuda" and os.environ.get("TGSR_D_STREAMS", "1") != "0" else []
+        self._dstreams = distinct_streams(len(self.netsD), self.device,
+                                          avoid=cur + ([self._wside.cuda_stream] if self._wside is not None else [])) \
+            if self.device.type == "cuda" and self.netsD and os.environ.get("TGSR_D_STREAMS", "1") != "0" else []
 
     def loss(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """hr_pyramid: the 3 target scales [B,3,2s,2s], [B,3,4s,4s], [B,3,8s,8s]."""

@@ -70,6 +70,25 @@ def _host_lens(cap_lens):
     return [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
 
 
+def distinct_streams(n, dev, avoid=()):
+    """n HIP streams whose handles differ from each other and from `avoid`.  `torch.cuda.Stream()` hands out the 32 streams of a
+    per-device pool round robin: deep into a long process two "new" stream objects - or a new one and torch's graph-capture
+    stream, or the stream a caller is on - can be the SAME hip stream, and a fork / join captured between them is then not the
+    topology the code describes (which of them coincide depends on how many streams the process has asked for so far)."""
+    seen = {int(h) for h in avoid}
+    out = []
+    for _ in range(96):
+        if len(out) == n:
+            break
+        st = torch.cuda.Stream(device=dev)
+        if int(st.cuda_stream) not in seen:
+            seen.add(int(st.cuda_stream))
+            out.append(st)
+    if len(out) != n:
+        raise RuntimeError("could not obtain %d distinct HIP streams" % n)
+    return out
+
+
 class SRPipeline:
     """The three networks of the SR path, built like trainer_objective.py:62-99: TREE.BRANCH_NUM == 4 selects the x8
     generators of model.py, anything else the x16 ones of models16.py (trainer_objective.py:74-87)."""
@@ -126,7 +145,7 @@ class SRPipeline:
         those gaps (B=16: 1.74 -> 1.57 ms per step with three lanes).  Each lane keeps its own activation buffers.
         Weight packs and the per-token gate table are built on first use, on whatever stream that forward runs: do
         one warm-up forward and `torch.cuda.synchronize()` after loading / changing weights before fanning out."""
-        return [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        return distinct_streams(n, self.device, avoid=[torch.cuda.current_stream(self.device).cuda_stream])
 
     # ------------------------------------------------------------------ hipGraph replay (BASELINE config 5)
     @torch.no_grad()
@@ -242,7 +261,7 @@ class SRPipeline:
                 self._side = {}
             side = self._side.get(main_.cuda_stream)     # one side stream per calling stream (callers may alternate
             if side is None:                             # lanes to overlap consecutive steps)
-                side = self._side[main_.cuda_stream] = torch.cuda.Stream(device=LR.device)
+                side = self._side[main_.cuda_stream] = distinct_streams(1, LR.device, avoid=[main_.cuda_stream])[0]
             side.wait_stream(main_)                      # LR / LRb are ready on the main stream
             with torch.cuda.stream(side):                # the trunk needs neither the text encoder nor G_SR_NET_low
                 feats = trunk()
@@ -310,7 +329,10 @@ class GraphedStep:
         self.bufs = bufs
         overlap = pipe.overlap
         try:
-            s = torch.cuda.Stream(device=dev)
+            # the capture stream, the warm-up stream and the lanes' branch streams: all different hip streams, none of them the
+            # caller's (distinct_streams: torch's stream pool wraps around)
+            cur = torch.cuda.current_stream(dev)
+            cap, s, *branch = distinct_streams(self.lanes + 1, dev, avoid=[cur.cuda_stream, torch.cuda.default_stream(dev).cuda_stream])
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):                   # weight packs, caches and the allocator warm up outside the graph
                 for _ in range(warmup):
@@ -318,14 +340,13 @@ class GraphedStep:
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            branch = [torch.cuda.Stream(device=dev) for _ in range(self.lanes - 1)]
             outs = []
             if self.lanes > 1:
                 # every lane is ONE chain: the lanes provide the concurrency the GL / GH stream split provides inside a
                 # single step.  (Two streams per lane would be a fork nested inside a forked branch: hipStreamEndCapture
                 # segfaults on that topology on ROCm 7.2 - also with the side streams created before the capture.)
                 pipe.overlap = False
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=cap):
                 main = torch.cuda.current_stream(dev)
                 for st in branch:                        # fork EVERY branch before any lane's work is captured: a
                     st.wait_stream(main)                 # wait recorded behind lane 0's kernels would make the branches
@@ -342,6 +363,9 @@ class GraphedStep:
                 lpx.force_bufs = None
             if self.lanes > 1:
                 pipe.overlap = overlap
+        # The streams of the capture stay referenced as long as the graph does (CUDA documents a graph as independent of the
+        # streams it was captured from; nothing says so for HIP).
+        self._capture_streams = [cap, s] + branch
         self.inputs = sets[0] if self.lanes == 1 else sets
         self.out = outs[0] if self.lanes == 1 else outs
 
