@@ -249,19 +249,25 @@ __global__ __launch_bounds__(128 * NCI * NCOB) void wino_wgrad_kernel(WinoWgradA
 //   X  tile [4 rows][64 ci][24 cols]  (cols 2 tx0 - 4 .. 2 tx0 + 19: six aligned 16-byte pieces per (row, channel))
 //   dY tile [2 rows][64 co][16 cols]  (four pieces per (row, channel))
 // 2 048 pieces, 4 per thread, each wholly inside the image or fetched from a zero block (no bounds handling, no selects
-// afterwards); raw tiles double-buffered (2 x 32 KB) so chunk k + 1 is in flight while chunk k is transformed and multiplied;
-// the transformed images stay single-buffered (72 KB): two barriers per chunk, 136 KB of LDS.
+// afterwards); ONE raw buffer (32 KB: chunk k + 1 is copied while chunk k is multiplied) and one set of transformed images
+// (72 KB): two barriers per chunk, 104 KB of LDS.
 typedef __attribute__((address_space(3))) void* lds_ptrg_t;
 __device__ __attribute__((aligned(16))) float g_wgrad_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
 constexpr int kWGXC = 24;                               // X tile columns
-constexpr int kWGX = 4 * 64 * kWGXC;                    // 6144 floats
-constexpr int kWGY = 2 * 64 * 16;                       // 2048 floats
-constexpr int kWGRaw = kWGX + kWGY;                     // 8192 floats = 32 KB = 32 DMA instructions of 1 KB
+constexpr int kWGY = 2 * 64 * 16;                       // 2048 floats of dY
 
-__global__ __launch_bounds__(512) void wino_wgrad_dma_kernel(WinoWgradArgs a) {
-  constexpr int NCO = 64, NCIN = 64;
-  __shared__ __attribute__((aligned(16))) float raw_s[2 * kWGRaw];
+// NCI = 2: 64 co x 64 ci per workgroup (8 waves, 104 KB of LDS: one workgroup per CU); NCI = 1 (TGSR_WGRAD_TILE=32): 64 co x 32 ci
+// (4 waves, 75 KB: TWO workgroups per CU, whose transform and MFMA phases can overlap each other's).
+template <int NCI>
+__global__ __launch_bounds__(256 * NCI) void wino_wgrad_dma_kernel(WinoWgradArgs a) {
+  constexpr int NT = 256 * NCI, NW = 4 * NCI, NCO = 64, NCIN = 32 * NCI;
+  constexpr int XF = 4 * NCIN * kWGXC;                  // floats of the X tile [4 rows][NCIN][24]
+  constexpr int NPX = XF / 4, NPIECE = NPX + 512;       // 16-byte pieces: X, then dY [2 rows][64 co][16]
+  constexpr int NK = NPIECE / NT;                       // pieces per thread: 4 | 5
+  static_assert(NK * NT == NPIECE, "pieces divide evenly");
+  constexpr int ND = NCO * kWWT / NT;                   // dM items per thread: 1 | 2
+  __shared__ __attribute__((aligned(16))) float raw_s[XF + kWGY];
   __shared__ float m_s[16 * NCO * kWWP];      // dM [p][co][tile]
   __shared__ float v_s[16 * NCIN * kWWP];     // V  [p][ci][tile]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -280,27 +286,26 @@ __global__ __launch_bounds__(512) void wino_wgrad_dma_kernel(WinoWgradArgs a) {
   const int c_lo = blockIdx.x * a.chunks_per_wg;
   const int c_hi = c_lo + a.chunks_per_wg < a.nchunks ? c_lo + a.chunks_per_wg : a.nchunks;
 
-  // DMA plan: instruction q (0..31) of a chunk is issued by wave q & 7 as its (q >> 3)-th; lane l of instruction q copies piece
-  // P = 64 q + l.  X pieces P < 1536: (row = P / 384, ci = (P % 384) / 6, j = P % 6); dY pieces P - 1536: (row = / 256, co = (% 256)
-  // / 4, j = % 4).  The LDS image of a chunk is simply the pieces in order: X [row][ci][24], dY [row][co][16].
-  int prow[4], pcol[4];                       // image row offset (relative to y0) and first column (relative to 2 tx0) of a piece
-  const float* pbase[4];                      // channel plane of the piece (batch 0)
-  int pisx[4];
+  // DMA plan: instruction q of a chunk is issued by wave q % NW as its (q / NW)-th; lane l of instruction q copies piece
+  // P = 64 q + l.  X pieces P < NPX: (row = P / (6 NCIN), ci = (P % (6 NCIN)) / 6, j = P % 6); dY pieces P - NPX: (row = / 256,
+  // co = (% 256) / 4, j = % 4).  The LDS image of a chunk is simply the pieces in order: X [row][ci][24], dY [row][co][16].
+  int prow[NK], pcol[NK], pisx[NK];           // image row offset (relative to y0), first column (relative to 2 tx0), X or dY
+  const float* pbase[NK];                     // channel plane of the piece (batch 0)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int P = 64 * (wave + 8 * k) + lane;
-    if (P < 1536) {
-      const int row = P / 384, r = P - row * 384, ci = r / 6, j = r - ci * 6;
+  for (int k = 0; k < NK; ++k) {
+    const int P = 64 * (wave + NW * k) + lane;
+    if (P < NPX) {
+      const int row = P / (6 * NCIN), r = P - row * (6 * NCIN), ci = r / 6, j = r - ci * 6;
       prow[k] = row - 1; pcol[k] = 4 * j - 4; pisx[k] = 1;
       pbase[k] = a.x + (int64_t)(ci0 + ci) * HW;
     } else {
-      const int Q = P - 1536, row = Q >> 8, r = Q & 255, co = r >> 2, j = r & 3;
+      const int Q = P - NPX, row = Q >> 8, r = Q & 255, co = r >> 2, j = r & 3;
       prow[k] = row; pcol[k] = 4 * j; pisx[k] = 0;
       pbase[k] = a.g + (int64_t)(co0 + co) * HW;
     }
   }
   const int64_t gbs = (int64_t)a.Cout * HW;
-  auto issue = [&](int chunk, int buf) {
+  auto issue = [&](int chunk) {
     int t = chunk;
     const int cx = t % a.chunks_x;
     t /= a.chunks_x;
@@ -308,34 +313,28 @@ __global__ __launch_bounds__(512) void wino_wgrad_dma_kernel(WinoWgradArgs a) {
     const int b = t / a.tiles_y;
     const int y0 = 2 * ty, xo = 2 * cx * kWWT;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NK; ++k) {
       const int gy = y0 + prow[k], gx = xo + pcol[k];
       const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;          // W % 4 == 0: a piece is all in or all out
       const float* src = ok ? pbase[k] + (int64_t)b * (pisx[k] ? a.xbs : gbs) + (int64_t)gy * a.W + gx : g_wgrad_zero;
-      const unsigned l = __builtin_amdgcn_readfirstlane(
-          (unsigned)(size_t)(lds_ptrg_t)(raw_s + buf * kWGRaw + (wave + 8 * k) * 256));
+      const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptrg_t)(raw_s + (wave + NW * k) * 256));
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(l) : "memory");
     }
   };
-  // transform items: thread = (channel c = tid >> 3, tile tl = tid & 7) of dM and of V
-  const int tc = tid >> 3, tl = tid & 7;
-  if (c_lo < c_hi) issue(c_lo, 0);
+  // ONE raw buffer: a chunk's copies are issued right behind the barrier that ends the transform of the previous chunk (the
+  // last reader of the buffer) and fly under that chunk's MFMAs.
+  if (c_lo < c_hi) issue(c_lo);
   for (int chunk = c_lo; chunk < c_hi; ++chunk) {
-    const int buf = (chunk - c_lo) & 1;
-    if (chunk + 1 < c_hi) {
-      issue(chunk + 1, buf ^ 1);              // raw[buf ^ 1] was consumed by the transform of chunk - 1 (two barriers ago)
-      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // this wave's pieces of `chunk` landed; the 4 just issued fly on
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of `chunk` landed; its MFMA operands are read
     __builtin_amdgcn_s_barrier();             // every wave's pieces landed AND the previous chunk's MFMAs are done with the images
-    {
-      const float* xr = raw_s + buf * kWGRaw + tc * kWGXC + 2 * tl + 3;          // row 0, column x - 1 of this item's 4x4 patch
-      const float* yr = raw_s + buf * kWGRaw + kWGX + tc * 16 + 2 * tl;
+#pragma unroll
+    for (int n = 0; n < ND; ++n) {            // dM item (co, tile)
+      const int item = tid + n * NT, c = item >> 3, tl = item & 7;
+      const float* yr = raw_s + XF + c * 16 + 2 * tl;
       const float2 g0 = *reinterpret_cast<const float2*>(yr), g1 = *reinterpret_cast<const float2*>(yr + 64 * 16);
       // A dY: rows (d0), (d0 + d1), (d0 - d1), (-d1); then the same along the columns
       const float r4[4][2] = {{g0.x, g0.y}, {g0.x + g1.x, g0.y + g1.y}, {g0.x - g1.x, g0.y - g1.y}, {-g1.x, -g1.y}};
-      float* mp = m_s + tc * kWWP + tl;
+      float* mp = m_s + c * kWWP + tl;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         mp[(i * 4 + 0) * NCO * kWWP] = r4[i][0];
@@ -343,10 +342,14 @@ __global__ __launch_bounds__(512) void wino_wgrad_dma_kernel(WinoWgradArgs a) {
         mp[(i * 4 + 2) * NCO * kWWP] = r4[i][0] - r4[i][1];
         mp[(i * 4 + 3) * NCO * kWWP] = -r4[i][1];
       }
+    }
+    {                                         // V item (ci, tile): one per thread
+      const int tc = tid >> 3, tl = tid & 7;
+      const float* xr = raw_s + tc * kWGXC + 2 * tl + 3;          // row 0, column x - 1 of this item's 4x4 patch
       float d[4][4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float* rp = xr + rr * (64 * kWGXC);
+        const float* rp = xr + rr * (NCIN * kWGXC);
         d[rr][0] = rp[0];
         const float2 mid = *reinterpret_cast<const float2*>(rp + 1);            // columns x, x + 1: 8-byte aligned (2 tl + 4)
         d[rr][1] = mid.x; d[rr][2] = mid.y;
@@ -370,7 +373,8 @@ __global__ __launch_bounds__(512) void wino_wgrad_dma_kernel(WinoWgradArgs a) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();             // images complete; the raw buffer is free
+    if (chunk + 1 < c_hi) issue(chunk + 1);   // in flight under this chunk's MFMAs
     const float* mw = m_s + (ph * 8 * NCO + cob * 32 + l31) * kWWP + hh;
     const float* vw = v_s + (ph * 8 * NCIN + cib * 32 + l31) * kWWP + hh;
 #pragma unroll
@@ -451,16 +455,30 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 
 using namespace tgsr;
 
+// TGSR_WGRAD_TILE = 32 | 64: force the DMA-staged kernel's 64 co x 32 ci (two workgroups per CU) or 64 x 64 form on the
+// Cout % 64 == 0, Cin % 64 == 0 layers (0 / unset: by layer size, see wwgrad_plan)
+static int wgrad_tile() {
+  static const int v = [] { const char* e = getenv("TGSR_WGRAD_TILE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 static void wwgrad_plan(int B, int Cin, int Cout, int H, int W, int* nci, int* groups, int* gi, int* nslots, int* cpw,
                         int* nchunks, int* tiles_y, int* chunks_x) {
-  *nci = (Cin % 64 == 0) ? 2 : 1;
-  *gi = Cin / (32 * *nci);
-  const int ncob = (Cout % 64 == 0) ? 2 : 1;
-  *groups = (Cout / (32 * ncob)) * *gi;
   *tiles_y = (H + 1) / 2;
   *chunks_x = ((W + 1) / 2 + kWWT - 1) / kWWT;
   *nchunks = B * *tiles_y * *chunks_x;
+  // The 64 x 32 tile (two 4-wave workgroups per CU) measured 3-20 % faster than the 64 x 64 one on the 32^2 and 64^2 layers
+  // (<= 2 048 chunks at batch 16: 47 -> 37, 35 -> 31, 83 -> 79, 57 -> 54 us) and 3 % slower on the 128^2 ones
+  // (tools/exp_wgrad.py; TGSR_WGRAD_TILE=32 | 64 forces one of them).
+  const bool can32 = Cin % 64 == 0 && Cout % 64 == 0 && W % 4 == 0;
+  const int force = wgrad_tile();
+  const bool use32 = can32 && (force == 32 || (force == 0 && *nchunks <= 2048));
+  *nci = (Cin % 64 == 0 && !use32) ? 2 : 1;
+  *gi = Cin / (32 * *nci);
+  const int ncob = (Cout % 64 == 0) ? 2 : 1;
+  *groups = (Cout / (32 * ncob)) * *gi;
   int want = 256 / *groups;                  // one 8-wave workgroup per CU: fewer, longer K walks keep the slabs small
+  if (use32) want = 512 / *groups;           // two 4-wave workgroups per CU
   // the 32 x 32 layers (<= 512 chunks at batch 16) are slab-bound - 2-4 chunks of work per workgroup against a 64-KB..512-KB
   // slab written and re-read: half the split measured 5-20 % faster there, slower everywhere else (tools/exp_wgrad.py)
   if (*nchunks <= 512 && want >= 64) want /= 2;
@@ -493,7 +511,9 @@ extern "C" int tgsr_wino_wgrad(const float* grad_out, const float* x, int64_t x_
   static const bool dma_on = [] { const char* e = getenv("TGSR_WGRAD_DMA"); return !(e && e[0] == '0'); }();
   const bool dma_ok = dma_on && W % 4 == 0 && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(x)) & 15) == 0 &&
                       x_bstride % 4 == 0;
-  if (nci == 2 && co64 && dma_ok) hipLaunchKernelGGL(wino_wgrad_dma_kernel, grid, dim3(512), 0, s, a);
+  if (nci == 2 && co64 && dma_ok) hipLaunchKernelGGL(wino_wgrad_dma_kernel<2>, grid, dim3(512), 0, s, a);
+  else if (nci == 1 && co64 && dma_ok && Cin % 64 == 0)      // the plan chose the 64 x 32 tile for a 64-ci-multiple layer
+    hipLaunchKernelGGL(wino_wgrad_dma_kernel<1>, grid, dim3(256), 0, s, a);
   else if (nci == 2 && co64) hipLaunchKernelGGL((wino_wgrad_kernel<2, 2>), grid, dim3(512), 0, s, a);
   else if (nci == 2) hipLaunchKernelGGL((wino_wgrad_kernel<2, 1>), grid, dim3(256), 0, s, a);
   else if (co64) hipLaunchKernelGGL((wino_wgrad_kernel<1, 2>), grid, dim3(256), 0, s, a);

@@ -343,8 +343,8 @@ class GraphedStep:
             outs = []
             if self.lanes > 1:
                 # every lane is ONE chain: the lanes provide the concurrency the GL / GH stream split provides inside a
-                # single step.  (Two streams per lane would be a fork nested inside a forked branch: hipStreamEndCapture
-                # segfaults on that topology on ROCm 7.2 - also with the side streams created before the capture.)
+                # single step.  (Two streams per lane are a fork nested inside a forked branch: the process segfaults on that
+                # topology on ROCm 7.2 - re-checked in round 4 with all streams distinct, §3.15: it still does.)
                 pipe.overlap = False
             with torch.cuda.graph(self.graph, stream=cap):
                 main = torch.cuda.current_stream(dev)
