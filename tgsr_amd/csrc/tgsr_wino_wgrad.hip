@@ -393,6 +393,13 @@ __global__ __launch_bounds__(256 * NCI) void wino_wgrad_dma_kernel(WinoWgradArgs
     for (int i = 0; i < 16; ++i) ps[p * CC + (int64_t)((i & 3) + 8 * (i >> 2)) * a.Cin] = acc[p][i];
 }
 
+// (Tried on top of this kernel and measured SLOWER, 283 vs 252 us on 64 -> 128 @128^2, so not kept: both phases overlapped again -
+// V images double-buffered, the dM images dropped (the A operand computed by the lane that needs it from the raw dY tile in LDS: 138
+// KB in all), SIMD partners taking transform and MFMAs in opposite order, one barrier per chunk.  A wave's VALU / LDS work does not
+// run under its SIMD partner's fp32 MFMAs any better than under its own: the stamps of the register-fetch kernel had already shown
+// a transform phase of 100 instructions taking 2 250 cycles beside a multiplying partner.  Fewer non-MFMA instructions per chunk
+// is the only lever on this pipe.)
+
 // dU[p][co][ci] = sum_slot partial (fixed order), then dW = G^T dU G with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ partial, int nslots, int Cout,
                                                                 int Cin, float* __restrict__ dw) {
