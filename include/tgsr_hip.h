@@ -187,6 +187,19 @@ int tgsr_bilstm_table_fwd(const int64_t* captions, int width, const int32_t* cap
                           void* stream);
 
 /*
+ * The GRU branch of RNN_ENCODER (util.py:207-211: `nn.GRU(ninput, nhidden, 1, batch_first=True, bidirectional=True)` when
+ * cfg.RNN_TYPE == 'GRU'; forward util.py:233-260, sent_emb = the final hidden states, :257), eval mode, same packed-sequence
+ * semantics.  Gate order r, z, n.  tgsr_gru_gate_table: table[ntoken][2][3H] = emb[tok] . w_ih[d]^T + b_ih[d] + b_hh_rz[d], where
+ * b_hh_rz [2][3H] = b_hh with its n third zeroed (b_hn enters inside r * (W_hn h + b_hn)); tgsr_bigru_table_fwd: the recurrence
+ * through the caption, b_hn [2][H].  words_emb [B][2H][Tmax] (zero behind a caption), sent_emb [B][2H].  H in {32, 64, 128}.
+ */
+int tgsr_gru_gate_table(const float* emb, int ntoken, int ninput, const float* w_ih, const float* b_ih, const float* b_hh_rz,
+                        int H, float* table, void* stream);
+int tgsr_bigru_table_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax, const float* table,
+                         int ntoken, const float* w_hh, const float* b_hn, int H, float* words_emb, float* sent_emb,
+                         void* stream);
+
+/*
  * Training path of the same encoder.  tgsr_bilstm_train_fwd takes the already embedded (and dropped-out) inputs
  * x [B][Tmax][ninput] and additionally saves acts [B][Tmax][2][5][H] (i, f, g, o activations and the cell state of
  * every step).  tgsr_bilstm_bwd walks every (sample, direction) back through time from d_words [B][2H][Tmax] and

@@ -167,6 +167,35 @@ def rnn_encoder(sd: SD, captions: Tensor, cap_lens: Sequence[int], p: str = "") 
     return out.transpose(1, 2), sent
 
 
+def rnn_encoder_gru(sd: SD, captions: Tensor, cap_lens: Sequence[int], p: str = "") -> Tuple[Tensor, Tensor]:
+    """util.py:207-211, 233-260 with cfg.RNN_TYPE == 'GRU': the same packed-sequence semantics as `rnn_encoder` over a 1-layer
+    bidirectional torch.nn.GRU (gate order r, z, n):
+        r = sigmoid(W_ir x + b_ir + W_hr h + b_hr),  z = sigmoid(W_iz x + b_iz + W_hz h + b_hz),
+        n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),  h' = (1 - z) * n + z * h;
+    sent_emb = the final hidden states of the two directions (util.py:257: `hidden.transpose(0, 1)`)."""
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    B, T = captions.shape[0], max(lens)
+    emb = sd[p + "encoder.weight"][captions[:, :T]]
+    H = sd[p + "rnn.weight_hh_l0"].shape[1]
+    out = emb.new_zeros(B, T, 2 * H)
+    sent = emb.new_zeros(B, 2 * H)
+    for d, suf in enumerate(("", "_reverse")):
+        w_ih, w_hh = sd[p + "rnn.weight_ih_l0" + suf], sd[p + "rnn.weight_hh_l0" + suf]
+        b_ih, b_hh = sd[p + "rnn.bias_ih_l0" + suf], sd[p + "rnn.bias_hh_l0" + suf]
+        for b in range(B):
+            hcur = emb.new_zeros(H)
+            steps = range(lens[b]) if d == 0 else range(lens[b] - 1, -1, -1)
+            for t in steps:
+                gi, gh = w_ih @ emb[b, t] + b_ih, w_hh @ hcur + b_hh
+                r = torch.sigmoid(gi[:H] + gh[:H])
+                z = torch.sigmoid(gi[H:2 * H] + gh[H:2 * H])
+                n = torch.tanh(gi[2 * H:] + r * gh[2 * H:])
+                hcur = (1 - z) * n + z * hcur
+                out[b, t, d * H:(d + 1) * H] = hcur
+            sent[b, d * H:(d + 1) * H] = hcur
+    return out.transpose(1, 2), sent
+
+
 def ca_net(sd: SD, sent_emb: Tensor, p: str = "ca_net.") -> Tuple[Tensor, Tensor]:
     """util.py:383-387  CA_NET.encode: Linear -> GLU -> split into (mu, logvar).  The sampled c_code
     (util.py:389-396) is discarded by G_SR_NET_low (model.py:51-52), so it is not restated."""

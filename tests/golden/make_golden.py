@@ -497,8 +497,35 @@ def gen_gan():
     print("gan_losses.npz", len(out), "arrays;", logs)
 
 
+def gen_gru():
+    """RNN_ENCODER with cfg.RNN_TYPE = 'GRU' (util.py:207-211, 244-258): the reference's own module, eval mode, two sizes -
+    the shipped hidden size (nhidden 256 -> H = 128) on ragged captions incl. a one-word one, and H = 32 at batch 1."""
+    cfg, GA, util, model, losses = _load_ref(ngf=32, nef=256)
+    cfg.RNN_TYPE = "GRU"
+    out = {}
+    try:
+        for tag, nhidden, lens, seed in (("a", 256, [9, 6, 6, 2, 1], 11), ("b", 64, [5], 12)):
+            torch.manual_seed(seed)
+            g = torch.Generator().manual_seed(seed)
+            enc = util.RNN_ENCODER(41, nhidden=nhidden)
+            assert isinstance(enc.rnn, torch.nn.GRU)
+            enc.eval()
+            cap, lens_t = _captions(g, lens, 41)
+            with torch.no_grad():
+                we, se = enc(cap, lens_t, enc.init_hidden(len(lens)))
+            out.update(_sd_np(enc, "gru_%s." % tag))
+            out.update({"gru_%s.captions" % tag: _np(cap), "gru_%s.cap_lens" % tag: _np(lens_t),
+                        "gru_%s.words_emb" % tag: _np(we), "gru_%s.sent_emb" % tag: _np(se)})
+    finally:
+        cfg.RNN_TYPE = "LSTM"
+    np.savez_compressed(os.path.join(OUT, "enc_gru.npz"), **out)
+    print("enc_gru.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "nets", "nets16", "damsm", "face", "gan"]
+    which = sys.argv[1:] or ["ops", "nets", "nets16", "damsm", "face", "gan", "gru"]
+    if "gru" in which:
+        gen_gru()
     if "gan" in which:
         gen_gan()
     if "nets16" in which:

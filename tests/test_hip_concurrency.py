@@ -46,6 +46,9 @@ def _victims(g, B=16):
     cap = torch.randint(1, ntok, (B, T), generator=g).to(DEV)
     table, w_hh = R(ntok, 2, 4 * H) * 0.5, R(2, 4 * H, H) * 0.08
     v["bilstm_table (H = 128)"] = lambda: torch.cat([t.flatten() for t in ops.bilstm_table(cap, [T] * B, table, w_hh)])
+    gtab, gbn = ops.gru_gate_table(R(ntok, 300) * 0.1, R(2, 3 * H, 300) * 0.05, R(2, 3 * H) * 0.1, R(2, 3 * H) * 0.1)
+    gw_hh = R(2, 3 * H, H) * 0.08
+    v["bigru_table (H = 128)"] = lambda: torch.cat([t.flatten() for t in ops.bigru_table(cap, [T] * B, gtab, gw_hh, gbn)])
     words, sent = R(B, 256, T), R(B, 256)
     ws = [R(32, 256) for _ in range(3)]
     caw, cab = R(400, 256) * 0.1, R(400)

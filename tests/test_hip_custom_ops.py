@@ -154,6 +154,11 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     chk(T.bilstm_table.default, (cap, lens, T.lstm_gate_table(emb, w_ih, b_ih, b_hh), w_hh), test_utils=basic)
     chk(T.bilstm_table_static.default, (cap, torch.tensor(lens, dtype=torch.int32, device=DEV),
                                         T.lstm_gate_table(emb, w_ih, b_ih, b_hh), w_hh), test_utils=basic)
+    gw_ih, gw_hh, gb = R(2, 3 * Hh, 24) * 0.2, R(2, 3 * Hh, Hh) * 0.2, R(2, 3 * Hh) * 0.1
+    chk(T.gru_gate_table.default, (emb, gw_ih, gb, gb), test_utils=basic)
+    gtab, gbn = T.gru_gate_table(emb, gw_ih, gb, gb)
+    chk(T.bigru_table.default, (cap, lens, gtab, gw_hh, gbn), test_utils=basic)
+    chk(T.bigru_table_static.default, (cap, torch.tensor(lens, dtype=torch.int32, device=DEV), gtab, gw_hh, gbn), test_utils=basic)
     xe = R(3, 6, 24)
     chk(T.bilstm_train.default, (xe, w_ih, w_hh, b_ih, b_hh, lens), test_utils=basic)
     wds, sent, acts = T.bilstm_train(xe, w_ih, w_hh, b_ih, b_hh, lens)

@@ -291,6 +291,39 @@ def test_bilstm_golden(ops_small):
     assert torch.equal(w2, words) and torch.equal(s2, sent)
 
 
+def test_rnn_encoder_gru_branch_golden():
+    """RNN_ENCODER with cfg.RNN_TYPE = 'GRU' (util.py:207-211): the drop-in module loads the reference's state_dict and reproduces
+    the reference's own outputs (enc_gru.npz) through tgsr_gru_gate_table + tgsr_bigru_table_fwd; host lengths give T_max
+    columns, device lengths the full caption width with zeros behind each caption (what a captured step uses): same values."""
+    import os
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.util import RNN_ENCODER
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "enc_gru.npz"))
+    cfg_reset()
+    cfg.RNN_TYPE = "GRU"
+    try:
+        for tag, nhidden in (("a", 256), ("b", 64)):
+            pre = "gru_%s." % tag
+            sd = {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre)}
+            enc = RNN_ENCODER(41, nhidden=nhidden).to(DEV).eval()
+            enc.load_state_dict({k: v for k, v in sd.items() if k.startswith(("encoder.", "rnn."))}, strict=True)
+            cap, lens = sd["captions"].to(DEV), sd["cap_lens"].tolist()
+            with torch.no_grad():
+                we, se = enc(cap, lens, enc.init_hidden(len(lens)))
+                wf, sf = enc(cap, torch.tensor(lens, dtype=torch.int32, device=DEV), None)
+            close(we, sd["words_emb"], atol=1e-5)
+            close(se, sd["sent_emb"], atol=1e-5)
+            T_ = max(lens)
+            assert tuple(wf.shape) == (len(lens), nhidden, cap.shape[1]) and torch.equal(wf[:, :, :T_], we) and torch.equal(sf, se)
+            assert float(wf[:, :, T_:].abs().max()) == 0 if T_ < cap.shape[1] else True
+            for b, n in enumerate(lens):                                     # zeros behind every caption
+                assert float(we[b, :, n:].abs().max()) == 0 if n < T_ else True
+            with pytest.raises(NotImplementedError):
+                enc.train()(cap, lens, None)
+    finally:
+        cfg_reset()
+
+
 def test_func_attention_golden(ops_small):
     from tgsr_amd import ops
     g = ops_small

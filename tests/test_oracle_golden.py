@@ -73,6 +73,20 @@ def test_rnn_encoder(ops_small):
     close(s, g["enc.sent_emb"], atol=1e-6)
 
 
+def test_rnn_encoder_gru_branch():
+    """util.py:207-211 (cfg.RNN_TYPE == 'GRU'): the oracle's explicit packed-sequence GRU against the reference's own
+    RNN_ENCODER run with that flag (tests/golden/enc_gru.npz, make_golden.py gen_gru): H = 128 with ragged captions incl. a
+    one-word one, H = 32 at batch 1."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "enc_gru.npz"))
+    for tag in ("a", "b"):
+        sd = {k[len("gru_%s." % tag):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("gru_%s." % tag)}
+        we, se = O.rnn_encoder_gru(sd, sd["captions"], sd["cap_lens"])
+        assert tuple(we.shape) == tuple(sd["words_emb"].shape)
+        np.testing.assert_allclose(we.numpy(), sd["words_emb"].numpy(), atol=1e-6)
+        np.testing.assert_allclose(se.numpy(), sd["sent_emb"].numpy(), atol=1e-6)
+
+
 def test_ca_net_kl_mse(ops_small):
     g = ops_small
     mu, lv = O.ca_net(split_sd(g, "ca."), T(g["enc.sent_emb"]), p="")

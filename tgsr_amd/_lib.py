@@ -75,6 +75,8 @@ SIGNATURES = {
     "tgsr_bn_train_fwd_from_stats": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp,
                                           _vp, _i64, _vp, _vp]),
     "tgsr_text_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "tgsr_gru_gate_table": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "tgsr_bigru_table_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "tgsr_lp_att_pack_bytes": (_i64, [_i, _i]),
     "tgsr_text_tail_lp_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "tgsr_lp_stem_att_fwd": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

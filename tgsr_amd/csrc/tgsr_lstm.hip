@@ -479,6 +479,104 @@ extern "C" int tgsr_lstm_gate_table(const float* emb, int ntoken, int ninput, co
   return note_launch(hipGetLastError(), "lstm_input_gates_kernel(table)");
 }
 
+// ------------------------------------------------------------------------------------------------------------ GRU
+// RNN_ENCODER with cfg.RNN_TYPE == 'GRU' (util.py:207-211): 1-layer bidirectional torch.nn.GRU, eval mode, over a per-token
+// gate table [ntoken][2][3H] = emb[tok] . w_ih[d]^T + b_ih[d] + (b_hr, b_hz, 0)[d] (tgsr_gru_gate_table: the r / z halves of
+// b_hh fold into the table; b_hn stays inside r * (W_hn h + b_hn)).  grid (B, 2), block 3H threads: thread j holds row j of
+// W_hh[d] in registers (gate order r, z, n), one mat-vec + one gate pass per step, packed-sequence semantics as the LSTM.
+template <int H>
+__global__ __launch_bounds__(3 * H) void gru_recurrent_kernel(const float* __restrict__ table,
+                                                              const int32_t* __restrict__ cap_lens, int Tmax,
+                                                              const float* __restrict__ w_hh, const float* __restrict__ b_hn,
+                                                              float* __restrict__ words_emb, float* __restrict__ sent_emb,
+                                                              const int64_t* __restrict__ captions, int width, int ntoken) {
+  __shared__ __attribute__((aligned(16))) float h_s[H];
+  __shared__ float g_s[3 * H];                 // r, z pre-activations; W_hn h + b_hn
+  __shared__ float xn_s[H];                    // W_in x + b_in of the step
+  const int b = blockIdx.x, d = blockIdx.y, j = threadIdx.x;
+  int len = cap_lens[b];
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  float w[H];
+  {
+    const float4* wr = reinterpret_cast<const float4*>(w_hh + ((int64_t)d * 3 * H + j) * H);
+#pragma unroll
+    for (int k = 0; k < H / 4; ++k) {
+      const float4 v = wr[k];
+      w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+    }
+  }
+  const float bn = j >= 2 * H ? b_hn[d * H + j - 2 * H] : 0.f;
+  float hcur = 0.f;
+  if (j < H) h_s[j] = 0.f;
+  float* wout = words_emb + ((int64_t)b * 2 * H + d * H + (j < H ? j : 0)) * Tmax;
+  if (j < H)
+    for (int t = len; t < Tmax; ++t) wout[t] = 0.f;
+  __syncthreads();
+  for (int s = 0; s < len; ++s) {
+    const int t = d == 0 ? s : len - 1 - s;
+    const int64_t v = captions[(int64_t)b * width + t];
+    const int64_t row = (v < 0 || v >= ntoken) ? 0 : v;
+    const float x = table[(row * 2 + d) * 3 * H + j];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;            // four independent chains, combined pairwise (as the LSTM kernel)
+#pragma unroll
+    for (int k = 0; k < H / 4; ++k) {
+      const float4 hv = *reinterpret_cast<const float4*>(h_s + 4 * k);
+      g0 = fmaf(w[4 * k], hv.x, g0);
+      g1 = fmaf(w[4 * k + 1], hv.y, g1);
+      g2 = fmaf(w[4 * k + 2], hv.z, g2);
+      g3 = fmaf(w[4 * k + 3], hv.w, g3);
+    }
+    const float hd = (g0 + g1) + (g2 + g3);
+    if (j < 2 * H) {
+      g_s[j] = x + hd;
+    } else {
+      g_s[j] = hd + bn;
+      xn_s[j - 2 * H] = x;
+    }
+    __syncthreads();
+    if (j < H) {
+      const float r = fsig_(g_s[j]), z = fsig_(g_s[H + j]);
+      const float n = ftanh_(xn_s[j] + r * g_s[2 * H + j]);
+      hcur = (1.f - z) * n + z * hcur;
+      h_s[j] = hcur;
+      wout[t] = hcur;
+    }
+    __syncthreads();
+  }
+  if (j < H) sent_emb[(int64_t)b * 2 * H + d * H + j] = hcur;
+}
+
+extern "C" int tgsr_gru_gate_table(const float* emb, int ntoken, int ninput, const float* w_ih, const float* b_ih,
+                                   const float* b_hh_rz, int H, float* table, void* stream) {
+  if (!emb || !w_ih || !b_ih || !b_hh_rz || !table || ntoken < 1 || ninput < 1 || H < 1) return TGSR_EINVAL;
+  const int N = 6 * H;
+  hipLaunchKernelGGL(lstm_input_gates_kernel, dim3((N + 127) / 128, (ntoken + 31) / 32), dim3(256), 0,
+                     as_stream(stream), (const int64_t*)nullptr, 1, 1, emb, ntoken, w_ih, b_ih, b_hh_rz, ntoken, N, ninput,
+                     table);
+  return note_launch(hipGetLastError(), "lstm_input_gates_kernel(gru table)");
+}
+
+extern "C" int tgsr_bigru_table_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax,
+                                    const float* table, int ntoken, const float* w_hh, const float* b_hn, int H,
+                                    float* words_emb, float* sent_emb, void* stream) {
+  if (!captions || !cap_lens || !table || !w_hh || !b_hn || !words_emb || !sent_emb) return TGSR_EINVAL;
+  if (B < 1 || Tmax < 1 || Tmax > width || ntoken < 1 || H < 1) return TGSR_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const dim3 grid(B, 2);
+  if (H == 128)
+    hipLaunchKernelGGL(gru_recurrent_kernel<128>, grid, dim3(384), 0, s, table, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
+                       captions, width, ntoken);
+  else if (H == 64)
+    hipLaunchKernelGGL(gru_recurrent_kernel<64>, grid, dim3(192), 0, s, table, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
+                       captions, width, ntoken);
+  else if (H == 32)
+    hipLaunchKernelGGL(gru_recurrent_kernel<32>, grid, dim3(96), 0, s, table, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
+                       captions, width, ntoken);
+  else
+    return TGSR_EUNSUPPORTED;
+  return note_launch(hipGetLastError(), "gru_recurrent_kernel");
+}
+
 extern "C" int tgsr_bilstm_table_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax,
                                      const float* table, int ntoken, const float* w_hh, int H, float* words_emb,
                                      float* sent_emb, void* stream) {

@@ -353,6 +353,19 @@ bilstm_table_static = _define("bilstm_table_static(Tensor captions, Tensor cap_l
                               lambda c, lens, table, w_hh: ops.bilstm_table(c, lens, table, w_hh),
                               lambda c, lens, table, w_hh: (table.new_empty(c.shape[0], 2 * w_hh.shape[2], c.shape[1]),
                                                             table.new_empty(c.shape[0], 2 * w_hh.shape[2])))
+# the GRU branch of RNN_ENCODER (util.py:207-211), eval mode
+gru_gate_table = _define("gru_gate_table(Tensor emb, Tensor w_ih, Tensor b_ih, Tensor b_hh) -> (Tensor, Tensor)",
+                         lambda e, w, bi, bh: ops.gru_gate_table(e, w, bi, bh),
+                         lambda e, w, bi, bh: (e.new_empty(e.shape[0], 2, w.shape[1]), e.new_empty(2, w.shape[1] // 3)))
+bigru_table = _define("bigru_table(Tensor captions, int[] cap_lens, Tensor table, Tensor w_hh, Tensor b_hn) -> (Tensor, Tensor)",
+                      lambda c, lens, table, w_hh, b_hn: ops.bigru_table(c, list(lens), table, w_hh, b_hn),
+                      lambda c, lens, table, w_hh, b_hn: (table.new_empty(c.shape[0], 2 * w_hh.shape[2], max(lens)),
+                                                          table.new_empty(c.shape[0], 2 * w_hh.shape[2])))
+bigru_table_static = _define("bigru_table_static(Tensor captions, Tensor cap_lens, Tensor table, Tensor w_hh, Tensor b_hn) -> "
+                             "(Tensor, Tensor)",
+                             lambda c, lens, table, w_hh, b_hn: ops.bigru_table(c, lens, table, w_hh, b_hn),
+                             lambda c, lens, table, w_hh, b_hn: (table.new_empty(c.shape[0], 2 * w_hh.shape[2], c.shape[1]),
+                                                                 table.new_empty(c.shape[0], 2 * w_hh.shape[2])))
 lstm_gate_table = _define("lstm_gate_table(Tensor emb, Tensor w_ih, Tensor b_ih, Tensor b_hh) -> Tensor",
                           lambda e, w, bi, bh: ops.lstm_gate_table(e, w, bi, bh),
                           lambda e, w, bi, bh: e.new_empty(e.shape[0], 2, w.shape[1]))

@@ -519,6 +519,46 @@ def lstm_gate_table(emb, w_ih, b_ih, b_hh):
     return table
 
 
+def gru_gate_table(emb, w_ih, b_ih, b_hh):
+    """[ntoken, 2, 3H] gate pre-activations of every token for the GRU encoder (tgsr_gru_gate_table): b_hh's r and z thirds
+    fold into the table, its n third stays with the recurrence (returned as b_hn [2, H])."""
+    _need_hip(emb, w_ih, b_ih, b_hh)
+    ts = [_f32(t.detach(), "gru tensor").contiguous() for t in (emb, w_ih, b_ih, b_hh)]
+    H = w_ih.shape[1] // 3
+    b_rz = ts[3].clone()
+    b_rz[:, 2 * H:] = 0
+    b_hn = ts[3][:, 2 * H:].contiguous()
+    table = torch.empty(emb.shape[0], 2, 3 * H, dtype=torch.float32, device=emb.device)
+    check(_lib.lib().tgsr_gru_gate_table(_p(ts[0]), emb.shape[0], emb.shape[1], _p(ts[1]), _p(ts[2]), _p(b_rz), H, _p(table),
+                                         _stream()), "tgsr_gru_gate_table")
+    return table, b_hn
+
+
+def bigru_table(captions, cap_lens, table, w_hh, b_hn):
+    """The bidirectional GRU recurrence over a per-token gate table (one launch): (words_emb, sent_emb); cap_lens on the host
+    (-> T_max columns) or as a device int32 tensor (-> full caption width, see bilstm_table)."""
+    _need_hip(captions, table, w_hh, b_hn)
+    B, width = captions.shape
+    H, dev = w_hh.shape[2], table.device
+    if torch.is_tensor(cap_lens) and cap_lens.is_cuda:
+        if cap_lens.dtype != torch.int32 or cap_lens.numel() != B or not cap_lens.is_contiguous():
+            raise TgsrError("bigru: device cap_lens must be a contiguous int32 [%d] tensor" % B)
+        Tmax, lens_d = width, cap_lens
+    else:
+        lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+        if len(lens) != B or min(lens) < 1 or max(lens) > width:
+            raise TgsrError("bigru: cap_lens %s invalid for captions %s" % (lens, tuple(captions.shape)))
+        Tmax, lens_d = max(lens), _lens_on_device(tuple(lens), dev)
+    captions = captions.to(torch.int64).contiguous()
+    words = torch.empty(B, 2 * H, Tmax, dtype=torch.float32, device=dev)
+    sent = torch.empty(B, 2 * H, dtype=torch.float32, device=dev)
+    rc = _lib.lib().tgsr_bigru_table_fwd(_p(captions), width, _p(lens_d), B, Tmax, _p(table), table.shape[0],
+                                         _p(_f32(w_hh.detach(), "w_hh").contiguous()), _p(_f32(b_hn, "b_hn").contiguous()), H,
+                                         _p(words), _p(sent), _stream())
+    check(rc, "tgsr_bigru_table_fwd")
+    return words, sent
+
+
 def bilstm_table(captions, cap_lens, table, w_hh):
     """The BiLSTM recurrence over a per-token gate table (one launch).  Returns (words_emb, sent_emb).
 

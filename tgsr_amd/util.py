@@ -311,13 +311,15 @@ class RNN_ENCODER(nn.Module):
         self.nlayers = nlayers
         self.bidirectional = bidirectional
         self.rnn_type = cfg.RNN_TYPE
-        if self.rnn_type != 'LSTM' or nlayers != 1 or not bidirectional:
-            raise NotImplementedError("HIP text encoder: 1-layer bidirectional LSTM only (the shipped configuration)")
+        if self.rnn_type not in ('LSTM', 'GRU') or nlayers != 1 or not bidirectional:
+            raise NotImplementedError("HIP text encoder: 1-layer bidirectional LSTM / GRU (util.py:199-211; every shipped "
+                                      "configuration is a 1-layer bidirectional LSTM)")
         self.num_directions = 2
         self.nhidden = nhidden // self.num_directions
         self.encoder = nn.Embedding(self.ntoken, self.ninput)
         self.drop = nn.Dropout(self.drop_prob)
-        self.rnn = nn.LSTM(self.ninput, self.nhidden, self.nlayers, batch_first=True, bidirectional=True)
+        rnn = nn.LSTM if self.rnn_type == 'LSTM' else nn.GRU             # util.py:199-211 (same parameter names: state_dict keys)
+        self.rnn = rnn(self.ninput, self.nhidden, self.nlayers, batch_first=True, bidirectional=True)
         self.init_weights()
         self._key = None
         self._stacked = None
@@ -330,7 +332,7 @@ class RNN_ENCODER(nn.Module):
     def init_hidden(self, bsz):
         w = next(self.parameters()).data
         z = w.new_zeros(self.nlayers * self.num_directions, bsz, self.nhidden)
-        return (z, z.clone())
+        return (z, z.clone()) if self.rnn_type == 'LSTM' else z          # util.py:222-231
 
     def _weights(self):
         r = self.rnn
@@ -347,6 +349,8 @@ class RNN_ENCODER(nn.Module):
     def forward(self, captions, cap_lens, hidden=None, mask=None):
         """captions int64 [B, n_steps] sorted by length (desc), cap_lens [B] -> (words_emb [B, 2H, T_max],
         sent_emb [B, 2H]).  `hidden` must be the zero state of init_hidden (the only use in the reference)."""
+        if self.rnn_type == 'GRU':
+            return self._forward_gru(captions, cap_lens)
         if self.training:
             # util.py:236-252: emb = drop(encoder(captions)) (torch embedding + dropout: their gradients are
             # autograd's), then the LSTM through its HIP forward / BPTT kernels (autograd.BiLSTM)
@@ -374,6 +378,28 @@ class RNN_ENCODER(nn.Module):
             lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
             return C.bilstm_table(captions, lens, self._table, w_hh)
         return ops.bilstm(captions, cap_lens, self.encoder.weight, w_ih, w_hh, b_ih, b_hh)
+
+
+def _rnn_encoder_forward_gru(self, captions, cap_lens):
+    """The GRU branch (util.py:207-211, 244-258), eval mode: a per-token gate table built once per weight version, then ONE
+    recurrence launch per batch (tgsr_bigru_table_fwd).  No shipped configuration selects GRU and nothing trains it here:
+    `.train()` raises (the LSTM branch has the HIP backward, autograd.BiLSTM)."""
+    if self.training:
+        raise NotImplementedError("RNN_ENCODER(GRU).train(): the HIP text encoder trains the LSTM branch only")
+    w_ih, w_hh, b_ih, b_hh = self._weights()
+    key = (self._key, _ver(self.encoder.weight))
+    if key != self._table_key:
+        self._table = C.gru_gate_table(self.encoder.weight.detach(), w_ih, b_ih, b_hh)      # (table, b_hn)
+        self._table_key = key
+    table, b_hn = self._table
+    if torch.is_tensor(cap_lens) and cap_lens.is_cuda:
+        lens_d = cap_lens if cap_lens.dtype == torch.int32 else cap_lens.to(torch.int32)
+        return C.bigru_table_static(captions, lens_d.contiguous(), table, w_hh, b_hn)
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    return C.bigru_table(captions, lens, table, w_hh, b_hn)
+
+
+RNN_ENCODER._forward_gru = _rnn_encoder_forward_gru
 
 
 _INCEPTION_BLOCKS = ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3", "Conv2d_3b_1x1", "Conv2d_4a_3x3", "Mixed_5b", "Mixed_5c",
