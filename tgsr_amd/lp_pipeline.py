@@ -210,7 +210,7 @@ class LpExecutor:
         wide = bufs["gl"][0]["wide"]
         B, H0, W0 = LR.shape[0], LR.shape[2], LR.shape[3]
         # The attention of stage k rides the kernel that produces its h when the step brought the attention pack
-        # (SRPipeline._text_tail -> proj.att_pack) and the shapes allow: att_args(k, attn) = the producer's extra arguments
+        # (SRPipeline._text_tail -> proj.att_pack) and the shapes allow: att_args(k) = the producer's extra arguments
         pack = getattr(proj, "att_pack", None) if self.fuse_attention else None
 
         def att_args(k):
