@@ -308,10 +308,10 @@ def test_full_size_gan_train_step_parity(face_weights):
         for leg in ("G+D+MSE+KL", "+DAMSM"):
             if leg == "+DAMSM":
                 tr.image_encoder = enc                    # every learning rate is 0: the weights are those of leg one
-                want = float(refG) + float(refR)
+                want = float(refG.detach()) + float(refR)
                 ref_grad = lambda v: v.grad
             else:
-                want = float(refG)
+                want = float(refG.detach())
                 ref_grad = lambda v: grads0[id(v)]
             errG, errsD = tr.step_gan(*args, class_ids=class_ids if leg == "+DAMSM" else None)
             torch.cuda.synchronize()
