@@ -34,6 +34,9 @@ def _neighbours(g, B=16):
     xf = R(B, 64, 64, 64)
     upf = ops.pack_wino_weight(R(128, 64, 3, 3) * 0.1, True, False)
     out["fp32 wino 64->128 glu @64^2"] = lambda: ops.conv3x3_wino(xf, upf, 128, sc3, sh3, True, None)
+    xf4 = R(B, 64, 128, 128)
+    upf4 = ops.pack_wino4_weight(R(128, 64, 3, 3) * 0.1, True)
+    out["fp32 wino4 64->128 glu @128^2"] = lambda: ops.conv3x3_wino4(xf4, upf4, 128, sc3, sh3, True, None)
     return out
 
 
@@ -66,6 +69,9 @@ def _victims(g, B=16):
     xw = R(B, 32, 32, 32)
     upw = ops.pack_wino_weight(R(64, 32, 3, 3) * 0.1, True, False)
     v["fp32 wino 32->64 glu @32^2"] = lambda: ops.conv3x3_wino(xw, upw, 64, sc64, sh64, True, None).flatten()
+    xw4 = R(2, 32, 64, 64)
+    upw4 = ops.pack_wino4_weight(R(64, 32, 3, 3) * 0.1, True)
+    v["fp32 wino4 32->64 glu @64^2"] = lambda: ops.conv3x3_wino4(xw4, upw4, 64, sc64, sh64, True, None).flatten()
     hf, wf, wc = R(B, 32, 32, 32), R(B, 256, T), R(32, 256)
     v["fp32 word attention @32^2"] = lambda: torch.cat([t.flatten() for t in ops.word_attention(hf, wf, wc, None)])
     xh, wh = R(B, 32, 64, 64), R(3, 32, 3, 3) * 0.1

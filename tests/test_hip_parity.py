@@ -186,6 +186,88 @@ def test_conv3x3_winograd(B, Cin, H, W, Cout, glu, res):
     close(out, ref, atol=3e-5, rtol=3e-5)
 
 
+WINO4_CASES = [
+    # B, Cin, H, W, Cout, glu, res
+    (2, 64, 128, 128, 128, True, False),   # the 128^2 ResBlock convolutions of G_SR_NET_low
+    (2, 64, 128, 128, 64, False, True),
+    (1, 4, 8, 64, 64, False, False),       # one stage, one workgroup
+    (2, 8, 16, 64, 64, True, False),       # two stages
+    (1, 12, 12, 68, 128, False, True),     # ragged rows / columns (W % 4 == 0), two channel groups
+    (1, 20, 5, 8, 64, True, False),        # image smaller than one tile row
+    (3, 32, 40, 132, 192, False, True),    # three channel groups, ragged
+    (1, 64, 256, 256, 64, True, False),    # the x16 generator's 256^2 stage
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,glu,res", WINO4_CASES)
+def test_conv3x3_winograd4(B, Cin, H, W, Cout, glu, res):
+    """F(4x4, 3x3): against F.conv2d in fp64.  Stated bound 1e-4 on unit-scale data (measured 1.6e-5 .. 3.4e-5; F(2x2) on
+    the same inputs 7e-7 .. 1.8e-6 - the price of 36 instead of 64 multiplies per 16 outputs)."""
+    from tgsr_amd import ops, custom_ops as C
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.3 * torch.randn(Cout, generator=g)
+    co = Cout // 2 if glu else Cout
+    r = torch.randn(B, co, H, W, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1) * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    ref = ref[:, :co] * torch.sigmoid(ref[:, co:]) if glu else ref
+    ref = ref + r.double() if res else ref
+    up = ops.pack_wino4_weight(w.to(DEV), glu=glu)
+    out = ops.conv3x3_wino4(x.to(DEV), up, Cout, scale.to(DEV), shift.to(DEV), glu=glu, residual=None if r is None else r.to(DEV))
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 1e-4, err
+    again = ops.conv3x3_wino4(x.to(DEV), up, Cout, scale.to(DEV), shift.to(DEV), glu=glu, residual=None if r is None else r.to(DEV))
+    assert torch.equal(out, again)
+    # the raw convolution (no affine), as the custom op
+    raw = C.conv3x3_wino4(x.to(DEV), ops.pack_wino4_weight(w.to(DEV), glu=False), Cout, None, None, False, None)
+    assert float((raw.cpu().double() - F.conv2d(x.double(), w.double(), None, 1, 1)).abs().max()) < 1e-4
+
+
+def test_conv3x3_winograd4_channel_slices_and_refusals():
+    """Reads from a channel slice, writes into one (batch strides of the wider tensors); misaligned tensors and
+    unsupported channel counts are refused, not mis-read."""
+    from tgsr_amd import ops
+    from tgsr_amd._lib import TgsrError
+    g = torch.Generator().manual_seed(11)
+    wide_in = torch.randn(2, 96, 16, 64, generator=g).to(DEV)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    wide_out = torch.full((2, 80, 16, 64), 7.0, device=DEV)
+    up = ops.pack_wino4_weight(w.to(DEV), glu=True)
+    ops.conv3x3_wino4(wide_in[:, 32:], up, 128, None, None, glu=True, out=wide_out[:, 8:72])
+    ref = O.glu(F.conv2d(wide_in[:, 32:].cpu().double(), w.double(), None, 1, 1))
+    assert float((wide_out[:, 8:72].cpu().double() - ref).abs().max()) < 1e-4
+    assert (wide_out[:, :8] == 7).all() and (wide_out[:, 72:] == 7).all()
+    with pytest.raises(TgsrError):
+        ops.pack_wino4_weight(torch.randn(32, 64, 3, 3, device=DEV))                    # Cout % 64
+    with pytest.raises(TgsrError):
+        ops.conv3x3_wino4(wide_in[:, 32:, :, 1:63], up, 128, None, None, glu=True)     # not contiguous rows / W % 4
+    with pytest.raises(TgsrError):
+        ops.conv3x3_wino4(wide_in[:, :32], up, 128, None, None, glu=True)              # pack made for 64 input channels
+
+
+def test_wino4_routing_follows_the_size_policy(monkeypatch):
+    """util._conv_bn sends the >= 128 x 128 layers to F(4x4) and everything else to F(2x2) / the direct kernel; TGSR_WINO4=0
+    keeps F(2x2) everywhere."""
+    from tgsr_amd import util, custom_ops as C
+    calls = []
+    real4, real2 = C.conv3x3_wino4, C.conv3x3_wino
+    monkeypatch.setattr(C, "conv3x3_wino4", lambda *a: (calls.append(4), real4(*a))[1])
+    monkeypatch.setattr(C, "conv3x3_wino", lambda *a: (calls.append(2), real2(*a))[1])
+    conv = torch.nn.Conv2d(64, 128, 3, 1, 1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(128).to(DEV).eval()
+    fp = util._FusedParams()
+    big, small = torch.randn(1, 64, 128, 128, device=DEV), torch.randn(1, 64, 64, 64, device=DEV)
+    y4 = util._conv_bn(big, fp, conv, bn, glu=True)
+    util._conv_bn(small, fp, conv, bn, glu=True)
+    assert calls == [4, 2]
+    monkeypatch.setenv("TGSR_WINO4", "0")
+    y2 = util._conv_bn(big, fp, conv, bn, glu=True)
+    assert calls == [4, 2, 2]
+    assert float((y4 - y2).abs().max()) < 1e-4
+
+
 def test_conv3x3_channel_slice_io():
     """Reads from / writes into channel slices of wider buffers (how torch.cat disappears)."""
     from tgsr_amd import ops
@@ -552,7 +634,10 @@ def test_full_size_batch16_vs_oracle(face_weights, cfg_face):
     p.netGL.h_net1.att.correct_mask = p.netGL.h_net2.att.correct_mask = p.netGL.h_net3.att.correct_mask = True
     full = p(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))["fine"][2]
     half = p(cap[:8].to(DEV), lens[:8].tolist(), LR[:8].to(DEV), LRb[:8].to(DEV))["fine"][2]
-    assert torch.equal(full[:8], half) or float((full[:8] - half).abs().max()) < 1e-5
+    # (not bitwise: a few kernels pick their tile shape by workgroup count, i.e. by batch - different summation orders, 1e-7 -
+    # and the F(4x4) convolutions of the 128^2 stage turn any such difference into one of the size of their own rounding noise,
+    # 1.5e-5 measured; a leak between samples - batch statistics, the mask quirk - would be 1e-2)
+    assert torch.equal(full[:8], half) or float((full[:8] - half).abs().max()) < 5e-5
     again = p(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))["fine"][2]
     assert torch.equal(full, again)
 

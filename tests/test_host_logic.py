@@ -187,3 +187,16 @@ def test_lazy_log_is_opt_in_and_formats_like_the_reference():
     text = "g_loss0: 1.50000 w_loss: 2.00000 s_loss: 3.00000 "
     assert str(log) == text and log == text and "w_loss" in log and len(log) == len(text) and log[:7] == "g_loss0"
     assert ("" + log) == text and (log + "x") == text + "x" and "%s" % log == text and log._parts is None
+
+
+def test_wino4_size_policy(monkeypatch):
+    """Which conv3x3 layers the inference path sends to the F(4x4, 3x3) kernel: whole 8 x 64 tiles, 64-channel groups and - the
+    numerics policy of tgsr_winograd4.hip - only images of >= 128 x 128 pixels; TGSR_WINO4=0 switches it off."""
+    from tgsr_amd import ops
+    monkeypatch.delenv("TGSR_WINO4", raising=False)
+    assert ops.wino4_wanted(64, 128, 128, 128) and ops.wino4_wanted(64, 64, 128, 128) and ops.wino4_wanted(64, 64, 256, 256)
+    assert not ops.wino4_wanted(64, 128, 64, 64) and not ops.wino4_wanted(64, 128, 32, 32)       # the policy
+    assert not ops.wino4_wanted(64, 32, 128, 128) and not ops.wino4_wanted(3, 64, 128, 128)      # channel groups / stages
+    assert not ops.wino4_wanted(64, 64, 128, 160) and not ops.wino4_wanted(64, 64, 132, 128)     # whole tiles
+    monkeypatch.setenv("TGSR_WINO4", "0")
+    assert not ops.wino4_wanted(64, 128, 128, 128)

@@ -1,0 +1,390 @@
+// 3x3 convolution (stride 1, pad 1) by Winograd F(4x4, 3x3) in fp32 on the MFMA units, same fused epilogues as
+// tgsr_winograd.hip (BatchNorm-eval affine, GLU | residual).  Serves the LARGE layers of the inference path - the 128^2
+// ResBlocks of G_SR_NET_low (util.py:110-130 behind NEXT_STAGE_G util.py:814-821), which carry 60 % of a forward's
+// convolution time:
+//
+//   Y(4x4) = A^T [ (G g G^T) (.) (B^T d B) ] A     per 6x6 input tile d, 3x3 filter g, interpolation points 0, +-1, +-2, inf:
+// 36 multiplies per 16 outputs instead of 144 - 1.78x fewer MFMAs than F(2x2, 3x3), 4x fewer than the direct form.
+// Numerics: the transforms hold 4, 5, 8 and 1/24 where F(2x2) holds 1 and 1/2; measured end to end on the shipped
+// checkpoint (oracle with this algorithm in fp32 on the 128^2 layers vs the fp64 oracle) the finest image
+// moves 3.07e-5 -> 3.35e-5 max, 5.4e-7 -> 5.5e-7 mean (stated tolerance 1e-4); used on the 64^2 and 32^2 layers as well
+// it would be 2.1e-4 - the launcher's callers (ops.wino4_wanted) therefore only route layers of >= 128 x 128 pixels here.
+//
+// Geometry.  MFMA 16x16x4, one accumulator per transformed position: a wave owns 16 tiles (one tile row = 4 x 64 output
+// pixels) x 16 output channels x 36 positions = 144 accumulator registers; a workgroup = 8 waves = 2 tile rows (g) x 4
+// channel blocks (cb) = 8 x 64 outputs x 64 couts, one workgroup per CU (two waves per SIMD).
+//   stage = 4 input channels = one MFMA k-step per position (36 MFMAs per wave).
+//   U   [9 quads][4 ci][4 cb][16 couts][4 positions] (36 KB, double buffered): a linear LDS-DMA copy of the pre-transformed
+//       pack; one ds_read_b128 = a lane's A operands of 4 positions.
+//   raw [4 ci][10 rows][72 cols] in planes of 768 floats (12 KB, double buffered; LDS-DMA in 16-byte pieces, the tile
+//       starts 4 columns left of the outputs so that every piece is aligned and wholly inside or outside the image;
+//       768 = 0 mod 64 banks: the transform's ds_read_b128 of 16 neighbouring tiles x 4 channels is conflict free).
+//   V   per tile row [9 quads][4 ci][16 tiles][4 positions] (9 KB, double buffered): the input transform B^T d B of one
+//       (tile, channel) per lane, split over the waves cb = 0, 1, 2 of the tile row by ROWS of B^T - {0, 5}, {1, 2},
+//       {3, 4}: 48 VALU operations each - one stage ahead; a quad = 4 consecutive of a wave's 12 values, which fixes the
+//       order of the 36 positions everywhere (w4_pos).
+// One barrier per stage; the copies of a stage (U(st+1), raw(st+2)) are issued at its start and have landed at its end:
+// a stage is ~3 k cycles (2 x 36 MFMAs of 32 cycles per SIMD), longer than a DMA round trip.  LDS 133 KB.
+// GLU: a channel block holds 8 value channels and their 8 gates, ordered so that a lane's four accumulator registers
+// are (value, value, gate, gate) of two output channels - the gate never leaves the lane.
+#include "tgsr_common.h"
+
+#include <type_traits>
+
+namespace tgsr {
+
+typedef __attribute__((address_space(3))) void* lds_ptr4_t;
+__device__ __attribute__((aligned(16))) float g_wino4_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct Wino4Args {
+  const float* x;
+  int64_t xbs;
+  int B, Cin, H, W;
+  const float* upack;     // [stage][group][quad 9][ci 4][cb 4][16][4]
+  int Cout;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  int64_t rbs;
+  float* out;
+  int64_t obs;
+  int tiles_x, tiles_y, nstages, ngroups;
+};
+
+constexpr int k4CK = 4;                                   // input channels per stage
+constexpr int k4TC = 72;                                  // raw tile columns: 64 + 8
+constexpr int k4TR = 10;                                  // raw tile rows: 8 + 2
+constexpr int k4PLANE = 768;                              // floats per channel plane (720 used)
+constexpr int k4RAW = k4CK * k4PLANE;                     // 3072 floats = 12 DMA pieces of 1 KB
+constexpr int k4U = 9 * k4CK * 64 * 4;                    // 9216 floats = 36 pieces
+constexpr int k4V = 9 * k4CK * 16 * 4;                    // 2304 floats per tile row
+constexpr int k4SMEM = 2 * k4U + 2 * k4RAW + 4 * k4V + 128;
+
+// The order of the 36 transformed positions: the wave that computes rows (ra, rb) of V = B^T d B produces 12 values
+// [ra][0..5], [rb][0..5] = 3 quads; waves 0, 1, 2 of a tile row take the row pairs (0, 5), (1, 2), (3, 4).
+__host__ __device__ constexpr int w4_row(int q, int e) {
+  return (q / 3 == 0) ? ((4 * (q % 3) + e) / 6 ? 5 : 0) : ((q / 3 == 1) ? ((4 * (q % 3) + e) / 6 ? 2 : 1) : ((4 * (q % 3) + e) / 6 ? 4 : 3));
+}
+__host__ __device__ constexpr int w4_col(int q, int e) { return (4 * (q % 3) + e) % 6; }
+__host__ __device__ constexpr int w4_pos(int i, int j) {   // accumulator index (4 * quad + element) of position (i, j)
+  return (3 * ((i == 0 || i == 5) ? 0 : ((i == 1 || i == 2) ? 1 : 2)) + (((i == 5 || i == 2 || i == 4) ? 6 : 0) + j) / 4) * 4 +
+         (((i == 5 || i == 2 || i == 4) ? 6 : 0) + j) % 4;
+}
+
+typedef float f32x4w4 __attribute__((ext_vector_type(4)));
+
+// one 1-D pass of the input transform restricted to a row pair: R = 0: rows 0, 5; 1: rows 1, 2; 2: rows 3, 4 of
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+template <int R>
+__device__ __forceinline__ void w4_bt_pair(float d0, float d1, float d2, float d3, float d4, float d5, float& oa, float& ob) {
+  if (R == 0) {
+    oa = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    ob = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+  } else if (R == 1) {
+    const float p = fmaf(-4.f, d2, d4), q = fmaf(-4.f, d1, d3);
+    oa = p + q;
+    ob = p - q;
+  } else {
+    const float p = d4 - d2, q = d3 - d1;
+    oa = fmaf(2.f, q, p);
+    ob = fmaf(-2.f, q, p);
+  }
+}
+// a full 1-D pass (all six rows of B^T) of one 6-vector
+__device__ __forceinline__ void w4_bt_full(const float (&t)[6], float (&o)[6]) {
+  o[0] = fmaf(4.f, t[0], fmaf(-5.f, t[2], t[4]));
+  const float p1 = fmaf(-4.f, t[2], t[4]), q1 = fmaf(-4.f, t[1], t[3]);
+  o[1] = p1 + q1;
+  o[2] = p1 - q1;
+  const float p2 = t[4] - t[2], q2 = t[3] - t[1];
+  o[3] = fmaf(2.f, q2, p2);
+  o[4] = fmaf(-2.f, q2, p2);
+  o[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));
+}
+// A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] applied to one 6-vector
+__device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
+  const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+  y[0] = m0 + s1 + s2;
+  y[1] = fmaf(2.f, d2, d1);
+  y[2] = fmaf(4.f, s2, s1);
+  y[3] = fmaf(8.f, d2, d1) + m5;
+}
+
+template <bool GLU>
+__global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
+  __shared__ __attribute__((aligned(16))) float smem[k4SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, cb = wave & 3;                // tile row / channel block of this wave
+  int t = xcd_remap(blockIdx.x, gridDim.x);              // the cout groups of a tile run back to back on one XCD
+  const int grp = t % a.ngroups;
+  t /= a.ngroups;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int y0 = ty * 8, x0 = tx * 64;
+  const float* xb = a.x + (int64_t)b * a.xbs;
+  const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
+  float* us = smem;
+  float* raws = smem + 2 * k4U;
+  float* vs = smem + 2 * k4U + 2 * k4RAW + g * 2 * k4V;  // this tile row's two V images
+  float* aff_s = smem + 2 * k4U + 2 * k4RAW + 4 * k4V;
+
+  // ---- DMA plan: 48 pieces of 1 KB per stage, six per wave.  raw: piece `wave`, and 8 + wave on waves 0-3; U: pieces
+  // wave + 8k (k < 4), and 28 + wave on waves 4-7.  Out-of-image (and plane padding) lanes read the zero block, stride 0.
+  const float* rptr[2];
+  int rstep[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = ((wave + 8 * k) * 64 + lane) * 4;      // first float of this lane's 16-byte piece
+    const int c = e / k4PLANE;
+    const int rem = e - c * k4PLANE;
+    const int r = rem / k4TC, j = rem - r * k4TC;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + j;
+    const bool ok = e < k4RAW && rem < k4TR * k4TC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // W % 4 == 0
+    rptr[k] = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino4_zero;
+    rstep[k] = ok ? (int)(k4CK * HW) : 0;
+  }
+  auto dma16 = [&](const float* gsrc, float* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr4_t)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
+  };
+  auto issue_raw = [&](int buf) {                        // stages 0, 1, 2, ... in order
+    dma16(rptr[0], raws + buf * k4RAW + wave * 256);
+    rptr[0] += rstep[0];
+    if (wave < 4) {
+      dma16(rptr[1], raws + buf * k4RAW + (8 + wave) * 256);
+      rptr[1] += rstep[1];
+    }
+  };
+  const float* ubase = a.upack + (int64_t)grp * k4U;     // stage 0 of this group
+  const int64_t ustride = (int64_t)a.ngroups * k4U;
+  auto issue_u = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      if (k < 4 || wave >= 4) {
+        const int piece = k < 4 ? wave + 8 * k : 28 + wave;
+        const unsigned off = (unsigned)((piece * 64 + lane) * 16);
+        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr4_t)(us + buf * k4U + piece * 256));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(ubase), "s"(l) : "memory");
+      }
+    }
+    ubase += ustride;
+  };
+
+  // ---- input transform of the row pair R = cb (cb = 3: none): lane = (tile l15, channel lg); the 6 x 6 patch of tile
+  // l15 of tile row g = raw rows 4g .. 4g + 5, raw columns 4 l15 + 3 .. 4 l15 + 8
+  const int rlane = lg * k4PLANE + (4 * g) * k4TC + 4 * l15;
+  const int vwl = (lg * 16 + l15) * 4;
+  auto t_read = [&](auto rc, const float* rawb, float (&d)[6][6]) {
+    constexpr int R = decltype(rc)::value;
+    const float* rp = rawb + rlane;
+#pragma unroll
+    for (int p = (R == 0 ? 0 : 1); p < (R == 0 ? 6 : 5); ++p) {
+      const f32x4w4 mid = *reinterpret_cast<const f32x4w4*>(rp + p * k4TC + 4);
+      d[p][0] = rp[p * k4TC + 3];
+      d[p][1] = mid[0]; d[p][2] = mid[1]; d[p][3] = mid[2]; d[p][4] = mid[3];
+      d[p][5] = rp[p * k4TC + 8];
+    }
+  };
+  auto t_write = [&](auto rc, const float (&d)[6][6], float* vdst) {
+    constexpr int R = decltype(rc)::value;
+    float ta[6], tb[6], oa[6], ob[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)                           // column pass: rows (ra, rb) of B^T d
+      w4_bt_pair<R>(R == 0 ? d[0][j] : 0.f, d[1][j], d[2][j], d[3][j], d[4][j], R == 0 ? d[5][j] : 0.f, ta[j], tb[j]);
+    w4_bt_full(ta, oa);                                   // row pass: all six columns of (B^T d) B
+    w4_bt_full(tb, ob);
+    constexpr int kVQ = k4CK * 16 * 4;                     // floats per quad of a V image
+    float* vp = vdst + vwl + (3 * R) * kVQ;
+    *reinterpret_cast<f32x4w4*>(vp) = f32x4w4{oa[0], oa[1], oa[2], oa[3]};
+    *reinterpret_cast<f32x4w4*>(vp + kVQ) = f32x4w4{oa[4], oa[5], ob[0], ob[1]};
+    *reinterpret_cast<f32x4w4*>(vp + 2 * kVQ) = f32x4w4{ob[2], ob[3], ob[4], ob[5]};
+  };
+
+  if (tid < 128) {   // aff_s[cb * 16 + m] = scale, [64 + ...] = shift of accumulator row m of block cb
+    const int lc = tid & 63, cbk = lc >> 4, m = lc & 15;
+    int col = GLU ? ((m & 2) ? (a.Cout >> 1) : 0) + grp * 32 + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * 64 + lc;
+    if (col >= a.Cout) col = 0;
+    aff_s[tid] = a.scale ? (tid < 64 ? a.scale[col] : a.shift[col]) : (tid < 64 ? 1.f : 0.f);
+  }
+
+  f32x4w4 M[36];
+#pragma unroll
+  for (int p = 0; p < 36; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M[p][i] = 0.f;
+
+  const int ulane = (lg * 64 + cb * 16 + l15) * 4;       // A: U[q][ci = lg][cb][l15][4]
+  const int vlane = (lg * 16 + l15) * 4;                 // B: V[q][ci = lg][l15][4]
+
+  auto run = [&](auto rc) {
+    constexpr int R = decltype(rc)::value;
+    // prologue: raw(0), U(0), raw(1); transform raw(0) -> V[0]
+    issue_raw(0);
+    issue_u(0);
+    if (a.nstages > 1) issue_raw(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (R < 3) {
+      float d[6][6];
+      t_read(rc, raws, d);
+      t_write(rc, d, vs);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int st = 0; st < a.nstages; ++st) {
+      const int par = st & 1;
+      const bool more = st + 1 < a.nstages, more2 = st + 2 < a.nstages;
+      if (more) issue_u(par ^ 1);                        // U(st+1) replaces U(st-1)
+      if (more2) issue_raw(par);                         // raw(st+2) replaces raw(st), transformed one stage ago
+      float d[6][6];
+      if (R < 3 && more) t_read(rc, raws + (par ^ 1) * k4RAW, d);
+      const float* ub = us + par * k4U + ulane;
+      const float* vb = vs + par * k4V + vlane;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const f32x4w4 af = *reinterpret_cast<const f32x4w4*>(ub + q * (k4CK * 64 * 4));
+        const f32x4w4 bf = *reinterpret_cast<const f32x4w4*>(vb + q * (k4CK * 16 * 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) M[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], M[4 * q + e], 0, 0, 0);
+        if (q == 4 && R < 3 && more) t_write(rc, d, vs + (par ^ 1) * k4V);
+      }
+      if (more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  if (cb == 0) run(std::integral_constant<int, 0>{});
+  else if (cb == 1) run(std::integral_constant<int, 1>{});
+  else if (cb == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+
+  // ---- output transform Y = A^T M A + epilogue; lane = tile l15, register i = accumulator row 4 lg + i of block cb
+  auto ytile = [&](int i, float (&y)[4][4]) {
+    float c[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float col[4];
+      w4_at(M[w4_pos(0, j)][i], M[w4_pos(1, j)][i], M[w4_pos(2, j)][i], M[w4_pos(3, j)][i], M[w4_pos(4, j)][i], M[w4_pos(5, j)][i], col);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r][j] = col[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w4_at(c[r][0], c[r][1], c[r][2], c[r][3], c[r][4], c[r][5], y[r]);
+  };
+  const int oy = y0 + 4 * g, ox = x0 + 4 * l15;
+  const int64_t HWo = (int64_t)a.H * a.W;
+  float* __restrict__ ob = a.out + (int64_t)b * a.obs;
+  const float* __restrict__ rb = a.res ? a.res + (int64_t)b * a.rbs : nullptr;
+  if (ox < a.W) {
+    if (GLU) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float yv[4][4], yg[4][4];
+        ytile(p, yv);
+        ytile(p + 2, yg);
+        const int m = 4 * lg + p;
+        const float sv = aff_s[cb * 16 + m], tv = aff_s[64 + cb * 16 + m], sg = aff_s[cb * 16 + m + 2], tg = aff_s[64 + cb * 16 + m + 2];
+        const int c = grp * 32 + cb * 8 + 2 * lg + p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (oy + r >= a.H) continue;
+          f32x4w4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o[k] = (yv[r][k] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[r][k] * sg + tg)));
+          *reinterpret_cast<f32x4w4*>(ob + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox) = o;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 4 * lg + i, c = grp * 64 + cb * 16 + m;
+        f32x4w4 rr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          rr[r] = f32x4w4{0.f, 0.f, 0.f, 0.f};
+          if (rb && oy + r < a.H) rr[r] = *reinterpret_cast<const f32x4w4*>(rb + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox);
+        }
+        float yv[4][4];
+        ytile(i, yv);
+        const float sv = aff_s[cb * 16 + m], tv = aff_s[64 + cb * 16 + m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (oy + r >= a.H) continue;
+          f32x4w4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = yv[r][k] * sv + tv + rr[r][k];
+          *reinterpret_cast<f32x4w4*>(ob + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox) = o;
+        }
+      }
+    }
+  }
+}
+
+// upack[stage][group][quad 9][ci 4][cb 4][row 16][4] <- U = G g G^T (computed in double, rounded once); a group is the 64
+// accumulator rows of one workgroup.  Row m of block cb: plain = cout grp*64 + cb*16 + m; GLU = value channel
+// grp*32 + cb*8 + 2 (m >> 2) + (m & 1) when m & 2 == 0, its gate (+ Cout/2) otherwise.
+__global__ void pack_wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu,
+                                         int64_t total) {
+  const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const int ngrp = Cout / 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 3), m = (int)((idx >> 2) & 15), cbk = (int)((idx >> 6) & 3), ci = (int)((idx >> 8) & 3);
+    int64_t t = idx >> 10;
+    const int q = (int)(t % 9);
+    t /= 9;
+    const int grp = (int)(t % ngrp);
+    const int st = (int)(t / ngrp);
+    const int i = w4_row(q, e), j = w4_col(q, e);
+    const int co = glu ? ((m & 2) ? (Cout >> 1) : 0) + grp * 32 + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * 64 + cbk * 16 + m;
+    const int c = st * k4CK + ci;
+    double u = 0.0;
+    if (c < Cin) {
+      const float* gw = w + ((int64_t)co * Cin + c) * 9;
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 3; ++l) u += G[i][k] * (double)gw[k * 3 + l] * G[j][l];
+    }
+    up[idx] = (float)u;
+  }
+}
+
+}  // namespace tgsr
+
+using namespace tgsr;
+
+extern "C" int64_t tgsr_packed_wino4_weight_elems(int Cout, int Cin) {
+  return (int64_t)((Cin + k4CK - 1) / k4CK) * 36 * k4CK * Cout;
+}
+
+extern "C" int tgsr_pack_wino4_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
+  if (!w || !upack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
+  if (Cout % 64 != 0) return TGSR_EUNSUPPORTED;
+  const int64_t total = tgsr_packed_wino4_weight_elems(Cout, Cin);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(pack_wino4_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin, glu ? 1 : 0,
+                     total);
+  return note_launch(hipGetLastError(), "pack_wino4_weight_kernel");
+}
+
+extern "C" int tgsr_wino4_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                                      int Cout, const float* scale, const float* shift, const float* residual,
+                                      int64_t res_bstride, float* out, int64_t out_bstride, int epilogue, void* stream) {
+  if (!x || !upack || !out || B < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return TGSR_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
+  const bool glu = epilogue == TGSR_EPI_AFFINE_GLU;
+  if (!glu && epilogue != TGSR_EPI_AFFINE) return TGSR_EINVAL;
+  if (glu && residual) return TGSR_EINVAL;
+  if (Cout % 64 != 0 || Cin % k4CK != 0) return TGSR_EUNSUPPORTED;
+  if ((int64_t)H * W >= (1 << 28) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
+  if ((W & 3) || (x_bstride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (out_bstride & 3) || (residual && ((reinterpret_cast<uintptr_t>(residual) & 15) || (res_bstride & 3))))
+    return TGSR_EUNSUPPORTED;
+  Wino4Args a;
+  a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
+  a.scale = scale; a.shift = shift; a.res = residual; a.rbs = res_bstride; a.out = out; a.obs = out_bstride;
+  a.tiles_x = (W + 63) / 64; a.tiles_y = (H + 7) / 8; a.nstages = Cin / k4CK; a.ngroups = Cout / 64;
+  const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.ngroups));
+  if (glu) hipLaunchKernelGGL((wino4_conv3x3_kernel<true>), grid, dim3(512), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((wino4_conv3x3_kernel<false>), grid, dim3(512), 0, as_stream(stream), a);
+  return note_launch(hipGetLastError(), "wino4_conv3x3_kernel");
+}

@@ -4,6 +4,7 @@ libtgsr_hip.so.  No function in this file computes on the CPU or through eager t
 """
 import ctypes
 import functools
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -78,6 +79,7 @@ def _nchw_bstride(t: torch.Tensor, name: str) -> Tuple[torch.Tensor, int]:
 def _pack_elems(kind: str, cout: int, cin: int) -> int:
     L = _lib.lib()
     return int({"conv": lambda: L.tgsr_packed_weight_elems(cout, cin, 3), "wino": lambda: L.tgsr_packed_wino_weight_elems(cout, cin),
+                "wino4": lambda: L.tgsr_packed_wino4_weight_elems(cout, cin),
                 "upconv": lambda: L.tgsr_packed_upconv_weight_elems(cout, cin),
                 "upwino": lambda: L.tgsr_packed_upwino_weight_elems(cout, cin)}[kind]())
 
@@ -221,6 +223,59 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
     if profile is not None:
         nbytes = 4 * (B * Cin * H * W + B * co * H * W * (2 if residual is not None else 1) + cout * Cin * 9)
         profile.append(("wino_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9, nbytes, e0, _ev()))
+    return out
+
+
+WINO4_MIN_PIXELS = 128 * 128      # per image; DESIGN.md 3.1e: the error study that allows F(4x4) on these layers only
+
+
+def wino4_wanted(cin: int, cout: int, H: int, W: int) -> bool:
+    """Does the inference path route a conv3x3 layer to the F(4x4, 3x3) kernel?  Shape support (Cout % 64, Cin % 4,
+    W % 64, H % 8: whole workgroup tiles) AND the numerics policy: only layers of >= 128 x 128 pixels - the four such
+    layers of a forward move the finest image by 3e-6 (max, vs fp64), every layer on it would cost 2e-4 (tgsr_winograd4.hip).
+    TGSR_WINO4=0 keeps every layer on F(2x2)."""
+    if os.environ.get("TGSR_WINO4", "1") == "0":
+        return False
+    return cout % 64 == 0 and cin % 4 == 0 and W % 64 == 0 and H % 8 == 0 and H * W >= WINO4_MIN_PIXELS
+
+
+def pack_wino4_weight(w: torch.Tensor, glu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> Winograd F(4x4,3x3) transformed weights [Cin/4][Cout/64][9 quads][4 ci][64 rows][4] (U = G g G^T in
+    double, rounded once); `glu` must match the epilogue the pack is used with."""
+    _need_hip(w)
+    w = _f32(w.detach(), "weight").contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = _pack_out(out, L.tgsr_packed_wino4_weight_elems(Cout, Cin), w.device)
+    check(L.tgsr_pack_wino4_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_wino4_weight")
+    return out
+
+
+def conv3x3_wino4(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, glu: bool = False,
+                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3 + affine + (GLU | residual) by Winograd F(4x4,3x3) (same contract as conv3x3_wino; 16-byte aligned tensors)."""
+    _need_hip(x, upack, scale, shift, residual, out)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    B, Cin, H, W = x.shape
+    _check_pack("conv3x3_wino4", "wino4", upack, cout, Cin)
+    co = cout // 2 if glu else cout
+    if out is None:
+        out = torch.empty(B, co, H, W, dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (B, co, H, W) or out.stride(3) != 1 or out.stride(2) != W or out.stride(1) != H * W:
+        raise TgsrError("conv3x3_wino4: bad `out` shape/strides %s %s" % (tuple(out.shape), out.stride()))
+    obs = out.stride(0) if B > 1 else co * H * W
+    rbs = 0
+    if residual is not None:
+        residual, rbs = _nchw_bstride(_f32(residual, "residual"), "residual")
+        if tuple(residual.shape) != (B, co, H, W):
+            raise TgsrError("conv3x3_wino4: residual shape %s" % (tuple(residual.shape),))
+    e0 = _ev() if profile is not None else None
+    rc = _lib.lib().tgsr_wino4_conv3x3_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(residual),
+                                           rbs, _p(out), obs, _lib.EPI_AFFINE_GLU if glu else _lib.EPI_AFFINE, _stream())
+    check(rc, "tgsr_wino4_conv3x3_fwd")
+    if profile is not None:
+        nbytes = 4 * (B * Cin * H * W + B * co * H * W * (2 if residual is not None else 1) + cout * Cin * 9)
+        profile.append(("wino4_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9, nbytes, e0, _ev()))
     return out
 
 

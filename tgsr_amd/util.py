@@ -25,7 +25,8 @@ def _ver(*ts):
 
 
 # Inference convolutions without upsampling go through the Winograd F(2x2,3x3) kernel where it applies
-# (ops.wino_supported: Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0); TGSR_WINOGRAD=0 keeps the direct kernel everywhere.
+# (ops.wino_supported: Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0), the layers of >= 128 x 128 pixels through F(4x4,3x3)
+# (ops.wino4_wanted; TGSR_WINO4=0: F(2x2) there too); TGSR_WINOGRAD=0 keeps the direct kernel everywhere.
 WINOGRAD = os.environ.get("TGSR_WINOGRAD", "1") != "0"
 
 
@@ -35,13 +36,13 @@ class _FusedParams:
 
     def __init__(self):
         self.key = None
-        self.wpack = self.upack = self.scale = self.shift = None
+        self.wpack = self.upack = self.u4pack = self.scale = self.shift = None
 
     def _refresh(self, conv: nn.Conv2d, bn):
         src = [conv.weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
         key = _ver(*src)
         if key != self.key:
-            self.wpack = self.upack = None
+            self.wpack = self.upack = self.u4pack = None
             if bn is not None:
                 self.scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
             else:
@@ -59,6 +60,25 @@ class _FusedParams:
         if self.upack is None:
             self.upack = ops.pack_wino_weight(conv.weight, glu=glu)
         return self.upack, self.scale, self.shift
+
+
+    def get_wino4(self, conv: nn.Conv2d, bn, glu: bool):
+        self._refresh(conv, bn)
+        if self.u4pack is None:
+            self.u4pack = C.pack_wino4_weight(conv.weight.detach(), glu)
+        return self.u4pack, self.scale, self.shift
+
+
+def _wino4_takes(x, cout, out, residual):
+    """The F(4x4, 3x3) kernel: the layers ops.wino4_wanted names (>= 128 x 128 pixels, whole 8 x 64 tiles, 64-channel groups)
+    when every tensor is 16-byte aligned with batch strides % 4 == 0."""
+    if x.dim() != 4 or not ops.wino4_wanted(x.shape[1], cout, x.shape[2], x.shape[3]):
+        return False
+    for t in (x, out, residual):
+        if t is not None and (t.data_ptr() % 16 != 0 or (t.shape[0] > 1 and t.stride(0) % 4 != 0) or t.stride(3) != 1 or
+                              t.stride(2) != t.shape[3] or t.stride(1) != t.shape[2] * t.shape[3]):
+            return False
+    return True
 
 
 def _wino_pays(x, cout, out, residual):
@@ -82,6 +102,12 @@ def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=
         if out is not None:
             raise RuntimeError("training path does not write into channel-slice views")
         return y
+    if WINOGRAD and not upsample and _wino4_takes(x, conv.out_channels, out, residual):
+        upack, scale, shift = fp.get_wino4(conv, bn, glu)
+        if out is None:
+            return C.conv3x3_wino4(x, upack, conv.out_channels, scale, shift, glu, residual)
+        C.conv3x3_wino4_out(x, upack, conv.out_channels, scale, shift, glu, residual, out)
+        return out
     if WINOGRAD and not upsample and _wino_pays(x, conv.out_channels, out, residual):
         upack, scale, shift = fp.get_wino(conv, bn, glu)
         if out is None:
