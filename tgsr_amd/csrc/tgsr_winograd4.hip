@@ -146,30 +146,29 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
     rptr[k] = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino4_zero;
     rstep[k] = ok ? (int)(k4CK * HW) : 0;
   }
-  auto dma16 = [&](const float* gsrc, float* lds_wave_base) {
-    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr4_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(l) : "memory");
-  };
+  // LDS addresses of the copies as plain integers (wave-uniform: SGPR arithmetic, no generic-pointer casts in the loop)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr4_t)smem);
+  const unsigned lds_raw = lds0 + (2 * k4U + wave * 256) * 4;        // + buf * k4RAW * 4 (+ 8 KB: the second piece)
+  const unsigned lds_u = lds0 + wave * 1024;                         // + buf * k4U * 4 + k * 8 KB
   auto issue_raw = [&](int buf) {                        // stages 0, 1, 2, ... in order
-    dma16(rptr[0], raws + buf * k4RAW + wave * 256);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr[0]), "s"(lds_raw + buf * (k4RAW * 4)) : "memory");
     rptr[0] += rstep[0];
     if (wave < 4) {
-      dma16(rptr[1], raws + buf * k4RAW + (8 + wave) * 256);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr[1]), "s"(lds_raw + buf * (k4RAW * 4) + 8192) : "memory");
       rptr[1] += rstep[1];
     }
   };
   const float* ubase = a.upack + (int64_t)grp * k4U;     // stage 0 of this group
   const int64_t ustride = (int64_t)a.ngroups * k4U;
+  unsigned uoff[5];                                      // per-lane byte offsets of this wave's U pieces
+#pragma unroll
+  for (int k = 0; k < 5; ++k) uoff[k] = (unsigned)(((k < 4 ? wave + 8 * k : 28 + wave) * 64 + lane) * 16);
   auto issue_u = [&](int buf) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      if (k < 4 || wave >= 4) {
-        const int piece = k < 4 ? wave + 8 * k : 28 + wave;
-        const unsigned off = (unsigned)((piece * 64 + lane) * 16);
-        const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr4_t)(us + buf * k4U + piece * 256));
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(ubase), "s"(l) : "memory");
-      }
-    }
+    for (int k = 0; k < 4; ++k)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff[k]), "s"(ubase), "s"(lds_u + buf * (k4U * 4) + k * 8192) : "memory");
+    if (wave >= 4)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff[4]), "s"(ubase), "s"(lds_u + buf * (k4U * 4) + 28 * 1024) : "memory");
     ubase += ustride;
   };
 
@@ -219,8 +218,46 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
   const int ulane = (lg * 64 + cb * 16 + l15) * 4;       // A: U[q][ci = lg][cb][l15][4]
   const int vlane = (lg * 16 + l15) * 4;                 // B: V[q][ci = lg][l15][4]
 
+  // One stage: the copies U(st+1) [MORE] and raw(st+2) [MORE2] first - they have the whole stage to land; the raw reads of the
+  // transform of raw(st+1); 36 MFMAs on U(st), V(st) with the transform arithmetic and its three V writes in the middle; the wait
+  // for this stage's copies and the barrier that publishes them and V(st+1).  The buffer parity is compile-time (the loop runs
+  // two stages per trip), the two flags are wave-uniform branches: with a stage instantiated per flag combination hipcc lost
+  // the in-place accumulators between the copies (900 spilled registers).
+  auto stage = [&](auto rc, auto parc, const bool MORE, const bool MORE2) {
+    constexpr int R = decltype(rc)::value, PAR = decltype(parc)::value;
+    if (MORE) issue_u(PAR ^ 1);                          // U(st+1) replaces U(st-1)
+    if (MORE2) issue_raw(PAR);                           // raw(st+2) replaces raw(st), transformed one stage ago
+    float d[6][6];
+    if (R < 3 && MORE) t_read(rc, raws + (PAR ^ 1) * k4RAW, d);
+    const float* ub = us + PAR * k4U + ulane;
+    const float* vb = vs + PAR * k4V + vlane;
+    // fragment reads one quad ahead of their MFMAs; the order is pinned (left alone, hipcc hoists all 18 reads of a stage
+    // above its first MFMA - 72 registers - and spills the accumulators)
+    f32x4w4 af[2], bf[2];
+    af[0] = *reinterpret_cast<const f32x4w4*>(ub);
+    bf[0] = *reinterpret_cast<const f32x4w4*>(vb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      if (q + 1 < 9) {
+        af[(q + 1) & 1] = *reinterpret_cast<const f32x4w4*>(ub + (q + 1) * (k4CK * 64 * 4));
+        bf[(q + 1) & 1] = *reinterpret_cast<const f32x4w4*>(vb + (q + 1) * (k4CK * 16 * 4));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        M[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q & 1][e], bf[q & 1][e], M[4 * q + e], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == 4 && R < 3 && MORE) {
+        t_write(rc, d, vs + (PAR ^ 1) * k4V);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (MORE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
   auto run = [&](auto rc) {
     constexpr int R = decltype(rc)::value;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
     // prologue: raw(0), U(0), raw(1); transform raw(0) -> V[0]
     issue_raw(0);
     issue_u(0);
@@ -232,25 +269,12 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
       t_write(rc, d, vs);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    for (int st = 0; st < a.nstages; ++st) {
-      const int par = st & 1;
-      const bool more = st + 1 < a.nstages, more2 = st + 2 < a.nstages;
-      if (more) issue_u(par ^ 1);                        // U(st+1) replaces U(st-1)
-      if (more2) issue_raw(par);                         // raw(st+2) replaces raw(st), transformed one stage ago
-      float d[6][6];
-      if (R < 3 && more) t_read(rc, raws + (par ^ 1) * k4RAW, d);
-      const float* ub = us + par * k4U + ulane;
-      const float* vb = vs + par * k4V + vlane;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const f32x4w4 af = *reinterpret_cast<const f32x4w4*>(ub + q * (k4CK * 64 * 4));
-        const f32x4w4 bf = *reinterpret_cast<const f32x4w4*>(vb + q * (k4CK * 16 * 4));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) M[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], M[4 * q + e], 0, 0, 0);
-        if (q == 4 && R < 3 && more) t_write(rc, d, vs + (par ^ 1) * k4V);
-      }
-      if (more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    int st = 0;
+    for (; st + 1 < a.nstages; st += 2) {
+      stage(rc, P0{}, true, st + 2 < a.nstages);
+      stage(rc, P1{}, st + 2 < a.nstages, st + 3 < a.nstages);
     }
+    if (st < a.nstages) stage(rc, P0{}, false, false);   // odd stage count
   };
   if (cb == 0) run(std::integral_constant<int, 0>{});
   else if (cb == 1) run(std::integral_constant<int, 1>{});
