@@ -36,6 +36,22 @@ namespace tgsr {
 typedef __attribute__((address_space(3))) void* lds_ptr4_t;
 __device__ __attribute__((aligned(16))) float g_wino4_zero[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifdef TGSR_WINO4_STAMPS
+// Diagnostic build only (tools/wino4_stamps.py): per-workgroup cycle stamps, never compiled into the shipped library.
+__device__ unsigned long long g_w4stamps[8 * 8192];
+#define TGSR_W4STAMP(k)                                                                                 \
+  do {                                                                                                  \
+    const int bid_ = blockIdx.x;                                                                        \
+    if (threadIdx.x == 0 && bid_ < 8192) {                                                              \
+      g_w4stamps[bid_ * 8 + (k)] = __builtin_amdgcn_s_memtime();                                        \
+      if ((k) == 0) g_w4stamps[bid_ * 8 + 6] = __builtin_amdgcn_s_memrealtime();                        \
+      if ((k) == 3) g_w4stamps[bid_ * 8 + 7] = __builtin_amdgcn_s_memrealtime();                        \
+    }                                                                                                   \
+  } while (0)
+#else
+#define TGSR_W4STAMP(k)
+#endif
+
 struct Wino4Args {
   const float* x;
   int64_t xbs;
@@ -130,45 +146,44 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
   float* raws = smem + 2 * k4U;
   float* vs = smem + 2 * k4U + 2 * k4RAW + g * 2 * k4V;  // this tile row's two V images
   float* aff_s = smem + 2 * k4U + 2 * k4RAW + 4 * k4V;
+  TGSR_W4STAMP(0);
 
-  // ---- DMA plan: 48 pieces of 1 KB per stage, six per wave.  raw: piece `wave`, and 8 + wave on waves 0-3; U: pieces
-  // wave + 8k (k < 4), and 28 + wave on waves 4-7.  Out-of-image (and plane padding) lanes read the zero block, stride 0.
+  // ---- DMA plan: 48 pieces of 1 KB per stage.  The six transforming waves (cb < 3) copy the raw tile, two pieces each
+  // (r6 = 3 g + cb and r6 + 6); the two others (cb = 3) copy U, 18 pieces each - what a stage costs beyond its MFMAs is the
+  // instruction count of its busiest SIMD, and the transform already puts 2 x 58 on three of the four (stamps: all copies
+  // spread evenly 3 733 cycles per stage, this split 3 651).  Out-of-image (and plane padding) lanes read the zero block, stride 0.
+  const int r6 = 3 * g + cb;
   const float* rptr[2];
   int rstep[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int e = ((wave + 8 * k) * 64 + lane) * 4;      // first float of this lane's 16-byte piece
+    const int e = (((cb < 3 ? r6 : 0) + 6 * k) * 64 + lane) * 4;   // first float of this lane's 16-byte piece
     const int c = e / k4PLANE;
     const int rem = e - c * k4PLANE;
     const int r = rem / k4TC, j = rem - r * k4TC;
     const int gy = y0 - 1 + r, gx = x0 - 4 + j;
-    const bool ok = e < k4RAW && rem < k4TR * k4TC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // W % 4 == 0
+    const bool ok = rem < k4TR * k4TC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;   // W % 4 == 0
     rptr[k] = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino4_zero;
     rstep[k] = ok ? (int)(k4CK * HW) : 0;
   }
   // LDS addresses of the copies as plain integers (wave-uniform: SGPR arithmetic, no generic-pointer casts in the loop)
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr4_t)smem);
-  const unsigned lds_raw = lds0 + (2 * k4U + wave * 256) * 4;        // + buf * k4RAW * 4 (+ 8 KB: the second piece)
-  const unsigned lds_u = lds0 + wave * 1024;                         // + buf * k4U * 4 + k * 8 KB
-  auto issue_raw = [&](int buf) {                        // stages 0, 1, 2, ... in order
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr[0]), "s"(lds_raw + buf * (k4RAW * 4)) : "memory");
-    rptr[0] += rstep[0];
-    if (wave < 4) {
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr[1]), "s"(lds_raw + buf * (k4RAW * 4) + 8192) : "memory");
-      rptr[1] += rstep[1];
+  const unsigned lds_raw = lds0 + (2 * k4U + r6 * 256) * 4;          // + buf * k4RAW * 4 (+ 6 KB: the second piece)
+  const unsigned lds_u = lds0 + g * (18 * 1024);                     // + buf * k4U * 4 + k KB
+  auto issue_raw = [&](int buf) {                        // waves cb < 3; stages 0, 1, 2, ... in order
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr[k]), "s"(lds_raw + buf * (k4RAW * 4) + k * 6144) : "memory");
+      rptr[k] += rstep[k];
     }
   };
   const float* ubase = a.upack + (int64_t)grp * k4U;     // stage 0 of this group
   const int64_t ustride = (int64_t)a.ngroups * k4U;
-  unsigned uoff[5];                                      // per-lane byte offsets of this wave's U pieces
+  const unsigned uoff0 = (unsigned)((g * 18 * 64 + lane) * 16);      // per-lane byte offset of this wave's first U piece
+  auto issue_u = [&](int buf) {                          // waves cb = 3
 #pragma unroll
-  for (int k = 0; k < 5; ++k) uoff[k] = (unsigned)(((k < 4 ? wave + 8 * k : 28 + wave) * 64 + lane) * 16);
-  auto issue_u = [&](int buf) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff[k]), "s"(ubase), "s"(lds_u + buf * (k4U * 4) + k * 8192) : "memory");
-    if (wave >= 4)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff[4]), "s"(ubase), "s"(lds_u + buf * (k4U * 4) + 28 * 1024) : "memory");
+    for (int k = 0; k < 18; ++k)
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff0 + k * 1024), "s"(ubase), "s"(lds_u + buf * (k4U * 4) + k * 1024) : "memory");
     ubase += ustride;
   };
 
@@ -219,39 +234,67 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
   const int vlane = (lg * 16 + l15) * 4;                 // B: V[q][ci = lg][l15][4]
 
   // One stage: the copies U(st+1) [MORE] and raw(st+2) [MORE2] first - they have the whole stage to land; the raw reads of the
-  // transform of raw(st+1); 36 MFMAs on U(st), V(st) with the transform arithmetic and its three V writes in the middle; the wait
-  // for this stage's copies and the barrier that publishes them and V(st+1).  The buffer parity is compile-time (the loop runs
-  // two stages per trip), the two flags are wave-uniform branches: with a stage instantiated per flag combination hipcc lost
-  // the in-place accumulators between the copies (900 spilled registers).
+  // transform of raw(st+1); then ONE scheduling region with the 36 MFMAs on U(st), V(st), their 18 fragment reads two quads
+  // ahead, and the transform's 48 VALU operations spread over the MFMA gaps, one or two per gap, with its three V writes behind
+  // quad 7; the wait for this stage's copies and the barrier that publishes them and V(st+1).
+  // What a stage costs (stamps + builds with parts compiled out, tools/wino4_stamps.py, 64 -> 128 @128^2): 2 304 cycles of MFMA
+  // (2 waves x 36 x 32), + 150 for the fragment reads, + 900 for the transform, + 375 for the copies = 3 700.  The transform's
+  // 900 are its 2 x 58 instructions on the busiest SIMD at ~7.7 cycles each: beside fp32 MFMAs a VALU / LDS instruction costs
+  // that much of the SIMD's time wherever it sits - as one block behind quad 2, staggered between the two waves of a SIMD, or
+  // one per MFMA gap as here, the stage took the same 3 650-3 730 cycles (the 24 free issue cycles per gap the guide measures
+  // beside bf16 MFMAs do not exist beside v_mfma_f32_16x16x4_f32; tgsr_winograd.hip found the same in round 1).  Fewer
+  // non-MFMA instructions per SIMD is the only lever: hence the copy split above (-80 cycles per stage).
+  // The transform is NOT skipped in the last stage (a branch would split the region): it reads the stale raw buffer and writes
+  // the V image nobody reads.  The buffer parity is compile-time (the loop runs two stages per trip), the two flags are
+  // wave-uniform branches: with a stage instantiated per flag combination hipcc lost the in-place accumulators between the
+  // copies (900 spilled registers).
   auto stage = [&](auto rc, auto parc, const bool MORE, const bool MORE2) {
     constexpr int R = decltype(rc)::value, PAR = decltype(parc)::value;
-    if (MORE) issue_u(PAR ^ 1);                          // U(st+1) replaces U(st-1)
-    if (MORE2) issue_raw(PAR);                           // raw(st+2) replaces raw(st), transformed one stage ago
+#if defined(TGSR_W4_EXP)   // diagnostic builds (wrong results): bit 0 = no U copies, bit 1 = no transform, bit 2 = no raw copies
+    constexpr bool kNoU = TGSR_W4_EXP & 1, kNoT = TGSR_W4_EXP & 2, kNoRaw = TGSR_W4_EXP & 4;
+#else
+    constexpr bool kNoU = false, kNoT = false, kNoRaw = false;
+#endif
+    constexpr bool TR = R < 3 && !kNoT;
+    if (R == 3 && MORE && !kNoU) issue_u(PAR ^ 1);       // U(st+1) replaces U(st-1)
+    if (R < 3 && MORE2 && !kNoRaw) issue_raw(PAR);       // raw(st+2) replaces raw(st), transformed one stage ago
     float d[6][6];
-    if (R < 3 && MORE) t_read(rc, raws + (PAR ^ 1) * k4RAW, d);
+    if (TR) t_read(rc, raws + (PAR ^ 1) * k4RAW, d);
+    __builtin_amdgcn_sched_barrier(0);
     const float* ub = us + PAR * k4U + ulane;
     const float* vb = vs + PAR * k4V + vlane;
-    // fragment reads one quad ahead of their MFMAs; the order is pinned (left alone, hipcc hoists all 18 reads of a stage
-    // above its first MFMA - 72 registers - and spills the accumulators)
-    f32x4w4 af[2], bf[2];
+    f32x4w4 af[3], bf[3];
     af[0] = *reinterpret_cast<const f32x4w4*>(ub);
     bf[0] = *reinterpret_cast<const f32x4w4*>(vb);
-    __builtin_amdgcn_sched_barrier(0);
+    af[1] = *reinterpret_cast<const f32x4w4*>(ub + (k4CK * 64 * 4));
+    bf[1] = *reinterpret_cast<const f32x4w4*>(vb + (k4CK * 16 * 4));
+    if (TR) t_write(rc, d, vs + (PAR ^ 1) * k4V);
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
-      if (q + 1 < 9) {
-        af[(q + 1) & 1] = *reinterpret_cast<const f32x4w4*>(ub + (q + 1) * (k4CK * 64 * 4));
-        bf[(q + 1) & 1] = *reinterpret_cast<const f32x4w4*>(vb + (q + 1) * (k4CK * 16 * 4));
+      if (q + 2 < 9) {
+        af[(q + 2) % 3] = *reinterpret_cast<const f32x4w4*>(ub + (q + 2) * (k4CK * 64 * 4));
+        bf[(q + 2) % 3] = *reinterpret_cast<const f32x4w4*>(vb + (q + 2) * (k4CK * 16 * 4));
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        M[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q & 1][e], bf[q & 1][e], M[4 * q + e], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (q == 4 && R < 3 && MORE) {
-        t_write(rc, d, vs + (PAR ^ 1) * k4V);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        M[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q % 3][e], bf[q % 3][e], M[4 * q + e], 0, 0, 0);
     }
+    // the order of the region: masks 0x008 MFMA, 0x002 VALU, 0x100 LDS read, 0x200 LDS write
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      if (q + 2 < 9) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (TR && q < 8) {
+          if (e < 2) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+      }
+      if (TR && q == 7) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (MORE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   auto run = [&](auto rc) {
@@ -259,9 +302,12 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     // prologue: raw(0), U(0), raw(1); transform raw(0) -> V[0]
-    issue_raw(0);
-    issue_u(0);
-    if (a.nstages > 1) issue_raw(1);
+    if (R < 3) {
+      issue_raw(0);
+      if (a.nstages > 1) issue_raw(1);
+    } else {
+      issue_u(0);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (R < 3) {
       float d[6][6];
@@ -269,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
       t_write(rc, d, vs);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    TGSR_W4STAMP(1);
     int st = 0;
     for (; st + 1 < a.nstages; st += 2) {
       stage(rc, P0{}, true, st + 2 < a.nstages);
@@ -280,6 +327,7 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
   else if (cb == 1) run(std::integral_constant<int, 1>{});
   else if (cb == 2) run(std::integral_constant<int, 2>{});
   else run(std::integral_constant<int, 3>{});
+  TGSR_W4STAMP(2);
 
   // ---- output transform Y = A^T M A + epilogue; lane = tile l15, register i = accumulator row 4 lg + i of block cb
   auto ytile = [&](int i, float (&y)[4][4]) {
@@ -319,15 +367,20 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
         }
       }
     } else {
+      // the residual tile of this lane (4 channels x 4 rows of 4 pixels): all 16 loads in flight before the first transform
+      f32x4w4 rr[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = grp * 64 + cb * 16 + 4 * lg + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          rr[i][r] = f32x4w4{0.f, 0.f, 0.f, 0.f};
+          if (rb && oy + r < a.H) rr[i][r] = *reinterpret_cast<const f32x4w4*>(rb + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = 4 * lg + i, c = grp * 64 + cb * 16 + m;
-        f32x4w4 rr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          rr[r] = f32x4w4{0.f, 0.f, 0.f, 0.f};
-          if (rb && oy + r < a.H) rr[r] = *reinterpret_cast<const f32x4w4*>(rb + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox);
-        }
         float yv[4][4];
         ytile(i, yv);
         const float sv = aff_s[cb * 16 + m], tv = aff_s[64 + cb * 16 + m];
@@ -336,12 +389,13 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
           if (oy + r >= a.H) continue;
           f32x4w4 o;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = yv[r][k] * sv + tv + rr[r][k];
+          for (int k = 0; k < 4; ++k) o[k] = yv[r][k] * sv + tv + rr[i][r][k];
           *reinterpret_cast<f32x4w4*>(ob + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox) = o;
         }
       }
     }
   }
+  TGSR_W4STAMP(3);
 }
 
 // upack[stage][group][quad 9][ci 4][cb 4][row 16][4] <- U = G g G^T (computed in double, rounded once); a group is the 64
@@ -375,6 +429,12 @@ __global__ void pack_wino4_weight_kernel(const float* __restrict__ w, float* __r
 }  // namespace tgsr
 
 using namespace tgsr;
+
+#ifdef TGSR_WINO4_STAMPS
+extern "C" int tgsr_debug_read_w4stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(tgsr::g_w4stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int64_t tgsr_packed_wino4_weight_elems(int Cout, int Cin) {
   return (int64_t)((Cin + k4CK - 1) / k4CK) * 36 * k4CK * Cout;

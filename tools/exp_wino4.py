@@ -40,7 +40,7 @@ for (b, cin, cout, h, w, glu, res) in ((1, 4, 64, 8, 64, 0, 0), (2, 8, 64, 16, 6
     print("B%d %d->%d %dx%d glu%d res%d: |F4-f64| max %.2e  |F2-f64| max %.2e" % (
         b, cin, cout, h, w, glu, res, float((o4.double() - ref).abs().max()), float((o2.double() - ref).abs().max())), flush=True)
 
-for cin, cout, h, glu, res in ((64, 128, 128, 1, 0), (64, 64, 128, 0, 1), (64, 128, 64, 1, 0), (64, 64, 64, 0, 1)):
+for cin, cout, h, glu, res in ((64, 128, 128, 1, 0), (64, 64, 128, 0, 1), (64, 128, 64, 1, 0), (64, 64, 64, 0, 1), (32, 128, 128, 1, 0), (128, 128, 128, 1, 0)):
     x = torch.randn(B, cin, h, h, device=dev)
     wt = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
     sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
