@@ -139,6 +139,8 @@ int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int
  */
 int64_t tgsr_packed_wino4_weight_elems(int Cout, int Cin);
 int tgsr_pack_wino4_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream);
+/* F(4x4) pack of the data-gradient convolution from the forward weight [Cin][Cout][3][3] (see tgsr_pack_conv_weight_dgrad). */
+int tgsr_pack_wino4_weight_dgrad(const float* w, float* upack, int Cout, int Cin, void* stream);
 int tgsr_wino4_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
                            const float* scale, const float* shift, const float* residual, int64_t res_bstride,
                            float* out, int64_t out_bstride, int epilogue, void* stream);
@@ -360,6 +362,10 @@ int tgsr_bn_train_fwd(const float* raw, int B, int C, int HW, const float* gamma
 int tgsr_wino_stats_nslots(int B, int H, int W, int Cout);
 int tgsr_wino_conv3x3_stats_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
                                 int Cout, float* out, int64_t out_bstride, float* stat_partial, void* stream);
+/* The same for the F(4x4, 3x3) kernel (training forward of the 128 x 128 layers): one pair per channel and 4 x 64 wave tile. */
+int tgsr_wino4_stats_nslots(int B, int H, int W, int Cout);
+int tgsr_wino4_conv3x3_stats_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                                 int Cout, float* out, int64_t out_bstride, float* stat_partial, void* stream);
 int tgsr_bn_train_fwd_from_stats(const float* raw, int B, int C, int HW, const float* gamma, const float* beta, float eps,
                                  float momentum, float* running_mean, float* running_var, int glu, const float* residual,
                                  int64_t res_bstride, const float* stat_partial, int nslots, float* mean, float* invstd,

@@ -121,8 +121,10 @@ def test_opcheck_training_text_damsm_and_lp_operators():
         chk(T.conv3x3_wgrad.default, (dr, x32, up, True, torch.empty(Cc, 32, 3, 3, device=DEV)), test_utils=basic)
     chk(T.conv3x3_wgrad.default, (R(B, 32, H, W), R(B, 3, H, W), False, True, torch.empty(32, 3, 3, 3, device=DEV)), test_utils=basic)
     chk(T.sumpool2x2.default, (raw,), test_utils=basic)
-    up4 = T.pack_wino4_weight(R(Cc, Cc, 3, 3), False)
-    chk(T.pack_wino4_weight.default, (R(Cc, Cc, 3, 3), True), test_utils=basic)
+    up4 = T.pack_wino4_weight(R(Cc, Cc, 3, 3), False, False)
+    chk(T.pack_wino4_weight.default, (R(Cc, Cc, 3, 3), True, False), test_utils=basic)
+    chk(T.pack_wino4_weight.default, (R(Cc, 128, 3, 3), False, True), test_utils=basic)
+    chk(T.conv3x3_wino4_stats.default, (x4 if False else R(B, Cc, 8, 64), up4, Cc), test_utils=basic)
     x4 = R(B, Cc, 8, 64)
     chk(T.conv3x3_wino4.default, (x4, up4, Cc, gam, bet, False, R(B, Cc, 8, 64)), test_utils=basic)
     chk(T.conv3x3_wino4_out.default, (x4, up4, Cc, None, None, False, None, torch.empty(B, Cc, 8, 64, device=DEV)), test_utils=basic)

@@ -247,6 +247,38 @@ def test_conv3x3_winograd4_channel_slices_and_refusals():
         ops.conv3x3_wino4(wide_in[:, :32], up, 128, None, None, glu=True)              # pack made for 64 input channels
 
 
+def test_winograd4_training_forms():
+    """What the training step uses of the F(4x4) kernel: the raw convolution whose epilogue leaves BatchNorm's batch
+    statistics as per-wave partial sums, and the data-gradient pack made from the FORWARD weight."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, Cin, Cout, H, W = 3, 64, 128, 24, 132
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 24).to(DEV)
+    up = ops.pack_wino4_weight(w)
+    raw, part = ops.conv3x3_wino4_stats(x, up, Cout)
+    assert torch.equal(raw, ops.conv3x3_wino4(x, up, Cout, None, None))
+    assert part.shape == (Cout, ops.wino4_stats_nslots(B, H, W, Cout), 2)
+    s = part.double().sum(1).cpu()
+    r = raw.double().cpu()
+    np.testing.assert_allclose(s[:, 0].numpy(), r.sum((0, 2, 3)).numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].numpy(), (r * r).sum((0, 2, 3)).numpy(), rtol=1e-5)
+    gam, bet = (torch.rand(Cout, generator=g) + 0.5).to(DEV), (torch.randn(Cout, generator=g) * 0.1).to(DEV)
+    rm0, rv0 = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    o0, st0 = ops.bn_train_fwd(raw, gam, bet, 1e-5, 0.1, rm0, rv0, 1)
+    o1, st1 = ops.bn_train_fwd(raw, gam, bet, 1e-5, 0.1, rm1, rv1, 1, stat_partial=part)
+    close(o1, o0, atol=1e-5, rtol=1e-5)
+    close(st1, st0, atol=1e-5, rtol=1e-5)
+    close(rv1, rv0, atol=1e-6, rtol=1e-5)
+    # data gradient of a 64 -> 128 convolution: 128 channels in, 64 out, from the forward weight
+    dy = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+    add = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    dx = ops.conv3x3_wino4(dy, ops.pack_wino4_weight(w, dgrad=True), Cin, None, None, residual=add)
+    ref = F.conv_transpose2d(dy.double().cpu(), w.double().cpu(), None, 1, 1) + add.double().cpu()
+    assert float((dx.double().cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+
+
 def test_wino4_routing_follows_the_size_policy(monkeypatch):
     """util._conv_bn sends the >= 128 x 128 layers to F(4x4) and everything else to F(2x2) / the direct kernel; TGSR_WINO4=0
     keeps F(2x2) everywhere."""

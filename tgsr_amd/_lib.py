@@ -41,6 +41,7 @@ SIGNATURES = {
     "tgsr_wino_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
     "tgsr_packed_wino4_weight_elems": (_i64, [_i, _i]),
     "tgsr_pack_wino4_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tgsr_pack_wino4_weight_dgrad": (_i, [_vp, _vp, _i, _i, _vp]),
     "tgsr_wino4_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
     "tgsr_conv_to3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),
     "tgsr_word_attention_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp]),
@@ -75,6 +76,8 @@ SIGNATURES = {
     "tgsr_glu": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "tgsr_wino_stats_nslots": (_i, [_i, _i, _i, _i]),
     "tgsr_wino_conv3x3_stats_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp]),
+    "tgsr_wino4_stats_nslots": (_i, [_i, _i, _i, _i]),
+    "tgsr_wino4_conv3x3_stats_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp]),
     "tgsr_bn_train_fwd_from_stats": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp,
                                           _vp, _i64, _vp, _vp]),
     "tgsr_text_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -91,6 +91,8 @@ class PackCache:
 
     @staticmethod
     def _pack(weight, kind, out):
+        if kind in ("wino4", "wino4_dgrad"):
+            return ops.pack_wino4_weight(weight, False, kind == "wino4_dgrad", out=out)
         if kind == "wino":
             return ops.pack_wino_weight(weight, False, False, out=out)
         if kind == "wino_dgrad":
@@ -138,6 +140,8 @@ _PACKS = None        # the PackCache of the trainer whose step is running (train
 def _packed(weight, kind):
     if _PACKS is not None and weight.is_cuda and not torch.cuda.is_current_stream_capturing():
         return _PACKS.get(weight, kind)
+    if kind in ("wino4", "wino4_dgrad"):
+        return C.pack_wino4_weight(weight, False, kind == "wino4_dgrad")
     if kind in ("wino", "wino_dgrad"):
         return C.pack_wino_weight(weight, False, kind == "wino_dgrad")
     if kind == "upwino":
@@ -155,6 +159,9 @@ def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgr
     transposed and flipped: no flip / transpose / copy kernels)."""
     from . import util
     Cout = weight.shape[1] if dgrad else weight.shape[0]
+    if util.WINOGRAD and not upsample and util._wino4_takes(x, Cout, None, residual):
+        # the 128 x 128 layers: F(4x4, 3x3), forward and data gradient alike (tgsr_winograd4.hip)
+        return C.conv3x3_wino4(x, _packed(weight, "wino4_dgrad" if dgrad else "wino4"), Cout, None, None, False, residual)
     if util.WINOGRAD and not upsample and util._wino_pays(x, Cout, None, None):
         return C.conv3x3_wino(x, _packed(weight, "wino_dgrad" if dgrad else "wino"), Cout, None, None, False, residual)
     if util.WINOGRAD and upsample and ops.upwino_supported(x, Cout):
@@ -167,6 +174,11 @@ def _cba_forward(x, weight, gamma, beta, running_mean, running_var, residual, gl
     """conv3x3 (raw) -> BatchNorm batch statistics -> normalise (+ GLU | + residual).  Returns (out, raw, stats)."""
     from . import util
     w = weight.detach()
+    if BN_STATS_IN_CONV and util.WINOGRAD and not upsample and util._wino4_takes(x, w.shape[0], None, None):
+        raw, part = C.conv3x3_wino4_stats(x, _packed(w, "wino4"), w.shape[0])
+        out, stats = C.bn_train_fwd_from_stats(raw, gamma.detach(), beta.detach(), float(eps), float(momentum), running_mean,
+                                               running_var, 1 if glu else 0, residual, nbt, part)
+        return out, raw, stats
     if BN_STATS_IN_CONV and util.WINOGRAD and not upsample and util._wino_pays(x, w.shape[0], None, None):
         # BatchNorm's statistics pass rides the convolution's epilogue: one (sum, sumsq) pair per channel and wave tile
         raw, part = C.conv3x3_wino_stats(x, _packed(w, "wino"), w.shape[0])

@@ -89,6 +89,13 @@ conv3x3_wino_out = _define("conv3x3_wino_out(Tensor x, Tensor upack, int cout, T
                            "Tensor? residual, Tensor(a!) out) -> ()", _conv3x3_wino_out, lambda *a: None)
 
 
+def _wino4_stats_fake(x, upack, cout):
+    n = ops.wino4_stats_nslots(x.shape[0], x.shape[2], x.shape[3], cout)
+    return x.new_empty(x.shape[0], cout, x.shape[2], x.shape[3]), x.new_empty(cout, n, 2)
+
+
+conv3x3_wino4_stats = _define("conv3x3_wino4_stats(Tensor x, Tensor upack, int cout) -> (Tensor, Tensor)",
+                              lambda x, upack, cout: ops.conv3x3_wino4_stats(x, upack, cout), _wino4_stats_fake)
 conv3x3_wino4 = _define("conv3x3_wino4(Tensor x, Tensor upack, int cout, Tensor? scale, Tensor? shift, bool glu, "
                         "Tensor? residual) -> Tensor",
                         lambda x, upack, cout, scale, shift, glu, residual:
@@ -268,8 +275,9 @@ pack_conv3x3_weight = _define("pack_conv3x3_weight(Tensor w, bool dgrad) -> Tens
 pack_wino_weight = _define("pack_wino_weight(Tensor w, bool glu, bool dgrad) -> Tensor",
                            lambda w, g, d: ops.pack_wino_weight(w, glu=g, dgrad=d),
                            lambda w, g, d: w.new_empty(((w.shape[0 if d else 1] + 3) // 4) * 64 * w.shape[1 if d else 0]))
-pack_wino4_weight = _define("pack_wino4_weight(Tensor w, bool glu) -> Tensor", lambda w, g: ops.pack_wino4_weight(w, glu=g),
-                            lambda w, g: w.new_empty(((w.shape[1] + 3) // 4) * 144 * w.shape[0]))
+pack_wino4_weight = _define("pack_wino4_weight(Tensor w, bool glu, bool dgrad) -> Tensor",
+                            lambda w, g, d: ops.pack_wino4_weight(w, glu=g, dgrad=d),
+                            lambda w, g, d: w.new_empty(((w.shape[0 if d else 1] + 3) // 4) * 144 * w.shape[1 if d else 0]))
 pack_upwino_weight = _define("pack_upwino_weight(Tensor w, bool glu) -> Tensor", lambda w, g: ops.pack_upwino_weight(w, glu=g),
                              lambda w, g: w.new_empty(((w.shape[1] + 3) // 4) * (w.shape[0] // 64) * 2304))
 upwino = _define("upwino(Tensor x, Tensor upack, int cout, Tensor? scale, Tensor? shift, bool glu) -> Tensor",

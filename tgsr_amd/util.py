@@ -65,7 +65,7 @@ class _FusedParams:
     def get_wino4(self, conv: nn.Conv2d, bn, glu: bool):
         self._refresh(conv, bn)
         if self.u4pack is None:
-            self.u4pack = C.pack_wino4_weight(conv.weight.detach(), glu)
+            self.u4pack = C.pack_wino4_weight(conv.weight.detach(), glu, False)
         return self.u4pack, self.scale, self.shift
 
 
