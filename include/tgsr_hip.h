@@ -130,9 +130,9 @@ int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int
 /*
  * The same convolution by Winograd F(4x4, 3x3): 36 multiplies per 16 outputs (1.78x fewer than F(2x2), 4x fewer than the
  * direct form), for the large layers of the inference path - ResBlock.block util.py:110-130 at 128^2 and above.  fp32
- * throughout; the transforms hold 4, 5, 8 and 1/24, so its rounding error is ~2x that of the other two forms per layer:
- * on the shipped checkpoint the finest image moves 3.07e-5 -> 3.35e-5 (max, against fp64) with the four 128^2 layers on
- * this kernel, 2.1e-4 with every layer on it - callers route by layer size.  upack from
+ * throughout; the transforms hold 4, 5, 8 and 1/24, so its rounding error is ~15x that of the other two forms per layer
+ * (3e-5 on unit-scale data): on the shipped checkpoint the finest image stays at 3.0e-5 (max, against fp64) with the 128^2
+ * and 64^2 layers on this kernel, 2.1e-4 with the 32^2 layers on it too - callers route by layer size.  upack from
  * tgsr_pack_wino4_weight (tgsr_packed_wino4_weight_elems floats; U = G g G^T computed in double, rounded once; `glu` must
  * match the epilogue).  Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0; x, out, residual 16-byte aligned with batch strides
  * % 4 == 0; same epilogue selectors and residual rule as tgsr_conv3x3_fwd.

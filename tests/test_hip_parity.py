@@ -280,8 +280,8 @@ def test_winograd4_training_forms():
 
 
 def test_wino4_routing_follows_the_size_policy(monkeypatch):
-    """util._conv_bn sends the >= 128 x 128 layers to F(4x4) and everything else to F(2x2) / the direct kernel; TGSR_WINO4=0
-    keeps F(2x2) everywhere."""
+    """util._conv_bn sends the large layers (>= 64 x 64 pixels, a full round of workgroups) to F(4x4) and everything else to
+    F(2x2) / the direct kernel; TGSR_WINO4=0 keeps F(2x2) everywhere."""
     from tgsr_amd import util, custom_ops as C
     calls = []
     real4, real2 = C.conv3x3_wino4, C.conv3x3_wino
@@ -290,13 +290,14 @@ def test_wino4_routing_follows_the_size_policy(monkeypatch):
     conv = torch.nn.Conv2d(64, 128, 3, 1, 1, bias=False).to(DEV)
     bn = torch.nn.BatchNorm2d(128).to(DEV).eval()
     fp = util._FusedParams()
-    big, small = torch.randn(1, 64, 128, 128, device=DEV), torch.randn(1, 64, 64, 64, device=DEV)
+    big, small, few = torch.randn(4, 64, 128, 128, device=DEV), torch.randn(4, 64, 32, 64, device=DEV), torch.randn(1, 64, 128, 128, device=DEV)
     y4 = util._conv_bn(big, fp, conv, bn, glu=True)
     util._conv_bn(small, fp, conv, bn, glu=True)
-    assert calls == [4, 2]
+    util._conv_bn(few, fp, conv, bn, glu=True)
+    assert calls == [4, 2, 2]
     monkeypatch.setenv("TGSR_WINO4", "0")
     y2 = util._conv_bn(big, fp, conv, bn, glu=True)
-    assert calls == [4, 2, 2]
+    assert calls == [4, 2, 2, 2]
     assert float((y4 - y2).abs().max()) < 1e-4
 
 

@@ -190,13 +190,16 @@ def test_lazy_log_is_opt_in_and_formats_like_the_reference():
 
 
 def test_wino4_size_policy(monkeypatch):
-    """Which conv3x3 layers the inference path sends to the F(4x4, 3x3) kernel: whole 8 x 64 tiles, 64-channel groups and - the
-    numerics policy of tgsr_winograd4.hip - only images of >= 128 x 128 pixels; TGSR_WINO4=0 switches it off."""
+    """Which conv3x3 layers go to the F(4x4, 3x3) kernel: whole 8 x 64 tiles, 64-channel groups, - the numerics policy of
+    tgsr_winograd4.hip - only images of >= 64 x 64 pixels, and at least one full round of workgroups; TGSR_WINO4=0 switches it
+    off."""
     from tgsr_amd import ops
     monkeypatch.delenv("TGSR_WINO4", raising=False)
-    assert ops.wino4_wanted(64, 128, 128, 128) and ops.wino4_wanted(64, 64, 128, 128) and ops.wino4_wanted(64, 64, 256, 256)
-    assert not ops.wino4_wanted(64, 128, 64, 64) and not ops.wino4_wanted(64, 128, 32, 32)       # the policy
-    assert not ops.wino4_wanted(64, 32, 128, 128) and not ops.wino4_wanted(3, 64, 128, 128)      # channel groups / stages
-    assert not ops.wino4_wanted(64, 64, 128, 160) and not ops.wino4_wanted(64, 64, 132, 128)     # whole tiles
+    assert ops.wino4_wanted(64, 128, 128, 128, 16) and ops.wino4_wanted(64, 64, 128, 128, 16) and ops.wino4_wanted(64, 64, 256, 256, 2)
+    assert ops.wino4_wanted(64, 128, 64, 64, 16) and not ops.wino4_wanted(64, 64, 64, 64, 16)    # 256 vs 128 workgroups
+    assert not ops.wino4_wanted(64, 128, 128, 128, 2)                                            # small batch: F(2x2)'s tiles
+    assert not ops.wino4_wanted(64, 128, 32, 32, 64) and not ops.wino4_wanted(128, 256, 32, 64, 64)   # the numerics policy
+    assert not ops.wino4_wanted(64, 32, 128, 128, 16) and not ops.wino4_wanted(3, 64, 128, 128, 16)   # channel groups / stages
+    assert not ops.wino4_wanted(64, 64, 128, 160, 16) and not ops.wino4_wanted(64, 64, 132, 128, 16)  # whole tiles
     monkeypatch.setenv("TGSR_WINO4", "0")
-    assert not ops.wino4_wanted(64, 128, 128, 128)
+    assert not ops.wino4_wanted(64, 128, 128, 128, 16)

@@ -5,10 +5,12 @@
 //
 //   Y(4x4) = A^T [ (G g G^T) (.) (B^T d B) ] A     per 6x6 input tile d, 3x3 filter g, interpolation points 0, +-1, +-2, inf:
 // 36 multiplies per 16 outputs instead of 144 - 1.78x fewer MFMAs than F(2x2, 3x3), 4x fewer than the direct form.
-// Numerics: the transforms hold 4, 5, 8 and 1/24 where F(2x2) holds 1 and 1/2; measured end to end on the shipped
-// checkpoint (oracle with this algorithm in fp32 on the 128^2 layers vs the fp64 oracle) the finest image
-// moves 3.07e-5 -> 3.35e-5 max, 5.4e-7 -> 5.5e-7 mean (stated tolerance 1e-4); used on the 64^2 and 32^2 layers as well
-// it would be 2.1e-4 - the launcher's callers (ops.wino4_wanted) therefore only route layers of >= 128 x 128 pixels here.
+// Numerics: the transforms hold 4, 5, 8 and 1/24 where F(2x2) holds 1 and 1/2: per layer, on unit-scale data, 1.6e-5 .. 3.4e-5
+// (max) against 7e-7 .. 1.8e-6.  Measured end to end on the shipped checkpoint (oracle with this algorithm in fp32 on chosen
+// layers vs the fp64 oracle; stated tolerance 1e-4): with the 128^2 layers on it the finest image stays at
+// 3.0e-5 max (the direct fp32 form: 2.9e-5; the reference's own CPU path 3.7e-5), with the 64^2 layers as well the 256^2
+// image of G_SR_NET_low moves 0.9e-5 -> 2.3e-5; with the 32^2 layers too the finest image is off by 2.1e-4 - the callers
+// (ops.wino4_wanted) therefore route layers of >= 64 x 64 pixels here and nothing smaller.
 //
 // Geometry.  MFMA 16x16x4, one accumulator per transformed position: a wave owns 16 tiles (one tile row = 4 x 64 output
 // pixels) x 16 output channels x 36 positions = 144 accumulator registers; a workgroup = 8 waves = 2 tile rows (g) x 4

@@ -226,17 +226,22 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
     return out
 
 
-WINO4_MIN_PIXELS = 128 * 128      # per image; DESIGN.md 3.1e: the error study that allows F(4x4) on these layers only
+WINO4_MIN_PIXELS = 64 * 64        # per image; DESIGN.md 3.1e: the error study that keeps F(4x4) off the 32 x 32 layers
+WINO4_MIN_WORKGROUPS = 256        # one 8-wave workgroup per CU: below a full round F(2x2)'s four times smaller tiles win
 
 
-def wino4_wanted(cin: int, cout: int, H: int, W: int) -> bool:
-    """Does the inference path route a conv3x3 layer to the F(4x4, 3x3) kernel?  Shape support (Cout % 64, Cin % 4,
-    W % 64, H % 8: whole workgroup tiles) AND the numerics policy: only layers of >= 128 x 128 pixels - the four such
-    layers of a forward move the finest image by 3e-6 (max, vs fp64), every layer on it would cost 2e-4 (tgsr_winograd4.hip).
+def wino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
+    """Does a conv3x3 layer go to the F(4x4, 3x3) kernel?  Shape support (Cout % 64, Cin % 4, W % 64, H % 8: whole workgroup
+    tiles), the numerics policy - only layers of >= 64 x 64 pixels: measured on the shipped checkpoint against fp64, the 128^2
+    and 64^2 layers on it move the finest images by <= 4e-6 (max), the 32^2 layers on it as well cost 2e-4 (tgsr_winograd4.hip)
+    - and enough work for its 8 x 64 x 64-channel workgroup tiles to fill the chip (batch 16: the 128^2 ResBlock convolutions
+    and the 64 -> 128 ones at 64^2; 64 -> 64 at 64^2 is 128 workgroups and stays on F(2x2): 29 vs 33 us).
     TGSR_WINO4=0 keeps every layer on F(2x2)."""
     if os.environ.get("TGSR_WINO4", "1") == "0":
         return False
-    return cout % 64 == 0 and cin % 4 == 0 and W % 64 == 0 and H % 8 == 0 and H * W >= WINO4_MIN_PIXELS
+    if not (cout % 64 == 0 and cin % 4 == 0 and W % 64 == 0 and H % 8 == 0 and H * W >= WINO4_MIN_PIXELS):
+        return False
+    return B * (H // 8) * (W // 64) * (cout // 64) >= WINO4_MIN_WORKGROUPS
 
 
 def pack_wino4_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -25,8 +25,8 @@ def _ver(*ts):
 
 
 # Inference convolutions without upsampling go through the Winograd F(2x2,3x3) kernel where it applies
-# (ops.wino_supported: Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0), the layers of >= 128 x 128 pixels through F(4x4,3x3)
-# (ops.wino4_wanted; TGSR_WINO4=0: F(2x2) there too); TGSR_WINOGRAD=0 keeps the direct kernel everywhere.
+# (ops.wino_supported: Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0), the large layers (>= 64 x 64 pixels and a full round of
+# workgroups: ops.wino4_wanted) through F(4x4,3x3) (TGSR_WINO4=0: F(2x2) there too); TGSR_WINOGRAD=0 keeps the direct kernel.
 WINOGRAD = os.environ.get("TGSR_WINOGRAD", "1") != "0"
 
 
@@ -70,9 +70,9 @@ class _FusedParams:
 
 
 def _wino4_takes(x, cout, out, residual):
-    """The F(4x4, 3x3) kernel: the layers ops.wino4_wanted names (>= 128 x 128 pixels, whole 8 x 64 tiles, 64-channel groups)
-    when every tensor is 16-byte aligned with batch strides % 4 == 0."""
-    if x.dim() != 4 or not ops.wino4_wanted(x.shape[1], cout, x.shape[2], x.shape[3]):
+    """The F(4x4, 3x3) kernel: the layers ops.wino4_wanted names (>= 64 x 64 pixels, whole 8 x 64 tiles, 64-channel groups, a
+    full round of workgroups) when every tensor is 16-byte aligned with batch strides % 4 == 0."""
+    if x.dim() != 4 or not ops.wino4_wanted(x.shape[1], cout, x.shape[2], x.shape[3], x.shape[0]):
         return False
     for t in (x, out, residual):
         if t is not None and (t.data_ptr() % 16 != 0 or (t.shape[0] > 1 and t.stride(0) % 4 != 0) or t.stride(3) != 1 or
