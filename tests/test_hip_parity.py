@@ -196,6 +196,9 @@ WINO4_CASES = [
     (1, 20, 5, 8, 64, True, False),        # image smaller than one tile row
     (3, 32, 40, 132, 192, False, True),    # three channel groups, ragged
     (1, 64, 256, 256, 64, True, False),    # the x16 generator's 256^2 stage
+    (2, 8, 10, 72, 256, True, False),      # wide form: two 128-row groups, ragged
+    (2, 16, 24, 64, 128, False, True),     # wide form, plain epilogue + residual
+    (16, 64, 64, 64, 128, True, False),    # the 64 -> 128 convolutions at 64^2, batch 16
 ]
 
 
@@ -223,6 +226,13 @@ def test_conv3x3_winograd4(B, Cin, H, W, Cout, glu, res):
     # the raw convolution (no affine), as the custom op
     raw = C.conv3x3_wino4(x.to(DEV), ops.pack_wino4_weight(w.to(DEV), glu=False), Cout, None, None, False, None)
     assert float((raw.cpu().double() - F.conv2d(x.double(), w.double(), None, 1, 1)).abs().max()) < 1e-4
+    if Cout % 128 == 0 and Cin % 8 == 0:
+        # the wide form (128-row workgroups, A fragments loaded from L2 into registers a stage ahead): the same arithmetic in the
+        # same order - bit-identical to the narrow form
+        upw = ops.pack_wino4w_weight(w.to(DEV), glu=glu)
+        ow = C.conv3x3_wino4w(x.to(DEV), upw, Cout, scale.to(DEV), shift.to(DEV), glu, None if r is None else r.to(DEV))
+        assert torch.equal(ow, out)
+        assert torch.equal(ow, C.conv3x3_wino4w(x.to(DEV), upw, Cout, scale.to(DEV), shift.to(DEV), glu, None if r is None else r.to(DEV)))
 
 
 def test_conv3x3_winograd4_channel_slices_and_refusals():
@@ -245,6 +255,9 @@ def test_conv3x3_winograd4_channel_slices_and_refusals():
         ops.conv3x3_wino4(wide_in[:, 32:, :, 1:63], up, 128, None, None, glu=True)     # not contiguous rows / W % 4
     with pytest.raises(TgsrError):
         ops.conv3x3_wino4(wide_in[:, :32], up, 128, None, None, glu=True)              # pack made for 64 input channels
+    with pytest.raises(TgsrError):                                                     # wide form: an even number of stages
+        ops.conv3x3_wino4(torch.randn(1, 12, 8, 64, device=DEV), ops.pack_wino4w_weight(torch.randn(128, 12, 3, 3, device=DEV)),
+                          128, None, None, wide=True)
 
 
 def test_winograd4_training_forms():
@@ -284,8 +297,8 @@ def test_wino4_routing_follows_the_size_policy(monkeypatch):
     F(2x2) / the direct kernel; TGSR_WINO4=0 keeps F(2x2) everywhere."""
     from tgsr_amd import util, custom_ops as C
     calls = []
-    real4, real2 = C.conv3x3_wino4, C.conv3x3_wino
-    monkeypatch.setattr(C, "conv3x3_wino4", lambda *a: (calls.append(4), real4(*a))[1])
+    real4, real2 = C.conv3x3_wino4w, C.conv3x3_wino
+    monkeypatch.setattr(C, "conv3x3_wino4w", lambda *a: (calls.append(4), real4(*a))[1])
     monkeypatch.setattr(C, "conv3x3_wino", lambda *a: (calls.append(2), real2(*a))[1])
     conv = torch.nn.Conv2d(64, 128, 3, 1, 1, bias=False).to(DEV)
     bn = torch.nn.BatchNorm2d(128).to(DEV).eval()

@@ -428,6 +428,281 @@ __global__ __launch_bounds__(512, 2) void wino4_conv3x3_kernel(Wino4Args a) {
   TGSR_W4STAMP(3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The wide form for layers with Cout % 128 == 0 (the GLU convolutions 64 -> 128 of the ResBlocks): a workgroup = 8 waves =
+// ONE tile row (4 x 64 outputs) x 8 channel blocks = 128 accumulator rows.  What a stage costs beyond its MFMAs is the
+// non-MFMA instruction count of its busiest SIMD, and most of that is the input transform (kernel above: 900 of 1 400
+// cycles): here one tile row's transform (3 waves) feeds 8 waves of MFMAs instead of 4, so a SIMD carries ONE transforming wave.
+// Sixteen accumulator rows more per tile row need twice the U per stage - 74 KB, which double-buffered no longer fits LDS -
+// so the A operands come straight from L2 into registers: the pack is in per-wave fragment order [stage][group][cb 8][quad 9]
+// [lane 64][4], one global_load_dwordx4 per quad, issued behind the quad's MFMAs for the NEXT stage into the same registers
+// (a rolling single buffer: the load has a whole stage to return; the registers' old contents were read by MFMAs issued
+// before it).  The loads are inline assembly with explicit, counted waits: per wave the VMEM stream is [raw copies of this
+// stage, 0-2][A loads of the next stage, 9], so `vmcnt(8)` in front of quad q's MFMAs means "A(q) has arrived" (eight younger
+// A loads may be in flight; younger copies only make the wait stricter) and `vmcnt(9)` at the stage's end means "my copies
+// have landed".  The last stage re-loads stage 0's fragments (harmless, keeps the counting uniform); `vmcnt(0)` in front of
+// the epilogue keeps late arrivals out of registers the epilogue reuses.
+// LDS: raw [4 ci][6 rows][72] in planes of 448 floats x 2 + V x 2 + affine table = 34 KB.
+constexpr int k4wTR = 6, k4wPLANE = 448, k4wRAW = k4CK * k4wPLANE;     // 1792 floats = 7 DMA pieces
+constexpr int k4wSMEM = 2 * k4wRAW + 2 * k4V + 256;
+constexpr int k4wUW = 9 * 256;                                          // floats of U per wave and stage
+
+template <bool GLU>
+__global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
+  __shared__ __attribute__((aligned(16))) float smem[k4wSMEM];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
+  const int cb = __builtin_amdgcn_readfirstlane(tid >> 6);             // channel block of this wave
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int grp = t % a.ngroups;
+  t /= a.ngroups;
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int y0 = ty * 4, x0 = tx * 64;
+  const float* xb = a.x + (int64_t)b * a.xbs;
+  const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
+  float* raws = smem;
+  float* vs = smem + 2 * k4wRAW;
+  float* aff_s = smem + 2 * k4wRAW + 2 * k4V;
+
+  // ---- raw copies: 7 pieces per stage on the five waves that do not transform - wave 3: pieces 0, 1; wave 7: 2, 3; waves
+  // 4, 5, 6: pieces 4, 5, 6
+  const int npiece = (cb == 3 || cb == 7) ? 2 : (cb >= 4 ? 1 : 0);
+  const int piece0 = cb == 3 ? 0 : (cb == 7 ? 2 : cb);
+  const float* rptr[2];
+  int rstep[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = (((npiece ? piece0 : 0) + k) * 64 + lane) * 4;
+    const int c = e / k4wPLANE;
+    const int rem = e - c * k4wPLANE;
+    const int r = rem / k4TC, j = rem - r * k4TC;
+    const int gy = y0 - 1 + r, gx = x0 - 4 + j;
+    const bool ok = e < k4wRAW && rem < k4wTR * k4TC && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    rptr[k] = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(gy * a.W + gx) : g_wino4_zero;
+    rstep[k] = ok ? (int)(k4CK * HW) : 0;
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr4_t)smem);
+  const unsigned lds_raw = lds0 + piece0 * 1024;
+  auto issue_raw = [&](int buf) {
+    if (npiece >= 1) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr[0]), "s"(lds_raw + buf * (k4wRAW * 4)) : "memory");
+      rptr[0] += rstep[0];
+    }
+    if (npiece >= 2) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr[1]), "s"(lds_raw + buf * (k4wRAW * 4) + 1024) : "memory");
+      rptr[1] += rstep[1];
+    }
+  };
+  // ---- A fragments: this wave's 9 KB of a stage, three per-lane offsets 4 KB apart + an immediate
+  const float* ubase = a.upack + ((int64_t)grp * 8 + cb) * k4wUW;      // stage 0
+  const float* const ubase0 = ubase;
+  const int64_t ustride = (int64_t)a.ngroups * 8 * k4wUW;
+  unsigned voff[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) voff[k] = (unsigned)(lane * 16 + k * 4096);
+  f32x4w4 af[9];
+#define TGSR_W4W_LOAD(q)                                                                                               \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(af[q]) : "v"(voff[(q) / 4]), "s"(ubase), "n"(((q) % 4) * 1024) : "memory")
+#define TGSR_W4W_WAIT(q) asm volatile("s_waitcnt vmcnt(8)" : "+v"(af[q])::"memory")
+
+  // ---- input transform: waves 0, 1, 2 take the row pairs (0, 5), (1, 2), (3, 4) of B^T (as in the kernel above, one tile row)
+  const int rlane = lg * k4wPLANE + 4 * l15;
+  const int vwl = (lg * 16 + l15) * 4;
+  auto t_read = [&](auto rc, const float* rawb, float (&d)[6][6]) {
+    constexpr int R = decltype(rc)::value;
+    const float* rp = rawb + rlane;
+#pragma unroll
+    for (int p = (R == 0 ? 0 : 1); p < (R == 0 ? 6 : 5); ++p) {
+      const f32x4w4 mid = *reinterpret_cast<const f32x4w4*>(rp + p * k4TC + 4);
+      d[p][0] = rp[p * k4TC + 3];
+      d[p][1] = mid[0]; d[p][2] = mid[1]; d[p][3] = mid[2]; d[p][4] = mid[3];
+      d[p][5] = rp[p * k4TC + 8];
+    }
+  };
+  auto t_write = [&](auto rc, const float (&d)[6][6], float* vdst) {
+    constexpr int R = decltype(rc)::value;
+    float ta[6], tb[6], oa[6], ob[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      w4_bt_pair<R>(R == 0 ? d[0][j] : 0.f, d[1][j], d[2][j], d[3][j], d[4][j], R == 0 ? d[5][j] : 0.f, ta[j], tb[j]);
+    w4_bt_full(ta, oa);
+    w4_bt_full(tb, ob);
+    constexpr int kVQ = k4CK * 16 * 4;
+    float* vp = vdst + vwl + (3 * R) * kVQ;
+    *reinterpret_cast<f32x4w4*>(vp) = f32x4w4{oa[0], oa[1], oa[2], oa[3]};
+    *reinterpret_cast<f32x4w4*>(vp + kVQ) = f32x4w4{oa[4], oa[5], ob[0], ob[1]};
+    *reinterpret_cast<f32x4w4*>(vp + 2 * kVQ) = f32x4w4{ob[2], ob[3], ob[4], ob[5]};
+  };
+
+  if (tid < 256) {   // aff_s[cb * 16 + m] = scale, [128 + ...] = shift of accumulator row m of block cb
+    const int lc = tid & 127, cbk = lc >> 4, m = lc & 15;
+    int col = GLU ? ((m & 2) ? (a.Cout >> 1) : 0) + grp * 64 + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * 128 + lc;
+    if (col >= a.Cout) col = 0;
+    aff_s[tid] = a.scale ? (tid < 128 ? a.scale[col] : a.shift[col]) : (tid < 128 ? 1.f : 0.f);
+  }
+
+  f32x4w4 M[36];
+#pragma unroll
+  for (int p = 0; p < 36; ++p)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) M[p][i] = 0.f;
+  const int vlane = (lg * 16 + l15) * 4;
+
+  auto stage = [&](auto rc, auto parc, const bool MORE, const bool MORE2) {
+    constexpr int R = decltype(rc)::value, PAR = decltype(parc)::value;
+    if (MORE2) issue_raw(PAR);                           // raw(st+2) replaces raw(st), transformed one stage ago
+    ubase = MORE ? ubase + ustride : ubase0;             // where the fragments loaded during this stage come from
+    float d[6][6];
+    if (R < 3) t_read(rc, raws + (PAR ^ 1) * k4wRAW, d);
+    const float* vb = vs + PAR * k4V + vlane;
+    f32x4w4 bf[3];
+    bf[0] = *reinterpret_cast<const f32x4w4*>(vb);
+    bf[1] = *reinterpret_cast<const f32x4w4*>(vb + (k4CK * 16 * 4));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      if (q + 2 < 9) bf[(q + 2) % 3] = *reinterpret_cast<const f32x4w4*>(vb + (q + 2) * (k4CK * 16 * 4));
+      TGSR_W4W_WAIT(q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        M[4 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][e], bf[q % 3][e], M[4 * q + e], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      TGSR_W4W_LOAD(q);
+      if (q == 2 && R < 3) {
+        t_write(rc, d, vs + (PAR ^ 1) * k4V);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (MORE) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  auto run = [&](auto rc) {
+    constexpr int R = decltype(rc)::value;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    issue_raw(0);
+    if (a.nstages > 1) issue_raw(1);
+    TGSR_W4W_LOAD(0); TGSR_W4W_LOAD(1); TGSR_W4W_LOAD(2); TGSR_W4W_LOAD(3); TGSR_W4W_LOAD(4);
+    TGSR_W4W_LOAD(5); TGSR_W4W_LOAD(6); TGSR_W4W_LOAD(7); TGSR_W4W_LOAD(8);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (R < 3) {
+      float d[6][6];
+      t_read(rc, raws, d);
+      t_write(rc, d, vs);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // an EVEN number of stages (host-checked): exactly two copies of the stage, P0 -> P1 -> back edge.  A third copy behind the
+    // loop (an odd tail) got other physical registers for af[] and hipcc bridged them with v_mov - of fragments that had not
+    // arrived yet (every output wrong at Cin = 12; the parity tests of the wide form would catch a recurrence)
+    for (int st = 0; st < a.nstages; st += 2) {
+      stage(rc, P0{}, true, st + 2 < a.nstages);
+      stage(rc, P1{}, st + 2 < a.nstages, st + 3 < a.nstages);
+    }
+  };
+  if (cb == 0) run(std::integral_constant<int, 0>{});
+  else if (cb == 1) run(std::integral_constant<int, 1>{});
+  else if (cb == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last stage's (unused) fragment loads: see the header
+#undef TGSR_W4W_LOAD
+#undef TGSR_W4W_WAIT
+
+  auto ytile = [&](int i, float (&y)[4][4]) {
+    float c[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float col[4];
+      w4_at(M[w4_pos(0, j)][i], M[w4_pos(1, j)][i], M[w4_pos(2, j)][i], M[w4_pos(3, j)][i], M[w4_pos(4, j)][i], M[w4_pos(5, j)][i], col);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c[r][j] = col[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w4_at(c[r][0], c[r][1], c[r][2], c[r][3], c[r][4], c[r][5], y[r]);
+  };
+  const int oy = y0, ox = x0 + 4 * l15;
+  const int64_t HWo = (int64_t)a.H * a.W;
+  float* __restrict__ ob = a.out + (int64_t)b * a.obs;
+  const float* __restrict__ rb = a.res ? a.res + (int64_t)b * a.rbs : nullptr;
+  if (ox < a.W) {
+    if (GLU) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float yv[4][4], yg[4][4];
+        ytile(p, yv);
+        ytile(p + 2, yg);
+        const int m = 4 * lg + p;
+        const float sv = aff_s[cb * 16 + m], tv = aff_s[128 + cb * 16 + m], sg = aff_s[cb * 16 + m + 2], tg = aff_s[128 + cb * 16 + m + 2];
+        const int c = grp * 64 + cb * 8 + 2 * lg + p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (oy + r >= a.H) continue;
+          f32x4w4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            o[k] = (yv[r][k] * sv + tv) * __builtin_amdgcn_rcpf(1.f + __expf(-(yg[r][k] * sg + tg)));
+          *reinterpret_cast<f32x4w4*>(ob + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox) = o;
+        }
+      }
+    } else {
+      f32x4w4 rr[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = grp * 128 + cb * 16 + 4 * lg + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          rr[i][r] = f32x4w4{0.f, 0.f, 0.f, 0.f};
+          if (rb && oy + r < a.H) rr[i][r] = *reinterpret_cast<const f32x4w4*>(rb + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = 4 * lg + i, c = grp * 128 + cb * 16 + m;
+        float yv[4][4];
+        ytile(i, yv);
+        const float sv = aff_s[cb * 16 + m], tv = aff_s[128 + cb * 16 + m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (oy + r >= a.H) continue;
+          f32x4w4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = yv[r][k] * sv + tv + rr[i][r][k];
+          *reinterpret_cast<f32x4w4*>(ob + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox) = o;
+        }
+      }
+    }
+  }
+}
+
+// wide pack: upack[stage][group of 128 rows][cb 8][quad 9][lane 64 = (ci lane >> 4, row lane & 15)][4]; row m of block cb:
+// plain = cout grp*128 + cb*16 + m; GLU = value channel grp*64 + cb*8 + 2 (m >> 2) + (m & 1) when m & 2 == 0, else its gate
+__global__ void pack_wino4w_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu,
+                                          int64_t total) {
+  const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  const int ngrp = Cout / 128;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(idx & 3), m = (int)((idx >> 2) & 15), ci = (int)((idx >> 6) & 3);
+    int64_t t = idx >> 8;
+    const int q = (int)(t % 9);
+    t /= 9;
+    const int cbk = (int)(t & 7);
+    t >>= 3;
+    const int grp = (int)(t % ngrp);
+    const int st = (int)(t / ngrp);
+    const int i = w4_row(q, e), j = w4_col(q, e);
+    const int co = glu ? ((m & 2) ? (Cout >> 1) : 0) + grp * 64 + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * 128 + cbk * 16 + m;
+    const int c = st * k4CK + ci;
+    double u = 0.0;
+    if (c < Cin) {
+      const float* gw = w + ((int64_t)co * Cin + c) * 9;
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 3; ++l) u += G[i][k] * (double)gw[k * 3 + l] * G[j][l];
+    }
+    up[idx] = (float)u;
+  }
+}
+
 // upack[stage][group][quad 9][ci 4][cb 4][row 16][4] <- U = G g G^T (computed in double, rounded once); a group is the 64
 // accumulator rows of one workgroup.  Row m of block cb: plain = cout grp*64 + cb*16 + m; GLU = value channel
 // grp*32 + cb*8 + 2 (m >> 2) + (m & 1) when m & 2 == 0, its gate (+ Cout/2) otherwise.
@@ -540,4 +815,38 @@ extern "C" int tgsr_wino4_conv3x3_stats_fwd(const float* x, int64_t x_bstride, i
   if (!stat_partial) return TGSR_EINVAL;
   return wino4_conv3x3(x, x_bstride, B, Cin, H, W, upack, Cout, nullptr, nullptr, nullptr, 0, out, out_bstride, TGSR_EPI_AFFINE,
                        stat_partial, stream);
+}
+
+extern "C" int tgsr_pack_wino4_wide_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
+  if (!w || !upack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
+  if (Cout % 128 != 0) return TGSR_EUNSUPPORTED;
+  const int64_t total = tgsr_packed_wino4_weight_elems(Cout, Cin);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(pack_wino4w_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin, glu ? 1 : 0, total);
+  return note_launch(hipGetLastError(), "pack_wino4w_weight_kernel");
+}
+
+extern "C" int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                                           int Cout, const float* scale, const float* shift, const float* residual,
+                                           int64_t res_bstride, float* out, int64_t out_bstride, int epilogue, void* stream) {
+  if (!x || !upack || !out || B < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return TGSR_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
+  const bool glu = epilogue == TGSR_EPI_AFFINE_GLU;
+  if (!glu && epilogue != TGSR_EPI_AFFINE) return TGSR_EINVAL;
+  if (glu && residual) return TGSR_EINVAL;
+  if (Cout % 128 != 0 || Cin % (2 * k4CK) != 0) return TGSR_EUNSUPPORTED;      // an even number of 4-channel stages
+  if ((int64_t)H * W >= (1 << 28) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
+  if ((W & 3) || (x_bstride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (reinterpret_cast<uintptr_t>(upack) & 15) || (out_bstride & 3) ||
+      (residual && ((reinterpret_cast<uintptr_t>(residual) & 15) || (res_bstride & 3))))
+    return TGSR_EUNSUPPORTED;
+  Wino4Args a;
+  a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
+  a.scale = scale; a.shift = shift; a.res = residual; a.rbs = res_bstride; a.out = out; a.obs = out_bstride;
+  a.tiles_x = (W + 63) / 64; a.tiles_y = (H + 3) / 4; a.nstages = Cin / k4CK; a.ngroups = Cout / 128;
+  a.stat = nullptr; a.nslots = 0;
+  const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.ngroups));
+  if (glu) hipLaunchKernelGGL((wino4w_conv3x3_kernel<true>), grid, dim3(512), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((wino4w_conv3x3_kernel<false>), grid, dim3(512), 0, as_stream(stream), a);
+  return note_launch(hipGetLastError(), "wino4w_conv3x3_kernel");
 }

@@ -109,6 +109,21 @@ conv3x3_wino4_out = _define("conv3x3_wino4_out(Tensor x, Tensor upack, int cout,
                             lambda *a: None)
 
 
+pack_wino4w_weight = _define("pack_wino4w_weight(Tensor w, bool glu) -> Tensor", lambda w, g: ops.pack_wino4w_weight(w, glu=g),
+                             lambda w, g: w.new_empty(((w.shape[1] + 3) // 4) * 144 * w.shape[0]))
+conv3x3_wino4w = _define("conv3x3_wino4w(Tensor x, Tensor upack, int cout, Tensor? scale, Tensor? shift, bool glu, "
+                         "Tensor? residual) -> Tensor",
+                         lambda x, upack, cout, scale, shift, glu, residual:
+                         ops.conv3x3_wino4(x, upack, cout, scale, shift, glu=glu, residual=residual, wide=True),
+                         lambda x, upack, cout, scale, shift, glu, residual:
+                         x.new_empty(x.shape[0], _co(cout, glu), x.shape[2], x.shape[3]))
+conv3x3_wino4w_out = _define("conv3x3_wino4w_out(Tensor x, Tensor upack, int cout, Tensor? scale, Tensor? shift, bool glu, "
+                             "Tensor? residual, Tensor(a!) out) -> ()",
+                             lambda x, upack, cout, scale, shift, glu, residual, out:
+                             (ops.conv3x3_wino4(x, upack, cout, scale, shift, glu=glu, residual=residual, out=out, wide=True), None)[1],
+                             lambda *a: None)
+
+
 # ------------------------------------------------------------------------------------------------ upBlock forms
 def _up_fake(x, pack, cout, scale, shift):
     return x.new_empty(x.shape[0], cout // 2, 2 * x.shape[2], 2 * x.shape[3])

@@ -263,9 +263,22 @@ def pack_wino4_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, o
     return out
 
 
+def pack_wino4w_weight(w: torch.Tensor, glu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The pack of the WIDE F(4x4,3x3) kernel (Cout % 128 == 0): per-wave fragment order [Cin/4][Cout/128][8 blocks][9 quads]
+    [64 lanes][4] - not interchangeable with pack_wino4_weight's."""
+    _need_hip(w)
+    w = _f32(w.detach(), "weight").contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = _pack_out(out, L.tgsr_packed_wino4_weight_elems(Cout, Cin), w.device)
+    check(L.tgsr_pack_wino4_wide_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_wino4_wide_weight")
+    return out
+
+
 def conv3x3_wino4(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, glu: bool = False,
-                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """conv3x3 + affine + (GLU | residual) by Winograd F(4x4,3x3) (same contract as conv3x3_wino; 16-byte aligned tensors)."""
+                  residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, wide: bool = False) -> torch.Tensor:
+    """conv3x3 + affine + (GLU | residual) by Winograd F(4x4,3x3) (same contract as conv3x3_wino; 16-byte aligned tensors).
+    `wide`: the Cout % 128 == 0 form, upack from pack_wino4w_weight."""
     _need_hip(x, upack, scale, shift, residual, out)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
@@ -282,9 +295,10 @@ def conv3x3_wino4(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
         if tuple(residual.shape) != (B, co, H, W):
             raise TgsrError("conv3x3_wino4: residual shape %s" % (tuple(residual.shape),))
     e0 = _ev() if profile is not None else None
-    rc = _lib.lib().tgsr_wino4_conv3x3_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(residual),
-                                           rbs, _p(out), obs, _lib.EPI_AFFINE_GLU if glu else _lib.EPI_AFFINE, _stream())
-    check(rc, "tgsr_wino4_conv3x3_fwd")
+    fn = _lib.lib().tgsr_wino4_wide_conv3x3_fwd if wide else _lib.lib().tgsr_wino4_conv3x3_fwd
+    rc = fn(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(residual), rbs, _p(out), obs,
+            _lib.EPI_AFFINE_GLU if glu else _lib.EPI_AFFINE, _stream())
+    check(rc, "tgsr_wino4_wide_conv3x3_fwd" if wide else "tgsr_wino4_conv3x3_fwd")
     if profile is not None:
         nbytes = 4 * (B * Cin * H * W + B * co * H * W * (2 if residual is not None else 1) + cout * Cin * 9)
         profile.append(("wino4_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9, nbytes, e0, _ev()))

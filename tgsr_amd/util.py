@@ -63,10 +63,14 @@ class _FusedParams:
 
 
     def get_wino4(self, conv: nn.Conv2d, bn, glu: bool):
+        """(pack, scale, shift, wide): the wide form of the F(4x4) kernel (tgsr_wino4_wide_conv3x3_fwd) where the layer has
+        128-channel groups and an even number of 4-channel stages."""
         self._refresh(conv, bn)
+        wide = conv.out_channels % 128 == 0 and conv.in_channels % 8 == 0
         if self.u4pack is None:
-            self.u4pack = C.pack_wino4_weight(conv.weight.detach(), glu, False)
-        return self.u4pack, self.scale, self.shift
+            self.u4pack = (C.pack_wino4w_weight(conv.weight.detach(), glu) if wide else
+                           C.pack_wino4_weight(conv.weight.detach(), glu, False))
+        return self.u4pack, self.scale, self.shift, wide
 
 
 def _wino4_takes(x, cout, out, residual):
@@ -103,10 +107,10 @@ def _conv_bn(x, fp: _FusedParams, conv, bn, glu=False, upsample=False, residual=
             raise RuntimeError("training path does not write into channel-slice views")
         return y
     if WINOGRAD and not upsample and _wino4_takes(x, conv.out_channels, out, residual):
-        upack, scale, shift = fp.get_wino4(conv, bn, glu)
+        upack, scale, shift, wide = fp.get_wino4(conv, bn, glu)
         if out is None:
-            return C.conv3x3_wino4(x, upack, conv.out_channels, scale, shift, glu, residual)
-        C.conv3x3_wino4_out(x, upack, conv.out_channels, scale, shift, glu, residual, out)
+            return (C.conv3x3_wino4w if wide else C.conv3x3_wino4)(x, upack, conv.out_channels, scale, shift, glu, residual)
+        (C.conv3x3_wino4w_out if wide else C.conv3x3_wino4_out)(x, upack, conv.out_channels, scale, shift, glu, residual, out)
         return out
     if WINOGRAD and not upsample and _wino_pays(x, conv.out_channels, out, residual):
         upack, scale, shift = fp.get_wino(conv, bn, glu)
