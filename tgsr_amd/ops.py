@@ -236,12 +236,13 @@ def wino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
     and 64^2 layers on it move the finest images by <= 4e-6 (max), the 32^2 layers on it as well cost 2e-4 (tgsr_winograd4.hip)
     - and enough work for its 8 x 64 x 64-channel workgroup tiles to fill the chip (batch 16: the 128^2 ResBlock convolutions
     and the 64 -> 128 ones at 64^2; 64 -> 64 at 64^2 is 128 workgroups and stays on F(2x2): 29 vs 33 us).
-    TGSR_WINO4=0 keeps every layer on F(2x2)."""
+    TGSR_WINO4=0 keeps every layer on F(2x2); TGSR_WINO4_MIN_WG=<n> moves the workgroup threshold (diagnostics: n = 1 puts the
+    batch-2 golden case on the kernel, tools/diag_precision.py)."""
     if os.environ.get("TGSR_WINO4", "1") == "0":
         return False
     if not (cout % 64 == 0 and cin % 4 == 0 and W % 64 == 0 and H % 8 == 0 and H * W >= WINO4_MIN_PIXELS):
         return False
-    return B * (H // 8) * (W // 64) * (cout // 64) >= WINO4_MIN_WORKGROUPS
+    return B * (H // 8) * (W // 64) * (cout // 64) >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
 
 
 def pack_wino4_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
