@@ -302,7 +302,7 @@ def conv3x3_wino4(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
     check(rc, "tgsr_wino4_wide_conv3x3_fwd" if wide else "tgsr_wino4_conv3x3_fwd")
     if profile is not None:
         nbytes = 4 * (B * Cin * H * W + B * co * H * W * (2 if residual is not None else 1) + cout * Cin * 9)
-        profile.append(("wino4_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9, nbytes, e0, _ev()))
+        profile.append(("wino4w_conv3x3_kernel" if wide else "wino4_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9, nbytes, e0, _ev()))
     return out
 
 
