@@ -39,7 +39,7 @@ PEAK_HBM_GBS = 8000.0
 # up-sample-aware Winograd: 9 of the 16 positions of a 2x2 output tile = 9/36)
 EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0 / 36.0, "wino4_conv3x3_kernel": 36.0 / 144.0, "wino4w_conv3x3_kernel": 36.0 / 144.0,
                          "upconv_glu_mfma_kernel": 4.0 / 9.0,
-                         "upwino_glu_kernel": 9.0 / 36.0, "lp_conv3x3_kernel": 1.0, "lp_upconv_glu_kernel": 4.0 / 9.0,
+                         "upwino_glu_kernel": 9.0 / 36.0, "upwino4_kernel": 25.0 / 144.0, "lp_conv3x3_kernel": 1.0, "lp_upconv_glu_kernel": 4.0 / 9.0,
                          # training: weight gradients in the Winograd domain (16 | 9 positions per 2x2 outputs), the direct
                          # 9-tap form, the image heads and the discriminators' implicit GEMM (every MAC issued)
                          "wino_wgrad_kernel": 16.0 / 36.0, "upwino_wgrad_kernel": 9.0 / 36.0, "conv3x3_wgrad_kernel": 1.0,
@@ -303,7 +303,7 @@ def roofline_objects(agg, nprof, dtype, serial, steps, batch=16, counters=True):
     peak_mfma = PEAK_LP_MFMA_TFLOPS if lp else PEAK_FP32_MFMA_TFLOPS
     # (counters=False: the committed counter tables were taken on the x8 generators' layer mix - not applied to the x16 line)
     pmc_file, pmc = pmc_table(dtype) if counters else (None, {})
-    conv_kernels = [k for k in ("lp_conv3x3_kernel", "lp_upconv_glu_kernel", "wino4w_conv3x3_kernel", "wino4_conv3x3_kernel", "wino_conv3x3_kernel", "upwino_glu_kernel",
+    conv_kernels = [k for k in ("lp_conv3x3_kernel", "lp_upconv_glu_kernel", "wino4w_conv3x3_kernel", "wino4_conv3x3_kernel", "wino_conv3x3_kernel", "upwino_glu_kernel", "upwino4_kernel",
                                 "conv3x3_mfma_kernel",
                                 "upconv_glu_mfma_kernel") if k in agg]
     dom = max(conv_kernels, key=lambda k: agg[k][3])

@@ -111,6 +111,20 @@ int tgsr_upwino_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, in
                     const float* scale, const float* shift, float* out, int64_t out_bstride, void* stream);
 
 /*
+ * upBlock by Winograd F(4x4, 3x3) on the up-sampled grid with the x2 folded into the input transform: 25 multiplies per
+ * 16 outputs (tgsr_upwino_glu_fwd: 36) - the third transformed row / column vanishes and the fifth is -1/3 of the fourth,
+ * so 5 x 5 positions carry products and their B operands come from 16 values per tile (tgsr_upwino4.hip).  `glu` != 0:
+ * out [B][Cout/2][2H][2W] = GLU(affine(conv3x3(upsample(x)))), else [B][Cout][2H][2W] without the gate (scale/shift may be
+ * NULL).  upack from tgsr_pack_upwino4_weight(glu) (tgsr_packed_upwino4_weight_elems floats).  Cout % 64 == 0,
+ * Cin % 4 == 0, W % 4 == 0, x / out 16-byte aligned with batch strides % 4 == 0.  Numerics: F(4x4)'s (see
+ * tgsr_wino4_conv3x3_fwd); callers route by output size (tgsr_amd.ops.upwino4_wanted).
+ */
+int64_t tgsr_packed_upwino4_weight_elems(int Cout, int Cin);
+int tgsr_pack_upwino4_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream);
+int tgsr_upwino4_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
+                     const float* scale, const float* shift, float* out, int64_t out_bstride, int glu, void* stream);
+
+/*
  * The same fused 3x3 convolution as tgsr_conv3x3_fwd (upsample = 0) by Winograd F(2x2, 3x3): 16 multiplies per 4
  * outputs instead of 36.  fp32 throughout; the transforms only use {0, +-1, +-1/2} (end-to-end error on the shipped
  * checkpoint indistinguishable from the direct fp32 form).  upack from tgsr_pack_wino_weight

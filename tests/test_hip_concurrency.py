@@ -37,6 +37,9 @@ def _neighbours(g, B=16):
     xf4 = R(B, 64, 128, 128)
     upf4 = ops.pack_wino4_weight(R(128, 64, 3, 3) * 0.1, True)
     out["fp32 wino4 64->128 glu @128^2"] = lambda: ops.conv3x3_wino4(xf4, upf4, 128, sc3, sh3, True, None)
+    xu4, pu4 = R(B, 64, 64, 64), ops.pack_upwino4_weight(R(64, 64, 3, 3) * 0.1)
+    sc64n, sh64n = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    out["fp32 upwino4 64 @64->128"] = lambda: ops.upwino4_glu(xu4, pu4, 64, sc64n, sh64n)
     upfw = ops.pack_wino4w_weight(R(128, 64, 3, 3) * 0.1, True)
     out["fp32 wino4 wide 64->128 glu @128^2"] = lambda: ops.conv3x3_wino4(xf4, upfw, 128, sc3, sh3, True, None, wide=True)
     return out
@@ -77,6 +80,8 @@ def _victims(g, B=16):
     xww, upww = R(2, 32, 64, 64), ops.pack_wino4w_weight(R(128, 32, 3, 3) * 0.1, True)
     sc128, sh128 = torch.rand(128, generator=g).to(DEV) + 0.5, R(128) * 0.1
     v["fp32 wino4 wide 32->128 glu @64^2"] = lambda: ops.conv3x3_wino4(xww, upww, 128, sc128, sh128, True, None, wide=True).flatten()
+    xuv, puv = R(2, 32, 32, 32), ops.pack_upwino4_weight(R(64, 32, 3, 3) * 0.1)
+    v["fp32 upwino4 32 @32->64"] = lambda: ops.upwino4_glu(xuv, puv, 64, sc64, sh64).flatten()
     hf, wf, wc = R(B, 32, 32, 32), R(B, 256, T), R(32, 256)
     v["fp32 word attention @32^2"] = lambda: torch.cat([t.flatten() for t in ops.word_attention(hf, wf, wc, None)])
     xh, wh = R(B, 32, 64, 64), R(3, 32, 3, 3) * 0.1

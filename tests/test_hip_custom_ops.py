@@ -121,6 +121,11 @@ def test_opcheck_training_text_damsm_and_lp_operators():
         chk(T.conv3x3_wgrad.default, (dr, x32, up, True, torch.empty(Cc, 32, 3, 3, device=DEV)), test_utils=basic)
     chk(T.conv3x3_wgrad.default, (R(B, 32, H, W), R(B, 3, H, W), False, True, torch.empty(32, 3, 3, 3, device=DEV)), test_utils=basic)
     chk(T.sumpool2x2.default, (raw,), test_utils=basic)
+    upu4 = T.pack_upwino4_weight(R(Cc, 32, 3, 3), True)
+    chk(T.pack_upwino4_weight.default, (R(Cc, 32, 3, 3), True), test_utils=basic)
+    xu4 = R(B, 32, 4, 32)
+    chk(T.upwino4_glu.default, (xu4, upu4, Cc, gam, bet), test_utils=basic)
+    chk(T.upwino4_glu_out.default, (xu4, upu4, Cc, gam, bet, torch.empty(B, Cc // 2, 8, 64, device=DEV)), test_utils=basic)
     up4 = T.pack_wino4_weight(R(Cc, Cc, 3, 3), False, False)
     chk(T.pack_wino4_weight.default, (R(Cc, Cc, 3, 3), True, False), test_utils=basic)
     chk(T.pack_wino4_weight.default, (R(Cc, 128, 3, 3), False, True), test_utils=basic)

@@ -260,6 +260,44 @@ def test_conv3x3_winograd4_channel_slices_and_refusals():
                           128, None, None, wide=True)
 
 
+UPW4_CASES = [
+    # B, Cin, H, W (low resolution), Cout, glu
+    (2, 64, 64, 64, 64, True),       # G_SR_NET_low's second upBlock (64^2 -> 128^2)
+    (1, 64, 128, 128, 64, True),     # ... third (128^2 -> 256^2)
+    (2, 32, 64, 64, 64, True),       # NetG_highweight's
+    (1, 4, 4, 32, 64, True),         # one stage, one workgroup
+    (2, 8, 8, 32, 64, False),        # without the gate
+    (1, 12, 6, 36, 128, True),       # ragged rows / columns, odd stage count, two channel groups
+    (3, 20, 3, 4, 64, True),         # image smaller than a tile row
+]
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,glu", UPW4_CASES)
+def test_upblock_winograd4_vs_upsample_conv(B, Cin, H, W, Cout, glu):
+    """Up-sample-aware F(4x4, 3x3): against F.conv2d(F.interpolate(x, 2)) in fp64, bound 1e-4 on unit-scale data (measured
+    1.0e-5 .. 2.9e-5; the F(2x2) form 5e-7 .. 2.7e-6), bit-reproducible, through the custom op and into a channel slice."""
+    from tgsr_amd import ops, custom_ops as C
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    shift = 0.3 * torch.randn(Cout, generator=g)
+    co = Cout // 2 if glu else Cout
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), None, 1, 1)
+    ref = ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    ref = ref[:, :co] * torch.sigmoid(ref[:, co:]) if glu else ref
+    up = ops.pack_upwino4_weight(w.to(DEV), glu=glu)
+    out = ops.upwino4_glu(x.to(DEV), up, Cout, scale.to(DEV), shift.to(DEV), glu=glu)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 1e-4, err
+    assert torch.equal(out, ops.upwino4_glu(x.to(DEV), up, Cout, scale.to(DEV), shift.to(DEV), glu=glu))
+    if glu:
+        wide = torch.full((B, co + 8, 2 * H, 2 * W), 3.0, device=DEV)
+        C.upwino4_glu_out(x.to(DEV), C.pack_upwino4_weight(w.to(DEV), True), Cout, scale.to(DEV), shift.to(DEV), wide[:, 4:4 + co])
+        assert torch.equal(wide[:, 4:4 + co], out)
+        assert (wide[:, :4] == 3).all() and (wide[:, 4 + co:] == 3).all()
+
+
 def test_winograd4_training_forms():
     """What the training step uses of the F(4x4) kernel: the raw convolution whose epilogue leaves BatchNorm's batch
     statistics as per-wave partial sums, and the data-gradient pack made from the FORWARD weight."""

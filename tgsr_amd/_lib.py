@@ -35,6 +35,9 @@ SIGNATURES = {
     "tgsr_pack_upwino_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tgsr_upwino_glu_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp]),
     "tgsr_upwino_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp]),
+    "tgsr_packed_upwino4_weight_elems": (_i64, [_i, _i]),
+    "tgsr_pack_upwino4_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tgsr_upwino4_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _vp]),
     "tgsr_packed_wino_weight_elems": (_i64, [_i, _i]),
     "tgsr_pack_wino_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tgsr_pack_wino_weight_dgrad": (_i, [_vp, _vp, _i, _i, _vp]),

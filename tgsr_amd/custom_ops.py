@@ -129,6 +129,12 @@ def _up_fake(x, pack, cout, scale, shift):
     return x.new_empty(x.shape[0], cout // 2, 2 * x.shape[2], 2 * x.shape[3])
 
 
+upwino4_glu = _define("upwino4_glu(Tensor x, Tensor upack, int cout, Tensor scale, Tensor shift) -> Tensor",
+                      lambda x, p, cout, s, t: ops.upwino4_glu(x, p, cout, s, t), _up_fake)
+upwino4_glu_out = _define("upwino4_glu_out(Tensor x, Tensor upack, int cout, Tensor scale, Tensor shift, Tensor(a!) out) -> ()",
+                          lambda x, p, cout, s, t, out: (ops.upwino4_glu(x, p, cout, s, t, out=out), None)[1], lambda *a: None)
+pack_upwino4_weight = _define("pack_upwino4_weight(Tensor w, bool glu) -> Tensor", lambda w, g: ops.pack_upwino4_weight(w, glu=g),
+                              lambda w, g: w.new_empty(((w.shape[1] + 3) // 4) * 112 * w.shape[0]))
 upwino_glu = _define("upwino_glu(Tensor x, Tensor upack, int cout, Tensor scale, Tensor shift) -> Tensor",
                      lambda x, p, cout, s, t: ops.upwino_glu(x, p, cout, s, t), _up_fake)
 upwino_glu_out = _define("upwino_glu_out(Tensor x, Tensor upack, int cout, Tensor scale, Tensor shift, Tensor(a!) out) -> ()",

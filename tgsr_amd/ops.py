@@ -81,7 +81,8 @@ def _pack_elems(kind: str, cout: int, cin: int) -> int:
     return int({"conv": lambda: L.tgsr_packed_weight_elems(cout, cin, 3), "wino": lambda: L.tgsr_packed_wino_weight_elems(cout, cin),
                 "wino4": lambda: L.tgsr_packed_wino4_weight_elems(cout, cin),
                 "upconv": lambda: L.tgsr_packed_upconv_weight_elems(cout, cin),
-                "upwino": lambda: L.tgsr_packed_upwino_weight_elems(cout, cin)}[kind]())
+                "upwino": lambda: L.tgsr_packed_upwino_weight_elems(cout, cin),
+                "upwino4": lambda: L.tgsr_packed_upwino4_weight_elems(cout, cin)}[kind]())
 
 
 def _check_pack(what: str, kind: str, pack: torch.Tensor, cout: int, cin: int):
@@ -434,6 +435,54 @@ def upwino_glu(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
     if profile is not None:
         nbytes = 4 * (B * Cin * H * W + B * co * Ho * Wo + cout * Cin * 9)
         profile.append(("upwino_glu_kernel", 2.0 * B * Ho * Wo * cout * Cin * 9, nbytes, e0, _ev()))
+    return out
+
+
+def upwino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
+    """Does an upBlock (low-resolution input H x W) go to the F(4x4) form of the up-sample-aware kernel?  Shape support
+    (Cout % 64, Cin % 4, whole 8 x 64 OUTPUT tiles), F(4x4)'s numerics floor on the OUTPUT (>= 64 x 64 pixels, see wino4_wanted)
+    and a full round of its 8-wave workgroups.  TGSR_WINO4=0 keeps the F(2x2) form."""
+    if os.environ.get("TGSR_WINO4", "1") == "0":
+        return False
+    Ho, Wo = 2 * H, 2 * W
+    if not (cout % 64 == 0 and cin % 4 == 0 and Wo % 64 == 0 and Ho % 8 == 0 and Ho * Wo >= WINO4_MIN_PIXELS):
+        return False
+    return B * (Ho // 8) * (Wo // 64) * (cout // 64) >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
+
+
+def pack_upwino4_weight(w: torch.Tensor, glu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> the 25 live positions of the up-sample-aware F(4x4,3x3) form (tgsr_upwino4_fwd), the -1/3 factors of
+    the fifth transformed row / column folded in; computed in double, rounded once."""
+    _need_hip(w)
+    w = _f32(w.detach(), "weight").contiguous()
+    Cout, Cin = w.shape[0], w.shape[1]
+    L = _lib.lib()
+    out = _pack_out(out, L.tgsr_packed_upwino4_weight_elems(Cout, Cin), w.device)
+    check(L.tgsr_pack_upwino4_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_upwino4_weight")
+    return out
+
+
+def upwino4_glu(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
+                out: Optional[torch.Tensor] = None, glu: bool = True) -> torch.Tensor:
+    """upBlock in one launch by F(4x4,3x3) on the up-sampled grid (25 products per 4x4 outputs); contract of upwino_glu with
+    16-byte aligned tensors."""
+    _need_hip(x, upack, scale, shift, out)
+    x, xbs = _nchw_bstride(_f32(x, "x"), "x")
+    B, Cin, H, W = x.shape
+    _check_pack("upwino4_glu", "upwino4", upack, cout, Cin)
+    co, Ho, Wo = (cout // 2 if glu else cout), 2 * H, 2 * W
+    if out is None:
+        out = torch.empty(B, co, Ho, Wo, dtype=torch.float32, device=x.device)
+    if tuple(out.shape) != (B, co, Ho, Wo) or out.stride(3) != 1 or out.stride(2) != Wo or out.stride(1) != Ho * Wo:
+        raise TgsrError("upwino4_glu: bad `out` shape/strides %s %s" % (tuple(out.shape), out.stride()))
+    obs = out.stride(0) if B > 1 else co * Ho * Wo
+    e0 = _ev() if profile is not None else None
+    rc = _lib.lib().tgsr_upwino4_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(scale), _p(shift), _p(out), obs,
+                                     1 if glu else 0, _stream())
+    check(rc, "tgsr_upwino4_fwd")
+    if profile is not None:
+        nbytes = 4 * (B * Cin * H * W + B * co * Ho * Wo + cout * Cin * 9)
+        profile.append(("upwino4_kernel", 2.0 * B * Ho * Wo * cout * Cin * 9, nbytes, e0, _ev()))
     return out
 
 

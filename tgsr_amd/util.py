@@ -188,17 +188,22 @@ class _UpBlock(nn.Sequential):
             # 16 positions survive: 2.25 multiplies per output); shapes it does not take use the sub-pixel form (four
             # 2x2 convs on the pre-upsample tensor, 4 multiplies per output)
             wino = WINOGRAD and ops.upwino_supported(x, conv.out_channels, out=out)
+            # ... and the F(4x4) form of it (25 of 36 positions: 1.56 multiplies per output) where ops.upwino4_wanted routes
+            # the layer (output >= 64 x 64 pixels, whole tiles, a full round of workgroups) and the tensors are 16-byte aligned
+            w4 = (wino and ops.upwino4_wanted(x.shape[1], conv.out_channels, x.shape[2], x.shape[3], x.shape[0]) and
+                  x.data_ptr() % 16 == 0 and (out is None or (out.data_ptr() % 16 == 0 and (out.shape[0] == 1 or out.stride(0) % 4 == 0))))
             src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-            key = (_ver(*src), wino)
+            key = (_ver(*src), wino, w4)
             if key != self._up_key:
-                self._up_pack = (ops.pack_upwino_weight if wino else ops.pack_upconv_weight)(conv.weight)
+                self._up_pack = (C.pack_upwino4_weight(conv.weight.detach(), True) if w4 else
+                                 (ops.pack_upwino_weight if wino else ops.pack_upconv_weight)(conv.weight))
                 self._up_aff = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
                 self._up_key = key
+            fn, fn_out = ((C.upwino4_glu, C.upwino4_glu_out) if w4 else
+                          ((C.upwino_glu, C.upwino_glu_out) if wino else (C.upconv3x3_glu, C.upconv3x3_glu_out)))
             if out is None:
-                return (C.upwino_glu if wino else C.upconv3x3_glu)(x, self._up_pack, conv.out_channels, self._up_aff[0],
-                                                                 self._up_aff[1])
-            (C.upwino_glu_out if wino else C.upconv3x3_glu_out)(x, self._up_pack, conv.out_channels, self._up_aff[0],
-                                                               self._up_aff[1], out)
+                return fn(x, self._up_pack, conv.out_channels, self._up_aff[0], self._up_aff[1])
+            fn_out(x, self._up_pack, conv.out_channels, self._up_aff[0], self._up_aff[1], out)
             return out
         return _conv_bn(x, self._fp, conv, bn, glu=True, upsample=True, out=out, training=self.training)
 
