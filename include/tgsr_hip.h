@@ -115,8 +115,9 @@ int tgsr_upwino_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, in
  * 16 outputs (tgsr_upwino_glu_fwd: 36) - the third transformed row / column vanishes and the fifth is -1/3 of the fourth,
  * so 5 x 5 positions carry products and their B operands come from 16 values per tile (tgsr_upwino4.hip).  `glu` != 0:
  * out [B][Cout/2][2H][2W] = GLU(affine(conv3x3(upsample(x)))), else [B][Cout][2H][2W] without the gate (scale/shift may be
- * NULL).  upack from tgsr_pack_upwino4_weight(glu) (tgsr_packed_upwino4_weight_elems floats).  Cout % 64 == 0,
- * Cin % 4 == 0, W % 4 == 0, x / out 16-byte aligned with batch strides % 4 == 0.  Numerics: F(4x4)'s (see
+ * NULL).  upack from tgsr_pack_upwino4_weight(glu) (tgsr_packed_upwino4_weight_elems floats, per-wave fragment order: the A
+ * operands go from L2 straight into registers).  Cout % 64 == 0, Cin % 8 == 0, W % 4 == 0, x / out / upack 16-byte aligned
+ * with batch strides % 4 == 0.  Numerics: F(4x4)'s (see
  * tgsr_wino4_conv3x3_fwd); callers route by output size (tgsr_amd.ops.upwino4_wanted).
  */
 int64_t tgsr_packed_upwino4_weight_elems(int Cout, int Cin);

@@ -265,10 +265,10 @@ UPW4_CASES = [
     (2, 64, 64, 64, 64, True),       # G_SR_NET_low's second upBlock (64^2 -> 128^2)
     (1, 64, 128, 128, 64, True),     # ... third (128^2 -> 256^2)
     (2, 32, 64, 64, 64, True),       # NetG_highweight's
-    (1, 4, 4, 32, 64, True),         # one stage, one workgroup
+    (1, 8, 4, 32, 64, True),         # two stages, two workgroups
     (2, 8, 8, 32, 64, False),        # without the gate
-    (1, 12, 6, 36, 128, True),       # ragged rows / columns, odd stage count, two channel groups
-    (3, 20, 3, 4, 64, True),         # image smaller than a tile row
+    (1, 16, 6, 36, 128, True),       # ragged rows / columns, two channel groups
+    (3, 24, 3, 4, 64, True),         # image smaller than a tile row
 ]
 
 
@@ -296,6 +296,10 @@ def test_upblock_winograd4_vs_upsample_conv(B, Cin, H, W, Cout, glu):
         C.upwino4_glu_out(x.to(DEV), C.pack_upwino4_weight(w.to(DEV), True), Cout, scale.to(DEV), shift.to(DEV), wide[:, 4:4 + co])
         assert torch.equal(wide[:, 4:4 + co], out)
         assert (wide[:, :4] == 3).all() and (wide[:, 4 + co:] == 3).all()
+    from tgsr_amd._lib import TgsrError
+    with pytest.raises(TgsrError):                                     # an odd number of 4-channel stages is refused
+        ops.upwino4_glu(torch.randn(1, 12, 4, 32, device=DEV), ops.pack_upwino4_weight(torch.randn(64, 12, 3, 3, device=DEV)), 64,
+                        scale[:64].to(DEV), shift[:64].to(DEV))
 
 
 def test_winograd4_training_forms():

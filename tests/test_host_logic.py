@@ -206,14 +206,14 @@ def test_wino4_size_policy(monkeypatch):
 
 
 def test_upwino4_size_policy(monkeypatch):
-    """The upBlocks that go to the F(4x4) form of the up-sample-aware kernel: by OUTPUT size (>= 64 x 64, whole 8 x 64 tiles) and
-    workgroup count; arguments are the low-resolution input's."""
+    """The upBlocks that go to the F(4x4) form of the up-sample-aware kernel: by OUTPUT size (>= 64 x 64, whole 4 x 64 tiles),
+    an even stage count and workgroup count; arguments are the low-resolution input's."""
     from tgsr_amd import ops
     monkeypatch.delenv("TGSR_WINO4", raising=False)
-    assert ops.upwino4_wanted(64, 64, 128, 128, 16) and ops.upwino4_wanted(64, 64, 64, 64, 16) and ops.upwino4_wanted(32, 64, 128, 128, 4)
-    assert not ops.upwino4_wanted(64, 64, 32, 32, 16)          # 32^2 -> 64^2: 128 workgroups
-    assert ops.upwino4_wanted(64, 64, 32, 32, 32)              # ... a full round at batch 32, output 64 x 64 = the floor
-    assert not ops.upwino4_wanted(64, 64, 16, 32, 64)          # output 32 x 64 pixels: below the floor
-    assert not ops.upwino4_wanted(64, 32, 128, 128, 16) and not ops.upwino4_wanted(64, 64, 66, 64, 16) and not ops.upwino4_wanted(64, 64, 64, 48, 16)
+    assert ops.upwino4_wanted(64, 64, 128, 128, 16) and ops.upwino4_wanted(64, 64, 64, 64, 16) and ops.upwino4_wanted(32, 64, 128, 128, 2)
+    assert not ops.upwino4_wanted(64, 64, 32, 32, 16) and not ops.upwino4_wanted(64, 64, 32, 32, 64)   # output 64 x 64: below the floor
+    assert ops.upwino4_wanted(64, 64, 64, 64, 4) and not ops.upwino4_wanted(32, 64, 64, 32, 4)         # 256 vs 128 workgroups
+    assert not ops.upwino4_wanted(12, 64, 128, 128, 16)        # three stages: the register-fed form takes an even number
+    assert not ops.upwino4_wanted(64, 32, 128, 128, 16) and not ops.upwino4_wanted(64, 64, 65, 64, 16) and not ops.upwino4_wanted(64, 64, 64, 48, 16)
     monkeypatch.setenv("TGSR_WINO4", "0")
     assert not ops.upwino4_wanted(64, 64, 128, 128, 16)

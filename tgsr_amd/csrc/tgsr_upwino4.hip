@@ -16,15 +16,21 @@
 // study's ">= 64 x 64 pixels" (tools/exp_wino4_numerics.py routes the upBlock-shaped convolutions as well: 3.4e-5 on the
 // finest image against fp64, stated tolerance 1e-4).
 //
-// Geometry = tgsr_winograd4.hip's narrow form: workgroup = 8 waves = 2 tile rows (g) x 4 channel blocks (cb) = 8 x 64
-// OUTPUT pixels x 64 accumulator rows, a wave = 16 tiles x 16 rows x 25 positions = 100 accumulator registers;
-// stage = 4 input channels = 25 MFMAs per wave.
-//   U   [7 quads][4 ci][4 cb][16][4]: positions p = 5 ri + cj (ri, cj = index into the live rows / columns 0,1,3,4,5),
-//       quad p / 4, element p % 4 (three pad slots); 28 KB per stage, double buffered, a linear LDS-DMA copy of the pack.
-//   raw [4 ci][6 low-res rows][40 cols] in planes of 256 floats (4 KB per stage, double buffered; the tile starts 4 columns
-//       left of the first low-res column so that every 16-byte piece is aligned and wholly inside or outside the image).
-//   S   per tile row [4 rows of S = quads][4 ci][16 tiles][4] (4 KB, double buffered): wave cb of a tile row computes row cb.
-// LDS 82 KB, one workgroup per CU.  GLU channel blocks as in tgsr_winograd4.hip (value, value, gate, gate per lane).
+// Geometry.  A workgroup = 4 waves = ONE tile row (4 x 64 OUTPUT pixels) x 4 channel blocks (64 accumulator rows); a wave =
+// 16 tiles x 16 rows x 25 positions = 100 accumulator registers; stage = 4 input channels = 25 MFMAs per wave; two workgroups
+// per CU (two waves per SIMD), independent of each other: one's prologue / epilogue runs under the other's main loop.
+//   A   straight from L2 into registers, as in tgsr_winograd4.hip's wide form: the pack is in per-wave fragment order
+//       [stage][group][cb 4][quad 7][lane 64][4] (positions p = 5 ri + cj over the live rows / columns 0,1,3,4,5, quad p / 4,
+//       element p % 4, three pad slots); one global_load_dwordx4 per quad, issued behind the quad's MFMAs for the NEXT stage
+//       into the same registers; counted waits: the VMEM stream of a wave is [raw copy of this stage, 0-1][7 fragment loads
+//       of the next], so vmcnt(6) in front of quad q's MFMAs = "A(q) has arrived", vmcnt(7) at the stage's end = "my copy has
+//       landed".  An EVEN number of stages (host-checked; see tgsr_winograd4.hip for why); the last stage prefetches stage 0
+//       again and vmcnt(0) precedes the epilogue.  (With U through LDS - 28 KB per stage, 32 copy instructions per 8-wave
+//       workgroup and stage - the 128^2 -> 256^2 upBlock took 187 us; this form: see DESIGN.md 3.1f.)
+//   raw [4 ci][4 low-res rows][40 cols] in planes of 192 floats (3 KB per stage, double buffered, LDS-DMA by waves 1-3; the
+//       tile starts 4 columns left of the first low-res column: every 16-byte piece is aligned and wholly in or out).
+//   S   [4 rows of S = quads][4 ci][16 tiles][4] (4 KB, double buffered): wave cb computes row cb.
+// LDS 15 KB.  GLU channel blocks as in tgsr_winograd4.hip (value, value, gate, gate per lane).
 #include "tgsr_common.h"
 
 #include <type_traits>
@@ -38,7 +44,7 @@ struct Upw4Args {
   const float* x;         // low-resolution input [B][Cin][H][W]
   int64_t xbs;
   int B, Cin, H, W;       // LOW-resolution size; the output is 2H x 2W
-  const float* upack;     // [stage][group][quad 7][ci 4][cb 4][16][4]
+  const float* upack;     // [stage][group][cb 4][quad 7][lane 64][4]
   int Cout;
   const float* scale;
   const float* shift;
@@ -49,13 +55,13 @@ struct Upw4Args {
 
 constexpr int ku4CK = 4;
 constexpr int ku4TC = 40;                                  // raw tile columns: 32 + 8 (low resolution)
-constexpr int ku4TR = 6;                                   // raw tile rows: 4 + 2 (low resolution)
-constexpr int ku4PLANE = 256;                              // floats per channel plane (240 used)
-constexpr int ku4RAW = ku4CK * ku4PLANE;                   // 1024 floats = 4 DMA pieces of 1 KB
+constexpr int ku4TR = 4;                                   // raw tile rows: 2 + 2 (low resolution)
+constexpr int ku4PLANE = 192;                              // floats per channel plane (160 used; 0 mod 64 banks)
+constexpr int ku4RAW = ku4CK * ku4PLANE;                   // 768 floats = 3 DMA pieces of 1 KB
 constexpr int ku4NQ = 7;                                   // A quads per stage (25 positions + 3 pad)
-constexpr int ku4U = ku4NQ * ku4CK * 64 * 4;               // 7168 floats = 28 pieces
-constexpr int ku4V = 4 * ku4CK * 16 * 4;                   // 1024 floats per tile row
-constexpr int ku4SMEM = 2 * ku4U + 2 * ku4RAW + 4 * ku4V + 128;
+constexpr int ku4UW = ku4NQ * 256;                         // floats of U per wave and stage
+constexpr int ku4V = 4 * ku4CK * 16 * 4;                   // 1024 floats of S
+constexpr int ku4SMEM = 2 * ku4RAW + 2 * ku4V + 128;
 
 // live transformed row / column k (0..4) -> index 0,1,3,4,5 of the 6 x 6 Winograd domain; -> row / column of S
 __host__ __device__ constexpr int u4_live(int k) { return k < 2 ? k : k + 1; }
@@ -84,11 +90,10 @@ __device__ __forceinline__ void u4_at(float m0, float m1, float m3, float m4, fl
 }
 
 template <bool GLU>
-__global__ __launch_bounds__(512, 2) void upwino4_kernel(Upw4Args a) {
+__global__ __launch_bounds__(256, 2) void upwino4_kernel(Upw4Args a) {
   __shared__ __attribute__((aligned(16))) float smem[ku4SMEM];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave >> 2, cb = wave & 3;                // tile row / channel block of this wave
+  const int cb = __builtin_amdgcn_readfirstlane(tid >> 6);             // channel block of this wave
   int t = xcd_remap(blockIdx.x, gridDim.x);
   const int grp = t % a.ngroups;
   t /= a.ngroups;
@@ -96,21 +101,19 @@ __global__ __launch_bounds__(512, 2) void upwino4_kernel(Upw4Args a) {
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
-  const int y0 = ty * 8, x0 = tx * 64;                   // OUTPUT origin of the workgroup tile
-  const int yl = ty * 4, xl = tx * 32;                   // low-resolution origin
+  const int y0 = ty * 4, x0 = tx * 64;                   // OUTPUT origin of the workgroup tile
+  const int yl = ty * 2, xl = tx * 32;                   // low-resolution origin
   const float* xb = a.x + (int64_t)b * a.xbs;
   const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
-  float* us = smem;
-  float* raws = smem + 2 * ku4U;
-  float* vs = smem + 2 * ku4U + 2 * ku4RAW + g * 2 * ku4V;
-  float* aff_s = smem + 2 * ku4U + 2 * ku4RAW + 4 * ku4V;
+  float* raws = smem;
+  float* vs = smem + 2 * ku4RAW;
+  float* aff_s = smem + 2 * ku4RAW + 2 * ku4V;
 
-  // ---- DMA plan: 32 pieces of 1 KB per stage, four per wave (every wave transforms here, so the copies are spread evenly):
-  // U pieces wave, wave + 8, wave + 16 and - waves 0-3 - wave + 24; waves 4-7: raw piece wave - 4
+  // ---- raw copies: 3 pieces per stage, waves 1, 2, 3 one each
   const float* rptr = g_upw4_zero;
   int rstep = 0;
-  if (wave >= 4) {
-    const int e = ((wave - 4) * 64 + lane) * 4;          // first float of this lane's 16-byte piece
+  if (cb >= 1) {
+    const int e = ((cb - 1) * 64 + lane) * 4;            // first float of this lane's 16-byte piece
     const int c = e / ku4PLANE;
     const int rem = e - c * ku4PLANE;
     const int r = rem / ku4TC, j = rem - r * ku4TC;
@@ -120,29 +123,28 @@ __global__ __launch_bounds__(512, 2) void upwino4_kernel(Upw4Args a) {
     rstep = ok ? (int)(ku4CK * HW) : 0;
   }
   const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptru4_t)smem);
-  const unsigned lds_raw = lds0 + (2 * ku4U + (wave & 3) * 256) * 4;
-  const unsigned lds_u = lds0 + wave * 1024;
-  const float* ubase = a.upack + (int64_t)grp * ku4U;    // stage 0 of this group
-  const int64_t ustride = (int64_t)a.ngroups * ku4U;
-  const unsigned uoff0 = (unsigned)((wave * 64 + lane) * 16);
-  auto issue_u = [&](int buf) {                          // stages 0, 1, 2, ... in order
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff0 + k * 8192), "s"(ubase), "s"(lds_u + buf * (ku4U * 4) + k * 8192) : "memory");
-    if (wave < 4)
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(uoff0 + 3 * 8192), "s"(ubase), "s"(lds_u + buf * (ku4U * 4) + 3 * 8192) : "memory");
-    ubase += ustride;
-  };
+  const unsigned lds_raw = lds0 + (cb >= 1 ? cb - 1 : 0) * 1024;
   auto issue_raw = [&](int buf) {
-    if (wave >= 4) {
+    if (cb >= 1) {
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(rptr), "s"(lds_raw + buf * (ku4RAW * 4)) : "memory");
       rptr += rstep;
     }
   };
+  // ---- A fragments: this wave's 7 KB of a stage, two per-lane offsets 4 KB apart + an immediate
+  const float* ubase = a.upack + ((int64_t)grp * 4 + cb) * ku4UW;      // stage 0
+  const float* const ubase0 = ubase;
+  const int64_t ustride = (int64_t)a.ngroups * 4 * ku4UW;
+  unsigned voff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) voff[k] = (unsigned)(lane * 16 + k * 4096);
+  f32x4u4 af[ku4NQ];
+#define TGSR_U4_LOAD(q)                                                                                                \
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(af[q]) : "v"(voff[(q) / 4]), "s"(ubase), "n"(((q) % 4) * 1024) : "memory")
+#define TGSR_U4_WAIT(q) asm volatile("s_waitcnt vmcnt(6)" : "+v"(af[q])::"memory")
 
-  // ---- input transform: lane = (tile l15, channel lg); wave cb of tile row g computes row cb of S = T P T^T, P = the 4 x 4
-  // low-resolution patch of tile l15: raw rows 2g .. 2g + 3, raw columns 2 l15 + 3 .. 2 l15 + 6
-  const int rlane = lg * ku4PLANE + (2 * g) * ku4TC + 2 * l15;
+  // ---- input transform: lane = (tile l15, channel lg); wave cb computes row cb of S = T P T^T, P = the 4 x 4 low-resolution
+  // patch of tile l15: raw rows 0 .. 3, raw columns 2 l15 + 3 .. 2 l15 + 6
+  const int rlane = lg * ku4PLANE + 2 * l15;
   const int vwl = (lg * 16 + l15) * 4;
   auto t_read = [&](auto rc, const float* rawb, float (&d)[4][4]) {
     constexpr int R = decltype(rc)::value;
@@ -177,52 +179,46 @@ __global__ __launch_bounds__(512, 2) void upwino4_kernel(Upw4Args a) {
   for (int p = 0; p < 25; ++p)
 #pragma unroll
     for (int i = 0; i < 4; ++i) M[p][i] = 0.f;
-
-  const int ulane = (lg * 64 + cb * 16 + l15) * 4;       // A: U[q][ci = lg][cb][l15][4]
   const int vlane = (lg * 16 + l15) * 4;                 // B: S[r][ci = lg][l15][4]
 
-  // One stage (as tgsr_winograd4.hip): copies first, the raw reads of the transform of raw(st+1), then the 25 MFMAs with
-  // their 7 + 4 fragment reads ahead of them and the transform's 16 operations behind the second quad; wait + barrier.
-  // The transform is not skipped in the last stage (stale raw in, an S image nobody reads out).
+  // One stage: the raw copy of stage st+2 first; the raw reads of the transform of raw(st+1); the 25 MFMAs, each quad behind
+  // the wait for its fragments and followed by the load of the next stage's; the transform's 16 operations behind the second
+  // quad; wait for the copy + barrier.  The transform is not skipped in the last stage (stale raw in, an S image nobody reads).
   auto stage = [&](auto rc, auto parc, const bool MORE, const bool MORE2) {
     constexpr int R = decltype(rc)::value, PAR = decltype(parc)::value;
-    if (MORE) issue_u(PAR ^ 1);                          // U(st+1) replaces U(st-1)
     if (MORE2) issue_raw(PAR);                           // raw(st+2) replaces raw(st), transformed one stage ago
+    ubase = MORE ? ubase + ustride : ubase0;             // where the fragments loaded during this stage come from
     float d[4][4];
     t_read(rc, raws + (PAR ^ 1) * ku4RAW, d);
-    const float* ub = us + PAR * ku4U + ulane;
     const float* vb = vs + PAR * ku4V + vlane;
-    f32x4u4 bf[4], af[3];
+    f32x4u4 bf[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bf[r] = *reinterpret_cast<const f32x4u4*>(vb + r * (ku4CK * 16 * 4));
-    af[0] = *reinterpret_cast<const f32x4u4*>(ub);
-    af[1] = *reinterpret_cast<const f32x4u4*>(ub + (ku4CK * 64 * 4));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < ku4NQ; ++q) {
-      if (q + 2 < ku4NQ) af[(q + 2) % 3] = *reinterpret_cast<const f32x4u4*>(ub + (q + 2) * (ku4CK * 64 * 4));
+      TGSR_U4_WAIT(q);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int p = 4 * q + e;
         if (p < 25)
-          M[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q % 3][e], bf[u4_rho(p / 5)][u4_rho(p % 5)], M[p], 0, 0, 0);
+          M[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[q][e], bf[u4_rho(p / 5)][u4_rho(p % 5)], M[p], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      TGSR_U4_LOAD(q);
       if (q == 1) {
         t_write(rc, d, vs + (PAR ^ 1) * ku4V);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (MORE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (MORE) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   auto run = [&](auto rc) {
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     issue_raw(0);
-    issue_u(0);
     if (a.nstages > 1) issue_raw(1);
+    TGSR_U4_LOAD(0); TGSR_U4_LOAD(1); TGSR_U4_LOAD(2); TGSR_U4_LOAD(3); TGSR_U4_LOAD(4); TGSR_U4_LOAD(5); TGSR_U4_LOAD(6);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
       float d[4][4];
@@ -230,17 +226,18 @@ __global__ __launch_bounds__(512, 2) void upwino4_kernel(Upw4Args a) {
       t_write(rc, d, vs);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    int st = 0;
-    for (; st + 1 < a.nstages; st += 2) {
+    for (int st = 0; st < a.nstages; st += 2) {          // an even number of stages: exactly two copies of the stage
       stage(rc, P0{}, true, st + 2 < a.nstages);
       stage(rc, P1{}, st + 2 < a.nstages, st + 3 < a.nstages);
     }
-    if (st < a.nstages) stage(rc, P0{}, false, false);   // odd stage count
   };
   if (cb == 0) run(std::integral_constant<int, 0>{});
   else if (cb == 1) run(std::integral_constant<int, 1>{});
   else if (cb == 2) run(std::integral_constant<int, 2>{});
   else run(std::integral_constant<int, 3>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the last stage's (unused) fragment loads
+#undef TGSR_U4_LOAD
+#undef TGSR_U4_WAIT
 
   // ---- output transform Y = A^T M A over the live rows / columns + epilogue; lane = tile l15, register i = accumulator
   // row 4 lg + i of block cb
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void upwino4_kernel(Upw4Args a) {
     for (int r = 0; r < 4; ++r) u4_at(c[r][0], c[r][1], c[r][2], c[r][3], c[r][4], y[r]);
   };
   const int Ho = 2 * a.H, Wo = 2 * a.W;
-  const int oy = y0 + 4 * g, ox = x0 + 4 * l15;
+  const int oy = y0, ox = x0 + 4 * l15;
   const int64_t HWo = (int64_t)Ho * Wo;
   float* __restrict__ ob = a.out + (int64_t)b * a.obs;
   if (ox < Wo) {
@@ -300,19 +297,21 @@ __global__ __launch_bounds__(512, 2) void upwino4_kernel(Upw4Args a) {
   }
 }
 
-// upack[stage][group][quad 7][ci 4][cb 4][row 16][4] <- U'[i][j] = f(i) f(j) (G g G^T)[i][j] over the live rows / columns
-// i, j in {0, 1, 3, 4, 5}, f(4) = -1/3 (the input transform's fifth entry is -1/3 of its fourth), else 1; position
-// p = 5 ri + cj at quad p / 4, element p % 4 (p >= 25: zero).  Rows of a block as in pack_wino4_weight_kernel.
+// upack[stage][group][cb 4][quad 7][lane 64 = (ci lane >> 4, row lane & 15)][4] <- U'[i][j] = f(i) f(j) (G g G^T)[i][j] over the
+// live rows / columns i, j in {0, 1, 3, 4, 5}, f(4) = -1/3 (the input transform's fifth entry is -1/3 of its fourth), else 1;
+// position p = 5 ri + cj at quad p / 4, element p % 4 (p >= 25: zero).  Rows of a block as in pack_wino4_weight_kernel.
 __global__ void pack_upwino4_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu,
                                            int64_t total) {
   const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
   const int ngrp = Cout / 64;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int e = (int)(idx & 3), m = (int)((idx >> 2) & 15), cbk = (int)((idx >> 6) & 3), ci = (int)((idx >> 8) & 3);
-    int64_t t = idx >> 10;
+    const int e = (int)(idx & 3), m = (int)((idx >> 2) & 15), ci = (int)((idx >> 6) & 3);
+    int64_t t = idx >> 8;
     const int q = (int)(t % ku4NQ);
     t /= ku4NQ;
+    const int cbk = (int)(t & 3);
+    t >>= 2;
     const int grp = (int)(t % ngrp);
     const int st = (int)(t / ngrp);
     const int p = 4 * q + e;
@@ -353,17 +352,17 @@ extern "C" int tgsr_upwino4_fwd(const float* x, int64_t x_bstride, int B, int Ci
                                 const float* scale, const float* shift, float* out, int64_t out_bstride, int glu, void* stream) {
   if (!x || !upack || !out || B < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return TGSR_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
-  if (Cout % 64 != 0 || Cin % ku4CK != 0) return TGSR_EUNSUPPORTED;
+  if (Cout % 64 != 0 || Cin % (2 * ku4CK) != 0) return TGSR_EUNSUPPORTED;          // an even number of 4-channel stages
   if ((int64_t)H * W >= (1 << 26) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
   if ((W & 3) || (x_bstride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
-      (out_bstride & 3))
+      (reinterpret_cast<uintptr_t>(upack) & 15) || (out_bstride & 3))
     return TGSR_EUNSUPPORTED;
   Upw4Args a;
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
   a.scale = scale; a.shift = shift; a.out = out; a.obs = out_bstride;
-  a.tiles_x = (2 * W + 63) / 64; a.tiles_y = (2 * H + 7) / 8; a.nstages = Cin / ku4CK; a.ngroups = Cout / 64;
+  a.tiles_x = (2 * W + 63) / 64; a.tiles_y = (2 * H + 3) / 4; a.nstages = Cin / ku4CK; a.ngroups = Cout / 64;
   const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.ngroups));
-  if (glu) hipLaunchKernelGGL((upwino4_kernel<true>), grid, dim3(512), 0, as_stream(stream), a);
-  else hipLaunchKernelGGL((upwino4_kernel<false>), grid, dim3(512), 0, as_stream(stream), a);
+  if (glu) hipLaunchKernelGGL((upwino4_kernel<true>), grid, dim3(256), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((upwino4_kernel<false>), grid, dim3(256), 0, as_stream(stream), a);
   return note_launch(hipGetLastError(), "upwino4_kernel");
 }

@@ -228,6 +228,7 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
 
 
 WINO4_MIN_PIXELS = 64 * 64        # per image; DESIGN.md 3.1e: the error study that keeps F(4x4) off the 32 x 32 layers
+UPWINO4_MIN_OUT_PIXELS = 128 * 128  # output pixels per image of an upBlock on the F(4x4) form (see upwino4_wanted)
 WINO4_MIN_WORKGROUPS = 256        # one 8-wave workgroup per CU: below a full round F(2x2)'s four times smaller tiles win
 
 
@@ -440,14 +441,17 @@ def upwino_glu(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
 
 def upwino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
     """Does an upBlock (low-resolution input H x W) go to the F(4x4) form of the up-sample-aware kernel?  Shape support
-    (Cout % 64, Cin % 4, whole 8 x 64 OUTPUT tiles), F(4x4)'s numerics floor on the OUTPUT (>= 64 x 64 pixels, see wino4_wanted)
-    and a full round of its 8-wave workgroups.  TGSR_WINO4=0 keeps the F(2x2) form."""
+    (Cout % 64, Cin % 8: an even number of 4-channel stages, whole 4 x 64 OUTPUT tiles), a numerics floor on the OUTPUT
+    (>= 128 x 128 pixels: the first upBlocks, 32^2 -> 64^2, would be faster on it too - 14.2 vs 17.5 us - but with them the
+    finest image of the C1 case moved to 8.4e-5 from the reference's fp32 output, against a stated 1e-4: early layers' errors are
+    the ones the network amplifies) and at least 256 of its 4-wave workgroups.  TGSR_WINO4=0 keeps the
+    F(2x2) form."""
     if os.environ.get("TGSR_WINO4", "1") == "0":
         return False
     Ho, Wo = 2 * H, 2 * W
-    if not (cout % 64 == 0 and cin % 4 == 0 and Wo % 64 == 0 and Ho % 8 == 0 and Ho * Wo >= WINO4_MIN_PIXELS):
+    if not (cout % 64 == 0 and cin % 8 == 0 and Wo % 64 == 0 and Ho % 4 == 0 and Ho * Wo >= UPWINO4_MIN_OUT_PIXELS):
         return False
-    return B * (Ho // 8) * (Wo // 64) * (cout // 64) >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
+    return B * (Ho // 4) * (Wo // 64) * (cout // 64) >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
 
 
 def pack_upwino4_weight(w: torch.Tensor, glu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:

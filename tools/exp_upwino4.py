@@ -21,7 +21,7 @@ def timeit(f, n=30):
     torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-for (b, cin, cout, h, w, glu) in ((1, 4, 64, 4, 32, 1), (2, 8, 64, 8, 32, 0), (1, 12, 128, 6, 36, 1), (2, 64, 64, 20, 64, 1), (1, 32, 64, 64, 64, 1)):
+for (b, cin, cout, h, w, glu) in ((1, 8, 64, 4, 32, 1), (2, 8, 64, 8, 32, 0), (1, 16, 128, 6, 36, 1), (2, 64, 64, 20, 64, 1), (1, 32, 64, 64, 64, 1)):
     x = torch.randn(b, cin, h, w, device=dev)
     wt = torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)
     sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.1
