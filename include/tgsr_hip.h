@@ -160,9 +160,10 @@ int tgsr_wino4_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, in
                            const float* scale, const float* shift, const float* residual, int64_t res_bstride,
                            float* out, int64_t out_bstride, int epilogue, void* stream);
 
-/* The wide form of the same kernel for Cout % 128 == 0 (a workgroup = one tile row x 128 accumulator rows, the A operands
- * straight from L2 in per-wave fragment order: the input transform is amortised over twice the channels).  Same contract
- * with Cin % 8 == 0; its own pack layout (tgsr_packed_wino4_weight_elems floats, 16-byte aligned). */
+/* The register-fed form of the same kernel: the A operands straight from L2 in per-wave fragment order.  Cout % 128 == 0: a
+ * workgroup = one tile row x 128 accumulator rows (the input transform amortised over twice the channels); else 64-row groups
+ * in 4-wave workgroups, two independent per CU.  Same contract with Cin % 8 == 0; its own pack layout
+ * (tgsr_packed_wino4_weight_elems floats, 16-byte aligned). */
 int tgsr_pack_wino4_wide_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream);
 int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
                                 const float* scale, const float* shift, const float* residual, int64_t res_bstride,

@@ -226,9 +226,9 @@ def test_conv3x3_winograd4(B, Cin, H, W, Cout, glu, res):
     # the raw convolution (no affine), as the custom op
     raw = C.conv3x3_wino4(x.to(DEV), ops.pack_wino4_weight(w.to(DEV), glu=False), Cout, None, None, False, None)
     assert float((raw.cpu().double() - F.conv2d(x.double(), w.double(), None, 1, 1)).abs().max()) < 1e-4
-    if Cout % 128 == 0 and Cin % 8 == 0:
-        # the wide form (128-row workgroups, A fragments loaded from L2 into registers a stage ahead): the same arithmetic in the
-        # same order - bit-identical to the narrow form
+    if Cin % 8 == 0:
+        # the register-fed form (A fragments loaded from L2 into registers a stage ahead; 128-row workgroups where Cout % 128 == 0,
+        # else 64-row 4-wave ones): the same arithmetic in the same order - bit-identical to the narrow form
         upw = ops.pack_wino4w_weight(w.to(DEV), glu=glu)
         ow = C.conv3x3_wino4w(x.to(DEV), upw, Cout, scale.to(DEV), shift.to(DEV), glu, None if r is None else r.to(DEV))
         assert torch.equal(ow, out)

@@ -196,7 +196,7 @@ def test_wino4_size_policy(monkeypatch):
     from tgsr_amd import ops
     monkeypatch.delenv("TGSR_WINO4", raising=False)
     assert ops.wino4_wanted(64, 128, 128, 128, 16) and ops.wino4_wanted(64, 64, 128, 128, 16) and ops.wino4_wanted(64, 64, 256, 256, 2)
-    assert ops.wino4_wanted(64, 128, 64, 64, 16) and not ops.wino4_wanted(64, 64, 64, 64, 16)    # 256 vs 128 workgroups
+    assert ops.wino4_wanted(64, 128, 64, 64, 16) and not ops.wino4_wanted(64, 64, 64, 64, 16)    # 256 vs 128 tiles
     assert not ops.wino4_wanted(64, 128, 128, 128, 2)                                            # small batch: F(2x2)'s tiles
     assert not ops.wino4_wanted(64, 128, 32, 32, 64) and not ops.wino4_wanted(128, 256, 32, 64, 64)   # the numerics policy
     assert not ops.wino4_wanted(64, 32, 128, 128, 16) and not ops.wino4_wanted(3, 64, 128, 128, 16)   # channel groups / stages

@@ -447,8 +447,13 @@ constexpr int k4wTR = 6, k4wPLANE = 448, k4wRAW = k4CK * k4wPLANE;     // 1792 f
 constexpr int k4wSMEM = 2 * k4wRAW + 2 * k4V + 256;
 constexpr int k4wUW = 9 * 256;                                          // floats of U per wave and stage
 
-template <bool GLU>
-__global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
+// NB = channel blocks (waves) per workgroup: 8 = the wide form proper (128 rows); 4 = the same register-fed kernel for 64-row
+// groups (Cout % 128 != 0: the +residual convolutions): 4-wave workgroups, two per CU that share nothing, so one's prologue and
+// epilogue - the residual variant's 131 KB in / 131 KB out burst - run under the other's main loop; the transform is not amortised
+// further than in the narrow form (three of four waves transform), what it saves is the 36 U copies and the A reads from LDS.
+template <bool GLU, int NB>
+__global__ __launch_bounds__(64 * NB, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
+  constexpr int NR = 16 * NB;                              // accumulator rows of a workgroup (128 | 64)
   __shared__ __attribute__((aligned(16))) float smem[k4wSMEM];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int cb = __builtin_amdgcn_readfirstlane(tid >> 6);             // channel block of this wave
@@ -468,8 +473,9 @@ __global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
 
   // ---- raw copies: 7 pieces per stage on the five waves that do not transform - wave 3: pieces 0, 1; wave 7: 2, 3; waves
   // 4, 5, 6: pieces 4, 5, 6
-  const int npiece = (cb == 3 || cb == 7) ? 2 : (cb >= 4 ? 1 : 0);
-  const int piece0 = cb == 3 ? 0 : (cb == 7 ? 2 : cb);
+  // (NB = 4: every wave copies - pieces 2 cb, 2 cb + 1 on waves 0-2, piece 6 on wave 3)
+  const int npiece = NB == 8 ? ((cb == 3 || cb == 7) ? 2 : (cb >= 4 ? 1 : 0)) : (cb == 3 ? 1 : 2);
+  const int piece0 = NB == 8 ? (cb == 3 ? 0 : (cb == 7 ? 2 : cb)) : 2 * cb;
   const float* rptr[2];
   int rstep[2];
 #pragma unroll
@@ -496,9 +502,9 @@ __global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
     }
   };
   // ---- A fragments: this wave's 9 KB of a stage, three per-lane offsets 4 KB apart + an immediate
-  const float* ubase = a.upack + ((int64_t)grp * 8 + cb) * k4wUW;      // stage 0
+  const float* ubase = a.upack + ((int64_t)grp * NB + cb) * k4wUW;     // stage 0
   const float* const ubase0 = ubase;
-  const int64_t ustride = (int64_t)a.ngroups * 8 * k4wUW;
+  const int64_t ustride = (int64_t)a.ngroups * NB * k4wUW;
   unsigned voff[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) voff[k] = (unsigned)(lane * 16 + k * 4096);
@@ -536,11 +542,11 @@ __global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
     *reinterpret_cast<f32x4w4*>(vp + 2 * kVQ) = f32x4w4{ob[2], ob[3], ob[4], ob[5]};
   };
 
-  if (tid < 256) {   // aff_s[cb * 16 + m] = scale, [128 + ...] = shift of accumulator row m of block cb
-    const int lc = tid & 127, cbk = lc >> 4, m = lc & 15;
-    int col = GLU ? ((m & 2) ? (a.Cout >> 1) : 0) + grp * 64 + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * 128 + lc;
+  if (tid < 2 * NR) {   // aff_s[cb * 16 + m] = scale, [NR + ...] = shift of accumulator row m of block cb
+    const int lc = tid & (NR - 1), cbk = lc >> 4, m = lc & 15;
+    int col = GLU ? ((m & 2) ? (a.Cout >> 1) : 0) + grp * (NR / 2) + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * NR + lc;
     if (col >= a.Cout) col = 0;
-    aff_s[tid] = a.scale ? (tid < 128 ? a.scale[col] : a.shift[col]) : (tid < 128 ? 1.f : 0.f);
+    aff_s[tid] = a.scale ? (tid < NR ? a.scale[col] : a.shift[col]) : (tid < NR ? 1.f : 0.f);
   }
 
   f32x4w4 M[36];
@@ -632,8 +638,8 @@ __global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
         ytile(p, yv);
         ytile(p + 2, yg);
         const int m = 4 * lg + p;
-        const float sv = aff_s[cb * 16 + m], tv = aff_s[128 + cb * 16 + m], sg = aff_s[cb * 16 + m + 2], tg = aff_s[128 + cb * 16 + m + 2];
-        const int c = grp * 64 + cb * 8 + 2 * lg + p;
+        const float sv = aff_s[cb * 16 + m], tv = aff_s[NR + cb * 16 + m], sg = aff_s[cb * 16 + m + 2], tg = aff_s[NR + cb * 16 + m + 2];
+        const int c = grp * (NR / 2) + cb * 8 + 2 * lg + p;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (oy + r >= a.H) continue;
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
       f32x4w4 rr[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int c = grp * 128 + cb * 16 + 4 * lg + i;
+        const int c = grp * NR + cb * 16 + 4 * lg + i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           rr[i][r] = f32x4w4{0.f, 0.f, 0.f, 0.f};
@@ -657,10 +663,10 @@ __global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int m = 4 * lg + i, c = grp * 128 + cb * 16 + m;
+        const int m = 4 * lg + i, c = grp * NR + cb * 16 + m;
         float yv[4][4];
         ytile(i, yv);
-        const float sv = aff_s[cb * 16 + m], tv = aff_s[128 + cb * 16 + m];
+        const float sv = aff_s[cb * 16 + m], tv = aff_s[NR + cb * 16 + m];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (oy + r >= a.H) continue;
@@ -674,24 +680,25 @@ __global__ __launch_bounds__(512, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
   }
 }
 
-// wide pack: upack[stage][group of 128 rows][cb 8][quad 9][lane 64 = (ci lane >> 4, row lane & 15)][4]; row m of block cb:
-// plain = cout grp*128 + cb*16 + m; GLU = value channel grp*64 + cb*8 + 2 (m >> 2) + (m & 1) when m & 2 == 0, else its gate
-__global__ void pack_wino4w_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu,
+// wide pack: upack[stage][group of 16 nb rows][cb nb][quad 9][lane 64 = (ci lane >> 4, row lane & 15)][4], nb = 8 (Cout % 128 == 0)
+// or 4; row m of block cb: plain = cout grp*16nb + cb*16 + m; GLU = value channel grp*8nb + cb*8 + 2 (m >> 2) + (m & 1) when
+// m & 2 == 0, else its gate
+__global__ void pack_wino4w_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu, int nb,
                                           int64_t total) {
   const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-  const int ngrp = Cout / 128;
+  const int ngrp = Cout / (16 * nb);                       // nb = 8 | 4 blocks per group
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 3), m = (int)((idx >> 2) & 15), ci = (int)((idx >> 6) & 3);
     int64_t t = idx >> 8;
     const int q = (int)(t % 9);
     t /= 9;
-    const int cbk = (int)(t & 7);
-    t >>= 3;
+    const int cbk = (int)(t % nb);
+    t /= nb;
     const int grp = (int)(t % ngrp);
     const int st = (int)(t / ngrp);
     const int i = w4_row(q, e), j = w4_col(q, e);
-    const int co = glu ? ((m & 2) ? (Cout >> 1) : 0) + grp * 64 + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * 128 + cbk * 16 + m;
+    const int co = glu ? ((m & 2) ? (Cout >> 1) : 0) + grp * (8 * nb) + cbk * 8 + 2 * (m >> 2) + (m & 1) : grp * (16 * nb) + cbk * 16 + m;
     const int c = st * k4CK + ci;
     double u = 0.0;
     if (c < Cin) {
@@ -819,10 +826,11 @@ extern "C" int tgsr_wino4_conv3x3_stats_fwd(const float* x, int64_t x_bstride, i
 
 extern "C" int tgsr_pack_wino4_wide_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
   if (!w || !upack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
-  if (Cout % 128 != 0) return TGSR_EUNSUPPORTED;
+  if (Cout % 64 != 0) return TGSR_EUNSUPPORTED;
   const int64_t total = tgsr_packed_wino4_weight_elems(Cout, Cin);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(pack_wino4w_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin, glu ? 1 : 0, total);
+  hipLaunchKernelGGL(pack_wino4w_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin, glu ? 1 : 0,
+                     Cout % 128 == 0 ? 8 : 4, total);
   return note_launch(hipGetLastError(), "pack_wino4w_weight_kernel");
 }
 
@@ -834,19 +842,25 @@ extern "C" int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, in
   const bool glu = epilogue == TGSR_EPI_AFFINE_GLU;
   if (!glu && epilogue != TGSR_EPI_AFFINE) return TGSR_EINVAL;
   if (glu && residual) return TGSR_EINVAL;
-  if (Cout % 128 != 0 || Cin % (2 * k4CK) != 0) return TGSR_EUNSUPPORTED;      // an even number of 4-channel stages
+  if (Cout % 64 != 0 || Cin % (2 * k4CK) != 0) return TGSR_EUNSUPPORTED;       // an even number of 4-channel stages
   if ((int64_t)H * W >= (1 << 28) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
   if ((W & 3) || (x_bstride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
       (reinterpret_cast<uintptr_t>(upack) & 15) || (out_bstride & 3) ||
       (residual && ((reinterpret_cast<uintptr_t>(residual) & 15) || (res_bstride & 3))))
     return TGSR_EUNSUPPORTED;
+  const int nb = Cout % 128 == 0 ? 8 : 4;                  // 128-row groups where the layer has them, else 64-row groups
   Wino4Args a;
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
   a.scale = scale; a.shift = shift; a.res = residual; a.rbs = res_bstride; a.out = out; a.obs = out_bstride;
-  a.tiles_x = (W + 63) / 64; a.tiles_y = (H + 3) / 4; a.nstages = Cin / k4CK; a.ngroups = Cout / 128;
+  a.tiles_x = (W + 63) / 64; a.tiles_y = (H + 3) / 4; a.nstages = Cin / k4CK; a.ngroups = Cout / (16 * nb);
   a.stat = nullptr; a.nslots = 0;
   const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.ngroups));
-  if (glu) hipLaunchKernelGGL((wino4w_conv3x3_kernel<true>), grid, dim3(512), 0, as_stream(stream), a);
-  else hipLaunchKernelGGL((wino4w_conv3x3_kernel<false>), grid, dim3(512), 0, as_stream(stream), a);
+  if (nb == 8) {
+    if (glu) hipLaunchKernelGGL((wino4w_conv3x3_kernel<true, 8>), grid, dim3(512), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((wino4w_conv3x3_kernel<false, 8>), grid, dim3(512), 0, as_stream(stream), a);
+  } else {
+    if (glu) hipLaunchKernelGGL((wino4w_conv3x3_kernel<true, 4>), grid, dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((wino4w_conv3x3_kernel<false, 4>), grid, dim3(256), 0, as_stream(stream), a);
+  }
   return note_launch(hipGetLastError(), "wino4w_conv3x3_kernel");
 }

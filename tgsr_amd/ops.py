@@ -229,17 +229,19 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
 
 WINO4_MIN_PIXELS = 64 * 64        # per image; DESIGN.md 3.1e: the error study that keeps F(4x4) off the 32 x 32 layers
 UPWINO4_MIN_OUT_PIXELS = 128 * 128  # output pixels per image of an upBlock on the F(4x4) form (see upwino4_wanted)
-WINO4_MIN_WORKGROUPS = 256        # one 8-wave workgroup per CU: below a full round F(2x2)'s four times smaller tiles win
+WINO4_MIN_WORKGROUPS = 256        # below a full round of its (large) workgroup tiles F(2x2)'s four times smaller ones win
 
 
 def wino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
-    """Does a conv3x3 layer go to the F(4x4, 3x3) kernel?  Shape support (Cout % 64, Cin % 4, W % 64, H % 8: whole workgroup
+    """Does a conv3x3 layer go to the F(4x4, 3x3) kernels?  Shape support (Cout % 64, Cin % 4, W % 64, H % 8: whole workgroup
     tiles), the numerics policy - only layers of >= 64 x 64 pixels: measured on the shipped checkpoint against fp64, the 128^2
     and 64^2 layers on it move the finest images by <= 4e-6 (max), the 32^2 layers on it as well cost 2e-4 (tgsr_winograd4.hip)
-    - and enough work for its 8 x 64 x 64-channel workgroup tiles to fill the chip (batch 16: the 128^2 ResBlock convolutions
-    and the 64 -> 128 ones at 64^2; 64 -> 64 at 64^2 is 128 workgroups and stays on F(2x2): 29 vs 33 us).
-    TGSR_WINO4=0 keeps every layer on F(2x2); TGSR_WINO4_MIN_WG=<n> moves the workgroup threshold (diagnostics: n = 1 puts the
-    batch-2 golden case on the kernel, tools/diag_precision.py)."""
+    - and enough work to fill the chip: >= 256 tiles of 8 x 64 pixels x 64 channels.  At batch 16: the ResBlock convolutions
+    of the 128^2 stage and the 64 -> 128 ones of the 64^2 stage; the batch-2 golden case stays on F(2x2).  (The 64 -> 64 ones
+    at 64^2 would be faster too on the register-fed form's half-height tiles - 22.6 vs 28.8 us - and are left where they are:
+    12 us per step against a finest image at 9.4e-5 instead of 8.6e-5 from the fp32 oracle at batch 16)
+    TGSR_WINO4=0 keeps every layer on F(2x2); TGSR_WINO4_MIN_WG=<n> moves the threshold (diagnostics: n = 32 gives the batch-2
+    golden case the routing of batch 16, tools/diag_precision.py)."""
     if os.environ.get("TGSR_WINO4", "1") == "0":
         return False
     if not (cout % 64 == 0 and cin % 4 == 0 and W % 64 == 0 and H % 8 == 0 and H * W >= WINO4_MIN_PIXELS):
@@ -267,8 +269,8 @@ def pack_wino4_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, o
 
 
 def pack_wino4w_weight(w: torch.Tensor, glu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """The pack of the WIDE F(4x4,3x3) kernel (Cout % 128 == 0): per-wave fragment order [Cin/4][Cout/128][8 blocks][9 quads]
-    [64 lanes][4] - not interchangeable with pack_wino4_weight's."""
+    """The pack of the register-fed F(4x4,3x3) kernel: per-wave fragment order [Cin/4][groups][8 | 4 blocks][9 quads][64 lanes][4]
+    (128-row groups where Cout % 128 == 0, else 64-row groups) - not interchangeable with pack_wino4_weight's."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
@@ -281,7 +283,7 @@ def pack_wino4w_weight(w: torch.Tensor, glu: bool = False, out: Optional[torch.T
 def conv3x3_wino4(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, glu: bool = False,
                   residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, wide: bool = False) -> torch.Tensor:
     """conv3x3 + affine + (GLU | residual) by Winograd F(4x4,3x3) (same contract as conv3x3_wino; 16-byte aligned tensors).
-    `wide`: the Cout % 128 == 0 form, upack from pack_wino4w_weight."""
+    `wide`: the register-fed form (Cin % 8 == 0), upack from pack_wino4w_weight."""
     _need_hip(x, upack, scale, shift, residual, out)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
@@ -449,6 +451,8 @@ def upwino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
     if os.environ.get("TGSR_WINO4", "1") == "0":
         return False
     Ho, Wo = 2 * H, 2 * W
+    if cin < int(os.environ.get("TGSR_UPWINO4_MIN_CIN", "0")):          # diagnostics: which upBlocks cost what
+        return False
     if not (cout % 64 == 0 and cin % 8 == 0 and Wo % 64 == 0 and Ho % 4 == 0 and Ho * Wo >= UPWINO4_MIN_OUT_PIXELS):
         return False
     return B * (Ho // 4) * (Wo // 64) * (cout // 64) >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))

@@ -63,10 +63,10 @@ class _FusedParams:
 
 
     def get_wino4(self, conv: nn.Conv2d, bn, glu: bool):
-        """(pack, scale, shift, wide): the wide form of the F(4x4) kernel (tgsr_wino4_wide_conv3x3_fwd) where the layer has
-        128-channel groups and an even number of 4-channel stages."""
+        """(pack, scale, shift, wide): the register-fed form of the F(4x4) kernel (tgsr_wino4_wide_conv3x3_fwd: 128-row groups
+        where Cout % 128 == 0, else 64-row groups in 4-wave workgroups) where the layer has an even number of 4-channel stages."""
         self._refresh(conv, bn)
-        wide = conv.out_channels % 128 == 0 and conv.in_channels % 8 == 0
+        wide = conv.in_channels % 8 == 0
         if self.u4pack is None:
             self.u4pack = (C.pack_wino4w_weight(conv.weight.detach(), glu) if wide else
                            C.pack_wino4_weight(conv.weight.detach(), glu, False))

@@ -14,9 +14,12 @@ def sd(pre, dt=torch.float32):
 cap, lens, LR, LRb = O.synthetic_batch(16)
 ref = O.sr_forward(sd("E."), sd("GL."), sd("GH."), cap, lens.tolist(), LR, LRb)
 cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 256
-for mode in ("1", "0"):
+for mode, extra in (("1", {}), ("1", {"TGSR_UPWINO4_MIN_CIN": "64"}), ("1", {"TGSR_UPWINO4_MIN_CIN": "1000"}), ("0", {})):
     os.environ["TGSR_WINO4"] = mode
+    for k in ("TGSR_UPWINO4_MIN_CIN",):
+        os.environ.pop(k, None)
+    os.environ.update(extra)
     p = SRPipeline(41, device="cuda", branch_num=4).load_state_dicts(sd("E."), sd("GL."), sd("GH."))
     r = p(cap.cuda(), lens.tolist(), LR.cuda(), LRb.cuda())
-    print("TGSR_WINO4=%s:" % mode, "  ".join("%s%d %.2e/%.1e" % (k, i, float((r[k][i].cpu() - ref[k][i]).abs().max()), float((r[k][i].cpu() - ref[k][i]).abs().mean()))
+    print("TGSR_WINO4=%s %s:" % (mode, extra), "  ".join("%s%d %.2e/%.1e" % (k, i, float((r[k][i].cpu() - ref[k][i]).abs().max()), float((r[k][i].cpu() - ref[k][i]).abs().mean()))
                                             for k in ("fake", "fine") for i in range(3)), flush=True)

@@ -38,7 +38,7 @@ for (b, cin, cout, h, w, glu, res) in ((1, 4, 64, 8, 64, 0, 0), (2, 8, 64, 16, 6
     up2 = ops.pack_wino_weight(wt, glu=bool(glu))
     o2 = ops.conv3x3_wino(x, up2, cout, sc, sh, bool(glu), r)
     ew = -1.0
-    if cout % 128 == 0:
+    if cin % 8 == 0:
         ow = ops.conv3x3_wino4(x, ops.pack_wino4w_weight(wt, glu=bool(glu)), cout, sc, sh, bool(glu), r, wide=True)
         ew = float((ow.double() - ref).abs().max())
     print("B%d %d->%d %dx%d glu%d res%d: |F4-f64| max %.2e  |F2-f64| max %.2e  |F4wide-f64| %.2e" % (
@@ -54,7 +54,7 @@ for cin, cout, h, glu, res in ((64, 128, 128, 1, 0), (64, 64, 128, 0, 1), (64, 1
     up4, up2 = ops.pack_wino4_weight(wt, glu=bool(glu)), ops.pack_wino_weight(wt, glu=bool(glu))
     t4 = timeit(lambda: ops.conv3x3_wino4(x, up4, cout, sc, sh, bool(glu), r, out))
     t2 = timeit(lambda: ops.conv3x3_wino(x, up2, cout, sc, sh, bool(glu), r, out))
-    if cout % 128 == 0:
+    if cin % 8 == 0:
         upw = ops.pack_wino4w_weight(wt, glu=bool(glu))
         tw = timeit(lambda: ops.conv3x3_wino4(x, upw, cout, sc, sh, bool(glu), r, out, wide=True))
         print("   wide: %.1f us (%.0f TFLOP/s alg, executed frac %.3f)" % (tw, 2.0 * B * h * h * cout * cin * 9 / tw / 1e6, 2.0 * B * h * h * cout * cin * 9 / 4 / tw / 1e6 / 157.3))
