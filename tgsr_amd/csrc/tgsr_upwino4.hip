@@ -17,8 +17,9 @@
 // finest image against fp64, stated tolerance 1e-4).
 //
 // Geometry.  A workgroup = 4 waves = ONE tile row (4 x 64 OUTPUT pixels) x 4 channel blocks (64 accumulator rows); a wave =
-// 16 tiles x 16 rows x 25 positions = 100 accumulator registers; stage = 4 input channels = 25 MFMAs per wave; two workgroups
-// per CU (two waves per SIMD), independent of each other: one's prologue / epilogue runs under the other's main loop.
+// 16 tiles x 16 rows x 25 positions = 100 accumulator registers; stage = 4 input channels = 25 MFMAs per wave; 168 registers:
+// THREE workgroups per CU (three waves per SIMD; two: 177 instead of 170 us on the largest layer), independent of each other:
+// one's prologue / epilogue runs under the others' main loops.
 //   A   straight from L2 into registers, as in tgsr_winograd4.hip's wide form: the pack is in per-wave fragment order
 //       [stage][group][cb 4][quad 7][lane 64][4] (positions p = 5 ri + cj over the live rows / columns 0,1,3,4,5, quad p / 4,
 //       element p % 4, three pad slots); one global_load_dwordx4 per quad, issued behind the quad's MFMAs for the NEXT stage
@@ -90,7 +91,7 @@ __device__ __forceinline__ void u4_at(float m0, float m1, float m3, float m4, fl
 }
 
 template <bool GLU>
-__global__ __launch_bounds__(256, 2) void upwino4_kernel(Upw4Args a) {
+__global__ __launch_bounds__(256, 3) void upwino4_kernel(Upw4Args a) {
   __shared__ __attribute__((aligned(16))) float smem[ku4SMEM];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
   const int cb = __builtin_amdgcn_readfirstlane(tid >> 6);             // channel block of this wave
