@@ -165,6 +165,12 @@ int tgsr_wino4_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, in
  * in 4-wave workgroups, two independent per CU.  Same contract with Cin % 8 == 0; its own pack layout
  * (tgsr_packed_wino4_weight_elems floats, 16-byte aligned). */
 int tgsr_pack_wino4_wide_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream);
+/* ... of the data-gradient convolution, from the forward weight [Cin][Cout][3][3] (see tgsr_pack_conv_weight_dgrad) */
+int tgsr_pack_wino4_wide_weight_dgrad(const float* w, float* upack, int Cout, int Cin, void* stream);
+/* ... with the statistics epilogue of tgsr_wino4_conv3x3_stats_fwd (training forward): one pair per channel and 4 x 64 wave tile */
+int tgsr_wino4_wide_stats_nslots(int B, int H, int W, int Cout);
+int tgsr_wino4_wide_conv3x3_stats_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                                      int Cout, float* out, int64_t out_bstride, float* stat_partial, void* stream);
 int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
                                 const float* scale, const float* shift, const float* residual, int64_t res_bstride,
                                 float* out, int64_t out_bstride, int epilogue, void* stream);

@@ -132,8 +132,10 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     chk(T.conv3x3_wino4_stats.default, (x4 if False else R(B, Cc, 8, 64), up4, Cc), test_utils=basic)
     x4 = R(B, Cc, 8, 64)
     chk(T.conv3x3_wino4.default, (x4, up4, Cc, gam, bet, False, R(B, Cc, 8, 64)), test_utils=basic)
-    upw4 = T.pack_wino4w_weight(R(128, Cc, 3, 3), True)
-    chk(T.pack_wino4w_weight.default, (R(128, Cc, 3, 3), False), test_utils=basic)
+    upw4 = T.pack_wino4w_weight(R(128, Cc, 3, 3), True, False)
+    chk(T.pack_wino4w_weight.default, (R(128, Cc, 3, 3), False, False), test_utils=basic)
+    chk(T.pack_wino4w_weight.default, (R(Cc, 128, 3, 3), False, True), test_utils=basic)
+    chk(T.conv3x3_wino4w_stats.default, (R(B, Cc, 8, 64), T.pack_wino4w_weight(R(128, Cc, 3, 3), False, False), 128), test_utils=basic)
     chk(T.conv3x3_wino4w.default, (x4, upw4, 128, None, None, True, None), test_utils=basic)
     chk(T.conv3x3_wino4w_out.default, (x4, upw4, 128, None, None, True, None, torch.empty(B, Cc, 8, 64, device=DEV)), test_utils=basic)
     chk(T.conv3x3_wino4_out.default, (x4, up4, Cc, None, None, False, None, torch.empty(B, Cc, 8, 64, device=DEV)), test_utils=basic)

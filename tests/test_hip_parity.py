@@ -332,6 +332,13 @@ def test_winograd4_training_forms():
     dx = ops.conv3x3_wino4(dy, ops.pack_wino4_weight(w, dgrad=True), Cin, None, None, residual=add)
     ref = F.conv_transpose2d(dy.double().cpu(), w.double().cpu(), None, 1, 1) + add.double().cpu()
     assert float((dx.double().cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max())
+    # the register-fed forms of both (128-row groups for the forward, 64-row groups for the gradient): bit-identical outputs,
+    # the same per-wave statistics in another slot order
+    raww, partw = ops.conv3x3_wino4_stats(x, ops.pack_wino4w_weight(w), Cout, wide=True)
+    assert torch.equal(raww, raw) and partw.shape == part.shape == (Cout, ops.wino4_stats_nslots(B, H, W, Cout, wide=True), 2)
+    np.testing.assert_allclose(partw.double().sum(1).cpu().numpy(), s.numpy(), rtol=1e-6, atol=1e-4)
+    assert torch.equal(torch.sort(partw[:, :, 0], dim=1).values, torch.sort(part[:, :, 0], dim=1).values)
+    assert torch.equal(ops.conv3x3_wino4(dy, ops.pack_wino4w_weight(w, dgrad=True), Cin, None, None, residual=add, wide=True), dx)
 
 
 def test_wino4_routing_follows_the_size_policy(monkeypatch):

@@ -46,6 +46,9 @@ SIGNATURES = {
     "tgsr_pack_wino4_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tgsr_pack_wino4_weight_dgrad": (_i, [_vp, _vp, _i, _i, _vp]),
     "tgsr_pack_wino4_wide_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "tgsr_pack_wino4_wide_weight_dgrad": (_i, [_vp, _vp, _i, _i, _vp]),
+    "tgsr_wino4_wide_stats_nslots": (_i, [_i, _i, _i, _i]),
+    "tgsr_wino4_wide_conv3x3_stats_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp]),
     "tgsr_wino4_wide_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
     "tgsr_wino4_conv3x3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i64, _vp, _i64, _i, _vp]),
     "tgsr_conv_to3_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i, _i, _vp, _f, _vp, _vp]),

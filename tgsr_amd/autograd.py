@@ -93,6 +93,8 @@ class PackCache:
     def _pack(weight, kind, out):
         if kind in ("wino4", "wino4_dgrad"):
             return ops.pack_wino4_weight(weight, False, kind == "wino4_dgrad", out=out)
+        if kind in ("wino4w", "wino4w_dgrad"):
+            return ops.pack_wino4w_weight(weight, False, kind == "wino4w_dgrad", out=out)
         if kind == "wino":
             return ops.pack_wino_weight(weight, False, False, out=out)
         if kind == "wino_dgrad":
@@ -142,6 +144,8 @@ def _packed(weight, kind):
         return _PACKS.get(weight, kind)
     if kind in ("wino4", "wino4_dgrad"):
         return C.pack_wino4_weight(weight, False, kind == "wino4_dgrad")
+    if kind in ("wino4w", "wino4w_dgrad"):
+        return C.pack_wino4w_weight(weight, False, kind == "wino4w_dgrad")
     if kind in ("wino", "wino_dgrad"):
         return C.pack_wino_weight(weight, False, kind == "wino_dgrad")
     if kind == "upwino":
@@ -160,7 +164,10 @@ def _conv_raw(x: torch.Tensor, weight: torch.Tensor, upsample: bool = False, dgr
     from . import util
     Cout = weight.shape[1] if dgrad else weight.shape[0]
     if util.WINOGRAD and not upsample and util._wino4_takes(x, Cout, None, residual):
-        # the 128 x 128 layers: F(4x4, 3x3), forward and data gradient alike (tgsr_winograd4.hip)
+        # the large layers: F(4x4, 3x3), forward and data gradient alike (tgsr_winograd4.hip); the register-fed form where the
+        # convolution has an even number of 4-channel stages
+        if x.shape[1] % 8 == 0:
+            return C.conv3x3_wino4w(x, _packed(weight, "wino4w_dgrad" if dgrad else "wino4w"), Cout, None, None, False, residual)
         return C.conv3x3_wino4(x, _packed(weight, "wino4_dgrad" if dgrad else "wino4"), Cout, None, None, False, residual)
     if util.WINOGRAD and not upsample and util._wino_pays(x, Cout, None, None):
         return C.conv3x3_wino(x, _packed(weight, "wino_dgrad" if dgrad else "wino"), Cout, None, None, False, residual)
@@ -175,7 +182,8 @@ def _cba_forward(x, weight, gamma, beta, running_mean, running_var, residual, gl
     from . import util
     w = weight.detach()
     if BN_STATS_IN_CONV and util.WINOGRAD and not upsample and util._wino4_takes(x, w.shape[0], None, None):
-        raw, part = C.conv3x3_wino4_stats(x, _packed(w, "wino4"), w.shape[0])
+        raw, part = (C.conv3x3_wino4w_stats(x, _packed(w, "wino4w"), w.shape[0]) if x.shape[1] % 8 == 0 else
+                     C.conv3x3_wino4_stats(x, _packed(w, "wino4"), w.shape[0]))
         out, stats = C.bn_train_fwd_from_stats(raw, gamma.detach(), beta.detach(), float(eps), float(momentum), running_mean,
                                                running_var, 1 if glu else 0, residual, nbt, part)
         return out, raw, stats

@@ -451,8 +451,9 @@ constexpr int k4wUW = 9 * 256;                                          // float
 // groups (Cout % 128 != 0: the +residual convolutions): 4-wave workgroups, two per CU that share nothing, so one's prologue and
 // epilogue - the residual variant's 131 KB in / 131 KB out burst - run under the other's main loop; the transform is not amortised
 // further than in the narrow form (three of four waves transform), what it saves is the 36 U copies and the A reads from LDS.
-template <bool GLU, int NB>
+template <bool GLU, int NB, bool STATS = false>
 __global__ __launch_bounds__(64 * NB, 2) void wino4w_conv3x3_kernel(Wino4Args a) {
+  static_assert(!(GLU && STATS), "batch statistics are taken of the raw (plain-epilogue) convolution output");
   constexpr int NR = 16 * NB;                              // accumulator rows of a workgroup (128 | 64)
   __shared__ __attribute__((aligned(16))) float smem[k4wSMEM];
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, lg = lane >> 4;
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(64 * NB, 2) void wino4w_conv3x3_kernel(Wino4Args a)
   const int64_t HWo = (int64_t)a.H * a.W;
   float* __restrict__ ob = a.out + (int64_t)b * a.obs;
   const float* __restrict__ rb = a.res ? a.res + (int64_t)b * a.rbs : nullptr;
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   if (ox < a.W) {
     if (GLU) {
 #pragma unroll
@@ -674,7 +676,29 @@ __global__ __launch_bounds__(64 * NB, 2) void wino4w_conv3x3_kernel(Wino4Args a)
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] = yv[r][k] * sv + tv + rr[i][r][k];
           *reinterpret_cast<f32x4w4*>(ob + (int64_t)c * HWo + (int64_t)(oy + r) * a.W + ox) = o;
+          if (STATS) {
+            ssum[i] += (o[0] + o[1]) + (o[2] + o[3]);
+            ssq[i] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+          }
         }
+      }
+    }
+  }
+  if (STATS) {
+    // BatchNorm's batch statistics (as in the narrow form): one (sum, sumsq) pair per channel and wave - slot = (sample, tile
+    // row, 64-column chunk): the narrow form's pairs in another order
+    const int slot = (b * a.tiles_y + ty) * a.tiles_x + tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float sm = ssum[i], sq = ssq[i];
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        sm += __shfl_xor(sm, o);
+        sq += __shfl_xor(sq, o);
+      }
+      if (l15 == 0) {
+        const int c = grp * NR + cb * 16 + 4 * lg + i;
+        *reinterpret_cast<float2*>(a.stat + ((int64_t)c * a.nslots + slot) * 2) = make_float2(sm, sq);
       }
     }
   }
@@ -683,8 +707,9 @@ __global__ __launch_bounds__(64 * NB, 2) void wino4w_conv3x3_kernel(Wino4Args a)
 // wide pack: upack[stage][group of 16 nb rows][cb nb][quad 9][lane 64 = (ci lane >> 4, row lane & 15)][4], nb = 8 (Cout % 128 == 0)
 // or 4; row m of block cb: plain = cout grp*16nb + cb*16 + m; GLU = value channel grp*8nb + cb*8 + 2 (m >> 2) + (m & 1) when
 // m & 2 == 0, else its gate
+// tr != 0: the source is the FORWARD conv's weight [Cin][Cout][3][3]; the pack is of the data-gradient conv (plain order)
 __global__ void pack_wino4w_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu, int nb,
-                                          int64_t total) {
+                                          int tr, int64_t total) {
   const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                           {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
   const int ngrp = Cout / (16 * nb);                       // nb = 8 | 4 blocks per group
@@ -702,9 +727,9 @@ __global__ void pack_wino4w_weight_kernel(const float* __restrict__ w, float* __
     const int c = st * k4CK + ci;
     double u = 0.0;
     if (c < Cin) {
-      const float* gw = w + ((int64_t)co * Cin + c) * 9;
+      const float* gw = tr ? w + ((int64_t)c * Cout + co) * 9 : w + ((int64_t)co * Cin + c) * 9;
       for (int k = 0; k < 3; ++k)
-        for (int l = 0; l < 3; ++l) u += G[i][k] * (double)gw[k * 3 + l] * G[j][l];
+        for (int l = 0; l < 3; ++l) u += G[i][k] * (double)(tr ? gw[8 - (k * 3 + l)] : gw[k * 3 + l]) * G[j][l];
     }
     up[idx] = (float)u;
   }
@@ -824,24 +849,33 @@ extern "C" int tgsr_wino4_conv3x3_stats_fwd(const float* x, int64_t x_bstride, i
                        stat_partial, stream);
 }
 
-extern "C" int tgsr_pack_wino4_wide_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
+static int pack_wino4_wide_weight(const float* w, float* upack, int Cout, int Cin, int glu, int tr, void* stream) {
   if (!w || !upack || Cout < 1 || Cin < 1) return TGSR_EINVAL;
   if (Cout % 64 != 0) return TGSR_EUNSUPPORTED;
   const int64_t total = tgsr_packed_wino4_weight_elems(Cout, Cin);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_wino4w_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, upack, Cout, Cin, glu ? 1 : 0,
-                     Cout % 128 == 0 ? 8 : 4, total);
+                     Cout % 128 == 0 ? 8 : 4, tr, total);
   return note_launch(hipGetLastError(), "pack_wino4w_weight_kernel");
 }
 
-extern "C" int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
-                                           int Cout, const float* scale, const float* shift, const float* residual,
-                                           int64_t res_bstride, float* out, int64_t out_bstride, int epilogue, void* stream) {
+extern "C" int tgsr_pack_wino4_wide_weight(const float* w, float* upack, int Cout, int Cin, int glu, void* stream) {
+  return pack_wino4_wide_weight(w, upack, Cout, Cin, glu, 0, stream);
+}
+
+extern "C" int tgsr_pack_wino4_wide_weight_dgrad(const float* w, float* upack, int Cout, int Cin, void* stream) {
+  return pack_wino4_wide_weight(w, upack, Cout, Cin, 0, 1, stream);
+}
+
+static int wino4_wide_conv3x3(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack, int Cout,
+                              const float* scale, const float* shift, const float* residual, int64_t res_bstride, float* out,
+                              int64_t out_bstride, int epilogue, float* stat, void* stream) {
   if (!x || !upack || !out || B < 1 || Cin < 1 || H < 1 || W < 1 || Cout < 1) return TGSR_EINVAL;
   if ((scale == nullptr) != (shift == nullptr)) return TGSR_EINVAL;
   const bool glu = epilogue == TGSR_EPI_AFFINE_GLU;
   if (!glu && epilogue != TGSR_EPI_AFFINE) return TGSR_EINVAL;
   if (glu && residual) return TGSR_EINVAL;
+  if (stat && (glu || residual || scale)) return TGSR_EINVAL;     // statistics are of the raw convolution output
   if (Cout % 64 != 0 || Cin % (2 * k4CK) != 0) return TGSR_EUNSUPPORTED;       // an even number of 4-channel stages
   if ((int64_t)H * W >= (1 << 28) || (int64_t)Cin * H * W >= (1ll << 32)) return TGSR_EUNSUPPORTED;
   if ((W & 3) || (x_bstride & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
@@ -853,14 +887,36 @@ extern "C" int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, in
   a.x = x; a.xbs = x_bstride; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.upack = upack; a.Cout = Cout;
   a.scale = scale; a.shift = shift; a.res = residual; a.rbs = res_bstride; a.out = out; a.obs = out_bstride;
   a.tiles_x = (W + 63) / 64; a.tiles_y = (H + 3) / 4; a.nstages = Cin / k4CK; a.ngroups = Cout / (16 * nb);
-  a.stat = nullptr; a.nslots = 0;
+  a.stat = stat; a.nslots = B * a.tiles_y * a.tiles_x;
   const dim3 grid((unsigned)(B * a.tiles_x * a.tiles_y * a.ngroups));
   if (nb == 8) {
     if (glu) hipLaunchKernelGGL((wino4w_conv3x3_kernel<true, 8>), grid, dim3(512), 0, as_stream(stream), a);
+    else if (stat) hipLaunchKernelGGL((wino4w_conv3x3_kernel<false, 8, true>), grid, dim3(512), 0, as_stream(stream), a);
     else hipLaunchKernelGGL((wino4w_conv3x3_kernel<false, 8>), grid, dim3(512), 0, as_stream(stream), a);
   } else {
     if (glu) hipLaunchKernelGGL((wino4w_conv3x3_kernel<true, 4>), grid, dim3(256), 0, as_stream(stream), a);
+    else if (stat) hipLaunchKernelGGL((wino4w_conv3x3_kernel<false, 4, true>), grid, dim3(256), 0, as_stream(stream), a);
     else hipLaunchKernelGGL((wino4w_conv3x3_kernel<false, 4>), grid, dim3(256), 0, as_stream(stream), a);
   }
   return note_launch(hipGetLastError(), "wino4w_conv3x3_kernel");
+}
+
+extern "C" int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* upack,
+                                           int Cout, const float* scale, const float* shift, const float* residual,
+                                           int64_t res_bstride, float* out, int64_t out_bstride, int epilogue, void* stream) {
+  return wino4_wide_conv3x3(x, x_bstride, B, Cin, H, W, upack, Cout, scale, shift, residual, res_bstride, out, out_bstride,
+                            epilogue, nullptr, stream);
+}
+
+extern "C" int tgsr_wino4_wide_stats_nslots(int B, int H, int W, int Cout) {
+  if (B < 1 || H < 1 || W < 1 || Cout < 1 || Cout % 64 != 0) return 0;
+  return B * ((H + 3) / 4) * ((W + 63) / 64);
+}
+
+extern "C" int tgsr_wino4_wide_conv3x3_stats_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W,
+                                                 const float* upack, int Cout, float* out, int64_t out_bstride,
+                                                 float* stat_partial, void* stream) {
+  if (!stat_partial) return TGSR_EINVAL;
+  return wino4_wide_conv3x3(x, x_bstride, B, Cin, H, W, upack, Cout, nullptr, nullptr, nullptr, 0, out, out_bstride,
+                            TGSR_EPI_AFFINE, stat_partial, stream);
 }

@@ -109,8 +109,18 @@ conv3x3_wino4_out = _define("conv3x3_wino4_out(Tensor x, Tensor upack, int cout,
                             lambda *a: None)
 
 
-pack_wino4w_weight = _define("pack_wino4w_weight(Tensor w, bool glu) -> Tensor", lambda w, g: ops.pack_wino4w_weight(w, glu=g),
-                             lambda w, g: w.new_empty(((w.shape[1] + 3) // 4) * 144 * w.shape[0]))
+pack_wino4w_weight = _define("pack_wino4w_weight(Tensor w, bool glu, bool dgrad) -> Tensor",
+                             lambda w, g, d: ops.pack_wino4w_weight(w, glu=g, dgrad=d),
+                             lambda w, g, d: w.new_empty(((w.shape[0 if d else 1] + 3) // 4) * 144 * w.shape[1 if d else 0]))
+
+
+def _wino4w_stats_fake(x, upack, cout):
+    n = ops.wino4_stats_nslots(x.shape[0], x.shape[2], x.shape[3], cout, wide=True)
+    return x.new_empty(x.shape[0], cout, x.shape[2], x.shape[3]), x.new_empty(cout, n, 2)
+
+
+conv3x3_wino4w_stats = _define("conv3x3_wino4w_stats(Tensor x, Tensor upack, int cout) -> (Tensor, Tensor)",
+                               lambda x, upack, cout: ops.conv3x3_wino4_stats(x, upack, cout, wide=True), _wino4w_stats_fake)
 conv3x3_wino4w = _define("conv3x3_wino4w(Tensor x, Tensor upack, int cout, Tensor? scale, Tensor? shift, bool glu, "
                          "Tensor? residual) -> Tensor",
                          lambda x, upack, cout, scale, shift, glu, residual:

@@ -268,15 +268,22 @@ def pack_wino4_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, o
     return out
 
 
-def pack_wino4w_weight(w: torch.Tensor, glu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def pack_wino4w_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The pack of the register-fed F(4x4,3x3) kernel: per-wave fragment order [Cin/4][groups][8 | 4 blocks][9 quads][64 lanes][4]
-    (128-row groups where Cout % 128 == 0, else 64-row groups) - not interchangeable with pack_wino4_weight's."""
+    (128-row groups where Cout % 128 == 0, else 64-row groups) - not interchangeable with pack_wino4_weight's.  `dgrad`: w is the
+    forward conv's weight, the pack is of its data-gradient conv."""
     _need_hip(w)
     w = _f32(w.detach(), "weight").contiguous()
     Cout, Cin = w.shape[0], w.shape[1]
+    if dgrad:
+        Cout, Cin = Cin, Cout
     L = _lib.lib()
     out = _pack_out(out, L.tgsr_packed_wino4_weight_elems(Cout, Cin), w.device)
-    check(L.tgsr_pack_wino4_wide_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_wino4_wide_weight")
+    if dgrad:
+        assert not glu
+        check(L.tgsr_pack_wino4_wide_weight_dgrad(_p(w), _p(out), Cout, Cin, _stream()), "tgsr_pack_wino4_wide_weight_dgrad")
+    else:
+        check(L.tgsr_pack_wino4_wide_weight(_p(w), _p(out), Cout, Cin, 1 if glu else 0, _stream()), "tgsr_pack_wino4_wide_weight")
     return out
 
 
@@ -310,28 +317,31 @@ def conv3x3_wino4(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
     return out
 
 
-def wino4_stats_nslots(B: int, H: int, W: int, cout: int) -> int:
+def wino4_stats_nslots(B: int, H: int, W: int, cout: int, wide: bool = False) -> int:
     """Partial-sum pairs per channel conv3x3_wino4_stats writes for this shape (0: unsupported)."""
-    return int(_lib.lib().tgsr_wino4_stats_nslots(int(B), int(H), int(W), int(cout)))
+    L = _lib.lib()
+    return int((L.tgsr_wino4_wide_stats_nslots if wide else L.tgsr_wino4_stats_nslots)(int(B), int(H), int(W), int(cout)))
 
 
-def conv3x3_wino4_stats(x: torch.Tensor, upack: torch.Tensor, cout: int):
-    """conv3x3_wino_stats on the F(4x4, 3x3) kernel: (out [B,cout,H,W], stat_partial [cout, nslots, 2])."""
+def conv3x3_wino4_stats(x: torch.Tensor, upack: torch.Tensor, cout: int, wide: bool = False):
+    """conv3x3_wino_stats on the F(4x4, 3x3) kernels: (out [B,cout,H,W], stat_partial [cout, nslots, 2]).  `wide`: the
+    register-fed form (upack from pack_wino4w_weight)."""
     _need_hip(x, upack)
     x, xbs = _nchw_bstride(_f32(x, "x"), "x")
     B, Cin, H, W = x.shape
     _check_pack("conv3x3_wino4_stats", "wino4", upack, cout, Cin)
     L = _lib.lib()
-    nslots = L.tgsr_wino4_stats_nslots(B, H, W, cout)
+    nslots = (L.tgsr_wino4_wide_stats_nslots if wide else L.tgsr_wino4_stats_nslots)(B, H, W, cout)
     if nslots < 1:
         raise TgsrError("conv3x3_wino4_stats: unsupported shape %s -> %d channels" % (tuple(x.shape), cout))
     out = torch.empty(B, cout, H, W, dtype=torch.float32, device=x.device)
     part = torch.empty(cout, nslots, 2, dtype=torch.float32, device=x.device)
     e0 = _ev() if profile is not None else None
-    check(L.tgsr_wino4_conv3x3_stats_fwd(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(out), cout * H * W, _p(part), _stream()),
-          "tgsr_wino4_conv3x3_stats_fwd")
+    fn = L.tgsr_wino4_wide_conv3x3_stats_fwd if wide else L.tgsr_wino4_conv3x3_stats_fwd
+    check(fn(_p(x), xbs, B, Cin, H, W, _p(upack), cout, _p(out), cout * H * W, _p(part), _stream()),
+          "tgsr_wino4_wide_conv3x3_stats_fwd" if wide else "tgsr_wino4_conv3x3_stats_fwd")
     if profile is not None:
-        profile.append(("wino4_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9,
+        profile.append(("wino4w_conv3x3_kernel" if wide else "wino4_conv3x3_kernel", 2.0 * B * H * W * cout * Cin * 9,
                         4 * (B * Cin * H * W + B * cout * H * W + cout * Cin * 9), e0, _ev()))
     return out, part
 

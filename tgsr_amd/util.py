@@ -68,7 +68,7 @@ class _FusedParams:
         self._refresh(conv, bn)
         wide = conv.in_channels % 8 == 0
         if self.u4pack is None:
-            self.u4pack = (C.pack_wino4w_weight(conv.weight.detach(), glu) if wide else
+            self.u4pack = (C.pack_wino4w_weight(conv.weight.detach(), glu, False) if wide else
                            C.pack_wino4_weight(conv.weight.detach(), glu, False))
         return self.u4pack, self.scale, self.shift, wide
 
