@@ -813,6 +813,32 @@ def test_captured_step_is_independent_of_caption_lengths():
     cfg_reset()
 
 
+def test_fp32_batch16_graph_lanes_run_the_f4_kernels_and_equal_eager(face_weights, cfg_face, monkeypatch):
+    """The default bench configuration in small: batch 16 (the size at which ops.wino4_wanted / upwino4_wanted route the 128^2 and
+    64^2 layers and the upBlocks to the F(4x4) kernels - register-fed fragments, counted vmcnt waits), two batches as parallel
+    lanes of ONE hipGraph: every lane bit-identical to its eager step, on replays with new inputs too."""
+    from tgsr_amd import custom_ops as C
+    from tgsr_amd.trainer import GraphedStep
+    seen = set()
+    for name in ("conv3x3_wino4w", "conv3x3_wino4w_out", "upwino4_glu", "upwino4_glu_out"):
+        real = getattr(C, name)
+        monkeypatch.setattr(C, name, (lambda real, name: lambda *a: (seen.add(name.replace("_out", "")), real(*a))[1])(real, name))
+    p = _pipeline(face_weights)
+    B = 16
+    batches = [O.synthetic_batch(B, seed=40 + k) for k in range(4)]
+    dev = [(b[0].to(DEV), b[1].tolist(), b[2].to(DEV), b[3].to(DEV)) for b in batches]
+    eager = [[t.clone() for t in p(*d)["fine"]] for d in dev]
+    assert seen == {"conv3x3_wino4w", "upwino4_glu"}, seen
+    step = GraphedStep(p, *dev[0], lanes=2)
+    for first in (0, 2):
+        out = step.replay([dev[first][0], dev[first + 1][0]], [dev[first][1], dev[first + 1][1]],
+                          [dev[first][2], dev[first + 1][2]], [dev[first][3], dev[first + 1][3]])
+        torch.cuda.synchronize()
+        for k in range(2):
+            for i in range(3):
+                assert torch.equal(out[k]["fine"][i], eager[first + k][i]), (first, k, i)
+
+
 @pytest.mark.parametrize("shape", [(2, 3, 256, 256), (1, 3, 7, 5), (5,)])
 def test_to_uint8_bytes_match_numpy(shape):
     """trainer_objective.py:153-155 on the device: identical bytes, including .5 ties, clipping and out-of-range."""
