@@ -190,15 +190,19 @@ def test_lazy_log_is_opt_in_and_formats_like_the_reference():
 
 
 def test_wino4_size_policy(monkeypatch):
-    """Which conv3x3 layers go to the F(4x4, 3x3) kernel: whole 8 x 64 tiles, 64-channel groups, - the numerics policy of
-    tgsr_winograd4.hip - only images of >= 64 x 64 pixels, and at least one full round of workgroups; TGSR_WINO4=0 switches it
-    off."""
+    """Which conv3x3 layers go to the F(4x4, 3x3) kernels: whole tiles and 64-channel groups; the numerics rule of
+    tgsr_winograd4.hip (>= 128 x 128 pixels, at 64 x 64 only 128-channel groups, nothing below); at least 256 workgroups of the
+    form the layer takes; TGSR_WINO4=0 switches it off."""
     from tgsr_amd import ops
     monkeypatch.delenv("TGSR_WINO4", raising=False)
+    monkeypatch.delenv("TGSR_WINO4_MIN_WG", raising=False)
     assert ops.wino4_wanted(64, 128, 128, 128, 16) and ops.wino4_wanted(64, 64, 128, 128, 16) and ops.wino4_wanted(64, 64, 256, 256, 2)
-    assert ops.wino4_wanted(64, 128, 64, 64, 16) and not ops.wino4_wanted(64, 64, 64, 64, 16)    # 256 vs 128 tiles
-    assert not ops.wino4_wanted(64, 128, 128, 128, 2)                                            # small batch: F(2x2)'s tiles
-    assert not ops.wino4_wanted(64, 128, 32, 32, 64) and not ops.wino4_wanted(128, 256, 32, 64, 64)   # the numerics policy
+    assert ops.wino4_wanted(64, 128, 64, 64, 16) and not ops.wino4_wanted(64, 64, 64, 64, 16)    # 64 x 64: 128-channel groups only
+    assert not ops.wino4_wanted(64, 64, 64, 64, 64)                                              # ... whatever the batch
+    assert ops.wino4_wanted(64, 64, 128, 128, 4) and not ops.wino4_wanted(64, 64, 128, 128, 2)   # 256 vs 128 four-wave workgroups
+    assert ops.wino4_wanted(64, 128, 128, 128, 4) and not ops.wino4_wanted(64, 128, 128, 128, 2)
+    assert ops.wino4_wanted(12, 64, 128, 128, 8) and not ops.wino4_wanted(12, 64, 128, 128, 4)   # LDS-fed form: 8-row tiles
+    assert not ops.wino4_wanted(64, 128, 32, 32, 64) and not ops.wino4_wanted(128, 256, 32, 64, 64)   # below 64 x 64
     assert not ops.wino4_wanted(64, 32, 128, 128, 16) and not ops.wino4_wanted(3, 64, 128, 128, 16)   # channel groups / stages
     assert not ops.wino4_wanted(64, 64, 128, 160, 16) and not ops.wino4_wanted(64, 64, 132, 128, 16)  # whole tiles
     monkeypatch.setenv("TGSR_WINO4", "0")

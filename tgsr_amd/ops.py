@@ -228,25 +228,33 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
 
 
 WINO4_MIN_PIXELS = 64 * 64        # per image; DESIGN.md 3.1e: the error study that keeps F(4x4) off the 32 x 32 layers
-UPWINO4_MIN_OUT_PIXELS = 128 * 128  # output pixels per image of an upBlock on the F(4x4) form (see upwino4_wanted)
+UPWINO4_MIN_OUT_PIXELS = 128 * 128  # pixels per image from which every 64-channel-group layer / upBlock output may use F(4x4)
 WINO4_MIN_WORKGROUPS = 256        # below a full round of its (large) workgroup tiles F(2x2)'s four times smaller ones win
 
 
 def wino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
-    """Does a conv3x3 layer go to the F(4x4, 3x3) kernels?  Shape support (Cout % 64, Cin % 4, W % 64, H % 8: whole workgroup
-    tiles), the numerics policy - only layers of >= 64 x 64 pixels: measured on the shipped checkpoint against fp64, the 128^2
-    and 64^2 layers on it move the finest images by <= 4e-6 (max), the 32^2 layers on it as well cost 2e-4 (tgsr_winograd4.hip)
-    - and enough work to fill the chip: >= 256 tiles of 8 x 64 pixels x 64 channels.  At batch 16: the ResBlock convolutions
-    of the 128^2 stage and the 64 -> 128 ones of the 64^2 stage; the batch-2 golden case stays on F(2x2).  (The 64 -> 64 ones
-    at 64^2 would be faster too on the register-fed form's half-height tiles - 22.6 vs 28.8 us - and are left where they are:
-    12 us per step against a finest image at 9.4e-5 instead of 8.6e-5 from the fp32 oracle at batch 16)
+    """Does a conv3x3 layer go to the F(4x4, 3x3) kernels?  Three rules.
+    Shape: Cout % 64, Cin % 4, W % 64, H % 8 (whole workgroup tiles).
+    Numerics (measured on the shipped checkpoint against fp64 and the fp32 oracle): layers of >= 128 x 128
+    pixels; at 64 x 64 .. 128 x 128 only the convolutions with 128-channel groups (the 64 -> 128 ones: with the 64 -> 64 ones of
+    that stage as well the finest image sits at 9.4e-5 instead of 8.6e-5 from the fp32 oracle at batch 16, stated 1e-4); nothing
+    below 64 x 64 (with the 32^2 layers: 2e-4).
+    Work: >= 256 workgroups of the form the layer takes - register-fed (Cin % 8 == 0): 4 x 64 pixels x 128 rows, or x 64 rows
+    where Cout % 128 != 0; else the LDS-fed form, 8 x 64 x 64 (measured at batch 4 .. 32: each routed layer faster than on
+    F(2x2), each unrouted one slower; the batch-2 golden case stays on F(2x2) except for the last upBlocks).
     TGSR_WINO4=0 keeps every layer on F(2x2); TGSR_WINO4_MIN_WG=<n> moves the threshold (diagnostics: n = 32 gives the batch-2
     golden case the routing of batch 16, tools/diag_precision.py)."""
     if os.environ.get("TGSR_WINO4", "1") == "0":
         return False
     if not (cout % 64 == 0 and cin % 4 == 0 and W % 64 == 0 and H % 8 == 0 and H * W >= WINO4_MIN_PIXELS):
         return False
-    return B * (H // 8) * (W // 64) * (cout // 64) >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
+    if H * W < UPWINO4_MIN_OUT_PIXELS and cout % 128 != 0:
+        return False
+    if cin % 8 == 0:
+        nwg = B * (H // 4) * (W // 64) * (cout // (128 if cout % 128 == 0 else 64))
+    else:
+        nwg = B * (H // 8) * (W // 64) * (cout // 64)
+    return nwg >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
 
 
 def pack_wino4_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
