@@ -182,7 +182,7 @@ def cpu_baseline(weights, batch, budget_s=20.0, x16_pipe=None):
 CONV_GFLOP_PER_IMAGE = 20.5     # direct-form FLOPs of the 36 conv3x3 launches of one forward
 
 
-def cpu_baseline_train(weights, batch, budget_s=25.0):
+def cpu_baseline_train(weights, batch, budget_s=12.0):
     """Generator train step on the CPU: the oracle's forward in train-mode BatchNorm + MSE + KL through torch autograd
     (what the reference would run: plain PyTorch ops), bounded sample of `batch` images."""
     from oracle import tgsr_oracle as O
@@ -206,14 +206,14 @@ def cpu_baseline_train(weights, batch, budget_s=25.0):
 
     one()
     ts, t_all = [], time.perf_counter()
-    while len(ts) < 3 and (time.perf_counter() - t_all) < budget_s:
+    while len(ts) < 3 and (not ts or (time.perf_counter() - t_all) < budget_s):
         t0 = time.perf_counter()
         one()
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
     return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle generators in train-mode BN, MSE + KL, torch autograd backward (fp32), batch %d, warm-up 1 + "
-                      "median of %d runs, %.2f s/step" % (batch, len(ts), med)}
+            "sample": "oracle generators in train-mode BN, MSE + KL, torch autograd backward (fp32), batch %d (the configuration's "
+                      "own), warm-up 1 + median of %d run(s) within %.0f s, %.2f s/step" % (batch, len(ts), budget_s, med)}
 
 
 def bench_damsm(args, rank, world, dist, dev):
@@ -394,6 +394,40 @@ def _max_over_ranks(dt, dist, dev):
     return float(t.item())
 
 
+def time_regions(run_k_steps, fence, reps, dist, dev):
+    """`reps` timed regions of exactly K steps each (run_k_steps(r) issues the K steps of region r), every one bracketed by
+    barrier + synchronize on both sides; per region the MAX over ranks; returns (median, all of them).  One K-step region of the
+    inference path is 10-30 ms - run-to-run +-4 % on one such region hid real changes - so the reported time per K
+    steps is the median over enough regions for >= 0.5 s of device time."""
+    ts = []
+    for r in range(reps):
+        fence()
+        t0 = time.perf_counter()
+        run_k_steps(r)
+        fence()
+        ts.append(time.perf_counter() - t0)
+    if dist is not None:
+        t = torch.tensor(ts, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ts = [float(x) for x in t.tolist()]
+    return float(np.median(ts)), ts
+
+
+def reps_for(est_region_s, args, lo=1, hi=40):
+    """Number of K-step regions for >= args.min_time seconds of timed device work (the same on every rank: from rank 0's estimate)."""
+    if args.repeats > 0:
+        return args.repeats
+    return int(max(lo, min(hi, np.ceil(args.min_time / max(est_region_s, 1e-6)))))
+
+
+def _bcast_int(n, dist, dev):
+    if dist is None:
+        return n
+    t = torch.tensor([n], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.broadcast(t, 0)
+    return int(t.item())
+
+
 def _psnr(a, b, peak=2.0):
     """10 log10(peak^2 / mse) of two device tensors (peak = the [-1, 1] image range, as oracle.tgsr_oracle_lp.psnr)."""
     mse = float(((a.double() - b.double()) ** 2).mean())
@@ -455,9 +489,15 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
         fence()
         t0 = time.perf_counter()
         for k in range(args.steps):
-            replay_on(pipe, pool, k)             # a different batch (captions, lengths, images) every step
+            replay_on(pipe, pool, k)
         fence()
-        dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
+        reps = _bcast_int(reps_for(time.perf_counter() - t0, args), dist, dev)
+
+        def region(r, pipe=pipe, pool=pool):
+            for k in range(args.steps):
+                replay_on(pipe, pool, r * args.steps + k)   # a different batch (captions, lengths, images) every step
+        dt, _ts = time_regions(region, fence, reps, dist, dev)
+        entry["repeats"] = reps
         ips = world * B * args.steps / dt
         mb_img = 173.9 / 2
         entry.update({"value": round(ips, 2), "unit": "images/s", "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -476,12 +516,10 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
                 entry["graph_lanes4"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 ok4 = False
             if _all_ok(ok4, dist, dev):
-                fence()
-                t0 = time.perf_counter()
-                for k in range(args.steps // 4):
-                    replay_on(multi, pool, k, 4)  # four different batches per replay, other ones every replay
-                fence()
-                dt4 = _max_over_ranks(time.perf_counter() - t0, dist, dev)
+                def region4(r, multi=multi, pool=pool):
+                    for k in range(args.steps // 4):
+                        replay_on(multi, pool, r * (args.steps // 4) + k, 4)  # four different batches per replay, other ones every replay
+                dt4, _ts = time_regions(region4, fence, reps, dist, dev)
                 ips4 = world * B * args.steps / dt4
                 entry["graph_lanes4"] = {"value": round(ips4, 2), "ms_per_step": round(dt4 / args.steps * 1e3, 4),
                                          "hbm_frac": round(ips4 / world * mb_img * 1e6 / (PEAK_HBM_GBS * 1e9), 4)}
@@ -537,7 +575,7 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
     return out
 
 
-def cpu_baseline_gan(weights, batch, budget_s=30.0):
+def cpu_baseline_gan(weights, batch, budget_s=20.0):
     """One G/D alternation on the CPU (oracle generators + the oracle's torch restatement of the build-declared
     discriminators, DF_DIM 64, torch autograd): the three discriminator losses backward, then the generator loss
     (adversarial + MSE + KL) backward - the arithmetic of SRTrainer.step_gan without the optimizer steps."""
@@ -575,8 +613,8 @@ def cpu_baseline_gan(weights, batch, budget_s=30.0):
     return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle generators (train-mode BN) + the torch restatement of D_NET64/128/256 (DF_DIM 64): three "
                       "discriminator_loss backward passes, then generator_loss + MSE + KL backward, torch autograd (fp32), "
-                      "batch %d, median of %d runs, %.2f s/step (no warm-up run: the first step is in the sample)"
-                      % (batch, len(ts), med)}
+                      "batch %d (the configuration's own), median of %d run(s) within %.0f s, %.2f s/step (no warm-up run: the first "
+                      "step is in the sample)" % (batch, len(ts), budget_s, med)}
 
 
 def train_object(args, rank, world, dist, dev, weights, fence):
@@ -629,13 +667,18 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
         return entry
     fence()
     t0 = time.perf_counter()
-    loss = float("nan")
-    for _ in range(steps):
-        loss = tr.step(cap, lens, LR, LRb, hr)
+    tr.step(cap, lens, LR, LRb, hr)
     fence()
-    dt = _max_over_ranks(time.perf_counter() - t0, dist, dev)
+    reps = _bcast_int(reps_for((time.perf_counter() - t0) * steps, args, hi=10), dist, dev)
+    loss = [float("nan")]
+
+    def region(r):
+        for _ in range(steps):
+            loss[0] = tr.step(cap, lens, LR, LRb, hr)
+    dt, _ts = time_regions(region, fence, reps, dist, dev)
+    loss = loss[0]
     sec = dt / max(1, steps)
-    entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4),
+    entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4), "repeats": reps,
                   "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
     # one more step with HIP events around every convolution launch (single stream).  EVERY rank takes it - the step
     # all-reduces the gradient bucket, a collective rank 0 alone would leave unmatched; only rank 0 records and reports.
@@ -684,7 +727,7 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
                         "WHOLE step time (BatchNorm passes, losses, optimizer, EMA included); `conv_kernels_only`: the "
                         "same MACs over the summed durations of those launches (HIP events, one single-stream step)"}
             if world == 1 and not args.no_cpu_baseline:
-                entry["cpu_baseline"] = (cpu_baseline_gan(weights, 2) if gan else cpu_baseline_train(weights, min(B, 4)))
+                entry["cpu_baseline"] = (cpu_baseline_gan(weights, B) if gan else cpu_baseline_train(weights, B))
         except Exception as e:      # noqa: BLE001
             entry["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
@@ -732,6 +775,9 @@ def main():
                     help="cfg.TREE.BRANCH_NUM: 4 = the x8 generators of model.py (BASELINE configs, the default); anything "
                          "else = the x16 generators of models16.py (trainer_objective.py:74-87: 32 -> 512, weight-tied stages, "
                          "a fourth attention at 256^2 = 65 536 pixels), seeded random-init weights (no x16 checkpoint ships)")
+    ap.add_argument("--min-time", type=float, default=0.5,
+                    help="every timed figure is the median over enough fenced K-step regions for this many seconds of timed work")
+    ap.add_argument("--repeats", type=int, default=0, help="number of fenced K-step regions per figure (0 = from --min-time)")
     ap.add_argument("--profile-every", type=int, default=20,
                     help="bracket every launch of every Nth timed step with HIP events for the roofline (0 = never); "
                          "two events per launch cost ~9 %% of a step, so the timed region samples instead of paying "
@@ -841,50 +887,48 @@ def main():
             step()
     if args.graph and args.profile_every > 0:
         step(eager=True)                    # untimed: the event-sampled steps run eagerly and own a buffer set too
-    prof, nprof = [], 0
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps // glanes):
-        if multi is not None:               # one replay = `glanes` steps on `glanes` different batches, other ones every
-            replay_on(multi, pool, k, glanes)   # replay; the per-launch sampling happens in the one-lane pass below (a
-            continue                        # replay of several lanes has no single step to sample)
-        # sampled steps are counted from the END of the run: the last step drains the lanes anyway
-        sample = args.profile_every > 0 and (args.steps - 1 - k) % args.profile_every == 0
-        ops.profile = prof if sample else None
-        pipe.overlap = (not args.serial) and not sample    # a launch is timed alone: sampled steps are single-stream
-        nprof += 1 if sample else 0
-        if sample or not lanes:
-            if lanes:
-                torch.cuda.synchronize()
-            step(eager=sample)                              # per-launch events need individual launches
-            if lanes:
-                torch.cuda.synchronize()
-        else:
-            with torch.cuda.stream(lanes[k % nlanes]):
+    prof, nprof = [], [0]
+    K = args.steps
+
+    # ---- the strict figure (BASELINE's metric: batch B per GPU, ONE step in flight): K steps issued one at a time, replayed
+    # from the one-lane hipGraph (or eager / serial as selected).  The event-sampled steps (every launch bracketed by HIP
+    # events on its stream, eager and single-stream so that a launch is timed alone) sit inside the LAST timed region only;
+    # the reported time is the median over the regions.
+    def region_one(r, last):
+        for k in range(K):
+            sample = last and args.profile_every > 0 and (K - 1 - k) % args.profile_every == 0
+            if sample:
+                ops.profile, pipe.overlap = prof, False
+                nprof[0] += 1
+                step(eager=True)
+                ops.profile, pipe.overlap = None, not args.serial
+            else:
                 step()
-    ops.profile = None
-    fence()
-    dt = time.perf_counter() - t0
-    # the same K steps one at a time (one lane = the "batch 16" latency figure), measured in this run, outside the
-    # timed region above: no sampling, two streams, eager or graph as selected
     pipe.overlap = not args.serial
     fence()
-    t1 = time.perf_counter()
-    for k in range(args.steps):
-        sample = multi is not None and args.profile_every > 0 and (args.steps - 1 - k) % args.profile_every == 0
-        if sample:
-            ops.profile, pipe.overlap = prof, False
-            nprof += 1
-            step(eager=True)
-            ops.profile, pipe.overlap = None, not args.serial
-        else:
-            step()
+    t0 = time.perf_counter()
+    region_one(0, False)
     fence()
-    dt1 = time.perf_counter() - t1
-    if dist is not None:
-        t = torch.tensor([dt, dt1], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, dt1 = float(t[0].item()), float(t[1].item())
+    reps = _bcast_int(reps_for(time.perf_counter() - t0, args), dist, dev)
+    dt1, ts1 = time_regions(lambda r: region_one(r, r == reps - 1), fence, reps, dist, dev)
+
+    # ---- the throughput form: several independent batches in flight (parallel branches of one hipGraph, or eager stream lanes)
+    dtm = None
+    if multi is not None:
+        def region_multi(r):
+            for k in range(K // glanes):    # one replay = `glanes` steps on `glanes` different batches, other ones every replay
+                replay_on(multi, pool, r * (K // glanes) + k, glanes)
+        dtm, _tsm = time_regions(region_multi, fence, reps, dist, dev)
+    elif lanes:
+        def region_lanes(r):
+            for k in range(K):
+                with torch.cuda.stream(lanes[k % nlanes]):
+                    step()
+        dtm, _tsm = time_regions(region_lanes, fence, reps, dist, dev)
+    ops.profile = None
+    nprof = nprof[0]
+    dt = dt1
+    form_multi = multi is not None
 
     extras = {}
     want = [e for e in args.extras.replace("none", "").split(",") if e]
@@ -935,13 +979,21 @@ def main():
             finally:
                 pipe._lp.fuse_attention, pipe.overlap, ops.profile = True, not args.serial, None
         dname = {"fp32": "f32", "bf16": "bf16", "f16": "f16"}[args.dtype]
-        res = {"metric": "SR images/sec (32->%d, batch %d per GPU)" % (512 if x16 else 256, B),
-               "value": round(world * B * args.steps / dt, 2),
-               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        tform = None
+        if dtm is not None:
+            tform = {"value": round(world * B * K / dtm, 2), "ms_per_step": round(dtm / K * 1e3, 4),
+                     "form": ("%d independent batches of %d as parallel branches of ONE hipGraph (%d images in flight), %d replays "
+                              "per region" % (glanes, B, B * glanes, K // glanes)) if form_multi else
+                             "%d eager stream lanes (consecutive steps alternate between them)" % nlanes,
+                     "images_in_flight": B * (glanes if form_multi else nlanes)}
+        res = {"metric": "SR images/sec (32->%d, batch %d per GPU, one step in flight)" % (512 if x16 else 256, B),
+               "value": round(world * B * K / dt, 2),
+               "unit": "images/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+               "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": dname, "data": "synthetic inputs (%d batches, seeds 100 + 1000 i); " % len(pool) + wdesc,
-               "value_one_lane": round(world * B * args.steps / dt1, 2),
-               "ms_per_step_one_lane": round(dt1 / args.steps * 1e3, 4),
+               "value_one_lane": round(world * B * K / dt1, 2),
+               "ms_per_step_one_lane": round(dt1 / K * 1e3, 4),
+               **({"value_throughput_form": tform["value"]} if tform else {}),
                "config": {"workload": ("CelebA face x16 (32->512, models16.py: TREE.BRANCH_NUM=%d) batch=%d per GPU, text-enc + "
                                        "G_SR_NET_low + NetG_highweight forward, eval BN (the reference's default branch, "
                                        "config.py:28; not a BASELINE config)" % (args.branch_num, B)) if x16 else
@@ -950,23 +1002,24 @@ def main():
                                       (B, 1 if args.dtype == "fp32" else 4),
                           "batch_per_gpu": B, "lr": 32, "sr": 512 if x16 else 256, "n_words": 41, "parallelism": "dp%d" % world,
                           "streams": 1 if args.serial else 2, "launch": "hipgraph" if args.graph else "eager",
-                          "lanes": nlanes, **({"graph_lanes": glanes} if glanes > 1 else {}), "storage": "fp32 NCHW" if args.dtype == "fp32" else
+                          "storage": "fp32 NCHW" if args.dtype == "fp32" else
                           "%s channels-last (zero-bordered), fp32 accumulate; inputs / outputs fp32" % args.dtype,
                           "sampled_steps": nprof,
+                          "timing": "median of %d fenced regions of exactly K = %d steps (barrier + synchronize on both sides of "
+                                    "each, max over ranks per region; >= %.1f s of timed work in all); regions, s: %s"
+                                    % (reps, K, args.min_time, [round(t, 5) for t in ts1]),
+                          "repeats": reps,
                           "batches": "%d different resident synthetic batches (captions, caption lengths, images) cycled "
                                      "through the steps: every timed step - every lane of a hipGraph replay - runs on another "
                                      "batch than the one before; a replay copies it into the graph's static inputs inside the "
                                      "timed loop (one copy launch); the captured step is independent of the caption lengths"
                                      % len(pool),
-                          **({"images_in_flight": B * glanes} if glanes > 1 else {}),
-                          "note": ("`value`: %d replays of ONE hipGraph holding %d independent batches of %d as parallel "
-                                   "branches (%d images in flight), no sampling inside; `value_one_lane`: the same K steps "
-                                   "issued one at a time (the strict batch-%d figure), measured right after, incl. the %d "
-                                   "event-sampled single-stream step(s)" % (args.steps // glanes, glanes, B, B * glanes, B, nprof))
-                                  if glanes > 1 else
-                                  ("`value` covers all %d steps incl. the %d event-sampled single-stream one(s) (~1 %% of "
-                                   "the mean at the default K); `value_one_lane` = the same K steps issued one at a time, "
-                                   "measured right after" % (args.steps, nprof))},
+                          **({"throughput_form": tform} if tform else {}),
+                          "note": ("`value` = the strict figure of BASELINE's metric: K steps of batch %d issued ONE AT A TIME "
+                                   "(%s), %d event-sampled eager single-stream step(s) inside the last region.  "
+                                   "`throughput_form` (not the headline): the same K steps with several independent batches in "
+                                   "flight, measured right after with the same fencing"
+                                   % (B, "replays of the one-lane hipGraph" if args.graph else "eager launches", nprof))},
                "roofline": roof, "kernels": kern}
         # the whole step against SURVEY.md 8(d)'s compulsory conv-path bytes (173.9 MB per image at the reference's layer
         # boundaries in fp32, half of that with 2-byte storage) and 21.07 GFLOP per image: the "fraction of the HBM

@@ -44,6 +44,26 @@ def make_pipeline(tr, device="cuda:0"):
     return pipe
 
 
+def damsm_case(B=4):
+    from oracle import tgsr_oracle as O
+    cap, lens, _LR, _LRb = O.synthetic_batch(B, seed=21)
+    g = torch.Generator().manual_seed(5)
+    return {"cap": cap, "lens": lens, "feats": torch.randn(B, 768, 17, 17, generator=g), "pooled": torch.randn(B, 2048, generator=g),
+            "class_ids": [0, 1, 0, 2][:B]}
+
+
+def make_damsm_trainer(device="cuda:0"):
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.train import DAMSMTrainer
+    cfg_reset()
+    cfg.TEXT.EMBEDDING_DIM = 64
+    cfg.TRAIN.FLAG = True
+    torch.manual_seed(4321)
+    tr = DAMSMTrainer(41, device=device, gather_negatives=True)
+    tr.text_encoder.drop.p = 0.0 if hasattr(tr.text_encoder, "drop") else 0.0          # no dropout noise in the comparison
+    return tr
+
+
 def shard_grads(tr, batch, lo, hi):
     cap, lens, LR, LRb, hr = batch
     dev = tr.device
@@ -79,6 +99,19 @@ def main():
     o = pipe(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev))
     torch.cuda.synchronize()
     res = {"flat": tr.bucket.flat.cpu(), "loss": float(loss), "fine": o["fine"][2].cpu(), "lo": lo, "hi": hi}
+    # ---- one optimisation step of the trainer itself (tr.step: the early all-reduce of NetG_highweight's range under the
+    # tail of backward + the closing one): every rank must leave it with the same parameters and running statistics
+    tr.step(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev), [h[lo:hi].to(dev) for h in hr])
+    torch.cuda.synchronize()
+    res["step_flat"] = tr.bucket.flat_all.cpu()
+    res["step_params"] = torch.cat([p.detach().flatten() for p in tr.params]).cpu()
+    # ---- DAMSM pre-training step with the contrastive losses of the GLOBAL batch (gathered features / embeddings)
+    d = damsm_case()
+    dt = make_damsm_trainer(dev)
+    dl = dt.step_features(d["feats"][lo:hi].to(dev), d["pooled"][lo:hi].to(dev), d["cap"][lo:hi].to(dev), d["lens"][lo:hi].tolist(),
+                          d["class_ids"][lo:hi])
+    torch.cuda.synchronize()
+    res["damsm_loss"], res["damsm_flat"] = float(dl), dt.bucket.flat.cpu()
     if backend == "nccl":
         # the G/D alternation's collectives: each discriminator's bucket is all-reduced on that discriminator's own
         # stream (train.py step_gan), then the generators' bucket on the main one - four RCCL all-reduces per step

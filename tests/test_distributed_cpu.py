@@ -89,6 +89,84 @@ def test_two_rank_sharding_and_gradient_bucket():
     assert e0 < 1e-6 and e1 < 1e-6 and n0 == n1 == 6 * 5 + 5 + 5 * 3 + 3
 
 
+def _damsm_worker(rank, world, port, q):
+    """DAMSM under data parallelism: the product's gather (parallel.gather_damsm_batch, the `x world` rule)
+    with the ORACLE's words_loss / sent_loss as the function evaluated on the gathered batch (CPU; the HIP loss kernels have no
+    CPU form - tests/test_hip_dp.py runs DAMSMTrainer through them on the GPU)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import tgsr_oracle as O
+    from tgsr_amd import parallel
+    parallel.init_distributed("gloo")
+    torch.manual_seed(3)
+    Bg, nef, T = 5, 8, 6                                   # uneven shards: 3 + 2 rows
+    feat_in, pooled_in = torch.randn(Bg, 6, 3, 3), torch.randn(Bg, 7)
+    words_in = torch.randn(Bg, 5, T)
+    lens = torch.tensor([6, 5, 4, 4, 2])                   # globally sorted, descending
+    class_ids = [3, 1, 3, 2, 0]
+
+    def nets():
+        torch.manual_seed(11)
+        return (torch.nn.Conv2d(6, nef, 1), torch.nn.Linear(7, nef), torch.nn.Conv1d(5, nef, 1))
+
+    def loss_of(regions, code, words, sent, ls, ids, B):
+        labels = torch.arange(B)
+        w0, w1, _ = O.words_loss(regions, words, labels, ls, ids, B, 4.0, 5.0, 10.0)
+        s0, s1 = O.sent_loss(code, sent, labels, ids, B, 10.0)
+        return w0 + w1 + s0 + s1
+
+    # single process, concatenated batch
+    ca, cb, cc = nets()
+    words = cc(words_in)
+    ref = loss_of(ca(feat_in), cb(pooled_in), words, words.mean(2), lens.tolist(), class_ids, Bg)
+    ref.backward()
+    ref_grads = [p.grad.clone() for m in (ca, cb, cc) for p in m.parameters()]
+    # two ranks: each encodes its shard (its words only up to the shard's longest caption), gathers, evaluates the global loss
+    da, db, dc = nets()
+    params = [p for m in (da, db, dc) for p in m.parameters()]
+    bucket = parallel.FlatGradBucket(params).attach()
+    lo, hi = parallel.shard_bounds(Bg, rank, world)
+    tmax = int(lens[lo:hi].max())
+    w_loc = dc(words_in[lo:hi, :, :tmax])
+    sent_loc = dc(words_in[lo:hi]).mean(2)
+    g = parallel.gather_damsm_batch(da(feat_in[lo:hi]), db(pooled_in[lo:hi]), w_loc, sent_loc, lens[lo:hi].tolist(),
+                                    class_ids[lo:hi], T)
+    regions, code, gw, gs, glens, gids, B, scale = g
+    assert B == Bg and scale == world and glens == lens.tolist() and list(gids) == class_ids and gw.shape[2] == T
+    loss = loss_of(regions, code, gw, gs, glens, list(gids), B)
+    (loss * scale).backward()
+    bucket.all_reduce_mean()
+    gerr = max(float((p.grad - r_).abs().max()) for p, r_ in zip(params, ref_grads))
+    # a range of the bucket sent early, the rest later (what SRTrainer does under the tail of backward)
+    b2 = parallel.FlatGradBucket(params).attach()
+    b2.flat.copy_(torch.arange(b2.numel, dtype=torch.float32) * (rank + 1))
+    h = b2.all_reduce_range_async(0, 10)
+    h.wait()
+    b2.all_reduce_mean(skip=(0, 10))
+    want = torch.arange(b2.numel, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+    rerr = float((b2.flat - want).abs().max())
+    q.put((rank, abs(float(loss) - float(ref)), gerr, rerr))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_damsm_gather_equals_single_process_loss():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_damsm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, lerr, gerr, rerr in res:
+        assert lerr < 1e-5, "gathered loss differs from the single-process loss on the concatenated batch: %g" % lerr
+        assert gerr < 1e-5, "all-reduced gradient differs from the single-process gradient: %g" % gerr
+        assert rerr < 1e-6
+
+
 def test_shard_bounds_partition():
     from tgsr_amd.parallel import shard_bounds
     for n in (1, 7, 16, 33):

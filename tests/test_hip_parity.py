@@ -343,7 +343,7 @@ def test_winograd4_training_forms():
 
 def test_wino4_routing_follows_the_size_policy(monkeypatch):
     """util._conv_bn sends the large layers (>= 64 x 64 pixels, a full round of workgroups) to F(4x4) and everything else to
-    F(2x2) / the direct kernel; TGSR_WINO4=0 keeps F(2x2) everywhere."""
+    F(2x2) / the direct kernel; ops.ROUTING.wino4 = False (TGSR_WINO4=0 at import) keeps F(2x2) everywhere."""
     from tgsr_amd import util, custom_ops as C
     calls = []
     real4, real2 = C.conv3x3_wino4w, C.conv3x3_wino
@@ -357,7 +357,8 @@ def test_wino4_routing_follows_the_size_policy(monkeypatch):
     util._conv_bn(small, fp, conv, bn, glu=True)
     util._conv_bn(few, fp, conv, bn, glu=True)
     assert calls == [4, 2, 2]
-    monkeypatch.setenv("TGSR_WINO4", "0")
+    from tgsr_amd import ops
+    monkeypatch.setattr(ops.ROUTING, "wino4", False)          # what TGSR_WINO4=0 sets at import
     y2 = util._conv_bn(big, fp, conv, bn, glu=True)
     assert calls == [4, 2, 2, 2]
     assert float((y4 - y2).abs().max()) < 1e-4

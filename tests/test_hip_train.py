@@ -32,6 +32,8 @@ CASES = [
     (1, 64, 5, 40, 64, False, False, True),      # ... several chunks per tile row
     (3, 32, 11, 24, 32, False, False, True),     # Winograd-domain wgrad of a 32 -> 32 layer (NetG_highweight's ResBlocks), ragged
     (2, 64, 8, 40, 32, False, False, False),     # ... 64 -> 32: two ci blocks, one co block
+    (2, 32, 12, 20, 32, True, True, False),      # upBlock(32, 16) / GF_DIM = 16: Cout = 32 has no up-sample-aware wgrad -> direct
+    (2, 32, 8, 16, 96, True, True, False),       # ... Cout % 64 == 32 likewise
 ]
 
 

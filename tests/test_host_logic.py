@@ -194,8 +194,7 @@ def test_wino4_size_policy(monkeypatch):
     tgsr_winograd4.hip (>= 128 x 128 pixels, at 64 x 64 only 128-channel groups, nothing below); at least 256 workgroups of the
     form the layer takes; TGSR_WINO4=0 switches it off."""
     from tgsr_amd import ops
-    monkeypatch.delenv("TGSR_WINO4", raising=False)
-    monkeypatch.delenv("TGSR_WINO4_MIN_WG", raising=False)
+    monkeypatch.setattr(ops, "ROUTING", ops._Routing(env={}))
     assert ops.wino4_wanted(64, 128, 128, 128, 16) and ops.wino4_wanted(64, 64, 128, 128, 16) and ops.wino4_wanted(64, 64, 256, 256, 2)
     assert ops.wino4_wanted(64, 128, 64, 64, 16) and not ops.wino4_wanted(64, 64, 64, 64, 16)    # 64 x 64: 128-channel groups only
     assert not ops.wino4_wanted(64, 64, 64, 64, 64)                                              # ... whatever the batch
@@ -205,7 +204,9 @@ def test_wino4_size_policy(monkeypatch):
     assert not ops.wino4_wanted(64, 128, 32, 32, 64) and not ops.wino4_wanted(128, 256, 32, 64, 64)   # below 64 x 64
     assert not ops.wino4_wanted(64, 32, 128, 128, 16) and not ops.wino4_wanted(3, 64, 128, 128, 16)   # channel groups / stages
     assert not ops.wino4_wanted(64, 64, 128, 160, 16) and not ops.wino4_wanted(64, 64, 132, 128, 16)  # whole tiles
-    monkeypatch.setenv("TGSR_WINO4", "0")
+    monkeypatch.setattr(ops.ROUTING, "pin_batch", 16)         # TGSR_WINO4_PIN_BATCH: the routing of batch 16 at every batch size
+    assert ops.wino4_wanted(64, 64, 128, 128, 2) and ops.wino4_wanted(64, 128, 64, 64, 1)
+    monkeypatch.setattr(ops, "ROUTING", ops._Routing(env={"TGSR_WINO4": "0"}))
     assert not ops.wino4_wanted(64, 128, 128, 128, 16)
 
 
@@ -213,11 +214,25 @@ def test_upwino4_size_policy(monkeypatch):
     """The upBlocks that go to the F(4x4) form of the up-sample-aware kernel: by OUTPUT size (>= 64 x 64, whole 4 x 64 tiles),
     an even stage count and workgroup count; arguments are the low-resolution input's."""
     from tgsr_amd import ops
-    monkeypatch.delenv("TGSR_WINO4", raising=False)
-    assert ops.upwino4_wanted(64, 64, 128, 128, 16) and ops.upwino4_wanted(64, 64, 64, 64, 16) and ops.upwino4_wanted(32, 64, 128, 128, 2)
-    assert not ops.upwino4_wanted(64, 64, 32, 32, 16) and not ops.upwino4_wanted(64, 64, 32, 32, 64)   # output 64 x 64: below the floor
-    assert ops.upwino4_wanted(64, 64, 64, 64, 4) and not ops.upwino4_wanted(32, 64, 64, 32, 4)         # 256 vs 128 workgroups
+    monkeypatch.setattr(ops, "ROUTING", ops._Routing(env={}))
+    assert ops.upwino4_wanted(64, 64, 128, 128, 16) and ops.upwino4_wanted(32, 64, 128, 128, 2) and ops.upwino4_wanted(64, 64, 256, 256, 1)
+    assert not ops.upwino4_wanted(64, 64, 64, 64, 16) and not ops.upwino4_wanted(64, 64, 32, 32, 64)   # output below 256 x 256: mid-network
+    assert ops.upwino4_wanted(64, 64, 128, 128, 1)             # a 256 x 256 output gives 256 workgroups per image
     assert not ops.upwino4_wanted(12, 64, 128, 128, 16)        # three stages: the register-fed form takes an even number
-    assert not ops.upwino4_wanted(64, 32, 128, 128, 16) and not ops.upwino4_wanted(64, 64, 65, 64, 16) and not ops.upwino4_wanted(64, 64, 64, 48, 16)
-    monkeypatch.setenv("TGSR_WINO4", "0")
+    assert not ops.upwino4_wanted(64, 32, 128, 128, 16) and not ops.upwino4_wanted(64, 64, 129, 128, 16) and not ops.upwino4_wanted(64, 64, 128, 144, 16)
+    monkeypatch.setattr(ops.ROUTING, "wino4", False)
     assert not ops.upwino4_wanted(64, 64, 128, 128, 16)
+
+
+def test_wgrad_kind_only_names_kernels_that_take_the_shape():
+    """ops.conv3x3_wgrad_kind: the up-sample-aware Winograd-domain weight gradient has 64-row co-blocks only (round 4's relaxation
+    to Cout % 32 would have sent upBlock(32, 16) to a kernel that refuses it - and its host planner into a divide by zero)."""
+    from tgsr_amd import ops
+    assert ops.conv3x3_wgrad_kind(64, 64, True) == "upwino" and ops.conv3x3_wgrad_kind(32, 128, True) == "upwino"
+    assert ops.conv3x3_wgrad_kind(32, 32, True) == "direct" and ops.conv3x3_wgrad_kind(32, 96, True) == "direct"
+    assert ops.conv3x3_wgrad_kind(32, 32, False) == "wino" and ops.conv3x3_wgrad_kind(64, 96, False) == "wino"
+    assert ops.conv3x3_wgrad_kind(3, 64, False) == "direct" and ops.conv3x3_wgrad_kind(64, 64, True, winograd=False) == "direct"
+    from tgsr_amd import _lib
+    L = _lib.lib()
+    assert L.tgsr_upwino_wgrad_ws_elems(2, 32, 32, 8, 8) == 0 and L.tgsr_upwino_wgrad_ws_elems(2, 32, 96, 8, 8) == 0
+    assert L.tgsr_upwino_wgrad_ws_elems(2, 32, 64, 8, 8) > 0

@@ -247,6 +247,7 @@ static void upwgrad_plan(int B, int Cin, int Cout, int H, int W, int* nci, int* 
 }
 
 extern "C" int64_t tgsr_upwino_wgrad_ws_elems(int B, int Cin, int Cout, int H, int W) {
+  if (B < 1 || H < 1 || W < 1 || Cout < 64 || Cout % 64 != 0 || Cin < 32 || Cin % 32 != 0) return 0;   // shapes tgsr_upwino_wgrad refuses
   int nci, groups, gi, nslots, cpw, nchunks;
   upwgrad_plan(B, Cin, Cout, H, W, &nci, &groups, &gi, &nslots, &cpw, &nchunks);
   return (int64_t)nslots * 9 * Cout * Cin;

@@ -93,41 +93,67 @@ __host__ __device__ constexpr int w4_pos(int i, int j) {   // accumulator index 
 
 typedef float f32x4w4 __attribute__((ext_vector_type(4)));
 
-// one 1-D pass of the input transform restricted to a row pair: R = 0: rows 0, 5; 1: rows 1, 2; 2: rows 3, 4 of
-//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+// Interpolation points 0, +-kP, +-kR, inf.  Rounds 1-4 used Lavin's 0, +-1, +-2, inf; what dominates the error of
+// F(4x4) in fp32 is the accumulation over the input channels of products whose magnitude - at the positions of the outermost
+// points - is many times the output's (they cancel in A^T M A), and that ratio is a property of the points alone (row scalings
+// between G, B^T and A^T leave it unchanged).  +-5/8, +-3/2 brings a layer's error on unit-scale data from 3.3e-5 max / 1.0e-6 mean
+// to 0.9e-5 / 5.5e-7 (Cin 64; tools/exp_wino4_points.py) at the same instruction count: a symmetric pair keeps the even / odd
+// sharing (P +- c Q), every constant is a dyadic rational (exact in fp32), and U = G g G^T is computed in double by the packs.
+constexpr double k4P = 0.625, k4R = 1.5;
+constexpr float k4P2 = (float)(k4P * k4P), k4R2 = (float)(k4R * k4R), k4PR2 = (float)(k4P * k4P * k4R * k4R),
+                k4S2 = (float)(k4P * k4P + k4R * k4R), k4Pf = (float)k4P, k4Rf = (float)k4R,
+                k4P3 = (float)(k4P * k4P * k4P), k4R3 = (float)(k4R * k4R * k4R);
+static_assert((double)k4PR2 == k4P * k4P * k4R * k4R && (double)k4S2 == k4P * k4P + k4R * k4R && (double)k4P3 == k4P * k4P * k4P &&
+              (double)k4R3 == k4R * k4R * k4R, "the interpolation points must give transform constants that are exact in fp32");
+// B^T (rows: points 0, +P, -P, +R, -R, inf) = [PR2 0 -S2 0 1 0; 0 -P R2 -R2 P 1 0; 0 P R2 -R2 -P 1 0; 0 -R P2 -P2 R 1 0;
+//   0 R P2 -P2 -R 1 0; 0 PR2 0 -S2 0 1]   (PR2 = P^2 R^2, S2 = P^2 + R^2);   G row of point x: (1, x, x^2) / prod(x - other points),
+// G row 0 = (1 / PR2, 0, 0), G row inf = (0, 0, 1);   A^T = [1 1 1 1 1 0; 0 P -P R -R 0; 0 P2 P2 R2 R2 0; 0 P3 -P3 R3 -R3 1].
+__host__ __device__ inline void w4_G(double (&G)[6][3]) {
+  const double pt[4] = {k4P, -k4P, k4R, -k4R};
+  G[0][0] = 1.0 / (k4P * k4P * k4R * k4R); G[0][1] = 0.0; G[0][2] = 0.0;
+  for (int j = 0; j < 4; ++j) {
+    double n = pt[j];                                      // (x - 0)
+    for (int k = 0; k < 4; ++k)
+      if (k != j) n *= pt[j] - pt[k];
+    G[1 + j][0] = 1.0 / n; G[1 + j][1] = pt[j] / n; G[1 + j][2] = pt[j] * pt[j] / n;
+  }
+  G[5][0] = 0.0; G[5][1] = 0.0; G[5][2] = 1.0;
+}
+
+// one 1-D pass of the input transform restricted to a row pair: R = 0: rows 0, 5; 1: rows 1, 2; 2: rows 3, 4 of B^T
 template <int R>
 __device__ __forceinline__ void w4_bt_pair(float d0, float d1, float d2, float d3, float d4, float d5, float& oa, float& ob) {
   if (R == 0) {
-    oa = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
-    ob = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    oa = fmaf(k4PR2, d0, fmaf(-k4S2, d2, d4));
+    ob = fmaf(k4PR2, d1, fmaf(-k4S2, d3, d5));
   } else if (R == 1) {
-    const float p = fmaf(-4.f, d2, d4), q = fmaf(-4.f, d1, d3);
-    oa = p + q;
-    ob = p - q;
+    const float p = fmaf(-k4R2, d2, d4), q = fmaf(-k4R2, d1, d3);
+    oa = fmaf(k4Pf, q, p);
+    ob = fmaf(-k4Pf, q, p);
   } else {
-    const float p = d4 - d2, q = d3 - d1;
-    oa = fmaf(2.f, q, p);
-    ob = fmaf(-2.f, q, p);
+    const float p = fmaf(-k4P2, d2, d4), q = fmaf(-k4P2, d1, d3);
+    oa = fmaf(k4Rf, q, p);
+    ob = fmaf(-k4Rf, q, p);
   }
 }
 // a full 1-D pass (all six rows of B^T) of one 6-vector
 __device__ __forceinline__ void w4_bt_full(const float (&t)[6], float (&o)[6]) {
-  o[0] = fmaf(4.f, t[0], fmaf(-5.f, t[2], t[4]));
-  const float p1 = fmaf(-4.f, t[2], t[4]), q1 = fmaf(-4.f, t[1], t[3]);
-  o[1] = p1 + q1;
-  o[2] = p1 - q1;
-  const float p2 = t[4] - t[2], q2 = t[3] - t[1];
-  o[3] = fmaf(2.f, q2, p2);
-  o[4] = fmaf(-2.f, q2, p2);
-  o[5] = fmaf(4.f, t[1], fmaf(-5.f, t[3], t[5]));
+  o[0] = fmaf(k4PR2, t[0], fmaf(-k4S2, t[2], t[4]));
+  const float p1 = fmaf(-k4R2, t[2], t[4]), q1 = fmaf(-k4R2, t[1], t[3]);
+  o[1] = fmaf(k4Pf, q1, p1);
+  o[2] = fmaf(-k4Pf, q1, p1);
+  const float p2 = fmaf(-k4P2, t[2], t[4]), q2 = fmaf(-k4P2, t[1], t[3]);
+  o[3] = fmaf(k4Rf, q2, p2);
+  o[4] = fmaf(-k4Rf, q2, p2);
+  o[5] = fmaf(k4PR2, t[1], fmaf(-k4S2, t[3], t[5]));
 }
-// A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1] applied to one 6-vector
+// A^T applied to one 6-vector
 __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
   const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
   y[0] = m0 + s1 + s2;
-  y[1] = fmaf(2.f, d2, d1);
-  y[2] = fmaf(4.f, s2, s1);
-  y[3] = fmaf(8.f, d2, d1) + m5;
+  y[1] = fmaf(k4Rf, d2, k4Pf * d1);
+  y[2] = fmaf(k4R2, s2, k4P2 * s1);
+  y[3] = fmaf(k4R3, d2, fmaf(k4P3, d1, m5));
 }
 
 template <bool GLU, bool STATS = false>
@@ -710,8 +736,8 @@ __global__ __launch_bounds__(64 * NB, 2) void wino4w_conv3x3_kernel(Wino4Args a)
 // tr != 0: the source is the FORWARD conv's weight [Cin][Cout][3][3]; the pack is of the data-gradient conv (plain order)
 __global__ void pack_wino4w_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu, int nb,
                                           int tr, int64_t total) {
-  const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  double G[6][3];
+  w4_G(G);
   const int ngrp = Cout / (16 * nb);                       // nb = 8 | 4 blocks per group
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 3), m = (int)((idx >> 2) & 15), ci = (int)((idx >> 6) & 3);
@@ -742,8 +768,8 @@ __global__ void pack_wino4w_weight_kernel(const float* __restrict__ w, float* __
 // w'[co][c][r][k] = w[c][co][2 - r][2 - k] (plain channel order)
 __global__ void pack_wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int glu, int tr,
                                          int64_t total) {
-  const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                          {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+  double G[6][3];
+  w4_G(G);
   const int ngrp = Cout / 64;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(idx & 3), m = (int)((idx >> 2) & 15), cbk = (int)((idx >> 6) & 3), ci = (int)((idx >> 8) & 3);

@@ -169,8 +169,27 @@ class _LazyLog:
         return hash(str(self))
 
 
+def damsm_terms(regions, code, words_embs, sent_emb, cap_lens, class_ids, gather=False):
+    """(w_loss0, w_loss1, s_loss0, s_loss1, scale, att_maps) of one shard's images and captions.  gather=False: the shard's own
+    B x B matching matrices (what the single-process reference computes), scale 1.  gather=True under torch.distributed: the
+    matrices of the GLOBAL batch (parallel.gather_damsm_batch; the same four numbers on every rank = the single-process
+    losses of the concatenated batch) and scale = world - multiply the term by it before backward, the gradient bucket
+    averages over ranks what a replicated loss needs summed."""
+    scale = 1
+    if gather:
+        from .. import parallel
+        regions, code, words_embs, sent_emb, cap_lens, class_ids, B, scale = parallel.gather_damsm_batch(
+            regions, code, words_embs, sent_emb, cap_lens, class_ids, cfg.TEXT.WORDS_NUM)
+    else:
+        B = sent_emb.shape[0]
+    labels = torch.arange(B, device=sent_emb.device)
+    w0, w1, att = words_loss(regions, words_embs, labels, cap_lens, class_ids, B)
+    s0, s1 = sent_loss(code, sent_emb, labels, class_ids, B)
+    return w0, w1, s0, s1, scale, att
+
+
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
-                   class_ids, w=1, s=1, g=1, streams=None, lazy_log=False):
+                   class_ids, w=1, s=1, g=1, streams=None, lazy_log=False, gather_negatives=False):
     """losses.py:351-391: per-scale adversarial terms + the DAMSM words / sentence ranking loss on the last scale
     (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log) like the reference: `log` is the same str; with `lazy_log=True` (not a
     reference argument) a _LazyLog stands in for it - the same text, formatted (and the device synchronised) only when it
@@ -205,11 +224,15 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
         parts.append(("g_loss%d: %%.5f " % k, adv.detach()))
         if k == len(netsD) - 1 and image_encoder is not None:
             regions, code = image_encoder(img)
-            w0, w1, _ = words_loss(regions, words_embs, match_labels, cap_lens, class_ids, B)
-            s0, s1 = sent_loss(code, sent_emb, match_labels, class_ids, B)
+            if gather_negatives:        # (not a reference argument) data parallel: the ranking term of the global batch
+                w0, w1, s0, s1, scale, _ = damsm_terms(regions, code, words_embs, sent_emb, cap_lens, class_ids, gather=True)
+            else:
+                w0, w1, _ = words_loss(regions, words_embs, match_labels, cap_lens, class_ids, B)
+                s0, s1 = sent_loss(code, sent_emb, match_labels, class_ids, B)
+                scale = 1
             w_term = w * (w0 + w1) * cfg.TRAIN.SMOOTH.LAMBDA
             s_term = s * (s0 + s1) * cfg.TRAIN.SMOOTH.LAMBDA
-            total = total + w_term + s_term
+            total = total + (w_term + s_term) * scale
             parts.append(("w_loss: %.5f s_loss: %.5f ", w_term.detach(), s_term.detach()))
     log = _LazyLog(parts)
     return total, (log if lazy_log else str(log))

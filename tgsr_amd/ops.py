@@ -228,33 +228,67 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
 
 
 WINO4_MIN_PIXELS = 64 * 64        # per image; DESIGN.md 3.1e: the error study that keeps F(4x4) off the 32 x 32 layers
-UPWINO4_MIN_OUT_PIXELS = 128 * 128  # pixels per image from which every 64-channel-group layer / upBlock output may use F(4x4)
+WINO4_MIN_PIXELS_64 = 128 * 128   # pixels per image from which layers with 64-channel groups only may use F(4x4) too
+# The up-sample-aware F(4x4) form must keep +-1 among its interpolation points (its 25-of-36 structure depends on them,
+# tgsr_upwino4.hip), so it does not get the better-conditioned points of tgsr_winograd4.hip: its OWN error is 1.9-2.2x the CPU
+# fp32 op's on the same input (tests/test_hip_parity_margin.py).  It therefore serves only upBlocks whose output is
+# the generator's finest feature map (>= 256 x 256: nothing but an image head reads it); an upBlock in mid-network feeds the
+# 128^2 stages that amplify whatever error they are handed.
+UPWINO4_MIN_OUT_PIXELS = 256 * 256
 WINO4_MIN_WORKGROUPS = 256        # below a full round of its (large) workgroup tiles F(2x2)'s four times smaller ones win
+
+
+class _Routing:
+    """Which layers go to the F(4x4) kernels.  Read from the environment ONCE, at import (the eager host path asks per layer and
+    per forward); tests and tools/ change the attributes of `ops.ROUTING` instead.
+      TGSR_WINO4=0                every layer stays on F(2x2)
+      TGSR_WINO4_MIN_WG=<n>       the work rule's threshold (n = 32 gives the batch-2 golden case the routing of batch 16)
+      TGSR_WINO4_PIN_BATCH=<b>    decide the work rule as if the batch were b: the same kernels - bit-identical images per
+                                  sample - whatever the batch size (reproducibility knob; default: the real batch)
+    diagnostics (tools/diag_precision_classes.py): min_cin / min_pixels / upwino4_min_cin switch layer classes off."""
+
+    def __init__(self, env=os.environ):
+        self.wino4 = env.get("TGSR_WINO4", "1") != "0"
+        self.min_workgroups = int(env.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
+        self.pin_batch = int(env.get("TGSR_WINO4_PIN_BATCH", "0"))
+        self.min_cin = int(env.get("TGSR_WINO4_MIN_CIN", "0"))
+        self.min_pixels = int(env.get("TGSR_WINO4_MIN_PIXELS", "0"))
+        self.upwino4_min_cin = int(env.get("TGSR_UPWINO4_MIN_CIN", "0"))
+
+    def reset(self, env=os.environ):
+        self.__init__(env)
+        return self
+
+
+ROUTING = _Routing()
 
 
 def wino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
     """Does a conv3x3 layer go to the F(4x4, 3x3) kernels?  Three rules.
     Shape: Cout % 64, Cin % 4, W % 64, H % 8 (whole workgroup tiles).
-    Numerics (measured on the shipped checkpoint against fp64 and the fp32 oracle): layers of >= 128 x 128
-    pixels; at 64 x 64 .. 128 x 128 only the convolutions with 128-channel groups (the 64 -> 128 ones: with the 64 -> 64 ones of
-    that stage as well the finest image sits at 9.4e-5 instead of 8.6e-5 from the fp32 oracle at batch 16, stated 1e-4); nothing
-    below 64 x 64 (with the 32^2 layers: 2e-4).
+    Numerics (DESIGN.md 3.1e / 3.1g; tests/test_hip_parity.py::test_fp32_parity_margin_*): layers of >= 128 x 128
+    pixels; at 64 x 64 .. 128 x 128 only the convolutions with 128-channel groups; nothing below 64 x 64 (the early, small layers
+    are the ones whose error the rest of the network amplifies).
     Work: >= 256 workgroups of the form the layer takes - register-fed (Cin % 8 == 0): 4 x 64 pixels x 128 rows, or x 64 rows
     where Cout % 128 != 0; else the LDS-fed form, 8 x 64 x 64 (measured at batch 4 .. 32: each routed layer faster than on
     F(2x2), each unrouted one slower; the batch-2 golden case stays on F(2x2) except for the last upBlocks).
-    TGSR_WINO4=0 keeps every layer on F(2x2); TGSR_WINO4_MIN_WG=<n> moves the threshold (diagnostics: n = 32 gives the batch-2
-    golden case the routing of batch 16, tools/diag_precision.py)."""
-    if os.environ.get("TGSR_WINO4", "1") == "0":
+    `ROUTING` holds the switches (environment, read at import)."""
+    R = ROUTING
+    if not R.wino4:
         return False
     if not (cout % 64 == 0 and cin % 4 == 0 and W % 64 == 0 and H % 8 == 0 and H * W >= WINO4_MIN_PIXELS):
         return False
-    if H * W < UPWINO4_MIN_OUT_PIXELS and cout % 128 != 0:
+    if cin < R.min_cin or H * W < R.min_pixels:          # diagnostics
         return False
+    if H * W < WINO4_MIN_PIXELS_64 and cout % 128 != 0:
+        return False
+    if R.pin_batch:
+        B = R.pin_batch
     if cin % 8 == 0:
         nwg = B * (H // 4) * (W // 64) * (cout // (128 if cout % 128 == 0 else 64))
     else:
         nwg = B * (H // 8) * (W // 64) * (cout // 64)
-    return nwg >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
+    return nwg >= R.min_workgroups
 
 
 def pack_wino4_weight(w: torch.Tensor, glu: bool = False, dgrad: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -462,18 +496,19 @@ def upwino_glu(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift,
 def upwino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
     """Does an upBlock (low-resolution input H x W) go to the F(4x4) form of the up-sample-aware kernel?  Shape support
     (Cout % 64, Cin % 8: an even number of 4-channel stages, whole 4 x 64 OUTPUT tiles), a numerics floor on the OUTPUT
-    (>= 128 x 128 pixels: the first upBlocks, 32^2 -> 64^2, would be faster on it too - 14.2 vs 17.5 us - but with them the
-    finest image of the C1 case moved to 8.4e-5 from the reference's fp32 output, against a stated 1e-4: early layers' errors are
-    the ones the network amplifies) and at least 256 of its 4-wave workgroups.  TGSR_WINO4=0 keeps the
-    F(2x2) form."""
-    if os.environ.get("TGSR_WINO4", "1") == "0":
+    (>= 256 x 256 pixels: the generator's last upBlock, read by an image head only - see UPWINO4_MIN_OUT_PIXELS) and at least 256
+    of its 4-wave workgroups.  `ROUTING.wino4 = False` (TGSR_WINO4=0) keeps the F(2x2) form."""
+    R = ROUTING
+    if not R.wino4:
         return False
     Ho, Wo = 2 * H, 2 * W
-    if cin < int(os.environ.get("TGSR_UPWINO4_MIN_CIN", "0")):          # diagnostics: which upBlocks cost what (DESIGN 3.1f)
+    if cin < R.upwino4_min_cin:                            # diagnostics: which upBlocks cost what (DESIGN 3.1f)
         return False
     if not (cout % 64 == 0 and cin % 8 == 0 and Wo % 64 == 0 and Ho % 4 == 0 and Ho * Wo >= UPWINO4_MIN_OUT_PIXELS):
         return False
-    return B * (Ho // 4) * (Wo // 64) * (cout // 64) >= int(os.environ.get("TGSR_WINO4_MIN_WG", WINO4_MIN_WORKGROUPS))
+    if R.pin_batch:
+        B = R.pin_batch
+    return B * (Ho // 4) * (Wo // 64) * (cout // 64) >= R.min_workgroups
 
 
 def pack_upwino4_weight(w: torch.Tensor, glu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -940,10 +975,15 @@ def sumpool2x2(x: torch.Tensor) -> torch.Tensor:
 
 
 def conv3x3_wgrad_kind(Cin: int, Cout: int, upsample: bool, winograd: bool = True) -> str:
-    """Which weight-gradient kernel serves a conv3x3 layer: "upwino" (9 Winograd positions on the low-resolution pixels of
-    an upBlock), "wino" (16 positions per 2x2 output tile) where Cout % 32 == 0 and Cin % 32 == 0, else "direct"."""
-    if winograd and Cout % 32 == 0 and Cin % 32 == 0:
-        return "upwino" if upsample else "wino"
+    """Which weight-gradient kernel serves a conv3x3 layer: "wino" (16 positions per 2x2 output tile) where Cout % 32 == 0 and
+    Cin % 32 == 0; for an upBlock "upwino" (9 Winograd positions on the low-resolution pixels) where Cout % 64 == 0 and
+    Cin % 32 == 0 - that kernel has 64-row co-blocks only (tgsr_upwino_wgrad.hip), so upBlock(32, 16) / GF_DIM = 16 (Cout = 32)
+    stay on the direct kernel; else "direct"."""
+    if winograd and Cin % 32 == 0:
+        if upsample:
+            return "upwino" if Cout % 64 == 0 else "direct"
+        if Cout % 32 == 0:
+            return "wino"
     return "direct"
 
 

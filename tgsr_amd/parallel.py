@@ -136,6 +136,17 @@ class FlatGradBucket:
             _SLOTS.pop(p.data_ptr(), None)       # the registry only holds buckets with a step in flight
         self.direct = False
 
+    def flush_params(self, i0: int, i1: int):
+        """end_step() for the parameters [i0, i1) only, DURING backward, once their gradients are final: their region of the
+        flat buffer is then complete and may go out (all_reduce_range_async); end_step() later finds them in place."""
+        for i in range(i0, i1):
+            p, v = self.params[i], self.views[i]
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+            p.grad = v
+            _SLOTS.pop(p.data_ptr(), None)
+
     def pack(self):
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -148,7 +159,24 @@ class FlatGradBucket:
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 p.grad = v.clone() if p.grad is None else p.grad.copy_(v)
 
-    def all_reduce_mean(self, async_op: bool = False):
+    def all_reduce_range_async(self, lo: int, hi: int):
+        """Start the all-reduce of flat[lo:hi] (a range of whole parameters whose gradients are final) while backward is
+        still producing the rest; returns a handle whose wait() scales the range.  all_reduce_mean(skip=(lo, hi)) then
+        reduces what is left.  Used by train.SRTrainer to send NetG_highweight's gradients - complete when backward enters
+        G_SR_NET_low - under the tail of backward."""
+        if dp_world() == 1:
+            return None
+        part = self.flat_all[lo:hi]
+        work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True)
+        world = dist.get_world_size()
+
+        class _Done:
+            def wait(_s):
+                work.wait()
+                part.div_(world)
+        return _Done()
+
+    def all_reduce_mean(self, async_op: bool = False, skip=None):
         """sum over ranks, x 1/world.  With attach() the gradients are already in place: pack/unpack are no-ops."""
         self.pack()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -157,6 +185,19 @@ class FlatGradBucket:
         if self.buffers:
             with torch.no_grad():
                 torch._foreach_copy_(self.buf_views, self.buffers)      # this step's running statistics -> the tail
+
+        if skip is not None:
+            # [lo, hi) went out earlier (all_reduce_range_async) and is already averaged: reduce the two pieces around it
+            lo, hi = skip
+            pieces = [t for t in (self.flat_all[:lo], self.flat_all[hi:]) if t.numel()]
+            for t in pieces:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t.div_(world)
+            self.unpack()
+            if self.buffers:
+                with torch.no_grad():
+                    torch._foreach_copy_(self.buffers, self.buf_views)
+            return None
 
         def finish():
             self.flat_all.div_(world)
@@ -176,6 +217,73 @@ class FlatGradBucket:
         dist.all_reduce(self.flat_all, op=dist.ReduceOp.SUM)
         finish()
         return None
+
+
+# DAMSM's contrastive losses under data parallelism: True = every rank evaluates them on the gathered GLOBAL batch (the loss a
+# single process would compute on the concatenated batch; gather_damsm_batch), False = on its own shard (B - 1 negatives per
+# sample instead of world x B - 1: cheaper - the pair kernel's work grows with world^2 when gathered - but a different loss).
+GATHER_NEGATIVES = os.environ.get("TGSR_DP_GATHER_NEGATIVES", "1") != "0"
+
+
+def dp_world() -> int:
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+class _AllGatherCat(torch.autograd.Function):
+    """cat(all_gather(x), 0) whose backward hands every rank the gradient rows of ITS slice.  Correct when every rank goes
+    on to evaluate the SAME function of the gathered tensor (the replicated contrastive loss below): rank r's copy of
+    dL/d(gathered)[rows of r] is then the whole derivative with respect to its slice - no reduce-scatter needed."""
+
+    @staticmethod
+    def forward(ctx, x):
+        world, rank = dist.get_world_size(), dist.get_rank()
+        x = x.contiguous()
+        n = torch.tensor([x.shape[0]], dtype=torch.int64, device=x.device)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        ns = [int(v) for v in ns]
+        m = max(ns)
+        if x.shape[0] < m:                                   # shards differ by at most one row (shard_bounds): pad, trim below
+            x = torch.cat((x, x.new_zeros((m - x.shape[0],) + tuple(x.shape[1:]))))
+        parts = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(parts, x)
+        ctx.lo, ctx.n = sum(ns[:rank]), ns[rank]
+        return torch.cat([p_[:k] for p_, k in zip(parts, ns)], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.lo:ctx.lo + ctx.n].contiguous()
+
+
+def gather_cat(x: torch.Tensor) -> torch.Tensor:
+    """The rows of every rank, in rank order (= the order of the globally length-sorted batch, shard_batch), differentiable."""
+    return x if dp_world() == 1 else _AllGatherCat.apply(x)
+
+
+def gather_damsm_batch(regions, code, words_embs, sent_emb, cap_lens, class_ids, width: int):
+    """DAMSM under data parallelism: `words_loss` / `sent_loss` are batch-contrastive (a B x B matching matrix,
+    losses.py:45-59, 116-133), so a shard alone would see only its own B - 1 negatives.  This gathers what the two losses
+    read - region features [B,nef,17,17], image codes [B,nef], word embeddings [B,nef,T] (padded to `width` words: T = the
+    shard's longest caption), sentence codes [B,nef], caption lengths, class ids - from every rank, ~5 MB at 16 x 8 images, so
+    that every rank evaluates the loss of the GLOBAL batch (identical on all ranks: the single-process loss on the
+    concatenated batch); its gradient flows back into the local rows only.  Returns the gathered arguments, the global batch
+    size and `world`: the caller multiplies the term by `world` before backward, because the gradient bucket's all-reduce
+    AVERAGES the per-rank parameter gradients while the rank contributions of a replicated loss must be SUMMED."""
+    world = dp_world()
+    lens = cap_lens.tolist() if torch.is_tensor(cap_lens) else [int(v) for v in cap_lens]
+    if world == 1:
+        return regions, code, words_embs, sent_emb, lens, class_ids, len(lens), 1
+    if words_embs.shape[2] < width:
+        words_embs = torch.nn.functional.pad(words_embs, (0, width - words_embs.shape[2]))
+    dev = words_embs.device
+    meta = torch.tensor(lens, dtype=torch.int64, device=dev)
+    glens = [int(v) for v in _AllGatherCat.apply(meta)]
+    gids = None
+    if class_ids is not None:
+        import numpy as np
+        ids = torch.as_tensor(np.asarray(class_ids), dtype=torch.int64).to(dev)
+        gids = _AllGatherCat.apply(ids).cpu().numpy()
+    return (gather_cat(regions), gather_cat(code), gather_cat(words_embs), gather_cat(sent_emb), glens, gids, len(glens), world)
 
 
 def gather_images(img: torch.Tensor, dst: int = 0):

@@ -35,7 +35,7 @@ def prepare_labels(batch_size, device):
 
 class SRTrainer:
     def __init__(self, n_words, device="cuda", low="lr", lr=None, ema_decay=0.999, image_encoder=None,
-                 discriminators=False, d_lr=None):
+                 discriminators=False, d_lr=None, gather_negatives=None):
         """image_encoder: optional frozen module image [B,3,256,256] -> (region features [B,nef,17,17], cnn_code
         [B,nef]) (a CNN_ENCODER with its trunk): adds the DAMSM ranking term of generator_loss (losses.py:375-386)
         on the finest image, x TRAIN.SMOOTH.LAMBDA.
@@ -47,6 +47,9 @@ class SRTrainer:
         loop: architecture and update order (D first, then G on the same fake images, as in the AttnGAN
         trainer TGSR was forked from) are the build's declaration."""
         self.device = torch.device(device)
+        # data parallel: the DAMSM ranking term on the gathered global batch (parallel.GATHER_NEGATIVES, default on) or per shard
+        from . import parallel as _par
+        self.gather_negatives = _par.GATHER_NEGATIVES if gather_negatives is None else bool(gather_negatives)
         # the generators' weight gradients run on a side stream beside the data-gradient chain while a step's backward
         # is in flight (12.7 -> 11.7 ms per step at B=16: the small layers' weight-gradient kernels and the slab sums
         # fill a fraction of the CUs); TGSR_WGRAD_SIDE=0 keeps everything on one stream
@@ -63,8 +66,21 @@ class SRTrainer:
         self.netGL = G_SR_NET_low().to(self.device).train()
         self.netGH = NetG_highweight(weightmap=False, low=low).to(self.device).train()
         self.params = list(self.netGL.parameters()) + list(self.netGH.parameters())
-        # (BatchNorm's running statistics ride the gradient bucket's all-reduce: identical on every rank, parallel.py)
-        self.bucket = FlatGradBucket(self.params, buffers=list(self.netGL.buffers()) + list(self.netGH.buffers())).attach()
+        # (BatchNorm's running statistics ride the gradient bucket's all-reduce: identical on every rank, parallel.py.)
+        # Bucket layout [NetG_highweight | G_SR_NET_low | buffers]: backward runs through NetG_highweight first (its nodes
+        # are the younger ones), so its gradients are final while G_SR_NET_low's backward still runs - that range goes out
+        # early (`_fire_early`), the rest with the step's closing all-reduce: two collectives, the first under backward.
+        gh_params = [p for p in self.netGH.parameters() if p.requires_grad]
+        self._bucket_bufs = list(self.netGL.buffers()) + list(self.netGH.buffers())
+        self.bucket = FlatGradBucket(gh_params + list(self.netGL.parameters()), buffers=self._bucket_bufs).attach()
+        self._early_n = len(gh_params)                                   # parameters of the early range
+        self._early_hi = sum(p.numel() for p in gh_params)               # ... = flat[0:_early_hi]
+        self._early_on = os.environ.get("TGSR_EARLY_ALLREDUCE", "1") != "0"
+        self._early_left, self._early = -1, None
+        self._comm = distinct_streams(1, self.device, avoid=cur + ([self._wside.cuda_stream] if self._wside is not None else []))[0] \
+            if self.device.type == "cuda" else None
+        for p in gh_params:
+            p.register_post_accumulate_grad_hook(self._gh_grad_done)
         self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999))
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
@@ -78,9 +94,53 @@ class SRTrainer:
                 self.bucketsD.append(FlatGradBucket(d.parameters(), buffers=d.buffers()).attach())
                 self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
                                                    betas=(0.5, 0.999)))
+        if self.netsD:
+            # the generator loss runs the train-mode discriminators on the fake images once more (g_loss): their running
+            # statistics move again, per rank, AFTER their own bucket's all-reduce - so they also ride the generators' bucket
+            # and every rank leaves the step with the same discriminator buffers (a snapshot is the same file on every rank)
+            self._bucket_bufs = self._bucket_bufs + [b for d in self.netsD for b in d.buffers()]
+            self.bucket = FlatGradBucket(gh_params + list(self.netGL.parameters()), buffers=self._bucket_bufs).attach()
         self._dstreams = distinct_streams(len(self.netsD), self.device,
-                                          avoid=cur + ([self._wside.cuda_stream] if self._wside is not None else [])) \
+                                          avoid=cur + ([self._wside.cuda_stream] if self._wside is not None else []) +
+                                          ([self._comm.cuda_stream] if self._comm is not None else [])) \
             if self.device.type == "cuda" and self.netsD and os.environ.get("TGSR_D_STREAMS", "1") != "0" else []
+
+    # ------------------------------------------------------------------ gradient all-reduce under the tail of backward
+    def _arm_early(self):
+        from .parallel import dp_world
+        self._early = None
+        self._early_left = self._early_n if (self._early_on and dp_world() > 1 and self._comm is not None) else -1
+
+    def _gh_grad_done(self, _p):
+        """post-accumulate hook of every NetG_highweight parameter: when the last one has its gradient, that range of the
+        bucket is final - flush it and start its all-reduce on the communication stream while G_SR_NET_low's backward goes on."""
+        if self._early_left <= 0:
+            return
+        self._early_left -= 1
+        if self._early_left == 0:
+            self._fire_early()
+
+    def _fire_early(self):
+        cur = torch.cuda.current_stream(self.device)
+        self.bucket.flush_params(0, self._early_n)
+        self._comm.wait_stream(cur)
+        if self._wside is not None:
+            self._comm.wait_stream(self._wside)            # the weight-gradient kernels of this range run there
+        with torch.cuda.stream(self._comm):
+            self._early = self.bucket.all_reduce_range_async(0, self._early_hi)
+
+    def _all_reduce(self):
+        """The step's closing collective: everything the early one did not take (all of it when none was started)."""
+        if self._early is None:
+            self._early_left = -1
+            self.bucket.all_reduce_mean()
+            return
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._comm):
+            self._early.wait()
+        cur.wait_stream(self._comm)
+        self._early, self._early_left = None, -1
+        self.bucket.all_reduce_mean(skip=(0, self._early_hi))
 
     def loss(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """hr_pyramid: the 3 target scales [B,3,2s,2s], [B,3,4s,4s], [B,3,8s,8s]."""
@@ -90,9 +150,9 @@ class SRTrainer:
             B = captions.shape[0]
             match_labels = torch.arange(B, device=self.device)
             region_features, cnn_code = self.image_encoder(fine_im[-1])
-            w0, w1, _ = losses.words_loss(region_features, words_embs, match_labels, cap_lens, class_ids, B)
-            s0, s1 = losses.sent_loss(cnn_code, sent_emb, match_labels, class_ids, B)
-            errG = errG + (w0 + w1 + s0 + s1) * cfg.TRAIN.SMOOTH.LAMBDA
+            w0, w1, s0, s1, scale, _ = losses.damsm_terms(region_features, cnn_code, words_embs, sent_emb, cap_lens, class_ids,
+                                                          gather=self.gather_negatives)
+            errG = errG + (w0 + w1 + s0 + s1) * (cfg.TRAIN.SMOOTH.LAMBDA * scale)
         return errG, fake_imgL, fine_im
 
     @staticmethod
@@ -124,7 +184,8 @@ class SRTrainer:
         B = sent_emb.shape[0]
         real_labels, _fake, match_labels = prepare_labels(B, self.device)
         adv, _log = losses.generator_loss(self.netsD, self.image_encoder, fine_im, real_labels, words_embs, sent_emb,
-                                          match_labels, cap_lens, class_ids, streams=self._dstreams or None, lazy_log=True)
+                                          match_labels, cap_lens, class_ids, streams=self._dstreams or None, lazy_log=True,
+                                          gather_negatives=self.gather_negatives)
         return adv + losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
 
     @contextlib.contextmanager
@@ -210,6 +271,7 @@ class SRTrainer:
                 p.requires_grad_(False)
         try:
             errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
+            self._arm_early()
             with self._use_packs(), self._wgrad_side():
                 errG.backward()
         finally:
@@ -219,7 +281,7 @@ class SRTrainer:
         self.bucket.end_step()
         for b in self.bucketsD:
             b.end_step()
-        self.bucket.all_reduce_mean()
+        self._all_reduce()
         self.opt.step()
         if self._packs is not None:
             self._packs.repack()
@@ -237,11 +299,12 @@ class SRTrainer:
         try:
             with self._use_packs():
                 errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
+                self._arm_early()
                 with self._wgrad_side():
                     errG.backward()
         finally:
             self.bucket.end_step()               # also after a failed step: `.grad` views restored, slots closed
-        self.bucket.all_reduce_mean()
+        self._all_reduce()
         self.opt.step()
         if self._packs is not None:
             self._packs.repack()                 # next step's packed weights, off the critical stream
@@ -258,10 +321,13 @@ class DAMSMTrainer:
     (CNN_ENCODER(trunk=...)) or pre-extracted features via `step_features`.  Like the reference: a fresh
     Adam(lr, betas (0.5, 0.999)) per epoch, lr x 0.98 per epoch down to ENCODER_LR / 10, gradient-norm clip
     RNN_GRAD_CLIP on the text encoder only.  Data parallel: one flat gradient bucket, one all-reduce per step; the
-    contrastive losses use the local shard's negatives."""
+    contrastive losses are those of the GLOBAL batch (features and embeddings all-gathered, parallel.gather_damsm_batch;
+    `gather_negatives=False` / TGSR_DP_GATHER_NEGATIVES=0: the local shard's negatives only - SURVEY section 8e (2))."""
 
-    def __init__(self, n_words, device="cuda", trunk=None, lr=None):
+    def __init__(self, n_words, device="cuda", trunk=None, lr=None, gather_negatives=None):
         self.device = torch.device(device)
+        from . import parallel as _par
+        self.gather_negatives = _par.GATHER_NEGATIVES if gather_negatives is None else bool(gather_negatives)
         self.text_encoder = RNN_ENCODER(n_words, nhidden=cfg.TEXT.EMBEDDING_DIM).to(self.device).train()
         self.image_encoder = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM,
                                          trunk=trunk if trunk is not None else torch.nn.Identity()).to(self.device)
@@ -362,8 +428,11 @@ class DAMSMTrainer:
         labels = torch.arange(B, device=self.device)
         words_features, sent_code = self.image_encoder.heads(features, pooled)
         words_emb, sent_emb = self.text_encoder(captions, cap_lens, self.text_encoder.init_hidden(B))
-        w0, w1, att = losses.words_loss(words_features, words_emb, labels, cap_lens, class_ids, B)
-        s0, s1 = losses.sent_loss(sent_code, sent_emb, labels, class_ids, B)
+        # data parallel (gather_negatives): the losses of the GLOBAL batch, identical on every rank; step_features multiplies by
+        # `_bw_scale` = world for backward (the bucket's all-reduce averages what a replicated loss needs summed)
+        w0, w1, s0, s1, scale, att = losses.damsm_terms(words_features, sent_code, words_emb, sent_emb, cap_lens, class_ids,
+                                                        gather=self.gather_negatives)
+        self._bw_scale = scale
         return w0 + w1 + s0 + s1, (w0.detach(), w1.detach(), s0.detach(), s1.detach()), att
 
     def step_features(self, features, pooled, captions, cap_lens, class_ids=None):
@@ -372,7 +441,7 @@ class DAMSMTrainer:
         for p, v in zip(self.bucket.params, self.bucket.views):
             p.grad = v
         loss, _parts, _att = self.loss_from_features(features, pooled, captions, cap_lens, class_ids)
-        loss.backward()
+        (loss * self._bw_scale if self._bw_scale != 1 else loss).backward()
         self.bucket.all_reduce_mean()
         torch.nn.utils.clip_grad_norm_(self.text_encoder.parameters(), cfg.TRAIN.RNN_GRAD_CLIP)   # :96-97
         self.opt.step()

@@ -189,7 +189,8 @@ class _UpBlock(nn.Sequential):
             # 2x2 convs on the pre-upsample tensor, 4 multiplies per output)
             wino = WINOGRAD and ops.upwino_supported(x, conv.out_channels, out=out)
             # ... and the F(4x4) form of it (25 of 36 positions: 1.56 multiplies per output) where ops.upwino4_wanted routes
-            # the layer (output >= 64 x 64 pixels, whole tiles, a full round of workgroups) and the tensors are 16-byte aligned
+            # the layer (output >= 256 x 256 pixels: the generator's last upBlock, whole tiles, a full round of workgroups) and the
+            # tensors are 16-byte aligned
             w4 = (wino and ops.upwino4_wanted(x.shape[1], conv.out_channels, x.shape[2], x.shape[3], x.shape[0]) and
                   x.data_ptr() % 16 == 0 and (out is None or (out.data_ptr() % 16 == 0 and (out.shape[0] == 1 or out.stride(0) % 4 == 0))))
             src = [conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var]

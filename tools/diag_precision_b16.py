@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import tgsr_oracle as O
 from tgsr_amd.miscc.config import cfg, cfg_reset
 from tgsr_amd.trainer import SRPipeline
+from tgsr_amd import ops
 G = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 w = np.load(os.path.join(G, "face_S8_weights.npz"))
 def sd(pre, dt=torch.float32):
@@ -15,10 +16,7 @@ cap, lens, LR, LRb = O.synthetic_batch(16)
 ref = O.sr_forward(sd("E."), sd("GL."), sd("GH."), cap, lens.tolist(), LR, LRb)
 cfg_reset(); cfg.GAN.GF_DIM = 32; cfg.TEXT.EMBEDDING_DIM = 256
 for mode, extra in (("1", {}), ("1", {"TGSR_UPWINO4_MIN_CIN": "64"}), ("1", {"TGSR_UPWINO4_MIN_CIN": "1000"}), ("0", {})):
-    os.environ["TGSR_WINO4"] = mode
-    for k in ("TGSR_UPWINO4_MIN_CIN",):
-        os.environ.pop(k, None)
-    os.environ.update(extra)
+    ops.ROUTING.reset(dict(extra, TGSR_WINO4=mode))
     p = SRPipeline(41, device="cuda", branch_num=4).load_state_dicts(sd("E."), sd("GL."), sd("GH."))
     r = p(cap.cuda(), lens.tolist(), LR.cuda(), LRb.cuda())
     print("TGSR_WINO4=%s %s:" % (mode, extra), "  ".join("%s%d %.2e/%.1e" % (k, i, float((r[k][i].cpu() - ref[k][i]).abs().max()), float((r[k][i].cpu() - ref[k][i]).abs().mean()))

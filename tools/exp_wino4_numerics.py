@@ -68,7 +68,7 @@ run(4, lambda h, ci, co: h == 128 and res(h, ci, co), "F(4x4): the 128^2 layers"
 run(4, lambda h, ci, co: (h == 128 and res(h, ci, co)) or (h == 64 and ci == 64 and co == 128), "F(4x4): 128^2 + the 64 -> 128 ones at 64^2")
 run(4, lambda h, ci, co: h in (64, 128) and res(h, ci, co), "F(4x4): 128^2 + 64^2")
 from tgsr_amd import ops
-os.environ.pop("TGSR_WINO4", None)
+ops.ROUTING.reset({})
 # the rule the product uses, at batch 16 (a superset of what runs on the kernel: the upBlocks' convolutions have the shapes of
 # ResBlock convolutions here, on the GPU they are the up-sample-aware kernel's)
 run(4, lambda h, ci, co: ops.wino4_wanted(ci, co, h, h, 16), "F(4x4): as ops.wino4_wanted routes at batch 16")
