@@ -359,6 +359,16 @@ int tgsr_text_tail_lp_fwd(const float* words, const float* const* w_ctx, int nse
  */
 int tgsr_multi_copy(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream);
 
+/*
+ * out[i] = t[i] + alpha * s[i] for n <= 4 dense fp32 images in one launch (host arrays of device pointers; numel[i] a
+ * multiple of 4, pointers 16-byte aligned).  The second half of NetG_highweight's heads (model.py:280, 288, 297:
+ * `ims = one * conv_output(out) + a * SRb`): the caller computes t = tanh(conv5x5(out)) with tgsr_conv_to3_fwd(addend = NULL)
+ * on the high-frequency branch's own stream - it needs nothing of G_SR_NET_low - and only this axpy waits for the
+ * low-frequency images.  fma(alpha, s, t), exactly what tgsr_conv_to3_fwd's epilogue evaluates when given the addend.
+ */
+int tgsr_axpy_images(int n, float* const* out, const float* const* t, const float* const* s, const int64_t* numel, float alpha,
+                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Training path (BatchNorm2d batch statistics + backward).  The reference trains through torch autograd over
  * nn.Conv2d / nn.BatchNorm2d(train) / GLU / nn.Upsample (util.py:74-80, 110-130); these entry points are the

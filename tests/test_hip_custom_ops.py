@@ -193,6 +193,7 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     chk(T.multi_copy.default, ([torch.empty(5, 7, device=DEV), torch.empty(3, dtype=torch.int64, device=DEV)],
                                [R(5, 7), cap[0, :3].contiguous()]), test_utils=basic)
     chk(T.to_uint8.default, (R(2, 3, 8, 8),), test_utils=basic)
+    chk(T.axpy_images.default, ([R(2, 3, 8, 8), R(2, 3, 4, 4)], [R(2, 3, 8, 8), R(2, 3, 4, 4)], 0.5), test_utils=basic)
     # reduced-precision path (lp images)
     xi = lp.from_nchw(R(2, 64, 8, 32), "bf16", cpitch=64)
     wp = lp.pack_conv3x3_weight(R(64, 64, 3, 3) / 24.0, "bf16")

@@ -67,6 +67,22 @@ def test_two_rank_gradients_and_sharded_inference(tmp_path, backend):
     for k in range(2):
         assert torch.allclose(full[r[k]["lo"]:r[k]["hi"]], r[k]["fine"], atol=1e-4, rtol=1e-4), \
             "sharded inference differs from the un-sharded rows"
+    # ---- SRTrainer.step under data parallelism: NetG_highweight's gradient range is all-reduced under the tail of backward
+    # (train.py `_fire_early`), the rest with the closing collective - every rank leaves the step with the same gradients,
+    # running statistics (they ride the bucket's tail) and parameters
+    assert torch.equal(r[0]["step_flat"], r[1]["step_flat"]) and float(r[0]["step_flat"].abs().max()) > 0
+    assert torch.equal(r[0]["step_params"], r[1]["step_params"])
+    # ---- DAMSM on the gathered global batch: both ranks report the loss of the WHOLE batch and hold its
+    # gradient - the single-process step on the concatenated batch
+    assert abs(r[0]["damsm_loss"] - r[1]["damsm_loss"]) < 1e-6 and torch.equal(r[0]["damsm_flat"], r[1]["damsm_flat"])
+    d = W.damsm_case()
+    dt = W.make_damsm_trainer()
+    one = dt.step_features(d["feats"].cuda(), d["pooled"].cuda(), d["cap"].cuda(), d["lens"].tolist(), d["class_ids"])
+    torch.cuda.synchronize()
+    assert abs(float(one) - r[0]["damsm_loss"]) < 1e-4 * max(1.0, abs(float(one))), (float(one), r[0]["damsm_loss"])
+    ref = dt.bucket.flat.cpu()
+    gerr = float((r[0]["damsm_flat"] - ref).abs().max()) / float(ref.abs().max())
+    assert gerr < 1e-4, "gathered-batch DAMSM gradient differs from the single-process gradient: %g" % gerr
     if backend == "nccl":
         # G/D alternation over RCCL: four all-reduces per step on four streams; after it every rank holds the same
         # generator gradients and has taken the same Adam steps (the shards differ, so identical discriminator parameters

@@ -434,3 +434,88 @@ def test_gan_losses_vs_reference_run_fixture():
         assert abs(float(err2) - float(g["errG.nocls.w05.s2.g3"])) < 1e-4 * abs(float(g["errG.nocls.w05.s2.g3"]))
     finally:
         cfg_reset()
+
+
+def test_cnn_encoder_walks_a_real_inception_v3_at_batch_16(face_weights):
+    """CNN_ENCODER.forward (util.py:308-368) for real, at configs[2]'s batch: bilinear resize to 299 x 299, the sixteen
+    Inception-v3 blocks (tests/inception_v3_arch.py: the published topology with seeded random weights - third-party arithmetic,
+    parity UNPINNED; the blocks run on MIOpen as the torch modules they are), 17 x 17 x 768 region features, 8 x 8
+    average pool, the two trainable heads on the HIP GEMM kernels.  Checked: state_dict keys like the reference's
+    image_encoder files, shapes, the same module's walk on the CPU (oneDNN) + the oracle's head formulas, the DAMSM losses on
+    those features, and one full-size G/D step with the ranking term through it (finite, gradient reaches both generators).
+    Prints what the encoder costs beside the step."""
+    import copy
+    import time
+    from conftest import split_sd
+    from inception_v3_arch import InceptionV3Arch
+    from tgsr_amd.miscc import losses
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.train import SRTrainer
+    from tgsr_amd.util import CNN_ENCODER
+    cfg_reset()
+    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.DF_DIM = 32, 256, 64
+    cfg.TRAIN.SMOOTH.GAMMA1, cfg.TRAIN.SMOOTH.LAMBDA = 4.0, 5.0
+    try:
+        torch.manual_seed(5)
+        enc_cpu = CNN_ENCODER(256, inception=InceptionV3Arch(seed=1)).eval()
+        keys = set(enc_cpu.state_dict())
+        assert {"Conv2d_1a_3x3.conv.weight", "Mixed_6e.branch7x7dbl_5.bn.running_var", "Mixed_7c.branch_pool.conv.weight",
+                "emb_features.weight", "emb_cnn_code.weight", "emb_cnn_code.bias"} <= keys
+        assert all(not p.requires_grad for p in enc_cpu.frozen_parameters()) and enc_cpu.emb_features.weight.requires_grad
+        enc = copy.deepcopy(enc_cpu).to(DEV).eval()
+        B = 16
+        g = torch.Generator().manual_seed(11)
+        imgs = torch.rand(B, 3, 256, 256, generator=g) * 2 - 1
+        with torch.no_grad():
+            fc, pc = enc_cpu.run_trunk(imgs)                                  # pure torch: runs on the CPU as well
+            regions_ref = F.conv2d(fc, enc_cpu.emb_features.weight)            # the heads' formulas (util.py:364-367)
+            code_ref = F.linear(pc, enc_cpu.emb_cnn_code.weight, enc_cpu.emb_cnn_code.bias)
+            xd = imgs.to(DEV)
+            enc(xd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            regions, code = enc(xd)
+            torch.cuda.synchronize()
+            t_fwd = time.perf_counter() - t0
+        assert tuple(regions.shape) == (B, 256, 17, 17) and tuple(code.shape) == (B, 256) and tuple(fc.shape) == (B, 768, 17, 17)
+        for got, ref in ((regions, regions_ref), (code, code_ref)):
+            err = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
+            assert err < 2e-3, err                                            # MIOpen vs oneDNN through 48 convolutions
+        # the DAMSM losses on these features: HIP kernels vs the oracle on the CPU walk's features
+        cap, lens, LR, LRb = O.synthetic_batch(B)
+        sdE = split_sd(face_weights, "E.")
+        words, sent = O.rnn_encoder(sdE, cap, lens.tolist())
+        labels = torch.arange(B)
+        w0, w1, _ = losses.words_loss(regions, words.to(DEV), labels.to(DEV), lens.tolist(), None, B)
+        s0, s1 = losses.sent_loss(code, sent.to(DEV), labels.to(DEV), None, B)
+        r0, r1, _ = O.words_loss(regions_ref, words, labels, lens.tolist(), None, B, 4.0, cfg.TRAIN.SMOOTH.GAMMA2, cfg.TRAIN.SMOOTH.GAMMA3)
+        q0, q1 = O.sent_loss(code_ref, sent, labels, None, B, cfg.TRAIN.SMOOTH.GAMMA3)
+        for a, b in ((w0, r0), (w1, r1), (s0, q0), (s1, q1)):
+            assert abs(float(a) - float(b)) < 5e-3 * max(1.0, abs(float(b))), (float(a), float(b))
+        # one full-size G/D alternation with the ranking term through the real walk
+        tr = SRTrainer(41, device=DEV, discriminators=True, image_encoder=enc)
+        tr.text_encoder.load_state_dict(sdE)
+        tr.netGL.load_state_dict(split_sd(face_weights, "GL."))
+        tr.netGH.load_state_dict({k: v for k, v in split_sd(face_weights, "GH.").items() if k != "a"})
+        hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+        args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+        tr.step_gan(*args, class_ids=np.arange(B))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        errG, errsD = tr.step_gan(*args, class_ids=np.arange(B))
+        torch.cuda.synchronize()
+        t_with = time.perf_counter() - t0
+        assert torch.isfinite(errG) and all(torch.isfinite(e) for e in errsD)
+        assert float(tr.bucket.flat.abs().max()) > 0 and torch.isfinite(tr.bucket.flat).all()
+        tr.image_encoder = None
+        tr.step_gan(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.step_gan(*args)
+        torch.cuda.synchronize()
+        t_without = time.perf_counter() - t0
+        print("\nCNN_ENCODER with a real Inception-v3 walk, batch 16: forward %.2f ms; G/D step with the DAMSM term %.1f ms, without %.1f ms"
+              " (the encoder's forward + backward-to-the-image + ranking losses: %.1f ms = %.0f %% of the step)"
+              % (t_fwd * 1e3, t_with * 1e3, t_without * 1e3, (t_with - t_without) * 1e3, 100 * (t_with - t_without) / t_with))
+    finally:
+        cfg_reset()

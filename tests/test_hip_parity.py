@@ -398,6 +398,48 @@ def test_conv_to3(B, Cin, H, W, K, act):
     close(out, ref, atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 16, 32), (3, 64, 64), (1, 128, 128)])
+def test_split_head_equals_fused_head_bit_for_bit(B, H, W):
+    """NetG_highweight's head `tanh(conv5x5(out)) + a * SRb` (model.py:280) computed in two launches - the convolution + tanh
+    without the addend (ahead of G_SR_NET_low), then tgsr_axpy_images - is the fused epilogue's result bit for bit, for several
+    scales in one axpy launch."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(H + W)
+    xs = [torch.randn(B, 32, H >> k, W >> k, generator=g).to(DEV) for k in range(3)]
+    adds = [torch.randn(B, 3, H >> k, W >> k, generator=g).to(DEV) for k in range(3)]
+    w = (torch.randn(3, 32, 5, 5, generator=g) / 28).to(DEV)
+    fused = [ops.conv_to3(x, w, tanh_axpy=True, addend=a, alpha=0.5) for x, a in zip(xs, adds)]
+    ts = [ops.conv_to3(x, w, tanh_axpy=True, addend=None, alpha=0.5) for x in xs]
+    split = torch.ops.tgsr.axpy_images(ts, adds, 0.5)
+    for f, s_ in zip(fused, split):
+        assert torch.equal(f, s_)
+    ref = torch.tanh(F.conv2d(xs[1].cpu(), w.cpu(), None, 1, 2)) + 0.5 * adds[1].cpu()
+    close(split[1], ref, atol=2e-5, rtol=2e-5)
+    with pytest.raises(ops.TgsrError):
+        ops.axpy_images([ts[0]], [adds[1]], 0.5)                      # shapes must agree
+    with pytest.raises(ops.TgsrError):
+        ops.axpy_images(ts + ts, adds + adds, 0.5)                    # at most 4 images per launch
+
+
+def test_pipeline_split_heads_equal_reference_order(face_weights, cfg_face, monkeypatch):
+    """SRPipeline with NetG_highweight's convolution heads on the side stream (the default) == the six stand-alone heads in the
+    reference's order (trainer.SPLIT_HEADS = False), bit for bit, eager and replayed from a hipGraph."""
+    from tgsr_amd import trainer
+    cap, lens, LR, LRb = O.synthetic_batch(4, seed=3)
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    assert trainer.SPLIT_HEADS
+    p = _pipeline(face_weights)
+    a = [f.clone() for f in p(*args)["fine"]]
+    monkeypatch.setattr(trainer, "SPLIT_HEADS", False)
+    b = [f.clone() for f in _pipeline(face_weights)(*args)["fine"]]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    monkeypatch.setattr(trainer, "SPLIT_HEADS", True)
+    p.capture(*args)
+    for x, y in zip(p.replay()["fine"], a):
+        assert torch.equal(x, y)
+
+
 def test_word_attention_golden_quirk_and_b1(ops_small):
     from tgsr_amd import ops
     g = ops_small

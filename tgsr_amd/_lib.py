@@ -97,6 +97,7 @@ SIGNATURES = {
     "tgsr_lp_upconv_glu_att_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i,
                                         _i, _i, _i, _i, _vp, _vp]),
     "tgsr_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "tgsr_axpy_images": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "tgsr_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "tgsr_gaussian_blur_u8": (_i, [_vp, _i, _i, _i, _i, ctypes.c_uint32, ctypes.c_uint32, _i, _vp, _vp, _vp]),

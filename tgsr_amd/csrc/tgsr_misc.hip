@@ -105,6 +105,35 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(MultiCopyArgs a) {
   }
 }
 
+// out_i = t_i + alpha * s_i for up to 4 dense images in one launch: NetG_highweight's `one * tanh(conv5x5(out)) + a * SRb`
+// (model.py:280, 288, 297) with the tanh(conv) part computed EARLIER, beside G_SR_NET_low, by tgsr_conv_to3_fwd without an
+// addend - the same fma(alpha, s, t) that kernel's own epilogue evaluates when it is handed the addend, so the images are
+// bit-identical.  blockIdx.y = image; 16-byte words (sizes are multiples of 4 floats: host-checked).
+struct AxpyArgs {
+  float* out[4];
+  const float* t[4];
+  const float* s[4];
+  uint32_t n4[4];
+  float alpha;
+};
+
+__global__ __launch_bounds__(256) void axpy_images_kernel(AxpyArgs a) {
+  const int k = blockIdx.y;
+  const float4* __restrict__ t = reinterpret_cast<const float4*>(a.t[k]);
+  const float4* __restrict__ sr = reinterpret_cast<const float4*>(a.s[k]);
+  float4* __restrict__ o = reinterpret_cast<float4*>(a.out[k]);
+  const float al = a.alpha;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < a.n4[k]; i += gridDim.x * 256) {
+    const float4 tv = t[i], sv = sr[i];
+    float4 r;
+    r.x = fmaf(al, sv.x, tv.x);
+    r.y = fmaf(al, sv.y, tv.y);
+    r.z = fmaf(al, sv.z, tv.z);
+    r.w = fmaf(al, sv.w, tv.w);
+    o[i] = r;
+  }
+}
+
 }  // namespace tgsr
 
 using namespace tgsr;
@@ -177,4 +206,26 @@ extern "C" int tgsr_multi_copy(int n, void* const* dst, const void* const* src, 
   const int bx = (int)((words + 255) / 256 < 64 ? (words + 255) / 256 : 64);
   hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, n), dim3(256), 0, as_stream(stream), a);
   return note_launch(hipGetLastError(), "multi_copy_kernel");
+}
+
+extern "C" int tgsr_axpy_images(int n, float* const* out, const float* const* t, const float* const* s, const int64_t* numel,
+                                float alpha, void* stream) {
+  if (n < 1 || !out || !t || !s || !numel) return TGSR_EINVAL;
+  if (n > 4) return TGSR_EUNSUPPORTED;
+  AxpyArgs a;
+  uint32_t most = 0;
+  for (int i = 0; i < 4; ++i) {
+    a.out[i] = nullptr; a.t[i] = nullptr; a.s[i] = nullptr; a.n4[i] = 0;
+    if (i >= n) continue;
+    if (!out[i] || !t[i] || !s[i] || numel[i] < 1) return TGSR_EINVAL;
+    if ((numel[i] & 3) || numel[i] > 0x7fffffff ||
+        ((reinterpret_cast<uintptr_t>(out[i]) | reinterpret_cast<uintptr_t>(t[i]) | reinterpret_cast<uintptr_t>(s[i])) & 15))
+      return TGSR_EUNSUPPORTED;
+    a.out[i] = out[i]; a.t[i] = t[i]; a.s[i] = s[i]; a.n4[i] = (uint32_t)(numel[i] >> 2);
+    most = a.n4[i] > most ? a.n4[i] : most;
+  }
+  a.alpha = alpha;
+  const int bx = (int)((most + 255) / 256 < 512 ? (most + 255) / 256 : 512);
+  hipLaunchKernelGGL(axpy_images_kernel, dim3(bx, n), dim3(256), 0, as_stream(stream), a);
+  return note_launch(hipGetLastError(), "axpy_images_kernel");
 }

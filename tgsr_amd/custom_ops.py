@@ -479,6 +479,8 @@ text_tail_lp = _define("text_tail_lp(Tensor words, Tensor[] w_ctxs, Tensor sent_
                         words.new_empty(words.shape[0], ncf),
                         words.new_empty(words.shape[0], words.shape[2], dtype=torch.uint8),
                         words.new_empty(len(ws) * words.shape[0] * 4096 + 4 * words.shape[0], dtype=torch.uint8)))
+axpy_images = _define("axpy_images(Tensor[] ts, Tensor[] ss, float alpha) -> Tensor[]",
+                      lambda ts, ss, alpha: ops.axpy_images(list(ts), list(ss), alpha), lambda ts, ss, alpha: [torch.empty_like(t) for t in ts])
 multi_copy = _define("multi_copy(Tensor(a!)[] dsts, Tensor[] srcs) -> ()",
                      lambda dsts, srcs: ops.multi_copy(list(dsts), list(srcs)), lambda dsts, srcs: None)
 to_uint8 = _define("to_uint8(Tensor img) -> Tensor", lambda x: ops.to_uint8(x), lambda x: torch.empty_like(x, dtype=torch.uint8))

@@ -138,6 +138,18 @@ class NetG_highweight(nn.Module):
         """ims_k = one * tanh(conv5x5(out_k)) + a * SRb_k   (model.py:280, 288, 297)."""
         return [self._head(f, sr) for f, sr in zip(feats, SRb)]
 
+    def tanh_heads(self, feats):
+        """The part of heads() that needs no low-frequency image: tanh(conv5x5(out_k)).  SRPipeline runs it on the
+        high-frequency branch's stream, beside G_SR_NET_low; `finish_heads` adds a * SRb_k (one launch for all scales) -
+        the same fma the fused epilogue evaluates, bit-identical images (tests/test_hip_parity.py)."""
+        from . import custom_ops as C
+        w = self.conv_output[0].weight.detach()
+        return [C.conv_to3(f, w, True, None, self._a) for f in feats]
+
+    def finish_heads(self, ts, SRb):
+        from . import custom_ops as C
+        return list(C.axpy_images(list(ts), [s.contiguous() for s in SRb[:len(ts)]], self._a))
+
     def forward(self, LR, SRb, LRb):
         ims = self.heads(self.trunk(LR, LRb), SRb[:3])
         a, one = self._const(LR)

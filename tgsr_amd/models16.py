@@ -109,6 +109,14 @@ class NetG_highweight(nn.Module):
         error as shipped)."""
         return [self._head(f, sr) for f, sr in zip(feats, SRb[:4])]
 
+    def tanh_heads(self, feats):
+        """tanh(conv5x5(out_k)) of every scale - needs no low-frequency image (see model.NetG_highweight.tanh_heads)."""
+        w = self.conv_output[0].weight.detach()
+        return [C.conv_to3(f, w, True, None, self.alpha()) for f in feats]
+
+    def finish_heads(self, ts, SRb):
+        return list(C.axpy_images(list(ts), [s.contiguous() for s in SRb[:len(ts)]], self.alpha()))
+
     def forward(self, LR, SRb, LRb):
         ims = self.heads(self.trunk(LR, LRb), SRb)
         one = self._one.get(LR.device)

@@ -1153,6 +1153,31 @@ def multi_copy(dsts, srcs) -> None:
     check(_lib.lib().tgsr_multi_copy(n, dp, sp, nb, _stream()), "tgsr_multi_copy")
 
 
+def axpy_images(ts, ss, alpha: float, outs=None):
+    """[t + alpha * s for t, s in zip(ts, ss)] for up to 4 dense fp32 images in one launch (tgsr_axpy_images): the closing
+    `+ a * SRb` of NetG_highweight's heads when tanh(conv5x5(.)) was computed ahead of the low-frequency images."""
+    import ctypes
+    n = len(ts)
+    if n == 0:
+        return []
+    if n != len(ss) or n > 4:
+        raise TgsrError("axpy_images: %d / %d images (at most 4)" % (n, len(ss)))
+    _need_hip(*ts, *ss)
+    ts = [_f32(t, "t").contiguous() for t in ts]
+    ss = [_f32(s_, "s").contiguous() for s_ in ss]
+    for t, s_ in zip(ts, ss):
+        if t.shape != s_.shape:
+            raise TgsrError("axpy_images: %s + alpha * %s" % (tuple(t.shape), tuple(s_.shape)))
+    if outs is None:
+        outs = [torch.empty_like(t) for t in ts]
+    tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    sp = (ctypes.c_void_p * n)(*[s_.data_ptr() for s_ in ss])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    ne = (ctypes.c_int64 * n)(*[t.numel() for t in ts])
+    check(_lib.lib().tgsr_axpy_images(n, op, tp, sp, ne, float(alpha), _stream()), "tgsr_axpy_images")
+    return outs
+
+
 # ----------------------------------------------------------------------------------------- image pyramid (uint8)
 def resize_bilinear_u8(x: torch.Tensor, out_h: int, out_w: int, htab, vtab) -> torch.Tensor:
     """Pillow's `resize(BILINEAR)` of planar uint8 images [..., H, W]; htab / vtab = (bounds, coefficients, ksize) device

@@ -40,7 +40,10 @@ def to_uint8(img):
 # where NetG_highweight's stream forks off: at the start of the step (0, the default) or behind the text tail (1).  Measured
 # neutral (round 4, hipGraph replays: bf16 31.3 k vs 31.3 k images/s, fp32 10.26 k vs 10.36 k): the step is G_SR_NET_low's
 # dependent chain either way, the other branch's kernels competing with the recurrence / text tail do not bound it.
-GH_AFTER_TEXT = os.environ.get("TGSR_GH_AFTER_TEXT", "0") == "1"
+GH_AFTER_TEXT = int(os.environ.get("TGSR_GH_AFTER_TEXT", "0"))      # 2: issued behind the text tail but dependent on the step's start only
+# fp32 path: NetG_highweight's 5x5 + tanh convolutions on the side stream, only `+ a * SRb` behind G_SR_NET_low (0: the six
+# stand-alone heads in the reference's order)
+SPLIT_HEADS = os.environ.get("TGSR_SPLIT_HEADS", "1") != "0"
 
 
 def crop_words(out, num_words):
@@ -248,13 +251,21 @@ class SRPipeline:
             low = lambda sent, words, mask, ca, proj: ex.low(bufs, LR, sent, words, mask, ca=ca, proj=proj,  # noqa: E731
                                                              defer_heads=True)
             heads = ex.high_heads
+        elif SPLIT_HEADS and not self.netGH.training:
+            # NetG_highweight's heads are `tanh(conv5x5(out_k)) + a * SRb_k` (model.py:280-297): only the addition needs
+            # G_SR_NET_low.  The convolutions (134 us at batch 16, 92 of them at 256^2) join the trunk on the side stream;
+            # what is left behind G_SR_NET_low's last head on the step's critical path is one axpy launch over the three
+            # images (~6 us) instead of the 256^2 head.
+            trunk = lambda: self.netGH.tanh_heads(self.netGH.trunk(LR, LRb))                                 # noqa: E731
+            low = lambda sent, words, mask, ca, proj: self.netGL(LR, sent, words, mask, ca=ca, proj=proj)    # noqa: E731
+            heads = self.netGH.finish_heads
         else:
             trunk = lambda: self.netGH.trunk(LR, LRb)                                                        # noqa: E731
             low = lambda sent, words, mask, ca, proj: self.netGL(LR, sent, words, mask, ca=ca, proj=proj)    # noqa: E731
             heads = self.netGH.heads
         feats = side = None
 
-        def fork_trunk():
+        def fork_trunk(start=None):
             nonlocal feats, side
             main_ = torch.cuda.current_stream(LR.device)
             if self._side is None:
@@ -262,21 +273,35 @@ class SRPipeline:
             side = self._side.get(main_.cuda_stream)     # one side stream per calling stream (callers may alternate
             if side is None:                             # lanes to overlap consecutive steps)
                 side = self._side[main_.cuda_stream] = distinct_streams(1, LR.device, avoid=[main_.cuda_stream])[0]
-            side.wait_stream(main_)                      # LR / LRb are ready on the main stream
+            if start is not None:
+                side.wait_event(start)                   # LR / LRb were ready when `start` was recorded
+            else:
+                side.wait_stream(main_)                  # LR / LRb are ready on the main stream
             with torch.cuda.stream(side):                # the trunk needs neither the text encoder nor G_SR_NET_low
                 feats = trunk()
             return main_
 
         main = None
-        if self.overlap and LR.is_cuda and not GH_AFTER_TEXT:
+        start = None
+        if self.overlap and LR.is_cuda and GH_AFTER_TEXT == 0:
             main = fork_trunk()
+        elif self.overlap and LR.is_cuda and GH_AFTER_TEXT == 2:
+            start = torch.cuda.Event()
+            start.record(torch.cuda.current_stream(LR.device))
         words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
         proj, ca, mask = self._text_tail(words_embs, sent_emb, captions)
-        if self.overlap and LR.is_cuda and GH_AFTER_TEXT:
+        if self.overlap and LR.is_cuda and GH_AFTER_TEXT in (1, 2):
             # NetG_highweight's branch has slack (G_SR_NET_low's dependent chain is the step): forked BEHIND the text tail, the
-            # recurrence and the tail - the head of that chain - run without its kernels competing for the CUs
-            main = fork_trunk()
+            # recurrence and the tail - the head of that chain - run without its kernels competing for the CUs (2: its nodes are
+            # ISSUED behind the text tail but depend on the step's start only)
+            main = fork_trunk(start)
+        gh_last = (self.overlap and LR.is_cuda and GH_AFTER_TEXT == 3 and main is None)
+        if gh_last:
+            start = torch.cuda.Event()
+            start.record(torch.cuda.current_stream(LR.device))
         res = low(sent_emb, words_embs, mask, ca, proj)
+        if gh_last:
+            main = fork_trunk(start)
         fake_imgL, attention_maps, mu, logvar = res[:4]
         pend = res[4:]       # lp path: (partial sums of the low-frequency heads still to be combined,) - heads() finishes them
         if side is not None:
