@@ -43,7 +43,10 @@ def close(a, b, atol=1e-4, rtol=1e-4):
                                                    (2, 64, 128, 8, 8, False), (5, 16, 32, 32, 32, True),
                                                    # split reductions (few pixels, many channels) and ragged 128-tiles
                                                    (4, 256, 520, 8, 8, False), (16, 3, 64, 64, 64, True),
-                                                   (3, 130, 200, 6, 10, False)])
+                                                   (3, 130, 200, 6, 10, False),
+                                                   # the image layer's own data-gradient kernel (Cin <= 4): ragged, 1 / 3 / 4 channels
+                                                   (3, 3, 64, 6, 10, True), (2, 1, 8, 8, 8, False), (1, 4, 16, 12, 260, False),
+                                                   (2, 6, 10, 8, 8, False)])      # Cout % 4 != 0: a partial last K-chunk in dgrad
 def test_conv4x4s2_fwd_dgrad_wgrad(B, Cin, Cout, H, W, leaky):
     from tgsr_amd.autograd import DownConv
     g = torch.Generator().manual_seed(B + Cin)

@@ -40,7 +40,8 @@ def to_uint8(img):
 # where NetG_highweight's stream forks off: at the start of the step (0, the default) or behind the text tail (1).  Measured
 # neutral (round 4, hipGraph replays: bf16 31.3 k vs 31.3 k images/s, fp32 10.26 k vs 10.36 k): the step is G_SR_NET_low's
 # dependent chain either way, the other branch's kernels competing with the recurrence / text tail do not bound it.
-GH_AFTER_TEXT = int(os.environ.get("TGSR_GH_AFTER_TEXT", "0"))      # 2: issued behind the text tail but dependent on the step's start only
+GH_AFTER_TEXT = int(os.environ.get("TGSR_GH_AFTER_TEXT", "-1"))     # -1: by context (see SRPipeline._forward); 0 first, 1 behind the text
+                                                                     # tail, 2 issued there but dependent on the start only, 3 last
 # fp32 path: NetG_highweight's 5x5 + tanh convolutions on the side stream, only `+ a * SRb` behind G_SR_NET_low (0: the six
 # stand-alone heads in the reference's order)
 SPLIT_HEADS = os.environ.get("TGSR_SPLIT_HEADS", "1") != "0"
@@ -283,19 +284,27 @@ class SRPipeline:
 
         main = None
         start = None
-        if self.overlap and LR.is_cuda and GH_AFTER_TEXT == 0:
+        # where NetG_highweight's branch is ISSUED.  Eager: first (0), so that the host launches it before G_SR_NET_low's chain.
+        # Inside a hipGraph capture: last (3) - the captured graph is a DAG, but ROCm 7.2's executor starts the branch that was
+        # created second only when a whole segment of the first one has been submitted: with the trunk first, its 13 small
+        # kernels run ALONE for ~110 us (bf16) / ~130 us (fp32) before the recurrence - the head of the step's dependent chain -
+        # starts (gpurun_out timelines); created last, the trunk runs in the shadow of G_SR_NET_low.
+        mode = GH_AFTER_TEXT
+        if mode < 0:
+            mode = 3 if (LR.is_cuda and torch.cuda.is_current_stream_capturing()) else 0
+        if self.overlap and LR.is_cuda and mode == 0:
             main = fork_trunk()
-        elif self.overlap and LR.is_cuda and GH_AFTER_TEXT == 2:
+        elif self.overlap and LR.is_cuda and mode == 2:
             start = torch.cuda.Event()
             start.record(torch.cuda.current_stream(LR.device))
         words_embs, sent_emb = self.text_encoder(captions, cap_lens, hidden)
         proj, ca, mask = self._text_tail(words_embs, sent_emb, captions)
-        if self.overlap and LR.is_cuda and GH_AFTER_TEXT in (1, 2):
+        if self.overlap and LR.is_cuda and mode in (1, 2):
             # NetG_highweight's branch has slack (G_SR_NET_low's dependent chain is the step): forked BEHIND the text tail, the
             # recurrence and the tail - the head of that chain - run without its kernels competing for the CUs (2: its nodes are
             # ISSUED behind the text tail but depend on the step's start only)
             main = fork_trunk(start)
-        gh_last = (self.overlap and LR.is_cuda and GH_AFTER_TEXT == 3 and main is None)
+        gh_last = (self.overlap and LR.is_cuda and mode == 3 and main is None)
         if gh_last:
             start = torch.cuda.Event()
             start.record(torch.cuda.current_stream(LR.device))
