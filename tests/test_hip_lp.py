@@ -459,7 +459,7 @@ def test_hipgraph_with_parallel_lanes(name, cfg_face, face_weights):
     LRbs = [(torch.rand(B, 3, 32, 32, generator=g) * 2 - 1).to(DEV) for _ in range(3)]
     eager = [pipe(capd, lens, LRs[k], LRbs[k])["fine"][2].clone() for k in range(3)]
     step = GraphedStep(pipe, capd, lens, LRs[0], LRbs[0], lanes=3)
-    out = step.replay([capd] * 3, None, LRs, LRbs)
+    out = step.replay([capd] * 3, [lens] * 3, LRs, LRbs)
     torch.cuda.synchronize()
     for k in range(3):
         assert torch.equal(out[k]["fine"][2], eager[k]), "lane %d differs from the eager step" % k

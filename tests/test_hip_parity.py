@@ -802,7 +802,11 @@ def test_pipeline_hipgraph_replay_matches_eager():
     for a, b in zip(out["fine"], eager):
         assert torch.equal(a, b)
     _, _, LR2, LRb2 = synthetic_batch(3, seed=8)
-    out2 = [f.clone() for f in pipe.replay(cap, None, LR2.to(DEV), LRb2.to(DEV))["fine"]]
+    out2 = [f.clone() for f in pipe.replay(None, None, LR2.to(DEV), LRb2.to(DEV))["fine"]]     # captions / lengths unchanged
+    with pytest.raises(ValueError):
+        pipe.replay(cap, None, LR2.to(DEV), LRb2.to(DEV))                     # new captions without their lengths
+    with pytest.raises(ValueError):
+        pipe.replay(cap, LR2.to(DEV), LRb2.to(DEV))                           # the old three-argument positional form
     eager2 = pipe(cap, lens, LR2.to(DEV), LRb2.to(DEV))["fine"]
     for a, b in zip(out2, eager2):
         assert torch.equal(a, b)

@@ -95,7 +95,12 @@ def _bce(logits, target):
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels):
     """losses.py:290-316.  The reference ships no discriminator class; any module exposing `COND_DNET` /
     `UNCOND_DNET` like AttnGAN's D_NET* works: real / fake / wrong-caption terms, the wrong pair being the batch
-    shifted by one (:302)."""
+    shifted by one (:302).
+    Under data parallelism (decided here): the shift stays INSIDE the shard - rank r pairs its image i with its
+    caption i + 1, so world x (B - 1) wrong pairs are scored instead of world x B - 1 (the pair that would straddle two shards
+    is dropped) and each weighs 1 / (world (B - 1)) after the gradient all-reduce's average.  The discriminators normalise with
+    per-shard BatchNorm statistics anyway (parallel.py), so this loss is a per-shard quantity by construction; no halo exchange
+    of conditions is made for one pair in B."""
     n = real_imgs.size(0)
     if getattr(netD, "supports_groups", False) and n > 1:
         # the build's D_NET*: the real and the fake pass as ONE batch whose two halves keep their own BatchNorm batch

@@ -653,11 +653,16 @@ _LENS_CACHE = {}
 def _lens_on_device(lens: tuple, dev) -> torch.Tensor:
     """int32 caption lengths on the device; cached so a steady-state step issues no blocking H2D copy."""
     key = (lens, str(dev))
-    t = _LENS_CACHE.get(key)
+    t = _LENS_CACHE.pop(key, None)
     if t is None:
-        if len(_LENS_CACHE) > 256:
-            _LENS_CACHE.clear()
-        t = _LENS_CACHE[key] = torch.tensor(lens, dtype=torch.int32).to(dev)
+        if len(_LENS_CACHE) >= 256:
+            _LENS_CACHE.pop(next(iter(_LENS_CACHE)))         # least recently used (dicts keep insertion order; hits re-insert)
+        t = torch.tensor(lens, dtype=torch.int32).to(dev)
+    _LENS_CACHE[key] = t
+    if t.is_cuda:
+        # the caller reads it on the CURRENT stream, which need not be the one it was allocated on (stream lanes share the
+        # cache): an evicted entry's memory must not be handed out again while such a read is pending
+        t.record_stream(torch.cuda.current_stream(t.device))
     return t
 
 

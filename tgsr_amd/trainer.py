@@ -428,15 +428,23 @@ class GraphedStep:
         pairs = []
         sets = [self.inputs] if self.lanes == 1 else self.inputs
         one = self.lanes == 1
+        if captions is not None and cap_lens is None:
+            # (also what an old positional call replay(captions, LR, LRb) of the three-argument signature lands on: its LR would
+            # have been taken for the lengths) - new captions with the previous batch's lengths would crop real words away
+            raise ValueError("replay: new captions need their cap_lens (host list / tensor, or a device tensor + num_words)")
         for k, dsts in enumerate(sets):
             ln = cap_lens if (one or cap_lens is None) else cap_lens[k]
             nw = num_words if (one or num_words is None or isinstance(num_words, int)) else num_words[k]
             if ln is not None:
                 if torch.is_tensor(ln) and ln.is_cuda:
+                    if ln.dim() != 1 or ln.numel() != dsts[1].numel() or ln.dtype not in (torch.int32, torch.int64):
+                        raise ValueError("replay: device cap_lens must be a 1-D int32 / int64 tensor of %d entries, got %s %s"
+                                         % (dsts[1].numel(), tuple(ln.shape), ln.dtype))
                     if ln.dtype != torch.int32:
                         ln = ln.to(torch.int32)
-                    if nw is not None:
-                        self.num_words[k] = int(nw)
+                    # lengths the host does not know: crop to what the caller says, else not at all (never to the PREVIOUS
+                    # batch's longest caption)
+                    self.num_words[k] = int(nw) if nw is not None else dsts[0].size(1)
                 else:
                     host = _host_lens(ln)
                     if min(host) < 1 or max(host) > dsts[0].size(1):
