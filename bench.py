@@ -617,6 +617,23 @@ def cpu_baseline_gan(weights, batch, budget_s=20.0):
                       "step is in the sample)" % (batch, len(ts), budget_s, med)}
 
 
+def _train_traffic(gan, conv):
+    """HBM bytes per launch (PMC counters, gfx950 corrections: tools/pmc_summary.py) of the train step's dominant convolution
+    kernel, from the newest `profiles/r*_train[_gan]_pmc.csv` (tools/profile_pmc.sh over `bench.py --mode train [--gan]`)."""
+    if not conv:
+        return {"traffic": None}
+    dom = max(conv, key=lambda k: conv[k][2])
+    fname, rows = pmc_table("train_gan" if gan else "train")
+    pre = dom[:-len("_kernel")] if dom.endswith("_kernel") else dom      # wino_wgrad -> wino_wgrad_kernel<..>, wino_wgrad_dma_kernel<..>
+    hit = [r for k, r in rows.items() if k.startswith(pre) and "reduce" not in k and "pack" not in k]
+    if not hit:
+        return {"traffic": None, "traffic_kernel": dom, "traffic_from": fname}
+    n = sum(float(r["launches"]) for r in hit)
+    mb = sum(float(r["launches"]) * float(r["avg_HBM_MB_per_launch"]) for r in hit) / n
+    return {"traffic": round(mb * 1e6), "traffic_kernel": dom, "traffic_from": fname,
+            "traffic_note": "launch-weighted mean over the instances of that kernel in the profiled step (batch 16)"}
+
+
 def train_object(args, rank, world, dist, dev, weights, fence):
     """BASELINE configs[2] inside the default run: the generator train step (fwd + bwd + Adam + EMA on MSE + KL) and the
     G/D alternation (three discriminators), each timed with the same fencing as the headline and priced by the MACs its
@@ -721,7 +738,7 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
                 "kernels": {k: {"launches": v[0], "ms": round(v[2] * 1e3, 3), "executed_fraction": round(EXECUTED_MAC_FRACTION[k], 4),
                                 "executed_TFLOPs": round(v[1] * EXECUTED_MAC_FRACTION[k] / v[2] / 1e12, 2)}
                             for k, v in sorted(conv.items(), key=lambda kv: -kv[1][2])},
-                "traffic": None,
+                **_train_traffic(gan, conv),
                 "note": "`achieved` / `frac`: MACs the convolution kernels of forward, data gradient and weight gradient "
                         "really issue (direct-form FLOPs of every launch x the kernel's executed fraction), over the "
                         "WHOLE step time (BatchNorm passes, losses, optimizer, EMA included); `conv_kernels_only`: the "

@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# TGSR_LIB_PATH: another build of the same library (tools/lp_conv_experiments.sh); never a different implementation
+# TGSR_LIB_PATH: another build of the same library (the stamp / experiment builds of tools/); never a different implementation
 LIB_PATH = os.environ.get("TGSR_LIB_PATH") or os.path.join(_HERE, "lib", "libtgsr_hip.so")
 ABI_VERSION = 2
 

@@ -55,8 +55,9 @@ constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the
   return (CIN == 64 || (COUT / 32) * (TR / 4) * 16 >= 64) ? 2 : 3;
 }
 
-// (timing experiments - parts of this kernel compiled out, in-kernel clock stamps - live in a diagnostic copy of this file:
-// tools/diag/tgsr_lp_conv_dbg.hip, built by tools/lp_conv_experiments.sh; nothing of them is in the shipped kernel)
+// (the timing experiments of DESIGN.md 3.8 - parts of this kernel compiled out, in-kernel clock stamps - were made on a diagnostic
+// COPY of this file, tools/diag/tgsr_lp_conv_dbg.hip; a second copy of a kernel drifts, so it was removed in round 5 - it is in the
+// history at 67ad6ee with its drivers tools/lp_conv_experiments.sh / lp_conv_clock.py)
 template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
 __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
   constexpr int NCB = COUT / 32, RW = TR / 4, TC = 34, NPIX = (TR + 2) * TC;

@@ -3,7 +3,7 @@
 # bench lines (default fp32, bf16 graph, f16 graph, bf16 eager lanes, bf16 B=8 graph, train) + rocprofv3 stats / PMC of
 # the fp32 and bf16 paths.  Everything lands in gpurun_out/<tag>_*; copy what is to be judged into profiles/.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-all}      # all | bench | prof
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
@@ -34,12 +34,13 @@ echo "x16 done"
 TGSR_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_rehearsal_2ranks.json 2> $OUT/${TAG}_bench_rehearsal.err || echo "rehearsal failed"
 fi
 if [ "$PART" != "bench" ]; then
-bash tools/profile_stats.sh ${TAG}_train --mode train --steps 8 --warmup 2 --no-cpu-baseline
-bash tools/profile_stats.sh ${TAG}_train_gan --mode train --gan --steps 4 --warmup 2 --no-cpu-baseline
-rm -f $OUT/${TAG}_train_stats.log $OUT/${TAG}_train_gan_stats.log
+# (counter passes incl. FETCH_SIZE / WRITE_SIZE for the train steps as well: `train.roofline.traffic`)
+bash tools/profile_pmc.sh ${TAG}_train --mode train --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline
+bash tools/profile_pmc.sh ${TAG}_train_gan --mode train --gan --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline
+rm -f $OUT/${TAG}_train_*.log $OUT/${TAG}_train_gan_*.log
 echo "train profiles done"
-bash tools/profile_pmc.sh ${TAG}_fp32 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial --extras none
-bash tools/profile_pmc.sh ${TAG}_bf16 --dtype bf16 --steps 4 --warmup 2 --no-cpu-baseline --profile-every 0 --serial --extras none
+bash tools/profile_pmc.sh ${TAG}_fp32 --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --profile-every 0 --serial --extras none
+bash tools/profile_pmc.sh ${TAG}_bf16 --dtype bf16 --steps 4 --warmup 2 --repeats 1 --no-cpu-baseline --profile-every 0 --serial --extras none
 fi
 for f in $OUT/${TAG}_bench_*.json; do python3 -c "
 import json,sys
