@@ -587,6 +587,24 @@ int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B, int Cin, 
                         void* stream);
 
 /*
+ * The two ResBlocks of a generator stage (util.py:110-130 as called by INIT_STAGE_GImgup / NEXT_STAGE_G, util.py:773, :818) on
+ * 64-channel lp images in ONE launch: four dependent convolutions
+ *     tmp = GLU(affine0(conv(x, w0)));  a = affine1(conv(tmp, w1)) + x;  tmp = GLU(affine2(conv(a, w2)));  b = affine3(conv(tmp, w3)) + a
+ * each computed per tile by the very code of tgsr_lp_conv3x3_fwd (bit-identical results); a tile's dependence on its neighbours'
+ * previous layer is guarded by per-tile flags in device memory instead of a kernel boundary (what a dependent launch costs in a
+ * replayed graph is more than these layers' work at 32^2 and 64^2).  wpack / scale / shift: HOST arrays of 4 device pointers
+ * (packs of [128,64,3,3], [64,64,3,3], [128,64,3,3], [64,64,3,3]; scale / shift NULL together = identity).  x, tmp, a_out, b_out:
+ * four distinct images [B][H+2][W+2][cpitch >= 64], channels [0, 64).  flags: tgsr_lp_resblocks_flag_elems(B, H, W) uint32,
+ * zeroed ONCE by the caller and then owned by this function across launches (one buffer per set of images: concurrent launches
+ * on different streams need different flag buffers); its last word is set to 1 if a wait ever timed out (results invalid).
+ * W % 32 == 0, H % 4 == 0.
+ */
+int64_t tgsr_lp_resblocks_flag_elems(int B, int H, int W);
+int tgsr_lp_resblocks_fwd(int dtype, const void* x, int x_cpitch, int B, int H, int W, const void* const* wpack,
+                          const float* const* scale, const float* const* shift, void* tmp, int tmp_cpitch, void* a_out,
+                          int a_cpitch, void* b_out, int b_cpitch, unsigned* flags, void* stream);
+
+/*
  * upBlock (util.py:74-80: Upsample(x2, nearest) -> conv3x3 -> BN -> GLU) on lp images by sub-pixel decomposition: each
  * output phase (row & 1, column & 1) is a 2x2 convolution of the LOW-resolution image with taps pre-summed in fp32 and
  * rounded once to `dtype` - 16 products per low-res pixel instead of 36 (tgsr_lp_conv3x3_fwd(upsample = 1) is the

@@ -200,6 +200,11 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     sc, sh = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
     chk(T.lp_conv3x3.default, (xi, wp, 64, 64, sc, sh, True, False, None, 0, lp.new_image(2, 8, 32, 64, "bf16", DEV), 32), test_utils=basic)
     chk(T.lp_conv3x3.default, (xi, wp, 64, 64, sc, sh, False, False, xi, 0, lp.new_image(2, 8, 32, 64, "bf16", DEV), 0), test_utils=basic)
+    rb_packs = [lp.pack_conv3x3_weight(R(co, 64, 3, 3) / 24.0, "bf16") for co in (128, 64, 128, 64)]
+    rb_aff = [torch.ones(co, device=DEV) for co in (128, 64, 128, 64)], [torch.zeros(co, device=DEV) for co in (128, 64, 128, 64)]
+    img64 = lambda: lp.new_image(2, 8, 32, 64, "bf16", DEV)                                   # noqa: E731
+    chk(T.lp_resblocks.default, (xi, rb_packs, rb_aff[0], rb_aff[1], img64(), img64(), img64(), lp.resblocks_flags(2, 8, 32, DEV)),
+        test_utils=basic)
     wu = lp.pack_upconv_weight(R(64, 64, 3, 3) / 24.0, "bf16")
     chk(T.lp_upconv_glu.default, (xi, wu, 64, 64, sc, sh, lp.new_image(2, 16, 64, 32, "bf16", DEV), 0), test_utils=basic)
     p3 = lp.pack_to3_weight(R(3, 32, 3, 3) / 17.0, "bf16")

@@ -673,3 +673,78 @@ def test_lp_pipeline_fused_heads_equal_standalone_heads(name, cfg_face, face_wei
             np.testing.assert_allclose(fused[k][i].cpu().numpy(), plain[k][i].cpu().numpy(), atol=3e-5, rtol=1e-5)
     for i in range(3):
         assert torch.equal(fused["att"][i], plain["att"][i])
+
+
+@pytest.mark.parametrize("name,td,ulp", DTYPES)
+@pytest.mark.parametrize("B,H,W", [(3, 32, 32), (2, 64, 64), (16, 32, 32), (1, 12, 96), (5, 4, 32)])
+def test_lp_resblocks_chain_equals_four_launches(B, H, W, name, td, ulp):
+    """tgsr_lp_resblocks_fwd - the two ResBlocks of a generator stage (four dependent convolutions, util.py:110-130) in ONE launch,
+    neighbouring tiles synchronised through device flags - against four tgsr_lp_conv3x3_fwd launches: bit-identical images, also on
+    the second and third launch over the same flag buffer (the flags are never reset), the error word untouched; one-tile images and
+    several tile columns included."""
+    from tgsr_amd import custom_ops, lp, ops          # noqa: F401  (custom_ops registers torch.ops.tgsr.*)
+    g = torch.Generator().manual_seed(B * 100 + H + W)
+    x = lp.from_nchw(OL.rnd(torch.randn(B, 64, H, W, generator=g), td).to(DEV), name, cpitch=64)
+    ws = [torch.randn(co, 64, 3, 3, generator=g) / 24.0 for co in (128, 64, 128, 64)]
+    packs = [lp.pack_conv3x3_weight(w.to(DEV), name) for w in ws]
+    scales = [(1 + 0.1 * torch.randn(w.shape[0], generator=g)).to(DEV) for w in ws]
+    shifts = [(0.1 * torch.randn(w.shape[0], generator=g)).to(DEV) for w in ws]
+    img = lambda: lp.new_image(B, H, W, 64, name, DEV)                        # noqa: E731
+    # reference: the four launches the executor issued before
+    tmp, a, b = img(), img(), img()
+    lp.conv3x3(x, packs[0], 64, 128, scales[0], shifts[0], glu=True, out=tmp)
+    lp.conv3x3(tmp, packs[1], 64, 64, scales[1], shifts[1], residual=x, out=a)
+    lp.conv3x3(a, packs[2], 64, 128, scales[2], shifts[2], glu=True, out=tmp)
+    lp.conv3x3(tmp, packs[3], 64, 64, scales[3], shifts[3], residual=a, out=b)
+    torch.cuda.synchronize()
+    flags = lp.resblocks_flags(B, H, W, DEV)
+    tmp2, a2, b2 = img(), img(), img()
+    for rep in range(3):
+        if rep:
+            a2.zero_(), b2.zero_(), tmp2.zero_()
+        torch.ops.tgsr.lp_resblocks(x, packs, scales, shifts, tmp2, a2, b2, flags)
+        torch.cuda.synchronize()
+        assert int(flags[-1]) == 0, "a flag wait timed out"
+        assert int(flags[0]) == rep + 1 and bool((flags[:-1] == rep + 1).all())
+        assert torch.equal(a2, a) and torch.equal(b2, b) and torch.equal(tmp2, tmp), "launch %d differs from the four launches" % rep
+    with pytest.raises(ops.TgsrError):
+        lp.resblocks(x, packs, scales, shifts, tmp2, a2, b2, flags[:-1])     # not this size's flag buffer
+
+
+@pytest.mark.parametrize("name", ["bf16", "f16"])
+def test_lp_pipeline_resblock_chain_equals_separate_launches(name, cfg_face, face_weights, monkeypatch):
+    """The whole reduced-precision step with the 32^2 and 64^2 stages' ResBlocks as one launch each (TGSR_LP_CHAIN=1) == the four
+    launches per stage, bit for bit: eager, replayed from a hipGraph, and as three parallel lanes of one graph (three instances of
+    the flag-synchronised kernel in flight at once, each with its own flag buffer)."""
+    from tgsr_amd import lp_pipeline
+    from tgsr_amd.trainer import GraphedStep
+    B = 4
+    cap, lens, LR, LRb = O.synthetic_batch(B, seed=12)
+    args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
+    monkeypatch.setattr(lp_pipeline, "CHAIN", True)        # off by default: measured slower than four launches (DESIGN.md 3.17)
+    chained = _pipe(cfg_face, face_weights, name)
+    a = chained(*args)
+    assert any(st.get("flags") is not None for bufs in chained._lp.bufs.values() for st in bufs["gl"])   # the chain kernel did run
+    monkeypatch.setattr(lp_pipeline, "CHAIN", False)
+    b = _pipe(cfg_face, face_weights, name)(*args)
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert torch.equal(a["fine"][k], b["fine"][k]) and torch.equal(a["fake"][k], b["fake"][k]) and torch.equal(a["att"][k], b["att"][k])
+    monkeypatch.setattr(lp_pipeline, "CHAIN", True)
+    want = [f.clone() for f in a["fine"]]
+    chained.capture(*args)
+    for _ in range(3):
+        r = chained.replay()
+        torch.cuda.synchronize()
+        for x, y in zip(r["fine"], want):
+            assert torch.equal(x, y)
+    step = GraphedStep(chained, *args, lanes=3)
+    out = step.replay()
+    torch.cuda.synchronize()
+    for lane in out:
+        for x, y in zip(lane["fine"], want):
+            assert torch.equal(x, y)
+    for bufs in step.bufs:
+        for st in bufs["gl"]:
+            if st.get("flags") is not None:
+                assert int(st["flags"][-1]) == 0

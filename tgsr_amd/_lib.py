@@ -120,6 +120,8 @@ SIGNATURES = {
     "tgsr_lp_packed_conv3x3_elems": (_i64, [_i, _i]),
     "tgsr_lp_pack_conv3x3_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_conv3x3_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "tgsr_lp_resblocks_flag_elems": (_i64, [_i, _i, _i]),
+    "tgsr_lp_resblocks_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "tgsr_lp_packed_upconv_elems": (_i64, [_i, _i]),
     "tgsr_lp_pack_upconv_weight": (_i, [_i, _vp, _vp, _i, _i, _vp]),
     "tgsr_lp_upconv_glu_fwd": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp]),

@@ -58,8 +58,19 @@ constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the
 // (the timing experiments of DESIGN.md 3.8 - parts of this kernel compiled out, in-kernel clock stamps - were made on a diagnostic
 // COPY of this file, tools/diag/tgsr_lp_conv_dbg.hip; a second copy of a kernel drifts, so it was removed in round 5 - it is in the
 // history at 67ad6ee with its drivers tools/lp_conv_experiments.sh / lp_conv_clock.py)
+// LDS bytes of one workgroup of lp_conv3x3_body (the constants are restated inside the body)
+template <int CIN, int COUT, int TR>
+constexpr int lp_conv_smem_bytes() {
+  constexpr int NSL = CIN / 8, TILE_INSTR = ((TR + 2) * 34 * NSL + 63) / 64, NK16 = CIN / 16;
+  constexpr int KC16_WANT = 128 / COUT > 1 ? 128 / COUT : 1, KC16 = KC16_WANT < NK16 ? KC16_WANT : NK16;
+  return TILE_INSTR * 1024 + 3 * (3 * (COUT / 32) * KC16) * 1024;
+}
+
+// One workgroup tile (index t = (b * tiles_y + ty) * tiles_x + tx) of the convolution; `smem`: lp_conv_smem_bytes() bytes of LDS,
+// 1024-byte aligned.  A device function so that lp_conv3x3_kernel (one tile per workgroup) and lp_resblocks_kernel (the four
+// convolutions of two ResBlocks, one after the other in the same workgroup) run the SAME instructions per tile.
 template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
-__global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
+__device__ __forceinline__ void lp_conv3x3_body(const LpConvArgs& a, int t, char* smem) {
   constexpr int NCB = COUT / 32, RW = TR / 4, TC = 34, NPIX = (TR + 2) * TC;
   constexpr int PB = CIN * 2, NSL = CIN / 8;
   constexpr int TILE_SLOTS = NPIX * NSL, TILE_INSTR = (TILE_SLOTS + 63) / 64, TILE_BYTES = TILE_INSTR * 1024;
@@ -78,14 +89,13 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
   constexpr int CHUNK_INSTR = 3 * NCB * KC16, CHUNK_BYTES = CHUNK_INSTR * 1024;
   constexpr int NKG = NK16 / KC16, NCH = 3 * NKG;
   static_assert(NK16 % KC16 == 0, "chunking");
-  __shared__ __attribute__((aligned(1024))) char smem[TILE_BYTES + NBUF * CHUNK_BYTES];
+  static_assert(TILE_BYTES + NBUF * CHUNK_BYTES == lp_conv_smem_bytes<CIN, COUT, TR>(), "LDS size");
   char* tile = smem;
   char* wbuf = smem + TILE_BYTES;
   float* aff = reinterpret_cast<float*>(smem + TILE_BYTES + NBUF * CHUNK_BYTES - COUT * 8);   // written after the main loop
 
   const int tid = threadIdx.x, lane = tid & 63, c0 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = t % a.tiles_x;
   t /= a.tiles_x;
   const int ty = t % a.tiles_y;
@@ -248,6 +258,97 @@ __global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x
     const u32x4 v = *reinterpret_cast<const u32x4*>(stg + S * 16);
     *reinterpret_cast<u32x4*>(ob + (pw >> 5) * orow + (int64_t)(pw & 31) * (a.ocp * 2) + q * 16) = v;
   }
+}
+
+template <class T, int CIN, int COUT, int EPI, bool UP, int TR>
+__global__ __launch_bounds__(256, (lp_conv_occ<CIN, COUT, TR>())) void lp_conv3x3_kernel(LpConvArgs a) {
+  __shared__ __attribute__((aligned(1024))) char smem[lp_conv_smem_bytes<CIN, COUT, TR>()];
+  lp_conv3x3_body<T, CIN, COUT, EPI, UP, TR>(a, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The two ResBlocks of a generator stage (util.py:110-130 behind INIT_STAGE_GImgup / NEXT_STAGE_G, :773, :818) - four dependent
+// convolutions on 64 channels - in ONE launch.  At 32^2 and 64^2 a convolution's body is ~5 us of work behind ~7 us of
+// kernel-to-kernel dependency latency in a replayed graph, and these eight layers sit on the step's dependent chain (DESIGN.md
+// 3.8e, 3.17).  A workgroup owns one tile (image b, rows ty, columns tx) through ALL four layers:
+//     L0  x   -> tmp   conv 64 -> 128 + affine + GLU          L2  a   -> tmp   the same for the second block
+//     L1  tmp -> a     conv 64 -> 64 + affine + x             L3  tmp -> b     ... + a
+// and what a layer reads from its neighbours - the one-pixel halo of the previous layer's output - is guarded by per-tile flags
+// instead of a kernel boundary: before layer k a workgroup waits until the (up to 8) neighbouring tiles of the SAME image have
+// published layer k - 1 (which also means they are done READING the buffer layer k is about to overwrite: tmp is written twice).
+// A flag holds the number of launches that have published it; every launch adds exactly one to each, so "published in this
+// launch" is "> the value my own flag had when I started" - nothing to reset between launches (hipGraph replays pass the same
+// arguments every time).
+// Progress: workgroups are dispatched in blockIdx order, the tile index IS blockIdx (no XCD remap here), and a workgroup only
+// waits for tiles at most tiles_x + 1 indices ahead of it - so of any set of resident workgroups all but the last few rows can
+// finish and free their slots, however many other kernels (other graph lanes running this same kernel included) compete for the
+// CUs: no workgroup ever waits for one that cannot be scheduled.  Every wait is bounded (2^20 polls, a fraction of a second) and reports through
+// the error word instead of hanging the device.
+struct LpChainArgs {
+  LpConvArgs l[4];
+  unsigned* flags;          // [4][ntiles] + 1 error word
+  int ntiles;
+};
+
+template <class T, int TR>
+__global__ __launch_bounds__(256, 2) void lp_resblocks_kernel(LpChainArgs c) {
+  constexpr int SM = lp_conv_smem_bytes<64, 128, TR>() > lp_conv_smem_bytes<64, 64, TR>() ? lp_conv_smem_bytes<64, 128, TR>()
+                                                                                         : lp_conv_smem_bytes<64, 64, TR>();
+  __shared__ __attribute__((aligned(1024))) char smem[SM];
+  __shared__ unsigned s_target;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int tiles_x = c.l[0].tiles_x, tiles_y = c.l[0].tiles_y;
+  const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y;
+  if (tid == 0) s_target = __hip_atomic_load(c.flags + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  __syncthreads();
+  const unsigned target = s_target;
+  // this thread's neighbour (threads 0 .. 8; 4 = the tile itself: nothing to wait for)
+  int nb = -1;
+  if (tid < 9 && tid != 4) {
+    const int ny = ty + tid / 3 - 1, nx = tx + tid % 3 - 1;
+    if ((unsigned)ny < (unsigned)tiles_y && (unsigned)nx < (unsigned)tiles_x) nb = t + (ny - ty) * tiles_x + (nx - tx);
+  }
+  // hand-off protocol of MI355X_MICROARCH.md (inter-workgroup visibility): producer - every storing wave drains its stores, the
+  // workgroup's barrier, then ONE lane: agent-scope release (writes back this XCD's L2), drained, relaxed agent flag store;
+  // consumer - relaxed polls, ONE agent-scope acquire (invalidates this CU's L1), drained, the workgroup's barrier, plain loads.
+  auto publish = [&](int k) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(c.flags + k * c.ntiles + t, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto wait_for = [&](int k) {                     // the neighbours have published layer k
+    if (tid < 64) {                                // wave 0: lanes 0 .. 8 poll, then one acquire for the CU
+      if (nb >= 0) {
+        const unsigned* f = c.flags + k * c.ntiles + nb;
+        int it = 0;
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++it > (1 << 20)) {                  // never spin forever: flag the launch as failed and go on
+            __hip_atomic_store(c.flags + 4 * c.ntiles, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  };
+  lp_conv3x3_body<T, 64, 128, kEpiGlu, false, TR>(c.l[0], t, smem);
+  publish(0);
+  wait_for(0);
+  lp_conv3x3_body<T, 64, 64, kEpiRes, false, TR>(c.l[1], t, smem);
+  publish(1);
+  wait_for(1);
+  lp_conv3x3_body<T, 64, 128, kEpiGlu, false, TR>(c.l[2], t, smem);
+  publish(2);
+  wait_for(2);
+  lp_conv3x3_body<T, 64, 64, kEpiRes, false, TR>(c.l[3], t, smem);
+  publish(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -793,6 +894,52 @@ extern "C" int tgsr_lp_conv3x3_fwd(int dtype, const void* x, int x_cpitch, int B
   const int epi = epilogue == TGSR_EPI_AFFINE_GLU ? kEpiGlu : (residual ? kEpiRes : kEpiAffine);
   if (dtype == TGSR_DT_BF16) return launch_lp_conv<BF16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
   return launch_lp_conv<F16>(a, Cin, Cout, epi, upsample != 0, as_stream(stream));
+}
+
+extern "C" int64_t tgsr_lp_resblocks_flag_elems(int B, int H, int W) {
+  if (B < 1 || H < 4 || W < 32 || H % 4 != 0 || W % 32 != 0) return 0;
+  return 4ll * B * (H / 4) * (W / 32) + 1;
+}
+
+extern "C" int tgsr_lp_resblocks_fwd(int dtype, const void* x, int x_cpitch, int B, int H, int W, const void* const* wpack,
+                                     const float* const* scale, const float* const* shift, void* tmp, int tmp_cpitch, void* a_out,
+                                     int a_cpitch, void* b_out, int b_cpitch, unsigned* flags, void* stream) {
+  if (!x || !wpack || !scale || !shift || !tmp || !a_out || !b_out || !flags || B < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  if (dtype != TGSR_DT_BF16 && dtype != TGSR_DT_F16) return TGSR_EINVAL;
+  if (W % 32 != 0 || H % 4 != 0) return TGSR_EUNSUPPORTED;
+  const int cps[4] = {x_cpitch, tmp_cpitch, a_cpitch, b_cpitch};
+  const void* ptrs[4] = {x, tmp, a_out, b_out};
+  int maxcp = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (cps[i] < 64 || cps[i] % 8 != 0 || (reinterpret_cast<uintptr_t>(ptrs[i]) & 15)) return TGSR_EUNSUPPORTED;
+    maxcp = cps[i] > maxcp ? cps[i] : maxcp;
+    if (!wpack[i] || (reinterpret_cast<uintptr_t>(wpack[i]) & 15) || (scale[i] == nullptr) != (shift[i] == nullptr)) return TGSR_EINVAL;
+  }
+  if (tmp == x || tmp == a_out || tmp == b_out || a_out == x || a_out == b_out) return TGSR_EINVAL;   // four distinct roles
+  if ((int64_t)(H + 2) * (W + 2) * maxcp * 2 >= (1ll << 31)) return TGSR_EUNSUPPORTED;
+  LpChainArgs c;
+  const char* in[4] = {static_cast<const char*>(x), static_cast<const char*>(tmp), static_cast<const char*>(a_out),
+                       static_cast<const char*>(tmp)};
+  const int incp[4] = {x_cpitch, tmp_cpitch, a_cpitch, tmp_cpitch};
+  char* out[4] = {static_cast<char*>(tmp), static_cast<char*>(a_out), static_cast<char*>(tmp), static_cast<char*>(b_out)};
+  const int outcp[4] = {tmp_cpitch, a_cpitch, tmp_cpitch, b_cpitch};
+  const char* res[4] = {nullptr, static_cast<const char*>(x), nullptr, static_cast<const char*>(a_out)};
+  const int rescp[4] = {0, x_cpitch, 0, a_cpitch};
+  for (int i = 0; i < 4; ++i) {
+    LpConvArgs& a = c.l[i];
+    a.x = in[i]; a.xcp = incp[i]; a.B = B; a.H = H; a.W = W; a.Hi = H; a.Wi = W;
+    a.wpack = static_cast<const char*>(wpack[i]); a.scale = scale[i]; a.shift = shift[i];
+    a.res = res[i]; a.rcp = rescp[i]; a.rco = 0;
+    a.out = out[i]; a.ocp = outcp[i]; a.oco = 0;
+    a.tiles_x = W / 32; a.tiles_y = H / 4;
+    a.hw = nullptr; a.hpart = nullptr;
+  }
+  c.flags = flags;
+  c.ntiles = B * (H / 4) * (W / 32);
+  const dim3 grid((unsigned)c.ntiles);
+  if (dtype == TGSR_DT_BF16) hipLaunchKernelGGL((lp_resblocks_kernel<BF16, 4>), grid, dim3(256), 0, as_stream(stream), c);
+  else hipLaunchKernelGGL((lp_resblocks_kernel<F16, 4>), grid, dim3(256), 0, as_stream(stream), c);
+  return note_launch(hipGetLastError(), "lp_resblocks_kernel");
 }
 
 extern "C" int64_t tgsr_lp_packed_upconv_elems(int Cout, int Cin) { return (int64_t)Cout * Cin * 16; }

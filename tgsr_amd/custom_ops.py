@@ -498,6 +498,10 @@ lp_conv3x3 = _define("lp_conv3x3(Tensor x, Tensor wpack, int cin, int cout, Tens
                      lambda x, wp, cin, cout, s, t, glu, up, res, rco, out, oco:
                      (_lp().conv3x3(x, wp, cin, cout, s, t, glu=glu, upsample=up, residual=res, res_coff=rco, out=out, out_coff=oco),
                       None)[1], lambda *a: None)
+lp_resblocks = _define("lp_resblocks(Tensor x, Tensor[] wpacks, Tensor[] scales, Tensor[] shifts, Tensor(a!) tmp, Tensor(b!) a, "
+                       "Tensor(c!) b, Tensor(d!) flags) -> ()",
+                       lambda x, wp, sc, sh, tmp, a, b, flags: (_lp().resblocks(x, list(wp), list(sc), list(sh), tmp, a, b, flags), None)[1],
+                       lambda *a: None)
 lp_upconv_glu = _define("lp_upconv_glu(Tensor x, Tensor wpack, int cin, int cout, Tensor? scale, Tensor? shift, Tensor(a!) out, "
                         "int out_coff) -> ()",
                         lambda x, wp, cin, cout, s, t, out, oco: (_lp().upconv_glu(x, wp, cin, cout, s, t, out=out, out_coff=oco), None)[1],

@@ -127,6 +127,49 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, cin: int, cout: int, scale, sh
     return out
 
 
+def resblocks_flags(B: int, H: int, W: int, device) -> torch.Tensor:
+    """The flag buffer of `resblocks` for images of this size: zeroed here once, then owned by the kernel across launches (one
+    per set of activation images)."""
+    n = _lib.lib().tgsr_lp_resblocks_flag_elems(B, H, W)
+    if n <= 0:
+        raise TgsrError("lp.resblocks: unsupported image size %d x %d" % (H, W))
+    return torch.zeros(n, dtype=torch.int32, device=device)
+
+
+def resblocks_supported(cin: int, H: int, W: int) -> bool:
+    return cin == 64 and W % 32 == 0 and H % 4 == 0
+
+
+def resblocks(x: torch.Tensor, wpacks, scales, shifts, tmp: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
+              flags: torch.Tensor) -> torch.Tensor:
+    """Two ResBlocks (four dependent conv3x3 on 64 channels: GLU, + residual, GLU, + residual) in one launch
+    (tgsr_lp_resblocks_fwd): x -> tmp -> a -> tmp -> b, bit-identical to four `conv3x3` launches.  Returns b."""
+    import ctypes
+    _need_hip(x, tmp, a, b, flags, *wpacks, *scales, *shifts)
+    B, H, W, xcp = _img(x, "x")
+    dims = [_img(t, n) for t, n in ((tmp, "tmp"), (a, "a"), (b, "b"))]
+    if any(d[:3] != (B, H, W) for d in dims) or any(t.dtype != x.dtype for t in (tmp, a, b)) or len(wpacks) != 4:
+        raise TgsrError("lp.resblocks: images %s / dtypes do not match x %s" % ([tuple(t.shape) for t in (tmp, a, b)], tuple(x.shape)))
+    L = _lib.lib()
+    for i, wp in enumerate(wpacks):
+        if wp.dtype != x.dtype or wp.numel() != L.tgsr_lp_packed_conv3x3_elems(128 if i % 2 == 0 else 64, 64):
+            raise TgsrError("lp.resblocks: pack %d is not a [%d, 64, 3, 3] filter of the images' type" % (i, 128 if i % 2 == 0 else 64))
+    if flags.dtype != torch.int32 or flags.numel() != L.tgsr_lp_resblocks_flag_elems(B, H, W):
+        raise TgsrError("lp.resblocks: flags must come from lp.resblocks_flags(%d, %d, %d)" % (B, H, W))
+    wp = (ctypes.c_void_p * 4)(*[w.data_ptr() for w in wpacks])
+    sc = (ctypes.c_void_p * 4)(*[None if s_ is None else s_.data_ptr() for s_ in scales])
+    sh = (ctypes.c_void_p * 4)(*[None if s_ is None else s_.data_ptr() for s_ in shifts])
+    from . import ops
+    e0 = ops._ev() if ops.profile is not None else None
+    rc = L.tgsr_lp_resblocks_fwd(DT[x.dtype], _p(x), xcp, B, H, W, wp, sc, sh, _p(tmp), dims[0][3], _p(a), dims[1][3], _p(b),
+                                 dims[2][3], _p(flags), _stream())
+    check(rc, "tgsr_lp_resblocks_fwd")
+    if ops.profile is not None:
+        px = B * H * W
+        ops.profile.append(("lp_conv3x3_kernel", 2.0 * px * 9 * 64 * (128 + 64 + 128 + 64), 2 * (px * 64 * 10 + 9 * 64 * 384), e0, ops._ev()))
+    return b
+
+
 class AttFuse:
     """Arguments of a word attention fused into the kernel that produces h (tgsr_lp_stem_att_fwd,
     tgsr_lp_upconv_glu_att_fwd): pack / nsets = ops.text_tail(..., lp_dtype)'s att_pack of this batch, `index` = which

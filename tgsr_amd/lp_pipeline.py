@@ -35,6 +35,14 @@ F16_TRUNK = os.environ.get("TGSR_LP_BF16_TRUNK", "f16") != "bf16"
 # the previous stage's lp_upconv_glu_kernel for the others; same device function as the stand-alone kernel: same bits):
 # three launches - and the re-read of h - leave G_SR_NET_low's dependent chain.  TGSR_LP_FUSE_ATT=0: stand-alone launches.
 FUSE_ATT = os.environ.get("TGSR_LP_FUSE_ATT", "1") != "0"
+# the two ResBlocks of a G_SR_NET_low stage (four dependent convolutions) as ONE launch, tiles synchronised through device flags
+# (tgsr_lp_resblocks_fwd; same per-tile code, bit-identical).  Built in round 5 for the 32^2 / 64^2 stages, whose layers are shorter
+# than the ~7 us a dependent kernel costs in a replayed graph - and measured SLOWER: on MI355X an in-kernel hand-off between
+# workgroups needs an agent-scope release (write-back of the XCD's L2: ~6.5 us with a freshly written 16 KB tile) and an acquire
+# (L1 invalidate, ~1.7 us) per layer, more than the kernel boundary it replaces (bf16 batch 16 one lane: 28.1 k images/s with it,
+# 32.0 k without).  OFF by default; TGSR_LP_CHAIN=1 switches it on (the tests do).
+CHAIN = os.environ.get("TGSR_LP_CHAIN", "0") == "1"
+CHAIN_MAX_PIXELS = 64 * 64
 
 
 def trunk_dtype_of(dtype):
@@ -225,10 +233,20 @@ class LpExecutor:
             if not fused_next:
                 atts.append(C.lp_word_attention(bb["wide"], srcs[k], mask, T, st["att"].correct_mask, 32))
             x = bb["wide"]
-            for (c0, c1), o in zip(st["res"], (bb["a"], bb["b"])):             # R_NUM = 2 ResBlocks (util.py:110-130)
-                c0(x, glu=True, out=bb["tmp"])
-                c1(bb["tmp"], residual=x, out=o)
-                x = o
+            Hk, Wk = x.shape[1] - 2, x.shape[2] - 2
+            if (CHAIN and len(st["res"]) == 2 and Hk * Wk <= CHAIN_MAX_PIXELS and lp.resblocks_supported(st["res"][0][0].cin, Hk, Wk)
+                    and all(c.cin == 64 for pair in st["res"] for c in pair)):
+                if bb.get("flags") is None:
+                    bb["flags"] = lp.resblocks_flags(B, Hk, Wk, x.device)
+                cs = [c for pair in st["res"] for c in pair]
+                C.lp_resblocks(x, [c.wpack for c in cs], [c.scale for c in cs], [c.shift for c in cs], bb["tmp"], bb["a"], bb["b"],
+                               bb["flags"])
+                x = bb["b"]
+            else:
+                for (c0, c1), o in zip(st["res"], (bb["a"], bb["b"])):         # R_NUM = 2 ResBlocks (util.py:110-130)
+                    c0(x, glu=True, out=bb["tmp"])
+                    c1(bb["tmp"], residual=x, out=o)
+                    x = o
             nxt = bufs["gl"][k + 1]["wide"] if k < last else bufs["h3"]
             # the NEXT stage's attention inside this upBlock (its output is that stage's h)
             fused_next = pack is not None and k < last and st["up"].att_fusable(x)
