@@ -248,6 +248,21 @@ int tgsr_bigru_table_fwd(const int64_t* captions, int width, const int32_t* cap_
                          void* stream);
 
 /*
+ * Training path of the GRU branch (the reference trains whichever cell cfg.RNN_TYPE names, pretrain_DAMSM.py:49-98 through
+ * util.py:233-260).  tgsr_bigru_train_fwd: x [B][Tmax][ninput] = the embedded, dropped-out captions; gates_ws [B*Tmax][2][3H]
+ * workspace; acts [B][Tmax][2][4][H] = (r, z, n, W_hn h + b_hn) of every step.  tgsr_bigru_bwd walks every (sample, direction) back
+ * through time from d_words [B][2H][Tmax] and d_sent [B][2H] (NULL = zero): dgx / dgh [B][Tmax][2][3H] = the gradients at the
+ * input-side (x W_ih^T + b_ih) and hidden-side (h W_hh^T + b_hh) gate pre-activations, hprev [B][Tmax][2][H] = h of the previous
+ * step, dbias [2][2][3H] = (d b_ih, d b_hh) (NULL: skipped).  The caller's GEMMs give dW_ih = dgx^T x, dW_hh = dgh^T hprev,
+ * dx = dgx W_ih.  Fixed summation orders.  H in {32, 64, 128}.
+ */
+int tgsr_bigru_train_fwd(const float* x, const int32_t* cap_lens, int B, int Tmax, int ninput, const float* w_ih,
+                         const float* w_hh, const float* b_ih, const float* b_hh_rz, const float* b_hn, int H, float* gates_ws,
+                         float* acts, float* words_emb, float* sent_emb, void* stream);
+int tgsr_bigru_bwd(const int32_t* cap_lens, int B, int Tmax, int H, const float* w_hh, const float* acts, const float* words_emb,
+                   const float* d_words, const float* d_sent, float* dgx, float* dgh, float* hprev, float* dbias, void* stream);
+
+/*
  * Training path of the same encoder.  tgsr_bilstm_train_fwd takes the already embedded (and dropped-out) inputs
  * x [B][Tmax][ninput] and additionally saves acts [B][Tmax][2][5][H] (i, f, g, o activations and the cell state of
  * every step).  tgsr_bilstm_bwd walks every (sample, direction) back through time from d_words [B][2H][Tmax] and

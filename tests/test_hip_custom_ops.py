@@ -181,6 +181,10 @@ def test_opcheck_training_text_damsm_and_lp_operators():
     chk(T.bilstm_train.default, (xe, w_ih, w_hh, b_ih, b_hh, lens), test_utils=basic)
     wds, sent, acts = T.bilstm_train(xe, w_ih, w_hh, b_ih, b_hh, lens)
     chk(T.bilstm_bwd.default, (lens, w_hh, acts, wds, torch.randn_like(wds), torch.randn_like(sent)), test_utils=basic)
+    gw_ih, gw_hh, gb = R(2, 96, 24) * 0.2, R(2, 96, 32) * 0.2, R(2, 96) * 0.1
+    chk(T.bigru_train.default, (xe, gw_ih, gw_hh, gb, gb.clone(), lens), test_utils=basic)
+    gwds, gsent, gacts = T.bigru_train(xe, gw_ih, gw_hh, gb, gb.clone(), lens)
+    chk(T.bigru_bwd.default, (lens, gw_hh, gacts, gwds, torch.randn_like(gwds), torch.randn_like(gsent)), test_utils=basic)
     # DAMSM
     feats, wemb = R(3, 64, 5, 5), R(3, 64, 6)
     chk(T.damsm_words.default, (feats, wemb, lens, 4.0, 5.0), test_utils=basic)

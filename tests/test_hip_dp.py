@@ -92,3 +92,42 @@ def test_two_rank_gradients_and_sharded_inference(tmp_path, backend):
             assert torch.equal(a, b)
         assert torch.equal(r[0]["gan_params"], r[1]["gan_params"])
         assert all(torch.isfinite(torch.tensor(r[k]["gan_losses"])).all() for k in range(2))
+
+
+def test_rccl_executes_on_this_box_single_rank(tmp_path):
+    """RCCL (backend "nccl" on ROCm) itself, on whatever the box has: a ONE-rank process group - the only shape a one-GPU box
+    allows over RCCL (it refuses two ranks on one device) - built the way `parallel.init_distributed`'s nccl branch does, then the collectives
+    the data-parallel path issues, on the product's own tensors: the flat bucket's all-reduce (a whole-buffer one and the early
+    range + rest pair of SRTrainer) and the DAMSM all-gather.  With one rank every collective is the identity, which is the
+    check; what it proves is that librccl loads, builds a communicator on this device and runs on the product's streams."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from tgsr_amd import parallel
+torch.cuda.set_device(0)                       # (parallel.init_distributed only builds a group for world > 1: this is its nccl branch)
+dist.init_process_group("nccl", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1 and parallel.dp_world() == 1
+m = torch.nn.Sequential(torch.nn.Linear(64, 32), torch.nn.Linear(32, 8)).cuda()
+b = parallel.FlatGradBucket(m.parameters()).attach()
+b.flat.copy_(torch.arange(b.numel, dtype=torch.float32, device="cuda"))
+want = b.flat.clone()
+dist.all_reduce(b.flat_all, op=dist.ReduceOp.SUM)                       # the step's closing collective
+h = dist.all_reduce(b.flat_all[:100], op=dist.ReduceOp.SUM, async_op=True)   # the early range, on its own stream
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    h.wait()
+torch.cuda.current_stream().wait_stream(side)
+x = torch.randn(3, 5, device="cuda", requires_grad=True)
+g = parallel._AllGatherCat.apply(x)                                     # DAMSM's gather (autograd-aware)
+g.square().sum().backward()
+torch.cuda.synchronize()
+assert torch.equal(b.flat, want) and torch.equal(g.detach(), x.detach()) and torch.allclose(x.grad, 2 * x.detach())
+print("RCCL_OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")
+dist.destroy_process_group()
+''' % ROOT
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout + p.stderr

@@ -91,6 +91,8 @@ SIGNATURES = {
     "tgsr_text_tail_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "tgsr_gru_gate_table": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "tgsr_bigru_table_fwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "tgsr_bigru_train_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tgsr_bigru_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_lp_att_pack_bytes": (_i64, [_i, _i]),
     "tgsr_text_tail_lp_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "tgsr_lp_stem_att_fwd": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

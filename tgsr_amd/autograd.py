@@ -564,6 +564,38 @@ class BiLSTM(torch.autograd.Function):
         return dx, dw_ih, dw_hh, dbias, dbias.clone(), None
 
 
+class BiGRU(torch.autograd.Function):
+    """RNN_ENCODER's bidirectional GRU (cfg.RNN_TYPE == 'GRU', util.py:207-211, 233-260) in training mode: forward =
+    tgsr::bigru_train on the embedded (and dropped-out) inputs, backward = tgsr::bigru_bwd (BPTT, one workgroup per sample and
+    direction) plus the GEMMs for dW_ih, dW_hh and dx.  w_* are the two directions stacked: [2,3H,ninput], [2,3H,H], [2,3H]
+    (gate order r, z, n)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, lens):
+        words, sent, acts = C.bigru_train(x, w_ih.detach(), w_hh.detach(), b_ih.detach(), b_hh.detach(), list(lens))
+        ctx.save_for_backward(x, w_ih, w_hh, acts, words)
+        ctx.lens = list(lens)
+        return words, sent
+
+    @staticmethod
+    def backward(ctx, d_words, d_sent):
+        x, w_ih, w_hh, acts, words = ctx.saved_tensors
+        B, Tmax, K = x.shape
+        H = w_hh.shape[2]
+        if d_words is None:
+            d_words = torch.zeros_like(words)
+        dgx, dgh, hprev, dbias = C.bigru_bwd(ctx.lens, w_hh.detach(), acts, words, d_words.contiguous(),
+                                             None if d_sent is None else d_sent.contiguous())
+        gemm = C._gemm_nt
+        g2 = dgx.reshape(B * Tmax, 6 * H)
+        x2 = x.detach().reshape(B * Tmax, K)
+        dw_ih = gemm(g2.t(), x2.t()).reshape(2, 3 * H, K)                        # dgx^T x
+        dx = gemm(g2, w_ih.detach().reshape(6 * H, K).t()).reshape(B, Tmax, K)   # dgx W_ih
+        dw_hh = torch.stack([gemm(dgh[:, :, d].reshape(B * Tmax, 3 * H).t(), hprev[:, :, d].reshape(B * Tmax, H).t())
+                             for d in range(2)])
+        return dx, dw_ih, dw_hh, dbias[0].contiguous(), dbias[1].contiguous(), None
+
+
 class LinearFn:
     """y = x W^T + b with all three GEMMs on the HIP kernel (CNN_ENCODER.emb_cnn_code, util.py:301,364): the differentiable
     operator tgsr::linear (autograd registered on the op itself)."""

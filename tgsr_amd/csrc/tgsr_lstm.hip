@@ -489,7 +489,11 @@ __global__ __launch_bounds__(3 * H) void gru_recurrent_kernel(const float* __res
                                                               const int32_t* __restrict__ cap_lens, int Tmax,
                                                               const float* __restrict__ w_hh, const float* __restrict__ b_hn,
                                                               float* __restrict__ words_emb, float* __restrict__ sent_emb,
-                                                              const int64_t* __restrict__ captions, int width, int ntoken) {
+                                                              const int64_t* __restrict__ captions, int width, int ntoken,
+                                                              float* __restrict__ acts) {
+  // captions == nullptr (training): `table` holds one row of gate pre-activations per (b, t) - the embedded, dropped-out input
+  // through W_ih - instead of one per token; acts [B][Tmax][2][4][H] then receives (r, z, n, W_hn h + b_hn) of every step for
+  // gru_bwd_kernel
   __shared__ __attribute__((aligned(16))) float h_s[H];
   __shared__ float g_s[3 * H];                 // r, z pre-activations; W_hn h + b_hn
   __shared__ float xn_s[H];                    // W_in x + b_in of the step
@@ -514,8 +518,13 @@ __global__ __launch_bounds__(3 * H) void gru_recurrent_kernel(const float* __res
   __syncthreads();
   for (int s = 0; s < len; ++s) {
     const int t = d == 0 ? s : len - 1 - s;
-    const int64_t v = captions[(int64_t)b * width + t];
-    const int64_t row = (v < 0 || v >= ntoken) ? 0 : v;
+    int64_t row;
+    if (captions) {
+      const int64_t v = captions[(int64_t)b * width + t];
+      row = (v < 0 || v >= ntoken) ? 0 : v;
+    } else {
+      row = (int64_t)b * Tmax + t;
+    }
     const float x = table[(row * 2 + d) * 3 * H + j];
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;            // four independent chains, combined pairwise (as the LSTM kernel)
 #pragma unroll
@@ -537,6 +546,10 @@ __global__ __launch_bounds__(3 * H) void gru_recurrent_kernel(const float* __res
     if (j < H) {
       const float r = fsig_(g_s[j]), z = fsig_(g_s[H + j]);
       const float n = ftanh_(xn_s[j] + r * g_s[2 * H + j]);
+      if (acts) {
+        float* ap = acts + ((((int64_t)b * Tmax + t) * 2 + d) * 4) * H + j;
+        ap[0] = r; ap[H] = z; ap[2 * H] = n; ap[3 * H] = g_s[2 * H + j];
+      }
       hcur = (1.f - z) * n + z * hcur;
       h_s[j] = hcur;
       wout[t] = hcur;
@@ -544,6 +557,65 @@ __global__ __launch_bounds__(3 * H) void gru_recurrent_kernel(const float* __res
     __syncthreads();
   }
   if (j < H) sent_emb[(int64_t)b * 2 * H + d * H + j] = hcur;
+}
+
+// BPTT of one (sample, direction) of the GRU: thread q * H + k keeps column k of the rows [q H, (q + 1) H) of W_hh (gate q = r, z, n)
+// for dh_prev[k] = sum_j W_hh[j][k] dgh[j]; per step the H unit threads turn dh into the gate gradients
+//   dn = dh (1 - z), dz = dh (h_prev - n), da_n = dn (1 - n^2), da_z = dz z (1 - z), d(W_hn h + b_hn) = da_n r, da_r = da_n hn r (1 - r)
+// dgx [B][Tmax][2][3H] = (da_r, da_z, da_n): the gradient at x W_ih^T + b_ih; dgh = (da_r, da_z, da_n r): at h W_hh^T + b_hh.
+template <int H>
+__global__ __launch_bounds__(3 * H) void gru_bwd_kernel(const int32_t* __restrict__ cap_lens, int Tmax, const float* __restrict__ w_hh,
+                                                        const float* __restrict__ acts, const float* __restrict__ words_emb,
+                                                        const float* __restrict__ d_words, const float* __restrict__ d_sent,
+                                                        float* __restrict__ dgx, float* __restrict__ dgh, float* __restrict__ hprev) {
+  __shared__ float dg_s[3 * H];
+  __shared__ float part_s[3 * H];
+  const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, q = tid / H, k = tid - q * H;
+  int len = cap_lens[b];
+  len = len < 0 ? 0 : (len > Tmax ? Tmax : len);
+  float w[H];
+#pragma unroll
+  for (int jj = 0; jj < H; ++jj) w[jj] = w_hh[((int64_t)d * 3 * H + q * H + jj) * H + k];
+  for (int t = len; t < Tmax; ++t) {                       // steps past the caption: no gradient
+    const int64_t row = ((int64_t)b * Tmax + t) * 2 + d;
+    dgx[row * 3 * H + tid] = 0.f;
+    dgh[row * 3 * H + tid] = 0.f;
+    if (tid < H) hprev[row * H + tid] = 0.f;
+  }
+  const float* hrow = words_emb + ((int64_t)b * 2 * H + d * H + k) * Tmax;
+  const float* dwrow = d_words + ((int64_t)b * 2 * H + d * H + k) * Tmax;
+  float dh_carry = 0.f;
+  if (tid < H && d_sent) dh_carry = d_sent[(int64_t)b * 2 * H + d * H + k];
+  for (int s = len - 1; s >= 0; --s) {
+    const int t = d == 0 ? s : len - 1 - s;
+    const int tp = d == 0 ? t - 1 : t + 1;
+    const int64_t row = ((int64_t)b * Tmax + t) * 2 + d;
+    float dh_direct = 0.f;
+    if (tid < H) {
+      const float* ap = acts + row * 4 * H + k;
+      const float r = ap[0], z = ap[H], n = ap[2 * H], hn = ap[3 * H];
+      const float hp = s > 0 ? hrow[tp] : 0.f;
+      const float dh = dwrow[t] + dh_carry;
+      const float dan = dh * (1.f - z) * (1.f - n * n);
+      const float daz = dh * (hp - n) * z * (1.f - z);
+      const float dhn = dan * r;
+      const float dar = dan * hn * r * (1.f - r);
+      dh_direct = dh * z;
+      dg_s[k] = dar; dg_s[H + k] = daz; dg_s[2 * H + k] = dhn;
+      float* gx = dgx + row * 3 * H + k;
+      gx[0] = dar; gx[H] = daz; gx[2 * H] = dan;
+      hprev[row * H + k] = hp;
+    }
+    __syncthreads();
+    dgh[row * 3 * H + tid] = dg_s[tid];
+    float p = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < H; ++jj) p = fmaf(w[jj], dg_s[q * H + jj], p);
+    part_s[tid] = p;
+    __syncthreads();
+    if (tid < H) dh_carry = dh_direct + (part_s[k] + part_s[H + k] + part_s[2 * H + k]);
+    __syncthreads();
+  }
 }
 
 extern "C" int tgsr_gru_gate_table(const float* emb, int ntoken, int ninput, const float* w_ih, const float* b_ih,
@@ -565,16 +637,70 @@ extern "C" int tgsr_bigru_table_fwd(const int64_t* captions, int width, const in
   const dim3 grid(B, 2);
   if (H == 128)
     hipLaunchKernelGGL(gru_recurrent_kernel<128>, grid, dim3(384), 0, s, table, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
-                       captions, width, ntoken);
+                       captions, width, ntoken, (float*)nullptr);
   else if (H == 64)
     hipLaunchKernelGGL(gru_recurrent_kernel<64>, grid, dim3(192), 0, s, table, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
-                       captions, width, ntoken);
+                       captions, width, ntoken, (float*)nullptr);
   else if (H == 32)
     hipLaunchKernelGGL(gru_recurrent_kernel<32>, grid, dim3(96), 0, s, table, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
-                       captions, width, ntoken);
+                       captions, width, ntoken, (float*)nullptr);
   else
     return TGSR_EUNSUPPORTED;
   return note_launch(hipGetLastError(), "gru_recurrent_kernel");
+}
+
+// Training forward of the bidirectional GRU on dense (embedded, dropped-out) inputs x [B][Tmax][ninput]: the gate GEMM
+// (b_hh_rz = b_hh with its n third zeroed: r / z biases fold, b_hn stays inside r * (W_hn h + b_hn)), then the recurrence with the
+// per-step activations saved for tgsr_bigru_bwd.  gates_ws [B*Tmax][2][3H], acts [B][Tmax][2][4][H].
+extern "C" int tgsr_bigru_train_fwd(const float* x, const int32_t* cap_lens, int B, int Tmax, int ninput, const float* w_ih,
+                                    const float* w_hh, const float* b_ih, const float* b_hh_rz, const float* b_hn, int H,
+                                    float* gates_ws, float* acts, float* words_emb, float* sent_emb, void* stream) {
+  if (!x || !cap_lens || !w_ih || !w_hh || !b_ih || !b_hh_rz || !b_hn || !gates_ws || !acts || !words_emb || !sent_emb)
+    return TGSR_EINVAL;
+  if (B < 1 || Tmax < 1 || ninput < 1 || H < 1) return TGSR_EINVAL;
+  if (H != 128 && H != 64 && H != 32) return TGSR_EUNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const int M = B * Tmax, N = 6 * H;
+  hipLaunchKernelGGL(lstm_input_gates_kernel, dim3((N + 127) / 128, (M + 31) / 32), dim3(256), 0, s, (const int64_t*)nullptr, 1, 1,
+                     x, M, w_ih, b_ih, b_hh_rz, M, N, ninput, gates_ws);
+  int rc = note_launch(hipGetLastError(), "lstm_input_gates_kernel(gru train)");
+  if (rc) return rc;
+  const dim3 grid(B, 2);
+  const int64_t* nocap = nullptr;
+  if (H == 128)
+    hipLaunchKernelGGL(gru_recurrent_kernel<128>, grid, dim3(384), 0, s, gates_ws, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
+                       nocap, 0, 0, acts);
+  else if (H == 64)
+    hipLaunchKernelGGL(gru_recurrent_kernel<64>, grid, dim3(192), 0, s, gates_ws, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
+                       nocap, 0, 0, acts);
+  else
+    hipLaunchKernelGGL(gru_recurrent_kernel<32>, grid, dim3(96), 0, s, gates_ws, cap_lens, Tmax, w_hh, b_hn, words_emb, sent_emb,
+                       nocap, 0, 0, acts);
+  return note_launch(hipGetLastError(), "gru_recurrent_kernel(train)");
+}
+
+// BPTT of both directions.  dgx / dgh [B][Tmax][2][3H] (gradients at the input-side / hidden-side gate pre-activations), hprev
+// [B][Tmax][2][H] (h of the previous step), dbias [2][2][3H] = (d b_ih, d b_hh) = their column sums (NULL: skipped).
+extern "C" int tgsr_bigru_bwd(const int32_t* cap_lens, int B, int Tmax, int H, const float* w_hh, const float* acts,
+                              const float* words_emb, const float* d_words, const float* d_sent, float* dgx, float* dgh,
+                              float* hprev, float* dbias, void* stream) {
+  if (!cap_lens || !w_hh || !acts || !words_emb || !d_words || !dgx || !dgh || !hprev || B < 1 || Tmax < 1) return TGSR_EINVAL;
+  hipStream_t s = as_stream(stream);
+  const dim3 grid(B, 2);
+  if (H == 128)
+    hipLaunchKernelGGL(gru_bwd_kernel<128>, grid, dim3(384), 0, s, cap_lens, Tmax, w_hh, acts, words_emb, d_words, d_sent, dgx, dgh, hprev);
+  else if (H == 64)
+    hipLaunchKernelGGL(gru_bwd_kernel<64>, grid, dim3(192), 0, s, cap_lens, Tmax, w_hh, acts, words_emb, d_words, d_sent, dgx, dgh, hprev);
+  else if (H == 32)
+    hipLaunchKernelGGL(gru_bwd_kernel<32>, grid, dim3(96), 0, s, cap_lens, Tmax, w_hh, acts, words_emb, d_words, d_sent, dgx, dgh, hprev);
+  else
+    return TGSR_EUNSUPPORTED;
+  int rc = note_launch(hipGetLastError(), "gru_bwd_kernel");
+  if (rc || !dbias) return rc;
+  const int m = 6 * H;
+  hipLaunchKernelGGL(lstm_colsum_kernel, dim3((m + 255) / 256), dim3(256), 0, s, dgx, B * Tmax, m, dbias);
+  hipLaunchKernelGGL(lstm_colsum_kernel, dim3((m + 255) / 256), dim3(256), 0, s, dgh, B * Tmax, m, dbias + m);
+  return note_launch(hipGetLastError(), "lstm_colsum_kernel");
 }
 
 extern "C" int tgsr_bilstm_table_fwd(const int64_t* captions, int width, const int32_t* cap_lens, int B, int Tmax,

@@ -435,6 +435,19 @@ bilstm_bwd = _define("bilstm_bwd(int[] cap_lens, Tensor w_hh, Tensor acts, Tenso
                      lambda lens, wh, acts, words, dw, ds: (acts.new_empty(acts.shape[0], acts.shape[1], 2, 4 * acts.shape[4]),
                                                             acts.new_empty(acts.shape[0], acts.shape[1], 2, acts.shape[4]),
                                                             acts.new_empty(2, 4 * acts.shape[4])))
+bigru_train = _define("bigru_train(Tensor x, Tensor w_ih, Tensor w_hh, Tensor b_ih, Tensor b_hh, int[] cap_lens) -> "
+                      "(Tensor, Tensor, Tensor)",
+                      lambda x, wi, wh, bi, bh, lens: ops.bigru_train_fwd(x, list(lens), wi, wh, bi, bh),
+                      lambda x, wi, wh, bi, bh, lens: (x.new_empty(x.shape[0], 2 * wh.shape[2], x.shape[1]),
+                                                       x.new_empty(x.shape[0], 2 * wh.shape[2]),
+                                                       x.new_empty(x.shape[0], x.shape[1], 2, 4, wh.shape[2])))
+bigru_bwd = _define("bigru_bwd(int[] cap_lens, Tensor w_hh, Tensor acts, Tensor words, Tensor d_words, Tensor? d_sent) -> "
+                    "(Tensor, Tensor, Tensor, Tensor)",
+                    lambda lens, wh, acts, words, dw, ds: ops.bigru_bwd(list(lens), wh, acts, words, dw, ds),
+                    lambda lens, wh, acts, words, dw, ds: (acts.new_empty(acts.shape[0], acts.shape[1], 2, 3 * acts.shape[4]),
+                                                           acts.new_empty(acts.shape[0], acts.shape[1], 2, 3 * acts.shape[4]),
+                                                           acts.new_empty(acts.shape[0], acts.shape[1], 2, acts.shape[4]),
+                                                           acts.new_empty(2, 2, 3 * acts.shape[4])))
 
 
 # ------------------------------------------------------------------------------------------------ DAMSM

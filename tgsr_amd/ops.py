@@ -731,6 +731,48 @@ def bilstm_bwd(cap_lens, w_hh, acts, words, d_words, d_sent):
     return dgates, hprev, dbias
 
 
+def bigru_train_fwd(x: torch.Tensor, cap_lens, w_ih, w_hh, b_ih, b_hh):
+    """Training forward of the bidirectional GRU on embedded inputs x [B,Tmax,ninput] (w_* stacked over the two directions:
+    [2,3H,ninput], [2,3H,H], [2,3H]): returns (words_emb [B,2H,Tmax], sent_emb [B,2H], acts [B,Tmax,2,4,H])."""
+    _need_hip(x, w_ih, w_hh, b_ih, b_hh)
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    B, Tmax, K = x.shape
+    if len(lens) != B or min(lens) < 1 or max(lens) > Tmax:
+        raise TgsrError("bigru_train_fwd: cap_lens %s invalid for x %s" % (lens, tuple(x.shape)))
+    H = w_hh.shape[2]
+    dev = x.device
+    ts = [_f32(t.detach(), "gru tensor").contiguous() for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    b_rz = ts[4].clone()
+    b_rz[:, 2 * H:] = 0
+    b_hn = ts[4][:, 2 * H:].contiguous()
+    gates = torch.empty(B * Tmax * 6 * H, dtype=torch.float32, device=dev)
+    acts = torch.empty(B, Tmax, 2, 4, H, dtype=torch.float32, device=dev)
+    words = torch.empty(B, 2 * H, Tmax, dtype=torch.float32, device=dev)
+    sent = torch.empty(B, 2 * H, dtype=torch.float32, device=dev)
+    rc = _lib.lib().tgsr_bigru_train_fwd(_p(ts[0]), _p(_lens_on_device(tuple(lens), dev)), B, Tmax, K, _p(ts[1]), _p(ts[2]),
+                                         _p(ts[3]), _p(b_rz), _p(b_hn), H, _p(gates), _p(acts), _p(words), _p(sent), _stream())
+    check(rc, "tgsr_bigru_train_fwd")
+    return words, sent, acts
+
+
+def bigru_bwd(cap_lens, w_hh, acts, words, d_words, d_sent):
+    """BPTT of both directions: (dgx [B,Tmax,2,3H], dgh [B,Tmax,2,3H], hprev [B,Tmax,2,H], dbias [2,2,3H] = (d b_ih, d b_hh))."""
+    _need_hip(w_hh, acts, words, d_words, d_sent)
+    lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+    B, Tmax, _, _, H = acts.shape
+    dev = acts.device
+    dgx = torch.empty(B, Tmax, 2, 3 * H, dtype=torch.float32, device=dev)
+    dgh = torch.empty(B, Tmax, 2, 3 * H, dtype=torch.float32, device=dev)
+    hprev = torch.empty(B, Tmax, 2, H, dtype=torch.float32, device=dev)
+    dbias = torch.empty(2, 2, 3 * H, dtype=torch.float32, device=dev)
+    dw = _f32(d_words, "d_words").contiguous()
+    ds = None if d_sent is None else _f32(d_sent, "d_sent").contiguous()
+    rc = _lib.lib().tgsr_bigru_bwd(_p(_lens_on_device(tuple(lens), dev)), B, Tmax, H, _p(_f32(w_hh.detach(), "w_hh").contiguous()),
+                                   _p(acts), _p(words.contiguous()), _p(dw), _p(ds), _p(dgx), _p(dgh), _p(hprev), _p(dbias), _stream())
+    check(rc, "tgsr_bigru_bwd")
+    return dgx, dgh, hprev, dbias
+
+
 def lstm_gate_table(emb, w_ih, b_ih, b_hh):
     """[ntoken, 2, 4H] gate pre-activations of every token (eval mode, frozen weights); see tgsr_lstm_gate_table."""
     _need_hip(emb, w_ih, b_ih, b_hh)

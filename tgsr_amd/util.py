@@ -418,10 +418,19 @@ class RNN_ENCODER(nn.Module):
 
 def _rnn_encoder_forward_gru(self, captions, cap_lens):
     """The GRU branch (util.py:207-211, 244-258), eval mode: a per-token gate table built once per weight version, then ONE
-    recurrence launch per batch (tgsr_bigru_table_fwd).  No shipped configuration selects GRU and nothing trains it here:
-    `.train()` raises (the LSTM branch has the HIP backward, autograd.BiLSTM)."""
+    recurrence launch per batch (tgsr_bigru_table_fwd); training mode: autograd.BiGRU (tgsr_bigru_train_fwd / tgsr_bigru_bwd).  No
+    shipped configuration selects GRU."""
     if self.training:
-        raise NotImplementedError("RNN_ENCODER(GRU).train(): the HIP text encoder trains the LSTM branch only")
+        # util.py:236-252 with the GRU cell: emb = drop(encoder(captions)) through torch (their gradients are autograd's), the
+        # recurrence and its BPTT on the HIP kernels (autograd.BiGRU)
+        from .autograd import BiGRU
+        lens = [int(v) for v in (cap_lens.tolist() if torch.is_tensor(cap_lens) else cap_lens)]
+        r = self.rnn
+        emb = self.drop(self.encoder(captions[:, :max(lens)]))
+        return BiGRU.apply(emb, torch.stack([r.weight_ih_l0, r.weight_ih_l0_reverse]),
+                           torch.stack([r.weight_hh_l0, r.weight_hh_l0_reverse]),
+                           torch.stack([r.bias_ih_l0, r.bias_ih_l0_reverse]),
+                           torch.stack([r.bias_hh_l0, r.bias_hh_l0_reverse]), lens)
     w_ih, w_hh, b_ih, b_hh = self._weights()
     key = (self._key, _ver(self.encoder.weight))
     if key != self._table_key:
