@@ -100,14 +100,14 @@ def test_models16_tied_stages_and_keys(cfg32):
 
 
 def test_committed_bench_lines_follow_the_contract():
-    """The JSON lines bench.py printed on the MI355X this round (committed under profiles/) carry every field of the
+    """The JSON lines bench.py printed on the MI355X this round (committed under profiles/: r05_*) carry every field of the
     driver's contract, an honest roofline object (frac = achieved / peak <= 1, counters looked up from a committed
     rocprofv3 table) and - on the default N=1 runs - the CPU baseline."""
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r04_bench_*.json")))
-    assert len(files) >= 10, "round-4 bench lines missing"
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r05_bench_*.json")))
+    assert len(files) >= 10, "round-5 bench lines missing"
     saw_cpu = saw_lp = saw_train = False
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
@@ -136,12 +136,18 @@ def test_committed_bench_lines_follow_the_contract():
             c = d["cpu_baseline"]
             assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert saw_cpu and saw_lp and saw_train
-    two = json.loads(open(os.path.join(root, "profiles", "r04_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
+    two = json.loads(open(os.path.join(root, "profiles", "r05_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
     assert two["n_gpus"] == 2                       # `bench.py --gpus 2` launched its two ranks itself
     assert "lp" in two and "train" in two and "error" not in json.dumps(two["train"])   # the extras survive N > 1 (all-reduce matched)
     # the default line (what the driver times): fp32 stays the headline, configs[4] and the train step ride along
-    d = json.loads(open(os.path.join(root, "profiles", "r04_bench_fp32.json")).read().strip().splitlines()[-1])
-    assert d["dtype"] == "f32" and d["config"]["launch"] == "hipgraph" and d["config"]["graph_lanes"] == 4
+    d = json.loads(open(os.path.join(root, "profiles", "r05_bench_fp32.json")).read().strip().splitlines()[-1])
+    assert d["dtype"] == "f32" and d["config"]["launch"] == "hipgraph"
+    # round 5: `value` is the STRICT figure of BASELINE's metric - batch 16, one step in flight - and says so; the four-lane
+    # throughput form rides along; every figure is a median over >= 0.5 s of fenced K-step regions
+    assert "one step in flight" in d["metric"] and d["value"] == d["value_one_lane"]
+    tf = d["config"]["throughput_form"]
+    assert tf["images_in_flight"] == 64 and tf["value"] == d["value_throughput_form"] > d["value"]
+    assert d["config"]["repeats"] >= 3 and "median" in d["config"]["timing"]
     runs = {(r["dtype"], r["batch_per_gpu"]): r for r in d["lp"]["runs"]}
     assert set(runs) == {("bf16", 16), ("f16", 16), ("bf16", 8), ("bf16", 128)}
     for r in runs.values():
@@ -154,10 +160,13 @@ def test_committed_bench_lines_follow_the_contract():
     assert runs[("bf16", 16)]["graph_lanes4"]["hbm_frac"] >= 0.36      # four lanes: 0.39-0.41 of the HBM roofline depending on the box
     assert runs[("bf16", 128)]["step_roofline"]["hbm_frac"] >= 0.40    # north-star: >= 40 % of the HBM roofline on the conv path
     # every timed step runs on another batch than the one before (captions, caption lengths, images)
-    assert "different resident synthetic batches" in d["config"]["batches"] and d["config"]["images_in_flight"] == 64
+    assert "different resident synthetic batches" in d["config"]["batches"]
     tr = d["train"]["runs"]
     assert len(tr) == 2 and all(0 < t["roofline"]["frac"] < 1 and "executed_fraction" in json.dumps(t["roofline"]) for t in tr)
-    assert all("cpu_baseline" in t for t in tr)
+    # the train steps' CPU baselines run at the configuration's own batch, their rooflines carry counter traffic
+    assert all("cpu_baseline" in t and "batch 16" in t["cpu_baseline"]["sample"] for t in tr)
+    assert all(t["roofline"]["traffic"] and t["roofline"]["traffic_from"].startswith("r05_train") for t in tr)
+    assert tr[1]["ms_per_step"] < 28.0              # the G/D alternation (29.1 ms at the end of round 4)
 
 
 def test_get_caption_crops_like_the_reference():
