@@ -375,6 +375,21 @@ int tgsr_text_tail_lp_fwd(const float* words, const float* const* w_ctx, int nse
 int tgsr_multi_copy(int n, void* const* dst, const void* const* src, const int64_t* nbytes, void* stream);
 
 /*
+ * The gradient collective of the data-parallel path behind the C ABI (`allreduce_flat`, an RCCL wrapper; the
+ * reference has no collective - trainer_objective.py:31 is single-process).  tgsr_allreduce_flat: buf[i] = scale * sum over ranks
+ * of buf[i], in place, n floats, asynchronous on `stream` (ncclAllReduce, then one scaling launch unless scale == 1) - what
+ * tgsr_amd.parallel.FlatGradBucket.all_reduce_mean does through torch.distributed by default.  Communicators: rank 0 calls
+ * tgsr_comm_unique_id(id) (128 bytes), the caller carries those bytes to every rank, every rank calls tgsr_comm_init(&comm, id,
+ * rank, world) with its device current; tgsr_comm_destroy(comm) at the end.  librccl is opened lazily (dlopen): where it is absent
+ * tgsr_comm_available() returns 0 and the other four return TGSR_EUNSUPPORTED - the rest of the library is unaffected.
+ */
+int tgsr_comm_available(void);
+int tgsr_comm_unique_id(void* id128);
+int tgsr_comm_init(void** comm, const void* id128, int rank, int world);
+int tgsr_allreduce_flat(void* comm, float* buf, int64_t n, float scale, void* stream);
+int tgsr_comm_destroy(void* comm);
+
+/*
  * out[i] = t[i] + alpha * s[i] for n <= 4 dense fp32 images in one launch (host arrays of device pointers; numel[i] a
  * multiple of 4, pointers 16-byte aligned).  The second half of NetG_highweight's heads (model.py:280, 288, 297:
  * `ims = one * conv_output(out) + a * SRb`): the caller computes t = tanh(conv5x5(out)) with tgsr_conv_to3_fwd(addend = NULL)

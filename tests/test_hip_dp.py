@@ -131,3 +131,43 @@ dist.destroy_process_group()
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout + p.stderr
+
+
+def test_allreduce_flat_through_the_c_abi_single_rank(tmp_path):
+    """`tgsr_allreduce_flat` (SURVEY 8b's op list): librccl opened by libtgsr_hip.so itself, a communicator built from a unique id
+    (one rank: what a one-GPU box allows), buf <- scale * sum over ranks - in a child process, like every test that builds a
+    communicator.  Checked: the scaled identity on a 1.2 M-float bucket, FlatGradBucket(comm=RcclDirect) reducing through it, and a
+    second, independent communicator."""
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tgsr_amd import ops, parallel
+assert ops.comm_available()
+torch.cuda.set_device(0)
+uid = ops.comm_unique_id()
+assert len(uid) == 128 and any(uid)
+comm = ops.comm_init(uid, 0, 1)
+x = torch.randn(1191313, device="cuda")
+want = (x * 0.25).clone()
+ops.allreduce_flat(comm, x, 0.25)
+torch.cuda.synchronize()
+assert torch.equal(x, want)
+ops.comm_destroy(comm)
+rc = parallel.RcclDirect.create()
+m = torch.nn.Linear(8, 4).cuda()
+b = parallel.FlatGradBucket(m.parameters(), comm=rc).attach()
+b.flat.copy_(torch.arange(b.numel, dtype=torch.float32, device="cuda"))
+import torch.distributed as dist
+b.comm.all_reduce_mean_(b.flat_all)
+torch.cuda.synchronize()
+assert torch.equal(b.flat, torch.arange(b.numel, dtype=torch.float32, device="cuda"))
+rc.close()
+try:
+    ops.allreduce_flat(0, x, 1.0)
+    raise SystemExit("a null communicator must be refused")
+except ops.TgsrError:
+    pass
+print("ALLREDUCE_FLAT_OK")
+''' % ROOT
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ALLREDUCE_FLAT_OK" in p.stdout, p.stdout + p.stderr

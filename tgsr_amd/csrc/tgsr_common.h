@@ -16,6 +16,8 @@ constexpr int kConvCK = 4;    // input channels per LDS stage (== the packed-wei
 
 // Records a launch failure for tgsr_last_error(); returns the ABI status.
 int note_launch(hipError_t e, const char* what);
+// Records a non-HIP failure (e.g. an RCCL status) for tgsr_last_error(); returns TGSR_ELAUNCH.
+int note_error(const char* what, const char* detail, int code);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -13,6 +13,11 @@ int note_launch(hipError_t e, const char* what) {
   return TGSR_ELAUNCH;
 }
 
+int note_error(const char* what, const char* detail, int code) {
+  snprintf(g_last_error, sizeof(g_last_error), "%s: %s (%d)", what, detail ? detail : "error", code);
+  return TGSR_ELAUNCH;
+}
+
 // wpack[chunk][tap][ci][Cout] <- w[Cout][Cin][K][K]; channels past Cin are zero.
 // tr != 0: the source is the FORWARD conv's weight [Cin][Cout][K][K] and the pack is of the data-gradient conv
 // w'[co][c][tap] = w[c][co][KK - 1 - tap] (in/out swapped, taps flipped) - no flip/transpose/copy kernels beforehand

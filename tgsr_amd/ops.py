@@ -1200,6 +1200,45 @@ def multi_copy(dsts, srcs) -> None:
     check(_lib.lib().tgsr_multi_copy(n, dp, sp, nb, _stream()), "tgsr_multi_copy")
 
 
+# ----------------------------------------------------------------------------------------- RCCL behind the C ABI
+def comm_available() -> bool:
+    """librccl could be opened by the library (tgsr_comm_available)."""
+    return bool(_lib.lib().tgsr_comm_available())
+
+
+def comm_unique_id() -> bytes:
+    """The 128-byte id rank 0 creates and every rank passes to comm_init (ncclGetUniqueId)."""
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    check(_lib.lib().tgsr_comm_unique_id(buf), "tgsr_comm_unique_id")
+    return bytes(buf.raw)
+
+
+def comm_init(unique_id: bytes, rank: int, world: int) -> int:
+    """An RCCL communicator on the current device (ncclCommInitRank; collective over the ranks); returns an opaque handle."""
+    import ctypes
+    if len(unique_id) != 128:
+        raise TgsrError("comm_init: the unique id has %d bytes, not 128" % len(unique_id))
+    comm = ctypes.c_void_p()
+    check(_lib.lib().tgsr_comm_init(ctypes.byref(comm), ctypes.create_string_buffer(unique_id, 128), int(rank), int(world)),
+          "tgsr_comm_init")
+    return comm.value
+
+
+def allreduce_flat(comm: int, flat: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """flat <- scale * sum over ranks of flat, in place, on torch's current stream (tgsr_allreduce_flat: ncclAllReduce + one
+    scaling launch): the gradient bucket's collective without torch.distributed in the way."""
+    _need_hip(flat)
+    if flat.dtype != torch.float32 or not flat.is_contiguous():
+        raise TgsrError("allreduce_flat: a dense fp32 buffer, got %s %s" % (flat.dtype, tuple(flat.shape)))
+    check(_lib.lib().tgsr_allreduce_flat(comm, _p(flat), flat.numel(), float(scale), _stream()), "tgsr_allreduce_flat")
+    return flat
+
+
+def comm_destroy(comm: int) -> None:
+    check(_lib.lib().tgsr_comm_destroy(comm), "tgsr_comm_destroy")
+
+
 def axpy_images(ts, ss, alpha: float, outs=None):
     """[t + alpha * s for t, s in zip(ts, ss)] for up to 4 dense fp32 images in one launch (tgsr_axpy_images): the closing
     `+ a * SRb` of NetG_highweight's heads when tanh(conv5x5(.)) was computed ahead of the low-frequency images."""

@@ -84,7 +84,7 @@ def grad_slot(param: torch.Tensor):
 class FlatGradBucket:
     """All gradients of `params` in one flat fp32 buffer; `all_reduce_mean()` = one collective per step."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], buffers: Iterable[torch.Tensor] = ()):
+    def __init__(self, params: Iterable[torch.nn.Parameter], buffers: Iterable[torch.Tensor] = (), comm=None):
         """buffers: module buffers to keep identical across ranks (BatchNorm running_mean / running_var; integer buffers
         such as num_batches_tracked advance in lockstep and are skipped): they travel in the tail of the flat buffer
         and come back as the mean over ranks with every all_reduce_mean() - no collective of their own."""
@@ -107,6 +107,7 @@ class FlatGradBucket:
             off += b.numel()
         self.direct = False
         self.filled = [False] * len(self.params)
+        self.comm = comm          # an RcclDirect: all_reduce_mean() then goes through tgsr_allreduce_flat instead of torch.distributed
 
     def attach(self):
         """Make every p.grad a view of the flat buffer, so backward writes straight into the bucket (no packing)."""
@@ -186,6 +187,13 @@ class FlatGradBucket:
             with torch.no_grad():
                 torch._foreach_copy_(self.buf_views, self.buffers)      # this step's running statistics -> the tail
 
+        if self.comm is not None and not async_op and skip is None:
+            self.comm.all_reduce_mean_(self.flat_all)       # sum and x 1/world inside the C ABI call, on the current stream
+            self.unpack()
+            if self.buffers:
+                with torch.no_grad():
+                    torch._foreach_copy_(self.buffers, self.buf_views)
+            return None
         if skip is not None:
             # [lo, hi) went out earlier (all_reduce_range_async) and is already averaged: reduce the two pieces around it
             lo, hi = skip
@@ -223,6 +231,39 @@ class FlatGradBucket:
 # single process would compute on the concatenated batch; gather_damsm_batch), False = on its own shard (B - 1 negatives per
 # sample instead of world x B - 1: cheaper - the pair kernel's work grows with world^2 when gathered - but a different loss).
 GATHER_NEGATIVES = os.environ.get("TGSR_DP_GATHER_NEGATIVES", "1") != "0"
+
+
+class RcclDirect:
+    """The gradient collective through the library's own C ABI (tgsr_allreduce_flat: librccl opened by libtgsr_hip.so, no
+    torch.distributed on the data path).  The 128-byte communicator id still has to travel from rank 0 to the others once:
+    `create()` uses the already initialised torch.distributed group (any backend) for that broadcast - a non-Python host would
+    use its own channel.  FlatGradBucket(..., comm=RcclDirect.create()) then reduces with it."""
+
+    def __init__(self, comm, rank, world):
+        self.comm, self.rank, self.world = comm, rank, world
+
+    @classmethod
+    def create(cls):
+        from . import ops
+        if not ops.comm_available():
+            raise RuntimeError("RcclDirect: librccl could not be opened by libtgsr_hip.so")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            rank, world = dist.get_rank(), dist.get_world_size()
+            box = [ops.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+        else:
+            rank, world, box = 0, 1, [ops.comm_unique_id()]
+        return cls(ops.comm_init(box[0], rank, world), rank, world)
+
+    def all_reduce_mean_(self, flat: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        return ops.allreduce_flat(self.comm, flat, 1.0 / self.world)
+
+    def close(self):
+        from . import ops
+        if self.comm:
+            ops.comm_destroy(self.comm)
+            self.comm = None
 
 
 def dp_world() -> int:
