@@ -538,8 +538,13 @@ def test_rnn_encoder_gru_branch_golden():
             assert float(wf[:, :, T_:].abs().max()) == 0 if T_ < cap.shape[1] else True
             for b, n in enumerate(lens):                                     # zeros behind every caption
                 assert float(we[b, :, n:].abs().max()) == 0 if n < T_ else True
-            with pytest.raises(NotImplementedError):
-                enc.train()(cap, lens, None)
+            enc.train()                                                      # the training branch (round 5): same values without dropout,
+            enc.drop.p = 0.0                                                 # and gradients reach the recurrent weights
+            wt, st = enc(cap, lens, None)
+            close(wt, sd["words_emb"], atol=1e-5)
+            close(st, sd["sent_emb"], atol=1e-5)
+            (wt.square().sum() + st.square().sum()).backward()
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0 for p in enc.rnn.parameters())
     finally:
         cfg_reset()
 
