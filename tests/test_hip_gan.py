@@ -47,8 +47,20 @@ def close(a, b, atol=1e-4, rtol=1e-4):
                                                    # the image layer's own data-gradient kernel (Cin <= 4): ragged, 1 / 3 / 4 channels
                                                    (3, 3, 64, 6, 10, True), (2, 1, 8, 8, 8, False), (1, 4, 16, 12, 260, False),
                                                    (2, 6, 10, 8, 8, False)])      # Cout % 4 != 0: a partial last K-chunk in dgrad
-def test_conv4x4s2_fwd_dgrad_wgrad(B, Cin, Cout, H, W, leaky):
+@pytest.mark.parametrize("split", [True, False])
+def test_conv4x4s2_fwd_dgrad_wgrad(B, Cin, Cout, H, W, leaky, split):
+    """split: the three GEMMs on the bf16 matrix pipe with three-piece fp32 operands (the default; shapes with K % 16 != 0 or, for the
+    weight gradient, output pixels % 8 != 0 fall back inside the library) | on the fp32 MFMA: same tolerances."""
+    from tgsr_amd import ops
     from tgsr_amd.autograd import DownConv
+    was = ops.dconv_set_split(split)
+    try:
+        _conv4x4s2_case(B, Cin, Cout, H, W, leaky, DownConv)
+    finally:
+        ops.dconv_set_split(was)
+
+
+def _conv4x4s2_case(B, Cin, Cout, H, W, leaky, DownConv):
     g = torch.Generator().manual_seed(B + Cin)
     x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
     w = (torch.randn(Cout, Cin, 4, 4, generator=g) / (4 * Cin ** 0.5)).requires_grad_(True)

@@ -15,6 +15,8 @@
 // (no BatchNorm) takes the LeakyReLU in this kernel's epilogue.  SURVEY.md 8(f)1.
 #include "tgsr_common.h"
 
+#include <type_traits>
+
 namespace tgsr {
 
 enum { kFwd4 = 0, kFwd3 = 1, kDgrad4 = 2, kDgrad3 = 3, kWgrad4 = 4, kWgrad3 = 5 };
@@ -30,6 +32,7 @@ struct IgArgs {
   int nsplit, chunks_per_split;
   int64_t slab_stride;
   int act;               // forward, nsplit == 1 only: 1 = LeakyReLU(0.2) epilogue
+  int64_t a_bytes, s_bytes;   // dconv_igemm6_kernel: sizes of A and S (buffer descriptors; < 4 GB, host-checked)
 };
 
 constexpr int kIgKC = 16, kIgP = 132;   // K-chunk; LDS pitch: (4 k + m) mod 64 is a bijection over a wave's writes
@@ -265,6 +268,425 @@ __global__ __launch_bounds__(256) void dconv_igemm_kernel(IgArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same GEMMs on the bf16 matrix pipe, fp32 in and out ("x6").  `v_mfma_f32_32x32x2_f32` runs at the fp32
+// VECTOR rate (64 FLOP/clk/SIMD, 1/16 of the bf16 MFMA) and every VALU instruction beside it costs its full issue time.  An
+// fp32 value is exactly x0 + x1 + x2 with three bf16 pieces (round-to-nearest split: 9 + 9 + 9 >= 24 significand bits), a
+// bf16 x bf16 product is exact in fp32 and the bf16 MFMA accumulates in fp32, so
+//     a b = a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0) + [a1 b2 + a2 b1 + a2 b2],   [..] <= 2^-26 |a b|:
+// six `v_mfma_f32_32x32x16_bf16` replace eight `32x32x2_f32` of the same K = 16 at 192 instead of 512 cycles, with the loaders'
+// VALU work in the issue slots the bf16 MFMA leaves free.  Measured (tools/diag/exp_split_mfma.hip): 374 against 157
+// fp32-equivalent TFLOP/s in registers, and - the a0 b0 products in their own accumulator, one rounding per 16 k instead of eight -
+// 2.5-3x LESS error against fp64 than the fp32 MFMA (which equals a sequential fmaf chain bit for bit).
+// Modes: the 4x4 stride-2 convolution's forward, data gradient and weight gradient with K % 16 == 0 (a K-chunk = one input
+// channel's 16 taps | four output channels x 4 taps | 16 pixels); everything else stays on the kernel above.
+// LDS tile per operand and piece: [k half 2][rows][8 k] bf16 (16 B per slot): item q -> (k half q / rows, row q % rows) loads 8
+// consecutive k, splits them and writes three 16-byte runs at q * 16: linear, conflict-free; a lane's MFMA operand (row l & 31,
+// k 8 (l >> 5) ..) is one ds_read_b128, 32 consecutive slots per half wave ([row][k half] gave every read a 2-way bank conflict).
+typedef unsigned int u32x4d __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8d __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned ig6_pack2(float lo, float hi) {       // v_cvt_pk_bf16_f32: round to nearest even, lo in bits 0..15
+  bf16x2d v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+// eight consecutive k of one row -> the three bf16 pieces (k even in the low half of a word)
+__device__ __forceinline__ void ig6_split8(const float (&v)[8], u32x4d& p0, u32x4d& p1, u32x4d& p2) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    const unsigned u0 = ig6_pack2(a, b);
+    const float ra = a - __uint_as_float(u0 << 16), rb = b - __uint_as_float(u0 & 0xffff0000u);       // exact
+    const unsigned u1 = ig6_pack2(ra, rb);
+    const float sa = ra - __uint_as_float(u1 << 16), sb = rb - __uint_as_float(u1 & 0xffff0000u);     // exact
+    p0[j] = u0;
+    p1[j] = u1;
+    p2[j] = ig6_pack2(sa, sb);
+  }
+}
+typedef unsigned int u32x2d __attribute__((ext_vector_type(2)));
+template <int NV>   // NV = 8 | 4 consecutive k -> NV / 2 words per piece
+__device__ __forceinline__ void ig6_split(const float (&v)[NV], unsigned (&p0)[NV / 2], unsigned (&p1)[NV / 2], unsigned (&p2)[NV / 2]) {
+#pragma unroll
+  for (int j = 0; j < NV / 2; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    const unsigned u0 = ig6_pack2(a, b);
+    const float ra = a - __uint_as_float(u0 << 16), rb = b - __uint_as_float(u0 & 0xffff0000u);       // exact
+    const unsigned u1 = ig6_pack2(ra, rb);
+    const float sa = ra - __uint_as_float(u1 << 16), sb = rb - __uint_as_float(u1 & 0xffff0000u);     // exact
+    p0[j] = u0;
+    p1[j] = u1;
+    p2[j] = ig6_pack2(sa, sb);
+  }
+}
+__device__ __forceinline__ f32x16 ig6_mfma(u32x4d a, u32x4d b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8d, a), __builtin_bit_cast(bf16x8d, b), c, 0, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) void* ig6_lds_t;
+
+// fp32 rows [M][K] (K % 16 == 0) -> the LDS images of dconv_igemm6_kernel's A operand: [m tile][chunk][piece 3][MB rows][16 k] bf16,
+// rows >= M zero.  One thread per (row, 8 consecutive k).
+template <int MB>
+__global__ __launch_bounds__(256) void ig6_split_rows_kernel(const float* __restrict__ src, unsigned* __restrict__ dst, int M, int K,
+                                                               int64_t total) {
+  const int kg = K >> 3;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % kg), m = (int)(idx / kg);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+      const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)m * K + 8 * g);
+      const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)m * K + 8 * g + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    }
+    u32x4d p0, p1, p2;
+    ig6_split8(v, p0, p1, p2);
+    const int mt = m / MB, r = m - mt * MB;
+    unsigned* d = dst + ((int64_t)mt * (K >> 4) + (g >> 1)) * (3 * MB * 8) + ((g & 1) * MB + r) * 4;
+    *reinterpret_cast<u32x4d*>(d) = p0;
+    *reinterpret_cast<u32x4d*>(d + MB * 8) = p1;
+    *reinterpret_cast<u32x4d*>(d + 2 * MB * 8) = p2;
+  }
+}
+
+// The data gradient's A operand from the forward weight w [Cout][Cin][4][4] (Cout % 4 == 0), regrouped by parity class and split:
+// A[cls = 2p + q][m = ci][k = 4 co + 2a + c] = w[co][ci][p + 2a][q + 2c]  ->  images [cls][m tile][chunk][piece][MB][16], rows >= Cin zero.
+// One thread per (ci, pair of output channels): two 64-byte filter reads, four classes x three 16-byte stores.
+template <int MB>
+__global__ __launch_bounds__(256) void ig6_pack_dgrad_kernel(const float* __restrict__ w, unsigned* __restrict__ dst, int Cout, int Cin,
+                                                               int mtiles, int64_t total) {
+  const int half_co = Cout >> 1, K = 4 * Cout;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int j2 = (int)(idx % half_co), ci = (int)(idx / half_co);
+    float f[2][16];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const float4* fp = reinterpret_cast<const float4*>(w + ((int64_t)(2 * j2 + o) * Cin + ci) * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 t = ci < Cin ? fp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        f[o][4 * i] = t.x; f[o][4 * i + 1] = t.y; f[o][4 * i + 2] = t.z; f[o][4 * i + 3] = t.w;
+      }
+    }
+    const int mt = ci / MB, r = ci - mt * MB;
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const int p = cls >> 1, q = cls & 1;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f[e >> 2][(p + 2 * ((e >> 1) & 1)) * 4 + q + 2 * (e & 1)];
+      u32x4d p0, p1, p2;
+      ig6_split8(v, p0, p1, p2);
+      unsigned* d = dst + (((int64_t)cls * mtiles + mt) * (K >> 4) + (j2 >> 1)) * (3 * MB * 8) + ((j2 & 1) * MB + r) * 4;
+      *reinterpret_cast<u32x4d*>(d) = p0;
+      *reinterpret_cast<u32x4d*>(d + MB * 8) = p1;
+      *reinterpret_cast<u32x4d*>(d + 2 * MB * 8) = p2;
+    }
+  }
+}
+
+// APRE: the A operand arrives pre-split as the LDS images (forward / data gradient; ig6_split_rows_kernel / ig6_pack_dgrad_kernel).
+// EXP (timing experiments only, wrong results): 1 = no barrier in a trip, 2 = no global loads in a trip, 3 = both, 4 = no split / LDS writes
+template <int MODE, bool WIDE = false, bool APRE = false, int EXP = 0>
+__global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
+  static_assert(MODE == kFwd4 || MODE == kDgrad4 || MODE == kWgrad4, "the 4x4 stride-2 convolution's three GEMMs");
+  constexpr bool WG = MODE == kWgrad4;
+  static_assert(!(WG && WIDE) && !(WG && APRE), "the wide tile and the pre-split A serve the pixel-column modes");
+  constexpr int MB = WIDE ? 64 : 128, NB = WIDE ? 256 : 128;
+  constexpr int APL = MB * 8, BPL = NB * 8;                // 32-bit words per piece of a tile
+  constexpr int NBI = NB / 128;                            // B items per thread
+  constexpr int AG = MB / 16;                              // A values per thread and chunk: 8 (one item) | 4 (half an item)
+  constexpr int NAR = APRE ? 3 * AG / 2 : AG;              // staged A registers per thread: three pieces | AG fp32 values
+  __shared__ __attribute__((aligned(16))) unsigned a_s[2][3 * APL];
+  __shared__ __attribute__((aligned(16))) unsigned b_s[2][3 * BPL];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5, wave = tid >> 6;
+  const int wm = WIDE ? 0 : wave >> 1, wn = WIDE ? wave : wave & 1;
+  const int ncls = MODE == kDgrad4 ? 4 : 1;
+  const int cls = MODE == kDgrad4 ? (int)blockIdx.z % ncls : 0;
+  const int z = (int)blockIdx.z / ncls;
+  const int m0 = blockIdx.y * MB, n0 = blockIdx.x * NB;
+  const int kbeg = z * a.chunks_per_split * kIgKC;         // multiples of 16; K % 16 == 0 (host-checked): whole chunks only
+  const int kend = min(a.K, kbeg + a.chunks_per_split * kIgKC);
+  const int nchunks = (kend - kbeg) / kIgKC;
+  const int HsWs = a.Hs * a.Ws, hw = a.PH * a.PW;
+
+  // Every load is a buffer load whose descriptor is rebased per chunk (base and size are workgroup-uniform: scalar work) and
+  // whose per-thread byte offsets are computed ONCE; what lies outside the image - or a row >= M, a column >= N - gets an offset
+  // the range check rejects and reads as zero.  No branch guards a load: hipcc can count them, so the loads of chunk c + 2 stay in
+  // flight while chunk c + 1 is stored (exec-masked loads made it wait for `vmcnt(0)` at the top of every trip).
+  constexpr unsigned kOut = 0xffffffffu;
+  // ---- A item of this thread: (k half, row) = (tid / MB, tid % MB), tid < 2 MB.  APRE: image [class][m tile][chunk][piece]
+  // [k half][MB rows][8 k], rows >= M zero: this thread's 16 bytes of each piece.  Otherwise rows of K-contiguous fp32: forward
+  // w [Cout][K], data gradient the fp32 class pack [Cin][4 Cout], weight gradient dy [b][Cout][hw] with k = b hw + r (hw % 16
+  // == 0: a chunk's 16 pixels never leave an image, so b and r are uniform).
+  // (the wide tile has 128 A items: a thread takes half of one - AG = 4 values - so that no branch guards the A path)
+  const int aq = tid / (8 / AG), asub = tid % (8 / AG);    // item, and which AG-run of its 8 k
+  const int arow = aq % MB, ahalf = aq / MB;
+  const bool aok = m0 + arow < a.M;
+  unsigned avo;                                            // byte offset of this thread's A data inside a chunk's descriptor
+  int64_t abase;                                           // element offset of chunk 0's descriptor base (uniform)
+  if (APRE) {
+    abase = ((int64_t)(cls * (int)gridDim.y + (int)blockIdx.y) * (a.K / kIgKC) + kbeg / kIgKC) * (3 * APL);
+    avo = (unsigned)(tid * (2 * AG));
+  } else if (!WG) {
+    abase = (MODE == kDgrad4 ? (int64_t)cls * a.M * a.K : 0) + kbeg;
+    avo = aok ? (unsigned)(((int64_t)(m0 + arow) * a.K + 8 * ahalf + AG * asub) * 4) : kOut;
+  } else {
+    abase = 0;
+    avo = aok ? (unsigned)(((int64_t)(m0 + arow) * hw + 8 * ahalf + AG * asub) * 4) : kOut;
+  }
+  // ---- B items: q = tid + 256 t -> (k half q / NB, row q % NB).  Forward / data gradient: row = a pixel, the 8 k of an item are
+  // window taps: their byte offsets relative to (sample 0, the chunk's first channel) never change.  Weight gradient: row = a
+  // column j = (ci, ky, kx), the 8 k are pixels.
+  unsigned bvo[NBI][8];
+  int wj[NBI], wsh[NBI];
+#pragma unroll
+  for (int t = 0; t < NBI; ++t) {
+    const int q = tid + 256 * t, half = q / NB, n = n0 + q % NB;
+    wj[t] = -1; wsh[t] = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bvo[t][e] = kOut;
+    if (n < a.N) {
+      if (!WG) {
+        int poff, piy, pix_;
+        ig_decode_p<MODE>(a, n, poff, piy, pix_);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          int iy, ix, ch;
+          if (MODE == kFwd4) {             // taps (ky = 2 half + (e >> 2), kx = e & 3) of channel k0 / 16
+            iy = piy + 2 * half + (e >> 2) - 1;
+            ix = pix_ + (e & 3) - 1;
+            ch = 0;
+          } else {                         // output channel k0 / 4 + 2 half + (e >> 2), tap (a = (e >> 1) & 1, c = e & 1)
+            iy = piy + 1 - (cls >> 1) - ((e >> 1) & 1);
+            ix = pix_ + 1 - (cls & 1) - (e & 1);
+            ch = 2 * half + (e >> 2);
+          }
+          if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws) bvo[t][e] = (unsigned)(poff + ch * HsWs + iy * a.Ws + ix) * 4u;
+        }
+      } else {
+        int off, dyk, dxk;
+        ig_decode_j<MODE>(a, n, 0, off, dyk, dxk);
+        wj[t] = off;
+        wsh[t] = (dyk + 4) | ((dxk + 4) << 4) | (half << 8);
+      }
+    }
+  }
+
+  // two register sets: the loads of chunk c + 2 are issued while chunk c is multiplied and chunk c + 1 is split and stored
+  unsigned ra[2][NAR];
+  float rb[2][NBI][8];
+  auto load = [&](int c, unsigned (&qa)[NAR], float (&qb)[NBI][8]) {
+    const int k0 = kbeg + c * kIgKC;
+    // A
+    int64_t aoff;                                          // uniform
+    if (APRE) aoff = (abase + (int64_t)c * (3 * APL)) * 4;
+    else if (!WG) aoff = (abase + (int64_t)c * kIgKC) * 4;
+    else {
+      const int b = k0 / hw, r = k0 - b * hw;
+      aoff = ((int64_t)b * a.M * hw + r) * 4;
+    }
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.A)) + aoff, 0, (int)(unsigned)(a.a_bytes - aoff), 0x00020000);
+    if constexpr (APRE) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        if constexpr (AG == 8) {
+          const u32x4d v = __builtin_amdgcn_raw_buffer_load_b128(ar, avo + p * (APL * 4), 0, 0);
+          qa[4 * p] = v[0]; qa[4 * p + 1] = v[1]; qa[4 * p + 2] = v[2]; qa[4 * p + 3] = v[3];
+        } else {
+          const u32x2d v = __builtin_amdgcn_raw_buffer_load_b64(ar, avo + p * (APL * 4), 0, 0);
+          qa[2 * p] = v[0]; qa[2 * p + 1] = v[1];
+        }
+      }
+    } else {
+      const u32x4d v0 = __builtin_amdgcn_raw_buffer_load_b128(ar, avo, 0, 0);
+      qa[0] = v0[0]; qa[1] = v0[1]; qa[2] = v0[2]; qa[3] = v0[3];
+      if constexpr (AG == 8) {
+        const u32x4d v1 = __builtin_amdgcn_raw_buffer_load_b128(ar, avo == kOut ? kOut : avo + 16u, 0, 0);
+        qa[4] = v1[0]; qa[5] = v1[1]; qa[6] = v1[2]; qa[7] = v1[3];
+      }
+    }
+    // B
+    if (!WG) {
+      const int64_t soff = (int64_t)(MODE == kFwd4 ? (k0 >> 4) : (k0 >> 2)) * HsWs * 4;      // the chunk's first channel
+      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + soff, 0, (int)(unsigned)(a.s_bytes - soff), 0x00020000);
+#pragma unroll
+      for (int t = 0; t < NBI; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qb[t][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, bvo[t][e], 0, 0));
+    } else {
+      // the chunk's 16 pixels lie in one image b (uniform); pixel r0 + 8 half + e -> (py, px)
+      const int b = k0 / hw, r0 = k0 - b * hw;
+      const int64_t soff = (int64_t)b * a.C * HsWs * 4;
+      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + soff, 0, (int)(unsigned)(a.s_bytes - soff), 0x00020000);
+      const int py0 = r0 / a.PW, px0 = r0 - py0 * a.PW;
+#pragma unroll
+      for (int t = 0; t < NBI; ++t) {
+        const int dyk = (wsh[t] & 15) - 4, dxk = ((wsh[t] >> 4) & 15) - 4;
+        int py = py0, px = px0 + 8 * (wsh[t] >> 8);
+        while (px >= a.PW) { px -= a.PW; ++py; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int iy = 2 * py + dyk, ix = 2 * px + dxk;
+          const bool ok = wj[t] >= 0 && (unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws;
+          qb[t][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, ok ? (unsigned)(wj[t] + iy * a.Ws + ix) * 4u : kOut, 0, 0));
+          ++px;
+          if (px == a.PW) { px = 0; ++py; }
+        }
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+  const int fa = (hh * MB + wm * 64 + l31) * 4, fb = (hh * NB + wn * 64 + l31) * 4;       // word offset of this lane's fragment, block 0
+
+  // split (or, APRE, pass on) a register set and write it into LDS buffer `ob`: branch-free
+  auto stage = [&](int ob, const unsigned (&qa)[NAR], const float (&qb)[NBI][8]) {
+    unsigned p[3][AG / 2];
+    if constexpr (APRE) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < AG / 2; ++j) p[i][j] = qa[i * (AG / 2) + j];
+    } else {
+      float v[AG];
+#pragma unroll
+      for (int e = 0; e < AG; ++e) v[e] = __uint_as_float(qa[e]);
+      ig6_split<AG>(v, p[0], p[1], p[2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if constexpr (AG == 8) *reinterpret_cast<u32x4d*>(&a_s[ob][i * APL + tid * 4]) = u32x4d{p[i][0], p[i][1], p[i][2], p[i][3]};
+      else *reinterpret_cast<u32x2d*>(&a_s[ob][i * APL + tid * 2]) = u32x2d{p[i][0], p[i][1]};
+    }
+#pragma unroll
+    for (int t = 0; t < NBI; ++t) {
+      u32x4d p0, p1, p2;
+      ig6_split8(qb[t], p0, p1, p2);
+      *reinterpret_cast<u32x4d*>(&b_s[ob][(tid + 256 * t) * 4]) = p0;
+      *reinterpret_cast<u32x4d*>(&b_s[ob][BPL + (tid + 256 * t) * 4]) = p1;
+      *reinterpret_cast<u32x4d*>(&b_s[ob][2 * BPL + (tid + 256 * t) * 4]) = p2;
+    }
+  };
+
+  // One trip: [LOAD: the loads of chunk c + 2 into set PAR] - the 24 MFMAs of chunk c out of LDS buffer PAR, with [STORE:] the
+  // split of chunk c + 1 (set PAR ^ 1: 44 VALU operations per item) in the issue slots the MFMAs leave free, ~6 per MFMA, and
+  // its LDS writes into buffer PAR ^ 1 (everybody finished reading that one before the barrier of the last trip) - barrier.
+  // The interleave is spelled out (sched_group_barrier): left to itself hipcc emits the MFMAs as one block and the split as
+  // another, and the two waves of a SIMD fall into step - both multiply, then both split: 45 % of the matrix pipe's cycles.
+  auto trip = [&](auto parc, auto loadc, auto storec, int c) {
+    constexpr int PAR = decltype(parc)::value;
+    constexpr bool LOAD = decltype(loadc)::value, STORE = decltype(storec)::value;
+    if constexpr (LOAD && !(EXP & 2)) load(c + 2, ra[PAR], rb[PAR]);
+    // fragment reads in the order the MFMAs consume them: the first product needs two reads, not nine
+    u32x4d af[2][3], bf[2][3];
+    auto rda = [&](int blk, int p) { af[blk][p] = *reinterpret_cast<const u32x4d*>(&a_s[PAR][p * APL + fa + blk * 128]); };
+    auto rdb = [&](int blk, int p) { bf[blk][p] = *reinterpret_cast<const u32x4d*>(&b_s[PAR][p * BPL + fb + blk * 128]); };
+    rda(0, 2); rdb(0, 0); rda(0, 0); rdb(0, 2); rda(0, 1); rdb(0, 1);
+    rdb(1, 0); rdb(1, 2); rdb(1, 1);
+    rda(1, 2); rda(1, 0); rda(1, 1);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        f32x16 s = acc[mb][nb];                            // the five small products first, smallest first
+        s = ig6_mfma(af[mb][2], bf[nb][0], s);
+        s = ig6_mfma(af[mb][0], bf[nb][2], s);
+        s = ig6_mfma(af[mb][1], bf[nb][1], s);
+        s = ig6_mfma(af[mb][1], bf[nb][0], s);
+        s = ig6_mfma(af[mb][0], bf[nb][1], s);
+        acc[mb][nb] = ig6_mfma(af[mb][0], bf[nb][0], s);
+      }
+    if constexpr (STORE && EXP != 4) stage(PAR ^ 1, ra[PAR ^ 1], rb[PAR ^ 1]);
+    {
+      // the order of the region: masks 0x008 MFMA, 0x002 VALU, 0x100 LDS read, 0x200 LDS write, 0x020 VMEM read
+      if (LOAD) __builtin_amdgcn_sched_group_barrier(0x020, 2 + 8 * NBI, 0);   // the loads of chunk c + 2 first: a whole trip more to return
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (STORE) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          if (i == 9 || i == 17 || i == 23) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
+        }
+      }
+    }
+    if constexpr (!(EXP & 1) || EXP == 4) __syncthreads();
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  using Yes = std::true_type;
+  using No = std::false_type;
+
+  // prologue: chunks 0 and 1 into the register sets, chunk 0 into LDS buffer 0
+  if (nchunks > 0) load(0, ra[0], rb[0]);
+  if (nchunks > 1) load(1, ra[1], rb[1]);
+  if (nchunks > 0) stage(0, ra[0], rb[0]);
+  __syncthreads();
+  int c = 0;
+  for (; c + 3 < nchunks; c += 2) {        // branch-free trips: chunks c + 2 and c + 3 exist
+    trip(T0{}, Yes{}, Yes{}, c);
+    trip(T1{}, Yes{}, Yes{}, c + 1);
+  }
+  // tail: at most three chunks left (c even: LDS buffer 0 holds chunk c, set 1 chunk c + 1)
+  if (c + 2 < nchunks) {                   // three
+    trip(T0{}, Yes{}, Yes{}, c);
+    trip(T1{}, No{}, Yes{}, c + 1);
+    trip(T0{}, No{}, No{}, c + 2);
+  } else if (c + 1 < nchunks) {            // two
+    trip(T0{}, No{}, Yes{}, c);
+    trip(T1{}, No{}, No{}, c + 1);
+  } else if (c < nchunks) {                // one
+    trip(T0{}, No{}, No{}, c);
+  }
+
+  // ---- epilogue: D[row = acc_row(i, hh)][col = lane & 31]; consecutive lanes = consecutive n (pixels | j): coalesced
+  float* ob = a.out + (int64_t)z * a.slab_stride;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wn * 64 + nb * 32 + l31;
+    if (n >= a.N) continue;
+    int64_t obase;
+    int64_t mstride;
+    if (WG) {
+      obase = n;
+      mstride = a.N;
+    } else {
+      const int b = n / hw, r = n - b * hw;
+      if (MODE == kDgrad4) {
+        const int py = r / a.PW, px = r - py * a.PW;
+        obase = (int64_t)b * a.M * a.OH * a.OW + (2 * py + 1 - (cls >> 1)) * a.OW + 2 * px + 1 - (cls & 1);
+        mstride = (int64_t)a.OH * a.OW;
+      } else {
+        obase = (int64_t)b * a.M * hw + r;
+        mstride = hw;
+      }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wm * 64 + mb * 32 + acc_row(i, hh);
+        if (m >= a.M) continue;
+        float v = acc[mb][nb][i];
+        if (a.act) v = v > 0.f ? v : 0.2f * v;
+        ob[obase + m * mstride] = v;
+      }
+  }
+}
+
 // Data gradient of the FIRST downBlock (Cin = 3: the image).  As a GEMM it is M = Cin = 3 rows of a 128-row tile - 2.5 TFLOP/s,
 // 1.3 ms at 256^2 and batch 32 (tools/exp_dconv.py) for 1.6 GFLOP and 150 MB of traffic.  Here a thread owns one low-resolution
 // position (y', x') = the 2 x 2 input pixels (2y' + r, 2x' + s) of every input channel and walks the output channels: input
@@ -385,15 +807,36 @@ static IgShape ig_shape(int kind, int op, int B, int Cin, int H, int W, int Cout
   return s;
 }
 
+// floats of workspace the split images of the A operand take (dconv_igemm6_kernel: forward = the weight, data gradient = its four
+// parity-class regroupings; 6 bytes per element, rows padded to whole tiles); 0 for shapes the split form does not take
+static int64_t ig6_image_elems(int kind, int op, int64_t M, int64_t K) {
+  if (kind != 4 || op == 2 || K % kIgKC != 0) return 0;
+  const int64_t MB = ig_wide(kind, op, M) ? 64 : 128, mt = (M + MB - 1) / MB;
+  return (op == 1 ? 4 : 1) * mt * MB * K * 3 / 2;
+}
+// the head of the workspace: the A images, or (data gradient on the fp32 MFMA) the fp32 parity-class pack; slabs follow
+static int64_t ig_ws_head(int kind, int op, const IgShape& s, int Cin, int Cout) {
+  const int64_t img = ig6_image_elems(kind, op, s.M, s.K), pack = (kind == 4 && op == 1) ? 16ll * Cin * Cout : 0;
+  return img > pack ? img : pack;
+}
+
 static int64_t ig_ws_elems(int kind, int op, int B, int Cin, int H, int W, int Cout) {
   const IgShape s = ig_shape(kind, op, B, Cin, H, W, Cout);
-  int64_t n = s.nsplit > 1 ? s.nsplit * s.out_elems : 0;
-  if (kind == 4 && op == 1) n += 16ll * Cin * Cout;          // the parity-class weight pack
+  const int64_t n = (s.nsplit > 1 ? s.nsplit * s.out_elems : 0) + ig_ws_head(kind, op, s, Cin, Cout);
   return n > 0 ? n : 1;
 }
 
+// 1 (default): the 4x4 convolution's GEMMs run on the bf16 matrix pipe with three-piece operands (dconv_igemm6_kernel) where
+// the shape allows; 0: fp32 MFMA everywhere.  TGSR_DCONV_SPLIT=0 | tgsr_dconv_set_split(0).
+// Bits: 1 = on; 2 = the weights pre-split into LDS images by a pass of their own (forward / data gradient).  (The a0 b0 products in
+// accumulators of their own - HILO, 2.5-3x less error than the fp32 MFMA - need 64 registers more than two waves per SIMD leave.)
+static int g_ig_split = [] {
+  const char* e = getenv("TGSR_DCONV_SPLIT");
+  return e ? (atoi(e) & 3) : 1;
+}();
+
 template <int MODE, bool WIDE = false>
-static int ig_launch(IgArgs a, const IgShape& sh, float* slabs, float* out, hipStream_t s, const char* what) {
+static int ig_launch(IgArgs a, const IgShape& sh, float* slabs, float* out, hipStream_t s, const char* what, bool split = false) {
   if (sh.M >= (1ll << 31) || sh.N >= (1ll << 31) || sh.K >= (1ll << 31) || sh.out_elems >= (1ll << 31)) return TGSR_EUNSUPPORTED;
   a.M = (int)sh.M; a.N = (int)sh.N; a.K = (int)sh.K;
   a.nsplit = sh.nsplit;
@@ -405,6 +848,24 @@ static int ig_launch(IgArgs a, const IgShape& sh, float* slabs, float* out, hipS
   if (a.nsplit > 1) a.act = 0;                                           // the slab sum applies it
   const dim3 grid(WIDE ? (unsigned)((sh.N + 255) / 256) : (unsigned)((sh.N + 127) / 128),
                   WIDE ? (unsigned)((sh.M + 63) / 64) : (unsigned)((sh.M + 127) / 128), (unsigned)(a.nsplit * sh.ncls));
+  if constexpr (MODE == kFwd4 || MODE == kDgrad4 || MODE == kWgrad4) {
+    if (split) {
+      constexpr bool CANPRE = MODE != kWgrad4;
+      const bool pre = CANPRE && (g_ig_split & 2);
+      if constexpr (CANPRE) {
+        if (pre) hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, true>), grid, dim3(256), 0, s, a);
+      }
+      static const int exp_ = [] { const char* e = getenv("TGSR_IG6_EXP"); return e ? atoi(e) : 0; }();
+      if constexpr (MODE == kFwd4 && !WIDE) {
+        if (exp_ == 1) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 1>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
+        if (exp_ == 2) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 2>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
+        if (exp_ == 3) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 3>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
+        if (exp_ == 4) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 4>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
+      }
+      if (!pre) hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false>), grid, dim3(256), 0, s, a);
+      return note_launch(hipGetLastError(), "dconv_igemm6_kernel");
+    }
+  }
   hipLaunchKernelGGL((dconv_igemm_kernel<MODE, WIDE>), grid, dim3(256), 0, s, a);
   return note_launch(hipGetLastError(), what);
 }
@@ -432,11 +893,27 @@ static int dconv_fwd(int kind, const float* x, int B, int Cin, int H, int W, con
   a.A = w; a.S = x; a.C = Cin; a.Hs = H; a.Ws = W;
   a.PH = kind == 4 ? H / 2 : H; a.PW = kind == 4 ? W / 2 : W; a.OH = a.PH; a.OW = a.PW; a.act = act ? 1 : 0;
   hipStream_t s = as_stream(stream);
-  const int rc = kind == 4 ? (ig_wide(4, 0, sh.M) ? ig_launch<kFwd4, true>(a, sh, ws, out, s, "dconv_igemm_kernel<fwd4, wide>")
-                                                  : ig_launch<kFwd4>(a, sh, ws, out, s, "dconv_igemm_kernel<fwd4>"))
-                           : ig_launch<kFwd3>(a, sh, ws, out, s, "dconv_igemm_kernel<fwd3>");
+  float* slabs = ws + ig_ws_head(kind, 0, sh, Cin, Cout);
+  const bool wide = ig_wide(kind, 0, sh.M);
+  const int64_t img = ig6_image_elems(kind, 0, sh.M, sh.K);
+  a.s_bytes = (int64_t)B * Cin * H * W * 4;
+  a.a_bytes = (g_ig_split & 2) ? img * 4 : (int64_t)Cout * sh.K * 4;
+  const bool split = g_ig_split && img > 0 && !(reinterpret_cast<uintptr_t>(ws) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15) &&
+                     a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
+  if (split && (g_ig_split & 2)) {   // the weight, split into three bf16 pieces, as the kernel's LDS images
+    const int64_t MB = wide ? 64 : 128, total = ((sh.M + MB - 1) / MB) * MB * (sh.K / 8);
+    const int pb = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (wide) hipLaunchKernelGGL(ig6_split_rows_kernel<64>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), (int)sh.M, (int)sh.K, total);
+    else hipLaunchKernelGGL(ig6_split_rows_kernel<128>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), (int)sh.M, (int)sh.K, total);
+    const int prc = note_launch(hipGetLastError(), "ig6_split_rows_kernel");
+    if (prc) return prc;
+    a.A = ws;
+  }
+  const int rc = kind == 4 ? (wide ? ig_launch<kFwd4, true>(a, sh, slabs, out, s, "dconv_igemm_kernel<fwd4, wide>", split)
+                                   : ig_launch<kFwd4>(a, sh, slabs, out, s, "dconv_igemm_kernel<fwd4>", split))
+                           : ig_launch<kFwd3>(a, sh, slabs, out, s, "dconv_igemm_kernel<fwd3>");
   if (rc) return rc;
-  return ig_finish(a, ig_used_splits(sh), act ? 1 : 0, ws, out, sh.out_elems, s);
+  return ig_finish(a, ig_used_splits(sh), act ? 1 : 0, slabs, out, sh.out_elems, s);
 }
 
 static int dconv_dgrad(int kind, const float* dy, int B, int Cin, int H, int W, const float* w, int Cout, float* ws,
@@ -463,14 +940,30 @@ static int dconv_dgrad(int kind, const float* dy, int B, int Cin, int H, int W, 
     return note_launch(hipGetLastError(), "dconv_dgrad4_image_kernel");
   }
   if (kind == 4) {
-    const int64_t total = 16ll * Cin * Cout;
-    const int64_t nf = (int64_t)Cin * Cout;
-    const int pb = (int)((nf + 255) / 256 < 4096 ? (nf + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv4x4s2_pack_dgrad_kernel, dim3(pb), dim3(256), 0, s, w, ws, Cout, Cin, total);
-    slabs = ws + total;
+    const bool wide = ig_wide(4, 1, sh.M);
+    const int64_t img = ig6_image_elems(4, 1, sh.M, sh.K);
+    a.s_bytes = (int64_t)B * Cout * (H / 2) * (W / 2) * 4;
+    a.a_bytes = (g_ig_split & 2) ? img * 4 : 64ll * Cin * Cout;
+    const bool split = g_ig_split && img > 0 && !(reinterpret_cast<uintptr_t>(ws) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15) &&
+                       a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
+    if (split && (g_ig_split & 2)) {   // regrouped by parity class AND split into three bf16 pieces, as the kernel's LDS images
+      const int64_t MB = wide ? 64 : 128, mt = (sh.M + MB - 1) / MB, total = mt * MB * (Cout / 2);
+      const int pb = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+      if (wide) hipLaunchKernelGGL(ig6_pack_dgrad_kernel<64>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), Cout, Cin, (int)mt, total);
+      else hipLaunchKernelGGL(ig6_pack_dgrad_kernel<128>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), Cout, Cin, (int)mt, total);
+      rc = note_launch(hipGetLastError(), "ig6_pack_dgrad_kernel");
+    } else {
+      const int64_t total = 16ll * Cin * Cout;
+      const int64_t nf = (int64_t)Cin * Cout;
+      const int pb = (int)((nf + 255) / 256 < 4096 ? (nf + 255) / 256 : 4096);
+      hipLaunchKernelGGL(conv4x4s2_pack_dgrad_kernel, dim3(pb), dim3(256), 0, s, w, ws, Cout, Cin, total);
+      rc = note_launch(hipGetLastError(), "conv4x4s2_pack_dgrad_kernel");
+    }
+    if (rc) return rc;
+    slabs = ws + ig_ws_head(4, 1, sh, Cin, Cout);
     a.A = ws; a.Hs = H / 2; a.Ws = W / 2; a.PH = H / 2; a.PW = W / 2;
-    rc = ig_wide(4, 1, sh.M) ? ig_launch<kDgrad4, true>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad4, wide>")
-                             : ig_launch<kDgrad4>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad4>");
+    rc = wide ? ig_launch<kDgrad4, true>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad4, wide>", split)
+              : ig_launch<kDgrad4>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad4>", split);
   } else {
     a.A = w; a.Hs = H; a.Ws = W; a.PH = H; a.PW = W;
     rc = ig_launch<kDgrad3>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad3>");
@@ -489,7 +982,12 @@ static int dconv_wgrad(int kind, const float* dy, const float* x, int B, int Cin
   a.A = dy; a.S = x; a.C = Cin; a.Hs = H; a.Ws = W;
   a.PH = kind == 4 ? H / 2 : H; a.PW = kind == 4 ? W / 2 : W; a.OH = a.PH; a.OW = a.PW;
   hipStream_t s = as_stream(stream);
-  const int rc = kind == 4 ? ig_launch<kWgrad4>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad4>")
+  // split form: 16-byte rows of dy; a chunk's sixteen pixels inside one image
+  a.a_bytes = (int64_t)B * Cout * a.PH * a.PW * 4;
+  a.s_bytes = (int64_t)B * Cin * H * W * 4;
+  const bool split = g_ig_split && kind == 4 && (a.PH * a.PW) % kIgKC == 0 && !(reinterpret_cast<uintptr_t>(dy) & 15) &&
+                     a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
+  const int rc = kind == 4 ? ig_launch<kWgrad4>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad4>", split)
                            : ig_launch<kWgrad3>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad3>");
   if (rc) return rc;
   return ig_finish(a, ig_used_splits(sh), 0, ws, dw, sh.out_elems, s);
@@ -498,6 +996,12 @@ static int dconv_wgrad(int kind, const float* dy, const float* x, int B, int Cin
 }  // namespace tgsr
 
 using namespace tgsr;
+
+extern "C" int tgsr_dconv_set_split(int on) {
+  const int was = g_ig_split;
+  g_ig_split = on & 3;
+  return was;
+}
 
 extern "C" int64_t tgsr_conv4x4s2_ws_elems(int op, int B, int Cin, int H, int W, int Cout) {
   return (op < 0 || op > 2) ? 0 : ig_ws_elems(4, op, B, Cin, H, W, Cout);

@@ -1407,6 +1407,12 @@ def _dconv_wgrad(kind, dy, x, out=None):
     return dw
 
 
+def dconv_set_split(on: int) -> int:
+    """The discriminators' 4x4 convolutions on the bf16 matrix pipe with three-piece fp32 operands (default on) or
+    on the fp32 MFMA.  Returns the previous setting (tgsr_dconv_set_split)."""
+    return _lib.lib().tgsr_dconv_set_split(int(on))
+
+
 def conv4x4s2(x: torch.Tensor, w: torch.Tensor, leaky: bool = False) -> torch.Tensor:
     """nn.Conv2d(Cin, Cout, 4, 2, 1, bias=False) (downBlock, util.py:92-98) [+ LeakyReLU(0.2)]: x [B,Cin,H,W] ->
     [B,Cout,H/2,W/2]."""
