@@ -43,7 +43,10 @@ EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0
                          # training: weight gradients in the Winograd domain (16 | 9 positions per 2x2 outputs), the direct
                          # 9-tap form, the image heads and the discriminators' implicit GEMM (every MAC issued)
                          "wino_wgrad_kernel": 16.0 / 36.0, "upwino_wgrad_kernel": 9.0 / 36.0, "conv3x3_wgrad_kernel": 1.0,
-                         "dconv_igemm_kernel": 1.0}
+                         "dconv_igemm_kernel": 1.0,
+                         # the same GEMMs on the bf16 pipe with three-piece operands: six bf16 MFMAs (6 x 32 cycles
+                         # per 32 x 32 x 16) where the fp32 form issues eight fp32 MFMAs (8 x 64 cycles): 0.375 of its matrix-pipe time
+                         "dconv_igemm6_kernel": 6.0 * 32 / (8.0 * 64)}
 # bench name of a kernel -> prefix of its name in the rocprofv3 tables under profiles/
 PMC_NAME = {"upwino_glu_kernel": "upwino_kernel"}
 
@@ -740,7 +743,9 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
                             for k, v in sorted(conv.items(), key=lambda kv: -kv[1][2])},
                 **_train_traffic(gan, conv),
                 "note": "`achieved` / `frac`: MACs the convolution kernels of forward, data gradient and weight gradient "
-                        "really issue (direct-form FLOPs of every launch x the kernel's executed fraction), over the "
+                        "really issue (direct-form FLOPs of every launch x the kernel's executed fraction; for dconv_igemm6_kernel, "
+                        "which runs on the bf16 pipe, the fraction is its matrix-pipe time relative to the fp32 MFMA form: `frac` stays "
+                        "the share of the matrix pipe's time at the spec clock), over the "
                         "WHOLE step time (BatchNorm passes, losses, optimizer, EMA included); `conv_kernels_only`: the "
                         "same MACs over the summed durations of those launches (HIP events, one single-stream step)"}
             if world == 1 and not args.no_cpu_baseline:

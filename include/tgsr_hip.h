@@ -465,13 +465,17 @@ int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int C, int HW,
  * The generator's 3x3 convolutions (32 ... 128 channels on 32^2 ... 256^2 pixels) are tgsr_wino_conv3x3_fwd /
  * tgsr_conv3x3_fwd, not these.
  * tgsr_leaky_relu: out = x > 0 ? x : 0.2 x, or with y_for_bwd != NULL the backward out = x * (y > 0 ? 1 : 0.2).
- * tgsr_dconv_set_split(on): on != 0 (the default; TGSR_DCONV_SPLIT=0 in the environment turns it off) lets the 4x4 form's three
- * GEMMs run on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces and six of the nine piece
+ * tgsr_dconv_set_split(on): on != 0 (the default; TGSR_DCONV_SPLIT=0 in the environment turns it off) lets the GEMMs of both
+ * forms run on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces and six of the nine piece
  * products accumulated in fp32 (what is left out is <= 2^-26 of a product; measured error against fp64: below the fp32 MFMA's) -
  * fp32 in, fp32 out, 2.4x the fp32 MFMA rate; shapes it does not take (K % 16 != 0, ...) and on == 0 use the fp32 MFMA.
  * Returns the previous setting.  Process-wide; not meant to be flipped while launches are being issued from other threads.
  */
 int tgsr_dconv_set_split(int on);
+/* 1 when tgsr_conv4x4s2_{fwd (op 0), dgrad (1), wgrad (2)} takes the split form for this shape under the current setting (operand
+ * alignment aside: the calls themselves also require 16-byte aligned w / dy / ws): what a caller's bookkeeping needs to price a launch. */
+int tgsr_conv4x4s2_split_form(int op, int B, int Cin, int H, int W, int Cout);
+int tgsr_conv3x3_gemm_split_form(int op, int B, int Cin, int H, int W, int Cout);
 int64_t tgsr_conv4x4s2_ws_elems(int op, int B, int Cin, int H, int W, int Cout);
 int tgsr_conv4x4s2_fwd(const float* x, int B, int Cin, int H, int W, const float* w, int Cout, int act, float* ws,
                        float* out, void* stream);

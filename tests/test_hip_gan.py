@@ -80,10 +80,22 @@ def _sd_cpu(m):
     return {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 256, 256, 4, 4), (16, 512, 384, 4, 4), (3, 300, 260, 5, 7), (1, 8, 16, 12, 9)])
-def test_conv3x3_gemm_fwd_dgrad_wgrad(B, Cin, Cout, H, W):
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 256, 256, 4, 4), (16, 512, 384, 4, 4), (3, 300, 260, 5, 7), (1, 8, 16, 12, 9),
+                                            (5, 48, 80, 4, 8), (2, 768, 512, 4, 4)])
+@pytest.mark.parametrize("split", [True, False])
+def test_conv3x3_gemm_fwd_dgrad_wgrad(B, Cin, Cout, H, W, split):
     """The implicit-GEMM 3x3 form (the discriminators' 4x4-pixel blocks) against torch: forward, data gradient (filter
-    read transposed + flipped in the kernel) and weight gradient, with split reductions and ragged tiles."""
+    read transposed + flipped in the kernel) and weight gradient, with split reductions and ragged tiles; on the bf16 pipe with
+    three-piece operands where the shape allows (9 C % 16 == 0 | pixels % 16 == 0) and on the fp32 MFMA."""
+    from tgsr_amd import ops
+    was = ops.dconv_set_split(split)
+    try:
+        _conv3x3_gemm_case(B, Cin, Cout, H, W)
+    finally:
+        ops.dconv_set_split(was)
+
+
+def _conv3x3_gemm_case(B, Cin, Cout, H, W):
     from tgsr_amd import ops
     g = torch.Generator().manual_seed(B * 3 + Cin)
     x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)

@@ -389,12 +389,13 @@ __global__ __launch_bounds__(256) void ig6_pack_dgrad_kernel(const float* __rest
 }
 
 // APRE: the A operand arrives pre-split as the LDS images (forward / data gradient; ig6_split_rows_kernel / ig6_pack_dgrad_kernel).
-// EXP (timing experiments only, wrong results): 1 = no barrier in a trip, 2 = no global loads in a trip, 3 = both, 4 = no split / LDS writes
-template <int MODE, bool WIDE = false, bool APRE = false, int EXP = 0>
+template <int MODE, bool WIDE = false, bool APRE = false>
 __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
-  static_assert(MODE == kFwd4 || MODE == kDgrad4 || MODE == kWgrad4, "the 4x4 stride-2 convolution's three GEMMs");
-  constexpr bool WG = MODE == kWgrad4;
-  static_assert(!(WG && WIDE) && !(WG && APRE), "the wide tile and the pre-split A serve the pixel-column modes");
+  constexpr bool WG = MODE == kWgrad4 || MODE == kWgrad3;
+  constexpr bool K3 = MODE == kFwd3 || MODE == kDgrad3;    // 3x3: k = (channel, tap) in 9s - a chunk of 16 straddles channels
+  constexpr int ST = (MODE == kFwd4 || MODE == kWgrad4) ? 2 : 1;       // stride of the gathered tensor's pixel grid
+  static_assert(!(WG && WIDE) && !(WG && APRE) && !(K3 && (WIDE || APRE)) && !(MODE == kWgrad3 && WIDE),
+                "the wide tile and the pre-split A serve the 4x4 convolution's pixel-column modes");
   constexpr int MB = WIDE ? 64 : 128, NB = WIDE ? 256 : 128;
   constexpr int APL = MB * 8, BPL = NB * 8;                // 32-bit words per piece of a tile
   constexpr int NBI = NB / 128;                            // B items per thread
@@ -431,6 +432,10 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
   if (APRE) {
     abase = ((int64_t)(cls * (int)gridDim.y + (int)blockIdx.y) * (a.K / kIgKC) + kbeg / kIgKC) * (3 * APL);
     avo = (unsigned)(tid * (2 * AG));
+  } else if (MODE == kDgrad3) {
+    // A[m = ci][k = 9 co + t] = w[co][ci][8 - t] (the filter read transposed and flipped): row part here, (co, t) part per trip
+    abase = 0;
+    avo = aok ? (unsigned)((m0 + arow) * 36) : kOut;
   } else if (!WG) {
     abase = (MODE == kDgrad4 ? (int64_t)cls * a.M * a.K : 0) + kbeg;
     avo = aok ? (unsigned)(((int64_t)(m0 + arow) * a.K + 8 * ahalf + AG * asub) * 4) : kOut;
@@ -450,7 +455,15 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bvo[t][e] = kOut;
     if (n < a.N) {
-      if (!WG) {
+      if (K3) {
+        // bvo[t][0] = byte offset of the pixel in channel 0 of its sample; wsh[t] = which of the nine taps fall inside the image
+        int poff, piy, pix_;
+        ig_decode_p<MODE>(a, n, poff, piy, pix_);
+        bvo[t][0] = (unsigned)(poff + piy * a.Ws + pix_) * 4u;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+          if ((unsigned)(piy + tp / 3 - 1) < (unsigned)a.Hs && (unsigned)(pix_ + tp % 3 - 1) < (unsigned)a.Ws) wsh[t] |= 1 << tp;
+      } else if (!WG) {
         int poff, piy, pix_;
         ig_decode_p<MODE>(a, n, poff, piy, pix_);
 #pragma unroll
@@ -476,21 +489,27 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
     }
   }
 
-  // two register sets: the loads of chunk c + 2 are issued while chunk c is multiplied and chunk c + 1 is split and stored
-  unsigned ra[2][NAR];
-  float rb[2][NBI][8];
+  // Two register sets: trip c starts with the loads of chunk c + 2 into set c % 2, multiplies chunk c and splits and stores chunk
+  // c + 1 (the other set).  A chunk past the end gets a descriptor of zero records: its loads touch no memory and return zeros,
+  // so no trip needs a branch.  (Three sets - two trips of cover - spilled 30-270 registers in every form tried; refilling a set
+  // right behind its split - 1.25 trips of cover - measured the same as this.)
+  constexpr int NSETS = 2;
+  unsigned ra[NSETS][NAR];
+  float rb[NSETS][NBI][8];
   auto load = [&](int c, unsigned (&qa)[NAR], float (&qb)[NBI][8]) {
     const int k0 = kbeg + c * kIgKC;
+    const bool live = c < nchunks;
     // A
     int64_t aoff;                                          // uniform
     if (APRE) aoff = (abase + (int64_t)c * (3 * APL)) * 4;
+    else if (MODE == kDgrad3) aoff = 0;
     else if (!WG) aoff = (abase + (int64_t)c * kIgKC) * 4;
     else {
       const int b = k0 / hw, r = k0 - b * hw;
       aoff = ((int64_t)b * a.M * hw + r) * 4;
     }
     const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(a.A)) + aoff, 0, (int)(unsigned)(a.a_bytes - aoff), 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(a.A)) + (live ? aoff : 0), 0, live ? (int)(unsigned)(a.a_bytes - aoff) : 0, 0x00020000);
     if constexpr (APRE) {
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
@@ -502,6 +521,14 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
           qa[2 * p] = v[0]; qa[2 * p + 1] = v[1];
         }
       }
+    } else if constexpr (MODE == kDgrad3) {
+      // the eight (co, t) of this item are wave-uniform (the k half is): scalar arithmetic, one add per load
+      const int kh = __builtin_amdgcn_readfirstlane(ahalf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + 8 * kh + e, co = k / 9, tp = k - 9 * co;
+        qa[e] = __builtin_amdgcn_raw_buffer_load_b32(ar, avo == kOut ? kOut : avo + (unsigned)((co * a.M * 9 + 8 - tp) * 4), 0, 0);
+      }
     } else {
       const u32x4d v0 = __builtin_amdgcn_raw_buffer_load_b128(ar, avo, 0, 0);
       qa[0] = v0[0]; qa[1] = v0[1]; qa[2] = v0[2]; qa[3] = v0[3];
@@ -511,10 +538,28 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
       }
     }
     // B
-    if (!WG) {
+    if constexpr (K3) {
+      // k = 9 channel + tap: the chunk starts in channel c0 at tap r0 (scalars); element j = 8 (k half) + e of it is tap
+      // (r0 + j) % 9 of channel c0 + (r0 + j) / 9 - wave-uniform, since the k half of an item is: scalar arithmetic, and per
+      // thread one mask test, one add and one select per load
+      const int c0 = k0 / 9, r0 = k0 - 9 * c0;
+      const int64_t soff = (int64_t)c0 * HsWs * 4;
+      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + (live ? soff : 0), 0, live ? (int)(unsigned)(a.s_bytes - soff) : 0, 0x00020000);
+#pragma unroll
+      for (int t = 0; t < NBI; ++t) {
+        const int kh = __builtin_amdgcn_readfirstlane((tid + 256 * t) / NB);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int q = r0 + 8 * kh + e, cl = q / 9, tp = q - 9 * cl;
+          const int off = (cl * HsWs + (tp / 3 - 1) * a.Ws + tp % 3 - 1) * 4;
+          qb[t][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, ((wsh[t] >> tp) & 1) ? bvo[t][0] + (unsigned)off : kOut, 0, 0));
+        }
+      }
+    } else if (!WG) {
       const int64_t soff = (int64_t)(MODE == kFwd4 ? (k0 >> 4) : (k0 >> 2)) * HsWs * 4;      // the chunk's first channel
       const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + soff, 0, (int)(unsigned)(a.s_bytes - soff), 0x00020000);
+          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + (live ? soff : 0), 0, live ? (int)(unsigned)(a.s_bytes - soff) : 0, 0x00020000);
 #pragma unroll
       for (int t = 0; t < NBI; ++t)
 #pragma unroll
@@ -524,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
       const int b = k0 / hw, r0 = k0 - b * hw;
       const int64_t soff = (int64_t)b * a.C * HsWs * 4;
       const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + soff, 0, (int)(unsigned)(a.s_bytes - soff), 0x00020000);
+          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + (live ? soff : 0), 0, live ? (int)(unsigned)(a.s_bytes - soff) : 0, 0x00020000);
       const int py0 = r0 / a.PW, px0 = r0 - py0 * a.PW;
 #pragma unroll
       for (int t = 0; t < NBI; ++t) {
@@ -533,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
         while (px >= a.PW) { px -= a.PW; ++py; }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int iy = 2 * py + dyk, ix = 2 * px + dxk;
+          const int iy = ST * py + dyk, ix = ST * px + dxk;
           const bool ok = wj[t] >= 0 && (unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws;
           qb[t][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, ok ? (unsigned)(wj[t] + iy * a.Ws + ix) * 4u : kOut, 0, 0));
           ++px;
@@ -581,15 +626,15 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
     }
   };
 
-  // One trip: [LOAD: the loads of chunk c + 2 into set PAR] - the 24 MFMAs of chunk c out of LDS buffer PAR, with [STORE:] the
-  // split of chunk c + 1 (set PAR ^ 1: 44 VALU operations per item) in the issue slots the MFMAs leave free, ~6 per MFMA, and
-  // its LDS writes into buffer PAR ^ 1 (everybody finished reading that one before the barrier of the last trip) - barrier.
-  // The interleave is spelled out (sched_group_barrier): left to itself hipcc emits the MFMAs as one block and the split as
-  // another, and the two waves of a SIMD fall into step - both multiply, then both split: 45 % of the matrix pipe's cycles.
-  auto trip = [&](auto parc, auto loadc, auto storec, int c) {
-    constexpr int PAR = decltype(parc)::value;
-    constexpr bool LOAD = decltype(loadc)::value, STORE = decltype(storec)::value;
-    if constexpr (LOAD && !(EXP & 2)) load(c + 2, ra[PAR], rb[PAR]);
+  // One trip (C = c mod 6: LDS buffer C % 2, register sets by C % NSETS): the loads of chunk c + NSETS into set c % NSETS - the 24
+  // MFMAs of chunk c out of LDS buffer c % 2, with the split of chunk c + 1 (set (c + 1) % NSETS: 44 VALU operations per item) in
+  // the issue slots the MFMAs leave free, ~6 per MFMA, and its LDS writes into the other buffer (everybody finished reading that
+  // one before the barrier of the last trip) - barrier.  The interleave is spelled out (sched_group_barrier): left to itself
+  // hipcc emits the MFMAs as one block and the split as another, and the two waves of a SIMD fall into step - both multiply,
+  // then both split: 45 % of the matrix pipe's cycles.
+  auto trip = [&](auto cc, int c) {
+    constexpr int PAR = decltype(cc)::value, SL = PAR, SS = PAR ^ 1;
+    load(c + 2, ra[SL], rb[SL]);
     // fragment reads in the order the MFMAs consume them: the first product needs two reads, not nine
     u32x4d af[2][3], bf[2][3];
     auto rda = [&](int blk, int p) { af[blk][p] = *reinterpret_cast<const u32x4d*>(&a_s[PAR][p * APL + fa + blk * 128]); };
@@ -609,47 +654,28 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
         s = ig6_mfma(af[mb][0], bf[nb][1], s);
         acc[mb][nb] = ig6_mfma(af[mb][0], bf[nb][0], s);
       }
-    if constexpr (STORE && EXP != 4) stage(PAR ^ 1, ra[PAR ^ 1], rb[PAR ^ 1]);
-    {
-      // the order of the region: masks 0x008 MFMA, 0x002 VALU, 0x100 LDS read, 0x200 LDS write, 0x020 VMEM read
-      if (LOAD) __builtin_amdgcn_sched_group_barrier(0x020, 2 + 8 * NBI, 0);   // the loads of chunk c + 2 first: a whole trip more to return
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+    stage(PAR ^ 1, ra[SS], rb[SS]);
+    // the order of the region: masks 0x008 MFMA, 0x002 VALU, 0x100 LDS read, 0x200 LDS write, 0x020 VMEM read
+    __builtin_amdgcn_sched_group_barrier(0x020, 2 + 8 * NBI, 0);   // the loads first
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (STORE) {
-          __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-          if (i == 9 || i == 17 || i == 23) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
-        }
-      }
+    for (int i = 0; i < 24; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+      if (i == 9 || i == 17 || i == 23) __builtin_amdgcn_sched_group_barrier(0x200, 3, 0);
     }
-    if constexpr (!(EXP & 1) || EXP == 4) __syncthreads();
+    __syncthreads();
   };
-  using T0 = std::integral_constant<int, 0>;
-  using T1 = std::integral_constant<int, 1>;
-  using Yes = std::true_type;
-  using No = std::false_type;
 
   // prologue: chunks 0 and 1 into the register sets, chunk 0 into LDS buffer 0
-  if (nchunks > 0) load(0, ra[0], rb[0]);
-  if (nchunks > 1) load(1, ra[1], rb[1]);
-  if (nchunks > 0) stage(0, ra[0], rb[0]);
+  load(0, ra[0], rb[0]);
+  load(1, ra[1], rb[1]);
+  stage(0, ra[0], rb[0]);
   __syncthreads();
-  int c = 0;
-  for (; c + 3 < nchunks; c += 2) {        // branch-free trips: chunks c + 2 and c + 3 exist
-    trip(T0{}, Yes{}, Yes{}, c);
-    trip(T1{}, Yes{}, Yes{}, c + 1);
-  }
-  // tail: at most three chunks left (c even: LDS buffer 0 holds chunk c, set 1 chunk c + 1)
-  if (c + 2 < nchunks) {                   // three
-    trip(T0{}, Yes{}, Yes{}, c);
-    trip(T1{}, No{}, Yes{}, c + 1);
-    trip(T0{}, No{}, No{}, c + 2);
-  } else if (c + 1 < nchunks) {            // two
-    trip(T0{}, No{}, Yes{}, c);
-    trip(T1{}, No{}, No{}, c + 1);
-  } else if (c < nchunks) {                // one
-    trip(T0{}, No{}, No{}, c);
+  for (int c = 0; c < nchunks; c += 2) {
+    trip(std::integral_constant<int, 0>{}, c);
+    if (c + 1 >= nchunks) break;
+    trip(std::integral_constant<int, 1>{}, c + 1);
   }
 
   // ---- epilogue: D[row = acc_row(i, hh)][col = lane & 31]; consecutive lanes = consecutive n (pixels | j): coalesced
@@ -848,23 +874,14 @@ static int ig_launch(IgArgs a, const IgShape& sh, float* slabs, float* out, hipS
   if (a.nsplit > 1) a.act = 0;                                           // the slab sum applies it
   const dim3 grid(WIDE ? (unsigned)((sh.N + 255) / 256) : (unsigned)((sh.N + 127) / 128),
                   WIDE ? (unsigned)((sh.M + 63) / 64) : (unsigned)((sh.M + 127) / 128), (unsigned)(a.nsplit * sh.ncls));
-  if constexpr (MODE == kFwd4 || MODE == kDgrad4 || MODE == kWgrad4) {
-    if (split) {
-      constexpr bool CANPRE = MODE != kWgrad4;
-      const bool pre = CANPRE && (g_ig_split & 2);
-      if constexpr (CANPRE) {
-        if (pre) hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, true>), grid, dim3(256), 0, s, a);
-      }
-      static const int exp_ = [] { const char* e = getenv("TGSR_IG6_EXP"); return e ? atoi(e) : 0; }();
-      if constexpr (MODE == kFwd4 && !WIDE) {
-        if (exp_ == 1) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 1>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
-        if (exp_ == 2) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 2>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
-        if (exp_ == 3) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 3>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
-        if (exp_ == 4) { hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false, 4>), grid, dim3(256), 0, s, a); return note_launch(hipGetLastError(), "exp"); }
-      }
-      if (!pre) hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false>), grid, dim3(256), 0, s, a);
-      return note_launch(hipGetLastError(), "dconv_igemm6_kernel");
+  if (split) {
+    constexpr bool CANPRE = MODE == kFwd4 || MODE == kDgrad4;
+    const bool pre = CANPRE && (g_ig_split & 2);
+    if constexpr (CANPRE) {
+      if (pre) hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, true>), grid, dim3(256), 0, s, a);
     }
+    if (!pre) hipLaunchKernelGGL((dconv_igemm6_kernel<MODE, WIDE, false>), grid, dim3(256), 0, s, a);
+    return note_launch(hipGetLastError(), "dconv_igemm6_kernel");
   }
   hipLaunchKernelGGL((dconv_igemm_kernel<MODE, WIDE>), grid, dim3(256), 0, s, a);
   return note_launch(hipGetLastError(), what);
@@ -898,8 +915,10 @@ static int dconv_fwd(int kind, const float* x, int B, int Cin, int H, int W, con
   const int64_t img = ig6_image_elems(kind, 0, sh.M, sh.K);
   a.s_bytes = (int64_t)B * Cin * H * W * 4;
   a.a_bytes = (g_ig_split & 2) ? img * 4 : (int64_t)Cout * sh.K * 4;
-  const bool split = g_ig_split && img > 0 && !(reinterpret_cast<uintptr_t>(ws) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15) &&
-                     a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
+  if (kind == 3) a.a_bytes = (int64_t)Cout * sh.K * 4;
+  // split form: whole chunks (3x3: 9 Cin % 16 == 0), 16-byte rows of w, both tensors inside a 4 GB descriptor
+  const bool split = g_ig_split && (kind == 4 ? img > 0 : sh.K % kIgKC == 0) && !(reinterpret_cast<uintptr_t>(ws) & 15) &&
+                     !(reinterpret_cast<uintptr_t>(w) & 15) && a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
   if (split && (g_ig_split & 2)) {   // the weight, split into three bf16 pieces, as the kernel's LDS images
     const int64_t MB = wide ? 64 : 128, total = ((sh.M + MB - 1) / MB) * MB * (sh.K / 8);
     const int pb = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -911,7 +930,7 @@ static int dconv_fwd(int kind, const float* x, int B, int Cin, int H, int W, con
   }
   const int rc = kind == 4 ? (wide ? ig_launch<kFwd4, true>(a, sh, slabs, out, s, "dconv_igemm_kernel<fwd4, wide>", split)
                                    : ig_launch<kFwd4>(a, sh, slabs, out, s, "dconv_igemm_kernel<fwd4>", split))
-                           : ig_launch<kFwd3>(a, sh, slabs, out, s, "dconv_igemm_kernel<fwd3>");
+                           : ig_launch<kFwd3>(a, sh, slabs, out, s, "dconv_igemm_kernel<fwd3>", split);
   if (rc) return rc;
   return ig_finish(a, ig_used_splits(sh), act ? 1 : 0, slabs, out, sh.out_elems, s);
 }
@@ -966,7 +985,10 @@ static int dconv_dgrad(int kind, const float* dy, int B, int Cin, int H, int W, 
               : ig_launch<kDgrad4>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad4>", split);
   } else {
     a.A = w; a.Hs = H; a.Ws = W; a.PH = H; a.PW = W;
-    rc = ig_launch<kDgrad3>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad3>");
+    a.s_bytes = (int64_t)B * Cout * H * W * 4;
+    a.a_bytes = 36ll * Cin * Cout;
+    const bool split = g_ig_split && sh.K % kIgKC == 0 && a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
+    rc = ig_launch<kDgrad3>(a, sh, slabs, dx, s, "dconv_igemm_kernel<dgrad3>", split);
   }
   if (rc) return rc;
   return ig_finish(a, ig_used_splits(sh), 0, slabs, dx, sh.out_elems, s);
@@ -985,10 +1007,10 @@ static int dconv_wgrad(int kind, const float* dy, const float* x, int B, int Cin
   // split form: 16-byte rows of dy; a chunk's sixteen pixels inside one image
   a.a_bytes = (int64_t)B * Cout * a.PH * a.PW * 4;
   a.s_bytes = (int64_t)B * Cin * H * W * 4;
-  const bool split = g_ig_split && kind == 4 && (a.PH * a.PW) % kIgKC == 0 && !(reinterpret_cast<uintptr_t>(dy) & 15) &&
+  const bool split = g_ig_split && (a.PH * a.PW) % kIgKC == 0 && !(reinterpret_cast<uintptr_t>(dy) & 15) &&
                      a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
   const int rc = kind == 4 ? ig_launch<kWgrad4>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad4>", split)
-                           : ig_launch<kWgrad3>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad3>");
+                           : ig_launch<kWgrad3>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad3>", split);
   if (rc) return rc;
   return ig_finish(a, ig_used_splits(sh), 0, ws, dw, sh.out_elems, s);
 }
@@ -1001,6 +1023,22 @@ extern "C" int tgsr_dconv_set_split(int on) {
   const int was = g_ig_split;
   g_ig_split = on & 3;
   return was;
+}
+
+extern "C" int tgsr_conv4x4s2_split_form(int op, int B, int Cin, int H, int W, int Cout) {
+  if (!g_ig_split || op < 0 || op > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2 || ((H | W) & 1)) return 0;
+  const IgShape sh = ig_shape(4, op, B, Cin, H, W, Cout);
+  const int64_t xb = (int64_t)B * Cin * H * W * 4, yb = (int64_t)B * Cout * (H / 2) * (W / 2) * 4, lim = 1ll << 32;
+  if (op == 0) return ig6_image_elems(4, 0, sh.M, sh.K) > 0 && xb < lim && (int64_t)Cout * sh.K * 4 < lim;
+  if (op == 1) return !(Cin <= 4 && (int64_t)Cout * Cin * 64 <= 64 * 1024) && ig6_image_elems(4, 1, sh.M, sh.K) > 0 && yb < lim;
+  return ((H / 2) * (W / 2)) % kIgKC == 0 && xb < lim && yb < lim;
+}
+
+extern "C" int tgsr_conv3x3_gemm_split_form(int op, int B, int Cin, int H, int W, int Cout) {
+  if (!g_ig_split || op < 0 || op > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return 0;
+  const int64_t xb = (int64_t)B * Cin * H * W * 4, yb = (int64_t)B * Cout * H * W * 4, wb = 36ll * Cin * Cout, lim = 1ll << 32;
+  if (xb >= lim || yb >= lim || wb >= lim) return 0;
+  return op == 0 ? (9 * Cin) % kIgKC == 0 : (op == 1 ? (9 * Cout) % kIgKC == 0 : (H * W) % kIgKC == 0);
 }
 
 extern "C" int64_t tgsr_conv4x4s2_ws_elems(int op, int B, int Cin, int H, int W, int Cout) {

@@ -1370,11 +1370,14 @@ def _dconv_fwd(kind, x, w, leaky):
     return out
 
 
-def _dconv_profile(e0, kind, B, Cin, H, W, Cout, Ho, Wo):
-    """bench.py's per-launch hook for the discriminators' implicit-GEMM kernel (forward / data / weight gradient alike:
-    2 B Ho Wo Cout Cin K^2 FLOPs, every one of them issued - no Winograd saving here)."""
+def _dconv_profile(e0, kind, B, Cin, H, W, Cout, Ho, Wo, op=0):
+    """bench.py's per-launch hook for the discriminators' implicit-GEMM kernels (forward / data / weight gradient alike:
+    2 B Ho Wo Cout Cin K^2 FLOPs, every one of them issued - no Winograd saving here; `dconv_igemm6_kernel` when the library
+    takes the three-piece bf16 form for this shape: six bf16 MFMAs per fp32 MAC)."""
     if profile is not None:
-        profile.append(("dconv_igemm_kernel", 2.0 * B * Ho * Wo * Cout * Cin * kind * kind,
+        L = _lib.lib()
+        split = (L.tgsr_conv4x4s2_split_form if kind == 4 else L.tgsr_conv3x3_gemm_split_form)(op, B, Cin, H, W, Cout)
+        profile.append(("dconv_igemm6_kernel" if split else "dconv_igemm_kernel", 2.0 * B * Ho * Wo * Cout * Cin * kind * kind,
                         4.0 * (B * Cin * H * W + B * Cout * Ho * Wo + Cout * Cin * kind * kind), e0, _ev()))
 
 
@@ -1388,7 +1391,7 @@ def _dconv_dgrad(kind, dy, w, H, W):
     ws = torch.empty(ws_elems(1, B, Cin, H, W, Cout), dtype=torch.float32, device=dy.device)
     e0 = _ev() if profile is not None else None
     check(dgrad(_p(dy), B, Cin, H, W, _p(w), Cout, _p(ws), _p(dx), _stream()), name + "_dgrad")
-    _dconv_profile(e0, kind, B, Cin, H, W, Cout, dy.shape[2], dy.shape[3])
+    _dconv_profile(e0, kind, B, Cin, H, W, Cout, dy.shape[2], dy.shape[3], 1)
     return dx
 
 
@@ -1403,7 +1406,7 @@ def _dconv_wgrad(kind, dy, x, out=None):
     dw = out if out is not None else torch.empty(Cout, Cin, kind, kind, dtype=torch.float32, device=x.device)
     e0 = _ev() if profile is not None else None
     check(wgrad(_p(dy), _p(x), B, Cin, H, W, Cout, _p(ws), _p(dw), _stream()), name + "_wgrad")
-    _dconv_profile(e0, kind, B, Cin, H, W, Cout, dy.shape[2], dy.shape[3])
+    _dconv_profile(e0, kind, B, Cin, H, W, Cout, dy.shape[2], dy.shape[3], 2)
     return dw
 
 
