@@ -6,6 +6,8 @@ restatement (values and gradients through torch autograd on the CPU).
 The discriminator ARCHITECTURE is the build's declaration (none exists in the reference): parity is "HIP kernels ==
 their torch restatement", not "== the reference".  The two loss functions and downBlock are the reference's.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -554,3 +556,45 @@ def test_cnn_encoder_walks_a_real_inception_v3_at_batch_16(face_weights):
               % (t_fwd * 1e3, t_with * 1e3, t_without * 1e3, (t_with - t_without) * 1e3, 100 * (t_with - t_without) / t_with))
     finally:
         cfg_reset()
+
+
+def test_split_operand_gemm_is_as_accurate_as_the_fp32_mfma():
+    """the discriminator GEMMs on the bf16 pipe (every fp32 operand = three bf16 pieces exactly, six of the nine piece
+    products, fp32 accumulation) against the same GEMMs on the fp32 MFMA, both measured from an fp64 convolution - a 256 -> 512 layer at
+    16^2 (K = 4096 forward, 2048 data gradient, 2048 pixels weight gradient) and a 3 x 3 block at 4 x 4 pixels (K = 4608): the split
+    form's maximum and rms error must not exceed the fp32 form's by more than a quarter (measured: 0.8-1.0 of it)."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows = []
+    for kind, B, Cin, Cout, H in ((4, 8, 256, 512, 16), (3, 16, 512, 256, 4)):
+        x = torch.randn(B, Cin, H, H, generator=g, dtype=torch.float64)
+        w = torch.randn(Cout, Cin, kind, kind, generator=g, dtype=torch.float64) / (kind * Cin ** 0.5)
+        Ho = H // 2 if kind == 4 else H
+        dy = torch.randn(B, Cout, Ho, Ho, generator=g, dtype=torch.float64)
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        ref = F.conv2d(xr, wr, None, 2 if kind == 4 else 1, 1)
+        ref.backward(dy)
+        xd, wd, dyd = x.float().to(DEV), w.float().to(DEV), dy.float().to(DEV)
+        # the fp64 reference of the fp32-rounded inputs: what both forms are asked to compute
+        xr, wr = xd.double().cpu().requires_grad_(True), wd.double().cpu().requires_grad_(True)
+        ref = F.conv2d(xr, wr, None, 2 if kind == 4 else 1, 1)
+        ref.backward(dyd.double().cpu())
+        err = {}
+        for split in (0, 1):
+            was = ops.dconv_set_split(split)
+            try:
+                if kind == 4:
+                    got = (ops.conv4x4s2(xd, wd), ops.conv4x4s2_dgrad(dyd, wd, H, H), ops.conv4x4s2_wgrad(dyd, xd))
+                else:
+                    got = (ops.conv3x3_gemm(xd, wd), ops.conv3x3_gemm_dgrad(dyd, wd), ops.conv3x3_gemm_wgrad(dyd, xd))
+            finally:
+                ops.dconv_set_split(was)
+            err[split] = [((a.double().cpu() - b.detach()).abs().max().item(), (a.double().cpu() - b.detach()).pow(2).mean().sqrt().item())
+                          for a, b in zip(got, (ref, xr.grad, wr.grad))]
+        for name, e0, e1 in zip(("forward", "data gradient", "weight gradient"), err[0], err[1]):
+            rows.append("%dx%d %-15s fp32 MFMA max %.3e rms %.3e | split max %.3e rms %.3e" % (kind, kind, name, e0[0], e0[1], e1[0], e1[1]))
+            assert e1[0] <= 1.25 * e0[0] and e1[1] <= 1.25 * e0[1], rows[-1]
+    report = os.environ.get("TGSR_MARGIN_REPORT")
+    if report:
+        with open(os.path.join(report, "split_gemm_errors.txt"), "w") as f:
+            f.write("\n".join(rows) + "\n")
