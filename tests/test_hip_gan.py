@@ -598,3 +598,46 @@ def test_split_operand_gemm_is_as_accurate_as_the_fp32_mfma():
     if report:
         with open(os.path.join(report, "split_gemm_errors.txt"), "w") as f:
             f.write("\n".join(rows) + "\n")
+
+
+def test_graph_replayed_discriminator_updates_equal_eager_ones():
+    """train.SRTrainer replays each discriminator's update (forward on real + fake, loss, backward, Adam) from a hipGraph after
+    GRAPH_D_WARMUP eager steps.  Two trainers from one initialisation - one replaying, one with the graphs switched off (same capturable
+    Adam) - take the same six G/D steps on changing batches: discriminator and generator parameters, running statistics and the losses
+    must be bit-identical (same kernels, same order), and the replaying trainer must really be replaying."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd import train
+    cfg_reset()
+    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.DF_DIM = 32, 256, 16
+    try:
+        B = 4
+        trs = []
+        for graphs in (True, False):
+            torch.manual_seed(5)
+            tr = train.SRTrainer(41, device=DEV, discriminators=True)
+            assert tr._graph_d                                   # capturable Adam on both
+            if not graphs:
+                tr._dsteps = -10 ** 9                            # never reaches the warm-up count: eager updates, same optimizer kind
+            trs.append(tr)
+        out = [[], []]
+        for step in range(6):
+            cap, lens, LR, LRb = O.synthetic_batch(B, seed=40 + step)
+            g = torch.Generator().manual_seed(step)
+            hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+            for k, tr in enumerate(trs):
+                torch.manual_seed(100 + step)                    # CA_NET's noise
+                errG, errsD = tr.step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+                out[k].append([float(errG)] + [float(e) for e in errsD])
+        assert all(g is not None and g is not False for g in trs[0]._dgraphs), "the updates were not captured"
+        assert all(g is None for g in trs[1]._dgraphs)
+        assert out[0] == out[1], (out[0], out[1])
+        for a, b in zip(trs[0].netsD + [trs[0].netGL, trs[0].netGH], trs[1].netsD + [trs[1].netGL, trs[1].netGH]):
+            for (ka, va), (_kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+                assert torch.equal(va, vb), ka
+        # another batch size is refused, not silently mis-replayed
+        cap, lens, LR, LRb = O.synthetic_batch(2, seed=9)
+        hr = [(torch.rand(2, 3, s, s) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+        with pytest.raises(ValueError):
+            trs[0].step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+    finally:
+        cfg_reset()

@@ -33,6 +33,10 @@ def prepare_labels(batch_size, device):
             torch.arange(batch_size, device=device))
 
 
+# eager G/D steps before the discriminator updates are captured (allocator, streams and Adam state warm)
+GRAPH_D_WARMUP = 3
+
+
 class SRTrainer:
     def __init__(self, n_words, device="cuda", low="lr", lr=None, ema_decay=0.999, image_encoder=None,
                  discriminators=False, d_lr=None, gather_negatives=None):
@@ -85,15 +89,22 @@ class SRTrainer:
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
         self.netsD, self.optsD, self.bucketsD = [], [], []
+        self._graph_d, self._dgraphs, self._dsteps = False, [], 0
         if discriminators:
             from . import model
             self.netsD = list(discriminators) if not isinstance(discriminators, bool) else \
                 [model.D_NET64(), model.D_NET128(), model.D_NET256()]
+            # A discriminator's update - forward on (real, fake.detach()), loss, backward, Adam - is a closed piece of device work
+            # with no host decision in it: replayed from a hipGraph per discriminator once the step has run `GRAPH_D_WARMUP` times
+            # (single process only: the captured region would have to hold the gradient all-reduce).  ~1 000 of a step's ~1 570
+            # launches leave the host that way; the step was issued no faster than 21-25 ms.  TGSR_GRAPH_D=0: eager.
+            self._graph_d = self.device.type == "cuda" and os.environ.get("TGSR_GRAPH_D", "1") != "0"
+            self._dgraphs, self._dsteps = [None] * len(self.netsD), 0
             for d in self.netsD:
                 d.to(self.device).train()
                 self.bucketsD.append(FlatGradBucket(d.parameters(), buffers=d.buffers()).attach())
                 self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
-                                                   betas=(0.5, 0.999)))
+                                                   betas=(0.5, 0.999), capturable=self._graph_d))
         if self.netsD:
             # the generator loss runs the train-mode discriminators on the fake images once more (g_loss): their running
             # statistics move again, per rank, AFTER their own bucket's all-reduce - so they also ride the generators' bucket
@@ -226,14 +237,62 @@ class SRTrainer:
             self.bucket.flat.zero_()
             raise
 
+    def _d_update_graphed(self, i, fake, real, sent, real_labels, fake_labels):
+        """Discriminator i's update from its hipGraph (captured on first use, on the discriminator's own stream, which is the
+        current one): the inputs are copied into the capture's buffers, the replay zeroes the gradient bucket, runs forward, loss,
+        backward and Adam.  Returns the loss (a buffer of the capture: valid until the next replay)."""
+        g = self._dgraphs[i]
+        if g is None:
+            g = self._dgraphs[i] = self._capture_d_update(i, fake, real, sent, real_labels, fake_labels)
+        if g is False:                                       # the capture failed once: eager from then on
+            d, b, o = self.netsD[i], self.bucketsD[i], self.optsD[i]
+            b.begin_step()
+            e = losses.discriminator_loss(d, real, fake, sent, real_labels, fake_labels)
+            e.backward()
+            b.end_step()
+            o.step()
+            return e
+        if tuple(fake.shape) != tuple(g["fake"].shape) or tuple(sent.shape) != tuple(g["sent"].shape):
+            raise ValueError("the discriminator update was captured for a batch of %d: a step with another batch size needs "
+                             "TGSR_GRAPH_D=0 (or a new trainer)" % g["fake"].shape[0])
+        with torch.no_grad():
+            torch._foreach_copy_([g["fake"], g["real"], g["sent"]], [fake.detach(), real, sent.detach()])
+        g["graph"].replay()
+        return g["err"]
+
+    def _capture_d_update(self, i, fake, real, sent, real_labels, fake_labels):
+        d, b, o, st = self.netsD[i], self.bucketsD[i], self.optsD[i], self._dstreams[i]
+        buf = {"fake": fake.detach().clone(), "real": real.clone(), "sent": sent.detach().clone(),
+               "rl": real_labels.clone(), "fl": fake_labels.clone()}
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=st):
+                b.begin_step()
+                e = losses.discriminator_loss(d, buf["real"], buf["fake"], buf["sent"], buf["rl"], buf["fl"])
+                e.backward()
+                b.end_step()
+                o.step()
+                buf["err"] = e.detach()
+        except Exception as ex:                               # noqa: BLE001 - the eager path is always there
+            import warnings
+            warnings.warn("discriminator %d: the update could not be captured (%s: %s); it stays eager" % (i, type(ex).__name__, ex))
+            b.end_step()                                      # close whatever begin_step opened
+            return False
+        buf["graph"] = graph
+        return buf
+
     def step_gan(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """One G/D alternation: forward the generators once; update every discriminator on (real, fake.detach());
         then update the generators through the UPDATED discriminators on the same fake images.  Returns
         (errG, [errD_i]) as detached tensors."""
         with self._use_packs():
             fake_imgL, fine_im, mu, logvar, words_embs, sent_emb = self.forward_G(captions, cap_lens, LR, LRb)
-        for b in self.bucketsD:
-            self._zero(b)
+        from .parallel import dp_world
+        graphed = bool(self._dstreams) and self._graph_d and dp_world() == 1 and self._dsteps >= GRAPH_D_WARMUP
+        self._dsteps += 1
+        if not graphed:
+            for b in self.bucketsD:
+                self._zero(b)
         if self._dstreams:
             # the three discriminators are independent of each other: each one's forward, backward, all-reduce and Adam
             # step run on a stream of their own (the 64^2 / 128^2 discriminators' layers leave most CUs idle)
@@ -246,11 +305,14 @@ class SRTrainer:
                 with torch.cuda.stream(st):
                     for t in (fine_im[i], hr_pyramid[i], sent_emb):
                         t.record_stream(st)
-                    e = losses.discriminator_loss(d, hr_pyramid[i], fine_im[i], sent_emb, real_labels, fake_labels)
-                    e.backward()
-                    b.end_step()
-                    b.all_reduce_mean()
-                    o.step()
+                    if graphed:
+                        e = self._d_update_graphed(i, fine_im[i], hr_pyramid[i], sent_emb, real_labels, fake_labels)
+                    else:
+                        e = losses.discriminator_loss(d, hr_pyramid[i], fine_im[i], sent_emb, real_labels, fake_labels)
+                        e.backward()
+                        b.end_step()
+                        b.all_reduce_mean()
+                        o.step()
                 errsD.append(e)
             for st in self._dstreams:
                 main.wait_stream(st)
