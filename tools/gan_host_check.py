@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Is the G/D alternation step (BASELINE configs[2]) bound by the host?  Times, per step: the host's time to ENQUEUE a step onto an
+"""Is the G/D alternation step (BASELINE configs[2]; GD=0: the generator step alone) bound by the host?  Times, per step: the host's time to ENQUEUE a step onto an
 empty queue (no synchronisation inside), and the wall time of back-to-back steps.  If the two are equal the GPU is waiting for Python.
     python tools/gan_host_check.py [B]"""
 import os, sys, time
@@ -11,7 +11,7 @@ from tgsr_amd.synthetic import synthetic_batch
 from tgsr_amd.train import SRTrainer
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = "cuda"
-tr = SRTrainer(41, device=dev, discriminators=True)
+tr = SRTrainer(41, device=dev, discriminators=(os.environ.get("GD", "1") == "1"))
 cap, lens, LR, LRb = synthetic_batch(B, seed=100)
 g = torch.Generator().manual_seed(7)
 hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(dev) for s in (64, 128, 256)]
