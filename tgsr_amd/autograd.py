@@ -115,9 +115,11 @@ class PackCache:
         self.entries[key] = [weight.detach(), kind, out, weight._version]
         return out
 
-    def repack(self):
+    def repack(self, force=False):
         """Re-derive every cached pack from the current weights on the pack stream (ordered behind everything queued on
-        the current stream: the optimizer step, and the previous backward's reads of the old packs)."""
+        the current stream: the optimizer step, and the previous backward's reads of the old packs).  `force`: whatever the
+        version counters say - the fused Adam kernel (`torch._fused_adam_`) updates the parameters WITHOUT bumping them, and a
+        cache that trusted the counters served the previous step's weights (caught by test_pack_cache_changes_nothing_over_steps)."""
         if not self.entries:
             return
         dev = next(iter(self.entries.values()))[0].device
@@ -127,7 +129,7 @@ class PackCache:
             self.stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self.stream), torch.no_grad():
                 for e in self.entries.values():
-                    if e[3] != e[0]._version:
+                    if force or e[3] != e[0]._version:
                         self._pack(e[0], e[1], e[2])
                         e[3] = e[0]._version
             self.event = torch.cuda.Event()

@@ -85,7 +85,8 @@ class SRTrainer:
             if self.device.type == "cuda" else None
         for p in gh_params:
             p.register_post_accumulate_grad_hook(self._gh_grad_done)
-        self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999))
+        self._fused_adam = self.device.type == "cuda" and os.environ.get("TGSR_FUSED_ADAM", "1") != "0"
+        self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999), fused=self._fused_adam)
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
         self.netsD, self.optsD, self.bucketsD = [], [], []
@@ -103,8 +104,10 @@ class SRTrainer:
             for d in self.netsD:
                 d.to(self.device).train()
                 self.bucketsD.append(FlatGradBucket(d.parameters(), buffers=d.buffers()).attach())
-                self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
-                                                   betas=(0.5, 0.999), capturable=self._graph_d))
+                # (fused: one pass over a discriminator's ~70 M parameters and their moments instead of the ~10 of the
+                # multi-tensor form - 2.0 ms of a G/D step were Adam kernels running alone on the device)
+                self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR, betas=(0.5, 0.999),
+                                                   capturable=self._graph_d, fused=self._fused_adam))
         if self.netsD:
             # the generator loss runs the train-mode discriminators on the fake images once more (g_loss): their running
             # statistics move again, per rank, AFTER their own bucket's all-reduce - so they also ride the generators' bucket
@@ -346,7 +349,7 @@ class SRTrainer:
         self._all_reduce()
         self.opt.step()
         if self._packs is not None:
-            self._packs.repack()
+            self._packs.repack(force=True)      # the optimizer has just run: every pack is stale, whatever the version counters say
         with torch.no_grad():
             torch._foreach_mul_(self.avg_param_G, self.ema_decay)
             torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
@@ -369,7 +372,7 @@ class SRTrainer:
         self._all_reduce()
         self.opt.step()
         if self._packs is not None:
-            self._packs.repack()                 # next step's packed weights, off the critical stream
+            self._packs.repack(force=True)      # the optimizer has just run: every pack is stale, whatever the version counters say                 # next step's packed weights, off the critical stream
         with torch.no_grad():
             torch._foreach_mul_(self.avg_param_G, self.ema_decay)
             torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
