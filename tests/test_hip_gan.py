@@ -634,6 +634,19 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
         for a, b in zip(trs[0].netsD + [trs[0].netGL, trs[0].netGH], trs[1].netsD + [trs[1].netGL, trs[1].netGH]):
             for (ka, va), (_kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
                 assert torch.equal(va, vb), ka
+        # a new learning rate is not silently ignored: the capture holds the old one and is dropped
+        old_graph = trs[0]._dgraphs[0]["graph"]
+        for k in (0, 1):
+            for pg in trs[k].optsD[0].param_groups:
+                pg["lr"] = 0.5 * pg["lr"]
+        cap, lens, LR, LRb = O.synthetic_batch(B, seed=77)
+        hr = [(torch.rand(B, 3, s, s, generator=torch.Generator().manual_seed(77)) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+        for k, tr in enumerate(trs):
+            torch.manual_seed(177)
+            tr.step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+        assert trs[0]._dgraphs[0]["graph"] is not old_graph
+        for (ka, va), (_kb, vb) in zip(trs[0].netsD[0].state_dict().items(), trs[1].netsD[0].state_dict().items()):
+            assert torch.equal(va, vb), ka
         # another batch size is refused, not silently mis-replayed
         cap, lens, LR, LRb = O.synthetic_batch(2, seed=9)
         hr = [(torch.rand(2, 3, s, s) * 2 - 1).to(DEV) for s in (64, 128, 256)]

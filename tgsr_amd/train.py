@@ -245,6 +245,8 @@ class SRTrainer:
         current one): the inputs are copied into the capture's buffers, the replay zeroes the gradient bucket, runs forward, loss,
         backward and Adam.  Returns the loss (a buffer of the capture: valid until the next replay)."""
         g = self._dgraphs[i]
+        if g not in (None, False) and g["hyper"] != self._d_hyper(i):
+            g = self._dgraphs[i] = None                     # lr / betas / eps changed since the capture (they are baked into it): capture again
         if g is None:
             g = self._dgraphs[i] = self._capture_d_update(i, fake, real, sent, real_labels, fake_labels)
         if g is False:                                       # the capture failed once: eager from then on
@@ -263,10 +265,20 @@ class SRTrainer:
         g["graph"].replay()
         return g["err"]
 
+    def _d_hyper(self, i):
+        """What a captured update has baked in besides the tensors: the optimizer object and its scalar hyper-parameters."""
+        o = self.optsD[i]
+        return (id(o),) + tuple((g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in o.param_groups)
+
+    def reset_d_graphs(self):
+        """Forget the captured discriminator updates (after replacing an optimizer or loading its state: the captures hold the
+        old moment tensors); the next steps capture again."""
+        self._dgraphs = [None] * len(self.netsD)
+
     def _capture_d_update(self, i, fake, real, sent, real_labels, fake_labels):
         d, b, o, st = self.netsD[i], self.bucketsD[i], self.optsD[i], self._dstreams[i]
         buf = {"fake": fake.detach().clone(), "real": real.clone(), "sent": sent.detach().clone(),
-               "rl": real_labels.clone(), "fl": fake_labels.clone()}
+               "rl": real_labels.clone(), "fl": fake_labels.clone(), "hyper": self._d_hyper(i)}
         graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(graph, stream=st):
