@@ -40,6 +40,15 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _rows4(stats: torch.Tensor):
+    """Pointers of the four rows of a [4, C] fp32 tensor (mean, invstd, scale, shift).  Address arithmetic where the tensor is
+    dense - four `stats[i]` views cost ~3 us of host time per call, on ~150 BatchNorm calls of a host-bound train step."""
+    if stats.dim() == 2 and stats.shape[0] == 4 and stats.is_contiguous() and stats.dtype == torch.float32:
+        base, step = stats.data_ptr(), stats.shape[1] * 4
+        return (ctypes.c_void_p(base), ctypes.c_void_p(base + step), ctypes.c_void_p(base + 2 * step), ctypes.c_void_p(base + 3 * step))
+    return _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3])
+
+
 def _need_hip(*ts):
     """Every tensor on ONE HIP device, and that device the current one: the kernels launch on the current device's
     stream (`_stream()`), so a tensor living elsewhere would be read through a foreign pointer on the wrong queue."""
@@ -973,17 +982,18 @@ def bn_train_fwd(raw: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
         if (stat_partial.dim() != 3 or stat_partial.shape[0] != C or stat_partial.shape[2] != 2 or
                 stat_partial.dtype != torch.float32 or not stat_partial.is_contiguous()):
             raise TgsrError("bn_train_fwd: stat_partial %s for %d channels" % (tuple(stat_partial.shape), C))
-        rc = L.tgsr_bn_train_fwd_from_stats(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps),
+        s0, s1, s2, s3 = _rows4(stats)
+        rc = L.tgsr_bn_train_fwd_from_stats(_p(raw), B, C, HW, _p(gamma), _p(beta), float(eps),
                                             float(momentum), _p(running_mean), _p(running_var), int(act), _p(res),
                                             0 if res is None else co * HW, _p(stat_partial), stat_partial.shape[1],
-                                            _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(out), co * HW, _p(nbt),
-                                            _stream())
+                                            s0, s1, s2, s3, _p(out), co * HW, _p(nbt), _stream())
         check(rc, "tgsr_bn_train_fwd_from_stats")
         return out, stats
     ws = torch.empty(C * L.tgsr_bn_train_nsplit(B, C, HW) * 4, dtype=torch.float32, device=dev)
-    rc = L.tgsr_bn_train_fwd(_p(raw), B, C, HW, _p(gamma.detach()), _p(beta.detach()), float(eps), float(momentum),
+    s0, s1, s2, s3 = _rows4(stats)
+    rc = L.tgsr_bn_train_fwd(_p(raw), B, C, HW, _p(gamma), _p(beta), float(eps), float(momentum),
                              _p(running_mean), _p(running_var), int(act), _p(res), 0 if res is None else co * HW, _p(ws),
-                             _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]), _p(out), co * HW, _p(nbt), _stream())
+                             s0, s1, s2, s3, _p(out), co * HW, _p(nbt), _stream())
     check(rc, "tgsr_bn_train_fwd")
     return out, stats
 
@@ -1005,7 +1015,8 @@ def bn_train_bwd(dout: torch.Tensor, raw: torch.Tensor, stats: torch.Tensor, act
     if dbeta is None:
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
     ws = torch.empty(co * L.tgsr_bn_train_nsplit(B, co, HW) * 4, dtype=torch.float32, device=dev)
-    rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, C, HW, _p(stats[2]), _p(stats[3]), _p(stats[0]), _p(stats[1]), int(act),
+    s0, s1, s2, s3 = _rows4(stats)
+    rc = L.tgsr_bn_train_bwd(_p(dout), _p(raw), B, C, HW, s2, s3, s0, s1, int(act),
                              _p(ws), _p(ws), _p(draw), _p(dgamma), _p(dbeta), _stream())
     check(rc, "tgsr_bn_train_bwd")
     return draw, dgamma, dbeta
