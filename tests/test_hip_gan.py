@@ -49,7 +49,7 @@ def close(a, b, atol=1e-4, rtol=1e-4):
                                                    # the image layer's own data-gradient kernel (Cin <= 4): ragged, 1 / 3 / 4 channels
                                                    (3, 3, 64, 6, 10, True), (2, 1, 8, 8, 8, False), (1, 4, 16, 12, 260, False),
                                                    (2, 6, 10, 8, 8, False)])      # Cout % 4 != 0: a partial last K-chunk in dgrad
-@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("split", [True, False, 3])      # 3: with the weights pre-split into LDS images by a pass of their own
 def test_conv4x4s2_fwd_dgrad_wgrad(B, Cin, Cout, H, W, leaky, split):
     """split: the three GEMMs on the bf16 matrix pipe with three-piece fp32 operands (the default; shapes with K % 16 != 0 or, for the
     weight gradient, output pixels % 8 != 0 fall back inside the library) | on the fp32 MFMA: same tolerances."""
@@ -84,7 +84,7 @@ def _sd_cpu(m):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 256, 256, 4, 4), (16, 512, 384, 4, 4), (3, 300, 260, 5, 7), (1, 8, 16, 12, 9),
                                             (5, 48, 80, 4, 8), (2, 768, 512, 4, 4)])
-@pytest.mark.parametrize("split", [True, False])
+@pytest.mark.parametrize("split", [True, False, 3])
 def test_conv3x3_gemm_fwd_dgrad_wgrad(B, Cin, Cout, H, W, split):
     """The implicit-GEMM 3x3 form (the discriminators' 4x4-pixel blocks) against torch: forward, data gradient (filter
     read transposed + flipped in the kernel) and weight gradient, with split reductions and ragged tiles; on the bf16 pipe with

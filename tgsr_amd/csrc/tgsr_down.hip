@@ -833,10 +833,19 @@ static IgShape ig_shape(int kind, int op, int B, int Cin, int H, int W, int Cout
   return s;
 }
 
+// 1 (default): the 4x4 convolution's GEMMs run on the bf16 matrix pipe with three-piece operands (dconv_igemm6_kernel) where
+// the shape allows; 0: fp32 MFMA everywhere.  TGSR_DCONV_SPLIT=0 | tgsr_dconv_set_split(0).
+// Bits: 1 = on; 2 = the weights pre-split into LDS images by a pass of their own (forward / data gradient).  (The a0 b0 products in
+// accumulators of their own - HILO, 2.5-3x less error than the fp32 MFMA - need 64 registers more than two waves per SIMD leave.)
+static int g_ig_split = [] {
+  const char* e = getenv("TGSR_DCONV_SPLIT");
+  return e ? (atoi(e) & 3) : 1;
+}();
+
 // floats of workspace the split images of the A operand take (dconv_igemm6_kernel: forward = the weight, data gradient = its four
 // parity-class regroupings; 6 bytes per element, rows padded to whole tiles); 0 for shapes the split form does not take
 static int64_t ig6_image_elems(int kind, int op, int64_t M, int64_t K) {
-  if (kind != 4 || op == 2 || K % kIgKC != 0) return 0;
+  if (!(g_ig_split & 2) || kind != 4 || op == 2 || K % kIgKC != 0) return 0;       // (only the pre-split variant needs them)
   const int64_t MB = ig_wide(kind, op, M) ? 64 : 128, mt = (M + MB - 1) / MB;
   return (op == 1 ? 4 : 1) * mt * MB * K * 3 / 2;
 }
@@ -852,14 +861,6 @@ static int64_t ig_ws_elems(int kind, int op, int B, int Cin, int H, int W, int C
   return n > 0 ? n : 1;
 }
 
-// 1 (default): the 4x4 convolution's GEMMs run on the bf16 matrix pipe with three-piece operands (dconv_igemm6_kernel) where
-// the shape allows; 0: fp32 MFMA everywhere.  TGSR_DCONV_SPLIT=0 | tgsr_dconv_set_split(0).
-// Bits: 1 = on; 2 = the weights pre-split into LDS images by a pass of their own (forward / data gradient).  (The a0 b0 products in
-// accumulators of their own - HILO, 2.5-3x less error than the fp32 MFMA - need 64 registers more than two waves per SIMD leave.)
-static int g_ig_split = [] {
-  const char* e = getenv("TGSR_DCONV_SPLIT");
-  return e ? (atoi(e) & 3) : 1;
-}();
 
 template <int MODE, bool WIDE = false>
 static int ig_launch(IgArgs a, const IgShape& sh, float* slabs, float* out, hipStream_t s, const char* what, bool split = false) {
@@ -917,9 +918,9 @@ static int dconv_fwd(int kind, const float* x, int B, int Cin, int H, int W, con
   a.a_bytes = (g_ig_split & 2) ? img * 4 : (int64_t)Cout * sh.K * 4;
   if (kind == 3) a.a_bytes = (int64_t)Cout * sh.K * 4;
   // split form: whole chunks (3x3: 9 Cin % 16 == 0), 16-byte rows of w, both tensors inside a 4 GB descriptor
-  const bool split = g_ig_split && (kind == 4 ? img > 0 : sh.K % kIgKC == 0) && !(reinterpret_cast<uintptr_t>(ws) & 15) &&
+  const bool split = g_ig_split && sh.K % kIgKC == 0 && !(reinterpret_cast<uintptr_t>(ws) & 15) &&
                      !(reinterpret_cast<uintptr_t>(w) & 15) && a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
-  if (split && (g_ig_split & 2)) {   // the weight, split into three bf16 pieces, as the kernel's LDS images
+  if (split && (g_ig_split & 2) && kind == 4) {   // the weight, split into three bf16 pieces, as the kernel's LDS images
     const int64_t MB = wide ? 64 : 128, total = ((sh.M + MB - 1) / MB) * MB * (sh.K / 8);
     const int pb = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (wide) hipLaunchKernelGGL(ig6_split_rows_kernel<64>, dim3(pb), dim3(256), 0, s, w, reinterpret_cast<unsigned*>(ws), (int)sh.M, (int)sh.K, total);
@@ -963,7 +964,7 @@ static int dconv_dgrad(int kind, const float* dy, int B, int Cin, int H, int W, 
     const int64_t img = ig6_image_elems(4, 1, sh.M, sh.K);
     a.s_bytes = (int64_t)B * Cout * (H / 2) * (W / 2) * 4;
     a.a_bytes = (g_ig_split & 2) ? img * 4 : 64ll * Cin * Cout;
-    const bool split = g_ig_split && img > 0 && !(reinterpret_cast<uintptr_t>(ws) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15) &&
+    const bool split = g_ig_split && sh.K % kIgKC == 0 && !(reinterpret_cast<uintptr_t>(ws) & 15) && !(reinterpret_cast<uintptr_t>(w) & 15) &&
                        a.s_bytes < (1ll << 32) && a.a_bytes < (1ll << 32);
     if (split && (g_ig_split & 2)) {   // regrouped by parity class AND split into three bf16 pieces, as the kernel's LDS images
       const int64_t MB = wide ? 64 : 128, mt = (sh.M + MB - 1) / MB, total = mt * MB * (Cout / 2);
@@ -1029,8 +1030,8 @@ extern "C" int tgsr_conv4x4s2_split_form(int op, int B, int Cin, int H, int W, i
   if (!g_ig_split || op < 0 || op > 2 || B < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2 || ((H | W) & 1)) return 0;
   const IgShape sh = ig_shape(4, op, B, Cin, H, W, Cout);
   const int64_t xb = (int64_t)B * Cin * H * W * 4, yb = (int64_t)B * Cout * (H / 2) * (W / 2) * 4, lim = 1ll << 32;
-  if (op == 0) return ig6_image_elems(4, 0, sh.M, sh.K) > 0 && xb < lim && (int64_t)Cout * sh.K * 4 < lim;
-  if (op == 1) return !(Cin <= 4 && (int64_t)Cout * Cin * 64 <= 64 * 1024) && ig6_image_elems(4, 1, sh.M, sh.K) > 0 && yb < lim;
+  if (op == 0) return sh.K % kIgKC == 0 && xb < lim && (int64_t)Cout * sh.K * 4 < lim;
+  if (op == 1) return !(Cin <= 4 && (int64_t)Cout * Cin * 64 <= 64 * 1024) && sh.K % kIgKC == 0 && yb < lim;
   return ((H / 2) * (W / 2)) % kIgKC == 0 && xb < lim && yb < lim;
 }
 
