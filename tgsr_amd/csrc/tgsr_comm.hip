@@ -24,25 +24,24 @@ struct RcclApi {
 };
 
 static RcclApi* rccl() {
-  static RcclApi api;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  // (a function-local static with an initialiser: C++11 runs it once, also under concurrent first calls)
+  static RcclApi* const loaded = []() -> RcclApi* {
+    static RcclApi api;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {
       api.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (api.so) break;
     }
-    if (api.so) {
-      api.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(api.so, "ncclGetUniqueId"));
-      api.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(api.so, "ncclCommInitRank"));
-      api.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(api.so, "ncclAllReduce"));
-      api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(api.so, "ncclCommDestroy"));
-      api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(api.so, "ncclGetErrorString"));
-      if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) api.so = nullptr;
-    }
-  }
-  return api.so ? &api : nullptr;
+    if (!api.so) return nullptr;
+    api.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(api.so, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(api.so, "ncclCommInitRank"));
+    api.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(api.so, "ncclAllReduce"));
+    api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(api.so, "ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(api.so, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) return nullptr;
+    return &api;
+  }();
+  return loaded;
 }
 
 struct UniqueId { char bytes[128]; };                       // ncclUniqueId: passed BY VALUE to ncclCommInitRank
