@@ -667,7 +667,19 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
              "steps": steps, "warmup": warmup}
     tr = None
     try:
-        tr = SRTrainer(41, device=dev, discriminators=gan)
+        enc = None
+        if gan and getattr(args, "damsm_encoder", False):
+            # generator_loss's DAMSM ranking term (losses.py:375-389) through CNN_ENCODER's real walk.  The trained Inception-v3 is
+            # third-party and absent here: the published TOPOLOGY with seeded random weights (tests/inception_v3_arch.py) runs in its
+            # place - same launches, same sizes, MIOpen convolutions; what it costs, not what it computes, is the point.
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from inception_v3_arch import InceptionV3Arch
+            from tgsr_amd.util import CNN_ENCODER
+            enc = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM, inception=InceptionV3Arch(seed=1)).to(dev).eval()
+            for q in enc.parameters():
+                q.requires_grad = False
+            entry["workload"] += " + the DAMSM ranking term through CNN_ENCODER (Inception-v3 topology, random weights)"
+        tr = SRTrainer(41, device=dev, discriminators=gan, image_encoder=enc)
         if weights is not None:
             tr.text_encoder.load_state_dict(weights["E."])
             tr.netGL.load_state_dict(weights["GL."])
@@ -778,6 +790,9 @@ def main():
                     help="infer = the headline (BASELINE configs[1]); train = generator fwd+bwd+Adam step on MSE+KL "
                          "(BASELINE configs[2] without the discriminator / DAMSM terms the reference does not define)")
     ap.add_argument("--gan", action="store_true", help="--mode train with the three discriminators (G/D alternation)")
+    ap.add_argument("--damsm-encoder", action="store_true",
+                    help="--mode train --gan: add generator_loss's DAMSM ranking term through CNN_ENCODER walking an Inception-v3 "
+                         "topology with random weights (tests/inception_v3_arch.py; the trained trunk is third-party)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (inference mode)")
     ap.add_argument("--eager", action="store_true",
                     help="inference: launch every kernel from the host and alternate `--lanes` stream lanes.  Default "
