@@ -675,6 +675,8 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from inception_v3_arch import InceptionV3Arch
             from tgsr_amd.util import CNN_ENCODER
+            # (the reference's trainer turns MIOpen's / cuDNN's algorithm search on, trainer_objective.py:32: so does this line)
+            torch.backends.cudnn.benchmark = os.environ.get("TGSR_CUDNN_BENCHMARK", "1") != "0"
             enc = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM, inception=InceptionV3Arch(seed=1)).to(dev).eval()
             for q in enc.parameters():
                 q.requires_grad = False
