@@ -245,3 +245,35 @@ def test_wgrad_kind_only_names_kernels_that_take_the_shape():
     L = _lib.lib()
     assert L.tgsr_upwino_wgrad_ws_elems(2, 32, 32, 8, 8) == 0 and L.tgsr_upwino_wgrad_ws_elems(2, 32, 96, 8, 8) == 0
     assert L.tgsr_upwino_wgrad_ws_elems(2, 32, 64, 8, 8) > 0
+
+
+def test_split_form_eligibility_is_host_arithmetic():
+    """Which shapes the discriminator GEMMs take on the bf16 pipe - pure host logic in the library, no GPU needed:
+    whole 16-deep K-chunks (forward: always for the 4x4 form; data gradient: Cout % 4 == 0; 3x3: 9 C % 16 == 0), a weight gradient
+    whose output pixels come in whole chunks, the image layer's data gradient on its own kernel, everything off with the switch."""
+    from tgsr_amd import _lib
+    L = _lib.lib()
+    was = L.tgsr_dconv_set_split(1)
+    try:
+        f4, f3 = L.tgsr_conv4x4s2_split_form, L.tgsr_conv3x3_gemm_split_form
+        assert f4(0, 32, 64, 128, 128, 128) == 1 and f4(1, 32, 64, 128, 128, 128) == 1 and f4(2, 32, 64, 128, 128, 128) == 1
+        assert f4(0, 2, 3, 16, 16, 8) == 1                      # forward: K = 16 Cin, always whole chunks
+        assert f4(1, 2, 3, 16, 16, 8) == 0                      # the image layer's data gradient has its own kernel
+        assert f4(1, 2, 6, 8, 8, 10) == 0                       # 4 Cout = 40: a partial chunk
+        assert f4(2, 1, 40, 4, 4, 33) == 0 and f4(2, 3, 8, 8, 12, 16) == 0      # 4 and 24 output pixels per image
+        assert f4(2, 2, 64, 8, 8, 128) == 1                     # 16 output pixels per image
+        assert f4(0, 2, 8, 7, 8, 8) == 0                        # odd height: the 4x4 form itself refuses it
+        assert f3(0, 2, 256, 4, 4, 256) == 1 and f3(1, 2, 256, 4, 4, 256) == 1 and f3(2, 2, 256, 4, 4, 256) == 1
+        assert f3(0, 3, 300, 5, 7, 260) == 0 and f3(1, 3, 300, 5, 7, 260) == 0 and f3(2, 3, 300, 5, 7, 260) == 0
+        assert f3(0, 1, 48, 4, 8, 80) == 1 and f3(1, 1, 48, 4, 8, 80) == 1 and f3(2, 1, 48, 4, 8, 80) == 1
+        assert f4(0, 1 << 20, 64, 128, 128, 128) == 0           # a tensor beyond a 4 GB buffer descriptor
+        assert L.tgsr_dconv_set_split(0) == 1
+        assert f4(0, 32, 64, 128, 128, 128) == 0 and f3(0, 2, 256, 4, 4, 256) == 0
+        # the workspace of the default form holds no weight images: slabs (+ the data gradient's fp32 class pack) only
+        L.tgsr_dconv_set_split(1)
+        assert L.tgsr_conv4x4s2_ws_elems(0, 32, 64, 128, 128, 128) == 1
+        assert L.tgsr_conv4x4s2_ws_elems(1, 32, 64, 128, 128, 128) == 16 * 64 * 128
+        L.tgsr_dconv_set_split(3)
+        assert L.tgsr_conv4x4s2_ws_elems(0, 32, 64, 128, 128, 128) == 128 * 1024 * 3 // 2
+    finally:
+        L.tgsr_dconv_set_split(was)
