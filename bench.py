@@ -692,6 +692,14 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
         cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
         for _ in range(warmup):
             tr.step(cap, lens, LR, LRb, hr)
+        # The train steps are issued by the host about as fast as the device runs them: whatever this process has
+        # alive by now (the earlier objects of the default line, the trainer's modules and buffers) is garbage-collector work on
+        # every allocation burst of a step.  Collect once and move the survivors out of the collector's sight - what a training
+        # script does after its set-up (`gc.freeze()`); stated in the entry.
+        import gc
+        gc.collect()
+        gc.freeze()
+        entry["host"] = "gc.collect() + gc.freeze() after the warm-up steps"
         ok = True
     except Exception as e:          # noqa: BLE001
         entry["error"] = "%s: %s" % (type(e).__name__, e)
