@@ -25,7 +25,8 @@ python3 bench.py --dtype bf16 --graph --graph-lanes 8 --batch 8 --steps 48 --no-
 python3 bench.py --dtype bf16 --graph --batch 128 --steps 6 --no-cpu-baseline > $OUT/${TAG}_bench_bf16_graph_b128.json 2> $OUT/${TAG}_bench_bf16_graph_b128.err
 echo "lp variants done"
 python3 bench.py --mode train --steps 10 > $OUT/${TAG}_bench_train.json 2> $OUT/${TAG}_bench_train.err
-python3 bench.py --mode train --gan --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_train_gan.json 2> $OUT/${TAG}_bench_train_gan.err
+python3 bench.py --mode train --gan --steps 10 > $OUT/${TAG}_bench_train_gan.json 2> $OUT/${TAG}_bench_train_gan.err
+python3 bench.py --mode train --gan --damsm-encoder --steps 10 --no-cpu-baseline > $OUT/${TAG}_bench_train_gan_damsm.json 2> $OUT/${TAG}_bench_train_gan_damsm.err
 echo "train done"
 python3 bench.py --branch-num 5 --steps 12 --warmup 3 > $OUT/${TAG}_bench_x16_fp32.json 2> $OUT/${TAG}_bench_x16_fp32.err
 python3 bench.py --branch-num 5 --dtype f16 --graph --steps 12 --warmup 3 --no-cpu-baseline > $OUT/${TAG}_bench_x16_f16_graph.json 2> $OUT/${TAG}_bench_x16_f16.err
