@@ -726,9 +726,9 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
     # all-reduces the gradient bucket, a collective rank 0 alone would leave unmatched; only rank 0 records and reports.
     prof = []
     perr = None
-    wside, dstreams = tr._wside, tr._dstreams
+    wside, dstreams, graph_g = tr._wside, tr._dstreams, tr._graph_g
     try:
-        tr._wside, tr._dstreams = None, []
+        tr._wside, tr._dstreams, tr._graph_g = None, [], False      # (eager: a replayed graph has no per-launch events to record)
         ops.profile = prof if rank == 0 else None
         tr.step(cap, lens, LR, LRb, hr)
         torch.cuda.synchronize()
@@ -736,7 +736,7 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
         perr = "%s: %s" % (type(e).__name__, e)
     finally:
         ops.profile = None
-        tr._wside, tr._dstreams = wside, dstreams
+        tr._wside, tr._dstreams, tr._graph_g = wside, dstreams, graph_g
     if not _all_ok(perr is None, dist, dev):       # a rank whose profiled step failed may have skipped a collective
         perr = perr or "the profiled step failed on another rank"
     if rank == 0 and perr is not None:

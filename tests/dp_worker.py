@@ -112,6 +112,31 @@ def main():
                           d["class_ids"][lo:hi])
     torch.cuda.synchronize()
     res["damsm_loss"], res["damsm_flat"] = float(dl), dt.bucket.flat.cpu()
+    # ---- updates replayed from hipGraphs under data parallelism (train.py `_capture_g` / `_capture_d_update`: segments with the
+    # bucket's all-reduce BETWEEN them) against the eager data-parallel step, same initial weights, same shards, same noise: bit
+    # for bit - the generator-only step and the G/D alternation
+    for gan in (False, True):
+        runs = []
+        for graphs in (False, True):
+            t = make_trainer(device=dev, discriminators=gan)
+            if not graphs:
+                t._gsteps = t._dsteps = -10 ** 9
+            ls = []
+            for it in range(6):
+                torch.manual_seed(50 + it)
+                ls.append(float(t.step(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev),
+                                       [h[lo:hi].to(dev) for h in hr])))
+            torch.cuda.synchronize()
+            sd = [v.detach().flatten().float() for m in [t.netGL, t.netGH] + list(t.netsD) for v in m.state_dict().values()]
+            runs.append({"losses": ls, "state": torch.cat(sd).cpu(),
+                         "split": bool(t._ggraphs) and all(isinstance(c, dict) and c["opt"] is not None for c in t._ggraphs.values()) and
+                         all(isinstance(c, dict) and c["opt"] is not None for c in t._dgraphs)})
+            del t
+        tag = "gan" if gan else "g"
+        res["graph_%s_equal" % tag] = runs[0]["losses"] == runs[1]["losses"] and torch.equal(runs[0]["state"], runs[1]["state"])
+        res["graph_%s_split" % tag] = runs[1]["split"] and not runs[0]["split"]
+        res["graph_%s_state" % tag] = runs[1]["state"]
+        res["graph_%s_losses" % tag] = (runs[0]["losses"], runs[1]["losses"])
     if backend == "nccl":
         # the G/D alternation's collectives: each discriminator's bucket is all-reduced on that discriminator's own
         # stream (train.py step_gan), then the generators' bucket on the main one - four RCCL all-reduces per step

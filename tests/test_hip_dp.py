@@ -83,6 +83,13 @@ def test_two_rank_gradients_and_sharded_inference(tmp_path, backend):
     ref = dt.bucket.flat.cpu()
     gerr = float((r[0]["damsm_flat"] - ref).abs().max()) / float(ref.abs().max())
     assert gerr < 1e-4, "gathered-batch DAMSM gradient differs from the single-process gradient: %g" % gerr
+    # ---- the hipGraph-replayed updates under data parallelism (segments around the bucket's all-reduce) == the eager
+    # data-parallel steps, bit for bit, on both ranks; and both ranks hold the same parameters and running statistics after them
+    for tag in ("g", "gan"):
+        for k in range(2):
+            assert r[k]["graph_%s_split" % tag], "rank %d: the %s update was not replayed in segments" % (k, tag)
+            assert r[k]["graph_%s_equal" % tag], (tag, k, r[k]["graph_%s_losses" % tag])
+        assert torch.equal(r[0]["graph_%s_state" % tag], r[1]["graph_%s_state" % tag])
     if backend == "nccl":
         # G/D alternation over RCCL: four all-reduces per step on four streams; after it every rank holds the same
         # generator gradients and has taken the same Adam steps (the shards differ, so identical discriminator parameters

@@ -602,9 +602,11 @@ def test_split_operand_gemm_is_as_accurate_as_the_fp32_mfma():
 
 def test_graph_replayed_discriminator_updates_equal_eager_ones():
     """train.SRTrainer replays each discriminator's update (forward on real + fake, loss, backward, Adam) from a hipGraph after
-    GRAPH_D_WARMUP eager steps.  Two trainers from one initialisation - one replaying, one with the graphs switched off (same capturable
-    Adam) - take the same six G/D steps on changing batches: discriminator and generator parameters, running statistics and the losses
-    must be bit-identical (same kernels, same order), and the replaying trainer must really be replaying."""
+    GRAPH_D_WARMUP eager steps, and the generators' half of the alternation (forward | generator_loss through the updated
+    discriminators, backward, Adam, re-pack, EMA) from two more after GRAPH_G_WARMUP.  Two trainers from one initialisation - one
+    replaying, one with the graphs switched off (same capturable Adam) - take the same six G/D steps on changing batches:
+    discriminator and generator parameters, running statistics and the losses must be bit-identical (same kernels, same order), and
+    the replaying trainer must really be replaying."""
     from tgsr_amd.miscc.config import cfg, cfg_reset
     from tgsr_amd import train
     cfg_reset()
@@ -616,8 +618,9 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
             torch.manual_seed(5)
             tr = train.SRTrainer(41, device=DEV, discriminators=True)
             assert tr._graph_d                                   # capturable Adam on both
+            assert tr._graph_g
             if not graphs:
-                tr._dsteps = -10 ** 9                            # never reaches the warm-up count: eager updates, same optimizer kind
+                tr._dsteps = tr._gsteps = -10 ** 9               # never reach the warm-up count: eager updates, same optimizer kind
             trs.append(tr)
         out = [[], []]
         for step in range(6):
@@ -630,7 +633,12 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
                 out[k].append([float(errG)] + [float(e) for e in errsD])
         assert all(g is not None and g is not False for g in trs[0]._dgraphs), "the updates were not captured"
         assert all(g is None for g in trs[1]._dgraphs)
+        gcaps = list(trs[0]._ggraphs.values())
+        assert gcaps and all(isinstance(c, dict) and c["fwd"] is not None for c in gcaps), "the generators' half was not captured"
+        assert not trs[1]._ggraphs
         assert out[0] == out[1], (out[0], out[1])
+        for a, b in zip(trs[0].avg_param_G, trs[1].avg_param_G):
+            assert torch.equal(a, b)
         for a, b in zip(trs[0].netsD + [trs[0].netGL, trs[0].netGH], trs[1].netsD + [trs[1].netGL, trs[1].netGH]):
             for (ka, va), (_kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
                 assert torch.equal(va, vb), ka
@@ -647,10 +655,18 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
         assert trs[0]._dgraphs[0]["graph"] is not old_graph
         for (ka, va), (_kb, vb) in zip(trs[0].netsD[0].state_dict().items(), trs[1].netsD[0].state_dict().items()):
             assert torch.equal(va, vb), ka
-        # another batch size is refused, not silently mis-replayed
+        # another batch size is not mis-replayed: the discriminators take the eager update for that step, the generators capture
+        # the new shape - still the eager trainer's numbers
         cap, lens, LR, LRb = O.synthetic_batch(2, seed=9)
-        hr = [(torch.rand(2, 3, s, s) * 2 - 1).to(DEV) for s in (64, 128, 256)]
-        with pytest.raises(ValueError):
-            trs[0].step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+        hr = [(torch.rand(2, 3, s, s, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+        res = []
+        for k, tr in enumerate(trs):
+            torch.manual_seed(178)
+            errG, errsD = tr.step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+            res.append([float(errG)] + [float(e) for e in errsD])
+        assert res[0] == res[1], res
+        for a, b in zip(trs[0].netsD + [trs[0].netGL, trs[0].netGH], trs[1].netsD + [trs[1].netGL, trs[1].netGH]):
+            for (ka, va), (_kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+                assert torch.equal(va, vb), ka
     finally:
         cfg_reset()

@@ -296,6 +296,62 @@ def test_pack_cache_changes_nothing_over_steps(monkeypatch):
         cfg_reset()
 
 
+def test_graph_replayed_generator_update_equals_eager_one():
+    """train.SRTrainer replays the generators' update (zero the bucket, forward, MSE + KL, backward with the weight gradients on
+    their side branch, fused Adam, the re-pack of every cached weight pack, EMA) from a hipGraph after GRAPH_G_WARMUP eager steps,
+    one capture per batch shape.  Two trainers from one initialisation - one replaying, one eager (same capturable Adam) - take
+    the same eight steps on changing batches of two caption widths: losses, parameters, running statistics and the EMA copies
+    must be bit-identical, the replaying trainer must really be replaying, and a replayed update must move the parameters'
+    version counters (the caches of derived tensors key on them)."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd import train
+    cfg_reset()
+    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM = 32, 256
+    try:
+        B = 4
+        trs = []
+        for graphs in (True, False):
+            torch.manual_seed(5)
+            tr = train.SRTrainer(41, device=DEV)
+            assert tr._graph_g and tr._packs is not None
+            if not graphs:
+                tr._gsteps = -10 ** 9                            # never reaches the warm-up count: eager updates, same optimizer kind
+            trs.append(tr)
+        out = [[], []]
+        for step in range(8):
+            cap, lens, _LR, LRb = O.synthetic_batch(B, seed=40 + step % 2)      # two caption widths in turn
+            g = torch.Generator().manual_seed(step)
+            LR = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+            hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+            for k, tr in enumerate(trs):
+                torch.manual_seed(100 + step)                    # CA_NET's noise
+                v0 = tr.params[0]._version
+                out[k].append(float(tr.step(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)))
+                assert tr.params[0]._version > v0
+        torch.cuda.synchronize()
+        caps = list(trs[0]._ggraphs.values())
+        assert caps and all(isinstance(c, dict) for c in caps), "the update was not captured: %r" % (caps,)
+        assert not trs[1]._ggraphs
+        assert out[0] == out[1], (out[0], out[1])
+        assert out[0][-1] < out[0][0]
+        for a, b in zip((trs[0].netGL, trs[0].netGH), (trs[1].netGL, trs[1].netGH)):
+            for (ka, va), (_kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+                assert torch.equal(va, vb), ka
+        for a, b in zip(trs[0].avg_param_G, trs[1].avg_param_G):
+            assert torch.equal(a, b)
+        # the eval-mode forward after replayed updates sees the updated weights (version-keyed caches were told)
+        cap, lens, LR, LRb = O.synthetic_batch(B, seed=77)
+        ims = []
+        for tr in trs:
+            tr.netGL.eval(); tr.netGH.eval()
+            with torch.no_grad():
+                w, s_, m = tr._text(cap.to(DEV), lens.tolist())
+                ims.append(tr._forward_nets(LR.to(DEV), LRb.to(DEV), w, s_, m)[1][2])
+        assert torch.equal(ims[0], ims[1])
+    finally:
+        cfg_reset()
+
+
 def test_train_step_decreases_loss_and_updates_running_stats(nets_small):
     from conftest import split_sd
     from tgsr_amd.miscc.config import cfg, cfg_reset

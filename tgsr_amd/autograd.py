@@ -60,10 +60,12 @@ def on_wgrad_stream(dev, inputs, fn, adopted):
         torch.cuda.current_stream(dev).wait_stream(side)
         return fn()
     side.wait_stream(torch.cuda.current_stream(dev))
-    if not torch.cuda.is_current_stream_capturing():     # (inside a graph capture the pool keeps its tensors alive)
-        for t in inputs:
-            if t is not None:
-                t.record_stream(side)
+    # Also inside a graph capture: a block with a recorded side-stream use is not handed out again until the capture has ended
+    # (the allocator defers its end-of-life events), so the next main-stream allocation of the capture cannot alias a tensor
+    # the side branch of the graph is still reading.
+    for t in inputs:
+        if t is not None:
+            t.record_stream(side)
     with torch.cuda.stream(side):
         return fn()
 
@@ -115,6 +117,34 @@ class PackCache:
         self.entries[key] = [weight.detach(), kind, out, weight._version]
         return out
 
+    def get_captured(self, weight, kind):
+        """Inside a hipGraph capture of a train step (train.SRTrainer): the cached pack, without a launch - the captured
+        optimizer segment rewrites every entry in place at the end of each replay (`repack_captured`), so whatever step is
+        replayed next finds the packs of the current weights at these addresses.  None when the (weight, kind) pair was never
+        packed by an eager step: the caller then packs inside the graph."""
+        e = self.entries.get((weight.data_ptr(), tuple(weight.shape), kind))
+        return None if e is None else e[2]
+
+    def repack_captured(self, side):
+        """`repack(force=True)` as nodes of the graph being captured on the current stream: the pack launches fork onto `side`
+        (a branch beside the EMA update) - the caller joins it (`current.wait_stream(side)`) before the capture ends."""
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), torch.no_grad():
+            for e in self.entries.values():
+                self._pack(e[0], e[1], e[2])
+
+    def mark_fresh(self):
+        """After a replay whose graph re-packed every entry: the entries match the weights' current version counters."""
+        for e in self.entries.values():
+            e[3] = e[0]._version
+
+    def settle(self, dev):
+        """Make the current stream wait for a pending eager repack (before a replay that reads the packs)."""
+        if self.event is not None:
+            torch.cuda.current_stream(dev).wait_event(self.event)
+            self.event = None
+
     def repack(self, force=False):
         """Re-derive every cached pack from the current weights on the pack stream (ordered behind everything queued on
         the current stream: the optimizer step, and the previous backward's reads of the old packs).  `force`: whatever the
@@ -142,8 +172,12 @@ _PACKS = None        # the PackCache of the trainer whose step is running (train
 
 
 def _packed(weight, kind):
-    if _PACKS is not None and weight.is_cuda and not torch.cuda.is_current_stream_capturing():
-        return _PACKS.get(weight, kind)
+    if _PACKS is not None and weight.is_cuda:
+        if not torch.cuda.is_current_stream_capturing():
+            return _PACKS.get(weight, kind)
+        hit = _PACKS.get_captured(weight, kind)
+        if hit is not None:
+            return hit
     if kind in ("wino4", "wino4_dgrad"):
         return C.pack_wino4_weight(weight, False, kind == "wino4_dgrad")
     if kind in ("wino4w", "wino4w_dgrad"):

@@ -35,6 +35,8 @@ def prepare_labels(batch_size, device):
 
 # eager G/D steps before the discriminator updates are captured (allocator, streams and Adam state warm)
 GRAPH_D_WARMUP = 3
+# eager steps before the generators' update is captured (the same, plus every weight pack of the step in the PackCache)
+GRAPH_G_WARMUP = 3
 
 
 class SRTrainer:
@@ -76,7 +78,7 @@ class SRTrainer:
         # early (`_fire_early`), the rest with the step's closing all-reduce: two collectives, the first under backward.
         gh_params = [p for p in self.netGH.parameters() if p.requires_grad]
         self._bucket_bufs = list(self.netGL.buffers()) + list(self.netGH.buffers())
-        self.bucket = FlatGradBucket(gh_params + list(self.netGL.parameters()), buffers=self._bucket_bufs).attach()
+        self._gh_params = gh_params
         self._early_n = len(gh_params)                                   # parameters of the early range
         self._early_hi = sum(p.numel() for p in gh_params)               # ... = flat[0:_early_hi]
         self._early_on = os.environ.get("TGSR_EARLY_ALLREDUCE", "1") != "0"
@@ -86,21 +88,27 @@ class SRTrainer:
         for p in gh_params:
             p.register_post_accumulate_grad_hook(self._gh_grad_done)
         self._fused_adam = self.device.type == "cuda" and os.environ.get("TGSR_FUSED_ADAM", "1") != "0"
-        self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999), fused=self._fused_adam)
+        # The generators' update - forward, losses, backward, Adam, re-pack, EMA - holds no host decision once the text encoder has
+        # produced the embeddings: it is replayed from hipGraphs (one per batch shape), in segments with the gradient all-reduce
+        # BETWEEN them, so the replayed step also exists with more than one rank (`_capture_g`).  TGSR_GRAPH_G=0: eager.
+        self._graph_g = self.device.type == "cuda" and os.environ.get("TGSR_GRAPH_G", "1") != "0"
+        self._ggraphs, self._gsteps, self._ghyper, self._g_bump = {}, 0, None, None
+        self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999), fused=self._fused_adam,
+                                    capturable=self._graph_g)
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
         self.netsD, self.optsD, self.bucketsD = [], [], []
-        self._graph_d, self._dgraphs, self._dsteps = False, [], 0
+        self._graph_d, self._dgraphs, self._dsteps, self._d_bump = False, [], 0, []
         if discriminators:
             from . import model
             self.netsD = list(discriminators) if not isinstance(discriminators, bool) else \
                 [model.D_NET64(), model.D_NET128(), model.D_NET256()]
             # A discriminator's update - forward on (real, fake.detach()), loss, backward, Adam - is a closed piece of device work
             # with no host decision in it: replayed from a hipGraph per discriminator once the step has run `GRAPH_D_WARMUP` times
-            # (single process only: the captured region would have to hold the gradient all-reduce).  ~1 000 of a step's ~1 570
+            # (with more than one rank as two graphs around the bucket's all-reduce: `_capture_d_update`).  ~1 000 of a step's ~1 570
             # launches leave the host that way; the step was issued no faster than 21-25 ms.  TGSR_GRAPH_D=0: eager.
             self._graph_d = self.device.type == "cuda" and os.environ.get("TGSR_GRAPH_D", "1") != "0"
-            self._dgraphs, self._dsteps = [None] * len(self.netsD), 0
+            self._dgraphs, self._dsteps, self._d_bump = [None] * len(self.netsD), 0, [None] * len(self.netsD)
             for d in self.netsD:
                 d.to(self.device).train()
                 self.bucketsD.append(FlatGradBucket(d.parameters(), buffers=d.buffers()).attach())
@@ -113,11 +121,14 @@ class SRTrainer:
             # statistics move again, per rank, AFTER their own bucket's all-reduce - so they also ride the generators' bucket
             # and every rank leaves the step with the same discriminator buffers (a snapshot is the same file on every rank)
             self._bucket_bufs = self._bucket_bufs + [b for d in self.netsD for b in d.buffers()]
-            self.bucket = FlatGradBucket(gh_params + list(self.netGL.parameters()), buffers=self._bucket_bufs).attach()
-        self._dstreams = distinct_streams(len(self.netsD), self.device,
-                                          avoid=cur + ([self._wside.cuda_stream] if self._wside is not None else []) +
-                                          ([self._comm.cuda_stream] if self._comm is not None else [])) \
+        self.bucket = FlatGradBucket(gh_params + list(self.netGL.parameters()), buffers=self._bucket_bufs).attach()
+        taken = cur + ([self._wside.cuda_stream] if self._wside is not None else []) + \
+            ([self._comm.cuda_stream] if self._comm is not None else [])
+        self._dstreams = distinct_streams(len(self.netsD), self.device, avoid=taken) \
             if self.device.type == "cuda" and self.netsD and os.environ.get("TGSR_D_STREAMS", "1") != "0" else []
+        taken = taken + [st.cuda_stream for st in self._dstreams]
+        # the stream the generators' graphs are captured on, and the branch their re-pack launches fork onto
+        self._gcap, self._gpack = distinct_streams(2, self.device, avoid=taken) if self._graph_g else (None, None)
 
     # ------------------------------------------------------------------ gradient all-reduce under the tail of backward
     def _arm_early(self):
@@ -159,14 +170,7 @@ class SRTrainer:
     def loss(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """hr_pyramid: the 3 target scales [B,3,2s,2s], [B,3,4s,4s], [B,3,8s,8s]."""
         fake_imgL, fine_im, mu, logvar, words_embs, sent_emb = self.forward_G(captions, cap_lens, LR, LRb)
-        errG = losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
-        if self.image_encoder is not None:
-            B = captions.shape[0]
-            match_labels = torch.arange(B, device=self.device)
-            region_features, cnn_code = self.image_encoder(fine_im[-1])
-            w0, w1, s0, s1, scale, _ = losses.damsm_terms(region_features, cnn_code, words_embs, sent_emb, cap_lens, class_ids,
-                                                          gather=self.gather_negatives)
-            errG = errG + (w0 + w1 + s0 + s1) * (cfg.TRAIN.SMOOTH.LAMBDA * scale)
+        errG = self._loss_from(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
         return errG, fake_imgL, fine_im
 
     @staticmethod
@@ -175,15 +179,23 @@ class SRTrainer:
         gradient kernels write straight into the bucket (parallel.grad_slot) instead of autograd adding into views."""
         bucket.begin_step()
 
-    def forward_G(self, captions, cap_lens, LR, LRb):
-        """Text encoder (frozen) + both generators in training mode: (fake_imgL, fine_im, mu, logvar, words, sent)."""
+    def _text(self, captions, cap_lens):
+        """The frozen text encoder and the caption mask: the only part of a step that reads host data (the caption lengths)."""
         with torch.no_grad():
             words_embs, sent_emb = self.text_encoder(captions, cap_lens, self.text_encoder.init_hidden(captions.shape[0]))
-        mask = caption_mask(captions, words_embs.size(2))
+        return words_embs, sent_emb, caption_mask(captions, words_embs.size(2))
+
+    def _forward_nets(self, LR, LRb, words_embs, sent_emb, mask):
         # (NetG_highweight's trunk on a second stream beside G_SR_NET_low, forward and backward, was measured: 11.9 ms
         # against 11.6 ms on one stream once the weight gradients have their side stream - not kept)
         fake_imgL, _att, mu, logvar = self.netGL(LR, sent_emb, words_embs, mask)
         fine_im, _a, _one = self.netGH(LR, fake_imgL, LRb)
+        return fake_imgL, fine_im, mu, logvar
+
+    def forward_G(self, captions, cap_lens, LR, LRb):
+        """Text encoder (frozen) + both generators in training mode: (fake_imgL, fine_im, mu, logvar, words, sent)."""
+        words_embs, sent_emb, mask = self._text(captions, cap_lens)
+        fake_imgL, fine_im, mu, logvar = self._forward_nets(LR, LRb, words_embs, sent_emb, mask)
         return fake_imgL, fine_im, mu, logvar, words_embs, sent_emb
 
     def d_losses(self, fine_im, hr_pyramid, sent_emb):
@@ -200,7 +212,7 @@ class SRTrainer:
         adv, _log = losses.generator_loss(self.netsD, self.image_encoder, fine_im, real_labels, words_embs, sent_emb,
                                           match_labels, cap_lens, class_ids, streams=self._dstreams or None, lazy_log=True,
                                           gather_negatives=self.gather_negatives)
-        return adv + losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
+        return adv + self._pixel_kl(fake_imgL, fine_im, mu, logvar, hr_pyramid)
 
     @contextlib.contextmanager
     def _use_packs(self):
@@ -240,154 +252,326 @@ class SRTrainer:
             self.bucket.flat.zero_()
             raise
 
+    # ------------------------------------------------------------------ updates replayed from hipGraphs
+    @staticmethod
+    def _opt_key(o):
+        """What a captured optimizer step has baked in: the optimizer object, the addresses of its moment / step tensors (a
+        load_state_dict replaces them) and its scalar hyper-parameters."""
+        first = o.param_groups[0]["params"][0]
+        st = o.state.get(first, {})
+        ids = tuple(int(st[k].data_ptr()) for k in ("exp_avg", "exp_avg_sq", "step") if torch.is_tensor(st.get(k)))
+        return (id(o), ids) + tuple((g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in o.param_groups)
+
+    def _d_hyper(self, i):
+        return self._opt_key(self.optsD[i])
+
+    def _bump_d(self, i):
+        """A replayed (or fused-Adam) update wrote parameters and running statistics without telling autograd's version counters,
+        which every cache of derived tensors keys on (util._FusedParams, PackCache.get, ...)."""
+        if self._d_bump[i] is None:
+            self._d_bump[i] = list(self.bucketsD[i].params) + [b for b in self.netsD[i].buffers()]
+        torch.autograd.graph.increment_version(self._d_bump[i])
+
+    def _bump_g(self):
+        if self._g_bump is None:
+            self._g_bump = list(self.params) + list(self._bucket_bufs)
+        torch.autograd.graph.increment_version(self._g_bump)
+
+    def _d_update_eager(self, i, fake, real, sent, real_labels, fake_labels):
+        d, b, o = self.netsD[i], self.bucketsD[i], self.optsD[i]
+        b.begin_step()
+        e = losses.discriminator_loss(d, real, fake, sent, real_labels, fake_labels)
+        e.backward()
+        b.end_step()
+        b.all_reduce_mean()
+        o.step()
+        self._bump_d(i)
+        return e
+
     def _d_update_graphed(self, i, fake, real, sent, real_labels, fake_labels):
-        """Discriminator i's update from its hipGraph (captured on first use, on the discriminator's own stream, which is the
-        current one): the inputs are copied into the capture's buffers, the replay zeroes the gradient bucket, runs forward, loss,
-        backward and Adam.  Returns the loss (a buffer of the capture: valid until the next replay)."""
+        """Discriminator i's update from its hipGraphs (captured on first use, on the discriminator's own stream, which is the
+        current one): the inputs are copied into the capture's buffers; segment "fb" zeroes the gradient bucket and runs forward,
+        loss and backward, the bucket's all-reduce follows on the same stream when there is more than one rank, segment "opt" is
+        Adam (one rank: one graph holds both).  Returns the loss (a buffer of the capture: valid until the next replay).  A batch
+        of another shape, or a capture that failed once, takes the eager update."""
         g = self._dgraphs[i]
         if g not in (None, False) and g["hyper"] != self._d_hyper(i):
-            g = self._dgraphs[i] = None                     # lr / betas / eps changed since the capture (they are baked into it): capture again
+            g = self._dgraphs[i] = None                     # lr / betas / eps / the moment tensors changed since the capture: capture again
+        if g not in (None, False) and (tuple(fake.shape) != tuple(g["fake"].shape) or tuple(sent.shape) != tuple(g["sent"].shape)):
+            return self._d_update_eager(i, fake, real, sent, real_labels, fake_labels)
         if g is None:
             g = self._dgraphs[i] = self._capture_d_update(i, fake, real, sent, real_labels, fake_labels)
         if g is False:                                       # the capture failed once: eager from then on
-            d, b, o = self.netsD[i], self.bucketsD[i], self.optsD[i]
-            b.begin_step()
-            e = losses.discriminator_loss(d, real, fake, sent, real_labels, fake_labels)
-            e.backward()
-            b.end_step()
-            o.step()
-            return e
-        if tuple(fake.shape) != tuple(g["fake"].shape) or tuple(sent.shape) != tuple(g["sent"].shape):
-            raise ValueError("the discriminator update was captured for a batch of %d: a step with another batch size needs "
-                             "TGSR_GRAPH_D=0 (or a new trainer)" % g["fake"].shape[0])
+            return self._d_update_eager(i, fake, real, sent, real_labels, fake_labels)
         with torch.no_grad():
             torch._foreach_copy_([g["fake"], g["real"], g["sent"]], [fake.detach(), real, sent.detach()])
-        g["graph"].replay()
+        g["fb"].replay()
+        if g["opt"] is not None:
+            self.bucketsD[i].all_reduce_mean()
+            g["opt"].replay()
+        self._bump_d(i)
         return g["err"]
 
-    def _d_hyper(self, i):
-        """What a captured update has baked in besides the tensors: the optimizer object and its scalar hyper-parameters."""
-        o = self.optsD[i]
-        return (id(o),) + tuple((g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]) for g in o.param_groups)
-
     def reset_d_graphs(self):
-        """Forget the captured discriminator updates (after replacing an optimizer or loading its state: the captures hold the
-        old moment tensors); the next steps capture again."""
+        """Forget the captured updates (they are also dropped by themselves when an optimizer's hyper-parameters or state
+        tensors change); the next steps capture again."""
         self._dgraphs = [None] * len(self.netsD)
+        self._ggraphs = {}
 
     def _capture_d_update(self, i, fake, real, sent, real_labels, fake_labels):
+        from .parallel import dp_world
         d, b, o, st = self.netsD[i], self.bucketsD[i], self.optsD[i], self._dstreams[i]
         buf = {"fake": fake.detach().clone(), "real": real.clone(), "sent": sent.detach().clone(),
-               "rl": real_labels.clone(), "fl": fake_labels.clone(), "hyper": self._d_hyper(i)}
-        graph = torch.cuda.CUDAGraph()
+               "rl": real_labels.clone(), "fl": fake_labels.clone(), "hyper": self._d_hyper(i), "opt": None}
+        split = dp_world() > 1                               # the all-reduce sits between the two segments
+        pool = torch.cuda.graph_pool_handle()
+        fb = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(graph, stream=st):
+            with torch.cuda.graph(fb, stream=st, pool=pool):
                 b.begin_step()
                 e = losses.discriminator_loss(d, buf["real"], buf["fake"], buf["sent"], buf["rl"], buf["fl"])
                 e.backward()
                 b.end_step()
-                o.step()
+                if not split:
+                    o.step()
                 buf["err"] = e.detach()
+            if split:
+                buf["opt"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(buf["opt"], stream=st, pool=pool):
+                    o.step()
         except Exception as ex:                               # noqa: BLE001 - the eager path is always there
             import warnings
             warnings.warn("discriminator %d: the update could not be captured (%s: %s); it stays eager" % (i, type(ex).__name__, ex))
             b.end_step()                                      # close whatever begin_step opened
             return False
-        buf["graph"] = graph
+        buf["fb"] = fb
         return buf
 
-    def step_gan(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
-        """One G/D alternation: forward the generators once; update every discriminator on (real, fake.detach());
-        then update the generators through the UPDATED discriminators on the same fake images.  Returns
-        (errG, [errD_i]) as detached tensors."""
-        with self._use_packs():
-            fake_imgL, fine_im, mu, logvar, words_embs, sent_emb = self.forward_G(captions, cap_lens, LR, LRb)
+    # ------------------------------------------------------------------ the generators' update from hipGraphs
+    def _g_key(self, gan, LR, words_embs, cap_lens, class_ids):
         from .parallel import dp_world
-        graphed = bool(self._dstreams) and self._graph_d and dp_world() == 1 and self._dsteps >= GRAPH_D_WARMUP
-        self._dsteps += 1
-        if not graphed:
-            for b in self.bucketsD:
-                self._zero(b)
-        if self._dstreams:
-            # the three discriminators are independent of each other: each one's forward, backward, all-reduce and Adam
-            # step run on a stream of their own (the 64^2 / 128^2 discriminators' layers leave most CUs idle)
-            B = sent_emb.shape[0]
-            real_labels, fake_labels, _ = prepare_labels(B, self.device)
-            main = torch.cuda.current_stream(self.device)
-            errsD = []
-            for i, (d, b, o, st) in enumerate(zip(self.netsD, self.bucketsD, self.optsD, self._dstreams)):
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    for t in (fine_im[i], hr_pyramid[i], sent_emb):
-                        t.record_stream(st)
-                    if graphed:
-                        e = self._d_update_graphed(i, fine_im[i], hr_pyramid[i], sent_emb, real_labels, fake_labels)
-                    else:
-                        e = losses.discriminator_loss(d, hr_pyramid[i], fine_im[i], sent_emb, real_labels, fake_labels)
-                        e.backward()
-                        b.end_step()
-                        b.all_reduce_mean()
-                        o.step()
-                errsD.append(e)
-            for st in self._dstreams:
-                main.wait_stream(st)
-        else:
-            errsD = self.d_losses(fine_im, hr_pyramid, sent_emb)
-            for e, b, o in zip(errsD, self.bucketsD, self.optsD):
-                e.backward()
-                b.end_step()
-                b.all_reduce_mean()
-                o.step()
-        self._zero(self.bucket)
-        for b in self.bucketsD:                       # the generator step also deposits gradients in the discriminators'
-            self._zero(b)                             # parameters; they are discarded (zeroed again next step)
-        # the discriminators only pass the gradient through to the images here: their own parameter gradients would be
-        # discarded (netsD[i].zero_grad() opens the next discriminator step), so they are not computed
-        for b in self.bucketsD:
-            for p in b.params:
-                p.requires_grad_(False)
-        try:
-            errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
+        key = (bool(gan), tuple(LR.shape), int(words_embs.shape[2]), dp_world())
+        if self.image_encoder is not None:
+            # the DAMSM kernels take the caption lengths (and the class mask) as launch arguments: part of what a capture bakes in
+            import numpy as np
+            key += (tuple(int(v) for v in cap_lens),
+                    None if class_ids is None else tuple(int(v) for v in np.asarray(class_ids).ravel()))
+        return key
+
+    def _g_graphs(self, gan, LR, LRb, hr_pyramid, words_embs, sent_emb, mask, cap_lens, class_ids):
+        """The captured update for this step's shapes: a dict of graphs and their static buffers, or None = take the eager step
+        (warm-up, switched off, a configuration that needs a collective inside the loss, or a capture that failed)."""
+        from .parallel import dp_world
+        use = self._graph_g and self._gsteps >= GRAPH_G_WARMUP
+        self._gsteps += 1
+        if not use or (self.image_encoder is not None and self.gather_negatives and dp_world() > 1):
+            return None                     # (DAMSM on the gathered global batch all-gathers inside generator_loss)
+        hyper = self._opt_key(self.opt) + (self.ema_decay,)
+        if hyper != self._ghyper:
+            self._ggraphs, self._ghyper = {}, hyper
+        key = self._g_key(gan, LR, words_embs, cap_lens, class_ids)
+        g = self._ggraphs.get(key)
+        if g is None:
+            g = self._ggraphs[key] = self._capture_g(gan, LR, LRb, hr_pyramid, words_embs, sent_emb, mask, cap_lens, class_ids)
+        return g or None
+
+    def _pixel_kl(self, fake_imgL, fine_im, mu, logvar, hr_pyramid):
+        return losses.MSE(fake_imgL, hr_pyramid) + losses.MSE(fine_im, hr_pyramid) + losses.KL_loss(mu, logvar)
+
+    def _loss_from(self, fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids):
+        """The generator-only step's loss on the networks' outputs (see `loss`)."""
+        errG = self._pixel_kl(fake_imgL, fine_im, mu, logvar, hr_pyramid)
+        if self.image_encoder is not None:
+            region_features, cnn_code = self.image_encoder(fine_im[-1])
+            w0, w1, s0, s1, scale, _ = losses.damsm_terms(region_features, cnn_code, words_embs, sent_emb, cap_lens, class_ids,
+                                                          gather=self.gather_negatives)
+            errG = errG + (w0 + w1 + s0 + s1) * (cfg.TRAIN.SMOOTH.LAMBDA * scale)
+        return errG
+
+    def _g_backward(self, errG, early=True):
+        """errG.backward() with the packs and the weight-gradient side stream; the discriminators only pass the gradient through
+        to the images (their own parameter gradients would be discarded: not computed)."""
+        if early:
             self._arm_early()
-            with self._use_packs(), self._wgrad_side():
-                errG.backward()
-        finally:
-            for b in self.bucketsD:
-                for p in b.params:
-                    p.requires_grad_(True)
-        self.bucket.end_step()
-        for b in self.bucketsD:
-            b.end_step()
-        self._all_reduce()
+        else:
+            self._early, self._early_left = None, -1
+        with self._use_packs(), self._wgrad_side():
+            errG.backward()
+
+    def _g_finish(self, captured=False):
+        """What follows the gradient all-reduce: Adam, the re-pack of every cached weight pack, the EMA of the parameters."""
         self.opt.step()
-        if self._packs is not None:
+        if captured:
+            if self._packs is not None:
+                self._packs.repack_captured(self._gpack)
+        elif self._packs is not None:
             self._packs.repack(force=True)      # the optimizer has just run: every pack is stale, whatever the version counters say
         with torch.no_grad():
             torch._foreach_mul_(self.avg_param_G, self.ema_decay)
             torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
+        if captured and self._packs is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._gpack)      # join the pack branch before the capture ends
+
+    def _capture_g(self, gan, LR, LRb, hr_pyramid, words_embs, sent_emb, mask, cap_lens, class_ids):
+        """Capture the generators' update for one batch shape.  Nothing executes here (stream capture records); `_g_run` replays.
+        Segments, all in one memory pool, the autograd graph of "fwd" alive while "fb" is recorded:
+            "fwd" (G/D alternation only)  both generators forward - the discriminator updates run between it and "fb";
+            "fb"   zero the bucket, [forward,] losses, backward (weight gradients on the side branch), gradients in place;
+            -- the bucket's all-reduce, eager, when there is more than one rank --
+            "opt"  fused Adam, every weight pack re-derived (a branch of its own), EMA      (one rank: part of "fb")."""
+        from .parallel import dp_world
+        split = dp_world() > 1
+        st = self._gcap
+        buf = {"LR": LR.clone(), "LRb": LRb.clone(), "hr": [h.clone() for h in hr_pyramid], "words": words_embs.clone(),
+               "sent": sent_emb.clone(), "mask": mask.clone(), "fwd": None, "opt": None}
+        buf["dst"] = [buf["LR"], buf["LRb"], buf["words"], buf["sent"], buf["mask"]] + buf["hr"]
+        pool = torch.cuda.graph_pool_handle()
+        cap_lens = [int(v) for v in cap_lens]
+        d_params = [p for b in self.bucketsD for p in b.params]
+        if self._packs is not None:
+            self._packs.settle(self.device)
+        opened = False
+        try:
+            if gan:
+                buf["fwd"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(buf["fwd"], stream=st, pool=pool):
+                    with self._use_packs():
+                        nets = self._forward_nets(buf["LR"], buf["LRb"], buf["words"], buf["sent"], buf["mask"])
+                buf["fine"] = nets[1]
+            fb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(fb, stream=st, pool=pool):
+                self.bucket.begin_step()
+                opened = True
+                if gan:
+                    for p in d_params:
+                        p.requires_grad_(False)
+                    errG = self.g_loss(nets[0], nets[1], nets[2], nets[3], buf["words"], buf["sent"], cap_lens, buf["hr"], class_ids)
+                else:
+                    with self._use_packs():
+                        nets = self._forward_nets(buf["LR"], buf["LRb"], buf["words"], buf["sent"], buf["mask"])
+                        errG = self._loss_from(nets[0], nets[1], nets[2], nets[3], buf["words"], buf["sent"], cap_lens, buf["hr"],
+                                               class_ids)
+                self._g_backward(errG, early=False)
+                self.bucket.end_step()
+                opened = False
+                if not split:
+                    self._g_finish(captured=True)
+                buf["err"] = errG.detach()
+            if split:
+                buf["opt"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(buf["opt"], stream=st, pool=pool):
+                    self._g_finish(captured=True)
+        except Exception as ex:                               # noqa: BLE001 - the eager path is always there
+            import warnings
+            warnings.warn("the generators' update could not be captured (%s: %s); it stays eager" % (type(ex).__name__, ex))
+            if opened:
+                self.bucket.end_step()
+            return False
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        buf["fb"] = fb
+        del nets, errG
+        return buf
+
+    def _g_load(self, g, LR, LRb, hr_pyramid, words_embs, sent_emb, mask):
+        with torch.no_grad():
+            torch._foreach_copy_(g["dst"], [LR, LRb, words_embs, sent_emb, mask] + list(hr_pyramid))
+        if self._packs is not None:
+            self._packs.settle(self.device)
+
+    def _g_update_replay(self, g):
+        """Segments "fb" [-> all-reduce] -> "opt" of a captured update; returns the loss (a buffer of the capture)."""
+        g["fb"].replay()
+        if g["opt"] is not None:
+            self._early, self._early_left = None, -1
+            self.bucket.all_reduce_mean()
+            g["opt"].replay()
+        self._bump_g()
+        if self._packs is not None:
+            self._packs.mark_fresh()
+        return g["err"]
+
+    def _d_updates(self, fine_im, hr_pyramid, sent_emb):
+        """Every discriminator's update on (real, fake.detach()): each on a stream of its own - replayed from its hipGraphs once
+        the step has run GRAPH_D_WARMUP times."""
+        graphed = bool(self._dstreams) and self._graph_d and self._dsteps >= GRAPH_D_WARMUP
+        self._dsteps += 1
+        B = sent_emb.shape[0]
+        real_labels, fake_labels, _ = prepare_labels(B, self.device)
+        if not self._dstreams:
+            return [self._d_update_eager(i, fine_im[i], hr_pyramid[i], sent_emb, real_labels, fake_labels)
+                    for i in range(len(self.netsD))]
+        # the three discriminators are independent of each other: each one's forward, backward, all-reduce and Adam
+        # step run on a stream of their own (the 64^2 / 128^2 discriminators' layers leave most CUs idle)
+        main = torch.cuda.current_stream(self.device)
+        errsD = []
+        for i, st in enumerate(self._dstreams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                for t in (fine_im[i], hr_pyramid[i], sent_emb):
+                    t.record_stream(st)
+                upd = self._d_update_graphed if graphed else self._d_update_eager
+                errsD.append(upd(i, fine_im[i], hr_pyramid[i], sent_emb, real_labels, fake_labels))
+        for st in self._dstreams:
+            main.wait_stream(st)
+        return errsD
+
+    def step_gan(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
+        """One G/D alternation: forward the generators once; update every discriminator on (real, fake.detach());
+        then update the generators through the UPDATED discriminators on the same fake images.  Returns
+        (errG, [errD_i]) as detached tensors (buffers of the captures when the step is replayed: valid until the next step)."""
+        words_embs, sent_emb, mask = self._text(captions, cap_lens)
+        g = self._g_graphs(True, LR, LRb, hr_pyramid, words_embs, sent_emb, mask, cap_lens, class_ids)
+        if g is not None:
+            self._g_load(g, LR, LRb, hr_pyramid, words_embs, sent_emb, mask)
+            g["fwd"].replay()
+            errsD = self._d_updates(g["fine"], g["hr"], g["sent"])
+            errG = self._g_update_replay(g)
+            return errG, [e.detach() for e in errsD]
+        with self._use_packs():
+            fake_imgL, fine_im, mu, logvar = self._forward_nets(LR, LRb, words_embs, sent_emb, mask)
+        errsD = self._d_updates(fine_im, hr_pyramid, sent_emb)
+        self._zero(self.bucket)
+        # the discriminators only pass the gradient through to the images here: their own parameter gradients would be
+        # discarded (the next discriminator update zeroes its bucket first), so they are not computed
+        d_params = [p for b in self.bucketsD for p in b.params]
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
+            self._g_backward(errG)
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+            self.bucket.end_step()
+        self._all_reduce()
+        self._g_finish()
+        self._bump_g()
         return errG.detach(), [e.detach() for e in errsD]
 
-    def step(self, captions, cap_lens, LR, LRb, hr_pyramid):
+    def step(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
         """forward + backward + gradient all-reduce (if distributed) + Adam + EMA.  Returns the loss tensor.  With
-        discriminators this is `step_gan` (the generator loss is returned)."""
+        discriminators this is `step_gan` (the generator loss is returned).  After GRAPH_G_WARMUP eager steps the update is
+        replayed from hipGraphs (`_capture_g`), bit-identical to the eager one."""
         if self.netsD:
-            return self.step_gan(captions, cap_lens, LR, LRb, hr_pyramid)[0]
+            return self.step_gan(captions, cap_lens, LR, LRb, hr_pyramid, class_ids)[0]
+        words_embs, sent_emb, mask = self._text(captions, cap_lens)
+        g = self._g_graphs(False, LR, LRb, hr_pyramid, words_embs, sent_emb, mask, cap_lens, class_ids)
+        if g is not None:
+            self._g_load(g, LR, LRb, hr_pyramid, words_embs, sent_emb, mask)
+            return self._g_update_replay(g)
         self._zero(self.bucket)
         try:
             with self._use_packs():
-                errG, _, _ = self.loss(captions, cap_lens, LR, LRb, hr_pyramid)
-                self._arm_early()
-                with self._wgrad_side():
-                    errG.backward()
+                nets = self._forward_nets(LR, LRb, words_embs, sent_emb, mask)
+                errG = self._loss_from(nets[0], nets[1], nets[2], nets[3], words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
+            self._g_backward(errG)
         finally:
             self.bucket.end_step()               # also after a failed step: `.grad` views restored, slots closed
         self._all_reduce()
-        self.opt.step()
-        if self._packs is not None:
-            self._packs.repack(force=True)      # the optimizer has just run: every pack is stale, whatever the version counters say                 # next step's packed weights, off the critical stream
-        with torch.no_grad():
-            torch._foreach_mul_(self.avg_param_G, self.ema_decay)
-            torch._foreach_add_(self.avg_param_G, [p.data for p in self.params], alpha=1.0 - self.ema_decay)
+        self._g_finish()
+        self._bump_g()
         return errG.detach()
 
 
