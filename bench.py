@@ -397,7 +397,69 @@ def _max_over_ranks(dt, dist, dev):
     return float(t.item())
 
 
-def time_regions(run_k_steps, fence, reps, dist, dev):
+def ranks_object(rank, world, dist, dev, ts_local=None):
+    """What the collective layer says about a multi-rank run (every rank calls it; rank 0 gets the dict): backend, one all-reduce
+    of ones through the process group (= world on every rank), the devices the ranks sit on (all distinct for RCCL), and - from
+    `ts_local`, this rank's own region times - the per-rank step time spread (the headline takes the MAX over ranks)."""
+    if dist is None:
+        return {"world": 1, "backend": None}
+    be = dist.get_backend()
+    cdev = dev if be == "nccl" else "cpu"
+    out = {"world": world, "backend": be}
+    x = torch.ones(1 << 16, dtype=torch.float32, device=cdev)
+    dist.all_reduce(x)
+    out["all_reduce_of_ones"] = float(x[0].item())
+    try:
+        ident = str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")) or "index %d" % dev.index
+    except Exception:          # noqa: BLE001
+        ident = "index %d" % dev.index
+    box = [None] * world
+    dist.all_gather_object(box, "cuda:%d %s" % (dev.index, ident))
+    out["devices"], out["distinct_devices"] = box, len(set(box))
+    if ts_local:
+        t = torch.tensor([float(np.median(ts_local))], dtype=torch.float64, device=cdev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per = [float(v.item()) for v in allt]
+        out["per_rank_region_s"] = [round(v, 6) for v in per]
+        out["per_rank_spread"] = round(max(per) / min(per), 4) if min(per) > 0 else None
+    return out
+
+
+def rccl_direct_evidence(world, dist, dev, timeout_s=60.0):
+    """The library's OWN RCCL communicator (parallel.RcclDirect: librccl opened by libtgsr_hip.so, the id broadcast once through
+    the process group): ncclCommCount / ncclCommUserRank as RCCL reports them and one tgsr_allreduce_flat of ones (= world).  Run
+    by every rank at the very END of the bench, on a watchdog thread: a second communicator beside torch's cannot be rehearsed
+    on a one-GPU box (RCCL refuses two ranks on one device), so if it does not return within `timeout_s` the line is printed
+    without it - the measurements are complete by then."""
+    if dist is None or dist.get_backend() != "nccl" or os.environ.get("TGSR_BENCH_RCCL_DIRECT", "1") == "0":
+        return None
+    import threading
+    out = {}
+
+    def work():
+        try:
+            torch.cuda.set_device(dev)
+            from tgsr_amd import ops as _ops
+            from tgsr_amd import parallel
+            rc = parallel.RcclDirect.create()
+            out["rccl_ranks"], out["rccl_rank"] = rc.count()
+            y = torch.ones(1 << 16, dtype=torch.float32, device=dev)
+            _ops.allreduce_flat(rc.comm, y, 1.0)
+            torch.cuda.synchronize()
+            out["allreduce_flat_of_ones"] = float(y[0].item())
+            rc.close()
+        except Exception as e:          # noqa: BLE001
+            out["error"] = "%s: %s" % (type(e).__name__, e)
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return {"error": "no answer within %.0f s" % timeout_s, "hung": True}
+    return out
+
+
+def time_regions(run_k_steps, fence, reps, dist, dev, local=None):
     """`reps` timed regions of exactly K steps each (run_k_steps(r) issues the K steps of region r), every one bracketed by
     barrier + synchronize on both sides; per region the MAX over ranks; returns (median, all of them).  One K-step region of the
     inference path is 10-30 ms - run-to-run +-4 % on one such region hid real changes - so the reported time per K
@@ -409,6 +471,8 @@ def time_regions(run_k_steps, fence, reps, dist, dev):
         run_k_steps(r)
         fence()
         ts.append(time.perf_counter() - t0)
+    if local is not None:
+        local[:] = ts                      # this rank's own times (ranks_object reports the spread)
     if dist is not None:
         t = torch.tensor(ts, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -578,7 +642,34 @@ def lp_object(args, rank, world, dist, dev, weights, fp32_pipe, fence):
     return out
 
 
-def cpu_baseline_gan(weights, batch, budget_s=20.0):
+def _cpu_image_encoder(nef):
+    """CNN_ENCODER on the CPU for the baselines: the Inception-v3 topology (tests/inception_v3_arch.py, seeded random weights, frozen,
+    eval mode) walked as util.py:308-362 does, then the two heads (conv1x1 768 -> nef, Linear 2048 -> nef, uniform(-0.1, 0.1))."""
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from inception_v3_arch import InceptionV3Arch
+    m = InceptionV3Arch(seed=1).eval()
+    for q in m.parameters():
+        q.requires_grad = False
+    g = torch.Generator().manual_seed(3)
+    w_f = (torch.rand(nef, 768, 1, 1, generator=g) * 0.2 - 0.1)
+    w_c, b_c = (torch.rand(nef, 2048, generator=g) * 0.2 - 0.1), torch.zeros(nef)
+
+    def enc(x):
+        x = F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=False)
+        x = m.Conv2d_2b_3x3(m.Conv2d_2a_3x3(m.Conv2d_1a_3x3(x)))
+        x = F.max_pool2d(x, kernel_size=3, stride=2)
+        x = m.Conv2d_4a_3x3(m.Conv2d_3b_1x1(x))
+        x = F.max_pool2d(x, kernel_size=3, stride=2)
+        x = m.Mixed_5d(m.Mixed_5c(m.Mixed_5b(x)))
+        x = m.Mixed_6e(m.Mixed_6d(m.Mixed_6c(m.Mixed_6b(m.Mixed_6a(x)))))
+        feat = x
+        x = F.avg_pool2d(m.Mixed_7c(m.Mixed_7b(m.Mixed_7a(x))), kernel_size=8)
+        return F.conv2d(feat, w_f), F.linear(x.view(x.size(0), -1), w_c, b_c)
+    return enc
+
+
+def cpu_baseline_gan(weights, batch, budget_s=20.0, encoder=False):
     """One G/D alternation on the CPU (oracle generators + the oracle's torch restatement of the build-declared
     discriminators, DF_DIM 64, torch autograd): the three discriminator losses backward, then the generator loss
     (adversarial + MSE + KL) backward - the arithmetic of SRTrainer.step_gan without the optimizer steps."""
@@ -599,13 +690,19 @@ def cpu_baseline_gan(weights, batch, budget_s=20.0):
         words, sent = O.rnn_encoder(sdE, cap, lens.tolist())
     mask = (cap == 0)[:, :words.shape[2]]
     rl, fl = torch.ones(batch), torch.zeros(batch)
+    enc = _cpu_image_encoder(words.shape[1]) if encoder else None
+    from tgsr_amd.miscc.config import cfg as _cfg
+    sm = _cfg.TRAIN.SMOOTH
 
     def one():
         imgs, _att, mu, logvar = O.g_sr_net_low(sdL, LR, sent, words, mask, training=True)
         fine, _a, _one = O.netg_highweight(sdH, LR, imgs, LRb, "lr", training=True)
         for i, sd in enumerate(sdD):
             O.discriminator_loss(sd, hr[i], fine[i].detach(), sent, rl, fl).backward()
-        (O.generator_adv_loss(sdD, fine, sent, rl) + O.mse(imgs, hr) + O.mse(fine, hr) + O.kl_loss(mu, logvar)).backward()
+        adv = (O.generator_adv_loss(sdD, fine, sent, rl) if enc is None else
+               O.generator_loss(sdD, enc, fine, rl, words, sent, torch.arange(batch), lens.tolist(), None, float(sm.GAMMA1),
+                                float(sm.GAMMA2), float(sm.GAMMA3), float(sm.LAMBDA)))
+        (adv + O.mse(imgs, hr) + O.mse(fine, hr) + O.kl_loss(mu, logvar)).backward()
 
     ts, t_all = [], time.perf_counter()
     while len(ts) < 3 and (not ts or (time.perf_counter() - t_all) < budget_s):
@@ -615,9 +712,10 @@ def cpu_baseline_gan(weights, batch, budget_s=20.0):
     med = float(np.median(ts))
     return {"value": round(batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle generators (train-mode BN) + the torch restatement of D_NET64/128/256 (DF_DIM 64): three "
-                      "discriminator_loss backward passes, then generator_loss + MSE + KL backward, torch autograd (fp32), "
+                      "discriminator_loss backward passes, then generator_loss + MSE + KL backward%s, torch autograd (fp32), "
                       "batch %d (the configuration's own), median of %d run(s) within %.0f s, %.2f s/step (no warm-up run: the first "
-                      "step is in the sample)" % (batch, len(ts), budget_s, med)}
+                      "step is in the sample)" % (" - with the DAMSM ranking term through the Inception-v3 topology (random weights) and the two "
+                                                  "heads" if encoder else "", batch, len(ts), budget_s, med)}
 
 
 def _train_traffic(gan, conv):
@@ -648,13 +746,16 @@ def train_object(args, rank, world, dist, dev, weights, fence):
     from tgsr_amd.miscc.config import cfg
     B = args.batch
     out = {"batch_per_gpu": B, "runs": []}
-    for gan in (False, True):
-        out["runs"].append(_train_run(args, rank, world, dist, dev, weights, fence, gan, max(2, min(args.steps, 10)), 3))
+    for gan, enc in ((False, False), (True, False), (True, True)):
+        # runs[2] = BASELINE configs[2] as stated ("G+D+DAMSM loss"): generator_loss's ranking term through CNN_ENCODER
+        out["runs"].append(_train_run(args, rank, world, dist, dev, weights, fence, gan, max(2, min(args.steps, 10)), 3, encoder=enc))
     return out
 
 
-def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup):
-    """One timed train configuration (see train_object): returns its entry dict."""
+def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup, encoder=None):
+    """One timed train configuration (see train_object): returns its entry dict.  encoder: None = as `--damsm-encoder` says."""
+    if encoder is None:
+        encoder = bool(getattr(args, "damsm_encoder", False))
     from tgsr_amd import ops
     from tgsr_amd.synthetic import synthetic_batch
     from tgsr_amd.train import SRTrainer
@@ -668,7 +769,7 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
     tr = None
     try:
         enc = None
-        if gan and getattr(args, "damsm_encoder", False):
+        if gan and encoder:
             # generator_loss's DAMSM ranking term (losses.py:375-389) through CNN_ENCODER's real walk.  The trained Inception-v3 is
             # third-party and absent here: the published TOPOLOGY with seeded random weights (tests/inception_v3_arch.py) runs in its
             # place - same launches, same sizes, MIOpen convolutions; what it costs, not what it computes, is the point.
@@ -722,6 +823,48 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
     sec = dt / max(1, steps)
     entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4), "repeats": reps,
                   "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
+    # one step under torch.profiler (roctracer): every kernel of the step as the device ran it - also the nodes of replayed graphs -
+    # summed by family: the library's own kernels (`tgsr::`), BatchNorm passes among them, everything else (aten / MIOpen / copies)
+    dterr = None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as tp:
+            tr.step(cap, lens, LR, LRb, hr)
+            torch.cuda.synchronize()
+        fam = {"tgsr": [0, 0.0], "bn": [0, 0.0], "other": [0, 0.0]}
+        top_other = {}
+        for ev in tp.events():
+            if ev.device_type != torch.autograd.DeviceType.CUDA:
+                continue
+            nm, us = ev.name, float(getattr(ev, "device_time", 0.0) or getattr(ev, "cuda_time", 0.0))
+            own = "tgsr::" in nm
+            f = fam["tgsr" if own else "other"]
+            f[0] += 1
+            f[1] += us
+            if own and "::bn_" in nm:
+                fam["bn"][0] += 1
+                fam["bn"][1] += us
+            if not own:
+                t = top_other.setdefault(nm[:60], [0, 0.0])
+                t[0] += 1
+                t[1] += us
+        tot = fam["tgsr"][1] + fam["other"][1]
+        if rank == 0 and tot > 0:
+            entry["device_time"] = {
+                "kernels": fam["tgsr"][0] + fam["other"][0], "kernel_ms": round(tot / 1e3, 3),
+                "tgsr_ms": round(fam["tgsr"][1] / 1e3, 3), "non_tgsr_ms": round(fam["other"][1] / 1e3, 3),
+                "non_tgsr_share": round(fam["other"][1] / tot, 4), "non_tgsr_launches": fam["other"][0],
+                "batchnorm_ms": round(fam["bn"][1] / 1e3, 3), "batchnorm_share": round(fam["bn"][1] / tot, 4),
+                "batchnorm_launches": fam["bn"][0],
+                "largest_non_tgsr": [{"name": k, "launches": v[0], "ms": round(v[1] / 1e3, 3)}
+                                     for k, v in sorted(top_other.items(), key=lambda kv: -kv[1][1])[:4]],
+                "note": "one step under torch.profiler (device activities only), summed kernel durations - streams overlap, so "
+                        "kernel_ms exceeds the step time"}
+    except Exception as e:          # noqa: BLE001
+        dterr = "%s: %s" % (type(e).__name__, e)
+    if not _all_ok(dterr is None, dist, dev) and rank == 0:
+        entry["device_time"] = {"error": dterr or "failed on another rank"}
     # one more step with HIP events around every convolution launch (single stream).  EVERY rank takes it - the step
     # all-reduces the gradient bucket, a collective rank 0 alone would leave unmatched; only rank 0 records and reports.
     prof = []
@@ -771,7 +914,8 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup)
                         "WHOLE step time (BatchNorm passes, losses, optimizer, EMA included); `conv_kernels_only`: the "
                         "same MACs over the summed durations of those launches (HIP events, one single-stream step)"}
             if world == 1 and not args.no_cpu_baseline:
-                entry["cpu_baseline"] = (cpu_baseline_gan(weights, B) if gan else cpu_baseline_train(weights, B))
+                entry["cpu_baseline"] = (cpu_baseline_gan(weights, B, encoder=bool(gan and encoder)) if gan else
+                                         cpu_baseline_train(weights, B))
         except Exception as e:      # noqa: BLE001
             entry["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
@@ -957,7 +1101,9 @@ def main():
     region_one(0, False)
     fence()
     reps = _bcast_int(reps_for(time.perf_counter() - t0, args), dist, dev)
-    dt1, ts1 = time_regions(lambda r: region_one(r, r == reps - 1), fence, reps, dist, dev)
+    ts_local = []
+    dt1, ts1 = time_regions(lambda r: region_one(r, r == reps - 1), fence, reps, dist, dev, local=ts_local)
+    ranks = ranks_object(rank, world, dist, dev, ts_local)
 
     # ---- the throughput form: several independent batches in flight (parallel branches of one hipGraph, or eager stream lanes)
     dtm = None
@@ -1090,7 +1236,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(weights, B, x16_pipe=pipe if x16 else None)
         res.update(extras)
+        res["ranks"] = ranks
+    direct = rccl_direct_evidence(world, dist, dev)
+    if rank == 0:
+        if direct is not None:
+            res["ranks"]["rccl_direct"] = direct
+            res["ranks"]["rccl_ranks"] = direct.get("rccl_ranks")
         print(json.dumps(res), flush=True)
+    if direct is not None and direct.get("hung"):
+        sys.stdout.flush()
+        os._exit(0)                      # a thread is stuck inside librccl: the line is out, leave without the interpreter's teardown
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -387,6 +387,7 @@ int tgsr_comm_available(void);
 int tgsr_comm_unique_id(void* id128);
 int tgsr_comm_init(void** comm, const void* id128, int rank, int world);
 int tgsr_allreduce_flat(void* comm, float* buf, int64_t n, float scale, void* stream);
+int tgsr_comm_count(void* comm, int* world, int* rank); /* ncclCommCount / ncclCommUserRank of a communicator: what RCCL itself says */
 int tgsr_comm_destroy(void* comm);
 
 /*
@@ -398,6 +399,27 @@ int tgsr_comm_destroy(void* comm);
  */
 int tgsr_axpy_images(int n, float* const* out, const float* const* t, const float* const* s, const int64_t* numel, float alpha,
                      void* stream);
+
+/*
+ * NetG_highweight(weightmap=True) (model.py:235-245, 276-297; models16.py:119-125, 149-178): `ims_k = one_k * conv_output(out) +
+ * a_k * SRb_k` with a_k a trainable [H, W] map (initial value 1) broadcast over batch and channels.
+ *   fwd: out[bc][p] = t[bc][p] + amap[p] * s[bc][p]     (t = conv_output(out): tgsr_conv_to3_fwd without addend)
+ *   bwd: ds = amap * dy (ds may be NULL), damap[p] = sum_bc dy[bc][p] * s[bc][p] (damap may be NULL), planes added in index order.
+ * BC = B * 3 planes of HW pixels, dense; HW % 4 == 0, pointers 16-byte aligned (else TGSR_EUNSUPPORTED).
+ */
+int tgsr_axpy_map_fwd(const float* t, const float* s, const float* amap, float* out, int BC, int HW, void* stream);
+int tgsr_axpy_map_bwd(const float* dy, const float* s, const float* amap, float* ds, float* damap, int BC, int HW, void* stream);
+
+/*
+ * Eval-mode BatchNorm2d + activation on a raw convolution output, dense NCHW: out = act(raw * scale[c] + shift[c]) with
+ * scale / shift from tgsr_bn_fold (running statistics) - downBlock / Block3x3_leakRelu under .eval() (util.py:92-98; the
+ * train-mode form is tgsr_bn_train_fwd).  act: 0 none, 2 LeakyReLU(0.2) (the selector values of tgsr_bn_train_fwd's `glu`).
+ * bwd: draw = dy * act'(out) * scale[c] (out = the forward output; may be NULL for act 0).  HW % 4 == 0, 16-byte aligned.
+ */
+int tgsr_affine_act_fwd(const float* raw, const float* scale, const float* shift, float* out, int B, int C, int HW, int act,
+                        void* stream);
+int tgsr_affine_act_bwd(const float* dy, const float* out, const float* scale, float* draw, int B, int C, int HW, int act,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Training path (BatchNorm2d batch statistics + backward).  The reference trains through torch autograd over

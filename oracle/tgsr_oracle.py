@@ -263,11 +263,14 @@ def g_sr_net_low16(sd: SD, LR: Tensor, sent_emb: Tensor, words: Tensor, mask: Op
 
 
 def netg_highweight(sd: SD, LR: Tensor, SRb: Sequence[Tensor], LRb: Tensor, low: str = "lr",
-                    training=False, update=None, p: str = ""):
-    """model.py:264-298  NetG_highweight.forward with weightmap=False.
+                    training=False, update=None, p: str = "", use_act: bool = True):
+    """model.py:264-298  NetG_highweight.forward.
 
-    `a` is the constant 0.5 and `one` the constant 1 (model.py:246-248: `.cuda()` on the Parameter
-    leaves a plain tensor, never trained nor saved), so ims_k = tanh(conv5x5(out_k)) + 0.5 * SRb_k.
+    weightmap=False: `a` is the constant 0.5 and `one` the constant 1 (model.py:246-248: `.cuda()` on the Parameter
+    leaves a plain tensor, never trained nor saved), so ims_k = conv_output(out_k) + 0.5 * SRb_k.
+    weightmap=True (recognised by the keys `a1..a3` in `sd`, model.py:235-245): ims_k = conv_output(out_k) + a_k * SRb_k with
+    a_k an [H, W] map broadcast over batch and channels (:277, 286, 294); returns (ims, a3, one) (:293-295).
+    use_act=False (model.py:223-226): conv_output is the bare conv5x5, no Tanh.
     """
     if low == "lrblur":
         x = LRb
@@ -275,6 +278,7 @@ def netg_highweight(sd: SD, LR: Tensor, SRb: Sequence[Tensor], LRb: Tensor, low:
         x = LR - LRb
     else:
         x = LR
+    maps = [sd[p + "a%d" % k] for k in (1, 2, 3)] if (p + "a1") in sd else None
     a = LR.new_tensor([0.5])
     one = LR.new_ones(1)
     out = conv_bn_glu(x, sd, p + "convin.", training, update)
@@ -284,18 +288,19 @@ def netg_highweight(sd: SD, LR: Tensor, SRb: Sequence[Tensor], LRb: Tensor, low:
         r += 1
     w5 = sd[p + "conv_output.0.weight"]
 
-    def head(o, sr):
-        return one * torch.tanh(F.conv2d(o, w5, None, 1, 2)) + a * sr     # model.py:224, 280
+    def head(o, sr, k):
+        c = F.conv2d(o, w5, None, 1, 2)
+        return one * (torch.tanh(c) if use_act else c) + (a if maps is None else maps[k]) * sr     # model.py:224, 280
 
     out = up_block(out, sd, p + "upscale2x.", training, update)
-    ims2 = head(out, SRb[0])
+    ims2 = head(out, SRb[0], 0)
     out = residual_nosum(out, sd, p + "residual24.", training, update)
     out = up_block(out, sd, p + "upscale4x.", training, update)
-    ims4 = head(out, SRb[1])
+    ims4 = head(out, SRb[1], 1)
     out = residual_nosum(out, sd, p + "residual48.", training, update)
     out = up_block(out, sd, p + "upscale8x.", training, update)
-    ims8 = head(out, SRb[2])
-    return [ims2, ims4, ims8], a, one
+    ims8 = head(out, SRb[2], 2)
+    return [ims2, ims4, ims8], (a if maps is None else maps[2]), one
 
 
 def netg_highweight16(sd: SD, LR: Tensor, SRb: Sequence[Tensor], LRb: Tensor, low: str = "lr",

@@ -522,8 +522,77 @@ def gen_gru():
     print("enc_gru.npz", len(out), "arrays")
 
 
+def gen_gh_variants():
+    """NetG_highweight's two non-shipped constructor forms (model.py:214, 223-226, 235-245, 276-297) and downBlock under .eval()
+    (util.py:92-98), all on the reference's own modules:
+      wm.*    weightmap=True, ngf 32, B = 1, LR 32 x 32 (the maps are hard-wired to 64 / 128 / 256 pixels): randomised a1..a3, eval-mode
+              images; train-mode BatchNorm: images, d(a_k), d(conv_output weight), d(SRb) for sum_k <ims_k, dy_k>;
+      na.*    useAct=False (no Tanh behind conv5x5), LR 16 x 16, B = 2, eval mode: images;
+      down.*  downBlock(16, 32) in eval mode on [3, 16, 16, 16]: output, and the input gradient of <out, dy>."""
+    cfg, GA, util, model, losses = _load_ref(ngf=32, nef=64)
+    out = {}
+    g = torch.Generator().manual_seed(2468)
+    torch.manual_seed(11)
+    net = model.NetG_highweight(weightmap=True, low="lr")
+    _randomize_bn(net, g)
+    for k, n in ((1, 64), (2, 128), (3, 256)):
+        getattr(net, "a%d" % k).data = 1.0 + 0.3 * torch.randn(n, n, generator=g)
+    LR = torch.rand(1, 3, 32, 32, generator=g) * 2 - 1
+    SRb = [torch.rand(1, 3, s, s, generator=g) * 2 - 1 for s in (64, 128, 256)]
+    dy = [torch.randn(1, 3, s, s, generator=g) for s in (64, 128, 256)]
+    out.update(_sd_np(net, "wm.GH."))
+    out["wm.LR"] = _np(LR)
+    for k in range(3):
+        out["wm.SRb%d" % k], out["wm.dy%d" % k] = _np(SRb[k]), _np(dy[k])
+    net.eval()
+    with torch.no_grad():
+        ims, a, one = net(LR, SRb, LR)
+    for k in range(3):
+        out["wm.eval.fine%d" % k] = _np(ims[k])
+    out["wm.eval.a"], out["wm.eval.one"] = _np(a), _np(one)
+    net.train()
+    sr = [s.clone().requires_grad_(True) for s in SRb]
+    ims, a, one = net(LR, sr, LR)
+    sum((i * d).sum() for i, d in zip(ims, dy)).backward()
+    out["wm.train.fine0"] = _np(ims[0])
+    for k in range(3):
+        out["wm.train.da%d" % (k + 1)] = _np(getattr(net, "a%d" % (k + 1)).grad)
+    out["wm.train.dSRb0"] = _np(sr[0].grad)
+    out["wm.train.dconv_output"] = _np(net.conv_output[0].weight.grad)
+    out["wm.train.dconvin"] = _np(net.convin[0].weight.grad)
+
+    torch.manual_seed(12)
+    net = model.NetG_highweight(weightmap=False, low="lr", useAct=False)
+    _randomize_bn(net, g)
+    net.eval()
+    LR = torch.rand(2, 3, 16, 16, generator=g) * 2 - 1
+    SRb = [torch.rand(2, 3, s, s, generator=g) * 2 - 1 for s in (32, 64, 128)]
+    out.update(_sd_np(net, "na.GH."))
+    out["na.LR"] = _np(LR)
+    with torch.no_grad():
+        ims, a, one = net(LR, SRb, LR)
+    for k in range(3):
+        out["na.SRb%d" % k], out["na.fine%d" % k] = _np(SRb[k]), _np(ims[k])
+
+    torch.manual_seed(13)
+    blk = util.downBlock(16, 32)
+    _randomize_bn(blk, g)
+    blk.eval()
+    x = torch.randn(3, 16, 16, 16, generator=g).requires_grad_(True)
+    dyb = torch.randn(3, 32, 8, 8, generator=g)
+    y = blk(x)
+    (y * dyb).sum().backward()
+    out.update(_sd_np(blk, "down."))
+    out.update({"down.x": _np(x), "down.dy": _np(dyb), "down.out": _np(y), "down.dx": _np(x.grad),
+                "down.dw": _np(blk[0].weight.grad)})
+    np.savez_compressed(os.path.join(OUT, "gh_variants.npz"), **out)
+    print("gh_variants.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "nets", "nets16", "damsm", "face", "gan", "gru"]
+    which = sys.argv[1:] or ["ops", "nets", "nets16", "damsm", "face", "gan", "gru", "ghv"]
+    if "ghv" in which:
+        gen_gh_variants()
     if "gru" in which:
         gen_gru()
     if "gan" in which:

@@ -154,6 +154,7 @@ torch.cuda.set_device(0)
 uid = ops.comm_unique_id()
 assert len(uid) == 128 and any(uid)
 comm = ops.comm_init(uid, 0, 1)
+assert ops.comm_count(comm) == (1, 0)            # ncclCommCount / ncclCommUserRank: what RCCL itself reports
 x = torch.randn(1191313, device="cuda")
 want = (x * 0.25).clone()
 ops.allreduce_flat(comm, x, 0.25)

@@ -142,8 +142,13 @@ def test_conv_bn_leaky_block(kind, B, Cin, Cout, H, cfg_d):
     close(blk[1].bias.grad, sdr["1.bias"].grad, atol=1e-3, rtol=1e-3)
     close(blk[1].running_mean, upd["1.running_mean"], atol=1e-5)
     close(blk[1].running_var, upd["1.running_var"], atol=1e-5)
-    with pytest.raises(NotImplementedError):
-        blk.eval()(xd)
+    rm = blk[1].running_mean.clone()                         # eval mode: the running statistics (tests/test_hip_variants.py), untouched
+    with torch.no_grad():
+        ye = blk.eval()(xd.detach())
+    upd2 = {}
+    close(ye, (O.down_block if kind == "down" else O.block3x3_leaky)(x, {k: v.detach() for k, v in _sd_cpu(blk).items()}, "", False, upd2),
+          atol=2e-4)
+    assert torch.equal(rm, blk[1].running_mean)
 
 
 @pytest.mark.parametrize("name,size", [("D_NET64", 64), ("D_NET128", 128), ("D_NET256", 256)])
@@ -643,7 +648,7 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
             for (ka, va), (_kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
                 assert torch.equal(va, vb), ka
         # a new learning rate is not silently ignored: the capture holds the old one and is dropped
-        old_graph = trs[0]._dgraphs[0]["graph"]
+        old_graph = trs[0]._dgraphs[0]["fb"]
         for k in (0, 1):
             for pg in trs[k].optsD[0].param_groups:
                 pg["lr"] = 0.5 * pg["lr"]
@@ -652,7 +657,7 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
         for k, tr in enumerate(trs):
             torch.manual_seed(177)
             tr.step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
-        assert trs[0]._dgraphs[0]["graph"] is not old_graph
+        assert trs[0]._dgraphs[0]["fb"] is not old_graph
         for (ka, va), (_kb, vb) in zip(trs[0].netsD[0].state_dict().items(), trs[1].netsD[0].state_dict().items()):
             assert torch.equal(va, vb), ka
         # another batch size is not mis-replayed: the discriminators take the eager update for that step, the generators capture

@@ -242,3 +242,35 @@ def test_gan_loss_formulas_golden():
                             float(g["lambda"]), w=0.5, s=2.0, g=3.0)
     close(err2, g["errG.nocls.w05.s2.g3"], atol=2e-5, rtol=1e-5)
     assert str(g["logs"]).startswith("g_loss0: ")
+
+
+def test_netg_highweight_weightmap_noact_and_eval_downblock():
+    """gh_variants.npz (the reference's own modules, tests/golden/make_golden.py gen_gh_variants): NetG_highweight(weightmap=True)
+    eval images + train-mode gradients of the maps, NetG_highweight(useAct=False) eval images, downBlock under .eval()."""
+    from conftest import load_npz
+    g = load_npz("gh_variants.npz")
+    sd = split_sd(g, "wm.GH.")
+    SRb = [T(g["wm.SRb%d" % k]) for k in range(3)]
+    ims, a, one = O.netg_highweight(sd, T(g["wm.LR"]), SRb, T(g["wm.LR"]), "lr")
+    for k in range(3):
+        close(ims[k], g["wm.eval.fine%d" % k], atol=2e-5)
+    close(a, g["wm.eval.a"])
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    sr = [s_.clone().requires_grad_(True) for s_ in SRb]
+    ims, _a, _one = O.netg_highweight(sdr, T(g["wm.LR"]), sr, T(g["wm.LR"]), "lr", training=True, update={})
+    sum((i * T(g["wm.dy%d" % k])).sum() for k, i in enumerate(ims)).backward()
+    close(ims[0], g["wm.train.fine0"], atol=2e-5)
+    for k in (1, 2, 3):
+        close(sdr["a%d" % k].grad, g["wm.train.da%d" % k], atol=2e-5)
+    close(sr[0].grad, g["wm.train.dSRb0"], atol=2e-5)
+    close(sdr["conv_output.0.weight"].grad, g["wm.train.dconv_output"], atol=2e-3, rtol=1e-4)
+    sd = split_sd(g, "na.GH.")
+    ims, a, one = O.netg_highweight(sd, T(g["na.LR"]), [T(g["na.SRb%d" % k]) for k in range(3)], T(g["na.LR"]), "lr", use_act=False)
+    for k in range(3):
+        close(ims[k], g["na.fine%d" % k], atol=2e-5)
+    sd = split_sd(g, "down.")
+    x = T(g["down.x"]).requires_grad_(True)
+    y = O.down_block(x, sd, "", training=False)
+    (y * T(g["down.dy"])).sum().backward()
+    close(y, g["down.out"])
+    close(x.grad, g["down.dx"])

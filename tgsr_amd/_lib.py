@@ -103,10 +103,15 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _vp, _vp]),
     "tgsr_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
     "tgsr_axpy_images": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp]),
+    "tgsr_axpy_map_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tgsr_axpy_map_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tgsr_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tgsr_affine_act_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tgsr_comm_available": (_i, []),
     "tgsr_comm_unique_id": (_i, [_vp]),
     "tgsr_comm_init": (_i, [_vp, _vp, _i, _i]),
     "tgsr_allreduce_flat": (_i, [_vp, _vp, _i64, _f, _vp]),
+    "tgsr_comm_count": (_i, [_vp, _vp, _vp]),
     "tgsr_comm_destroy": (_i, [_vp]),
     "tgsr_sumpool2x2": (_i, [_vp, _i64, _i, _i, _vp, _vp]),
     "tgsr_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -388,6 +388,78 @@ class DownConv(torch.autograd.Function):
         return dx, dw, None
 
 
+def _dconv_raw(x, weight, kind):
+    """The discriminator blocks' convolution without BatchNorm / activation: kind "down" = conv4x4 stride 2 (downBlock), "3x3"."""
+    if kind == "down":
+        return C.conv4x4s2(x, weight.detach(), False)
+    if ops.conv3x3_gemm_pays(x.shape[1], weight.shape[0], x.shape[2], x.shape[3]):
+        return C.conv3x3_gemm(x, weight.detach())          # many channels on 4x4 pixels: the implicit-GEMM form
+    return C.conv3x3_fused(x, C.pack_conv3x3_weight(weight.detach(), False), weight.shape[0], None, None, False, False, None)
+
+
+def _dconv_grads(x, weight, draw, kind, need_dx, need_dw):
+    """(dx, dw) of `_dconv_raw` given d(raw); dw goes into the weight's gradient-bucket slot when one is open."""
+    dx = dw = None
+    Cin, H, W = x.shape[1], x.shape[2], x.shape[3]
+    Cc, dev = draw.shape[1], x.device
+    w = weight.detach()
+    if kind == "down":
+        if need_dx:
+            dx = C.conv4x4s2_dgrad(draw, w, H, W)
+        if need_dw:
+            dw = _grad_out(weight, weight.shape, dev)
+            C.conv4x4s2_wgrad_out(draw, x, dw)
+    elif ops.conv3x3_gemm_pays(Cin, Cc, H, W):
+        if need_dx:
+            dx = C.conv3x3_gemm_dgrad(draw, w)
+        if need_dw:
+            dw = _grad_out(weight, weight.shape, dev)
+            C.conv3x3_gemm_wgrad_out(draw, x, dw)
+    else:
+        if need_dx:
+            wT = _dgrad_weight(w)
+            cpad = (Cin + 31) // 32 * 32
+            if cpad != Cin:
+                wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cc, 3, 3)), 0)
+            dx = C.conv3x3_fused(draw, C.pack_conv3x3_weight(wT, False), cpad, None, None, False, False, None)
+            if cpad != Cin:
+                dx = dx[:, :Cin].contiguous()
+        if need_dw:
+            dw = torch.empty_like(weight)
+            C.conv3x3_wgrad(draw, x, False, False, dw)
+    return dx, dw
+
+
+class ConvBnLeakyEval(torch.autograd.Function):
+    """downBlock / Block3x3_leakRelu under .eval() (util.py:92-98 with nn.BatchNorm2d normalising by its running statistics):
+    the same convolution kernels, then tgsr::affine_act with the folded scale / shift.  Differentiable (a frozen, eval-mode
+    discriminator still passes the generator's gradient through): d(raw) = tgsr::affine_act_bwd, data / weight gradient on the
+    training path's kernels; the rarely wanted BatchNorm parameter gradients are two torch reductions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, kind, eps):
+        x = x.contiguous()
+        raw = _dconv_raw(x, weight, kind)
+        scale, shift = ops.bn_fold(gamma.detach(), beta.detach(), running_mean, running_var, eps)
+        out = C.affine_act(raw, scale, shift, 2)
+        ctx.save_for_backward(x, weight, raw, out, scale, running_mean, running_var)
+        ctx.kind, ctx.eps = kind, float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, raw, out, scale, rm, rv = ctx.saved_tensors
+        dout = dout.contiguous()
+        draw = C.affine_act_bwd(dout, out, scale, 2)
+        dx, dw = _dconv_grads(x, weight, draw, ctx.kind, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            g = C.affine_act_bwd(dout, out, torch.ones_like(scale), 2)                    # dy * act'
+            dbeta = g.sum((0, 2, 3))
+            dgamma = (g * (raw - rm.view(1, -1, 1, 1))).sum((0, 2, 3)) * torch.rsqrt(rv + ctx.eps)
+        return dx, dw, dgamma, dbeta, None, None, None, None
+
+
 class ConvBnLeaky(torch.autograd.Function):
     """conv -> BatchNorm2d(batch statistics) -> LeakyReLU(0.2) with `kind` = "down" (conv4x4 stride 2: downBlock,
     util.py:92-98) or "3x3" (the discriminators' Block3x3_leakRelu).  BatchNorm + activation forward / backward =
@@ -401,12 +473,7 @@ class ConvBnLeaky(torch.autograd.Function):
         fake / mismatched images of discriminator_loss) as one convolution launch, one data-gradient launch and one
         weight-gradient launch, numerically the passes run one by one."""
         x = x.contiguous()
-        if kind == "down":
-            raw = C.conv4x4s2(x, weight.detach(), False)
-        elif ops.conv3x3_gemm_pays(x.shape[1], weight.shape[0], x.shape[2], x.shape[3]):
-            raw = C.conv3x3_gemm(x, weight.detach())          # many channels on 4x4 pixels: the implicit-GEMM form
-        else:
-            raw = C.conv3x3_fused(x, C.pack_conv3x3_weight(weight.detach(), False), weight.shape[0], None, None, False, False, None)
+        raw = _dconv_raw(x, weight, kind)
         B, Cc = raw.shape[0], raw.shape[1]
         groups = (B,) if groups is None else tuple(int(g) for g in groups)
         if sum(groups) != B or min(groups) < 1:
@@ -442,33 +509,7 @@ class ConvBnLeaky(torch.autograd.Function):
                 dgamma += dg
                 dbeta += db
             o += n
-        dx = dw = None
-        Cin, H, W = x.shape[1], x.shape[2], x.shape[3]
-        w = weight.detach()
-        if ctx.kind == "down":
-            if ctx.needs_input_grad[0]:
-                dx = C.conv4x4s2_dgrad(draw, w, H, W)
-            if ctx.needs_input_grad[1]:
-                dw = _grad_out(weight, weight.shape, dev)
-                C.conv4x4s2_wgrad_out(draw, x, dw)
-        elif ops.conv3x3_gemm_pays(Cin, Cc, H, W):
-            if ctx.needs_input_grad[0]:
-                dx = C.conv3x3_gemm_dgrad(draw, w)
-            if ctx.needs_input_grad[1]:
-                dw = _grad_out(weight, weight.shape, dev)
-                C.conv3x3_gemm_wgrad_out(draw, x, dw)
-        else:
-            if ctx.needs_input_grad[0]:
-                wT = _dgrad_weight(w)
-                cpad = (Cin + 31) // 32 * 32
-                if cpad != Cin:
-                    wT = torch.cat((wT, wT.new_zeros(cpad - Cin, Cc, 3, 3)), 0)
-                dx = C.conv3x3_fused(draw, C.pack_conv3x3_weight(wT, False), cpad, None, None, False, False, None)
-                if cpad != Cin:
-                    dx = dx[:, :Cin].contiguous()
-            if ctx.needs_input_grad[1]:
-                dw = torch.empty_like(weight)
-                C.conv3x3_wgrad(draw, x, False, False, dw)
+        dx, dw = _dconv_grads(x, weight, draw, ctx.kind, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -513,6 +554,20 @@ class ConvTo3(torch.autograd.Function):
         if ctx.alpha_is_tensor and ctx.needs_input_grad[4] and addend is not None:
             dalpha = (dy * addend).sum().reshape(1)              # out = tanh(conv) + alpha * addend
         return (dx if need_dx else None), (dw if need_dw else None), dadd, None, dalpha
+
+
+class AxpyImage(torch.autograd.Function):
+    """t + alpha * s with a host constant alpha (tgsr::axpy_images): NetG_highweight(useAct=False)'s `conv_output(out) + a * SRb`
+    (model.py:226, 280) - the tanh form has the addend inside the convolution's epilogue instead."""
+
+    @staticmethod
+    def forward(ctx, t, s, alpha):
+        ctx.alpha = float(alpha)
+        return C.axpy_images([t.contiguous()], [s.contiguous()], ctx.alpha)[0]
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dy if ctx.needs_input_grad[0] else None), (dy * ctx.alpha if ctx.needs_input_grad[1] else None), None
 
 
 class WordAttention(torch.autograd.Function):

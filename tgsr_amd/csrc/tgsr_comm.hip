@@ -20,6 +20,8 @@ struct RcclApi {
   int (*CommInitRank)(void**, int, const void*, int) = nullptr;     // (comm*, nranks, id BY VALUE: see comm_init), rank
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
+  int (*CommUserRank)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
 };
 
@@ -37,6 +39,8 @@ static RcclApi* rccl() {
     api.CommInitRank = reinterpret_cast<int (*)(void**, int, const void*, int)>(dlsym(api.so, "ncclCommInitRank"));
     api.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(api.so, "ncclAllReduce"));
     api.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(api.so, "ncclCommDestroy"));
+    api.CommCount = reinterpret_cast<int (*)(void*, int*)>(dlsym(api.so, "ncclCommCount"));
+    api.CommUserRank = reinterpret_cast<int (*)(void*, int*)>(dlsym(api.so, "ncclCommUserRank"));
     api.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(api.so, "ncclGetErrorString"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) return nullptr;
     return &api;
@@ -92,6 +96,16 @@ extern "C" int tgsr_allreduce_flat(void* comm, float* buf, int64_t n, float scal
     return note_launch(hipGetLastError(), "scale_flat_kernel");
   }
   return TGSR_OK;
+}
+
+extern "C" int tgsr_comm_count(void* comm, int* world, int* rank) {
+  if (!comm || !world || !rank) return TGSR_EINVAL;
+  RcclApi* a = rccl();
+  if (!a || !a->CommCount || !a->CommUserRank) return TGSR_EUNSUPPORTED;
+  int rc = a->CommCount(comm, world);
+  if (rc) return rccl_fail(a, rc, "ncclCommCount");
+  rc = a->CommUserRank(comm, rank);
+  return rc ? rccl_fail(a, rc, "ncclCommUserRank") : TGSR_OK;
 }
 
 extern "C" int tgsr_comm_destroy(void* comm) {

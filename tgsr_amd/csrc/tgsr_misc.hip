@@ -139,6 +139,87 @@ __global__ __launch_bounds__(256) void axpy_images_kernel(AxpyArgs a) {
   }
 }
 
+// out[b][c][p] = t[b][c][p] + amap[p] * s[b][c][p]: NetG_highweight(weightmap=True)'s heads (model.py:235-245, 276-297: `a_k` is a
+// trainable [H, W] map broadcast over batch and channels).  One float4 of pixels per thread; HW % 4 == 0.
+__global__ __launch_bounds__(256) void axpy_map_kernel(const float* __restrict__ t, const float* __restrict__ s,
+                                                       const float* __restrict__ amap, float* __restrict__ out, int64_t n4,
+                                                       uint32_t hw4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 tv = reinterpret_cast<const float4*>(t)[i], sv = reinterpret_cast<const float4*>(s)[i];
+    const float4 av = reinterpret_cast<const float4*>(amap)[i % hw4];
+    float4 r;
+    r.x = fmaf(av.x, sv.x, tv.x);
+    r.y = fmaf(av.y, sv.y, tv.y);
+    r.z = fmaf(av.z, sv.z, tv.z);
+    r.w = fmaf(av.w, sv.w, tv.w);
+    reinterpret_cast<float4*>(out)[i] = r;
+  }
+}
+
+// Its backward: ds = amap * dy (when ds != nullptr) and damap[p] = sum over the BC planes of dy * s, planes added in index order
+// (one thread owns a float4 of pixels: deterministic, coalesced across the plane).
+__global__ __launch_bounds__(256) void axpy_map_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s,
+                                                           const float* __restrict__ amap, float* __restrict__ ds,
+                                                           float* __restrict__ damap, int BC, uint32_t hw4) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= hw4) return;
+  const float4 av = reinterpret_cast<const float4*>(amap)[p];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < BC; ++k) {
+    const int64_t i = (int64_t)k * hw4 + p;
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    if (s) {
+      const float4 sv = reinterpret_cast<const float4*>(s)[i];
+      acc.x = fmaf(g.x, sv.x, acc.x); acc.y = fmaf(g.y, sv.y, acc.y);
+      acc.z = fmaf(g.z, sv.z, acc.z); acc.w = fmaf(g.w, sv.w, acc.w);
+    }
+    if (ds) reinterpret_cast<float4*>(ds)[i] = make_float4(av.x * g.x, av.y * g.y, av.z * g.z, av.w * g.w);
+  }
+  if (damap) reinterpret_cast<float4*>(damap)[p] = acc;
+}
+
+// Eval-mode BatchNorm (running statistics folded to scale / shift by bn_fold_kernel) + activation on a raw convolution output:
+// downBlock / Block3x3_leakRelu under .eval() (util.py:92-98).  act 0: none, 2: LeakyReLU(0.2).  grid (C, splits), HW % 4 == 0.
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ raw, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ out, int B, int C,
+                                                         int HW, int act) {
+  const int c = blockIdx.x;
+  const float sv = scale[c], tv = shift[c];
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t e = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 4; e < total; e += (int64_t)gridDim.y * 1024) {
+    const int b = (int)(e / HW);
+    const int64_t o = ((int64_t)b * C + c) * HW + (e - (int64_t)b * HW);
+    const float4 v = *reinterpret_cast<const float4*>(raw + o);
+    float4 y = make_float4(fmaf(v.x, sv, tv), fmaf(v.y, sv, tv), fmaf(v.z, sv, tv), fmaf(v.w, sv, tv));
+    if (act == 2) {
+      y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y;
+      y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
+    }
+    *reinterpret_cast<float4*>(out + o) = y;
+  }
+}
+
+// d(raw) = dy * act'(out) * scale[c]  (LeakyReLU's slope is positive: the sign of `out` is the sign of its argument)
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ out,
+                                                             const float* __restrict__ scale, float* __restrict__ draw, int B,
+                                                             int C, int HW, int act) {
+  const int c = blockIdx.x;
+  const float sv = scale[c];
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t e = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 4; e < total; e += (int64_t)gridDim.y * 1024) {
+    const int b = (int)(e / HW);
+    const int64_t o = ((int64_t)b * C + c) * HW + (e - (int64_t)b * HW);
+    const float4 g = *reinterpret_cast<const float4*>(dy + o);
+    float4 r = make_float4(g.x * sv, g.y * sv, g.z * sv, g.w * sv);
+    if (act == 2) {
+      const float4 y = *reinterpret_cast<const float4*>(out + o);
+      r.x = y.x > 0.f ? r.x : 0.2f * r.x; r.y = y.y > 0.f ? r.y : 0.2f * r.y;
+      r.z = y.z > 0.f ? r.z : 0.2f * r.z; r.w = y.w > 0.f ? r.w : 0.2f * r.w;
+    }
+    *reinterpret_cast<float4*>(draw + o) = r;
+  }
+}
+
 }  // namespace tgsr
 
 using namespace tgsr;
@@ -233,4 +314,53 @@ extern "C" int tgsr_axpy_images(int n, float* const* out, const float* const* t,
   const int bx = (int)((most + 255) / 256 < 512 ? (most + 255) / 256 : 512);
   hipLaunchKernelGGL(axpy_images_kernel, dim3(bx, n), dim3(256), 0, as_stream(stream), a);
   return note_launch(hipGetLastError(), "axpy_images_kernel");
+}
+
+extern "C" int tgsr_axpy_map_fwd(const float* t, const float* s, const float* amap, float* out, int BC, int HW, void* stream) {
+  if (!t || !s || !amap || !out || BC < 1 || HW < 1) return TGSR_EINVAL;
+  if ((HW & 3) || ((reinterpret_cast<uintptr_t>(t) | reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(amap) |
+                    reinterpret_cast<uintptr_t>(out)) & 15))
+    return TGSR_EUNSUPPORTED;
+  const int64_t n4 = (int64_t)BC * (HW >> 2);
+  const int bx = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(axpy_map_kernel, dim3(bx), dim3(256), 0, as_stream(stream), t, s, amap, out, n4, (uint32_t)(HW >> 2));
+  return note_launch(hipGetLastError(), "axpy_map_kernel");
+}
+
+extern "C" int tgsr_axpy_map_bwd(const float* dy, const float* s, const float* amap, float* ds, float* damap, int BC, int HW,
+                                 void* stream) {
+  if (!dy || !amap || BC < 1 || HW < 1 || (!ds && !damap) || (damap && !s)) return TGSR_EINVAL;
+  if ((HW & 3) || ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(amap) |
+                    reinterpret_cast<uintptr_t>(ds) | reinterpret_cast<uintptr_t>(damap)) & 15))
+    return TGSR_EUNSUPPORTED;
+  const uint32_t hw4 = (uint32_t)(HW >> 2);
+  hipLaunchKernelGGL(axpy_map_bwd_kernel, dim3((hw4 + 255) / 256), dim3(256), 0, as_stream(stream), dy, damap ? s : nullptr, amap,
+                     ds, damap, BC, hw4);
+  return note_launch(hipGetLastError(), "axpy_map_bwd_kernel");
+}
+
+static int affine_grid_y(int B, int C, int HW) {
+  const int64_t per = ((int64_t)B * HW + 1023) / 1024;
+  int64_t want = (2048 + C - 1) / C;
+  if (want > per) want = per;
+  return (int)(want < 1 ? 1 : want);
+}
+
+extern "C" int tgsr_affine_act_fwd(const float* raw, const float* scale, const float* shift, float* out, int B, int C, int HW,
+                                   int act, void* stream) {
+  if (!raw || !scale || !shift || !out || B < 1 || C < 1 || HW < 1 || (act != 0 && act != 2)) return TGSR_EINVAL;
+  if ((HW & 3) || ((reinterpret_cast<uintptr_t>(raw) | reinterpret_cast<uintptr_t>(out)) & 15)) return TGSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(C, affine_grid_y(B, C, HW)), dim3(256), 0, as_stream(stream), raw, scale, shift, out,
+                     B, C, HW, act);
+  return note_launch(hipGetLastError(), "affine_act_kernel");
+}
+
+extern "C" int tgsr_affine_act_bwd(const float* dy, const float* out, const float* scale, float* draw, int B, int C, int HW,
+                                   int act, void* stream) {
+  if (!dy || !scale || !draw || B < 1 || C < 1 || HW < 1 || (act != 0 && act != 2) || (act == 2 && !out)) return TGSR_EINVAL;
+  if ((HW & 3) || ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(draw)) & 15))
+    return TGSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(affine_act_bwd_kernel, dim3(C, affine_grid_y(B, C, HW)), dim3(256), 0, as_stream(stream), dy, out, scale,
+                     draw, B, C, HW, act);
+  return note_launch(hipGetLastError(), "affine_act_bwd_kernel");
 }

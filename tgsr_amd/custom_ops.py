@@ -494,6 +494,35 @@ text_tail_lp = _define("text_tail_lp(Tensor words, Tensor[] w_ctxs, Tensor sent_
                         words.new_empty(len(ws) * words.shape[0] * 4096 + 4 * words.shape[0], dtype=torch.uint8)))
 axpy_images = _define("axpy_images(Tensor[] ts, Tensor[] ss, float alpha) -> Tensor[]",
                       lambda ts, ss, alpha: ops.axpy_images(list(ts), list(ss), alpha), lambda ts, ss, alpha: [torch.empty_like(t) for t in ts])
+axpy_map = _define("axpy_map(Tensor t, Tensor s, Tensor amap) -> Tensor", lambda t, s, a: ops.axpy_map(t, s, a),
+                   lambda t, s, a: torch.empty_like(t))
+
+
+def _axpy_map_bwd(dy, s, amap, need_ds, need_da):
+    ds, da = ops.axpy_map_bwd(dy, s, amap, need_ds, need_da)
+    return (ds if ds is not None else dy.new_empty(0)), (da if da is not None else dy.new_empty(0))
+
+
+axpy_map_bwd = _define("axpy_map_bwd(Tensor dy, Tensor s, Tensor amap, bool need_ds, bool need_da) -> (Tensor, Tensor)", _axpy_map_bwd,
+                       lambda dy, s, a, nds, nda: (torch.empty_like(dy) if nds else dy.new_empty(0),
+                                                   torch.empty_like(a) if nda else dy.new_empty(0)))
+
+
+def _axpy_map_backward(ctx, dy):
+    s, amap = ctx.saved_tensors
+    nds, nda = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+    ds = da = None
+    if nds or nda:
+        ds, da = axpy_map_bwd(dy.contiguous(), s, amap, nds, nda)
+    return (dy if ctx.needs_input_grad[0] else None), (ds if nds else None), (da if nda else None)
+
+
+torch.library.register_autograd("tgsr::axpy_map", _axpy_map_backward,
+                                setup_context=lambda ctx, inputs, output: ctx.save_for_backward(inputs[1], inputs[2]), lib=_lib)
+affine_act = _define("affine_act(Tensor raw, Tensor scale, Tensor shift, int act) -> Tensor",
+                     lambda raw, sc, sh, act: ops.affine_act(raw, sc, sh, act), lambda raw, sc, sh, act: torch.empty_like(raw))
+affine_act_bwd = _define("affine_act_bwd(Tensor dy, Tensor? out, Tensor scale, int act) -> Tensor",
+                         lambda dy, out, sc, act: ops.affine_act_bwd(dy, out, sc, act), lambda dy, out, sc, act: torch.empty_like(dy))
 multi_copy = _define("multi_copy(Tensor(a!)[] dsts, Tensor[] srcs) -> ()",
                      lambda dsts, srcs: ops.multi_copy(list(dsts), list(srcs)), lambda dsts, srcs: None)
 to_uint8 = _define("to_uint8(Tensor img) -> Tensor", lambda x: ops.to_uint8(x), lambda x: torch.empty_like(x, dtype=torch.uint8))

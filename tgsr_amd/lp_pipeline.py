@@ -135,6 +135,9 @@ class LpExecutor:
         dt, GL, GH = self.dtype, self.netGL, self.netGH
         if GL.training or GH.training:
             raise RuntimeError("the reduced-precision path is inference only: call .eval() on the generators")
+        if getattr(GH, "weightmap", False) or not getattr(GH, "useAct", True):
+            raise NotImplementedError("the reduced-precision path builds NetG_highweight's shipped heads (weightmap=False, "
+                                      "useAct=True: trainer_objective.py:58, 88); the fp32 path runs the other two forms")
 
         def res(rb, dt=dt):
             return (_Conv(rb.block[0], rb.block[1], dt), _Conv(rb.block[3], rb.block[4], dt))

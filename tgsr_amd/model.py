@@ -81,18 +81,21 @@ class G_SR_NET_low(nn.Module):
 
 
 class NetG_highweight(nn.Module):
-    """model.py:212-298 with weightmap=False: SRResNet-style high-frequency generator whose three heads are
-    `one * tanh(conv5x5(out)) + a * SRb_k`.  `a` = 0.5 and `one` = 1 are constants, not parameters: in the
-    reference `nn.Parameter(...).cuda()` leaves a plain tensor that is neither trained nor saved
-    (model.py:246-248; netGH_epoch_7.pth has no key `a`)."""
+    """model.py:212-298: SRResNet-style high-frequency generator whose three heads are `one_k * conv_output(out_k) + a_k * SRb_k`
+    (conv_output = conv5x5 [+ Tanh when useAct]).
+    weightmap=False: `a` = 0.5 and `one` = 1 are constants, not parameters - in the reference `nn.Parameter(...).cuda()` leaves a
+    plain tensor that is neither trained nor saved (model.py:246-248; netGH_epoch_7.pth has no key `a`).
+    weightmap=True (model.py:235-245): `a1`, `a2`, `a3` are trainable [64,64] / [128,128] / [256,256] maps (initial value 1;
+    here `nn.Parameter(tensor.cuda())` IS a registered parameter: state_dict keys `a1..a3`), broadcast over batch and channels:
+    tgsr::axpy_map and its backward; forward returns (ims, a3, one3) like the reference (:293-295)."""
+
+    MAP_SIZES = (64, 128, 256)
 
     def __init__(self, weightmap=False, low='lr-lrblur', useAct=True):
         super(NetG_highweight, self).__init__()
-        if weightmap:
-            raise NotImplementedError("weightmap=True is dead on the shipped path (trainer_objective.py:58)")
         ngf = cfg.GAN.GF_DIM
         self.low = low
-        self.useAct = useAct
+        self.useAct = bool(useAct)
         self.residual = nn.Sequential(*[ResBlock(channel_num=32) for _ in range(6)])   # model.py:258-262
         self.upscale4x = upBlock(ngf, ngf)
         self.upscale2x = upBlock(ngf, ngf)
@@ -101,7 +104,10 @@ class NetG_highweight(nn.Module):
         self.convin = _ConvBnGlu(3, ngf)
         self.residual24 = _ResidualNoSum(ngf)
         self.residual48 = _ResidualNoSum(ngf)
-        self.weightmap = False
+        self.weightmap = bool(weightmap)
+        if self.weightmap:
+            for k, n in enumerate(self.MAP_SIZES):
+                setattr(self, "a%d" % (k + 1), nn.Parameter(torch.ones([n, n], dtype=torch.float32)))
         self._a = 0.5
         self._consts = {}
 
@@ -112,11 +118,21 @@ class NetG_highweight(nn.Module):
             c = self._consts[ref.device] = (ref.new_tensor([self._a]), ref.new_ones(1))
         return c
 
-    def _head(self, out, SRb):
-        if not self.useAct:
-            raise NotImplementedError("useAct=False is never constructed by the reference's callers")
-        from . import custom_ops as C
-        return C.conv_to3(out, self.conv_output[0].weight, True, SRb, self._a)   # torch.ops.tgsr.conv_to3 (+ autograd)
+    def maps(self):
+        return [getattr(self, "a%d" % (k + 1)) for k in range(len(self.MAP_SIZES))] if self.weightmap else None
+
+    def _head(self, out, SRb, k=0):
+        w = self.conv_output[0].weight
+        if self.weightmap:                                    # one_k * conv_output(out) + a_k * SRb  (model.py:277, 286, 294)
+            amap = self.maps()[k]
+            if tuple(amap.shape) != tuple(out.shape[2:]):
+                raise ValueError("NetG_highweight(weightmap=True): a%d is %s but scale %d of this input is %s (the maps are sized "
+                                 "for 32 x 32 inputs, model.py:236-239)" % (k + 1, tuple(amap.shape), k, tuple(out.shape[2:])))
+            return C.axpy_map(C.conv_to3(out, w, self.useAct, None, 0.0), SRb, amap)
+        if self.useAct:
+            return C.conv_to3(out, w, True, SRb, self._a)     # torch.ops.tgsr.conv_to3 (+ autograd): tanh(conv) + a * SRb, one launch
+        from .autograd import AxpyImage
+        return AxpyImage.apply(C.conv_to3(out, w, False, None, 0.0), SRb, self._a)      # conv + a * SRb (useAct=False, model.py:226)
 
     def trunk(self, LR, LRb):
         """Everything of forward() that does not need the low-frequency images: convin -> 6 ResBlocks -> the three
@@ -135,24 +151,26 @@ class NetG_highweight(nn.Module):
         return out2, out4, out8
 
     def heads(self, feats, SRb):
-        """ims_k = one * tanh(conv5x5(out_k)) + a * SRb_k   (model.py:280, 288, 297)."""
-        return [self._head(f, sr) for f, sr in zip(feats, SRb)]
+        """ims_k = one * conv_output(out_k) + a * SRb_k   (model.py:280, 288, 297)."""
+        return [self._head(f, sr, k) for k, (f, sr) in enumerate(zip(feats, SRb))]
 
     def tanh_heads(self, feats):
-        """The part of heads() that needs no low-frequency image: tanh(conv5x5(out_k)).  SRPipeline runs it on the
+        """The part of heads() that needs no low-frequency image: conv_output(out_k).  SRPipeline runs it on the
         high-frequency branch's stream, beside G_SR_NET_low; `finish_heads` adds a * SRb_k (one launch for all scales) -
         the same fma the fused epilogue evaluates, bit-identical images (tests/test_hip_parity.py)."""
-        from . import custom_ops as C
         w = self.conv_output[0].weight.detach()
-        return [C.conv_to3(f, w, True, None, self._a) for f in feats]
+        return [C.conv_to3(f, w, self.useAct, None, self._a) for f in feats]
 
     def finish_heads(self, ts, SRb):
-        from . import custom_ops as C
+        if self.weightmap:
+            return [C.axpy_map(t, s.contiguous(), a.detach()) for t, s, a in zip(ts, SRb, self.maps())]
         return list(C.axpy_images(list(ts), [s.contiguous() for s in SRb[:len(ts)]], self._a))
 
     def forward(self, LR, SRb, LRb):
         ims = self.heads(self.trunk(LR, LRb), SRb[:3])
         a, one = self._const(LR)
+        if self.weightmap:
+            return ims, self.a3, one
         return ims, a, one
 
 

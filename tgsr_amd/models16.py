@@ -59,13 +59,14 @@ class G_SR_NET_low(nn.Module):
 
 
 class NetG_highweight(nn.Module):
-    """models16.py:97-179 with weightmap=False.  Here `a` IS a registered parameter (no `.cuda()` on it,
-    models16.py:126), initial value 0.5; `one` is the constant 1."""
+    """models16.py:97-179.  weightmap=False: `a` IS a registered parameter here (no `.cuda()` on it, models16.py:126), initial
+    value 0.5; `one` is the constant 1.  weightmap=True (models16.py:119-125): four trainable maps `a1..a4` of 32 / 64 / 128 /
+    256 pixels (for 16 x 16 inputs), initial value 1, no `a`; forward returns (ims, a4, one4)."""
+
+    MAP_SIZES = (32, 64, 128, 256)
 
     def __init__(self, weightmap=False, low='lr-lrblur'):
         super(NetG_highweight, self).__init__()
-        if weightmap:
-            raise NotImplementedError("weightmap=True is dead on the shipped path (trainer_objective.py:58)")
         ngf = cfg.GAN.GF_DIM
         self.low = low
         self.residual = nn.Sequential(*[ResBlock(channel_num=32) for _ in range(6)])
@@ -78,12 +79,25 @@ class NetG_highweight(nn.Module):
         self.residual24 = _ResidualNoSum(ngf)
         self.residual48 = _ResidualNoSum(ngf)
         self.residual816 = _ResidualNoSum(ngf)       # parameters only: never called (models16.py:172)
-        self.weightmap = False
-        self.a = nn.Parameter(torch.FloatTensor([0.5]))
+        self.weightmap = bool(weightmap)
+        if self.weightmap:
+            for k, n in enumerate(self.MAP_SIZES):
+                setattr(self, "a%d" % (k + 1), nn.Parameter(torch.ones([n, n], dtype=torch.float32)))
+        else:
+            self.a = nn.Parameter(torch.FloatTensor([0.5]))
         self._one = {}
         self._a_host = (None, 0.5)       # (version key, host copy of `a`): one D2H sync per weight version, not per head
 
-    def _head(self, out, SRb):
+    def maps(self):
+        return [getattr(self, "a%d" % (k + 1)) for k in range(len(self.MAP_SIZES))] if self.weightmap else None
+
+    def _head(self, out, SRb, k=0):
+        if self.weightmap:                                    # one_k * conv_output(out) + a_k * SRb  (models16.py:150, 159, 167, 175)
+            amap = self.maps()[k]
+            if tuple(amap.shape) != tuple(out.shape[2:]):
+                raise ValueError("models16.NetG_highweight(weightmap=True): a%d is %s but scale %d of this input is %s (the maps "
+                                 "are sized for 16 x 16 inputs, models16.py:120-123)" % (k + 1, tuple(amap.shape), k, tuple(out.shape[2:])))
+            return C.axpy_map(C.conv_to3(out, self.conv_output[0].weight, True, None, 0.0), SRb, amap)
         if self.training:
             from .autograd import ConvTo3
             return ConvTo3.apply(out, self.conv_output[0].weight, SRb, True, self.a)   # d/da = sum(dy * SRb)
@@ -107,14 +121,16 @@ class NetG_highweight(nn.Module):
     def heads(self, feats, SRb):
         """ims_k = one * tanh(conv5x5(out_k)) + a * SRb_k; the 16x head adds SRb16 (models16.py:178 says SRb8: a shape
         error as shipped)."""
-        return [self._head(f, sr) for f, sr in zip(feats, SRb[:4])]
+        return [self._head(f, sr, k) for k, (f, sr) in enumerate(zip(feats, SRb[:4]))]
 
     def tanh_heads(self, feats):
         """tanh(conv5x5(out_k)) of every scale - needs no low-frequency image (see model.NetG_highweight.tanh_heads)."""
         w = self.conv_output[0].weight.detach()
-        return [C.conv_to3(f, w, True, None, self.alpha()) for f in feats]
+        return [C.conv_to3(f, w, True, None, 0.0 if self.weightmap else self.alpha()) for f in feats]
 
     def finish_heads(self, ts, SRb):
+        if self.weightmap:
+            return [C.axpy_map(t, s.contiguous(), a.detach()) for t, s, a in zip(ts, SRb, self.maps())]
         return list(C.axpy_images(list(ts), [s.contiguous() for s in SRb[:len(ts)]], self.alpha()))
 
     def forward(self, LR, SRb, LRb):
@@ -122,7 +138,7 @@ class NetG_highweight(nn.Module):
         one = self._one.get(LR.device)
         if one is None:
             one = self._one[LR.device] = LR.new_ones(1)
-        return ims, self.a, one
+        return ims, (self.a4 if self.weightmap else self.a), one
 
     def alpha(self):
         """Host value of `a` for the inference kernels: one D2H copy per weight version, none per step (and none inside

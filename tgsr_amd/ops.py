@@ -1246,6 +1246,14 @@ def allreduce_flat(comm: int, flat: torch.Tensor, scale: float = 1.0) -> torch.T
     return flat
 
 
+def comm_count(comm: int) -> tuple:
+    """(world, rank) as RCCL reports them for a communicator (ncclCommCount, ncclCommUserRank)."""
+    import ctypes
+    w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    check(_lib.lib().tgsr_comm_count(comm, ctypes.byref(w), ctypes.byref(r)), "tgsr_comm_count")
+    return int(w.value), int(r.value)
+
+
 def comm_destroy(comm: int) -> None:
     check(_lib.lib().tgsr_comm_destroy(comm), "tgsr_comm_destroy")
 
@@ -1273,6 +1281,52 @@ def axpy_images(ts, ss, alpha: float, outs=None):
     ne = (ctypes.c_int64 * n)(*[t.numel() for t in ts])
     check(_lib.lib().tgsr_axpy_images(n, op, tp, sp, ne, float(alpha), _stream()), "tgsr_axpy_images")
     return outs
+
+
+def axpy_map(t: torch.Tensor, s: torch.Tensor, amap: torch.Tensor) -> torch.Tensor:
+    """t + amap * s with amap [H, W] broadcast over batch and channels (NetG_highweight(weightmap=True), model.py:276-297)."""
+    _need_hip(t, s, amap)
+    t, s, amap = _f32(t, "t").contiguous(), _f32(s, "s").contiguous(), _f32(amap.detach(), "amap").contiguous()
+    if t.shape != s.shape or t.dim() != 4 or tuple(amap.shape) != tuple(t.shape[2:]):
+        raise TgsrError("axpy_map: %s + %s * %s" % (tuple(t.shape), tuple(amap.shape), tuple(s.shape)))
+    out = torch.empty_like(t)
+    check(_lib.lib().tgsr_axpy_map_fwd(_p(t), _p(s), _p(amap), _p(out), t.shape[0] * t.shape[1], t.shape[2] * t.shape[3], _stream()),
+          "tgsr_axpy_map_fwd")
+    return out
+
+
+def axpy_map_bwd(dy: torch.Tensor, s: torch.Tensor, amap: torch.Tensor, need_ds: bool = True, need_da: bool = True):
+    """(ds, damap) of axpy_map: ds = amap * dy, damap = sum over batch and channels of dy * s."""
+    _need_hip(dy, s, amap)
+    dy, s, amap = _f32(dy, "dy").contiguous(), _f32(s, "s").contiguous(), _f32(amap.detach(), "amap").contiguous()
+    ds = torch.empty_like(dy) if need_ds else None
+    da = torch.empty_like(amap) if need_da else None
+    if ds is None and da is None:
+        return None, None
+    check(_lib.lib().tgsr_axpy_map_bwd(_p(dy), _p(s), _p(amap), _p(ds), _p(da), dy.shape[0] * dy.shape[1], dy.shape[2] * dy.shape[3],
+                                       _stream()), "tgsr_axpy_map_bwd")
+    return ds, da
+
+
+def affine_act(raw: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, act: int) -> torch.Tensor:
+    """act(raw * scale[c] + shift[c]) on a dense NCHW tensor (eval-mode BatchNorm + LeakyReLU(0.2) for act = 2)."""
+    _need_hip(raw, scale, shift)
+    raw = _f32(raw, "raw").contiguous()
+    B, Cc, H, W = raw.shape
+    out = torch.empty_like(raw)
+    check(_lib.lib().tgsr_affine_act_fwd(_p(raw), _p(scale.contiguous()), _p(shift.contiguous()), _p(out), B, Cc, H * W, int(act),
+                                         _stream()), "tgsr_affine_act_fwd")
+    return out
+
+
+def affine_act_bwd(dy: torch.Tensor, out: Optional[torch.Tensor], scale: torch.Tensor, act: int) -> torch.Tensor:
+    _need_hip(dy, out, scale)
+    dy = _f32(dy, "dy").contiguous()
+    B, Cc, H, W = dy.shape
+    draw = torch.empty_like(dy)
+    check(_lib.lib().tgsr_affine_act_bwd(_p(dy), _p(None if out is None else out.contiguous()), _p(scale.contiguous()), _p(draw),
+                                         B, Cc, H * W, int(act), _stream()), "tgsr_affine_act_bwd")
+    return draw
 
 
 # ----------------------------------------------------------------------------------------- image pyramid (uint8)

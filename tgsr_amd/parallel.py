@@ -259,6 +259,11 @@ class RcclDirect:
         from . import ops
         return ops.allreduce_flat(self.comm, flat, 1.0 / self.world)
 
+    def count(self) -> tuple:
+        """(world, rank) from RCCL itself (ncclCommCount / ncclCommUserRank)."""
+        from . import ops
+        return ops.comm_count(self.comm)
+
     def close(self):
         from . import ops
         if self.comm:

@@ -122,6 +122,16 @@ class SRTrainer:
             # and every rank leaves the step with the same discriminator buffers (a snapshot is the same file on every rank)
             self._bucket_bufs = self._bucket_bufs + [b for d in self.netsD for b in d.buffers()]
         self.bucket = FlatGradBucket(gh_params + list(self.netGL.parameters()), buffers=self._bucket_bufs).attach()
+        # TGSR_COMM=direct: the buckets' closing all-reduce through the library's own RCCL communicator (tgsr_allreduce_flat,
+        # parallel.RcclDirect) instead of torch.distributed's; the early range and the DAMSM gather stay on the process group
+        self._rccl = None
+        if os.environ.get("TGSR_COMM", "") == "direct" and self.device.type == "cuda":
+            from .parallel import RcclDirect, dp_world
+            if dp_world() > 1:
+                self._rccl = RcclDirect.create()
+                self._early_on = False
+                for b in [self.bucket] + self.bucketsD:
+                    b.comm = self._rccl
         taken = cur + ([self._wside.cuda_stream] if self._wside is not None else []) + \
             ([self._comm.cuda_stream] if self._comm is not None else [])
         self._dstreams = distinct_streams(len(self.netsD), self.device, avoid=taken) \

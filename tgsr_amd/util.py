@@ -233,8 +233,9 @@ def Block3x3_relu(in_planes, out_planes):
 class _ConvBnLeaky(nn.Sequential):
     """[conv, BatchNorm2d, LeakyReLU(0.2)] as one fused training block (keys `0.weight`, `1.*`).  `kind` = "down":
     downBlock, nn.Conv2d(in, out, 4, 2, 1, bias=False) (util.py:92-98); "3x3": conv3x3 (the discriminators'
-    Block3x3_leakRelu).  The discriminators only exist in training (losses.py:290-374 call them with batch-statistics
-    BatchNorm), so there is no folded inference form."""
+    Block3x3_leakRelu).  Training mode (what losses.py:290-374 run): batch-statistics BatchNorm, autograd.ConvBnLeaky.  Under
+    .eval(): the running statistics, autograd.ConvBnLeakyEval (`groups` then only partitions the batch - every slice is
+    normalised by the same running statistics)."""
 
     def __init__(self, conv, out_planes, kind):
         super().__init__(conv, nn.BatchNorm2d(out_planes), nn.LeakyReLU(0.2, inplace=True))
@@ -243,7 +244,11 @@ class _ConvBnLeaky(nn.Sequential):
     def forward(self, x, groups=None):
         """groups: sizes of consecutive batch slices normalised with their own batch statistics (autograd.ConvBnLeaky)."""
         if not self.training:
-            raise NotImplementedError("discriminator blocks run with batch-statistics BatchNorm only (training mode)")
+            from .autograd import ConvBnLeakyEval
+            bn = self[1]
+            if not bn.track_running_stats or bn.running_mean is None:
+                raise NotImplementedError("eval-mode BatchNorm2d without running statistics")
+            return ConvBnLeakyEval.apply(x, self[0].weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self._kind, bn.eps)
         from .autograd import conv_bn_leaky_train
         return conv_bn_leaky_train(x, self[0], self[1], self._kind, groups)
 
