@@ -801,6 +801,10 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup,
         gc.collect()
         gc.freeze()
         entry["host"] = "gc.collect() + gc.freeze() after the warm-up steps"
+        entry["launch"] = ("generators' half replayed from hipGraphs (fwd | loss + bwd [| all-reduce |] Adam + re-pack + EMA)" if tr._graph_g
+                           else "generators' update eager") + (
+            "; each discriminator's update replayed from its hipGraph%s" % ("s around its bucket's all-reduce" if world > 1 else "")
+            if (tr._graph_d and tr._dstreams) else "")
         ok = True
     except Exception as e:          # noqa: BLE001
         entry["error"] = "%s: %s" % (type(e).__name__, e)
@@ -823,15 +827,21 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup,
     sec = dt / max(1, steps)
     entry.update({"value": round(world * B / sec, 2), "unit": "images/s", "ms_per_step": round(sec * 1e3, 4), "repeats": reps,
                   "final_loss": round(float(loss), 5), "grad_bucket_MB": round(tr.bucket.numel * 4 / 1e6, 2)})
-    # one step under torch.profiler (roctracer): every kernel of the step as the device ran it - also the nodes of replayed graphs -
-    # summed by family: the library's own kernels (`tgsr::`), BatchNorm passes among them, everything else (aten / MIOpen / copies)
+    # one EAGER step under torch.profiler (roctracer does not report the nodes of a replayed hipGraph; the eager step issues the
+    # same kernels): every kernel of the step as the device ran it, summed by family - the library's own kernels (`tgsr::`),
+    # BatchNorm passes among them, everything else (aten / MIOpen / copies)
     dterr = None
     try:
         from torch.profiler import ProfilerActivity, profile
         torch.cuda.synchronize()
-        with profile(activities=[ProfilerActivity.CUDA]) as tp:
-            tr.step(cap, lens, LR, LRb, hr)
-            torch.cuda.synchronize()
+        keep = (tr._graph_g, tr._dsteps)
+        tr._graph_g, tr._dsteps = False, -10 ** 9
+        try:
+            with profile(activities=[ProfilerActivity.CUDA]) as tp:
+                tr.step(cap, lens, LR, LRb, hr)
+                torch.cuda.synchronize()
+        finally:
+            tr._graph_g, tr._dsteps = keep
         fam = {"tgsr": [0, 0.0], "bn": [0, 0.0], "other": [0, 0.0]}
         top_other = {}
         for ev in tp.events():
@@ -859,8 +869,8 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup,
                 "batchnorm_launches": fam["bn"][0],
                 "largest_non_tgsr": [{"name": k, "launches": v[0], "ms": round(v[1] / 1e3, 3)}
                                      for k, v in sorted(top_other.items(), key=lambda kv: -kv[1][1])[:4]],
-                "note": "one step under torch.profiler (device activities only), summed kernel durations - streams overlap, so "
-                        "kernel_ms exceeds the step time"}
+                "note": "one eager step under torch.profiler (device activities only), summed kernel durations - streams overlap, "
+                        "so kernel_ms exceeds the step time"}
     except Exception as e:          # noqa: BLE001
         dterr = "%s: %s" % (type(e).__name__, e)
     if not _all_ok(dterr is None, dist, dev) and rank == 0:

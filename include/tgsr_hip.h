@@ -407,6 +407,17 @@ int tgsr_axpy_images(int n, float* const* out, const float* const* t, const floa
  *   bwd: ds = amap * dy (ds may be NULL), damap[p] = sum_bc dy[bc][p] * s[bc][p] (damap may be NULL), planes added in index order.
  * BC = B * 3 planes of HW pixels, dense; HW % 4 == 0, pointers 16-byte aligned (else TGSR_EUNSUPPORTED).
  */
+/*
+ * The adversarial terms of discriminator_loss / generator_loss (losses.py:290-316, 358-371) in one launch: out[0] = sum_i
+ * weight[i] * BCEWithLogits(l[i], target[i]) over l = [a (na logits); b (nb logits, may be NULL / 0)] - the reference's up to five
+ * mean-reduced nn.BCEWithLogitsLoss calls with their 1/n means and /2, /3 combination folded into `weight`.  One workgroup, fixed
+ * summation order.  bwd: da / db = dy[0] * weight * (sigmoid(l) - target) (either may be NULL).
+ */
+int tgsr_weighted_bce_fwd(const float* a, int na, const float* b, int nb, const float* target, const float* weight, float* out,
+                          void* stream);
+int tgsr_weighted_bce_bwd(const float* dy, const float* a, int na, const float* b, int nb, const float* target, const float* weight,
+                          float* da, float* db, void* stream);
+
 int tgsr_axpy_map_fwd(const float* t, const float* s, const float* amap, float* out, int BC, int HW, void* stream);
 int tgsr_axpy_map_bwd(const float* dy, const float* s, const float* amap, float* ds, float* damap, int BC, int HW, void* stream);
 

@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The fp32 path's ONE stated tolerance against the CPU fp32 oracle / the reference's captured outputs: atol = rtol = 2e-4 on
+# un-clamped images, every value (tests/test_hip_parity_margin.py measures how much of it 15 full-size cases use: at most 0.68;
+# DESIGN.md section 4).  Op- and module-level tests hold their cases to tighter, measured bounds of their own.
+FP32_TOL = 2e-4
 
 
 def pytest_configure(config):

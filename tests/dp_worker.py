@@ -119,8 +119,10 @@ def main():
         runs = []
         for graphs in (False, True):
             t = make_trainer(device=dev, discriminators=gan)
+            assert t._graph_capable
+            t._graph_g = graphs
             if not graphs:
-                t._gsteps = t._dsteps = -10 ** 9
+                t._dsteps = -10 ** 9
             ls = []
             for it in range(6):
                 torch.manual_seed(50 + it)

@@ -623,9 +623,10 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
             torch.manual_seed(5)
             tr = train.SRTrainer(41, device=DEV, discriminators=True)
             assert tr._graph_d                                   # capturable Adam on both
-            assert tr._graph_g
+            assert tr._graph_g and tr._graph_capable             # the default policy replays the G/D alternation
             if not graphs:
-                tr._dsteps = tr._gsteps = -10 ** 9               # never reach the warm-up count: eager updates, same optimizer kind
+                tr._graph_g = False
+                tr._dsteps = -10 ** 9                            # never reaches the warm-up count: eager updates, same optimizer kind
             trs.append(tr)
         out = [[], []]
         for step in range(6):
@@ -675,3 +676,37 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
                 assert torch.equal(va, vb), ka
     finally:
         cfg_reset()
+
+
+def test_weighted_bce_op_equals_the_sum_of_torch_bce_terms():
+    """tgsr::weighted_bce (the five BCE-with-logits terms of discriminator_loss and their /2, /3 combination in one launch, losses.py:
+    303-316) against F.binary_cross_entropy_with_logits term by term: value and the gradients of both logit vectors; and
+    discriminator_loss through it against the un-fused formulas on the same logits."""
+    from tgsr_amd import custom_ops as C
+    from tgsr_amd.miscc import losses
+    n = 7
+    gen = torch.Generator().manual_seed(4)
+    lc, lu = (torch.randn(3 * n - 1, generator=gen) * 3), (torch.randn(2 * n, generator=gen) * 3)
+    rl, fl = torch.ones(n), torch.zeros(n)
+    bce = F.binary_cross_entropy_with_logits
+    a, b = lc.clone().requires_grad_(True), lu.clone().requires_grad_(True)
+    ref = (bce(b[:n], rl) + bce(a[:n], rl)) / 2. + (bce(b[n:], fl) + bce(a[n:2 * n], fl) + bce(a[2 * n:], fl[1:n])) / 3.
+    ref.backward()
+    ad, bd = lc.to(DEV).requires_grad_(True), lu.to(DEV).requires_grad_(True)
+    w = losses._bce_weights(torch.device(DEV, torch.cuda.current_device()), (n, .5 / n), (n, 1. / (3 * n)), (n - 1, 1. / (3 * (n - 1))),
+                            (n, .5 / n), (n, 1. / (3 * n)))
+    t = torch.cat((rl, fl, fl[1:n], rl, fl)).to(DEV)
+    out = C.weighted_bce(ad, bd, t, w)
+    out.backward()
+    assert out.dim() == 0 and abs(float(out) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    close(ad.grad, a.grad, atol=1e-7, rtol=1e-5)
+    close(bd.grad, b.grad, atol=1e-7, rtol=1e-5)
+    # one logit vector only, extreme logits (the stable form), a scaled upstream gradient
+    l1 = torch.tensor([-80.0, -3.0, 0.0, 2.5, 90.0])
+    a1 = l1.clone().requires_grad_(True)
+    (3.0 * bce(a1, torch.ones(5))).backward()
+    a1d = l1.to(DEV).requires_grad_(True)
+    o1 = C.weighted_bce(a1d, None, torch.ones(5, device=DEV), torch.full((5,), 0.2, device=DEV))
+    (3.0 * o1).backward()
+    assert abs(float(o1) - float(bce(l1, torch.ones(5)))) < 1e-5 * float(bce(l1, torch.ones(5)))
+    close(a1d.grad, a1.grad, atol=1e-7, rtol=1e-5)

@@ -1,7 +1,10 @@
 """GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed goldens.
 
-fp32 tolerance stated by the north-star / SURVEY 8c: atol = rtol = 1e-4 on un-clamped outputs (the reference's
-own fp32-vs-fp64 deviation is 1.7e-5, thread-count nondeterminism 2.5e-6).  Op-level checks use a tighter bound.
+The path's ONE stated fp32 tolerance is conftest.FP32_TOL: atol = rtol = 2e-4 on un-clamped outputs, every value (round 6; SURVEY 8c
+proposed 1e-4 from a single batch-2 input whose fp32-vs-fp64 deviation was 1.7e-5 - over 15 full-size cases the reference's own CPU
+fp32 path is up to 8.4e-5 from fp64 and two correct fp32 evaluations differ by up to 1.35e-4 at isolated outlier pixels:
+tests/test_hip_parity_margin.py).  The cases of THIS file are pinned seeds and are held to the tighter 1e-4
+they measure within (ATOL below); op-level checks use tighter bounds still.
 """
 import os
 
@@ -15,9 +18,10 @@ from oracle import tgsr_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-ATOL = RTOL = 1e-4
-# the 256^2 images under TGSR_WINOGRAD=0 (direct kernels); the default Winograd kernels meet ATOL there too
-ATOL256 = 2e-4 if os.environ.get("TGSR_WINOGRAD", "1") == "0" else ATOL
+from conftest import FP32_TOL
+ATOL = RTOL = 1e-4        # these pinned cases' measured bound: tighter than the stated FP32_TOL
+# the 256^2 images under TGSR_WINOGRAD=0 (direct kernels): the stated tolerance; the default Winograd kernels meet ATOL there too
+ATOL256 = FP32_TOL if os.environ.get("TGSR_WINOGRAD", "1") == "0" else ATOL
 DEV = "cuda"
 
 

@@ -313,9 +313,8 @@ def test_graph_replayed_generator_update_equals_eager_one():
         for graphs in (True, False):
             torch.manual_seed(5)
             tr = train.SRTrainer(41, device=DEV)
-            assert tr._graph_g and tr._packs is not None
-            if not graphs:
-                tr._gsteps = -10 ** 9                            # never reaches the warm-up count: eager updates, same optimizer kind
+            assert tr._graph_capable and tr._packs is not None   # capturable Adam on both
+            tr._graph_g = graphs                                 # (the default policy keeps the generator-only step eager: train.py)
             trs.append(tr)
         out = [[], []]
         for step in range(8):

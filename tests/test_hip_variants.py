@@ -9,7 +9,7 @@ from conftest import load_npz, split_sd
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-ATOL = RTOL = 1e-4          # the path's stated fp32 tolerance
+ATOL = RTOL = 1e-4          # these cases' bound: tighter than the path's stated conftest.FP32_TOL (2e-4)
 
 
 def T(a):
@@ -99,7 +99,9 @@ def test_netg_highweight_without_tanh(g, cfg32):
     from tgsr_amd import model
     net = model.NetG_highweight(weightmap=False, low="lr", useAct=False)
     assert len(net.conv_output) == 1
-    net.load_state_dict(split_sd(g, "na.GH."), strict=True)
+    # (the fixture was captured on the CPU, where the reference's `nn.Parameter(...).cuda()` keeps `a` a parameter; on a GPU - and in
+    # the shipped netGH_epoch_7.pth - it is a plain tensor that is neither saved nor trained: SURVEY Q3, tgsr_amd/model.py)
+    net.load_state_dict({k: v for k, v in split_sd(g, "na.GH.").items() if k != "a"}, strict=True)
     net.to(DEV).eval()
     LR, SRb = T(g["na.LR"]), [T(g["na.SRb%d" % k]) for k in range(3)]
     with torch.no_grad():
@@ -121,7 +123,7 @@ def test_downblock_in_eval_mode(g, cfg32):
     weight gradients against the reference module's; a whole discriminator runs in eval mode."""
     from tgsr_amd import model, util
     blk = util.downBlock(16, 32)
-    blk.load_state_dict(split_sd(g, "down."), strict=True)
+    blk.load_state_dict({k: v for k, v in split_sd(g, "down.").items() if k[0] in "01"}, strict=True)
     blk.to(DEV).eval()
     x = T(g["down.x"]).requires_grad_(True)
     y = blk(x)

@@ -103,6 +103,8 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _vp, _vp]),
     "tgsr_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
     "tgsr_axpy_images": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp]),
+    "tgsr_weighted_bce_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "tgsr_weighted_bce_bwd": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_axpy_map_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tgsr_axpy_map_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tgsr_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -26,6 +26,24 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// A workgroup's walk over its slice [lo, hi) of a channel's B x HW values, one float4 per thread and step: (b, p) advance by
+// addition - the 64-bit division `e / HW` per step that this replaces was a fifth of the GLU passes' VALU work (they are
+// VALU-bound: exp + rcp per value) - and the passes issue two steps' loads before they compute (`TGSR_BN_STEP2`).
+struct BnWalk {
+  int64_t e, hi;
+  int b, p, HW;
+  __device__ __forceinline__ BnWalk(int64_t lo, int64_t hi_, int HW_) : e(lo + 4 * threadIdx.x), hi(hi_), HW(HW_) {
+    b = (int)(e / HW_);
+    p = (int)(e - (int64_t)b * HW_);
+  }
+  __device__ __forceinline__ bool ok() const { return e < hi; }
+  __device__ __forceinline__ void next() {
+    e += 4 * kBnThreads;
+    p += 4 * kBnThreads;
+    while (p >= HW) { p -= HW; ++b; }
+  }
+};
+
 // grid (C, nsplit): partial[c][s] = (sum, sumsq) of raw[b][c][:] over the b's / pixel ranges of split s
 __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __restrict__ raw, int64_t bstride, int B,
                                                               int HW, float* __restrict__ partial, int nsplit) {
@@ -37,12 +55,20 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __res
   float s = 0.f, q = 0.f;
   const bool vec = (HW & 3) == 0;
   if (vec) {
-    for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
-      const int b = (int)(e / HW);
-      const int p = (int)(e - (int64_t)b * HW);
-      const float4 v = *reinterpret_cast<const float4*>(raw + b * bstride + (int64_t)c * HW + p);
+    BnWalk w(lo, hi, HW);
+    while (w.ok()) {
+      const float4 v = *reinterpret_cast<const float4*>(raw + w.b * bstride + (int64_t)c * HW + w.p);
+      w.next();
+      const bool two = w.ok();
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (two) u = *reinterpret_cast<const float4*>(raw + w.b * bstride + (int64_t)c * HW + w.p);
       s += (v.x + v.y) + (v.z + v.w);
       q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      if (two) {
+        s += (u.x + u.y) + (u.z + u.w);
+        q += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+        w.next();
+      }
     }
   } else {
     for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
@@ -94,14 +120,24 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
     }
   };
   if ((HW & 3) == 0 && (per & 3) == 0) {                 // float4 streams (every slice starts on a multiple of 4)
-    for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
-      const int b = (int)(e / HW);
-      const int p = (int)(e - (int64_t)b * HW);
-      const float4 dy = *reinterpret_cast<const float4*>(dout + ((int64_t)b * Co + c) * HW + p);
-      const float4 rv = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c) * HW + p);
-      float4 rg = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (GLU) rg = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c + Co) * HW + p);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    BnWalk w(lo, hi, HW);
+    while (w.ok()) {
+      const float4 dy = *reinterpret_cast<const float4*>(dout + ((int64_t)w.b * Co + c) * HW + w.p);
+      const float4 rv = *reinterpret_cast<const float4*>(raw + ((int64_t)w.b * C + c) * HW + w.p);
+      float4 rg = z4;
+      if (GLU) rg = *reinterpret_cast<const float4*>(raw + ((int64_t)w.b * C + c + Co) * HW + w.p);
+      w.next();
+      const bool two = w.ok();
+      float4 dy2 = z4, rv2 = z4, rg2 = z4;
+      if (two) {
+        dy2 = *reinterpret_cast<const float4*>(dout + ((int64_t)w.b * Co + c) * HW + w.p);
+        rv2 = *reinterpret_cast<const float4*>(raw + ((int64_t)w.b * C + c) * HW + w.p);
+        if (GLU) rg2 = *reinterpret_cast<const float4*>(raw + ((int64_t)w.b * C + c + Co) * HW + w.p);
+        w.next();
+      }
       acc1(dy.x, rv.x, rg.x); acc1(dy.y, rv.y, rg.y); acc1(dy.z, rv.z, rg.z); acc1(dy.w, rv.w, rg.w);
+      if (two) { acc1(dy2.x, rv2.x, rg2.x); acc1(dy2.y, rv2.y, rg2.y); acc1(dy2.z, rv2.z, rg2.z); acc1(dy2.w, rv2.w, rg2.w); }
     }
   } else {
     for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {
@@ -222,25 +258,41 @@ __global__ __launch_bounds__(kBnThreads) void bn_fin_act_fwd_kernel(
   const int64_t total = (int64_t)B * HW;
   const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
   const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
-  for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
-    const int b = (int)(e / HW);
-    const int p = (int)(e - (int64_t)b * HW);
-    const float4 v = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c) * HW + p);
+  auto act4 = [&](const float4 v, const float4 g, const float4 r) {
     float4 y = make_float4(v.x * sv + tv, v.y * sv + tv, v.z * sv + tv, v.w * sv + tv);
     if (GLU) {
-      const float4 g = *reinterpret_cast<const float4*>(raw + ((int64_t)b * C + c + Co) * HW + p);
       y.x *= sigm(g.x * sg + tg);
       y.y *= sigm(g.y * sg + tg);
       y.z *= sigm(g.z * sg + tg);
       y.w *= sigm(g.w * sg + tg);
     } else if (res) {
-      const float4 r = *reinterpret_cast<const float4*>(res + b * rbs + (int64_t)c * HW + p);
       y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
     } else if (leaky) {                                    // LeakyReLU(0.2): downBlock / Block3x3_leakRelu (util.py:92-98)
       y.x = y.x > 0.f ? y.x : 0.2f * y.x; y.y = y.y > 0.f ? y.y : 0.2f * y.y;
       y.z = y.z > 0.f ? y.z : 0.2f * y.z; y.w = y.w > 0.f ? y.w : 0.2f * y.w;
     }
-    *reinterpret_cast<float4*>(out + b * obs + (int64_t)c * HW + p) = y;
+    return y;
+  };
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  BnWalk w(lo, hi, HW);
+  while (w.ok()) {
+    const int b0 = w.b, p0 = w.p;
+    const float4 v = *reinterpret_cast<const float4*>(raw + ((int64_t)b0 * C + c) * HW + p0);
+    float4 g = z4, r = z4;
+    if (GLU) g = *reinterpret_cast<const float4*>(raw + ((int64_t)b0 * C + c + Co) * HW + p0);
+    else if (res) r = *reinterpret_cast<const float4*>(res + b0 * rbs + (int64_t)c * HW + p0);
+    w.next();
+    const bool two = w.ok();
+    const int b1 = w.b, p1 = w.p;
+    float4 v2 = z4, g2 = z4, r2 = z4;
+    if (two) {
+      v2 = *reinterpret_cast<const float4*>(raw + ((int64_t)b1 * C + c) * HW + p1);
+      if (GLU) g2 = *reinterpret_cast<const float4*>(raw + ((int64_t)b1 * C + c + Co) * HW + p1);
+      else if (res) r2 = *reinterpret_cast<const float4*>(res + b1 * rbs + (int64_t)c * HW + p1);
+      w.next();
+    }
+    *reinterpret_cast<float4*>(out + b0 * obs + (int64_t)c * HW + p0) = act4(v, g, r);
+    if (two) *reinterpret_cast<float4*>(out + b1 * obs + (int64_t)c * HW + p1) = act4(v2, g2, r2);
   }
 }
 
@@ -293,18 +345,34 @@ __global__ __launch_bounds__(kBnThreads) void bn_fin_act_bwd_apply_kernel(
     }
   };
   if ((HW & 3) == 0) {
-    for (int64_t e = lo + 4 * threadIdx.x; e < hi; e += 4 * kBnThreads) {
-      const int b = (int)(e / HW);
-      const int p = (int)(e - (int64_t)b * HW);
-      const int64_t iv_ = ((int64_t)b * C + c) * HW + p, ig_ = iv_ + (int64_t)Co * HW;
-      const float4 dy = *reinterpret_cast<const float4*>(dout + ((int64_t)b * Co + c) * HW + p);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    BnWalk w(lo, hi, HW);
+    while (w.ok()) {
+      const int64_t iv_ = ((int64_t)w.b * C + c) * HW + w.p, ig_ = iv_ + (int64_t)Co * HW;
+      const float4 dy = *reinterpret_cast<const float4*>(dout + ((int64_t)w.b * Co + c) * HW + w.p);
       const float4 rv = *reinterpret_cast<const float4*>(raw + iv_);
-      float4 rg = make_float4(0.f, 0.f, 0.f, 0.f), ov, og;
+      float4 rg = z4, ov, og = z4;
       if (GLU) rg = *reinterpret_cast<const float4*>(raw + ig_);
+      w.next();
+      const bool two = w.ok();
+      const int64_t iv2 = ((int64_t)w.b * C + c) * HW + w.p, ig2 = iv2 + (int64_t)Co * HW;
+      float4 dy2 = z4, rv2 = z4, rg2 = z4, ov2, og2 = z4;
+      if (two) {
+        dy2 = *reinterpret_cast<const float4*>(dout + ((int64_t)w.b * Co + c) * HW + w.p);
+        rv2 = *reinterpret_cast<const float4*>(raw + iv2);
+        if (GLU) rg2 = *reinterpret_cast<const float4*>(raw + ig2);
+        w.next();
+      }
       one(dy.x, rv.x, rg.x, ov.x, og.x); one(dy.y, rv.y, rg.y, ov.y, og.y);
       one(dy.z, rv.z, rg.z, ov.z, og.z); one(dy.w, rv.w, rg.w, ov.w, og.w);
       *reinterpret_cast<float4*>(draw + iv_) = ov;
       if (GLU) *reinterpret_cast<float4*>(draw + ig_) = og;
+      if (two) {
+        one(dy2.x, rv2.x, rg2.x, ov2.x, og2.x); one(dy2.y, rv2.y, rg2.y, ov2.y, og2.y);
+        one(dy2.z, rv2.z, rg2.z, ov2.z, og2.z); one(dy2.w, rv2.w, rg2.w, ov2.w, og2.w);
+        *reinterpret_cast<float4*>(draw + iv2) = ov2;
+        if (GLU) *reinterpret_cast<float4*>(draw + ig2) = og2;
+      }
     }
   } else {
     for (int64_t e = lo + threadIdx.x; e < hi; e += kBnThreads) {

@@ -220,6 +220,41 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const float* __rest
   }
 }
 
+// sum_i w[i] * BCEWithLogits(l[i], t[i]) over the concatenation l = [a (na values); b (nb values)]: the terms of discriminator_loss
+// / generator_loss (losses.py:290-316, 358-371: up to five mean-reduced F.binary_cross_entropy_with_logits calls, their /2 and /3
+// weights folded into w) in ONE launch, one workgroup, the lanes' partial sums combined in a fixed order.
+// BCEWithLogits(l, t) = max(l, 0) - l t + log1p(exp(-|l|)).
+__global__ __launch_bounds__(256) void weighted_bce_kernel(const float* __restrict__ a, int na, const float* __restrict__ b, int nb,
+                                                           const float* __restrict__ t, const float* __restrict__ w,
+                                                           float* __restrict__ out) {
+  __shared__ float red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < na + nb; i += 256) {
+    const float l = i < na ? a[i] : b[i - na];
+    acc += w[i] * (fmaxf(l, 0.f) - l * t[i] + log1pf(expf(-fabsf(l))));
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// d/dl[i] = dy * w[i] * (sigmoid(l[i]) - t[i])
+__global__ __launch_bounds__(256) void weighted_bce_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a, int na,
+                                                               const float* __restrict__ b, int nb, const float* __restrict__ t,
+                                                               const float* __restrict__ w, float* __restrict__ da,
+                                                               float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= na + nb) return;
+  const float l = i < na ? a[i] : b[i - na];
+  const float g = dy[0] * w[i] * (1.f / (1.f + expf(-l)) - t[i]);
+  if (i < na) { if (da) da[i] = g; }
+  else if (db) db[i - na] = g;
+}
+
 }  // namespace tgsr
 
 using namespace tgsr;
@@ -363,4 +398,19 @@ extern "C" int tgsr_affine_act_bwd(const float* dy, const float* out, const floa
   hipLaunchKernelGGL(affine_act_bwd_kernel, dim3(C, affine_grid_y(B, C, HW)), dim3(256), 0, as_stream(stream), dy, out, scale,
                      draw, B, C, HW, act);
   return note_launch(hipGetLastError(), "affine_act_bwd_kernel");
+}
+
+extern "C" int tgsr_weighted_bce_fwd(const float* a, int na, const float* b, int nb, const float* target, const float* weight,
+                                     float* out, void* stream) {
+  if (!a || na < 1 || nb < 0 || (nb > 0 && !b) || !target || !weight || !out) return TGSR_EINVAL;
+  hipLaunchKernelGGL(weighted_bce_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, na, b, nb, target, weight, out);
+  return note_launch(hipGetLastError(), "weighted_bce_kernel");
+}
+
+extern "C" int tgsr_weighted_bce_bwd(const float* dy, const float* a, int na, const float* b, int nb, const float* target,
+                                     const float* weight, float* da, float* db, void* stream) {
+  if (!dy || !a || na < 1 || nb < 0 || (nb > 0 && !b) || !target || !weight || (!da && !db)) return TGSR_EINVAL;
+  hipLaunchKernelGGL(weighted_bce_bwd_kernel, dim3((na + nb + 255) / 256), dim3(256), 0, as_stream(stream), dy, a, na, b, nb, target,
+                     weight, da, db);
+  return note_launch(hipGetLastError(), "weighted_bce_bwd_kernel");
 }

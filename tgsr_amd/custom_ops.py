@@ -494,6 +494,35 @@ text_tail_lp = _define("text_tail_lp(Tensor words, Tensor[] w_ctxs, Tensor sent_
                         words.new_empty(len(ws) * words.shape[0] * 4096 + 4 * words.shape[0], dtype=torch.uint8)))
 axpy_images = _define("axpy_images(Tensor[] ts, Tensor[] ss, float alpha) -> Tensor[]",
                       lambda ts, ss, alpha: ops.axpy_images(list(ts), list(ss), alpha), lambda ts, ss, alpha: [torch.empty_like(t) for t in ts])
+weighted_bce = _define("weighted_bce(Tensor a, Tensor? b, Tensor target, Tensor weight) -> Tensor",
+                       lambda a, b, t, w: ops.weighted_bce(a, b, t, w), lambda a, b, t, w: a.new_empty(()))
+
+
+def _weighted_bce_bwd(dy, a, b, t, w):
+    da, db = ops.weighted_bce_bwd(dy, a, b, t, w)
+    return da, (db if db is not None else a.new_empty(0))
+
+
+weighted_bce_bwd = _define("weighted_bce_bwd(Tensor dy, Tensor a, Tensor? b, Tensor target, Tensor weight) -> (Tensor, Tensor)",
+                           _weighted_bce_bwd, lambda dy, a, b, t, w: (torch.empty_like(a), torch.empty_like(b) if b is not None else a.new_empty(0)))
+
+
+def _weighted_bce_backward(ctx, dy):
+    a, b, t, w = ctx.saved_tensors if ctx.has_b else (ctx.saved_tensors[0], None, ctx.saved_tensors[1], ctx.saved_tensors[2])
+    da, db = weighted_bce_bwd(dy.contiguous(), a, b, t, w)
+    return (da if ctx.needs_input_grad[0] else None), (db if ctx.has_b and ctx.needs_input_grad[1] else None), None, None
+
+
+def _weighted_bce_setup(ctx, inputs, output):
+    a, b, t, w = inputs
+    ctx.has_b = b is not None
+    if b is not None:
+        ctx.save_for_backward(a, b, t, w)
+    else:
+        ctx.save_for_backward(a, t, w)
+
+
+torch.library.register_autograd("tgsr::weighted_bce", _weighted_bce_backward, setup_context=_weighted_bce_setup, lib=_lib)
 axpy_map = _define("axpy_map(Tensor t, Tensor s, Tensor amap) -> Tensor", lambda t, s, a: ops.axpy_map(t, s, a),
                    lambda t, s, a: torch.empty_like(t))
 

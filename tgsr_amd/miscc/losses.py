@@ -92,6 +92,23 @@ def _bce(logits, target):
     return F.binary_cross_entropy_with_logits(logits, target)
 
 
+_BCE_WEIGHTS = {}
+
+
+def _bce_weights(device, *runs):
+    """The per-logit weights of a sum of mean-reduced BCE terms, `runs` = (count, weight of every element) in order: a device
+    tensor built from fill kernels once per distinct argument list (no host copy: also legal inside a hipGraph capture)."""
+    key = (str(device),) + runs
+    w = _BCE_WEIGHTS.get(key)
+    if w is None:
+        w = _BCE_WEIGHTS[key] = torch.cat([torch.full((int(n),), float(v), dtype=torch.float32, device=device) for n, v in runs])
+    return w
+
+
+def _fused_bce_ok(*ts):
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in ts)
+
+
 def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake_labels):
     """losses.py:290-316.  The reference ships no discriminator class; any module exposing `COND_DNET` /
     `UNCOND_DNET` like AttnGAN's D_NET* works: real / fake / wrong-caption terms, the wrong pair being the batch
@@ -111,11 +128,20 @@ def discriminator_loss(netD, real_imgs, fake_imgs, conditions, real_labels, fake
         feat_real, feat_fake = feats[:n], feats[n:]
         lc = netD.COND_DNET(torch.cat((feats, feat_real[:n - 1])), torch.cat((conditions, conditions, conditions[1:n])),
                             groups=(n, n, n - 1))
+        lu = netD.UNCOND_DNET(feats) if netD.UNCOND_DNET is not None else None
+        if _fused_bce_ok(lc, lu, real_labels, fake_labels):
+            # the five mean-reduced BCE terms and their /2, /3 combination as ONE launch (tgsr::weighted_bce; its backward another):
+            # ~40 small aten launches per discriminator and step otherwise (BCE, mean, slice backward fills, adds)
+            tc = (real_labels, fake_labels, fake_labels[1:n])
+            if lu is None:
+                return C.weighted_bce(lc, None, torch.cat(tc), _bce_weights(lc.device, (n, 1. / n), (n, .5 / n), (n - 1, .5 / (n - 1))))
+            return C.weighted_bce(lc, lu, torch.cat(tc + (real_labels, fake_labels)),
+                                  _bce_weights(lc.device, (n, .5 / n), (n, 1. / (3 * n)), (n - 1, 1. / (3 * (n - 1))), (n, .5 / n),
+                                               (n, 1. / (3 * n))))
         cond = {"real": _bce(lc[:n], real_labels), "fake": _bce(lc[n:2 * n], fake_labels),
                 "wrong": _bce(lc[2 * n:], fake_labels[1:n])}
-        if netD.UNCOND_DNET is None:
+        if lu is None:
             return cond["real"] + (cond["fake"] + cond["wrong"]) / 2.
-        lu = netD.UNCOND_DNET(feats)
         return (_bce(lu[:n], real_labels) + cond["real"]) / 2. + (_bce(lu[n:], fake_labels) + cond["fake"] + cond["wrong"]) / 3.
     feat_real, feat_fake = netD(real_imgs), netD(fake_imgs.detach())
     cond = {"real": _bce(netD.COND_DNET(feat_real, conditions), real_labels),
@@ -215,10 +241,17 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
                 for t in (img, sent_emb, real_labels):
                     t.record_stream(st)                    # allocated on the calling stream, read on this one
             feat = netD(img)
-            adv = _bce(netD.COND_DNET(feat, sent_emb), real_labels)
-            if netD.UNCOND_DNET is not None:
-                adv = adv + _bce(netD.UNCOND_DNET(feat), real_labels)
-            adv = g * adv
+            lc = netD.COND_DNET(feat, sent_emb)
+            lu = netD.UNCOND_DNET(feat) if netD.UNCOND_DNET is not None else None
+            if _fused_bce_ok(lc, lu, real_labels) and lc.dim() == 1:
+                # g * (BCE(cond logits, real) + BCE(uncond logits, real)), one launch
+                adv = C.weighted_bce(lc, lu, real_labels if lu is None else torch.cat((real_labels, real_labels)),
+                                     _bce_weights(lc.device, (lc.numel() + (0 if lu is None else lu.numel()), float(g) / B)))
+            else:
+                adv = _bce(lc, real_labels)
+                if lu is not None:
+                    adv = adv + _bce(lu, real_labels)
+                adv = g * adv
         advs.append(adv)
     for k, (netD, img) in enumerate(zip(netsD, fake_imgs)):
         adv = advs[k]

@@ -1283,6 +1283,34 @@ def axpy_images(ts, ss, alpha: float, outs=None):
     return outs
 
 
+def weighted_bce(a: torch.Tensor, b: Optional[torch.Tensor], target: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """sum_i weight[i] * BCEWithLogits([a; b][i], target[i]) as a 0-dim tensor (the adversarial terms of the GAN losses)."""
+    _need_hip(a, b, target, weight)
+    a = _f32(a, "a").contiguous().view(-1)
+    b = None if b is None else _f32(b, "b").contiguous().view(-1)
+    n = a.numel() + (0 if b is None else b.numel())
+    if target.numel() != n or weight.numel() != n or target.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise TgsrError("weighted_bce: %d logits, %d targets, %d weights" % (n, target.numel(), weight.numel()))
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    check(_lib.lib().tgsr_weighted_bce_fwd(_p(a), a.numel(), _p(b), 0 if b is None else b.numel(), _p(target.contiguous()),
+                                           _p(weight.contiguous()), _p(out), _stream()), "tgsr_weighted_bce_fwd")
+    return out
+
+
+def weighted_bce_bwd(dy: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor], target: torch.Tensor, weight: torch.Tensor):
+    """(da, db) of weighted_bce."""
+    _need_hip(dy, a, b, target, weight)
+    dy = _f32(dy, "dy").contiguous()
+    af = a.contiguous().view(-1)
+    bf = None if b is None else b.contiguous().view(-1)
+    da = torch.empty_like(a, memory_format=torch.contiguous_format)
+    db = None if b is None else torch.empty_like(b, memory_format=torch.contiguous_format)
+    check(_lib.lib().tgsr_weighted_bce_bwd(_p(dy), _p(af), af.numel(), _p(bf), 0 if bf is None else bf.numel(),
+                                           _p(target.contiguous()), _p(weight.contiguous()), _p(da), _p(db), _stream()),
+          "tgsr_weighted_bce_bwd")
+    return da, db
+
+
 def axpy_map(t: torch.Tensor, s: torch.Tensor, amap: torch.Tensor) -> torch.Tensor:
     """t + amap * s with amap [H, W] broadcast over batch and channels (NetG_highweight(weightmap=True), model.py:276-297)."""
     _need_hip(t, s, amap)

@@ -91,10 +91,19 @@ class SRTrainer:
         # The generators' update - forward, losses, backward, Adam, re-pack, EMA - holds no host decision once the text encoder has
         # produced the embeddings: it is replayed from hipGraphs (one per batch shape), in segments with the gradient all-reduce
         # BETWEEN them, so the replayed step also exists with more than one rank (`_capture_g`).  TGSR_GRAPH_G=0: eager.
-        self._graph_g = self.device.type == "cuda" and os.environ.get("TGSR_GRAPH_G", "1") != "0"
+        # Default ("auto"): replay where it measured at least as fast as the eager step on an idle host - the G/D alternation
+        # (20.6 vs 20.9 ms); the generator-only step (10.0-10.3 vs 9.9 ms) and the step with the Inception encoder (38.8 vs 35.2 ms:
+        # ~1 000 more small kernels, each dependent node of a replay costs a few microseconds more than a launch from a host that
+        # keeps ahead) stay eager: the steps are DEVICE-bound (kernel time 12.1 ms, busy 9.6 ms of a 9.9 ms generator step), so
+        # taking the host out buys nothing there.  TGSR_GRAPH_G=1 replays all of them (a loaded or slower host: under rocprofv3
+        # the replayed generator step runs 10.7 ms, the eager one 15.7), 0 none.
+        mode = os.environ.get("TGSR_GRAPH_G", "auto")
+        self._graph_g = self.device.type == "cuda" and (mode == "1" or (mode == "auto" and bool(discriminators) and
+                                                                         image_encoder is None))
+        self._graph_capable = self.device.type == "cuda" and mode != "0"
         self._ggraphs, self._gsteps, self._ghyper, self._g_bump = {}, 0, None, None
         self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999), fused=self._fused_adam,
-                                    capturable=self._graph_g)
+                                    capturable=self._graph_capable)
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
         self.netsD, self.optsD, self.bucketsD = [], [], []
@@ -138,7 +147,7 @@ class SRTrainer:
             if self.device.type == "cuda" and self.netsD and os.environ.get("TGSR_D_STREAMS", "1") != "0" else []
         taken = taken + [st.cuda_stream for st in self._dstreams]
         # the stream the generators' graphs are captured on, and the branch their re-pack launches fork onto
-        self._gcap, self._gpack = distinct_streams(2, self.device, avoid=taken) if self._graph_g else (None, None)
+        self._gcap, self._gpack = distinct_streams(2, self.device, avoid=taken) if self._graph_capable else (None, None)
 
     # ------------------------------------------------------------------ gradient all-reduce under the tail of backward
     def _arm_early(self):
