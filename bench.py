@@ -772,7 +772,8 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup,
         if gan and encoder:
             # generator_loss's DAMSM ranking term (losses.py:375-389) through CNN_ENCODER's real walk.  The trained Inception-v3 is
             # third-party and absent here: the published TOPOLOGY with seeded random weights (tests/inception_v3_arch.py) runs in its
-            # place - same launches, same sizes, MIOpen convolutions; what it costs, not what it computes, is the point.
+            # place - same layers, same sizes; what it costs, not what it computes, is the point.  In eval mode the walk runs on the
+            # library's own kernels (tgsr_amd/inception.py, csrc/tgsr_igemm.hip; TGSR_TRUNK=torch: the torch modules on MIOpen).
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from inception_v3_arch import InceptionV3Arch
             from tgsr_amd.util import CNN_ENCODER
@@ -781,7 +782,9 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup,
             enc = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM, inception=InceptionV3Arch(seed=1)).to(dev).eval()
             for q in enc.parameters():
                 q.requires_grad = False
-            entry["workload"] += " + the DAMSM ranking term through CNN_ENCODER (Inception-v3 topology, random weights)"
+            entry["workload"] += (" + the DAMSM ranking term through CNN_ENCODER (Inception-v3 topology, random weights; trunk on %s)"
+                                  % ("torch modules / MIOpen" if os.environ.get("TGSR_TRUNK", "hip") == "torch" else
+                                     "the library's own HIP kernels"))
         tr = SRTrainer(41, device=dev, discriminators=gan, image_encoder=enc)
         if weights is not None:
             tr.text_encoder.load_state_dict(weights["E."])

@@ -407,6 +407,46 @@ int tgsr_axpy_images(int n, float* const* out, const float* const* t, const floa
  *   bwd: ds = amap * dy (ds may be NULL), damap[p] = sum_bc dy[bc][p] * s[bc][p] (damap may be NULL), planes added in index order.
  * BC = B * 3 planes of HW pixels, dense; HW % 4 == 0, pointers 16-byte aligned (else TGSR_EUNSUPPORTED).
  */
+/* ------------------------------------------------------------------------------------------------------------------
+ * CNN_ENCODER's frozen Inception-v3 trunk (util.py:263-368, every parameter `requires_grad = False`, util.py:274-275; run by
+ * generator_loss for the DAMSM ranking term, losses.py:375-389): forward and the gradient with respect to the image.
+ *
+ * tgsr_gconv: a convolution of any KH x KW (KH KW <= 64), stride 1 | 2, zero padding, as one implicit GEMM on the fp32 MFMA.
+ *   dgrad = 0  forward.  A = w' [M = Cout][K = Cin KH KW] (tgsr_gconv_pack(dgrad = 0): the filter times the folded BatchNorm scale),
+ *              S = x based at its first channel, [B] samples `s_bstride` floats apart, Hs x Ws pixels; pixel grid PH x PW = the
+ *              OUTPUT size; out[b][m][PH][PW] (+)= relu?(sum + bias[m]) based at the output's channel slice, samples
+ *              `o_bstride` apart (a block's branches write straight into their slices of its concatenation).
+ *   dgrad = 1  data gradient.  A = w'T [M = Cin][K = Cout KH KW] (tgsr_gconv_pack(dgrad = 1)), S = g = d(loss)/d(pre-activation) with
+ *              the forward's OUTPUT size Hs x Ws, pixel grid PH x PW = the forward's INPUT size; out = dx (accumulate = 1: +=,
+ *              a block input collects its branches' gradients one after the other).  bias / relu must be 0.
+ *   mask (nullable; laid out like `out`, same batch stride): the contribution is kept where mask > 0 and dropped elsewhere - the
+ *              ReLU of the tensor whose gradient is being written (a 0 / 1 factor distributes over the sum of a tensor's consumers,
+ *              so every consumer applies it to its own contribution and no separate mask pass runs).  Also on the pool backwards.
+ *   ws: tgsr_gconv_ws_elems(B, M, PH, PW, K) floats (0 when the shape is not split over K).  Deterministic (slabs summed in order).
+ * tgsr_maxpool3s2_*: F.max_pool2d(x, 3, stride 2); the backward routes dy to the FIRST maximum of a window (torch's rule).
+ * tgsr_avgpool3: F.avg_pool2d(x, 3, 1, 1) (count_include_pad); symmetric, so it is also its own backward (accumulate = 1).
+ * tgsr_plane_mean(_bwd): the 8 x 8 global average (F.avg_pool2d(x, 8) on an 8 x 8 map).  tgsr_relu_mask: out = dy * (y > 0).
+ * tgsr_bilinear_*: nn.Upsample(size = (OH, OW), mode = 'bilinear') (align_corners = False), util.py:310, on dense planes.
+ */
+int tgsr_gconv_set_form(int split); /* 1 (default): three-piece bf16 form where K % 16 == 0, <= 25 taps, stride-1 data gradient; 0: fp32 MFMA.  Returns the old value */
+int tgsr_gconv_nsplit(int M, int N, int K);
+int64_t tgsr_gconv_ws_elems(int B, int M, int PH, int PW, int K);
+int tgsr_gconv(int dgrad, const float* A, const float* S, int64_t s_bstride, int B, int Hs, int Ws, int M, int K, int PH, int PW,
+               int KH, int KW, int stride, int padh, int padw, const float* bias, int relu, int accumulate, const float* mask,
+               float* out, int64_t o_bstride, float* ws, void* stream);
+int tgsr_gconv_pack(const float* w, const float* scale, float* out, int Cout, int Cin, int KK, int dgrad, void* stream);
+int tgsr_maxpool3s2_fwd(const float* x, int64_t x_bstride, int B, int C, int H, int W, float* out, int64_t o_bstride, void* stream);
+int tgsr_maxpool3s2_bwd(const float* x, int64_t x_bstride, const float* dy, int64_t dy_bstride, int B, int C, int H, int W, float* dx,
+                        int64_t dx_bstride, int accumulate, const float* mask, void* stream);
+int tgsr_avgpool3(const float* x, int64_t x_bstride, int B, int C, int H, int W, float* out, int64_t o_bstride, int accumulate,
+                  const float* mask, void* stream);
+int tgsr_plane_mean(const float* x, float* out, int64_t planes, int HW, void* stream);
+int tgsr_plane_mean_bwd(const float* dy, float* dx, int64_t planes, int HW, void* stream);
+int tgsr_relu_mask(const float* dy, int64_t dy_bstride, const float* y, int64_t y_bstride, float* out, int64_t o_bstride, int B,
+                   int64_t per_sample, void* stream);
+int tgsr_bilinear_fwd(const float* x, int64_t planes, int H, int W, int OH, int OW, float* out, void* stream);
+int tgsr_bilinear_bwd(const float* dy, int64_t planes, int H, int W, int OH, int OW, float* dx, void* stream);
+
 /*
  * The adversarial terms of discriminator_loss / generator_loss (losses.py:290-316, 358-371) in one launch: out[0] = sum_i
  * weight[i] * BCEWithLogits(l[i], target[i]) over l = [a (na logits); b (nb logits, may be NULL / 0)] - the reference's up to five

@@ -115,8 +115,11 @@ def main():
     # ---- updates replayed from hipGraphs under data parallelism (train.py `_capture_g` / `_capture_d_update`: segments with the
     # bucket's all-reduce BETWEEN them) against the eager data-parallel step, same initial weights, same shards, same noise: bit
     # for bit - the generator-only step and the G/D alternation
+    # (the discriminators are built for 64 / 128 / 256-pixel images: the G/D runs take a 32 x 32 batch)
+    cap32, lens32, LR32, LRb32, hr32 = build_batch(B, lr=32)
     for gan in (False, True):
         runs = []
+        bc, bl, bLR, bLRb, bhr = (cap32, lens32, LR32, LRb32, hr32) if gan else (cap, lens, LR, LRb, hr)
         for graphs in (False, True):
             t = make_trainer(device=dev, discriminators=gan)
             assert t._graph_capable
@@ -126,8 +129,8 @@ def main():
             ls = []
             for it in range(6):
                 torch.manual_seed(50 + it)
-                ls.append(float(t.step(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev),
-                                       [h[lo:hi].to(dev) for h in hr])))
+                ls.append(float(t.step(bc[lo:hi].to(dev), bl[lo:hi].tolist(), bLR[lo:hi].to(dev), bLRb[lo:hi].to(dev),
+                                       [h[lo:hi].to(dev) for h in bhr])))
             torch.cuda.synchronize()
             sd = [v.detach().flatten().float() for m in [t.netGL, t.netGH] + list(t.netsD) for v in m.state_dict().values()]
             runs.append({"losses": ls, "state": torch.cat(sd).cpu(),
@@ -143,8 +146,8 @@ def main():
         # the G/D alternation's collectives: each discriminator's bucket is all-reduced on that discriminator's own
         # stream (train.py step_gan), then the generators' bucket on the main one - four RCCL all-reduces per step
         tg = make_trainer(device=dev, discriminators=True)
-        errG, errsD = tg.step_gan(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev),
-                                  [h[lo:hi].to(dev) for h in hr])
+        errG, errsD = tg.step_gan(cap32[lo:hi].to(dev), lens32[lo:hi].tolist(), LR32[lo:hi].to(dev), LRb32[lo:hi].to(dev),
+                                  [h[lo:hi].to(dev) for h in hr32])
         torch.cuda.synchronize()
         res["gan_flat"] = tg.bucket.flat.cpu()
         res["gan_params_d"] = [torch.cat([p.detach().flatten() for p in b.params]).cpu() for b in tg.bucketsD]

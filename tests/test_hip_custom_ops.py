@@ -250,3 +250,41 @@ def test_only_the_tensor_wrappers_touch_the_c_abi():
             continue
         src = open(path).read()
         assert "_lib.lib()" not in src and "lib()." not in src, path
+
+
+def test_opcheck_round6_operators():
+    """The operators added in round 6: the weight-map heads (`axpy_map`), eval-mode BatchNorm + activation (`affine_act`), the GAN
+    losses' BCE terms (`weighted_bce`) and the kernels of CNN_ENCODER's frozen trunk (`gconv` ... `bilinear`): schema (declared
+    mutations are the only ones), fake kernels, and the autograd registration of the differentiable ones."""
+    T = torch.ops.tgsr
+    g = torch.Generator().manual_seed(1)
+    R = lambda *s: torch.randn(*s, generator=g).to(DEV)                 # noqa: E731
+    basic = ("test_schema", "test_faketensor")
+    full = basic + ("test_autograd_registration",)
+    chk = torch.library.opcheck
+    chk(T.axpy_map.default, (R(2, 3, 8, 12).requires_grad_(True), R(2, 3, 8, 12).requires_grad_(True), R(8, 12).requires_grad_(True)),
+        test_utils=full)
+    chk(T.axpy_map_bwd.default, (R(2, 3, 8, 12), R(2, 3, 8, 12), R(8, 12), True, True), test_utils=basic)
+    raw, sc, sh = R(2, 6, 4, 8), R(6), R(6)
+    chk(T.affine_act.default, (raw, sc, sh, 2), test_utils=basic)
+    chk(T.affine_act_bwd.default, (R(2, 6, 4, 8), T.affine_act(raw, sc, sh, 2), sc, 2), test_utils=basic)
+    a, b = R(11).requires_grad_(True), R(6).requires_grad_(True)
+    t, w = torch.rand(17, generator=g).to(DEV), torch.rand(17, generator=g).to(DEV)
+    chk(T.weighted_bce.default, (a, b, t, w), test_utils=full)
+    chk(T.weighted_bce.default, (a, None, t[:11].contiguous(), w[:11].contiguous()), test_utils=full)
+    chk(T.weighted_bce_bwd.default, (R(1).reshape(()), a.detach(), b.detach(), t, w), test_utils=basic)
+    wt = R(8, 5, 3, 3)
+    chk(T.gconv_pack.default, (wt, R(8), False), test_utils=basic)
+    chk(T.gconv_pack.default, (wt, None, True), test_utils=basic)
+    x, out = R(2, 5, 9, 9), torch.zeros(2, 10, 9, 9, device=DEV)
+    chk(T.gconv.default, (False, T.gconv_pack(wt, None, False), x, 0, 5, out, 1, 3, 3, 1, 1, 1, R(8), True, False, None, None), test_utils=basic)
+    chk(T.gconv.default, (True, T.gconv_pack(wt, None, True), out, 1, 8, torch.zeros(2, 5, 9, 9, device=DEV), 0, 3, 3, 1, 1, 1, None, False,
+                          True, None, R(2, 5, 9, 9)), test_utils=basic)
+    chk(T.maxpool3s2.default, (x, torch.zeros(2, 7, 4, 4, device=DEV), 2), test_utils=basic)
+    chk(T.maxpool3s2_bwd.default, (x, R(2, 7, 4, 4), 2, torch.zeros(2, 5, 9, 9, device=DEV), True, R(2, 5, 9, 9)), test_utils=basic)
+    chk(T.avgpool3.default, (x, torch.zeros(2, 5, 9, 9, device=DEV), False, None), test_utils=basic)
+    chk(T.plane_mean.default, (x,), test_utils=basic)
+    chk(T.plane_mean_bwd.default, (R(2, 5), 9, 9), test_utils=basic)
+    chk(T.relu_mask_.default, (R(2, 5, 9, 9), x, 1, 3), test_utils=basic)
+    chk(T.bilinear.default, (x, 13, 17), test_utils=basic)
+    chk(T.bilinear_bwd.default, (R(2, 5, 13, 17), 9, 9), test_utils=basic)

@@ -481,7 +481,7 @@ def test_gan_losses_vs_reference_run_fixture():
 def test_cnn_encoder_walks_a_real_inception_v3_at_batch_16(face_weights):
     """CNN_ENCODER.forward (util.py:308-368) for real, at configs[2]'s batch: bilinear resize to 299 x 299, the sixteen
     Inception-v3 blocks (tests/inception_v3_arch.py: the published topology with seeded random weights - third-party arithmetic,
-    parity UNPINNED; the blocks run on MIOpen as the torch modules they are), 17 x 17 x 768 region features, 8 x 8
+    parity UNPINNED; in eval mode the blocks run on the library's own kernels, tgsr_amd/inception.py), 17 x 17 x 768 region features, 8 x 8
     average pool, the two trainable heads on the HIP GEMM kernels.  Checked: state_dict keys like the reference's
     image_encoder files, shapes, the same module's walk on the CPU (oneDNN) + the oracle's head formulas, the DAMSM losses on
     those features, and one full-size G/D step with the ranking term through it (finite, gradient reaches both generators).
@@ -522,7 +522,7 @@ def test_cnn_encoder_walks_a_real_inception_v3_at_batch_16(face_weights):
         assert tuple(regions.shape) == (B, 256, 17, 17) and tuple(code.shape) == (B, 256) and tuple(fc.shape) == (B, 768, 17, 17)
         for got, ref in ((regions, regions_ref), (code, code_ref)):
             err = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
-            assert err < 2e-3, err                                            # MIOpen vs oneDNN through 48 convolutions
+            assert err < 2e-3, err                                            # the HIP walk vs oneDNN through 48 convolutions
         # the DAMSM losses on these features: HIP kernels vs the oracle on the CPU walk's features
         cap, lens, LR, LRb = O.synthetic_batch(B)
         sdE = split_sd(face_weights, "E.")

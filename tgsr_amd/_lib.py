@@ -103,6 +103,19 @@ SIGNATURES = {
                                         _i, _i, _i, _i, _vp, _vp]),
     "tgsr_multi_copy": (_i, [_i, _vp, _vp, _vp, _vp]),
     "tgsr_axpy_images": (_i, [_i, _vp, _vp, _vp, _vp, _f, _vp]),
+    "tgsr_gconv_set_form": (_i, [_i]),
+    "tgsr_gconv_nsplit": (_i, [_i, _i, _i]),
+    "tgsr_gconv_ws_elems": (_i64, [_i, _i, _i, _i, _i]),
+    "tgsr_gconv": (_i, [_i, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i64, _vp, _vp]),
+    "tgsr_gconv_pack": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tgsr_maxpool3s2_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "tgsr_maxpool3s2_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp, _vp]),
+    "tgsr_avgpool3": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp, _vp]),
+    "tgsr_plane_mean": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "tgsr_plane_mean_bwd": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "tgsr_relu_mask": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp]),
+    "tgsr_bilinear_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "tgsr_bilinear_bwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "tgsr_weighted_bce_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "tgsr_weighted_bce_bwd": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_axpy_map_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

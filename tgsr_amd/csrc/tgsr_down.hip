@@ -19,7 +19,9 @@
 
 namespace tgsr {
 
-enum { kFwd4 = 0, kFwd3 = 1, kDgrad4 = 2, kDgrad3 = 3, kWgrad4 = 4, kWgrad3 = 5 };
+enum { kFwd4 = 0, kFwd3 = 1, kDgrad4 = 2, kDgrad3 = 3, kWgrad4 = 4, kWgrad3 = 5,
+       // generic taps (CNN_ENCODER's frozen trunk, tgsr_igemm.hip): any KH x KW <= 32 taps, forward stride 1 | 2, data gradient stride 1
+       kFwdG = 6, kDgradG = 7 };
 
 struct IgArgs {
   const float* A;        // fwd: w [Cout][K]; dgrad4: packed [4][Cin][4 Cout]; dgrad3: w [Cout][Cin][3][3]; wgrad: dy
@@ -33,6 +35,13 @@ struct IgArgs {
   int64_t slab_stride;
   int act;               // forward, nsplit == 1 only: 1 = LeakyReLU(0.2) epilogue
   int64_t a_bytes, s_bytes;   // dconv_igemm6_kernel: sizes of A and S (buffer descriptors; < 4 GB, host-checked)
+  // kFwdG / kDgradG only
+  int gKH, gKW, gKK, gst, gpadh, gpadw;
+  unsigned gmKK, gmKW;        // q / KK = (q * gmKK) >> 16 for q < 64;  t / KW likewise
+  int64_t s_bstride, o_bstride;          // batch strides (elements) of S and of the output (channel slices of wider tensors)
+  const float* gbias;
+  const float* gmask;         // nullable, laid out like the output: the contribution is kept where gmask > 0
+  int grelu, gacc;
 };
 
 constexpr int kIgKC = 16, kIgP = 132;   // K-chunk; LDS pitch: (4 k + m) mod 64 is a bijection over a wave's writes
@@ -63,6 +72,18 @@ template <int MODE>
 __device__ __forceinline__ void ig_decode_p(const IgArgs& a, int p, int& off, int& iy0, int& ix0) {
   const int hw = a.PH * a.PW;
   const int b = p / hw, r = p - b * hw, py = r / a.PW, px = r - py * a.PW;
+  if (MODE == kFwdG) {                      // where tap (0, 0) of the window sits
+    iy0 = a.gst * py - a.gpadh;
+    ix0 = a.gst * px - a.gpadw;
+    off = (int)(b * a.s_bstride);
+    return;
+  }
+  if (MODE == kDgradG) {                    // tap (ky, kx) reads g at (iy0 - ky, ix0 - kx)
+    iy0 = py + a.gpadh;
+    ix0 = px + a.gpadw;
+    off = (int)(b * a.s_bstride);
+    return;
+  }
   constexpr int S = (MODE == kFwd4 || MODE == kWgrad4) ? 2 : 1;
   iy0 = S * py;
   ix0 = S * px;
@@ -392,10 +413,11 @@ __global__ __launch_bounds__(256) void ig6_pack_dgrad_kernel(const float* __rest
 template <int MODE, bool WIDE = false, bool APRE = false>
 __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
   constexpr bool WG = MODE == kWgrad4 || MODE == kWgrad3;
-  constexpr bool K3 = MODE == kFwd3 || MODE == kDgrad3;    // 3x3: k = (channel, tap) in 9s - a chunk of 16 straddles channels
+  constexpr bool KG = MODE == kFwdG || MODE == kDgradG;    // generic taps: k = (channel, tap) in KKs, KK a launch argument
+  constexpr bool K3 = MODE == kFwd3 || MODE == kDgrad3 || KG;    // 3x3: k = (channel, tap) in 9s - a chunk of 16 straddles channels
   constexpr int ST = (MODE == kFwd4 || MODE == kWgrad4) ? 2 : 1;       // stride of the gathered tensor's pixel grid
-  static_assert(!(WG && WIDE) && !(WG && APRE) && !(K3 && (WIDE || APRE)) && !(MODE == kWgrad3 && WIDE),
-                "the wide tile and the pre-split A serve the 4x4 convolution's pixel-column modes");
+  static_assert(!(WG && WIDE) && !(WG && APRE) && !(K3 && APRE) && !(K3 && !KG && WIDE) && !(MODE == kWgrad3 && WIDE),
+                "the wide tile and the pre-split A serve the 4x4 convolution's pixel-column modes (and the generic-tap ones)");
   constexpr int MB = WIDE ? 64 : 128, NB = WIDE ? 256 : 128;
   constexpr int APL = MB * 8, BPL = NB * 8;                // 32-bit words per piece of a tile
   constexpr int NBI = NB / 128;                            // B items per thread
@@ -455,7 +477,18 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bvo[t][e] = kOut;
     if (n < a.N) {
-      if (K3) {
+      if (KG) {
+        // bvo[t][0] = byte offset (mod 2^32: the anchor may lie outside the image) of the window's anchor in channel 0 of its
+        // sample; wsh[t] = which of the KK <= 32 taps fall inside the image
+        int poff, piy, pix_;
+        ig_decode_p<MODE>(a, n, poff, piy, pix_);
+        bvo[t][0] = (unsigned)(poff + piy * a.Ws + pix_) * 4u;
+        for (int tp = 0; tp < a.gKK; ++tp) {
+          const int ky = (int)(((unsigned)tp * a.gmKW) >> 16), kx = tp - ky * a.gKW;
+          const int iy = MODE == kFwdG ? piy + ky : piy - ky, ix = MODE == kFwdG ? pix_ + kx : pix_ - kx;
+          if ((unsigned)iy < (unsigned)a.Hs && (unsigned)ix < (unsigned)a.Ws) wsh[t] |= 1 << tp;
+        }
+      } else if (K3) {
         // bvo[t][0] = byte offset of the pixel in channel 0 of its sample; wsh[t] = which of the nine taps fall inside the image
         int poff, piy, pix_;
         ig_decode_p<MODE>(a, n, poff, piy, pix_);
@@ -538,7 +571,27 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
       }
     }
     // B
-    if constexpr (K3) {
+    if constexpr (KG) {
+      // as the 3x3 path below with KK = KH KW taps per channel (launch arguments; the small divisions by multiply-shift)
+      const int KK = a.gKK;
+      const int c0 = k0 / KK, r0 = k0 - KK * c0;
+      const int64_t soff = (int64_t)c0 * HsWs * 4;
+      const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.S)) + (live ? soff : 0), 0, live ? (int)(unsigned)(a.s_bytes - soff) : 0, 0x00020000);
+#pragma unroll
+      for (int t = 0; t < NBI; ++t) {
+        const int kh = __builtin_amdgcn_readfirstlane((tid + 256 * t) / NB);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int q = r0 + 8 * kh + e;
+          const int cl = (int)(((unsigned)q * a.gmKK) >> 16), tp = q - KK * cl;
+          const int ky = (int)(((unsigned)tp * a.gmKW) >> 16), kx = tp - ky * a.gKW;
+          const int tapo = ky * a.Ws + kx;
+          const int off = (cl * HsWs + (MODE == kFwdG ? tapo : -tapo)) * 4;
+          qb[t][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sr, ((wsh[t] >> tp) & 1) ? bvo[t][0] + (unsigned)off : kOut, 0, 0));
+        }
+      }
+    } else if constexpr (K3) {
       // k = 9 channel + tap: the chunk starts in channel c0 at tap r0 (scalars); element j = 8 (k half) + e of it is tap
       // (r0 + j) % 9 of channel c0 + (r0 + j) / 9 - wave-uniform, since the k half of an item is: scalar arithmetic, and per
       // thread one mask test, one add and one select per load
@@ -700,6 +753,10 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
         mstride = hw;
       }
     }
+    if (KG && a.nsplit <= 1) {               // straight into the output's channel slice: + shift, ReLU, += as asked
+      const int b = n / hw;
+      obase = (int64_t)b * a.o_bstride + (n - b * hw);
+    }
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -707,7 +764,14 @@ __global__ __launch_bounds__(256, 2) void dconv_igemm6_kernel(IgArgs a) {
         const int m = m0 + wm * 64 + mb * 32 + acc_row(i, hh);
         if (m >= a.M) continue;
         float v = acc[mb][nb][i];
-        if (a.act) v = v > 0.f ? v : 0.2f * v;
+        if (KG) {
+          if (a.nsplit <= 1) {
+            if (a.gbias) v += a.gbias[m];
+            if (a.grelu) v = v > 0.f ? v : 0.f;
+            if (a.gmask && !(a.gmask[obase + m * mstride] > 0.f)) v = 0.f;
+            if (a.gacc) v += ob[obase + m * mstride];
+          }
+        } else if (a.act) v = v > 0.f ? v : 0.2f * v;
         ob[obase + m * mstride] = v;
       }
   }
@@ -1014,6 +1078,43 @@ static int dconv_wgrad(int kind, const float* dy, const float* x, int B, int Cin
                            : ig_launch<kWgrad3>(a, sh, ws, dw, s, "dconv_igemm_kernel<wgrad3>", split);
   if (rc) return rc;
   return ig_finish(a, ig_used_splits(sh), 0, ws, dw, sh.out_elems, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Generic-tap convolutions (CNN_ENCODER's frozen trunk: tgsr_igemm.hip owns the entry point, the fp32-MFMA fallback and the slab
+// finish) on dconv_igemm6_kernel: forward (stride 1 | 2) and stride-1 data gradient of any KH x KW <= 32 taps with K % 16 == 0.
+// Returns TGSR_EUNSUPPORTED for shapes this form does not take - the caller then uses its own kernel.
+int ig6_gconv_launch(int dgrad, const float* A, const float* S, int64_t s_bstride, int64_t s_bytes, int B, int Hs, int Ws, int M, int K,
+                     int PH, int PW, int KH, int KW, int stride, int padh, int padw, const float* bias, int relu, int accumulate,
+                     const float* mask, float* out, int64_t o_bstride, float* slabs, int nsplit, int chunks_per_split, hipStream_t s) {
+  const int KK = KH * KW;
+  if (!g_ig_split || KK > 25 || K % kIgKC != 0 || (dgrad && stride != 1) || (stride != 1 && stride != 2)) return TGSR_EUNSUPPORTED;
+  const int64_t a_bytes = (int64_t)M * K * 4;
+  if ((reinterpret_cast<uintptr_t>(A) & 15) || s_bytes >= (1ll << 31) || a_bytes >= (1ll << 32)) return TGSR_EUNSUPPORTED;
+  const int64_t N = (int64_t)B * PH * PW;
+  if (N >= (1ll << 31)) return TGSR_EUNSUPPORTED;
+  IgArgs a = {};
+  a.A = A; a.S = S; a.out = nsplit > 1 ? slabs : out;
+  a.M = M; a.N = (int)N; a.K = K; a.C = K / KK; a.Hs = Hs; a.Ws = Ws; a.PH = PH; a.PW = PW; a.OH = PH; a.OW = PW;
+  a.nsplit = nsplit; a.chunks_per_split = chunks_per_split;
+  a.slab_stride = nsplit > 1 ? (int64_t)B * M * PH * PW : 0;
+  a.act = 0;
+  a.a_bytes = a_bytes; a.s_bytes = s_bytes;
+  a.gKH = KH; a.gKW = KW; a.gKK = KK; a.gst = stride; a.gpadh = padh; a.gpadw = padw;
+  a.gmKK = (unsigned)((65536 + KK - 1) / KK); a.gmKW = (unsigned)((65536 + KW - 1) / KW);
+  a.s_bstride = s_bstride; a.o_bstride = o_bstride;
+  a.gbias = bias; a.gmask = mask; a.grelu = relu; a.gacc = accumulate;
+  const bool wide = M <= 64;
+  const dim3 grid(wide ? (unsigned)((N + 255) / 256) : (unsigned)((N + 127) / 128), wide ? (unsigned)((M + 63) / 64) : (unsigned)((M + 127) / 128),
+                  (unsigned)nsplit);
+  if (dgrad) {
+    if (wide) hipLaunchKernelGGL((dconv_igemm6_kernel<kDgradG, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dconv_igemm6_kernel<kDgradG, false, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (wide) hipLaunchKernelGGL((dconv_igemm6_kernel<kFwdG, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dconv_igemm6_kernel<kFwdG, false, false>), grid, dim3(256), 0, s, a);
+  }
+  return note_launch(hipGetLastError(), "dconv_igemm6_kernel<generic taps>");
 }
 
 }  // namespace tgsr

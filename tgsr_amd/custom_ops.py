@@ -494,6 +494,29 @@ text_tail_lp = _define("text_tail_lp(Tensor words, Tensor[] w_ctxs, Tensor sent_
                         words.new_empty(len(ws) * words.shape[0] * 4096 + 4 * words.shape[0], dtype=torch.uint8)))
 axpy_images = _define("axpy_images(Tensor[] ts, Tensor[] ss, float alpha) -> Tensor[]",
                       lambda ts, ss, alpha: ops.axpy_images(list(ts), list(ss), alpha), lambda ts, ss, alpha: [torch.empty_like(t) for t in ts])
+# ------------------------------------------------------------------------------------------------ CNN_ENCODER's frozen trunk
+gconv_pack = _define("gconv_pack(Tensor w, Tensor? scale, bool dgrad) -> Tensor", lambda w, sc, dg: ops.gconv_pack(w, sc, dg),
+                     lambda w, sc, dg: w.new_empty((w.shape[1], w.shape[0] * w.shape[2] * w.shape[3]) if dg else
+                                                   (w.shape[0], w.shape[1] * w.shape[2] * w.shape[3])))
+gconv = _define("gconv(bool dgrad, Tensor A, Tensor S, int s_coff, int s_ch, Tensor(a!) out, int o_coff, int kh, int kw, int stride, "
+                "int padh, int padw, Tensor? bias, bool relu, bool accumulate, Tensor(b!)? ws, Tensor? mask) -> ()",
+                lambda dg, A, S, sc, sch, out, oc, kh, kw, st, ph, pw, bias, relu, acc, ws, mask:
+                ops.gconv(dg, A, S, sc, sch, out, oc, kh, kw, st, ph, pw, bias, relu, acc, ws, mask), lambda *a: None)
+maxpool3s2 = _define("maxpool3s2(Tensor x, Tensor(a!) out, int o_coff) -> ()", lambda x, out, oc: ops.maxpool3s2(x, out, oc),
+                     lambda *a: None)
+maxpool3s2_bwd = _define("maxpool3s2_bwd(Tensor x, Tensor dy, int dy_coff, Tensor(a!) dx, bool accumulate, Tensor? mask) -> ()",
+                         lambda x, dy, dc, dx, acc, mask: ops.maxpool3s2_bwd(x, dy, dc, dx, acc, mask), lambda *a: None)
+avgpool3 = _define("avgpool3(Tensor x, Tensor(a!) out, bool accumulate, Tensor? mask) -> ()",
+                   lambda x, out, acc, mask: ops.avgpool3(x, out, acc, mask), lambda *a: None)
+plane_mean = _define("plane_mean(Tensor x) -> Tensor", lambda x: ops.plane_mean(x), lambda x: x.new_empty(x.shape[0], x.shape[1]))
+plane_mean_bwd = _define("plane_mean_bwd(Tensor dy, int H, int W) -> Tensor", lambda dy, H, W: ops.plane_mean_bwd(dy, H, W),
+                         lambda dy, H, W: dy.new_empty(dy.shape[0], dy.shape[1], H, W))
+relu_mask_ = _define("relu_mask_(Tensor(a!) dy, Tensor y, int coff, int ch) -> ()", lambda dy, y, c, ch: ops.relu_mask_(dy, y, c, ch),
+                     lambda *a: None)
+bilinear = _define("bilinear(Tensor x, int OH, int OW) -> Tensor", lambda x, OH, OW: ops.bilinear(x, OH, OW),
+                   lambda x, OH, OW: x.new_empty(x.shape[0], x.shape[1], OH, OW))
+bilinear_bwd = _define("bilinear_bwd(Tensor dy, int H, int W) -> Tensor", lambda dy, H, W: ops.bilinear_bwd(dy, H, W),
+                       lambda dy, H, W: dy.new_empty(dy.shape[0], dy.shape[1], H, W))
 weighted_bce = _define("weighted_bce(Tensor a, Tensor? b, Tensor target, Tensor weight) -> Tensor",
                        lambda a, b, t, w: ops.weighted_bce(a, b, t, w), lambda a, b, t, w: a.new_empty(()))
 

@@ -1,0 +1,308 @@
+"""CNN_ENCODER's frozen Inception-v3 trunk on the library's own kernels (csrc/tgsr_igemm.hip).
+
+The reference copies sixteen blocks out of `torchvision.models.inception_v3` (util.py:281-298), freezes every parameter
+(util.py:274-275) and walks them in `CNN_ENCODER.forward` (util.py:308-362): bilinear resize to 299 x 299, five stem convolutions
+with two max pools, Mixed_5b..6e (-> the 17 x 17 x 768 region features), Mixed_7a..7c, the 8 x 8 average pool.  `generator_loss`
+(losses.py:375-389) runs it on the finest fake image and needs the gradient back to that image - never a weight gradient.
+
+This module executes that walk for ANY object carrying torchvision's attribute names (conv + bn pairs `m.conv`, `m.bn`; block
+branches `branch1x1`, `branch5x5_1`, ... - the names the reference's checkpoints are keyed by): the layers are read off the modules,
+eval-mode BatchNorm is folded into the filter once per weight version (scale) and into the convolution's epilogue (shift + ReLU), every
+branch writes straight into its channel slice of the block's concatenation, and the backward is the recorded tape run in reverse on
+the same kernels (ReLU mask in place, data gradients accumulated into the block input in a fixed order).  The trunk's ARITHMETIC is
+third-party (torchvision's weights are absent here): parity is pinned against the same modules run by torch, not against the
+reference (unpinned).
+"""
+import torch
+
+from . import custom_ops as C
+from ._lib import TgsrError
+
+RESIZE = 299
+
+
+class _Layer:
+    """conv (bias-free) + BatchNorm2d(eval) + ReLU of one `m.conv` / `m.bn` pair, packed for tgsr::gconv."""
+
+    def __init__(self, mod):
+        conv, bn = mod.conv, mod.bn
+        if conv.bias is not None or conv.groups != 1 or tuple(conv.dilation) != (1, 1) or conv.stride[0] != conv.stride[1]:
+            raise TgsrError("the trunk kernels take bias-free, dense, undilated convolutions with one stride")
+        self.conv, self.bn = conv, bn
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.kh, self.kw = conv.kernel_size
+        self.stride = conv.stride[0]
+        self.ph, self.pw = conv.padding
+        self.key = None
+        self.refresh()
+
+    def _key(self):
+        bn = self.bn
+        return tuple((t.data_ptr(), t._version) for t in (self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+
+    def refresh(self):
+        k = self._key()
+        if k == self.key:
+            return
+        from . import ops
+        bn = self.bn
+        scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+        self.wf = C.gconv_pack(self.conv.weight.detach(), scale, False)
+        self.wd = C.gconv_pack(self.conv.weight.detach(), scale, True)
+        self.key = k
+
+    def out_hw(self, H, W):
+        return (H + 2 * self.ph - self.kh) // self.stride + 1, (W + 2 * self.pw - self.kw) // self.stride + 1
+
+
+def _pool_hw(H, W):
+    return (H - 3) // 2 + 1, (W - 3) // 2 + 1
+
+
+class InceptionTrunk:
+    """The walk of util.py:308-362 (up to, not including, the two heads) over `enc`'s sixteen blocks.  `forward(x)` returns
+    (features [B,768,17,17], pooled [B,2048]) and keeps the tape; `backward(d_features, d_pooled)` returns d(loss)/dx."""
+
+    STEM = ("Conv2d_1a_3x3", "Conv2d_2a_3x3", "Conv2d_2b_3x3", "Conv2d_3b_1x1", "Conv2d_4a_3x3")
+    MIXED = ("Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e", "Mixed_7a", "Mixed_7b",
+             "Mixed_7c")
+
+    def __init__(self, enc):
+        self.enc = enc
+        self.layers = {}
+        for name in self.STEM + self.MIXED:
+            blk = getattr(enc, name)
+            if hasattr(blk, "conv") and hasattr(blk, "bn"):
+                self.layers[name] = _Layer(blk)
+            else:
+                for bname, sub in blk.named_children():
+                    if hasattr(sub, "conv") and hasattr(sub, "bn"):
+                        self.layers[name + "." + bname] = _Layer(sub)
+        self.tape = None
+
+    def refresh(self):
+        for L in self.layers.values():
+            L.refresh()
+
+    # ------------------------------------------------------------------ forward primitives (each records its backward)
+    def _new(self, B, Cc, H, W, dev):
+        t = torch.empty(B, Cc, H, W, dtype=torch.float32, device=dev)
+        self.tensors.append(t)
+        return len(self.tensors) - 1
+
+    def _ws(self, need, dev):
+        if need > self.ws.numel():
+            self.ws = torch.empty(need, dtype=torch.float32, device=dev)
+        return self.ws if need else None
+
+    def _conv(self, name, src, dst=None, coff=0):
+        """ConvBnRelu `name` on tensor id `src`; into channels [coff, coff + cout) of tensor id `dst` (a fresh tensor when None)."""
+        L = self.layers[name]
+        x = self.tensors[src]
+        B, Cs, H, W = x.shape
+        if Cs != L.cin:
+            raise TgsrError("%s expects %d channels, got %d" % (name, L.cin, Cs))
+        OH, OW = L.out_hw(H, W)
+        if dst is None:
+            dst = self._new(B, L.cout, OH, OW, x.device)
+        y = self.tensors[dst]
+        ws = self._ws(ops_ws(B, L.cout, OH, OW, L.cin * L.kh * L.kw), x.device)
+        C.gconv(False, L.wf, x, 0, L.cin, y, coff, L.kh, L.kw, L.stride, L.ph, L.pw, L.shift, True, False, ws, None)
+        self.tape.append(("conv", L, src, dst, coff))
+        return dst
+
+    def _maxpool(self, src, dst=None, coff=0):
+        x = self.tensors[src]
+        B, Cc, H, W = x.shape
+        OH, OW = _pool_hw(H, W)
+        if dst is None:
+            dst = self._new(B, Cc, OH, OW, x.device)
+        C.maxpool3s2(x, self.tensors[dst], coff)
+        self.tape.append(("maxpool", None, src, dst, coff))
+        return dst
+
+    def _avgpool(self, src):
+        x = self.tensors[src]
+        dst = self._new(*x.shape, x.device)
+        C.avgpool3(x, self.tensors[dst], False, None)
+        self.tape.append(("avgpool", None, src, dst, 0))
+        return dst
+
+    def _block(self, name, src):
+        """One Mixed_* block by torchvision's branch names; returns the id of its concatenated output."""
+        blk = getattr(self.enc, name)
+        x = self.tensors[src]
+        B, _, H, W = x.shape
+        dev = x.device
+        has = lambda b: hasattr(blk, b)                                                   # noqa: E731
+        co = lambda b: self.layers[name + "." + b].cout                                   # noqa: E731
+        n = lambda b: name + "." + b                                                      # noqa: E731
+        if has("branch5x5_1"):                              # InceptionA: 1x1 | 1x1-5x5 | 1x1-3x3-3x3 | avg pool-1x1
+            widths = [co("branch1x1"), co("branch5x5_2"), co("branch3x3dbl_3"), co("branch_pool")]
+            out = self._new(B, sum(widths), H, W, dev)
+            self._conv(n("branch1x1"), src, out, 0)
+            self._conv(n("branch5x5_2"), self._conv(n("branch5x5_1"), src), out, widths[0])
+            t = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src))
+            self._conv(n("branch3x3dbl_3"), t, out, widths[0] + widths[1])
+            self._conv(n("branch_pool"), self._avgpool(src), out, widths[0] + widths[1] + widths[2])
+            return out
+        if has("branch7x7x3_1"):                            # InceptionD: 1x1-3x3 s2 | 1x1-1x7-7x1-3x3 s2 | max pool
+            OH, OW = _pool_hw(H, W)
+            widths = [co("branch3x3_2"), co("branch7x7x3_4"), x.shape[1]]
+            out = self._new(B, sum(widths), OH, OW, dev)
+            self._conv(n("branch3x3_2"), self._conv(n("branch3x3_1"), src), out, 0)
+            t = self._conv(n("branch7x7x3_3"), self._conv(n("branch7x7x3_2"), self._conv(n("branch7x7x3_1"), src)))
+            self._conv(n("branch7x7x3_4"), t, out, widths[0])
+            self._maxpool(src, out, widths[0] + widths[1])
+            return out
+        if has("branch7x7_1"):                              # InceptionC: 1x1 | 1x1-1x7-7x1 | 1x1-7x1-1x7-7x1-1x7 | avg pool-1x1
+            widths = [co("branch1x1"), co("branch7x7_3"), co("branch7x7dbl_5"), co("branch_pool")]
+            out = self._new(B, sum(widths), H, W, dev)
+            self._conv(n("branch1x1"), src, out, 0)
+            self._conv(n("branch7x7_3"), self._conv(n("branch7x7_2"), self._conv(n("branch7x7_1"), src)), out, widths[0])
+            t = self._conv(n("branch7x7dbl_1"), src)
+            for b in ("branch7x7dbl_2", "branch7x7dbl_3", "branch7x7dbl_4"):
+                t = self._conv(n(b), t)
+            self._conv(n("branch7x7dbl_5"), t, out, widths[0] + widths[1])
+            self._conv(n("branch_pool"), self._avgpool(src), out, widths[0] + widths[1] + widths[2])
+            return out
+        if has("branch3x3_2a"):                             # InceptionE: 1x1 | 1x1-(1x3, 3x1) | 1x1-3x3-(1x3, 3x1) | avg pool-1x1
+            widths = [co("branch1x1"), co("branch3x3_2a"), co("branch3x3_2b"), co("branch3x3dbl_3a"), co("branch3x3dbl_3b"),
+                      co("branch_pool")]
+            out = self._new(B, sum(widths), H, W, dev)
+            offs = [sum(widths[:i]) for i in range(6)]
+            self._conv(n("branch1x1"), src, out, 0)
+            a = self._conv(n("branch3x3_1"), src)
+            self._conv(n("branch3x3_2a"), a, out, offs[1])
+            self._conv(n("branch3x3_2b"), a, out, offs[2])
+            b_ = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src))
+            self._conv(n("branch3x3dbl_3a"), b_, out, offs[3])
+            self._conv(n("branch3x3dbl_3b"), b_, out, offs[4])
+            self._conv(n("branch_pool"), self._avgpool(src), out, offs[5])
+            return out
+        if has("branch3x3dbl_3") and has("branch3x3"):      # InceptionB: 3x3 s2 | 1x1-3x3-3x3 s2 | max pool
+            OH, OW = _pool_hw(H, W)
+            widths = [co("branch3x3"), co("branch3x3dbl_3"), x.shape[1]]
+            out = self._new(B, sum(widths), OH, OW, dev)
+            self._conv(n("branch3x3"), src, out, 0)
+            t = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src))
+            self._conv(n("branch3x3dbl_3"), t, out, widths[0])
+            self._maxpool(src, out, widths[0] + widths[1])
+            return out
+        raise TgsrError("%s: not one of torchvision's Inception-v3 block layouts" % name)
+
+    # ------------------------------------------------------------------ the walk
+    @torch.no_grad()
+    def forward(self, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3):
+            raise TgsrError("InceptionTrunk: a HIP fp32 image batch [B, 3, H, W] expected, got %s %s" % (x.dtype, tuple(x.shape)))
+        self.refresh()
+        self.tensors, self.tape = [], []
+        self.ws = torch.empty(0, dtype=torch.float32, device=x.device)
+        self.in_hw = (x.shape[2], x.shape[3])
+        self.tensors.append(C.bilinear(x.contiguous(), RESIZE, RESIZE))                       # nn.Upsample(size=(299, 299), 'bilinear')
+        t = 0
+        self.marks = {"resize": 0}                                                             # name -> tensor id (diagnostics)
+        for name in self.STEM[:3]:
+            t = self.marks[name] = self._conv(name, t)
+        t = self.marks["pool1"] = self._maxpool(t)
+        for name in self.STEM[3:]:
+            t = self.marks[name] = self._conv(name, t)
+        t = self.marks["pool2"] = self._maxpool(t)
+        for name in self.MIXED[:8]:
+            t = self.marks[name] = self._block(name, t)
+        self.feat_id = t                                                                       # 17 x 17 x 768 (after Mixed_6e)
+        for name in self.MIXED[8:]:
+            t = self.marks[name] = self._block(name, t)
+        self.last_id = t
+        return self.tensors[self.feat_id], C.plane_mean(self.tensors[t])                      # F.avg_pool2d(x, 8) on the 8 x 8 map
+
+    @torch.no_grad()
+    def backward(self, d_features, d_pooled):
+        """The tape in reverse.  d_features / d_pooled: gradients of the two outputs (None = zero).  Returns d(loss)/d(image)."""
+        if self.tape is None:
+            raise TgsrError("InceptionTrunk.backward without a forward")
+        T = self.tensors
+        grads = [None] * len(T)
+        self.snaps = {}
+        last = T[self.last_id]
+        # Every tensor but the resized image is the output of ReLU'd convolutions (or a pool of such): the factor (y > 0) of its
+        # gradient distributes over the sum of its consumers' contributions, so each consumer applies it to its own contribution in
+        # its epilogue (`mask`), and the two gradients that arrive from outside are masked once here.  (A max / average pool's output is
+        # zero only where everything it read is zero - positions whose gradient the producer's mask drops anyway.)
+        if d_pooled is not None:
+            grads[self.last_id] = C.plane_mean_bwd(d_pooled.contiguous(), last.shape[2], last.shape[3])
+            C.relu_mask_(grads[self.last_id], last, 0, last.shape[1])
+        if d_features is not None:
+            grads[self.feat_id] = d_features.contiguous().clone()
+            C.relu_mask_(grads[self.feat_id], T[self.feat_id], 0, T[self.feat_id].shape[1])
+
+        def target(i):
+            """(gradient buffer of tensor i, whether it already holds a contribution, its ReLU mask)"""
+            m = T[i] if i != 0 else None
+            if grads[i] is None:
+                grads[i] = torch.empty_like(T[i])
+                return grads[i], False, m
+            return grads[i], True, m
+        for kind, L, src, dst, coff in reversed(self.tape):
+            g = grads[dst]
+            if g is None:                       # nothing downstream of this tensor reached the loss
+                continue
+            if self.keep_grads and dst not in self.snaps:
+                self.snaps[dst] = g.clone()
+            if kind == "conv":
+                dx, acc, m = target(src)
+                ws = self._ws(ops_ws(dx.shape[0], L.cin, dx.shape[2], dx.shape[3], L.cout * L.kh * L.kw), dx.device)
+                C.gconv(True, L.wd, g, coff, L.cout, dx, 0, L.kh, L.kw, L.stride, L.ph, L.pw, None, False, acc, ws, m)
+            elif kind == "maxpool":
+                dx, acc, m = target(src)
+                C.maxpool3s2_bwd(T[src], g, coff, dx, acc, m)
+            else:                               # avgpool3: symmetric
+                dx, acc, m = target(src)
+                C.avgpool3(g, dx, acc, m)
+        d299 = grads[0]
+        if self.keep_grads:
+            self.snaps[0] = d299
+        if d299 is None:
+            return None
+        return C.bilinear_bwd(d299, self.in_hw[0], self.in_hw[1])
+
+    keep_grads = False          # diagnostics (tools/debug_trunk.py): keep every tensor's gradient of the last backward
+
+    def take_state(self):
+        """Detach the tape of the last forward (tensors, ops, bookkeeping) so that another forward can run before its backward."""
+        st = (self.tensors, self.tape, self.feat_id, self.last_id, self.in_hw)
+        self.tensors = self.tape = None
+        return st
+
+    def put_state(self, st):
+        self.tensors, self.tape, self.feat_id, self.last_id, self.in_hw = st
+
+
+def ops_ws(B, M, PH, PW, K):
+    from . import ops
+    return ops.gconv_ws_elems(B, M, PH, PW, K)
+
+
+class TrunkFn(torch.autograd.Function):
+    """images -> (features, pooled) through InceptionTrunk with its tape-driven backward (gradient to the images only: the trunk's
+    parameters are frozen, util.py:274-275)."""
+
+    @staticmethod
+    def forward(ctx, x, runner):
+        feats, pooled = runner.forward(x)
+        st = runner.take_state()
+        ctx.runner = runner
+        ctx.state = st if ctx.needs_input_grad[0] else None
+        return feats, pooled
+
+    @staticmethod
+    def backward(ctx, d_feats, d_pooled):
+        if ctx.state is None:
+            return None, None
+        ctx.runner.put_state(ctx.state)
+        ctx.state = None
+        try:
+            return ctx.runner.backward(d_feats, d_pooled), None
+        finally:
+            ctx.runner.take_state()

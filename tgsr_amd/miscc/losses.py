@@ -253,6 +253,12 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
                     adv = adv + _bce(lu, real_labels)
                 adv = g * adv
         advs.append(adv)
+    # the ranking term's image encoder (the frozen trunk: ~190 launches forward) is issued BEFORE the calling stream joins the
+    # discriminators' streams: it reads the last fake image only, so it runs beside their forward passes (and, through autograd's
+    # stream rule, its backward beside theirs)
+    enc_out = None
+    if image_encoder is not None and len(netsD) > 0:
+        enc_out = image_encoder(fake_imgs[len(netsD) - 1])
     for k, (netD, img) in enumerate(zip(netsD, fake_imgs)):
         adv = advs[k]
         if streams:
@@ -261,7 +267,7 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
         total = total + adv
         parts.append(("g_loss%d: %%.5f " % k, adv.detach()))
         if k == len(netsD) - 1 and image_encoder is not None:
-            regions, code = image_encoder(img)
+            regions, code = enc_out
             if gather_negatives:        # (not a reference argument) data parallel: the ranking term of the global batch
                 w0, w1, s0, s1, scale, _ = damsm_terms(regions, code, words_embs, sent_emb, cap_lens, class_ids, gather=True)
             else:

@@ -1357,6 +1357,149 @@ def affine_act_bwd(dy: torch.Tensor, out: Optional[torch.Tensor], scale: torch.T
     return draw
 
 
+# ----------------------------------------------------------------------------------------- CNN_ENCODER's frozen trunk (tgsr_igemm.hip)
+def _slice_ptr(t: torch.Tensor, coff: int):
+    """Pointer to channel `coff` of a dense NCHW tensor and its batch stride in elements."""
+    if t.dim() != 4 or not t.is_contiguous() or t.dtype != torch.float32:
+        raise TgsrError("dense fp32 NCHW tensor expected, got %s %s" % (t.dtype, tuple(t.shape)))
+    return t.data_ptr() + 4 * coff * t.shape[2] * t.shape[3], t.shape[1] * t.shape[2] * t.shape[3]
+
+
+def gconv_pack(w: torch.Tensor, scale: Optional[torch.Tensor], dgrad: bool) -> torch.Tensor:
+    """The filter [Cout, Cin, KH, KW] times the folded BatchNorm scale, as the A operand of gconv: forward [Cout, Cin KH KW] or data
+    gradient [Cin, Cout KH KW]."""
+    _need_hip(w, scale)
+    w = _f32(w.detach(), "w").contiguous()
+    Cout, Cin, KH, KW = w.shape
+    out = torch.empty((Cin, Cout * KH * KW) if dgrad else (Cout, Cin * KH * KW), dtype=torch.float32, device=w.device)
+    check(_lib.lib().tgsr_gconv_pack(_p(w), _p(scale), _p(out), Cout, Cin, KH * KW, 1 if dgrad else 0, _stream()), "tgsr_gconv_pack")
+    return out
+
+
+def gconv_set_form(split: bool) -> bool:
+    """The arithmetic form of gconv: True (default) = three-piece bf16 operands on the bf16 matrix pipe where the shape qualifies,
+    False = fp32 MFMA everywhere.  Returns the previous setting."""
+    return bool(_lib.lib().tgsr_gconv_set_form(1 if split else 0))
+
+
+def gconv_ws_elems(B: int, M: int, PH: int, PW: int, K: int) -> int:
+    return int(_lib.lib().tgsr_gconv_ws_elems(B, M, PH, PW, K))
+
+
+def gconv(dgrad: bool, A: torch.Tensor, S: torch.Tensor, s_coff: int, s_ch: int, out: torch.Tensor, o_coff: int, kh: int, kw: int,
+          stride: int, padh: int, padw: int, bias: Optional[torch.Tensor], relu: bool, accumulate: bool, ws: Optional[torch.Tensor],
+          mask: Optional[torch.Tensor] = None):
+    """Convolution (dgrad False) or its data gradient (True) as one implicit GEMM: reads channels [s_coff, s_coff + s_ch) of S,
+    writes channels [o_coff, o_coff + A.shape[0]) of out (+= when accumulate).  mask (shaped like out): the contribution is kept
+    where mask > 0 (the ReLU of the tensor whose gradient `out` is)."""
+    _need_hip(A, S, out, bias, ws, mask)
+    if mask is not None and (mask.shape != out.shape or not mask.is_contiguous() or mask.dtype != torch.float32):
+        raise TgsrError("gconv: the mask must be a dense fp32 tensor shaped like the output")
+    M, K = A.shape
+    B, Hs, Ws = S.shape[0], S.shape[2], S.shape[3]
+    PH, PW = out.shape[2], out.shape[3]
+    if K != s_ch * kh * kw or s_coff + s_ch > S.shape[1] or o_coff + M > out.shape[1] or out.shape[0] != B:
+        raise TgsrError("gconv: A %s against %d channels of %s -> channels %d.. of %s" % (tuple(A.shape), s_ch, tuple(S.shape), o_coff,
+                                                                                          tuple(out.shape)))
+    if dgrad:
+        ok = Hs == (PH + 2 * padh - kh) // stride + 1 and Ws == (PW + 2 * padw - kw) // stride + 1
+    else:
+        ok = PH == (Hs + 2 * padh - kh) // stride + 1 and PW == (Ws + 2 * padw - kw) // stride + 1
+    if not ok:
+        raise TgsrError("gconv: %dx%d / stride %d / pad (%d, %d) does not map %s to %s" % (kh, kw, stride, padh, padw, tuple(S.shape),
+                                                                                          tuple(out.shape)))
+    need = gconv_ws_elems(B, M, PH, PW, K)
+    if need and (ws is None or ws.numel() < need):
+        raise TgsrError("gconv: %d floats of workspace needed" % need)
+    sp, sbs = _slice_ptr(S, s_coff)
+    op, obs = _slice_ptr(out, o_coff)
+    mp = None if mask is None else _slice_ptr(mask, o_coff)[0]
+    check(_lib.lib().tgsr_gconv(1 if dgrad else 0, _p(A.contiguous()), sp, sbs, B, Hs, Ws, M, K, PH, PW, kh, kw, stride, padh, padw,
+                                _p(bias), 1 if relu else 0, 1 if accumulate else 0, mp, op, obs, _p(ws), _stream()), "tgsr_gconv")
+
+
+def maxpool3s2(x: torch.Tensor, out: torch.Tensor, o_coff: int):
+    _need_hip(x, out)
+    B, Cc, H, W = x.shape
+    xp, xbs = _slice_ptr(x, 0)
+    op, obs = _slice_ptr(out, o_coff)
+    if out.shape[2] != (H - 3) // 2 + 1 or out.shape[3] != (W - 3) // 2 + 1 or o_coff + Cc > out.shape[1]:
+        raise TgsrError("maxpool3s2: %s -> %s" % (tuple(x.shape), tuple(out.shape)))
+    check(_lib.lib().tgsr_maxpool3s2_fwd(xp, xbs, B, Cc, H, W, op, obs, _stream()), "tgsr_maxpool3s2_fwd")
+
+
+def maxpool3s2_bwd(x: torch.Tensor, dy: torch.Tensor, dy_coff: int, dx: torch.Tensor, accumulate: bool, mask: Optional[torch.Tensor] = None):
+    _need_hip(x, dy, dx, mask)
+    if mask is not None and (mask.shape != dx.shape or not mask.is_contiguous()):
+        raise TgsrError("maxpool3s2_bwd: the mask must be dense and shaped like dx")
+    B, Cc, H, W = x.shape
+    xp, xbs = _slice_ptr(x, 0)
+    gp, gbs = _slice_ptr(dy, dy_coff)
+    dp, dbs = _slice_ptr(dx, 0)
+    if dx.shape != x.shape or dy_coff + Cc > dy.shape[1]:
+        raise TgsrError("maxpool3s2_bwd: shapes")
+    check(_lib.lib().tgsr_maxpool3s2_bwd(xp, xbs, gp, gbs, B, Cc, H, W, dp, dbs, 1 if accumulate else 0, _p(mask), _stream()),
+          "tgsr_maxpool3s2_bwd")
+
+
+def avgpool3(x: torch.Tensor, out: torch.Tensor, accumulate: bool, mask: Optional[torch.Tensor] = None):
+    _need_hip(x, out, mask)
+    if mask is not None and (mask.shape != out.shape or not mask.is_contiguous()):
+        raise TgsrError("avgpool3: the mask must be dense and shaped like the output")
+    if x.shape != out.shape:
+        raise TgsrError("avgpool3: %s -> %s" % (tuple(x.shape), tuple(out.shape)))
+    B, Cc, H, W = x.shape
+    xp, xbs = _slice_ptr(x, 0)
+    op, obs = _slice_ptr(out, 0)
+    check(_lib.lib().tgsr_avgpool3(xp, xbs, B, Cc, H, W, op, obs, 1 if accumulate else 0, _p(mask), _stream()), "tgsr_avgpool3")
+
+
+def plane_mean(x: torch.Tensor) -> torch.Tensor:
+    _need_hip(x)
+    x = _f32(x, "x").contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+    check(_lib.lib().tgsr_plane_mean(_p(x), _p(out), B * Cc, H * W, _stream()), "tgsr_plane_mean")
+    return out
+
+
+def plane_mean_bwd(dy: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    _need_hip(dy)
+    dy = _f32(dy, "dy").contiguous()
+    B, Cc = dy.shape
+    dx = torch.empty(B, Cc, H, W, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().tgsr_plane_mean_bwd(_p(dy), _p(dx), B * Cc, H * W, _stream()), "tgsr_plane_mean_bwd")
+    return dx
+
+
+def relu_mask_(dy: torch.Tensor, y: torch.Tensor, coff: int, ch: int):
+    """dy[:, coff:coff+ch] *= (y[:, coff:coff+ch] > 0) in place (two equally shaped dense NCHW tensors)."""
+    _need_hip(dy, y)
+    if dy.shape != y.shape or coff + ch > dy.shape[1]:
+        raise TgsrError("relu_mask: %s / %s" % (tuple(dy.shape), tuple(y.shape)))
+    gp, gbs = _slice_ptr(dy, coff)
+    yp, ybs = _slice_ptr(y, coff)
+    check(_lib.lib().tgsr_relu_mask(gp, gbs, yp, ybs, gp, gbs, dy.shape[0], ch * dy.shape[2] * dy.shape[3], _stream()), "tgsr_relu_mask")
+
+
+def bilinear(x: torch.Tensor, OH: int, OW: int) -> torch.Tensor:
+    _need_hip(x)
+    x = _f32(x, "x").contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, Cc, OH, OW, dtype=torch.float32, device=x.device)
+    check(_lib.lib().tgsr_bilinear_fwd(_p(x), B * Cc, H, W, OH, OW, _p(out), _stream()), "tgsr_bilinear_fwd")
+    return out
+
+
+def bilinear_bwd(dy: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    _need_hip(dy)
+    dy = _f32(dy, "dy").contiguous()
+    B, Cc, OH, OW = dy.shape
+    dx = torch.empty(B, Cc, H, W, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().tgsr_bilinear_bwd(_p(dy), B * Cc, H, W, OH, OW, _p(dx), _stream()), "tgsr_bilinear_bwd")
+    return dx
+
+
 # ----------------------------------------------------------------------------------------- image pyramid (uint8)
 def resize_bilinear_u8(x: torch.Tensor, out_h: int, out_w: int, htab, vtab) -> torch.Tensor:
     """Pillow's `resize(BILINEAR)` of planar uint8 images [..., H, W]; htab / vtab = (bounds, coefficients, ksize) device

@@ -506,6 +506,13 @@ class CNN_ENCODER(nn.Module):
         Third-party blocks run as the torch modules they are; only the order / pooling / resize is the reference's."""
         if self.trunk is not None:
             return self.trunk(x)
+        if self._hip_trunk_ok(x):
+            # eval mode, frozen (what generator_loss runs, losses.py:375-389): the whole walk on the library's kernels
+            # (tgsr_amd/inception.py, csrc/tgsr_igemm.hip); its backward reaches the image only
+            from .inception import InceptionTrunk, TrunkFn
+            if self._hip_trunk is None:
+                self._hip_trunk = InceptionTrunk(self)
+            return TrunkFn.apply(x, self._hip_trunk)
         import torch.nn.functional as F
         x = F.interpolate(x, size=(299, 299), mode='bilinear', align_corners=False)   # nn.Upsample(size=(299, 299), 'bilinear')
         x = self.Conv2d_2b_3x3(self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x)))              # 149 -> 147 -> 147
@@ -518,6 +525,23 @@ class CNN_ENCODER(nn.Module):
         x = self.Mixed_7c(self.Mixed_7b(self.Mixed_7a(x)))                              # 8 x 8 x 2048
         x = F.avg_pool2d(x, kernel_size=8)
         return features, x.view(x.size(0), -1)
+
+    _hip_trunk = None
+
+    def _hip_trunk_ok(self, x):
+        """The HIP walk serves the frozen trunk in eval mode on fp32 HIP images (TGSR_TRUNK=torch: the torch modules, e.g. on
+        MIOpen).  In training mode (pretrain_DAMSM.py:49-50 puts the whole encoder in train mode: the trunk's BatchNorm then
+        normalises with batch statistics) the blocks run as the torch modules they are."""
+        import os
+        if os.environ.get("TGSR_TRUNK", "hip") == "torch" or self.training or not (x.is_cuda and x.dtype == torch.float32):
+            return False
+        if self._hip_trunk is None:
+            first = getattr(self, _INCEPTION_BLOCKS[0], None)
+            if not (hasattr(first, "conv") and hasattr(first, "bn")):
+                return False                                  # not torchvision's layout (e.g. a stub): walk the modules
+            if any(p.requires_grad for p in self.frozen_parameters()):
+                return False
+        return True
 
     def heads(self, features, pooled):
         """(features [B,768,17,17], pooled [B,2048]) -> (region features [B,nef,17,17], cnn_code [B,nef])."""

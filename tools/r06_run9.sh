@@ -1,0 +1,14 @@
+#!/bin/bash
+set -o pipefail
+OUT=gpurun_out/r06
+mkdir -p $OUT
+timeout -k 10 600 python -m pytest tests/test_hip_inception.py tests/test_hip_custom_ops.py -x -q > $OUT/t9.log 2>&1
+echo "pytest rc=$?"; tail -n 15 $OUT/t9.log | cut -c1-200
+python tools/debug_trunk.py 2>&1 | tail -22
+timeout -k 10 400 python bench.py --mode train --gan --damsm-encoder --steps 10 --no-cpu-baseline > $OUT/train_enc_hip9.json 2> $OUT/train_enc_hip9.err; echo "rc=$?"
+python - "$OUT/train_enc_hip9.json" <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[1], d["ms_per_step"], d["value"], d["final_loss"])
+except Exception as e: print("no line", e); print(open(sys.argv[1].replace(".json",".err")).read()[-2000:])
+PY
