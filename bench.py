@@ -44,7 +44,7 @@ EXECUTED_MAC_FRACTION = {"conv3x3_mfma_kernel": 1.0, "wino_conv3x3_kernel": 16.0
                          # 9-tap form, the image heads and the discriminators' implicit GEMM (every MAC issued)
                          "wino_wgrad_kernel": 16.0 / 36.0, "upwino_wgrad_kernel": 9.0 / 36.0, "conv3x3_wgrad_kernel": 1.0,
                          "dconv_igemm_kernel": 1.0,
-                         # the same GEMMs on the bf16 pipe with three-piece operands: six bf16 MFMAs (6 x 32 cycles
+                         # the same GEMMs on the bf16 pipe with three-piece operands (profiles/HISTORY.md 3.18): six bf16 MFMAs (6 x 32 cycles
                          # per 32 x 32 x 16) where the fp32 form issues eight fp32 MFMAs (8 x 64 cycles): 0.375 of its matrix-pipe time
                          "dconv_igemm6_kernel": 6.0 * 32 / (8.0 * 64)}
 # bench name of a kernel -> prefix of its name in the rocprofv3 tables under profiles/
@@ -182,7 +182,7 @@ def cpu_baseline(weights, batch, budget_s=20.0, x16_pipe=None):
                       "runs, %.2f s/batch" % (name, batch, len(ts), med)}
 
 
-CONV_GFLOP_PER_IMAGE = 20.5     # direct-form FLOPs of the 36 conv3x3 launches of one forward
+CONV_GFLOP_PER_IMAGE = 20.5     # direct-form FLOPs of the 36 conv3x3 launches of one forward (profiles/HISTORY.md section 3.1)
 
 
 def cpu_baseline_train(weights, batch, budget_s=12.0):
@@ -796,7 +796,7 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup,
         cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
         for _ in range(warmup):
             tr.step(cap, lens, LR, LRb, hr)
-        # The train steps are issued by the host about as fast as the device runs them: whatever this process has
+        # The train steps are issued by the host about as fast as the device runs them (profiles/HISTORY.md 3.18): whatever this process has
         # alive by now (the earlier objects of the default line, the trainer's modules and buffers) is garbage-collector work on
         # every allocation burst of a step.  Collect once and move the survivors out of the collector's sight - what a training
         # script does after its set-up (`gc.freeze()`); stated in the entry.

@@ -147,7 +147,7 @@ int tgsr_wino_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int
  * direct form), for the large layers of the inference path - ResBlock.block util.py:110-130 at 128^2 and above.  fp32
  * throughout; the transforms hold 4, 5, 8 and 1/24, so its rounding error is ~15x that of the other two forms per layer
  * (3e-5 on unit-scale data): on the shipped checkpoint the finest image stays at 3.0e-5 (max, against fp64) with the 128^2
- * and 64^2 layers on this kernel, 2.1e-4 with the 32^2 layers on it too - callers route by layer size.  upack from
+ * and 64^2 layers on this kernel, 2.1e-4 with the 32^2 layers on it too (profiles/HISTORY.md 3.1e) - callers route by layer size.  upack from
  * tgsr_pack_wino4_weight (tgsr_packed_wino4_weight_elems floats; U = G g G^T computed in double, rounded once; `glu` must
  * match the epilogue).  Cout % 64 == 0, Cin % 4 == 0, W % 4 == 0; x, out, residual 16-byte aligned with batch strides
  * % 4 == 0; same epilogue selectors and residual rule as tgsr_conv3x3_fwd.
@@ -677,7 +677,7 @@ int tgsr_lp_to_nchw(int dtype, const void* x, float* out, int B, int C, int H, i
 /* An lp image (any shape; the whole buffer incl. its zero border, n_elems % 8 == 0, 16-byte aligned) from one 2-byte type
  * to the other: TGSR_DT_F16 -> TGSR_DT_BF16 (one round-to-nearest-even) or back (exact while |x| < 65504).  Used where a
  * section of a generator runs with f16 operands inside the bf16 configuration (NetG_highweight's 32x32 trunk: the six
- * chained ResBlocks of model.py:258-262 are where 8-bit mantissas cost the finest image 7 dB). */
+ * chained ResBlocks of model.py:258-262 are where 8-bit mantissas cost the finest image 7 dB; profiles/HISTORY.md 3.8d). */
 int tgsr_lp_convert(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n_elems, void* stream);
 
 /* conv weight [Cout][Cin][3][3] (fp32, torch layout) -> MFMA fragment order

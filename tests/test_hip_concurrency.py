@@ -3,7 +3,7 @@
 Every inference kernel of the path is launched on one stream while an MFMA-heavy neighbour loops on a second stream, and
 its output is compared bit for bit with the one it gives alone.  The case this pins: packed fp32 instructions
 (v_pk_fma_f32 ...) whose registers are reloaded right behind them read the NEW contents when the matrix pipe is busy with
-another wave's MFMAs (tools/lds_neighbour_check.py) - the LSTM recurrence and the lp stem gave
+another wave's MFMAs (profiles/HISTORY.md section 3.13, tools/lds_neighbour_check.py) - the LSTM recurrence and the lp stem gave
 different results under a hipGraph's concurrency until their packed instructions were removed."""
 import pytest
 import torch

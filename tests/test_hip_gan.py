@@ -564,7 +564,7 @@ def test_cnn_encoder_walks_a_real_inception_v3_at_batch_16(face_weights):
 
 
 def test_split_operand_gemm_is_as_accurate_as_the_fp32_mfma():
-    """the discriminator GEMMs on the bf16 pipe (every fp32 operand = three bf16 pieces exactly, six of the nine piece
+    """profiles/HISTORY.md 3.18: the discriminator GEMMs on the bf16 pipe (every fp32 operand = three bf16 pieces exactly, six of the nine piece
     products, fp32 accumulation) against the same GEMMs on the fp32 MFMA, both measured from an fp64 convolution - a 256 -> 512 layer at
     16^2 (K = 4096 forward, 2048 data gradient, 2048 pixels weight gradient) and a 3 x 3 block at 4 x 4 pixels (K = 4608): the split
     form's maximum and rms error must not exceed the fp32 form's by more than a quarter (measured: 0.8-1.0 of it)."""

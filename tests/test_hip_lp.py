@@ -721,7 +721,7 @@ def test_lp_pipeline_resblock_chain_equals_separate_launches(name, cfg_face, fac
     B = 4
     cap, lens, LR, LRb = O.synthetic_batch(B, seed=12)
     args = (cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV))
-    monkeypatch.setattr(lp_pipeline, "CHAIN", True)        # off by default: measured slower than four launches
+    monkeypatch.setattr(lp_pipeline, "CHAIN", True)        # off by default: measured slower than four launches (profiles/HISTORY.md 3.17)
     chained = _pipe(cfg_face, face_weights, name)
     a = chained(*args)
     assert any(st.get("flags") is not None for bufs in chained._lp.bufs.values() for st in bufs["gl"])   # the chain kernel did run

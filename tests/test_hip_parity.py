@@ -209,7 +209,7 @@ WINO4_CASES = [
 @pytest.mark.parametrize("B,Cin,H,W,Cout,glu,res", WINO4_CASES)
 def test_conv3x3_winograd4(B, Cin, H, W, Cout, glu, res):
     """F(4x4, 3x3): against F.conv2d in fp64.  Stated bound 1e-4 on unit-scale data (measured 1.6e-5 .. 3.4e-5; F(2x2) on
-    the same inputs 7e-7 .. 1.8e-6 - the price of 36 instead of 64 multiplies per 16 outputs)."""
+    the same inputs 7e-7 .. 1.8e-6 - the price of 36 instead of 64 multiplies per 16 outputs, profiles/HISTORY.md 3.1e)."""
     from tgsr_amd import ops, custom_ops as C
     g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
     x = torch.randn(B, Cin, H, W, generator=g)

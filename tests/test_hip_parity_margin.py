@@ -5,7 +5,7 @@ upwino4_wanted) and is compared with (a) the CPU fp32 oracle at the path's ONE s
 2e-4, every value, no outlier allowance - round 6, see below) and (b) an
 fp64 run of the oracle, next to the CPU fp32 oracle's OWN distance from fp64 - the reference's arithmetic against exact
 arithmetic is the yardstick, not one fp32 evaluation against another (two correct fp32 evaluations of this network differ by up to
-1e-4 at the few pixels whose activations are 20-50x the typical size: DESIGN.md 3.1g).
+1e-4 at the few pixels whose activations are 20-50x the typical size: profiles/HISTORY.md 3.1g).
 
 Cases: the 8 batches `bench.py` times (shipped face checkpoint, seeds 100 + 1000 i), 4 more seeds, seeded-random weights with
 randomised BatchNorm statistics (x8), and the x16 generators.  What the table showed (profiles/r05_parity_margin.txt, DESIGN.md

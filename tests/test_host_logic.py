@@ -248,7 +248,7 @@ def test_wgrad_kind_only_names_kernels_that_take_the_shape():
 
 
 def test_split_form_eligibility_is_host_arithmetic():
-    """Which shapes the discriminator GEMMs take on the bf16 pipe - pure host logic in the library, no GPU needed:
+    """Which shapes the discriminator GEMMs take on the bf16 pipe (profiles/HISTORY.md 3.18) - pure host logic in the library, no GPU needed:
     whole 16-deep K-chunks (forward: always for the 4x4 form; data gradient: Cout % 4 == 0; 3x3: 9 C % 16 == 0), a weight gradient
     whose output pixels come in whole chunks, the image layer's data gradient on its own kernel, everything off with the switch."""
     from tgsr_amd import _lib

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void dconv_igemm_kernel(IgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same GEMMs on the bf16 matrix pipe, fp32 in and out ("x6").  `v_mfma_f32_32x32x2_f32` runs at the fp32
+// The same GEMMs on the bf16 matrix pipe, fp32 in and out ("x6", profiles/HISTORY.md 3.18).  `v_mfma_f32_32x32x2_f32` runs at the fp32
 // VECTOR rate (64 FLOP/clk/SIMD, 1/16 of the bf16 MFMA) and every VALU instruction beside it costs its full issue time.  An
 // fp32 value is exactly x0 + x1 + x2 with three bf16 pieces (round-to-nearest split: 9 + 9 + 9 >= 24 significand bits), a
 // bf16 x bf16 product is exact in fp32 and the bf16 MFMA accumulates in fp32, so

@@ -55,7 +55,7 @@ constexpr int lp_conv_occ() {   // waves per SIMD to allocate registers for: the
   return (CIN == 64 || (COUT / 32) * (TR / 4) * 16 >= 64) ? 2 : 3;
 }
 
-// (the timing experiments of DESIGN.md 3.8 - parts of this kernel compiled out, in-kernel clock stamps - were made on a diagnostic
+// (the timing experiments of profiles/HISTORY.md 3.8 - parts of this kernel compiled out, in-kernel clock stamps - were made on a diagnostic
 // COPY of this file, tools/diag/tgsr_lp_conv_dbg.hip; a second copy of a kernel drifts, so it was removed in round 5 - it is in the
 // history at 67ad6ee with its drivers tools/lp_conv_experiments.sh / lp_conv_clock.py)
 // LDS bytes of one workgroup of lp_conv3x3_body (the constants are restated inside the body)

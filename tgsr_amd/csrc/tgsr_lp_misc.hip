@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void lp_stem_kernel(LpStemArgs a) {
       for (int dx = 0; dx < 3; ++dx) in[c * 9 + dy * 3 + dx] = in_s[(c * 3 + dy) * 34 + px + dx];
   // (Round 3 history: built with the SLP vectorizer this loop became v_pk_fma_f32 fed by late re-reads of in_s into the same
   // registers, and the kernel intermittently computed other values - lanes 48-63, the later channels - whenever a hipGraph ran
-  // MFMA-bound convolutions beside it.  That was the packed-fp32 hazard of DESIGN.md 3.13, not a property of this kernel: the
+  // MFMA-bound convolutions beside it.  That was the packed-fp32 hazard of profiles/HISTORY.md 3.13, not a property of this kernel: the
   // library's inference kernels are built without packed fp32 instructions now, tests/test_hip_concurrency.py watches it.)
   float o[8];
 #pragma unroll

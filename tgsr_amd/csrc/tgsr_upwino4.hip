@@ -27,7 +27,7 @@
 //       of the next], so vmcnt(6) in front of quad q's MFMAs = "A(q) has arrived", vmcnt(7) at the stage's end = "my copy has
 //       landed".  An EVEN number of stages (host-checked; see tgsr_winograd4.hip for why); the last stage prefetches stage 0
 //       again and vmcnt(0) precedes the epilogue.  (With U through LDS - 28 KB per stage, 32 copy instructions per 8-wave
-//       workgroup and stage - the 128^2 -> 256^2 upBlock took 187 us; this form: see DESIGN.md 3.1f.)
+//       workgroup and stage - the 128^2 -> 256^2 upBlock took 187 us; this form: see profiles/HISTORY.md 3.1f.)
 //   raw [4 ci][4 low-res rows][40 cols] in planes of 192 floats (3 KB per stage, double buffered, LDS-DMA by waves 1-3; the
 //       tile starts 4 columns left of the first low-res column: every 16-byte piece is aligned and wholly in or out).
 //   S   [4 rows of S = quads][4 ci][16 tiles][4] (4 KB, double buffered): wave cb computes row cb.

@@ -7,7 +7,7 @@
 // 36 multiplies per 16 outputs instead of 144 - 1.78x fewer MFMAs than F(2x2, 3x3), 4x fewer than the direct form.
 // Numerics: the transforms hold 4, 5, 8 and 1/24 where F(2x2) holds 1 and 1/2: per layer, on unit-scale data, 1.6e-5 .. 3.4e-5
 // (max) against 7e-7 .. 1.8e-6.  Measured end to end on the shipped checkpoint (oracle with this algorithm in fp32 on chosen
-// layers vs the fp64 oracle; stated tolerance 1e-4): with the 128^2 layers on it the finest image stays at
+// layers vs the fp64 oracle, profiles/HISTORY.md 3.1e; stated tolerance 1e-4): with the 128^2 layers on it the finest image stays at
 // 3.0e-5 max (the direct fp32 form: 2.9e-5; the reference's own CPU path 3.7e-5), with the 64^2 layers as well the 256^2
 // image of G_SR_NET_low moves 0.9e-5 -> 2.3e-5; with the 32^2 layers too the finest image is off by 2.1e-4 - the callers
 // (ops.wino4_wanted) therefore route layers of >= 64 x 64 pixels here and nothing smaller.
@@ -93,7 +93,7 @@ __host__ __device__ constexpr int w4_pos(int i, int j) {   // accumulator index 
 
 typedef float f32x4w4 __attribute__((ext_vector_type(4)));
 
-// Interpolation points 0, +-kP, +-kR, inf.  Rounds 1-4 used Lavin's 0, +-1, +-2, inf; what dominates the error of
+// Interpolation points 0, +-kP, +-kR, inf (profiles/HISTORY.md 3.1g).  Rounds 1-4 used Lavin's 0, +-1, +-2, inf; what dominates the error of
 // F(4x4) in fp32 is the accumulation over the input channels of products whose magnitude - at the positions of the outermost
 // points - is many times the output's (they cancel in A^T M A), and that ratio is a property of the points alone (row scalings
 // between G, B^T and A^T leave it unchanged).  +-5/8, +-3/2 brings a layer's error on unit-scale data from 3.3e-5 max / 1.0e-6 mean

@@ -40,7 +40,7 @@ FUSE_ATT = os.environ.get("TGSR_LP_FUSE_ATT", "1") != "0"
 # than the ~7 us a dependent kernel costs in a replayed graph - and measured SLOWER: on MI355X an in-kernel hand-off between
 # workgroups needs an agent-scope release (write-back of the XCD's L2: ~6.5 us with a freshly written 16 KB tile) and an acquire
 # (L1 invalidate, ~1.7 us) per layer, more than the kernel boundary it replaces (bf16 batch 16 one lane: 28.1 k images/s with it,
-# 32.0 k without).  OFF by default; TGSR_LP_CHAIN=1 switches it on (the tests do).
+# 32.0 k without; profiles/HISTORY.md 3.17).  OFF by default; TGSR_LP_CHAIN=1 switches it on (the tests do).
 CHAIN = os.environ.get("TGSR_LP_CHAIN", "0") == "1"
 CHAIN_MAX_PIXELS = 64 * 64
 

@@ -236,11 +236,11 @@ def conv3x3_wino(x: torch.Tensor, upack: torch.Tensor, cout: int, scale, shift, 
     return out
 
 
-WINO4_MIN_PIXELS = 64 * 64        # per image; DESIGN.md 3.1e: the error study that keeps F(4x4) off the 32 x 32 layers
+WINO4_MIN_PIXELS = 64 * 64        # per image; profiles/HISTORY.md 3.1e: the error study that keeps F(4x4) off the 32 x 32 layers
 WINO4_MIN_PIXELS_64 = 128 * 128   # pixels per image from which layers with 64-channel groups only may use F(4x4) too
 # The up-sample-aware F(4x4) form must keep +-1 among its interpolation points (its 25-of-36 structure depends on them,
 # tgsr_upwino4.hip), so it does not get the better-conditioned points of tgsr_winograd4.hip: its OWN error is 1.9-2.2x the CPU
-# fp32 op's on the same input (tests/test_hip_parity_margin.py).  It therefore serves only upBlocks whose output is
+# fp32 op's on the same input (tests/test_hip_parity_margin.py, profiles/HISTORY.md 3.1g).  It therefore serves only upBlocks whose output is
 # the generator's finest feature map (>= 256 x 256: nothing but an image head reads it); an upBlock in mid-network feeds the
 # 128^2 stages that amplify whatever error they are handed.
 UPWINO4_MIN_OUT_PIXELS = 256 * 256
@@ -275,7 +275,7 @@ ROUTING = _Routing()
 def wino4_wanted(cin: int, cout: int, H: int, W: int, B: int = 16) -> bool:
     """Does a conv3x3 layer go to the F(4x4, 3x3) kernels?  Three rules.
     Shape: Cout % 64, Cin % 4, W % 64, H % 8 (whole workgroup tiles).
-    Numerics (DESIGN.md 3.1e / 3.1g; tests/test_hip_parity.py::test_fp32_parity_margin_*): layers of >= 128 x 128
+    Numerics (profiles/HISTORY.md 3.1e / 3.1g; tests/test_hip_parity.py::test_fp32_parity_margin_*): layers of >= 128 x 128
     pixels; at 64 x 64 .. 128 x 128 only the convolutions with 128-channel groups; nothing below 64 x 64 (the early, small layers
     are the ones whose error the rest of the network amplifies).
     Work: >= 256 workgroups of the form the layer takes - register-fed (Cin % 8 == 0): 4 x 64 pixels x 128 rows, or x 64 rows
@@ -1647,7 +1647,7 @@ def _dconv_wgrad(kind, dy, x, out=None):
 
 
 def dconv_set_split(on: int) -> int:
-    """The discriminators' 4x4 convolutions on the bf16 matrix pipe with three-piece fp32 operands (default on) or
+    """The discriminators' 4x4 convolutions on the bf16 matrix pipe with three-piece fp32 operands (default on; profiles/HISTORY.md 3.18) or
     on the fp32 MFMA.  Returns the previous setting (tgsr_dconv_set_split)."""
     return _lib.lib().tgsr_dconv_set_split(int(on))
 

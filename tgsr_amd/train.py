@@ -115,7 +115,7 @@ class SRTrainer:
             # A discriminator's update - forward on (real, fake.detach()), loss, backward, Adam - is a closed piece of device work
             # with no host decision in it: replayed from a hipGraph per discriminator once the step has run `GRAPH_D_WARMUP` times
             # (with more than one rank as two graphs around the bucket's all-reduce: `_capture_d_update`).  ~1 000 of a step's ~1 570
-            # launches leave the host that way; the step was issued no faster than 21-25 ms.  TGSR_GRAPH_D=0: eager.
+            # launches leave the host that way; the step was issued no faster than 21-25 ms (profiles/HISTORY.md 3.18).  TGSR_GRAPH_D=0: eager.
             self._graph_d = self.device.type == "cuda" and os.environ.get("TGSR_GRAPH_D", "1") != "0"
             self._dgraphs, self._dsteps, self._d_bump = [None] * len(self.netsD), 0, [None] * len(self.netsD)
             for d in self.netsD:

@@ -288,7 +288,7 @@ class SRPipeline:
         # Inside a hipGraph capture: last (3) - the captured graph is a DAG, but ROCm 7.2's executor starts the branch that was
         # created second only when a whole segment of the first one has been submitted: with the trunk first, its 13 small
         # kernels run ALONE for ~110 us (bf16) / ~130 us (fp32) before the recurrence - the head of the step's dependent chain -
-        # starts (gpurun_out timelines); created last, the trunk runs in the shadow of G_SR_NET_low.
+        # starts (gpurun_out timelines, profiles/HISTORY.md 3.16); created last, the trunk runs in the shadow of G_SR_NET_low.
         mode = GH_AFTER_TEXT
         if mode < 0:
             mode = 3 if (LR.is_cuda and torch.cuda.is_current_stream_capturing()) else 0

@@ -1,7 +1,7 @@
 // Experiment (not product code): can fp32 matrix products run on the bf16 matrix pipe?
 //
 // On gfx950 `v_mfma_f32_16x16x4_f32` runs at 64 FLOP/clk/SIMD - the fp32 VECTOR rate, 1/16 of the bf16 MFMA rate - and every
-// VALU instruction beside it costs its full issue time (DESIGN.md 3.1c / 3.1e measured ~7.7 cycles each): the fp32 convolution
+// VALU instruction beside it costs its full issue time (profiles/HISTORY.md 3.1c / 3.1e measured ~7.7 cycles each): the fp32 convolution
 // kernels are bound by that.  An fp32 number is exactly the sum of three bf16 numbers (round-to-nearest split: 9 + 9 + 9 >= 24
 // significand bits), a bf16 x bf16 product is exact in fp32, and the bf16 MFMA accumulates in fp32 - so
 //     a b = a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0) + [a1 b2 + a2 b1 + a2 b2]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The discriminators' convolutions layer by layer (D_NET256's shapes at the G/D step's batch: 32 = real + fake, DF_DIM 64):
-forward, data gradient, weight gradient - us per launch and TFLOP/s of the 157.3 fp32 MFMA peak.  DESIGN.md 3.9.
+forward, data gradient, weight gradient - us per launch and TFLOP/s of the 157.3 fp32 MFMA peak.  profiles/HISTORY.md 3.9.
     python tools/exp_dconv.py [B]"""
 import os, sys
 import torch

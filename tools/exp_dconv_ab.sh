@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the discriminators' GEMMs: fp32 MFMA (0) vs three-piece bf16 operands (1; 3 = with pre-split weights).  DESIGN.md 3.18.
+# A/B of the discriminators' GEMMs: fp32 MFMA (0) vs three-piece bf16 operands (1; 3 = with pre-split weights).  profiles/HISTORY.md 3.18.
 #   tools/exp_dconv_ab.sh [B] [modes...]
 set -e
 cd "$(dirname "$0")/.."

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What Winograd F(4x4,3x3) in fp32 costs END TO END on the shipped checkpoint, layer set by layer set (CPU; the fp32 oracle with
 its conv3x3 replaced by an emulation of the algorithm - U = G g G^T rounded once, V = B^T d B, products and A^T M A in fp32 -
-against the fp64 oracle; full-size C1 case of tests/golden).  The table in DESIGN.md 3.1e is this script's output; it decides
+against the fp64 oracle; full-size C1 case of tests/golden).  The table in profiles/HISTORY.md 3.1e is this script's output; it decides
 which layers tgsr_amd.ops.wino4_wanted routes to tgsr_winograd4.hip.     python tools/exp_wino4_numerics.py"""
 import os, sys
 import numpy as np, torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which interpolation points should Winograd F(4x4,3x3) use in fp32?  (CPU)
+"""Which interpolation points should Winograd F(4x4,3x3) use in fp32?  (CPU; profiles/HISTORY.md 3.1g.)
 
 Two measurements per candidate point set {0, p1..p4, inf} (the Toom-Cook matrices are built from the points in exact rationals):
  (1) per layer, unit-scale data, the accumulation over input channels done the way the MFMA kernel does it (sequentially, one fp32

@@ -6,7 +6,7 @@ neighbour kernel loops on a second stream; every output is compared with the one
 The canaries (LDS contents, registers, packed FMAs on registers, packed FMAs fed from LDS, plain LDS write/barrier/read) live in
 tools/diag/lds_canary.hip:
     hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -shared -o tgsr_amd/lib/diag/liblds_canary.so tools/diag/lds_canary.hip
-What it found is DESIGN.md section 3.13: v_pk_fma_f32 fed from ds_read_b128 gives other results beside MFMA-bound kernels."""
+What it found is profiles/HISTORY.md section 3.13: v_pk_fma_f32 fed from ds_read_b128 gives other results beside MFMA-bound kernels."""
 import sys, os
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

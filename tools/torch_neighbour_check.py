@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: are PyTorch's own elementwise / optimizer kernels exposed to the packed-fp32 hazard of DESIGN.md 3.13 when they
+"""Diagnostic: are PyTorch's own elementwise / optimizer kernels exposed to the packed-fp32 hazard of profiles/HISTORY.md 3.13 when they
 run beside this library's MFMA-bound kernels (as they do during a training step's backward)?  Same method as
 tests/test_hip_concurrency.py: victim on one stream, neighbour looping on another, torch.equal against the solo result."""
 import os, sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What would fusing the fp32 image heads into their upBlocks remove from the PRODUCER?  Times the two 256^2
+"""What would fusing the fp32 image heads into their upBlocks (profiles/HISTORY.md 3.11) remove from the PRODUCER?  Times the two 256^2
 upBlocks of a forward (upwino_kernel: G_SR_NET_low 64 -> 64 GLU, NetG_highweight 32 -> 64 GLU, batch 16, 128^2 -> 256^2) with the
 shipped library and with a diagnostic build whose epilogue computes everything but does not store
 (-DTGSR_UPW_NOSTORE: results wrong by construction, only the times mean anything), and the two stand-alone heads that read them.
