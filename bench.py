@@ -794,8 +794,10 @@ def _train_run(args, rank, world, dist, dev, weights, fence, gan, steps, warmup,
         g = torch.Generator().manual_seed(7 + rank)
         hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(dev) for s in (64, 128, 256)]
         cap, LR, LRb, lens = cap.to(dev), LR.to(dev), LRb.to(dev), lens.tolist()
-        for _ in range(warmup):
+        from tgsr_amd.train import GRAPH_G_SETTLED
+        for _ in range(max(warmup, GRAPH_G_SETTLED if tr._auto is not None else 0)):     # (TGSR_GRAPH_G=auto settles in the warm-up)
             tr.step(cap, lens, LR, LRb, hr)
+        entry["graph_policy"] = dict(tr.graph_policy)
         # The train steps are issued by the host about as fast as the device runs them (profiles/HISTORY.md 3.18): whatever this process has
         # alive by now (the earlier objects of the default line, the trainer's modules and buffers) is garbage-collector work on
         # every allocation burst of a step.  Collect once and move the survivors out of the collector's sight - what a training
@@ -1256,9 +1258,24 @@ def main():
             res["ranks"]["rccl_direct"] = direct
             res["ranks"]["rccl_ranks"] = direct.get("rccl_ranks")
         print(json.dumps(res), flush=True)
-    if direct is not None and direct.get("hung"):
-        sys.stdout.flush()
-        os._exit(0)                      # a thread is stuck inside librccl: the line is out, leave without the interpreter's teardown
+    if direct is not None:
+        # Every rank must leave the same way: a rank stuck inside librccl cannot take part in the closing barrier, and the others
+        # would wait in it for ever (a non-zero exit of the launcher although the line is out).  The verdicts travel through the
+        # rendezvous store (TCP, no GPU involved); any hung rank -> all of them leave without the interpreter's teardown.
+        anyhung = bool(direct.get("hung"))
+        try:
+            from torch.distributed.distributed_c10d import _get_default_store
+            import datetime
+            store = _get_default_store()
+            store.set("tgsr_direct_%d" % rank, "hung" if anyhung else "ok")
+            store.set_timeout(datetime.timedelta(seconds=90))
+            for r in range(world):
+                anyhung = anyhung or store.get("tgsr_direct_%d" % r) == b"hung"
+        except Exception:                # noqa: BLE001 - a rank that never wrote its key is a hung rank
+            anyhung = True
+        if anyhung:
+            sys.stdout.flush()
+            os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -624,8 +624,10 @@ def test_graph_replayed_discriminator_updates_equal_eager_ones():
             tr = train.SRTrainer(41, device=DEV, discriminators=True)
             assert tr._graph_d                                   # capturable Adam on both
             assert tr._graph_g and tr._graph_capable             # the default policy replays the G/D alternation
+            assert tr._auto is not None                          # ... as the first guess of the measured policy (TGSR_GRAPH_G=auto)
+            tr._graph_g = graphs                                 # pinned here: replay from step GRAPH_G_WARMUP on | never
+            assert tr._auto is None
             if not graphs:
-                tr._graph_g = False
                 tr._dsteps = -10 ** 9                            # never reaches the warm-up count: eager updates, same optimizer kind
             trs.append(tr)
         out = [[], []]

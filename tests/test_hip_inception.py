@@ -212,3 +212,55 @@ def test_whole_trunk_forward_and_image_gradient_against_the_modules_in_float64()
         assert not enc._hip_trunk_ok(xd)
     finally:
         cfg_reset()
+
+
+def test_branch_streams_equal_the_single_stream_walk_bit_for_bit():
+    """The branches of a Mixed_* block on streams of their own (the default) run the same kernels with the same order of every
+    accumulation as the walk on one stream: features, pooled code and d(loss)/d(image) are identical bits - eagerly, twice in a row
+    (the second walk reuses the allocator's blocks of the first), and replayed from a hipGraph that captured the forked walk."""
+    from inception_v3_arch import InceptionV3Arch
+    from tgsr_amd import inception
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd.util import CNN_ENCODER
+    cfg_reset()
+    cfg.TRAIN.FLAG = True
+    try:
+        enc = CNN_ENCODER(64, inception=InceptionV3Arch(seed=4)).eval().to(DEV)
+        for p in enc.frozen_parameters():
+            p.requires_grad = False
+        B = 8
+        g = torch.Generator().manual_seed(9)
+        img = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(DEV)
+        wf, wp = torch.randn(B, 768, 17, 17, generator=g).to(DEV), torch.randn(B, 2048, generator=g).to(DEV)
+
+        def walk(nstreams, x):
+            assert enc._hip_trunk_ok(x)
+            enc.run_trunk(x.detach())                       # builds the runner
+            enc._hip_trunk.nstreams = nstreams
+            f, p = enc.run_trunk(x)
+            ((f * wf).sum() + (p * wp).sum()).backward()
+            return f.detach().clone(), p.detach().clone(), x.grad.detach().clone()
+
+        one = walk(1, img.clone().requires_grad_(True))
+        assert len(enc._hip_trunk._streams) == 1
+        for _ in range(2):
+            many = walk(4, img.clone().requires_grad_(True))
+            assert len(enc._hip_trunk._streams) == 4
+            for a, b in zip(one, many):
+                assert torch.equal(a, b)
+        # captured: the forks and joins become the graph's branches
+        xs = img.clone().requires_grad_(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=side):
+            f, p = enc.run_trunk(xs)
+            gx, = torch.autograd.grad((f * wf).sum() + (p * wp).sum(), xs)
+        with torch.no_grad():
+            xs.copy_(img.flip(0))
+        gr.replay()
+        torch.cuda.synchronize()
+        ref = walk(1, img.flip(0).clone().requires_grad_(True))
+        assert torch.equal(f, ref[0]) and torch.equal(p, ref[1]) and torch.equal(gx, ref[2])
+    finally:
+        cfg_reset()

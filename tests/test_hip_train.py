@@ -351,6 +351,48 @@ def test_graph_replayed_generator_update_equals_eager_one():
         cfg_reset()
 
 
+def test_measured_graph_policy_settles_and_changes_no_bit():
+    """TGSR_GRAPH_G=auto (the default): the trainer times GRAPH_G_TRIALS eager steps, captures, times as many replayed ones and
+    keeps the faster form - whichever it keeps, every step along the way (eager, capturing, replayed, chosen) leaves the same
+    bits as a trainer pinned to the eager form; the report says what was measured."""
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd import train
+    cfg_reset()
+    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM = 32, 256
+    try:
+        B = 4
+        trs = []
+        for pinned in (False, True):
+            torch.manual_seed(5)
+            tr = train.SRTrainer(41, device=DEV)
+            assert tr._auto is not None and tr.graph_policy["mode"] == "auto"
+            if pinned:
+                tr._graph_g = False
+            trs.append(tr)
+        out = [[], []]
+        forms = []
+        cap, lens, _LR, LRb = O.synthetic_batch(B, seed=40)
+        for step in range(train.GRAPH_G_SETTLED + 2):
+            g = torch.Generator().manual_seed(step)
+            LR = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+            hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+            for k, tr in enumerate(trs):
+                torch.manual_seed(100 + step)
+                out[k].append(float(tr.step(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)))
+            forms.append(None if trs[0]._auto is None else trs[0]._auto["form"])
+        a = trs[0]
+        assert forms[:train.GRAPH_G_WARMUP + train.GRAPH_G_TRIALS] == ["eager"] * (train.GRAPH_G_WARMUP + train.GRAPH_G_TRIALS)
+        assert forms[train.GRAPH_G_SETTLED - 1] is None and a._auto is None, forms          # settled
+        pol = a.graph_policy
+        assert pol["chosen"] in ("eager", "replay") and pol["eager_ms"] > 0 and pol["replay_ms"] > 0, pol
+        assert a._graph_g == (pol["chosen"] == "replay") and a._ggraphs
+        assert out[0] == out[1], (out[0], out[1])
+        for x, y in zip(a.params, trs[1].params):
+            assert torch.equal(x, y)
+    finally:
+        cfg_reset()
+
+
 def test_train_step_decreases_loss_and_updates_running_stats(nets_small):
     from conftest import split_sd
     from tgsr_amd.miscc.config import cfg, cfg_reset

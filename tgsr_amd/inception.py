@@ -13,12 +13,19 @@ the same kernels (ReLU mask in place, data gradients accumulated into the block 
 third-party (torchvision's weights are absent here): parity is pinned against the same modules run by torch, not against the
 reference (unpinned).
 """
+import contextlib
+import os
+
 import torch
 
 from . import custom_ops as C
 from ._lib import TgsrError
 
 RESIZE = 299
+# The branches of a Mixed_* block are independent chains of small GEMMs (35 us launches that fill a fraction of the CUs):
+# each branch runs on a stream of its own, forward and backward, ordered by events on the tensors it reads and writes.
+# TGSR_TRUNK_STREAMS=1: everything on the caller's stream (the same kernels in the same order of accumulation: bit-identical).
+TRUNK_STREAMS = max(1, min(4, int(os.environ.get("TGSR_TRUNK_STREAMS", "4"))))
 
 
 class _Layer:
@@ -79,6 +86,10 @@ class InceptionTrunk:
                     if hasattr(sub, "conv") and hasattr(sub, "bn"):
                         self.layers[name + "." + bname] = _Layer(sub)
         self.tape = None
+        self.nstreams = TRUNK_STREAMS
+        self._side = None                      # the side streams (created on first use, distinct from the caller's)
+        self._streams = None                   # [caller's stream] + side streams of the walk in progress
+        self._pending = {}
 
     def refresh(self):
         for L in self.layers.values():
@@ -90,14 +101,74 @@ class InceptionTrunk:
         self.tensors.append(t)
         return len(self.tensors) - 1
 
-    def _ws(self, need, dev):
-        if need > self.ws.numel():
-            self.ws = torch.empty(need, dtype=torch.float32, device=dev)
-        return self.ws if need else None
+    def _ws(self, need, dev, s=0):
+        """Split-reduction workspace of stream index s (allocated on the caller's stream; a replaced buffer may still be read
+        by kernels queued on stream s: record_stream keeps the allocator from handing it out before they are done)."""
+        if need > self.wss[s].numel():
+            if s and self.wss[s].numel():
+                self.wss[s].record_stream(self._streams[s])
+            self.wss[s] = torch.empty(need, dtype=torch.float32, device=dev)
+        return self.wss[s] if need else None
 
-    def _conv(self, name, src, dst=None, coff=0):
-        """ConvBnRelu `name` on tensor id `src`; into channels [coff, coff + cout) of tensor id `dst` (a fresh tensor when None)."""
+    # ------------------------------------------------------------------ streams: a dataflow order over tensor ids
+    def _open_streams(self, dev):
+        """[the caller's stream, side streams...] for one walk; every tensor is allocated on the caller's stream (the `torch.empty`
+        calls sit outside the stream scopes) and every side stream is joined back before the walk returns."""
+        main = torch.cuda.current_stream(dev)
+        if self.nstreams > 1:
+            if self._side is None or any(int(st.cuda_stream) == int(main.cuda_stream) for st in self._side):
+                from .trainer import distinct_streams
+                self._side = distinct_streams(self.nstreams - 1, dev, avoid=[main.cuda_stream])
+            self._streams = [main] + list(self._side)
+        else:
+            self._streams = [main]
+        self._pending = {}
+        self.wss = [torch.empty(0, dtype=torch.float32, device=dev) for _ in self._streams]
+
+    def _join_streams(self):
+        """The caller's stream waits for everything queued on the side streams (the end of a walk)."""
+        main = self._streams[0]
+        for st in self._streams[1:]:
+            main.wait_stream(st)
+        self._pending = {}
+
+    def _fork_streams(self):
+        """Every side stream waits for what the caller's stream holds so far (weight packs, tensors written outside `_run`)."""
+        main = self._streams[0]
+        for st in self._streams[1:]:
+            st.wait_stream(main)
+
+    def _sidx(self, s):
+        return s % len(self._streams)
+
+    @contextlib.contextmanager
+    def _run(self, s, reads, write):
+        """Scope of ONE launch on stream index s: behind the writers of the tensors it reads and - for a gradient, which is
+        accumulated - behind the earlier writers of the tensor it writes, so that the sum keeps the order the host issues it in.
+        Keys: ("t", id) = a tensor (its writers fill disjoint channel slices of a concatenation: unordered among themselves),
+        ("g", id) = its gradient."""
+        if len(self._streams) == 1:
+            yield
+            return
+        st = self._streams[s]
+        for k in tuple(reads) + ((write,) if write[0] == "g" else ()):
+            for ps, ev in self._pending.get(k, ()):
+                if ps != s:
+                    st.wait_event(ev)
+        with torch.cuda.stream(st):
+            yield
+            ev = torch.cuda.Event()
+            ev.record(st)
+        if write[0] == "t":
+            self._pending.setdefault(write, []).append((s, ev))      # slices of a concatenation: every writer stays listed
+        else:
+            self._pending[write] = [(s, ev)]                           # ordered behind the earlier writers: it stands for them
+
+    def _conv(self, name, src, dst=None, coff=0, s=0):
+        """ConvBnRelu `name` on tensor id `src`; into channels [coff, coff + cout) of tensor id `dst` (a fresh tensor when None);
+        on stream index s."""
         L = self.layers[name]
+        s = self._sidx(s)
         x = self.tensors[src]
         B, Cs, H, W = x.shape
         if Cs != L.cin:
@@ -106,26 +177,31 @@ class InceptionTrunk:
         if dst is None:
             dst = self._new(B, L.cout, OH, OW, x.device)
         y = self.tensors[dst]
-        ws = self._ws(ops_ws(B, L.cout, OH, OW, L.cin * L.kh * L.kw), x.device)
-        C.gconv(False, L.wf, x, 0, L.cin, y, coff, L.kh, L.kw, L.stride, L.ph, L.pw, L.shift, True, False, ws, None)
-        self.tape.append(("conv", L, src, dst, coff))
+        ws = self._ws(ops_ws(B, L.cout, OH, OW, L.cin * L.kh * L.kw), x.device, s)
+        with self._run(s, [("t", src)], ("t", dst)):
+            C.gconv(False, L.wf, x, 0, L.cin, y, coff, L.kh, L.kw, L.stride, L.ph, L.pw, L.shift, True, False, ws, None)
+        self.tape.append(("conv", L, src, dst, coff, s))
         return dst
 
-    def _maxpool(self, src, dst=None, coff=0):
+    def _maxpool(self, src, dst=None, coff=0, s=0):
         x = self.tensors[src]
         B, Cc, H, W = x.shape
         OH, OW = _pool_hw(H, W)
         if dst is None:
             dst = self._new(B, Cc, OH, OW, x.device)
-        C.maxpool3s2(x, self.tensors[dst], coff)
-        self.tape.append(("maxpool", None, src, dst, coff))
+        s = self._sidx(s)
+        with self._run(s, [("t", src)], ("t", dst)):
+            C.maxpool3s2(x, self.tensors[dst], coff)
+        self.tape.append(("maxpool", None, src, dst, coff, s))
         return dst
 
-    def _avgpool(self, src):
+    def _avgpool(self, src, s=0):
         x = self.tensors[src]
         dst = self._new(*x.shape, x.device)
-        C.avgpool3(x, self.tensors[dst], False, None)
-        self.tape.append(("avgpool", None, src, dst, 0))
+        s = self._sidx(s)
+        with self._run(s, [("t", src)], ("t", dst)):
+            C.avgpool3(x, self.tensors[dst], False, None)
+        self.tape.append(("avgpool", None, src, dst, 0, s))
         return dst
 
     def _block(self, name, src):
@@ -140,54 +216,54 @@ class InceptionTrunk:
         if has("branch5x5_1"):                              # InceptionA: 1x1 | 1x1-5x5 | 1x1-3x3-3x3 | avg pool-1x1
             widths = [co("branch1x1"), co("branch5x5_2"), co("branch3x3dbl_3"), co("branch_pool")]
             out = self._new(B, sum(widths), H, W, dev)
-            self._conv(n("branch1x1"), src, out, 0)
-            self._conv(n("branch5x5_2"), self._conv(n("branch5x5_1"), src), out, widths[0])
-            t = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src))
-            self._conv(n("branch3x3dbl_3"), t, out, widths[0] + widths[1])
-            self._conv(n("branch_pool"), self._avgpool(src), out, widths[0] + widths[1] + widths[2])
+            self._conv(n("branch1x1"), src, out, 0, s=3)
+            self._conv(n("branch5x5_2"), self._conv(n("branch5x5_1"), src, s=1), out, widths[0], s=1)
+            t = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src, s=0), s=0)
+            self._conv(n("branch3x3dbl_3"), t, out, widths[0] + widths[1], s=0)
+            self._conv(n("branch_pool"), self._avgpool(src, s=2), out, widths[0] + widths[1] + widths[2], s=2)
             return out
         if has("branch7x7x3_1"):                            # InceptionD: 1x1-3x3 s2 | 1x1-1x7-7x1-3x3 s2 | max pool
             OH, OW = _pool_hw(H, W)
             widths = [co("branch3x3_2"), co("branch7x7x3_4"), x.shape[1]]
             out = self._new(B, sum(widths), OH, OW, dev)
-            self._conv(n("branch3x3_2"), self._conv(n("branch3x3_1"), src), out, 0)
-            t = self._conv(n("branch7x7x3_3"), self._conv(n("branch7x7x3_2"), self._conv(n("branch7x7x3_1"), src)))
-            self._conv(n("branch7x7x3_4"), t, out, widths[0])
-            self._maxpool(src, out, widths[0] + widths[1])
+            self._conv(n("branch3x3_2"), self._conv(n("branch3x3_1"), src, s=1), out, 0, s=1)
+            t = self._conv(n("branch7x7x3_3"), self._conv(n("branch7x7x3_2"), self._conv(n("branch7x7x3_1"), src, s=0), s=0), s=0)
+            self._conv(n("branch7x7x3_4"), t, out, widths[0], s=0)
+            self._maxpool(src, out, widths[0] + widths[1], s=2)
             return out
         if has("branch7x7_1"):                              # InceptionC: 1x1 | 1x1-1x7-7x1 | 1x1-7x1-1x7-7x1-1x7 | avg pool-1x1
             widths = [co("branch1x1"), co("branch7x7_3"), co("branch7x7dbl_5"), co("branch_pool")]
             out = self._new(B, sum(widths), H, W, dev)
-            self._conv(n("branch1x1"), src, out, 0)
-            self._conv(n("branch7x7_3"), self._conv(n("branch7x7_2"), self._conv(n("branch7x7_1"), src)), out, widths[0])
-            t = self._conv(n("branch7x7dbl_1"), src)
+            self._conv(n("branch1x1"), src, out, 0, s=3)
+            self._conv(n("branch7x7_3"), self._conv(n("branch7x7_2"), self._conv(n("branch7x7_1"), src, s=1), s=1), out, widths[0], s=1)
+            t = self._conv(n("branch7x7dbl_1"), src, s=0)
             for b in ("branch7x7dbl_2", "branch7x7dbl_3", "branch7x7dbl_4"):
-                t = self._conv(n(b), t)
-            self._conv(n("branch7x7dbl_5"), t, out, widths[0] + widths[1])
-            self._conv(n("branch_pool"), self._avgpool(src), out, widths[0] + widths[1] + widths[2])
+                t = self._conv(n(b), t, s=0)
+            self._conv(n("branch7x7dbl_5"), t, out, widths[0] + widths[1], s=0)
+            self._conv(n("branch_pool"), self._avgpool(src, s=2), out, widths[0] + widths[1] + widths[2], s=2)
             return out
         if has("branch3x3_2a"):                             # InceptionE: 1x1 | 1x1-(1x3, 3x1) | 1x1-3x3-(1x3, 3x1) | avg pool-1x1
             widths = [co("branch1x1"), co("branch3x3_2a"), co("branch3x3_2b"), co("branch3x3dbl_3a"), co("branch3x3dbl_3b"),
                       co("branch_pool")]
             out = self._new(B, sum(widths), H, W, dev)
             offs = [sum(widths[:i]) for i in range(6)]
-            self._conv(n("branch1x1"), src, out, 0)
-            a = self._conv(n("branch3x3_1"), src)
-            self._conv(n("branch3x3_2a"), a, out, offs[1])
-            self._conv(n("branch3x3_2b"), a, out, offs[2])
-            b_ = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src))
-            self._conv(n("branch3x3dbl_3a"), b_, out, offs[3])
-            self._conv(n("branch3x3dbl_3b"), b_, out, offs[4])
-            self._conv(n("branch_pool"), self._avgpool(src), out, offs[5])
+            self._conv(n("branch1x1"), src, out, 0, s=3)
+            a = self._conv(n("branch3x3_1"), src, s=1)
+            self._conv(n("branch3x3_2a"), a, out, offs[1], s=1)
+            self._conv(n("branch3x3_2b"), a, out, offs[2], s=3)
+            b_ = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src, s=0), s=0)
+            self._conv(n("branch3x3dbl_3a"), b_, out, offs[3], s=0)
+            self._conv(n("branch3x3dbl_3b"), b_, out, offs[4], s=2)
+            self._conv(n("branch_pool"), self._avgpool(src, s=2), out, offs[5], s=2)
             return out
         if has("branch3x3dbl_3") and has("branch3x3"):      # InceptionB: 3x3 s2 | 1x1-3x3-3x3 s2 | max pool
             OH, OW = _pool_hw(H, W)
             widths = [co("branch3x3"), co("branch3x3dbl_3"), x.shape[1]]
             out = self._new(B, sum(widths), OH, OW, dev)
-            self._conv(n("branch3x3"), src, out, 0)
-            t = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src))
-            self._conv(n("branch3x3dbl_3"), t, out, widths[0])
-            self._maxpool(src, out, widths[0] + widths[1])
+            self._conv(n("branch3x3"), src, out, 0, s=1)
+            t = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src, s=0), s=0)
+            self._conv(n("branch3x3dbl_3"), t, out, widths[0], s=0)
+            self._maxpool(src, out, widths[0] + widths[1], s=2)
             return out
         raise TgsrError("%s: not one of torchvision's Inception-v3 block layouts" % name)
 
@@ -198,9 +274,10 @@ class InceptionTrunk:
             raise TgsrError("InceptionTrunk: a HIP fp32 image batch [B, 3, H, W] expected, got %s %s" % (x.dtype, tuple(x.shape)))
         self.refresh()
         self.tensors, self.tape = [], []
-        self.ws = torch.empty(0, dtype=torch.float32, device=x.device)
+        self._open_streams(x.device)
         self.in_hw = (x.shape[2], x.shape[3])
         self.tensors.append(C.bilinear(x.contiguous(), RESIZE, RESIZE))                       # nn.Upsample(size=(299, 299), 'bilinear')
+        self._fork_streams()                                                                   # behind the weight packs and the resize
         t = 0
         self.marks = {"resize": 0}                                                             # name -> tensor id (diagnostics)
         for name in self.STEM[:3]:
@@ -215,6 +292,7 @@ class InceptionTrunk:
         for name in self.MIXED[8:]:
             t = self.marks[name] = self._block(name, t)
         self.last_id = t
+        self._join_streams()
         return self.tensors[self.feat_id], C.plane_mean(self.tensors[t])                      # F.avg_pool2d(x, 8) on the 8 x 8 map
 
     @torch.no_grad()
@@ -226,6 +304,7 @@ class InceptionTrunk:
         grads = [None] * len(T)
         self.snaps = {}
         last = T[self.last_id]
+        self._open_streams(last.device)
         # Every tensor but the resized image is the output of ReLU'd convolutions (or a pool of such): the factor (y > 0) of its
         # gradient distributes over the sum of its consumers' contributions, so each consumer applies it to its own contribution in
         # its epilogue (`mask`), and the two gradients that arrive from outside are masked once here.  (A max / average pool's output is
@@ -244,22 +323,28 @@ class InceptionTrunk:
                 grads[i] = torch.empty_like(T[i])
                 return grads[i], False, m
             return grads[i], True, m
-        for kind, L, src, dst, coff in reversed(self.tape):
+        self._fork_streams()                    # behind the gradients that arrived from outside (written on the caller's stream)
+        for kind, L, src, dst, coff, s in reversed(self.tape):
+            s = self._sidx(s)
             g = grads[dst]
             if g is None:                       # nothing downstream of this tensor reached the loss
                 continue
             if self.keep_grads and dst not in self.snaps:
+                self._join_streams()
                 self.snaps[dst] = g.clone()
+                self._fork_streams()
+            dx, acc, m = target(src)            # (allocated on the caller's stream, outside the launch's stream scope)
             if kind == "conv":
-                dx, acc, m = target(src)
-                ws = self._ws(ops_ws(dx.shape[0], L.cin, dx.shape[2], dx.shape[3], L.cout * L.kh * L.kw), dx.device)
-                C.gconv(True, L.wd, g, coff, L.cout, dx, 0, L.kh, L.kw, L.stride, L.ph, L.pw, None, False, acc, ws, m)
+                ws = self._ws(ops_ws(dx.shape[0], L.cin, dx.shape[2], dx.shape[3], L.cout * L.kh * L.kw), dx.device, s)
+                with self._run(s, [("g", dst)], ("g", src)):
+                    C.gconv(True, L.wd, g, coff, L.cout, dx, 0, L.kh, L.kw, L.stride, L.ph, L.pw, None, False, acc, ws, m)
             elif kind == "maxpool":
-                dx, acc, m = target(src)
-                C.maxpool3s2_bwd(T[src], g, coff, dx, acc, m)
+                with self._run(s, [("g", dst)], ("g", src)):
+                    C.maxpool3s2_bwd(T[src], g, coff, dx, acc, m)
             else:                               # avgpool3: symmetric
-                dx, acc, m = target(src)
-                C.avgpool3(g, dx, acc, m)
+                with self._run(s, [("g", dst)], ("g", src)):
+                    C.avgpool3(g, dx, acc, m)
+        self._join_streams()
         d299 = grads[0]
         if self.keep_grads:
             self.snaps[0] = d299

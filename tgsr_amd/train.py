@@ -16,6 +16,7 @@ Data parallel: gradients live in one flat bucket, one all-reduce per step (tgsr_
 """
 import contextlib
 import os
+import time
 
 import torch
 
@@ -37,6 +38,10 @@ def prepare_labels(batch_size, device):
 GRAPH_D_WARMUP = 3
 # eager steps before the generators' update is captured (the same, plus every weight pack of the step in the PackCache)
 GRAPH_G_WARMUP = 3
+# TGSR_GRAPH_G=auto: steps of each form (eager, replayed) the trainer times before it settles on the faster one
+GRAPH_G_TRIALS = 3
+# ... and the number of steps after which that choice has been made (warm-up, eager trials, the capturing step, replayed trials)
+GRAPH_G_SETTLED = GRAPH_G_WARMUP + 2 * GRAPH_G_TRIALS + 1
 
 
 class SRTrainer:
@@ -97,10 +102,19 @@ class SRTrainer:
         # keeps ahead) stay eager: the steps are DEVICE-bound (kernel time 12.1 ms, busy 9.6 ms of a 9.9 ms generator step), so
         # taking the host out buys nothing there.  TGSR_GRAPH_G=1 replays all of them (a loaded or slower host: under rocprofv3
         # the replayed generator step runs 10.7 ms, the eager one 15.7), 0 none.
+        # Which of the two wins is a property of the HOST the process lands on (round 6: the same tree ran the eager generator
+        # step in 9.9 ms on one box and 12.0 ms on another, whose replays would have taken 10.3), so "auto" MEASURES: after the
+        # warm-up it times GRAPH_G_TRIALS eager steps, captures, times as many replayed ones and keeps the faster form (with
+        # several ranks: the slowest rank's times, so that every rank takes the same one).  The rule above is only the form the
+        # first steps take; assigning `_graph_g` by hand ends the measurement and pins the form.
         mode = os.environ.get("TGSR_GRAPH_G", "auto")
+        self._auto = None
         self._graph_g = self.device.type == "cuda" and (mode == "1" or (mode == "auto" and bool(discriminators) and
                                                                          image_encoder is None))
         self._graph_capable = self.device.type == "cuda" and mode != "0"
+        if mode == "auto" and self.device.type == "cuda":
+            self._auto = {"eager_s": [], "replay_s": [], "t0": None, "form": None}
+        self.graph_policy = {"mode": mode, "prior": "replay" if self._graph_g else "eager"}
         self._ggraphs, self._gsteps, self._ghyper, self._g_bump = {}, 0, None, None
         self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999), fused=self._fused_adam,
                                     capturable=self._graph_capable)
@@ -148,6 +162,58 @@ class SRTrainer:
         taken = taken + [st.cuda_stream for st in self._dstreams]
         # the stream the generators' graphs are captured on, and the branch their re-pack launches fork onto
         self._gcap, self._gpack = distinct_streams(2, self.device, avoid=taken) if self._graph_capable else (None, None)
+
+    @property
+    def _graph_g(self):
+        return self._graph_g_value
+
+    @_graph_g.setter
+    def _graph_g(self, v):
+        self._graph_g_value = bool(v)
+        self._auto = None                    # an explicit choice ends the measured policy
+
+    # ------------------------------------------------------------------ TGSR_GRAPH_G=auto: the faster form, measured
+    def _auto_begin(self):
+        """Called at the top of a step: which form this step takes while the policy is still measuring (None = settled), and the
+        start of its clock.  Steps [WARMUP, WARMUP + TRIALS) are timed eager, step WARMUP + TRIALS captures (untimed), the next
+        TRIALS are timed replays; then `_auto_end` decides."""
+        a = self._auto
+        if a is None:
+            return
+        k = self._gsteps
+        a["form"] = "eager" if k < GRAPH_G_WARMUP + GRAPH_G_TRIALS else "replay"
+        timed = GRAPH_G_WARMUP <= k and k != GRAPH_G_WARMUP + GRAPH_G_TRIALS
+        if timed:
+            torch.cuda.synchronize(self.device)
+            a["t0"] = time.perf_counter()
+        else:
+            a["t0"] = None
+
+    def _auto_end(self, replayed):
+        a = self._auto
+        if a is None:
+            return
+        if a["t0"] is not None:
+            torch.cuda.synchronize(self.device)
+            dt = time.perf_counter() - a["t0"]
+            if a["form"] == "replay":
+                a["replay_s"].append(dt if replayed else float("inf"))     # (the capture failed or the configuration has none)
+            else:
+                a["eager_s"].append(dt)
+        if self._gsteps < GRAPH_G_SETTLED:
+            return
+        import statistics
+        te, tp = statistics.median(a["eager_s"]), statistics.median(a["replay_s"])
+        from .parallel import dp_world
+        if dp_world() > 1:
+            import torch.distributed as dist
+            t = torch.tensor([te, tp], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            te, tp = float(t[0]), float(t[1])
+        self._graph_g = tp <= te                                            # (the setter ends the measurement)
+        self.graph_policy.update({"eager_ms": round(te * 1e3, 3), "replay_ms": None if tp == float("inf") else round(tp * 1e3, 3),
+                                  "chosen": "replay" if tp <= te else "eager",
+                                  "trials": "median of %d steps of each form, device idle on both sides" % GRAPH_G_TRIALS})
 
     # ------------------------------------------------------------------ gradient all-reduce under the tail of backward
     def _arm_early(self):
@@ -381,7 +447,7 @@ class SRTrainer:
         """The captured update for this step's shapes: a dict of graphs and their static buffers, or None = take the eager step
         (warm-up, switched off, a configuration that needs a collective inside the loss, or a capture that failed)."""
         from .parallel import dp_world
-        use = self._graph_g and self._gsteps >= GRAPH_G_WARMUP
+        use = (self._graph_g if self._auto is None else self._auto["form"] == "replay") and self._gsteps >= GRAPH_G_WARMUP
         self._gsteps += 1
         if not use or (self.image_encoder is not None and self.gather_negatives and dp_world() > 1):
             return None                     # (DAMSM on the gathered global batch all-gathers inside generator_loss)
@@ -540,6 +606,7 @@ class SRTrainer:
         """One G/D alternation: forward the generators once; update every discriminator on (real, fake.detach());
         then update the generators through the UPDATED discriminators on the same fake images.  Returns
         (errG, [errD_i]) as detached tensors (buffers of the captures when the step is replayed: valid until the next step)."""
+        self._auto_begin()
         words_embs, sent_emb, mask = self._text(captions, cap_lens)
         g = self._g_graphs(True, LR, LRb, hr_pyramid, words_embs, sent_emb, mask, cap_lens, class_ids)
         if g is not None:
@@ -547,6 +614,7 @@ class SRTrainer:
             g["fwd"].replay()
             errsD = self._d_updates(g["fine"], g["hr"], g["sent"])
             errG = self._g_update_replay(g)
+            self._auto_end(True)
             return errG, [e.detach() for e in errsD]
         with self._use_packs():
             fake_imgL, fine_im, mu, logvar = self._forward_nets(LR, LRb, words_embs, sent_emb, mask)
@@ -567,6 +635,7 @@ class SRTrainer:
         self._all_reduce()
         self._g_finish()
         self._bump_g()
+        self._auto_end(False)
         return errG.detach(), [e.detach() for e in errsD]
 
     def step(self, captions, cap_lens, LR, LRb, hr_pyramid, class_ids=None):
@@ -575,11 +644,14 @@ class SRTrainer:
         replayed from hipGraphs (`_capture_g`), bit-identical to the eager one."""
         if self.netsD:
             return self.step_gan(captions, cap_lens, LR, LRb, hr_pyramid, class_ids)[0]
+        self._auto_begin()
         words_embs, sent_emb, mask = self._text(captions, cap_lens)
         g = self._g_graphs(False, LR, LRb, hr_pyramid, words_embs, sent_emb, mask, cap_lens, class_ids)
         if g is not None:
             self._g_load(g, LR, LRb, hr_pyramid, words_embs, sent_emb, mask)
-            return self._g_update_replay(g)
+            err = self._g_update_replay(g)
+            self._auto_end(True)
+            return err
         self._zero(self.bucket)
         try:
             with self._use_packs():
@@ -591,6 +663,7 @@ class SRTrainer:
         self._all_reduce()
         self._g_finish()
         self._bump_g()
+        self._auto_end(False)
         return errG.detach()
 
 
