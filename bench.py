@@ -291,7 +291,8 @@ def bench_train(args, rank, world, dist, dev, weights):
             "data": "synthetic inputs and HR targets",
             "config": {"workload": "CelebA x8 " + e["workload"] + ", batch=%d per GPU" % B, "batch_per_gpu": B,
                        "parallelism": "dp%d" % world, "grad_bucket_MB": e["grad_bucket_MB"]},
-            "final_loss": e["final_loss"], "roofline": e.get("roofline"),
+            "final_loss": e["final_loss"], "roofline": e.get("roofline"), "launch": e.get("launch"),
+            "graph_policy": e.get("graph_policy"), "device_time": e.get("device_time"),
             **({"cpu_baseline": e["cpu_baseline"]} if "cpu_baseline" in e else {})}), flush=True)
     if dist is not None:
         dist.barrier()

@@ -458,6 +458,17 @@ int tgsr_weighted_bce_fwd(const float* a, int na, const float* b, int nb, const 
 int tgsr_weighted_bce_bwd(const float* dy, const float* a, int na, const float* b, int nb, const float* target, const float* weight,
                           float* da, float* db, void* stream);
 
+/*
+ * Adam over flat fp32 buffers (torch.optim.Adam's update, trainer_objective.py's optimizers: no amsgrad; weight_decay = L2 added to
+ * the gradient), one pass: param, grad, exp_avg, exp_avg_sq are dense buffers of n floats, 16-byte aligned.  state = 3 device
+ * floats [step, 1 - beta1^step, sqrt(1 - beta2^step)]: advance != 0 first bumps the step and recomputes the two corrections on the
+ * device (a one-thread launch: the count survives hipGraph replays); a caller with several parameter ranges advances once and
+ * passes advance = 0 for the others.  The hyper-parameters arrive as the doubles the caller holds: 1 - beta is rounded to fp32 from
+ * the double difference, as torch does (1.f - 0.999f is 4.7e-5 away from 0.001f).
+ */
+int tgsr_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* state, int64_t n, double lr,
+                   double beta1, double beta2, double eps, double weight_decay, int advance, void* stream);
+
 int tgsr_axpy_map_fwd(const float* t, const float* s, const float* amap, float* out, int BC, int HW, void* stream);
 int tgsr_axpy_map_bwd(const float* dy, const float* s, const float* amap, float* ds, float* damap, int BC, int HW, void* stream);
 
@@ -479,6 +490,12 @@ int tgsr_affine_act_bwd(const float* dy, const float* out, const float* scale, f
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* Number of partial-sum splits tgsr_bn_train_* use for (B, C, HW); partial_ws must hold C * nsplit * 4 floats. */
+/*
+ * Small layers (one workgroup per channel covers the batch: B * HW < 8192, no GLU - the discriminators' 16^2 .. 4^2 maps) run the
+ * statistics / reduce pass INSIDE the normalise / apply kernel: one launch instead of two, bit-identical results.
+ * tgsr_bn_set_fuse_small(on): default on (TGSR_BN_FUSE_SMALL=0 in the environment turns it off); returns the previous setting.
+ */
+int tgsr_bn_set_fuse_small(int on);
 int tgsr_bn_train_nsplit(int B, int C, int HW);
 
 /*

@@ -288,3 +288,7 @@ def test_opcheck_round6_operators():
     chk(T.relu_mask_.default, (R(2, 5, 9, 9), x, 1, 3), test_utils=basic)
     chk(T.bilinear.default, (x, 13, 17), test_utils=basic)
     chk(T.bilinear_bwd.default, (R(2, 5, 13, 17), 9, 9), test_utils=basic)
+    # the flat Adam update: four in-place buffers and the device-side step state, all declared
+    n = 1000
+    chk(T.adam_flat_.default, (R(n), R(n), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV),
+                               torch.tensor([0.0, 1.0, 1.0], device=DEV), 1e-3, 0.5, 0.999, 1e-8, 0.0, True), test_utils=basic)

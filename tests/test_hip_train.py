@@ -720,3 +720,42 @@ def test_models16_train_mode_gradients():
         assert "a" in seen and any(k.startswith("h_net2.") for k in seen) and "img_net1.img.0.weight" in seen
     finally:
         cfg_reset()
+
+
+@pytest.mark.parametrize("B,C,H,W,act,res", [(16, 512, 16, 16, 2, False), (16, 2048, 4, 4, 2, False), (4, 7, 2, 2, 0, False),
+                                              (3, 33, 8, 8, 0, True), (16, 128, 16, 16, 2, False), (2, 5, 60, 32, 2, False)])
+def test_small_batchnorm_layers_in_one_launch_equal_the_two_pass_form_bit_for_bit(B, C, H, W, act, res):
+    """A layer whose channel fits one workgroup's walk (B * HW < 8192, no GLU: the discriminators' small maps) runs statistics +
+    normalise, and reduce + apply, as ONE launch each (ops.bn_set_fuse_small, the default): every output - activations, batch and
+    running statistics, the three gradients - carries the bits of the two-launch form."""
+    from tgsr_amd import _lib, ops
+    assert _lib.lib().tgsr_bn_train_nsplit(B, C, H * W) == 1
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    raw = (torch.randn(B, C, H, W, generator=g) * 1.7 + 0.3).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    resid = torch.randn(B, C, H, W, generator=g).to(DEV) if res else None
+    dout = torch.randn(B, C, H, W, generator=g).to(DEV)
+    outs = []
+    was = ops.bn_set_fuse_small(True)
+    try:
+        for fused in (True, False):
+            ops.bn_set_fuse_small(fused)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+            out, stats = ops.bn_train_fwd(raw, gamma, beta, 1e-5, 0.1, rm, rv, act=act, residual=resid, nbt=nbt)
+            draw, dgamma, dbeta = ops.bn_train_bwd(dout, raw, stats, act)
+            outs.append((out, stats, rm, rv, nbt, draw, dgamma, dbeta))
+    finally:
+        ops.bn_set_fuse_small(was)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # and against torch's own BatchNorm (fp64) for good measure
+    x64 = raw.double().cpu().requires_grad_(True)
+    y = torch.nn.functional.batch_norm(x64, None, None, gamma.double().cpu(), beta.double().cpu(), True, 0.1, 1e-5)
+    if res:
+        y = y + resid.double().cpu()
+    if act == 2:
+        y = torch.nn.functional.leaky_relu(y, 0.2)
+    y.backward(dout.double().cpu())
+    assert torch.allclose(outs[0][0].cpu().double(), y.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(outs[0][5].cpu().double(), x64.grad, rtol=1e-3, atol=2e-4)

@@ -17,7 +17,7 @@ EPI_AFFINE, EPI_AFFINE_GLU = 0, 1
 ACT_NONE, ACT_TANH_AXPY = 0, 1
 DT_BF16, DT_F16 = 1, 2
 
-_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 # name -> (restype, argtypes); must list every function of include/tgsr_hip.h (tests/test_abi.py checks it)
 SIGNATURES = {
@@ -73,6 +73,7 @@ SIGNATURES = {
                                _i64, _vp, _vp]),
     "tgsr_bn_train_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_dconv_set_split": (_i, [_i]),
+    "tgsr_bn_set_fuse_small": (_i, [_i]),
     "tgsr_conv4x4s2_split_form": (_i, [_i, _i, _i, _i, _i, _i]),
     "tgsr_conv3x3_gemm_split_form": (_i, [_i, _i, _i, _i, _i, _i]),
     "tgsr_conv4x4s2_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),
@@ -116,6 +117,7 @@ SIGNATURES = {
     "tgsr_relu_mask": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp]),
     "tgsr_bilinear_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
     "tgsr_bilinear_bwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "tgsr_adam_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _i, _vp]),
     "tgsr_weighted_bce_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "tgsr_weighted_bce_bwd": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_axpy_map_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),

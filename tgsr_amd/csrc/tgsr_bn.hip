@@ -44,15 +44,9 @@ struct BnWalk {
   }
 };
 
-// grid (C, nsplit): partial[c][s] = (sum, sumsq) of raw[b][c][:] over the b's / pixel ranges of split s
-__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __restrict__ raw, int64_t bstride, int B,
-                                                              int HW, float* __restrict__ partial, int nsplit) {
-  __shared__ float red[4];
-  const int c = blockIdx.x, sp = blockIdx.y;
-  const int64_t total = (int64_t)B * HW;
-  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
-  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
-  float s = 0.f, q = 0.f;
+// a thread's share of (sum, sumsq) over the slice [lo, hi) of channel c's B x HW values
+__device__ __forceinline__ void bn_stats_slice(const float* __restrict__ raw, int64_t bstride, int HW, int c, int64_t lo, int64_t hi,
+                                               float& s, float& q) {
   const bool vec = (HW & 3) == 0;
   if (vec) {
     BnWalk w(lo, hi, HW);
@@ -79,6 +73,18 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __res
       q += v * v;
     }
   }
+}
+
+// grid (C, nsplit): partial[c][s] = (sum, sumsq) of raw[b][c][:] over the b's / pixel ranges of split s
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __restrict__ raw, int64_t bstride, int B,
+                                                              int HW, float* __restrict__ partial, int nsplit) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
+  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
+  float s = 0.f, q = 0.f;
+  bn_stats_slice(raw, bstride, HW, c, lo, hi, s, q);
   s = block_sum(s, red);
   q = block_sum(q, red);
   if (threadIdx.x == 0) {
@@ -91,23 +97,18 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float* __res
 // passes of BatchNorm's forward / backward are VALU-bound (the step lost 14 % without packed math, csrc/Makefile)
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
-// Backward, pass 1.  grid (Co, nsplit).  For output channel c: GLU -> BN channels c (value) and c+Co (gate).
-// partial[c][s] = (sum dz_v, sum dz_v*xhat_v, sum dz_g, sum dz_g*xhat_g)   (non-GLU: the last two are 0)
+// Backward, pass 1: a thread's share, over the slice [lo, hi) of output channel c (GLU -> BN channels c (value) and c+Co (gate)), of
+// (sum dz_v, sum dz_v*xhat_v, sum dz_g, sum dz_g*xhat_g)   (non-GLU: the last two stay 0)
 template <bool GLU>
-__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
-    const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
-    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, float* __restrict__ partial, int nsplit, int leaky) {
-  __shared__ float red[4];
+__device__ __forceinline__ void bn_bwd_reduce_slice(const float* __restrict__ dout, const float* __restrict__ raw, int C, int HW, int c,
+                                                    int64_t lo, int64_t hi, int64_t per, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const float* __restrict__ mean,
+                                                    const float* __restrict__ invstd, int leaky, float& a0, float& a1, float& a2,
+                                                    float& a3) {
   const int Co = GLU ? C / 2 : C;
-  const int c = blockIdx.x, sp = blockIdx.y;
-  const int64_t total = (int64_t)B * HW;
-  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
-  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
   const float sv = scale[c], tv = shift[c], mv = mean[c], iv = invstd[c];
   float sg = 0.f, tg = 0.f, mg = 0.f, ig = 0.f;
   if (GLU) { sg = scale[c + Co]; tg = shift[c + Co]; mg = mean[c + Co]; ig = invstd[c + Co]; }
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   auto acc1 = [&](float dy, float rv, float rg) {
     if (GLU) {
       const float av = rv * sv + tv, s = sigm(rg * sg + tg);
@@ -147,6 +148,21 @@ __global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
            GLU ? raw[((int64_t)b * C + c + Co) * HW + p] : 0.f);
     }
   }
+}
+
+// grid (Co, nsplit): partial[c][s] = the four sums of slice s
+template <bool GLU>
+__global__ __launch_bounds__(kBnThreads) void bn_act_bwd_reduce_kernel(
+    const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ partial, int nsplit, int leaky) {
+  __shared__ float red[4];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int64_t total = (int64_t)B * HW;
+  const int64_t per = ((total + nsplit - 1) / nsplit + 3) & ~3ll;
+  const int64_t lo = sp * per, hi = lo + per < total ? lo + per : total;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  bn_bwd_reduce_slice<GLU>(dout, raw, C, HW, c, lo, hi, per, scale, shift, mean, invstd, leaky, a0, a1, a2, a3);
   a0 = block_sum(a0, red); a1 = block_sum(a1, red);
   if (GLU) { a2 = block_sum(a2, red); a3 = block_sum(a3, red); }
   if (threadIdx.x == 0) {
@@ -166,6 +182,31 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   return v;
+}
+
+// ONE thread: channel ch's (scale, shift) into bc[0..1] from its (sum, sum of squares); `publish` also writes the statistics.
+__device__ __forceinline__ void bn_affine_thread0(double s, double q, int ch, double count, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, float eps, float momentum, float* running_mean,
+                                                  float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                                  bool publish, float* bc) {
+  const double m = s / count;
+  double var = q / count - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[ch] * is, sh = beta[ch] - (float)m * sc;
+  bc[0] = sc;
+  bc[1] = sh;
+  if (publish) {
+    mean[ch] = (float)m;
+    invstd[ch] = is;
+    scale[ch] = sc;
+    shift[ch] = sh;
+    if (running_mean) {
+      const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+      running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+      running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
+    }
+  }
 }
 
 // channel ch: (scale, shift) from the statistics partials; slice-0 workgroups publish the statistics.
@@ -212,41 +253,38 @@ __device__ __forceinline__ void bn_channel_affine(const float* __restrict__ part
     }
     s = wave_sum_d(s);
     q = wave_sum_d(q);
-    if (threadIdx.x == 0) {
-      const double m = s / count;
-      double var = q / count - m * m;
-      var = var < 0.0 ? 0.0 : var;
-      const float is = (float)(1.0 / sqrt(var + (double)eps));
-      const float sc = gamma[ch] * is, sh = beta[ch] - (float)m * sc;
-      bc[0] = sc;
-      bc[1] = sh;
-      if (publish) {
-        mean[ch] = (float)m;
-        invstd[ch] = is;
-        scale[ch] = sc;
-        shift[ch] = sh;
-        if (running_mean) {
-          const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-          running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
-          running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unb;
-        }
-      }
-    }
+    if (threadIdx.x == 0)
+      bn_affine_thread0(s, q, ch, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, publish, bc);
   }
 }
 
-template <bool GLU>
+// FUSED (small layers - the discriminators' 16^2 .. 4^2 maps - where ONE workgroup per channel covers the whole batch, grid (C, 1),
+// no GLU): the statistics pass runs inside this kernel - the same per-thread sums in the same order as bn_stats_kernel with one
+// split, the same finalize: bit-identical to the two launches it replaces (the second read of the channel's <= 32 KB comes from L2).
+template <bool GLU, bool FUSED = false>
 __global__ __launch_bounds__(kBnThreads) void bn_fin_act_fwd_kernel(
     const float* __restrict__ raw, int B, int C, int HW, const float* __restrict__ partial, int nsplit_stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* running_mean,
     float* running_var, float* mean, float* invstd, float* scale, float* shift, long long* num_batches_tracked,
     const float* __restrict__ res, int64_t rbs, float* __restrict__ out, int64_t obs, int leaky, int nsplit) {
+  static_assert(!(GLU && FUSED), "the fused form serves the plain / LeakyReLU layers");
   __shared__ float bc[4];
   const int Co = GLU ? C / 2 : C;
   const int c = blockIdx.x, sp = blockIdx.y;
   const double count = (double)B * HW;
-  bn_channel_affine(partial, nsplit_stats, c, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
-                    scale, shift, sp == 0, bc);
+  if (FUSED) {
+    __shared__ float red[4];
+    float s = 0.f, q = 0.f;
+    bn_stats_slice(raw, (int64_t)C * HW, HW, c, 0, (int64_t)B * HW, s, q);
+    s = block_sum(s, red);
+    q = block_sum(q, red);
+    if (threadIdx.x == 0)
+      bn_affine_thread0((double)s, (double)q, c, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale,
+                        shift, true, bc);
+  } else {
+    bn_channel_affine(partial, nsplit_stats, c, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd,
+                      scale, shift, sp == 0, bc);
+  }
   if (GLU) {
     __syncthreads();      // (bc[0..1] written by thread 0; the gate channel goes to bc[2..3])
     bn_channel_affine(partial, nsplit_stats, c + Co, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
@@ -297,16 +335,30 @@ __global__ __launch_bounds__(kBnThreads) void bn_fin_act_fwd_kernel(
 }
 
 // Backward, pass 2 with the finalize folded in: grid (Co, nsplit) - the partials of bn_act_bwd_reduce_kernel on the same grid
-template <bool GLU>
+// FUSED (as the forward's: one workgroup per channel, no GLU): pass 1 runs inside this kernel, the same sums in the same order.
+template <bool GLU, bool FUSED = false>
 __global__ __launch_bounds__(kBnThreads) void bn_fin_act_bwd_apply_kernel(
     const float* __restrict__ dout, const float* __restrict__ raw, int B, int C, int HW,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ partial, int nsplit, float invN,
     float* __restrict__ draw, float* __restrict__ dgamma, float* __restrict__ dbeta, int leaky) {
+  static_assert(!(GLU && FUSED), "the fused form serves the plain / LeakyReLU layers");
   __shared__ float bs[4];
   const int Co = GLU ? C / 2 : C;
   const int c = blockIdx.x, sp = blockIdx.y;
-  if (threadIdx.x < 64) {
+  if (FUSED) {
+    __shared__ float red[4];
+    const int64_t tot = (int64_t)B * HW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    bn_bwd_reduce_slice<false>(dout, raw, C, HW, c, 0, tot, (tot + 3) & ~3ll, scale, shift, mean, invstd, leaky, a0, a1, a2, a3);
+    a0 = block_sum(a0, red);
+    a1 = block_sum(a1, red);
+    if (threadIdx.x == 0) {
+      bs[0] = a0; bs[1] = a1; bs[2] = 0.f; bs[3] = 0.f;
+      dbeta[c] = a0;
+      dgamma[c] = a1;
+    }
+  } else if (threadIdx.x < 64) {
     double a[4] = {0, 0, 0, 0};
     if ((int)threadIdx.x < nsplit)
       for (int j = 0; j < 4; ++j) a[j] = partial[((int64_t)c * nsplit + threadIdx.x) * 4 + j];
@@ -403,6 +455,12 @@ __global__ __launch_bounds__(256) void sumpool2x2_kernel(const float* __restrict
   }
 }
 
+static int g_bn_fuse_small = [] {
+  const char* e = getenv("TGSR_BN_FUSE_SMALL");
+  return (e && e[0] == '0') ? 0 : 1;
+}();
+static inline bool bn_fuse_small() { return g_bn_fuse_small != 0; }
+
 static inline int grid_for(int64_t n) {
   int64_t g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -411,6 +469,12 @@ static inline int grid_for(int64_t n) {
 }  // namespace tgsr
 
 using namespace tgsr;
+
+extern "C" int tgsr_bn_set_fuse_small(int on) {
+  const int was = g_bn_fuse_small;
+  g_bn_fuse_small = on ? 1 : 0;
+  return was;
+}
 
 extern "C" int tgsr_bn_train_nsplit(int B, int C, int HW) {
   // enough workgroups to fill the chip (>= 1024) without splitting below ~4k elements per workgroup
@@ -436,12 +500,20 @@ static int bn_train_fwd(const float* raw, int B, int C, int HW, const float* gam
   // given_nsplit > 0: partial_ws already holds that many (sum, sumsq) pairs per channel (a convolution's epilogue wrote
   // them): the statistics pass over the raw tensor is not launched
   const int nsplit = given_nsplit > 0 ? given_nsplit : tgsr_bn_train_nsplit(B, C, HW);
-  if (given_nsplit <= 0)
+  // one workgroup per channel covers the batch: statistics and normalisation in ONE launch (bit-identical; TGSR_BN_FUSE_SMALL=0: two)
+  const bool fused = given_nsplit <= 0 && nsplit == 1 && !glu && bn_fuse_small();
+  if (given_nsplit <= 0 && !fused)
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, nsplit), dim3(kBnThreads), 0, s, raw, (int64_t)C * HW, B, HW,
                        partial_ws, nsplit);
   const int Co = glu ? C / 2 : C;
   const int ns2 = tgsr_bn_train_nsplit(B, Co, HW);
   long long* nbt = reinterpret_cast<long long*>(num_batches_tracked);
+  if (fused) {
+    hipLaunchKernelGGL((bn_fin_act_fwd_kernel<false, true>), dim3(C, 1), dim3(kBnThreads), 0, s, raw, B, C, HW, partial_ws, 1, gamma,
+                       beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, nbt, residual, res_bstride, out,
+                       out_bstride, leaky, 1);
+    return note_launch(hipGetLastError(), "bn_train_fwd");
+  }
   if (glu)
     hipLaunchKernelGGL(bn_fin_act_fwd_kernel<true>, dim3(Co, ns2), dim3(kBnThreads), 0, s, raw, B, C, HW, partial_ws, nsplit,
                        gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift, nbt, nullptr,
@@ -488,6 +560,11 @@ extern "C" int tgsr_bn_train_bwd(const float* dout, const float* raw, int B, int
   const int nsplit = tgsr_bn_train_nsplit(B, Co, HW);
   const float invN = (float)(1.0 / ((double)B * HW));
   (void)sums_ws;                         // (was the finalize kernel's output; the apply pass combines the partials itself)
+  if (nsplit == 1 && !glu && bn_fuse_small()) {            // both passes in one launch (see bn_fin_act_bwd_apply_kernel)
+    hipLaunchKernelGGL((bn_fin_act_bwd_apply_kernel<false, true>), dim3(Co, 1), dim3(kBnThreads), 0, s, dout, raw, B, C, HW, scale,
+                       shift, mean, invstd, partial_ws, 1, invN, draw, dgamma, dbeta, leaky);
+    return note_launch(hipGetLastError(), "bn_train_bwd");
+  }
   if (glu) {
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<true>, dim3(Co, nsplit), dim3(kBnThreads), 0, s, dout, raw, B, C, HW,
                        scale, shift, mean, invstd, partial_ws, nsplit, 0);

@@ -463,13 +463,21 @@ extern "C" int tgsr_gconv_set_form(int split) {
   return was;
 }
 
-// How many K slabs a shape is split into (1 = none): fill ~2 workgroups per CU when M x N alone cannot.
+// Workgroups a launch should reach before the reduction is split no further (TGSR_GCONV_FILL; default 320 = ~1.25 per CU: the
+// trunk's branches run side by side on streams of their own, inception.py, so a launch need not fill the chip alone).
+static int g_gconv_fill = [] {
+  const char* e = getenv("TGSR_GCONV_FILL");
+  const int v = e ? atoi(e) : 320;
+  return v < 1 ? 320 : v;
+}();
+
+// How many K slabs a shape is split into (1 = none): fill ~g_gconv_fill workgroups when M x N alone cannot.
 extern "C" int tgsr_gconv_nsplit(int M, int N, int K) {
   const bool wide = M <= 64;
   const int64_t tiles = (int64_t)((M + (wide ? 63 : 127)) / (wide ? 64 : 128)) * ((N + (wide ? 255 : 127)) / (wide ? 256 : 128));
   const int chunks = (K + kGcKC - 1) / kGcKC;
-  if (tiles >= 192 || chunks < 16) return 1;               // (every split costs a finishing launch: ~7 us each, 140 per step before)
-  int64_t s = (320 + tiles - 1) / tiles;
+  if (tiles >= 192 || tiles * 5 >= g_gconv_fill * 3 || chunks < 16) return 1;   // (every split costs a finishing launch: ~7 us each)
+  int64_t s = (g_gconv_fill + tiles - 1) / tiles;
   if (s > chunks / 8) s = chunks / 8;                      // at least 8 chunks (128 k) per slab
   if (s > 32) s = 32;
   return (int)(s < 1 ? 1 : s);

@@ -517,6 +517,10 @@ bilinear = _define("bilinear(Tensor x, int OH, int OW) -> Tensor", lambda x, OH,
                    lambda x, OH, OW: x.new_empty(x.shape[0], x.shape[1], OH, OW))
 bilinear_bwd = _define("bilinear_bwd(Tensor dy, int H, int W) -> Tensor", lambda dy, H, W: ops.bilinear_bwd(dy, H, W),
                        lambda dy, H, W: dy.new_empty(dy.shape[0], dy.shape[1], H, W))
+adam_flat_ = _define("adam_flat_(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) state, float lr, "
+                     "float beta1, float beta2, float eps, float weight_decay, bool advance) -> ()",
+                     lambda p, g, m, v, st, lr, b1, b2, eps, wd, adv: ops.adam_flat(p, g, m, v, st, lr, b1, b2, eps, wd, adv),
+                     lambda *a: None)
 weighted_bce = _define("weighted_bce(Tensor a, Tensor? b, Tensor target, Tensor weight) -> Tensor",
                        lambda a, b, t, w: ops.weighted_bce(a, b, t, w), lambda a, b, t, w: a.new_empty(()))
 

@@ -23,8 +23,10 @@ from ._lib import TgsrError
 
 RESIZE = 299
 # The branches of a Mixed_* block are independent chains of small GEMMs (35 us launches that fill a fraction of the CUs):
-# each branch runs on a stream of its own, forward and backward, ordered by events on the tensors it reads and writes.
-# TGSR_TRUNK_STREAMS=1: everything on the caller's stream (the same kernels in the same order of accumulation: bit-identical).
+# each branch runs on a stream of its own, forward and backward, as plain fork / join diamonds off the caller's stream per block (no
+# edge between two side streams: a fork nested inside a forked branch is what ROCm 7.2's stream capture does not survive, and the
+# walk is captured into the generators' hipGraphs).  TGSR_TRUNK_STREAMS=1: everything on the caller's stream (the same kernels in
+# the same order of accumulation: bit-identical).
 TRUNK_STREAMS = max(1, min(4, int(os.environ.get("TGSR_TRUNK_STREAMS", "4"))))
 
 
@@ -89,7 +91,6 @@ class InceptionTrunk:
         self.nstreams = TRUNK_STREAMS
         self._side = None                      # the side streams (created on first use, distinct from the caller's)
         self._streams = None                   # [caller's stream] + side streams of the walk in progress
-        self._pending = {}
 
     def refresh(self):
         for L in self.layers.values():
@@ -102,11 +103,11 @@ class InceptionTrunk:
         return len(self.tensors) - 1
 
     def _ws(self, need, dev, s=0):
-        """Split-reduction workspace of stream index s (allocated on the caller's stream; a replaced buffer may still be read
-        by kernels queued on stream s: record_stream keeps the allocator from handing it out before they are done)."""
+        """Split-reduction workspace of stream index s (allocated on the caller's stream).  A buffer that is outgrown stays
+        referenced until the next walk opens: kernels queued on stream s may still read it, and the allocator - which knows only
+        the caller's stream - must not hand its memory to another stream's workspace meanwhile."""
         if need > self.wss[s].numel():
-            if s and self.wss[s].numel():
-                self.wss[s].record_stream(self._streams[s])
+            self._ws_old.append(self.wss[s])
             self.wss[s] = torch.empty(need, dtype=torch.float32, device=dev)
         return self.wss[s] if need else None
 
@@ -122,15 +123,14 @@ class InceptionTrunk:
             self._streams = [main] + list(self._side)
         else:
             self._streams = [main]
-        self._pending = {}
         self.wss = [torch.empty(0, dtype=torch.float32, device=dev) for _ in self._streams]
+        self._ws_old = []
 
     def _join_streams(self):
         """The caller's stream waits for everything queued on the side streams (the end of a walk)."""
         main = self._streams[0]
         for st in self._streams[1:]:
             main.wait_stream(st)
-        self._pending = {}
 
     def _fork_streams(self):
         """Every side stream waits for what the caller's stream holds so far (weight packs, tensors written outside `_run`)."""
@@ -142,27 +142,16 @@ class InceptionTrunk:
         return s % len(self._streams)
 
     @contextlib.contextmanager
-    def _run(self, s, reads, write):
-        """Scope of ONE launch on stream index s: behind the writers of the tensors it reads and - for a gradient, which is
-        accumulated - behind the earlier writers of the tensor it writes, so that the sum keeps the order the host issues it in.
-        Keys: ("t", id) = a tensor (its writers fill disjoint channel slices of a concatenation: unordered among themselves),
-        ("g", id) = its gradient."""
-        if len(self._streams) == 1:
+    def _run(self, s):
+        """Scope of a launch on stream index s.  Inside a block (between `_fork_streams` and `_join_streams`) every branch keeps to
+        ONE stream, reads what existed at the fork (the block input / the gradient of the block output) or what its own stream
+        produced, and writes tensors - or channel slices - no other branch touches; the gradient of the block input, which every
+        branch adds to, is written after the join, on the caller's stream (`backward`)."""
+        if s == 0:
             yield
             return
-        st = self._streams[s]
-        for k in tuple(reads) + ((write,) if write[0] == "g" else ()):
-            for ps, ev in self._pending.get(k, ()):
-                if ps != s:
-                    st.wait_event(ev)
-        with torch.cuda.stream(st):
+        with torch.cuda.stream(self._streams[s]):
             yield
-            ev = torch.cuda.Event()
-            ev.record(st)
-        if write[0] == "t":
-            self._pending.setdefault(write, []).append((s, ev))      # slices of a concatenation: every writer stays listed
-        else:
-            self._pending[write] = [(s, ev)]                           # ordered behind the earlier writers: it stands for them
 
     def _conv(self, name, src, dst=None, coff=0, s=0):
         """ConvBnRelu `name` on tensor id `src`; into channels [coff, coff + cout) of tensor id `dst` (a fresh tensor when None);
@@ -178,7 +167,7 @@ class InceptionTrunk:
             dst = self._new(B, L.cout, OH, OW, x.device)
         y = self.tensors[dst]
         ws = self._ws(ops_ws(B, L.cout, OH, OW, L.cin * L.kh * L.kw), x.device, s)
-        with self._run(s, [("t", src)], ("t", dst)):
+        with self._run(s):
             C.gconv(False, L.wf, x, 0, L.cin, y, coff, L.kh, L.kw, L.stride, L.ph, L.pw, L.shift, True, False, ws, None)
         self.tape.append(("conv", L, src, dst, coff, s))
         return dst
@@ -190,7 +179,7 @@ class InceptionTrunk:
         if dst is None:
             dst = self._new(B, Cc, OH, OW, x.device)
         s = self._sidx(s)
-        with self._run(s, [("t", src)], ("t", dst)):
+        with self._run(s):
             C.maxpool3s2(x, self.tensors[dst], coff)
         self.tape.append(("maxpool", None, src, dst, coff, s))
         return dst
@@ -199,13 +188,22 @@ class InceptionTrunk:
         x = self.tensors[src]
         dst = self._new(*x.shape, x.device)
         s = self._sidx(s)
-        with self._run(s, [("t", src)], ("t", dst)):
+        with self._run(s):
             C.avgpool3(x, self.tensors[dst], False, None)
         self.tape.append(("avgpool", None, src, dst, 0, s))
         return dst
 
     def _block(self, name, src):
-        """One Mixed_* block by torchvision's branch names; returns the id of its concatenated output."""
+        """One Mixed_* block: its branches between a fork and a join of the side streams; returns the id of the concatenation."""
+        self._fork_streams()
+        self.tape.append(("fork", None, src, None, 0, 0))
+        out = self._branches(name, src)
+        self.tape.append(("join", None, src, out, 0, 0))
+        self._join_streams()
+        return out
+
+    def _branches(self, name, src):
+        """The branches of one Mixed_* block by torchvision's names (every branch on one stream index)."""
         blk = getattr(self.enc, name)
         x = self.tensors[src]
         B, _, H, W = x.shape
@@ -250,10 +248,10 @@ class InceptionTrunk:
             self._conv(n("branch1x1"), src, out, 0, s=3)
             a = self._conv(n("branch3x3_1"), src, s=1)
             self._conv(n("branch3x3_2a"), a, out, offs[1], s=1)
-            self._conv(n("branch3x3_2b"), a, out, offs[2], s=3)
+            self._conv(n("branch3x3_2b"), a, out, offs[2], s=1)
             b_ = self._conv(n("branch3x3dbl_2"), self._conv(n("branch3x3dbl_1"), src, s=0), s=0)
             self._conv(n("branch3x3dbl_3a"), b_, out, offs[3], s=0)
-            self._conv(n("branch3x3dbl_3b"), b_, out, offs[4], s=2)
+            self._conv(n("branch3x3dbl_3b"), b_, out, offs[4], s=0)
             self._conv(n("branch_pool"), self._avgpool(src, s=2), out, offs[5], s=2)
             return out
         if has("branch3x3dbl_3") and has("branch3x3"):      # InceptionB: 3x3 s2 | 1x1-3x3-3x3 s2 | max pool
@@ -277,7 +275,6 @@ class InceptionTrunk:
         self._open_streams(x.device)
         self.in_hw = (x.shape[2], x.shape[3])
         self.tensors.append(C.bilinear(x.contiguous(), RESIZE, RESIZE))                       # nn.Upsample(size=(299, 299), 'bilinear')
-        self._fork_streams()                                                                   # behind the weight packs and the resize
         t = 0
         self.marks = {"resize": 0}                                                             # name -> tensor id (diagnostics)
         for name in self.STEM[:3]:
@@ -292,7 +289,6 @@ class InceptionTrunk:
         for name in self.MIXED[8:]:
             t = self.marks[name] = self._block(name, t)
         self.last_id = t
-        self._join_streams()
         return self.tensors[self.feat_id], C.plane_mean(self.tensors[t])                      # F.avg_pool2d(x, 8) on the 8 x 8 map
 
     @torch.no_grad()
@@ -323,28 +319,49 @@ class InceptionTrunk:
                 grads[i] = torch.empty_like(T[i])
                 return grads[i], False, m
             return grads[i], True, m
-        self._fork_streams()                    # behind the gradients that arrived from outside (written on the caller's stream)
-        for kind, L, src, dst, coff, s in reversed(self.tape):
-            s = self._sidx(s)
+        def one(kind, L, src, dst, coff, s):
             g = grads[dst]
             if g is None:                       # nothing downstream of this tensor reached the loss
-                continue
+                return
             if self.keep_grads and dst not in self.snaps:
-                self._join_streams()
+                if block_src is not None:
+                    self._join_streams()
                 self.snaps[dst] = g.clone()
-                self._fork_streams()
+                if block_src is not None:
+                    self._fork_streams()
             dx, acc, m = target(src)            # (allocated on the caller's stream, outside the launch's stream scope)
             if kind == "conv":
                 ws = self._ws(ops_ws(dx.shape[0], L.cin, dx.shape[2], dx.shape[3], L.cout * L.kh * L.kw), dx.device, s)
-                with self._run(s, [("g", dst)], ("g", src)):
+                with self._run(s):
                     C.gconv(True, L.wd, g, coff, L.cout, dx, 0, L.kh, L.kw, L.stride, L.ph, L.pw, None, False, acc, ws, m)
             elif kind == "maxpool":
-                with self._run(s, [("g", dst)], ("g", src)):
+                with self._run(s):
                     C.maxpool3s2_bwd(T[src], g, coff, dx, acc, m)
             else:                               # avgpool3: symmetric
-                with self._run(s, [("g", dst)], ("g", src)):
+                with self._run(s):
                     C.avgpool3(g, dx, acc, m)
-        self._join_streams()
+
+        # A block's backward: fork, every branch's layers on its stream EXCEPT the ones that add into the gradient of the block
+        # input (the head of every branch) - those run after the join, on the caller's stream, in the order of the tape: the sum
+        # is formed in the same order as on one stream.
+        block_src, heads = None, []
+        for kind, L, src, dst, coff, s in reversed(self.tape):
+            if kind == "join":                  # (the end of a block in the forward walk = where its backward begins)
+                if grads[dst] is not None:
+                    block_src, heads = src, []
+                    self._fork_streams()
+                continue
+            if kind == "fork":
+                if block_src is not None:
+                    self._join_streams()
+                    block_src = None
+                    for h in heads:
+                        one(*h[:5], 0)
+                continue
+            if block_src is not None and src == block_src:
+                heads.append((kind, L, src, dst, coff))
+                continue
+            one(kind, L, src, dst, coff, self._sidx(s) if block_src is not None else 0)
         d299 = grads[0]
         if self.keep_grads:
             self.snaps[0] = d299

@@ -955,6 +955,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 
 # ----------------------------------------------------------------------------------------- training path primitives
+def bn_set_fuse_small(on: bool) -> bool:
+    """Small BatchNorm layers (one workgroup per channel) as one launch per direction (default) or two; returns the previous setting."""
+    return bool(_lib.lib().tgsr_bn_set_fuse_small(1 if on else 0))
+
+
 def bn_train_fwd(raw: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, momentum: float,
                  running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], act: int = 0,
                  residual: Optional[torch.Tensor] = None, nbt: Optional[torch.Tensor] = None,
@@ -1282,6 +1287,21 @@ def axpy_images(ts, ss, alpha: float, outs=None):
     check(_lib.lib().tgsr_axpy_images(n, op, tp, sp, ne, float(alpha), _stream()), "tgsr_axpy_images")
     return outs
 
+
+
+def adam_flat(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, state: torch.Tensor,
+              lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, advance: bool) -> None:
+    """One Adam update over flat buffers, in place (tgsr_adam_flat): `state` = 3 device floats [step, 1 - b1^t, sqrt(1 - b2^t)],
+    advanced on the device first when `advance`."""
+    _need_hip(param, grad, exp_avg, exp_avg_sq, state)
+    n = param.numel()
+    for t in (param, grad, exp_avg, exp_avg_sq):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise TgsrError("adam_flat: dense fp32 buffers of one length expected")
+    if state.dtype != torch.float32 or state.numel() != 3 or not state.is_contiguous():
+        raise TgsrError("adam_flat: state = 3 fp32 values")
+    check(_lib.lib().tgsr_adam_flat(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(state), n, float(lr), float(beta1),
+                                    float(beta2), float(eps), float(weight_decay), 1 if advance else 0, _stream()), "tgsr_adam_flat")
 
 def weighted_bce(a: torch.Tensor, b: Optional[torch.Tensor], target: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """sum_i weight[i] * BCEWithLogits([a; b][i], target[i]) as a 0-dim tensor (the adversarial terms of the GAN losses)."""

@@ -92,15 +92,18 @@ class FlatGradBucket:
         if not self.params:
             raise ValueError("FlatGradBucket: no trainable parameters")
         dev, dt = self.params[0].device, self.params[0].dtype
-        self.numel = sum(p.numel() for p in self.params)
+        # every parameter's region starts on a multiple of 4 elements (16 bytes): optim.FlatAdam lays the PARAMETERS out the same
+        # way, and the kernels want 16-byte aligned weights; the padding elements stay zero (gradient, moments and update)
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append((off, p.numel()))
+            off += (p.numel() + 3) & ~3
+        self.numel = off
         self.buffers: List[torch.Tensor] = [b for b in buffers if b.is_floating_point() and b.dtype == dt]
         self.flat_all = torch.zeros(self.numel + sum(b.numel() for b in self.buffers), dtype=dt, device=dev)
         self.flat = self.flat_all[:self.numel]                 # the gradients (what begin_step zeroes, what is clipped)
-        self.views, self.offsets, off = [], [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            self.offsets.append((off, p.numel()))
-            off += p.numel()
+        self.views = [self.flat[o:o + n].view_as(p) for p, (o, n) in zip(self.params, self.offsets)]
+        off = self.numel
         self.buf_views = []
         for b in self.buffers:
             self.buf_views.append(self.flat_all[off:off + b.numel()].view_as(b))

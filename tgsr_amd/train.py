@@ -85,7 +85,7 @@ class SRTrainer:
         self._bucket_bufs = list(self.netGL.buffers()) + list(self.netGH.buffers())
         self._gh_params = gh_params
         self._early_n = len(gh_params)                                   # parameters of the early range
-        self._early_hi = sum(p.numel() for p in gh_params)               # ... = flat[0:_early_hi]
+        self._early_hi = None                                            # ... = flat[0:_early_hi], set once the bucket exists
         self._early_on = os.environ.get("TGSR_EARLY_ALLREDUCE", "1") != "0"
         self._early_left, self._early = -1, None
         self._comm = distinct_streams(1, self.device, avoid=cur + ([self._wside.cuda_stream] if self._wside is not None else []))[0] \
@@ -116,8 +116,10 @@ class SRTrainer:
             self._auto = {"eager_s": [], "replay_s": [], "t0": None, "form": None}
         self.graph_policy = {"mode": mode, "prior": "replay" if self._graph_g else "eager"}
         self._ggraphs, self._gsteps, self._ghyper, self._g_bump = {}, 0, None, None
-        self.opt = torch.optim.Adam(self.params, lr=lr or cfg.TRAIN.GENERATOR_LR, betas=(0.5, 0.999), fused=self._fused_adam,
-                                    capturable=self._graph_capable)
+        # TGSR_FLAT_ADAM (default on, HIP only): parameters and moments re-homed into flat buffers beside the flat gradient bucket,
+        # the update ONE launch of tgsr::adam_flat_ (optim.FlatAdam; the same rule as torch.optim.Adam); 0 = torch's fused Adam
+        self._flat_adam = self.device.type == "cuda" and os.environ.get("TGSR_FLAT_ADAM", "1") != "0"
+        self._g_lr = lr or cfg.TRAIN.GENERATOR_LR
         self.ema_decay = ema_decay
         self.avg_param_G = copy_G_params(self.netGL) + copy_G_params(self.netGH)
         self.netsD, self.optsD, self.bucketsD = [], [], []
@@ -137,14 +139,26 @@ class SRTrainer:
                 self.bucketsD.append(FlatGradBucket(d.parameters(), buffers=d.buffers()).attach())
                 # (fused: one pass over a discriminator's ~70 M parameters and their moments instead of the ~10 of the
                 # multi-tensor form - 2.0 ms of a G/D step were Adam kernels running alone on the device)
-                self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR, betas=(0.5, 0.999),
-                                                   capturable=self._graph_d, fused=self._fused_adam))
+                if self._flat_adam:
+                    from .optim import FlatAdam
+                    self.optsD.append(FlatAdam(self.bucketsD[-1].params, self.bucketsD[-1].flat, lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR,
+                                               betas=(0.5, 0.999)))
+                else:
+                    self.optsD.append(torch.optim.Adam(d.parameters(), lr=d_lr or cfg.TRAIN.DISCRIMINATOR_LR, betas=(0.5, 0.999),
+                                                       capturable=self._graph_d, fused=self._fused_adam))
         if self.netsD:
             # the generator loss runs the train-mode discriminators on the fake images once more (g_loss): their running
             # statistics move again, per rank, AFTER their own bucket's all-reduce - so they also ride the generators' bucket
             # and every rank leaves the step with the same discriminator buffers (a snapshot is the same file on every rank)
             self._bucket_bufs = self._bucket_bufs + [b for d in self.netsD for b in d.buffers()]
         self.bucket = FlatGradBucket(gh_params + list(self.netGL.parameters()), buffers=self._bucket_bufs).attach()
+        self._early_hi = self.bucket.offsets[self._early_n][0] if self._early_n < len(self.bucket.params) else self.bucket.numel
+        if self._flat_adam:
+            from .optim import FlatAdam
+            self.opt = FlatAdam(self.bucket.params, self.bucket.flat, lr=self._g_lr, betas=(0.5, 0.999))
+        else:
+            self.opt = torch.optim.Adam(self.params, lr=self._g_lr, betas=(0.5, 0.999), fused=self._fused_adam,
+                                        capturable=self._graph_capable)
         # TGSR_COMM=direct: the buckets' closing all-reduce through the library's own RCCL communicator (tgsr_allreduce_flat,
         # parallel.RcclDirect) instead of torch.distributed's; the early range and the DAMSM gather stay on the process group
         self._rccl = None
