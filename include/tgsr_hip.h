@@ -428,7 +428,16 @@ int tgsr_axpy_images(int n, float* const* out, const float* const* t, const floa
  * tgsr_plane_mean(_bwd): the 8 x 8 global average (F.avg_pool2d(x, 8) on an 8 x 8 map).  tgsr_relu_mask: out = dy * (y > 0).
  * tgsr_bilinear_*: nn.Upsample(size = (OH, OW), mode = 'bilinear') (align_corners = False), util.py:310, on dense planes.
  */
-int tgsr_gconv_set_form(int split); /* 1 (default): three-piece bf16 form where K % 16 == 0, <= 25 taps, stride-1 data gradient; 0: fp32 MFMA.  Returns the old value */
+int tgsr_gconv_set_form(int split); /*
+ * dx[b][c][2Y + py][2X + px] (+)= t_{py px}[b][c][Y][X] over `planes` = B * C dense planes of H x W: weaves the four parity classes of
+ * a stride-2 convolution's data gradient - each a stride-1 data gradient over its own taps (tgsr_gconv), dense at half resolution,
+ * ceil((H - py) / 2) x ceil((W - px) / 2) pixels - into the gradient of the input (util.py:281-298's stride-2 layers: a quarter of the
+ * products of the direct form).  mask (dense, like dx) keeps the value where mask > 0; accumulate != 0 adds.
+ */
+int tgsr_interleave2x2(const float* t00, const float* t01, const float* t10, const float* t11, float* dx, int64_t planes, int H, int W,
+                       int accumulate, const float* mask, void* stream);
+
+/* 1 (default): three-piece bf16 form where K % 16 == 0, <= 25 taps, stride-1 data gradient; 0: fp32 MFMA.  Returns the old value */
 int tgsr_gconv_nsplit(int M, int N, int K);
 int64_t tgsr_gconv_ws_elems(int B, int M, int PH, int PW, int K);
 int tgsr_gconv(int dgrad, const float* A, const float* S, int64_t s_bstride, int B, int Hs, int Ws, int M, int K, int PH, int PW,

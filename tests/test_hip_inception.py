@@ -264,3 +264,57 @@ def test_branch_streams_equal_the_single_stream_walk_bit_for_bit():
         assert torch.equal(f, ref[0]) and torch.equal(p, ref[1]) and torch.equal(gx, ref[2])
     finally:
         cfg_reset()
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,pad", [(2, 288, 35, 35, 384, 3, 0), (2, 96, 35, 35, 96, 3, 0), (3, 192, 17, 17, 320, 3, 0),
+                                                  (2, 16, 12, 14, 32, 4, 0), (1, 32, 9, 11, 16, 5, 0), (2, 8, 6, 6, 16, 2, 0),
+                                                  (2, 16, 12, 14, 32, 4, 1), (2, 16, 12, 13, 32, 3, 0)])
+def test_stride2_data_gradient_by_parity_classes_matches_the_direct_form(B, Cin, H, W, Cout, k, pad):
+    """inception._Layer's class form of a stride-2 layer's data gradient (four stride-1 tgsr::gconv launches over the taps of each
+    input-pixel parity class, woven together by tgsr::interleave2x2_ with the ReLU mask and the accumulation) against torch's
+    convolution backward in float64, and against the direct stride-2 launch it replaces."""
+    from tgsr_amd import custom_ops as C
+    from tgsr_amd import inception, ops
+    assert inception.CLASS_DGRAD
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+
+    class M:                       # a conv + bn pair as _Layer reads it
+        pass
+    m = M()
+    m.conv = torch.nn.Conv2d(Cin, Cout, k, 2, pad, bias=False).to(DEV)
+    m.bn = torch.nn.BatchNorm2d(Cout).to(DEV).eval()
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+        m.bn.weight.copy_(torch.rand(Cout, generator=g) + 0.5)
+        m.bn.running_var.copy_(torch.rand(Cout, generator=g) + 0.5)
+    L = inception._Layer(m)
+    assert L.class_dgrad_ok(H, W) == (pad == 0 and (H - k) % 2 == 0 and (W - k) % 2 == 0)
+    if not L.class_dgrad_ok(H, W):
+        return                     # (padded layers and sizes with an unread trailing row / column keep the direct form)
+    OH, OW = L.out_hw(H, W)
+    dy = torch.randn(B, Cout, OH, OW, generator=g)
+    scale = (m.bn.weight / torch.sqrt(m.bn.running_var + m.bn.eps)).double().cpu()
+    x64 = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x64, m.conv.weight.double().cpu() * scale.view(-1, 1, 1, 1), None, 2, pad).backward(dy.double())
+    gd = dy.to(DEV)
+    base = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    mask = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    for acc, mk in ((False, None), (True, mask)):
+        dx = base.clone()
+        parts = [torch.empty(B, Cin, (H - py + 1) // 2, (W - px + 1) // 2, device=DEV) for py, px, *_ in L.cls]
+        ws = torch.empty(max(max(ops.gconv_ws_elems(B, Cin, t.shape[2], t.shape[3], Cout * c[3] * c[4]) for t, c in zip(parts, L.cls)), 1),
+                         device=DEV)
+        for t, (_py, _px, A, khc, kwc, phc, pwc) in zip(parts, L.cls):
+            C.gconv(True, A, gd, 0, Cout, t, 0, khc, kwc, 1, phc, pwc, None, False, False, ws, None)
+        C.interleave2x2_(parts[0], parts[1], parts[2], parts[3], dx, acc, mk)
+        want = x64.grad.clone()
+        if mk is not None:
+            want = torch.where(mk.cpu() > 0, want, torch.zeros_like(want))
+        if acc:
+            want = want + base.double().cpu()
+        assert rel(dx, want) < 5e-5, (acc, rel(dx, want))
+    # the direct stride-2 launch agrees too
+    direct = torch.empty(B, Cin, H, W, device=DEV)
+    wsd = torch.empty(max(ops.gconv_ws_elems(B, Cin, H, W, Cout * k * k), 1), device=DEV)
+    C.gconv(True, L.wd, gd, 0, Cout, direct, 0, k, k, 2, pad, pad, None, False, False, wsd, None)
+    assert rel(direct, x64.grad) < 5e-5

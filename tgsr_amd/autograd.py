@@ -403,18 +403,25 @@ def _dconv_grads(x, weight, draw, kind, need_dx, need_dw):
     Cin, H, W = x.shape[1], x.shape[2], x.shape[3]
     Cc, dev = draw.shape[1], x.device
     w = weight.detach()
+    def side(fn):
+        # the weight gradient is a leaf of the backward graph: beside the data-gradient chain when the trainer has registered a
+        # side stream for this update (train.SRTrainer._d_wgrad_side) and the gradient lands in its bucket slot unaccumulated
+        adopted = dw._base is not None and weight.grad is None and not torch.is_grad_enabled()
+        if adopted and wgrad_stream(dev) is not None:
+            _ADOPTED.append((weight, dw.data_ptr()))
+        on_wgrad_stream(dev, (draw, x), fn, adopted)
     if kind == "down":
         if need_dx:
             dx = C.conv4x4s2_dgrad(draw, w, H, W)
         if need_dw:
             dw = _grad_out(weight, weight.shape, dev)
-            C.conv4x4s2_wgrad_out(draw, x, dw)
+            side(lambda: C.conv4x4s2_wgrad_out(draw, x, dw))
     elif ops.conv3x3_gemm_pays(Cin, Cc, H, W):
         if need_dx:
             dx = C.conv3x3_gemm_dgrad(draw, w)
         if need_dw:
             dw = _grad_out(weight, weight.shape, dev)
-            C.conv3x3_gemm_wgrad_out(draw, x, dw)
+            side(lambda: C.conv3x3_gemm_wgrad_out(draw, x, dw))
     else:
         if need_dx:
             wT = _dgrad_weight(w)

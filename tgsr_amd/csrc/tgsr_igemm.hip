@@ -348,6 +348,26 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const float* __restrict__
   }
 }
 
+// dx[b][c][2Y + py][2X + px] (+)= t_{py px}[b][c][Y][X]: the four parity classes of a stride-2 convolution's data gradient (each one a
+// stride-1 data gradient over its own taps, computed dense at half resolution) woven into the gradient of the H x W input; `mask`
+// (shaped like dx): the value is kept where mask > 0.  Class (py, px) holds ceil((H - py) / 2) x ceil((W - px) / 2) pixels.
+__global__ __launch_bounds__(256) void interleave2x2_kernel(const float* __restrict__ t00, const float* __restrict__ t01,
+                                                            const float* __restrict__ t10, const float* __restrict__ t11,
+                                                            float* __restrict__ dx, int H, int W, int64_t total, int accumulate,
+                                                            const float* __restrict__ mask) {
+  const int H0 = (H + 1) >> 1, H1 = H >> 1, W0 = (W + 1) >> 1, W1 = W >> 1;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int x = (int)(e % W), y = (int)((e / W) % H);
+    const int64_t pl = e / ((int64_t)W * H);
+    const int py = y & 1, px = x & 1, Y = y >> 1, X = x >> 1;
+    const float* t = py ? (px ? t11 : t10) : (px ? t01 : t00);
+    const int Hc = py ? H1 : H0, Wc = px ? W1 : W0;
+    float v = t[(pl * Hc + Y) * Wc + X];
+    if (mask && !(mask[e] > 0.f)) v = 0.f;
+    dx[e] = accumulate ? dx[e] + v : v;
+  }
+}
+
 // mean over the HW pixels of every (b, c) plane: one wave per plane (the 8 x 8 global average pool); backward: broadcast / HW
 __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes, int HW) {
   const int64_t pl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -591,6 +611,16 @@ extern "C" int tgsr_avgpool3(const float* x, int64_t x_bstride, int B, int C, in
   hipLaunchKernelGGL(avgpool3_kernel, dim3(gc_grid(total)), dim3(256), 0, as_stream(stream), x, out, C, H, W, x_bstride, o_bstride, total,
                      accumulate, mask);
   return note_launch(hipGetLastError(), "avgpool3_kernel");
+}
+
+extern "C" int tgsr_interleave2x2(const float* t00, const float* t01, const float* t10, const float* t11, float* dx, int64_t planes,
+                                  int H, int W, int accumulate, const float* mask, void* stream) {
+  if (!t00 || !dx || planes < 1 || H < 1 || W < 1) return TGSR_EINVAL;
+  if ((W > 1 && !t01) || (H > 1 && !t10) || (H > 1 && W > 1 && !t11)) return TGSR_EINVAL;
+  const int64_t total = planes * H * W;
+  hipLaunchKernelGGL(interleave2x2_kernel, dim3(gc_grid(total)), dim3(256), 0, as_stream(stream), t00, t01, t10, t11, dx, H, W, total,
+                     accumulate, mask);
+  return note_launch(hipGetLastError(), "interleave2x2_kernel");
 }
 
 extern "C" int tgsr_plane_mean(const float* x, float* out, int64_t planes, int HW, void* stream) {

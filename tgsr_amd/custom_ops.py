@@ -515,6 +515,8 @@ relu_mask_ = _define("relu_mask_(Tensor(a!) dy, Tensor y, int coff, int ch) -> (
                      lambda *a: None)
 bilinear = _define("bilinear(Tensor x, int OH, int OW) -> Tensor", lambda x, OH, OW: ops.bilinear(x, OH, OW),
                    lambda x, OH, OW: x.new_empty(x.shape[0], x.shape[1], OH, OW))
+interleave2x2_ = _define("interleave2x2_(Tensor t00, Tensor t01, Tensor t10, Tensor t11, Tensor(a!) dx, bool accumulate, Tensor? mask) -> ()",
+                         lambda a, b, c, d, dx, acc, m: ops.interleave2x2((a, b, c, d), dx, acc, m), lambda *a: None)
 bilinear_bwd = _define("bilinear_bwd(Tensor dy, int H, int W) -> Tensor", lambda dy, H, W: ops.bilinear_bwd(dy, H, W),
                        lambda dy, H, W: dy.new_empty(dy.shape[0], dy.shape[1], H, W))
 adam_flat_ = _define("adam_flat_(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor(d!) state, float lr, "

@@ -28,6 +28,8 @@ RESIZE = 299
 # walk is captured into the generators' hipGraphs).  TGSR_TRUNK_STREAMS=1: everything on the caller's stream (the same kernels in
 # the same order of accumulation: bit-identical).
 TRUNK_STREAMS = max(1, min(4, int(os.environ.get("TGSR_TRUNK_STREAMS", "4"))))
+# stride-2 data gradients as four stride-1 class GEMMs + an interleave (_Layer.refresh); TGSR_TRUNK_CLASS_DGRAD=0: the direct form
+CLASS_DGRAD = os.environ.get("TGSR_TRUNK_CLASS_DGRAD", "1") != "0"
 
 
 class _Layer:
@@ -58,7 +60,27 @@ class _Layer:
         scale, self.shift = ops.bn_fold(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
         self.wf = C.gconv_pack(self.conv.weight.detach(), scale, False)
         self.wd = C.gconv_pack(self.conv.weight.detach(), scale, True)
+        # A stride-2 layer's data gradient by parity classes of the input pixel: input row y = 2 Y + py meets only the taps
+        # ky = k0 + 2 a (k0 = (py + pad) % 2) - dx[2 Y + py] = sum_a g[Y + c0 - a] w[k0 + 2 a], c0 = (py + pad - k0) / 2 - which is the
+        # STRIDE-1 data gradient of the kernel w[k0::2] with padding c0, dense at half resolution: four small GEMMs over a quarter
+        # of the direct form's products (three quarters of those multiply the zeros between the strided samples), then one
+        # interleaving pass (tgsr::interleave2x2_).  (py, px, pack, kh', kw', pad_h', pad_w')
+        self.cls = None
+        if self.stride == 2 and self.kh >= 2 and self.kw >= 2 and self.ph == 0 and self.pw == 0 and self.cin > 4 and CLASS_DGRAD:
+            self.cls = []
+            w = self.conv.weight.detach()
+            for py in (0, 1):
+                for px in (0, 1):
+                    ky0, kx0 = (py + self.ph) % 2, (px + self.pw) % 2
+                    wc = w[:, :, ky0::2, kx0::2].contiguous()
+                    self.cls.append((py, px, C.gconv_pack(wc, scale, True), wc.shape[2], wc.shape[3], (py + self.ph - ky0) // 2,
+                                     (px + self.pw - kx0) // 2))
         self.key = k
+
+    def class_dgrad_ok(self, H, W):
+        """The class form covers unpadded layers on input sizes the forward uses completely ((H - k) even: no trailing row / column
+        that no output reads; a class is then exactly the stride-1 gradient's size) - every Inception-v3 stride-2 layer: 299, 35, 17."""
+        return self.cls is not None and (H + 2 * self.ph - self.kh) % 2 == 0 and (W + 2 * self.pw - self.kw) % 2 == 0 and H > 1 and W > 1
 
     def out_hw(self, H, W):
         return (H + 2 * self.ph - self.kh) // self.stride + 1, (W + 2 * self.pw - self.kw) // self.stride + 1
@@ -330,7 +352,18 @@ class InceptionTrunk:
                 if block_src is not None:
                     self._fork_streams()
             dx, acc, m = target(src)            # (allocated on the caller's stream, outside the launch's stream scope)
-            if kind == "conv":
+            if kind == "conv" and L.class_dgrad_ok(dx.shape[2], dx.shape[3]):
+                Bn, _, H, W = dx.shape
+                parts = [torch.empty(Bn, L.cin, (H - py + 1) // 2, (W - px + 1) // 2, dtype=torch.float32, device=dx.device)
+                         for py, px, *_ in L.cls]
+                self._ws_old.extend(parts)          # (alive until the next walk opens: stream s still reads them - see _ws)
+                ws = self._ws(max(ops_ws(Bn, L.cin, t.shape[2], t.shape[3], L.cout * c[3] * c[4]) for t, c in zip(parts, L.cls)),
+                              dx.device, s)
+                with self._run(s):
+                    for t, (_py, _px, A, khc, kwc, phc, pwc) in zip(parts, L.cls):
+                        C.gconv(True, A, g, coff, L.cout, t, 0, khc, kwc, 1, phc, pwc, None, False, False, ws, None)
+                    C.interleave2x2_(parts[0], parts[1], parts[2], parts[3], dx, acc, m)
+            elif kind == "conv":
                 ws = self._ws(ops_ws(dx.shape[0], L.cin, dx.shape[2], dx.shape[3], L.cout * L.kh * L.kw), dx.device, s)
                 with self._run(s):
                     C.gconv(True, L.wd, g, coff, L.cout, dx, 0, L.kh, L.kw, L.stride, L.ph, L.pw, None, False, acc, ws, m)

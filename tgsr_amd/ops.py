@@ -1438,6 +1438,23 @@ def gconv(dgrad: bool, A: torch.Tensor, S: torch.Tensor, s_coff: int, s_ch: int,
                                 _p(bias), 1 if relu else 0, 1 if accumulate else 0, mp, op, obs, _p(ws), _stream()), "tgsr_gconv")
 
 
+
+def interleave2x2(parts, dx: torch.Tensor, accumulate: bool, mask: Optional[torch.Tensor] = None):
+    """dx[:, :, py::2, px::2] (+)= parts[2 py + px] (dense [B, C, ceil((H - py) / 2), ceil((W - px) / 2)]), masked where mask <= 0:
+    the four parity classes of a stride-2 convolution's data gradient woven into one tensor (tgsr_interleave2x2)."""
+    _need_hip(dx, mask, *parts)
+    B, Cc, H, W = dx.shape
+    if not dx.is_contiguous() or dx.dtype != torch.float32 or len(parts) != 4:
+        raise TgsrError("interleave2x2: a dense fp32 dx and four class tensors expected")
+    for k, t in enumerate(parts):
+        want = (B, Cc, (H - (k >> 1) + 1) // 2, (W - (k & 1) + 1) // 2)
+        if tuple(t.shape) != want or not t.is_contiguous() or t.dtype != torch.float32:
+            raise TgsrError("interleave2x2: class %d is %s, expected dense %s" % (k, tuple(t.shape), want))
+    if mask is not None and (mask.shape != dx.shape or not mask.is_contiguous() or mask.dtype != torch.float32):
+        raise TgsrError("interleave2x2: the mask must be a dense fp32 tensor shaped like dx")
+    check(_lib.lib().tgsr_interleave2x2(_p(parts[0]), _p(parts[1]), _p(parts[2]), _p(parts[3]), _p(dx), B * Cc, H, W,
+                                        1 if accumulate else 0, _p(mask), _stream()), "tgsr_interleave2x2")
+
 def maxpool3s2(x: torch.Tensor, out: torch.Tensor, o_coff: int):
     _need_hip(x, out)
     B, Cc, H, W = x.shape

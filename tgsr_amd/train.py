@@ -174,6 +174,15 @@ class SRTrainer:
         self._dstreams = distinct_streams(len(self.netsD), self.device, avoid=taken) \
             if self.device.type == "cuda" and self.netsD and os.environ.get("TGSR_D_STREAMS", "1") != "0" else []
         taken = taken + [st.cuda_stream for st in self._dstreams]
+        # TGSR_D_WGRAD_SIDE=1 (opt-in): each discriminator's weight gradients on a side stream of its own, beside its data-gradient
+        # chain - the 256^2 discriminator's update is the longest dependent chain of a G/D step and a quarter of its backward
+        # kernels are weight gradients nothing waits for until Adam.  Built, bit-identical (the gan / dp suites pass with it), and
+        # SLOWER on this chip: 20.8 against 19.6 ms per G/D step, 31.9 against 30.3 with the ranking term (same box) - the three
+        # updates already run side by side, and six streams compete for four hardware queues (GPU_MAX_HW_QUEUES=8 is worse
+        # still: 43.6 ms).  Left off.
+        self._dwside = distinct_streams(len(self._dstreams), self.device, avoid=taken) \
+            if self._dstreams and os.environ.get("TGSR_D_WGRAD_SIDE", "0") == "1" else []
+        taken = taken + [st.cuda_stream for st in self._dwside]
         # the stream the generators' graphs are captured on, and the branch their re-pack launches fork onto
         self._gcap, self._gpack = distinct_streams(2, self.device, avoid=taken) if self._graph_capable else (None, None)
 
@@ -351,6 +360,36 @@ class SRTrainer:
             self.bucket.flat.zero_()
             raise
 
+    @contextlib.contextmanager
+    def _d_wgrad_side(self, i):
+        """`_wgrad_side` for discriminator i's update: its weight gradients on the discriminator's side stream, joined into the
+        CURRENT stream (the discriminator's own) on exit, before the bucket is closed, reduced or read."""
+        from . import autograd
+        if not self._dwside:
+            yield
+            return
+        side = self._dwside[i]
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        prev = autograd.WGRAD_SIDE.get(idx)
+        autograd.WGRAD_SIDE[idx] = side
+        ok = False
+        try:
+            yield
+            ok = True
+        finally:
+            if prev is None:
+                autograd.WGRAD_SIDE.pop(idx, None)
+            else:
+                autograd.WGRAD_SIDE[idx] = prev
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            if not ok:
+                autograd._ADOPTED.clear()
+        try:
+            autograd.check_adopted()
+        except Exception:
+            self.bucketsD[i].flat.zero_()
+            raise
+
     # ------------------------------------------------------------------ updates replayed from hipGraphs
     @staticmethod
     def _opt_key(o):
@@ -380,7 +419,8 @@ class SRTrainer:
         d, b, o = self.netsD[i], self.bucketsD[i], self.optsD[i]
         b.begin_step()
         e = losses.discriminator_loss(d, real, fake, sent, real_labels, fake_labels)
-        e.backward()
+        with self._d_wgrad_side(i):
+            e.backward()
         b.end_step()
         b.all_reduce_mean()
         o.step()
@@ -429,7 +469,8 @@ class SRTrainer:
             with torch.cuda.graph(fb, stream=st, pool=pool):
                 b.begin_step()
                 e = losses.discriminator_loss(d, buf["real"], buf["fake"], buf["sent"], buf["rl"], buf["fl"])
-                e.backward()
+                with self._d_wgrad_side(i):
+                    e.backward()
                 b.end_step()
                 if not split:
                     o.step()

@@ -12,6 +12,11 @@ if len(marks) < 3:
 def short(n):
     n = n.replace("void ", "").replace("tgsr::", "")
     return n[:70]
+# which steps: the last two by default; `--middle` (argv[2]) = two steps from the middle of the run (bench.py's timed region - the last
+# steps of a bench run are its event-sampled eager ones)
+if len(sys.argv) > 2 and sys.argv[2] == "--middle":
+    mid = len(marks) // 2
+    marks = marks[:mid + 2]
 for a, b in zip(marks[-3:-1], marks[-2:]):
     step = ev[a:b]
     t0, t1 = step[0][0], max(e[1] for e in step)
