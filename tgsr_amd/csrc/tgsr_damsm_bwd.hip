@@ -37,8 +37,15 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   float* dwc_s = word_s + ndf * 32;          // [ndf][32]
   float* cs = dwc_s + ndf * 32;              // [ndf][33] ctx chunk
   float* gcs = cs + ndf * 33;                // [ndf][33] gctx chunk
-  float* red = gcs + ndf * 33;               // [4][32] reductions
+  // (cs .. gcs also hold the region-mapped phases' [32][S] ctx slab: the region is as large as the larger of the two uses)
+  const int csz = 2 * ndf * 33 > 32 * S ? 2 * ndf * 33 : 32 * S;
+  float* red = cs + csz;                     // [4][32] reductions
   float* wpart = red + 128;                  // [4 waves][128]: the waves' partial sums of those, combined in a fixed order
+  // the chunk's columns of the attention images, [region][32 words]: the thread = d phases read every (word, region) value of the
+  // chunk in EVERY thread - as LDS broadcasts (8 ds_read_b128 per region) instead of 32 / 64 dependent global loads per region from
+  // the per-pair workspace (one wave per SIMD hides none of their latency: the kernel ran 0.95 ms, alone on the device, that way)
+  float* a2s = wpart + 4 * 128;              // [32 regions][32]
+  float* a3s = a2s + kBwdChunk * 32;         // [32 regions][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int j = blockIdx.x / a.B, i = blockIdx.x - j * a.B;
@@ -59,15 +66,47 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   __syncthreads();
 
   // ---- thread = r: scores, softmax over words, x gamma1
+  // ctx arrives in slabs of 32 feature rows [32][S] through LDS (the cs .. gcs region: 64 x 33 x ndf / 32 >= 32 x 320 floats), loaded
+  // with every thread's requests in flight together: the per-row global load inside the accumulation loop (256 dependent round
+  // trips per region at one wave per SIMD) was most of this phase's time.  Both passes over the regions (r = tid, tid + 256) share a slab.
+  float* slab = cs;
+  float sA[32], sB[32];
+#pragma unroll
+  for (int l = 0; l < 32; ++l) { sA[l] = 0.f; sB[l] = 0.f; }
+  const bool hasB = tid + 256 < S;
+  for (int d0 = 0; d0 < ndf; d0 += 32) {
+    for (int o = tid; o < 32 * S; o += 256) slab[o] = cb[(int64_t)d0 * S + o];
+    __syncthreads();
+    if (tid < S) {
+      for (int dd = 0; dd < 32; ++dd) {
+        const float c = slab[dd * S + tid];
+        const float4* wp = reinterpret_cast<const float4*>(word_s + (d0 + dd) * 32);
+#pragma unroll
+        for (int l4 = 0; l4 < 8; ++l4) {
+          const float4 w4 = wp[l4];
+          sA[4 * l4] = fmaf(w4.x, c, sA[4 * l4]); sA[4 * l4 + 1] = fmaf(w4.y, c, sA[4 * l4 + 1]);
+          sA[4 * l4 + 2] = fmaf(w4.z, c, sA[4 * l4 + 2]); sA[4 * l4 + 3] = fmaf(w4.w, c, sA[4 * l4 + 3]);
+        }
+      }
+    }
+    if (hasB) {
+      for (int dd = 0; dd < 32; ++dd) {
+        const float c = slab[dd * S + tid + 256];
+        const float4* wp = reinterpret_cast<const float4*>(word_s + (d0 + dd) * 32);
+#pragma unroll
+        for (int l4 = 0; l4 < 8; ++l4) {
+          const float4 w4 = wp[l4];
+          sB[4 * l4] = fmaf(w4.x, c, sB[4 * l4]); sB[4 * l4 + 1] = fmaf(w4.y, c, sB[4 * l4 + 1]);
+          sB[4 * l4 + 2] = fmaf(w4.z, c, sB[4 * l4 + 2]); sB[4 * l4 + 3] = fmaf(w4.w, c, sB[4 * l4 + 3]);
+        }
+      }
+    }
+    __syncthreads();
+  }
   for (int r = tid; r < S; r += 256) {
     float s[32];
 #pragma unroll
-    for (int l = 0; l < 32; ++l) s[l] = 0.f;
-    for (int d = 0; d < ndf; ++d) {
-      const float c = cb[(int64_t)d * S + r];
-#pragma unroll
-      for (int l = 0; l < 32; ++l) s[l] = fmaf(word_s[d * 32 + l], c, s[l]);
-    }
+    for (int l = 0; l < 32; ++l) s[l] = r == tid ? sA[l] : sB[l];
     float mx = -INFINITY;
 #pragma unroll
     for (int l = 0; l < 32; ++l) {
@@ -91,23 +130,33 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   __syncthreads();
 
   // ---- wave per word row: softmax over regions -> a2
+  // (a lane's <= 5 values of the row stay in registers between the three passes: one read and one write of the global workspace per
+  // row instead of five dependent round trips - S <= 320, host-checked)
   for (int l = wave; l < 32; l += 4) {
     float* row = a2 + l * S;
     if (l < L) {
+      float v[5];
       float mx = -INFINITY;
-      for (int r = lane; r < S; r += 64) mx = fmaxf(mx, row[r]);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const int r = lane + 64 * k;
+        v[k] = r < S ? row[r] : -INFINITY;
+        mx = fmaxf(mx, v[k]);
+      }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
       float sum = 0.f;
-      for (int r = lane; r < S; r += 64) {
-        const float e = expf(row[r] - mx);
-        row[r] = e;
-        sum += e;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        v[k] = lane + 64 * k < S ? expf(v[k] - mx) : 0.f;
+        sum += v[k];
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
       const float inv = 1.f / sum;
-      for (int r = lane; r < S; r += 64) row[r] *= inv;
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if (lane + 64 * k < S) row[lane + 64 * k] = v[k] * inv;
     } else {
       for (int r = lane; r < S; r += 64) row[r] = 0.f;
     }
@@ -128,13 +177,24 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
       const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
       cs[dd * 33 + rr] = r0 + rr < S ? cb[(int64_t)dd * S + r0 + rr] : 0.f;
     }
+    for (int o = tid; o < 32 * kBwdChunk; o += 256) {      // a2[l][r0 + rr] -> a2s[rr][l] (coalesced over rr)
+      const int l = o / kBwdChunk, rr = o - l * kBwdChunk;
+      a2s[rr * 32 + l] = r0 + rr < S ? a2[l * S + r0 + rr] : 0.f;
+    }
     __syncthreads();
     if (dok) {
       const int nr = S - r0 < kBwdChunk ? S - r0 : kBwdChunk;
       for (int rr = 0; rr < nr; ++rr) {
         const float c = cs[d * 33 + rr];
+        const float4* ap = reinterpret_cast<const float4*>(a2s + rr * 32);
 #pragma unroll
-        for (int l = 0; l < 32; ++l) wc[l] = fmaf(c, a2[l * S + r0 + rr], wc[l]);
+        for (int l4 = 0; l4 < 8; ++l4) {
+          const float4 av = ap[l4];
+          wc[4 * l4] = fmaf(c, av.x, wc[4 * l4]);
+          wc[4 * l4 + 1] = fmaf(c, av.y, wc[4 * l4 + 1]);
+          wc[4 * l4 + 2] = fmaf(c, av.z, wc[4 * l4 + 2]);
+          wc[4 * l4 + 3] = fmaf(c, av.w, wc[4 * l4 + 3]);
+        }
       }
     }
     __syncthreads();
@@ -202,16 +262,40 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   {
     float rd[32];
 #pragma unroll
-    for (int l = 0; l < 32; ++l) rd[l] = 0.f;
+    for (int l = 0; l < 32; ++l) { rd[l] = 0.f; sA[l] = 0.f; sB[l] = 0.f; }
+    for (int d0 = 0; d0 < ndf; d0 += 32) {                 // ctx in slabs of 32 rows through LDS, as for the scores
+      for (int o = tid; o < 32 * S; o += 256) slab[o] = cb[(int64_t)d0 * S + o];
+      __syncthreads();
+      if (tid < S) {
+        for (int dd = 0; dd < 32; ++dd) {
+          const float c = slab[dd * S + tid];
+          const float4* wp = reinterpret_cast<const float4*>(dwc_s + (d0 + dd) * 32);
+#pragma unroll
+          for (int l4 = 0; l4 < 8; ++l4) {
+            const float4 w4 = wp[l4];
+            sA[4 * l4] = fmaf(w4.x, c, sA[4 * l4]); sA[4 * l4 + 1] = fmaf(w4.y, c, sA[4 * l4 + 1]);
+            sA[4 * l4 + 2] = fmaf(w4.z, c, sA[4 * l4 + 2]); sA[4 * l4 + 3] = fmaf(w4.w, c, sA[4 * l4 + 3]);
+          }
+        }
+      }
+      if (hasB) {
+        for (int dd = 0; dd < 32; ++dd) {
+          const float c = slab[dd * S + tid + 256];
+          const float4* wp = reinterpret_cast<const float4*>(dwc_s + (d0 + dd) * 32);
+#pragma unroll
+          for (int l4 = 0; l4 < 8; ++l4) {
+            const float4 w4 = wp[l4];
+            sB[4 * l4] = fmaf(w4.x, c, sB[4 * l4]); sB[4 * l4 + 1] = fmaf(w4.y, c, sB[4 * l4 + 1]);
+            sB[4 * l4 + 2] = fmaf(w4.z, c, sB[4 * l4 + 2]); sB[4 * l4 + 3] = fmaf(w4.w, c, sB[4 * l4 + 3]);
+          }
+        }
+      }
+      __syncthreads();
+    }
     for (int r = tid; r < S; r += 256) {
       float g[32];
 #pragma unroll
-      for (int l = 0; l < 32; ++l) g[l] = 0.f;
-      for (int dd = 0; dd < ndf; ++dd) {
-        const float c = cb[(int64_t)dd * S + r];
-#pragma unroll
-        for (int l = 0; l < 32; ++l) g[l] = fmaf(dwc_s[dd * 32 + l], c, g[l]);
-      }
+      for (int l = 0; l < 32; ++l) g[l] = r == tid ? sA[l] : sB[l];
 #pragma unroll
       for (int l = 0; l < 32; ++l) {
         a3[l * S + r] = g[l];
@@ -250,18 +334,31 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
       const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
       cs[dd * 33 + rr] = r0 + rr < S ? cb[(int64_t)dd * S + r0 + rr] : 0.f;
     }
+    for (int o = tid; o < 32 * kBwdChunk; o += 256) {
+      const int l = o / kBwdChunk, rr = o - l * kBwdChunk;
+      const bool in = r0 + rr < S;
+      a2s[rr * 32 + l] = in ? a2[l * S + r0 + rr] : 0.f;
+      a3s[rr * 32 + l] = in ? a3[l * S + r0 + rr] : 0.f;
+    }
     __syncthreads();
     const int nr = S - r0 < kBwdChunk ? S - r0 : kBwdChunk;
     if (dok) {
       for (int rr = 0; rr < nr; ++rr) {
         const float c = cs[d * 33 + rr];
+        const float4* p2 = reinterpret_cast<const float4*>(a2s + rr * 32);
+        const float4* p3 = reinterpret_cast<const float4*>(a3s + rr * 32);
         float g = 0.f;
 #pragma unroll
-        for (int l = 0; l < 32; ++l) {
-          const float dsv = a3[l * S + r0 + rr];
-          gw[l] = fmaf(dsv, c, gw[l]);
-          g = fmaf(wrow[l], dsv, g);
-          g = fmaf(dwc[l], a2[l * S + r0 + rr], g);
+        for (int l4 = 0; l4 < 8; ++l4) {
+          const float4 d4 = p3[l4], q4 = p2[l4];
+          const float dsv[4] = {d4.x, d4.y, d4.z, d4.w}, a2v[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {                    // (word by word in ascending order: the sums keep their order)
+            const int l = 4 * l4 + k;
+            gw[l] = fmaf(dsv[k], c, gw[l]);
+            g = fmaf(wrow[l], dsv[k], g);
+            g = fmaf(dwc[l], a2v[k], g);
+          }
         }
         gcs[d * 33 + rr] = g;
       }
@@ -308,7 +405,8 @@ extern "C" int tgsr_damsm_words_bwd(const float* words, const int32_t* cap_lens,
   a.ws = ws;
   a.gw_part = ws + (int64_t)B * B * 3 * 32 * S;
   a.gc_part = a.gw_part + (int64_t)B * B * ndf * 32;
-  const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + (size_t)ndf * 33 * 2 + 128 + 4 * 128);
+  const size_t csz = (size_t)ndf * 33 * 2 > (size_t)32 * S ? (size_t)ndf * 33 * 2 : (size_t)32 * S;
+  const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + csz + 128 + 4 * 128 + 2 * kBwdChunk * 32);
   static bool attr_set[64] = {false};   // the > 64 KB opt-in belongs to the DEVICE's code object: once per device, not per
   int dev = 0;                          // process (one process driving two GPUs would otherwise fail on the second)
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
