@@ -100,14 +100,14 @@ def test_models16_tied_stages_and_keys(cfg32):
 
 
 def test_committed_bench_lines_follow_the_contract():
-    """The JSON lines bench.py printed on the MI355X this round (committed under profiles/: r05_*) carry every field of the
+    """The JSON lines bench.py printed on the MI355X this round (committed under profiles/: r06_*) carry every field of the
     driver's contract, an honest roofline object (frac = achieved / peak <= 1, counters looked up from a committed
     rocprofv3 table) and - on the default N=1 runs - the CPU baseline."""
     import glob
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = sorted(glob.glob(os.path.join(root, "profiles", "r05_bench_*.json")))
-    assert len(files) >= 10, "round-5 bench lines missing"
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r06_bench_*.json")))
+    assert len(files) >= 10, "round-6 bench lines missing"
     saw_cpu = saw_lp = saw_train = False
     for f in files:
         d = json.loads(open(f).read().strip().splitlines()[-1])
@@ -136,11 +136,12 @@ def test_committed_bench_lines_follow_the_contract():
             c = d["cpu_baseline"]
             assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert saw_cpu and saw_lp and saw_train
-    two = json.loads(open(os.path.join(root, "profiles", "r05_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
+    two = json.loads(open(os.path.join(root, "profiles", "r06_bench_rehearsal_2ranks.json")).read().strip().splitlines()[-1])
     assert two["n_gpus"] == 2                       # `bench.py --gpus 2` launched its two ranks itself
     assert "lp" in two and "train" in two and "error" not in json.dumps(two["train"])   # the extras survive N > 1 (all-reduce matched)
+    assert two["ranks"]["world"] == 2 and two["ranks"]["all_reduce_of_ones"] == 2.0     # round 6: what the collective layer itself says
     # the default line (what the driver times): fp32 stays the headline, configs[4] and the train step ride along
-    d = json.loads(open(os.path.join(root, "profiles", "r05_bench_fp32.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(root, "profiles", "r06_bench_fp32.json")).read().strip().splitlines()[-1])
     assert d["dtype"] == "f32" and d["config"]["launch"] == "hipgraph"
     # round 5: `value` is the STRICT figure of BASELINE's metric - batch 16, one step in flight - and says so; the four-lane
     # throughput form rides along; every figure is a median over >= 0.5 s of fenced K-step regions
@@ -162,11 +163,17 @@ def test_committed_bench_lines_follow_the_contract():
     # every timed step runs on another batch than the one before (captions, caption lengths, images)
     assert "different resident synthetic batches" in d["config"]["batches"]
     tr = d["train"]["runs"]
-    assert len(tr) == 2 and all(0 < t["roofline"]["frac"] < 1 and "executed_fraction" in json.dumps(t["roofline"]) for t in tr)
+    # round 6: generator step, G/D alternation, and configs[2] as BASELINE states it (G/D + DAMSM through CNN_ENCODER)
+    assert len(tr) == 3 and all(0 < t["roofline"]["frac"] < 1 and "executed_fraction" in json.dumps(t["roofline"]) for t in tr)
     # the train steps' CPU baselines run at the configuration's own batch, their rooflines carry counter traffic
     assert all("cpu_baseline" in t and "batch 16" in t["cpu_baseline"]["sample"] for t in tr)
-    assert all(t["roofline"]["traffic"] and t["roofline"]["traffic_from"].startswith("r05_train") for t in tr)
-    assert tr[1]["ms_per_step"] < 28.0              # the G/D alternation (29.1 ms at the end of round 4)
+    assert all(t["roofline"]["traffic"] and t["roofline"]["traffic_from"].startswith("r06_train") for t in tr)
+    assert d["roofline"]["counters_from"].startswith("r06_fp32")
+    assert tr[1]["ms_per_step"] < 22.0              # the G/D alternation (29.1 ms at the end of round 4, 21.1 of round 5)
+    assert tr[2]["ms_per_step"] < 34.0 and "CNN_ENCODER" in tr[2]["workload"]      # 35.2 with MIOpen's trunk (round 5)
+    # the measured graph policy reports what it timed; the device-time breakdown: non-library kernels <= 8 % of a G/D step
+    assert all(t["graph_policy"]["chosen"] in ("eager", "replay") and t["graph_policy"]["eager_ms"] > 0 for t in tr)
+    assert tr[1]["device_time"]["non_tgsr_share"] <= 0.08
 
 
 def test_get_caption_crops_like_the_reference():
