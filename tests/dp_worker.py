@@ -142,6 +142,28 @@ def main():
         res["graph_%s_split" % tag] = runs[1]["split"] and not runs[0]["split"]
         res["graph_%s_state" % tag] = runs[1]["state"]
         res["graph_%s_losses" % tag] = (runs[0]["losses"], runs[1]["losses"])
+    # ---- the MEASURED graph policy (TGSR_GRAPH_G=auto, the default) under data parallelism: the ranks time their eager and replayed
+    # steps, take the slowest rank's medians (one all-reduce) and settle on the SAME form; whatever it is, the steps leave the
+    # bits of the pinned-eager data-parallel trainer
+    from tgsr_amd import train as _train
+    runs = []
+    for mode in ("eager", "auto"):
+        t = make_trainer(device=dev, discriminators=False)
+        if mode == "eager":
+            t._graph_g = False
+        else:
+            assert t._auto is not None
+        ls = []
+        for it in range(_train.GRAPH_G_SETTLED + 1):
+            torch.manual_seed(70 + it)
+            ls.append(float(t.step(cap[lo:hi].to(dev), lens[lo:hi].tolist(), LR[lo:hi].to(dev), LRb[lo:hi].to(dev),
+                                   [h[lo:hi].to(dev) for h in hr])))
+        torch.cuda.synchronize()
+        runs.append({"losses": ls, "state": torch.cat([p.detach().flatten() for p in t.params]).cpu(), "policy": dict(t.graph_policy),
+                     "settled": t._auto is None})
+        del t
+    res["graph_auto_equal"] = runs[0]["losses"] == runs[1]["losses"] and torch.equal(runs[0]["state"], runs[1]["state"])
+    res["graph_auto_policy"], res["graph_auto_settled"] = runs[1]["policy"], runs[1]["settled"]
     if backend == "nccl":
         # the G/D alternation's collectives: each discriminator's bucket is all-reduced on that discriminator's own
         # stream (train.py step_gan), then the generators' bucket on the main one - four RCCL all-reduces per step

@@ -90,6 +90,11 @@ def test_two_rank_gradients_and_sharded_inference(tmp_path, backend):
             assert r[k]["graph_%s_split" % tag], "rank %d: the %s update was not replayed in segments" % (k, tag)
             assert r[k]["graph_%s_equal" % tag], (tag, k, r[k]["graph_%s_losses" % tag])
         assert torch.equal(r[0]["graph_%s_state" % tag], r[1]["graph_%s_state" % tag])
+    # the measured graph policy settles on ONE form for both ranks (the slowest rank's medians decide) and changes no bit
+    for k in range(2):
+        assert r[k]["graph_auto_settled"] and r[k]["graph_auto_equal"], (k, r[k]["graph_auto_policy"])
+    assert r[0]["graph_auto_policy"]["chosen"] == r[1]["graph_auto_policy"]["chosen"]
+    assert r[0]["graph_auto_policy"]["eager_ms"] == r[1]["graph_auto_policy"]["eager_ms"]
     if backend == "nccl":
         # G/D alternation over RCCL: four all-reduces per step on four streams; after it every rank holds the same
         # generator gradients and has taken the same Adam steps (the shards differ, so identical discriminator parameters

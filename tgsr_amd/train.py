@@ -226,13 +226,19 @@ class SRTrainer:
         if self._gsteps < GRAPH_G_SETTLED:
             return
         import statistics
-        te, tp = statistics.median(a["eager_s"]), statistics.median(a["replay_s"])
+        inf = float("inf")
+        te = statistics.median(a["eager_s"]) if a["eager_s"] else inf      # (steps that raised may have left a form untimed)
+        tp = statistics.median(a["replay_s"]) if a["replay_s"] else inf
         from .parallel import dp_world
         if dp_world() > 1:
             import torch.distributed as dist
             t = torch.tensor([te, tp], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             te, tp = float(t[0]), float(t[1])
+        if te == inf:                                               # nothing to compare with: the first guess stands
+            self._graph_g = self._graph_g_value
+            self.graph_policy["chosen"] = "replay" if self._graph_g_value else "eager"
+            return
         self._graph_g = tp <= te                                            # (the setter ends the measurement)
         self.graph_policy.update({"eager_ms": round(te * 1e3, 3), "replay_ms": None if tp == float("inf") else round(tp * 1e3, 3),
                                   "chosen": "replay" if tp <= te else "eager",
