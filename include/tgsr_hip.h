@@ -176,6 +176,13 @@ int tgsr_wino4_wide_conv3x3_fwd(const float* x, int64_t x_bstride, int B, int Ci
                                 float* out, int64_t out_bstride, int epilogue, void* stream);
 
 /*
+ * tgsr_conv_to3_set_pipe(on): the streaming form of tgsr_conv_to3_fwd with its LDS copies two stages ahead in a ring of three buffers
+ * (counted waits) and the filter in LDS - on by default where W % 4 == 0 and the filter takes <= 16 KB (TGSR_TO3_PIPE=0 in the
+ * environment turns it off); the images are bit-identical either way.  Returns the previous setting.
+ */
+int tgsr_conv_to3_set_pipe(int on);
+
+/*
  * KxK convolution (K = 3 or 5, stride 1, zero pad K/2, no bias) to 3 output channels + optional epilogue.
  * Replaces GET_IMAGE_G_noAct.img (util.py:913-915; K=3, TGSR_ACT_NONE) and
  * conv_output = conv5x5 + Tanh followed by `one*. + a*SRb` (model.py:224, 280/288/297; K=5, TGSR_ACT_TANH_AXPY).

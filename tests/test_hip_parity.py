@@ -402,12 +402,40 @@ def test_conv_to3(B, Cin, H, W, K, act):
     close(out, ref, atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,K,act", [(16, 32, 256, 256, 3, False), (4, 32, 128, 128, 3, False), (2, 32, 64, 64, 3, False),
+                                             (2, 32, 64, 64, 5, True), (3, 64, 36, 128, 3, True), (1, 5, 9, 64, 3, False),
+                                             (2, 32, 130, 68, 5, False), (1, 33, 16, 192, 3, True)])
+def test_conv_to3_with_copies_in_flight_equals_the_double_buffered_kernel_bit_for_bit(B, Cin, H, W, K, act):
+    """conv_to3_pipe_kernel (LDS copies two stages ahead in a ring of three buffers behind counted waits, the filter in LDS: the
+    default where W % 4 == 0) runs the FMA chains of conv_to3_kernel in the same order: identical bits, on every tile form (16-, 8-
+    and 4-row tiles with 1 / 2 / 4 channel groups), ragged heights, odd channel counts - and both agree with torch."""
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(K * 100 + H + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(3, Cin, K, K, generator=g) / (K * Cin ** 0.5)).to(DEV)
+    add = torch.randn(B, 3, H, W, generator=g).to(DEV) if act else None
+    outs = []
+    was = ops.conv_to3_set_pipe(True)
+    try:
+        for pipe in (True, False):
+            ops.conv_to3_set_pipe(pipe)
+            outs.append(ops.conv_to3(x, w, tanh_axpy=act, addend=add, alpha=0.5))
+    finally:
+        ops.conv_to3_set_pipe(was)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.conv2d(x.cpu(), w.cpu(), None, 1, K // 2)
+    if act:
+        ref = torch.tanh(ref) + 0.5 * add.cpu()
+    close(outs[0], ref, atol=2e-5, rtol=2e-5)
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 16, 32), (3, 64, 64), (1, 128, 128)])
 def test_split_head_equals_fused_head_bit_for_bit(B, H, W):
     """NetG_highweight's head `tanh(conv5x5(out)) + a * SRb` (model.py:280) computed in two launches - the convolution + tanh
     without the addend (ahead of G_SR_NET_low), then tgsr_axpy_images - is the fused epilogue's result bit for bit, for several
     scales in one axpy launch."""
     from tgsr_amd import ops
+    import tgsr_amd.custom_ops  # noqa: F401   (registers torch.ops.tgsr.*: the test must not depend on an earlier one having done so)
     g = torch.Generator().manual_seed(H + W)
     xs = [torch.randn(B, 32, H >> k, W >> k, generator=g).to(DEV) for k in range(3)]
     adds = [torch.randn(B, 3, H >> k, W >> k, generator=g).to(DEV) for k in range(3)]

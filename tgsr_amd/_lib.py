@@ -74,6 +74,7 @@ SIGNATURES = {
     "tgsr_bn_train_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tgsr_dconv_set_split": (_i, [_i]),
     "tgsr_bn_set_fuse_small": (_i, [_i]),
+    "tgsr_conv_to3_set_pipe": (_i, [_i]),
     "tgsr_conv4x4s2_split_form": (_i, [_i, _i, _i, _i, _i, _i]),
     "tgsr_conv3x3_gemm_split_form": (_i, [_i, _i, _i, _i, _i, _i]),
     "tgsr_conv4x4s2_ws_elems": (_i64, [_i, _i, _i, _i, _i, _i]),

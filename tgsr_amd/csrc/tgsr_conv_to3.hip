@@ -213,6 +213,169 @@ __global__ __launch_bounds__(16 * TH * KS) void conv_to3_kernel(To3Args a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The streaming kernel above, with its copies really in flight (round 6).  hipcc cannot tell which LDS bytes an LDS-DMA
+// (`__builtin_amdgcn_global_load_lds`) writes, so it puts `s_waitcnt vmcnt(0)` in front of the first ds_read behind one: the "copy of
+// stage c + 1 under the FMAs of stage c" of the kernel above never overlapped anything - every 2-channel stage paid a full HBM round
+// trip (~1.5 us against ~0.3 us of FMAs; 2.7 TB/s on the 256^2 head, which sits ALONE at the end of the one-lane step) - and the
+// filter taps, which it loads with vector loads right before their use (the kernel stores to global memory, so the loads are not
+// provably invariant and do not become scalar loads), paid an L2 round trip per channel.  Here:
+//   * the copies are issued in inline assembly (the compiler does not see them) into a ring of THREE stage buffers, two stages
+//     ahead, with counted waits: every wave issues exactly UK pieces per stage (the buffer is padded to whole rounds of pieces;
+//     the padding pieces read the zero block), so `vmcnt(UK)` in front of a stage means "this stage has landed, the next one may
+//     still be in flight"; one barrier per stage, the copy of stage i + 2 is issued behind it (everybody has left stage i - 1);
+//   * the whole filter sits in LDS ([Cin][3 K K, padded to 4]; dynamic shared memory), read as broadcasts.
+// The FMA chains are those of the kernel above in the same order: the images are bit-identical.  Needs W % 4 == 0 (the 16-byte copy
+// form) and a filter of <= 16 KB; everything else stays on the kernel above (TGSR_TO3_PIPE=0: everything).
+// Measured (batch 16, the six stand-alone heads of an inference step, same box): 0.206 -> 0.189 ms per step, 1.87 -> 2.04 TB/s -
+// 8 %, not the 2x the serialised copies suggested: four workgroups per CU already overlapped one another's round trips.
+template <int K, int ACT, int TH, int KS>
+__global__ __launch_bounds__(16 * TH * KS) void conv_to3_pipe_kernel(To3Args a) {
+  constexpr int P = K / 2, CK = 2, TW = 64, NG = 16 * TH, NW = NG / 64, NT = 16 * TH * KS;
+  constexpr int TR = TH + K - 1;
+  constexpr int PITCH = 72;
+  constexpr int STAGE = CK * TR * PITCH;
+  constexpr int UK = ((STAGE + 255) / 256 + NW - 1) / NW;          // 1 KB pieces per wave and stage: the same for every wave
+  constexpr int BUF = UK * NW * 256, D = 3;
+  constexpr int WPC = (3 * K * K + 3) & ~3;                        // filter floats per input channel ([co][ky][kx], padded)
+  static_assert(NG % 64 == 0, "a channel group is a whole number of waves");
+  static_assert((KS - 1) * 12 * NG <= KS * D * BUF, "reduction buffer fits the stage buffers");
+  __shared__ __attribute__((aligned(16))) float smem_all[KS * D * BUF];
+  extern __shared__ __attribute__((aligned(16))) float w_s[];      // [Cin][WPC]
+
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / NG);
+  const int tid = threadIdx.x - grp * NG, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* smem = smem_all + grp * D * BUF;
+  const int lq = (lane >> 2) & 7;                                  // (the lane -> (row, quad) mapping of the kernel above)
+  const int txi = (lq >> 1) * 4 + (lane & 3), tyi = 4 * wave + 2 * (lane >> 5) + ((0x96 >> lq) & 1);
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const uint32_t HW = (uint32_t)a.H * (uint32_t)a.W;
+  const float* xb = a.x + (int64_t)b * a.xbs;
+
+  for (int o = threadIdx.x; o < a.Cin * 3 * K * K; o += NT) {      // the filter -> LDS, [c][co][tap]
+    const int c = o / (3 * K * K), r = o - c * (3 * K * K);
+    const int co = r / (K * K), tp = r - co * (K * K);
+    w_s[c * WPC + r] = a.w[((int64_t)co * a.Cin + c) * (K * K) + tp];
+  }
+
+  int off[UK];                                                     // (channel-in-stage << 28) | (gy * W + gx), -1 = zero fill
+#pragma unroll
+  for (int k = 0; k < UK; ++k) {
+    const int e = ((wave + NW * k) * 64 + lane) * 4;
+    const int c = e / (TR * PITCH);
+    const int rem = e - c * (TR * PITCH);
+    const int r = rem / PITCH, j = rem - r * PITCH;
+    const int gy = y0 - P + r, gx = x0 - 4 + j;
+    const bool ok = c < CK && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    off[k] = ok ? ((c << 28) | (gy * a.W + gx)) : -1;
+  }
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr3_t)smem) + (unsigned)wave * 1024u;
+  auto issue = [&](int bi, int c0) {                               // stage of channels c0, c0 + 1 -> ring buffer bi
+#pragma unroll
+    for (int k = 0; k < UK; ++k) {
+      const int v = off[k];
+      const int c = c0 + (v >> 28);
+      const bool ok = v >= 0 && c < a.Cin;
+      const float* g = ok ? xb + (uint64_t)(uint32_t)c * HW + (uint32_t)(v & 0x0fffffff) : g_to3_zero;
+      const unsigned dst = lds0 + (unsigned)(bi * BUF + NW * k * 256) * 4u;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory");
+    }
+  };
+
+  float acc[3][4];
+#pragma unroll
+  for (int co = 0; co < 3; ++co)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+
+  const int nst = (a.Cin + CK - 1) / CK, per = (nst + KS - 1) / KS;
+  const int s0 = grp * per, s1 = s0 + per < nst ? s0 + per : nst;
+  if (s0 < s1) issue(0, s0 * CK);
+  if (s0 + 1 < s1) issue(1, (s0 + 1) * CK);
+  __syncthreads();                                                 // the filter is in LDS (the copies are not waited for here)
+
+  int bi = 0;                                                      // ring buffer of stage i
+  for (int i = 0; i < per; ++i) {
+    const int st = s0 + i;
+    // stage i has landed (the pieces of stage i + 1, issued behind it, may still be in flight); everybody has left stage i - 1
+    if (st + 1 < s1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(UK) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (st + 2 < s1) issue(bi >= 1 ? bi - 1 : 2, (st + 2) * CK);   // (bi + 2) % 3: the buffer stage i - 1 was read from
+    const float* cur = smem + bi * BUF;
+    const int c0 = st * CK;
+    if (st < s1) {   // group-uniform
+#pragma unroll
+      for (int c = 0; c < CK; ++c) {
+        if (c0 + c < a.Cin) {   // uniform
+          const float* wc = w_s + (c0 + c) * WPC;
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            const float* row = cur + (c * TR + tyi + ky) * PITCH + 4 * txi;
+            float4 v0 = *reinterpret_cast<const float4*>(row);
+            float4 v1 = *reinterpret_cast<const float4*>(row + 4);
+            float4 v2 = *reinterpret_cast<const float4*>(row + 8);
+            asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w));       // (whole ds_read_b128s: see the kernel above)
+            asm volatile("" : "+v"(v2.x), "+v"(v2.y), "+v"(v2.z), "+v"(v2.w));
+            const float in[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+              for (int co = 0; co < 3; ++co) {
+                const float wv = wc[co * K * K + ky * K + kx];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, in[4 + p + kx - P], acc[co][p]);
+              }
+            }
+          }
+        }
+      }
+    }
+    bi = bi == 2 ? 0 : bi + 1;
+  }
+
+  if (KS > 1) {       // sum the channel groups (fixed order) into group 0
+    __syncthreads();  // every group has finished reading its stage buffers: the reduction image goes on top of them
+    float* red = smem_all;
+    if (grp > 0) {
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) red[((grp - 1) * 12 + co * 4 + p) * NG + tid] = acc[co][p];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g)
+#pragma unroll
+      for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[co][p] += red[((g - 1) * 12 + co * 4 + p) * NG + tid];
+  }
+
+  const int y = y0 + tyi, xx = x0 + 4 * txi;
+  float* __restrict__ outp = a.out;
+  const float* __restrict__ addp = a.addend;
+  if (y < a.H && xx < a.W) {                                       // (W % 4 == 0: a thread's four pixels are inside or outside together)
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+      const int64_t o = ((int64_t)b * 3 + co) * HW + (int64_t)y * a.W + xx;
+      float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ACT == TGSR_ACT_TANH_AXPY && addp) ad = *reinterpret_cast<const float4*>(addp + o);
+      const float adv[4] = {ad.x, ad.y, ad.z, ad.w};
+      float r[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) r[p] = ACT == TGSR_ACT_TANH_AXPY ? fast_tanh(acc[co][p]) + a.alpha * adv[p] : acc[co][p];
+      *reinterpret_cast<float4*>(outp + o) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The same heads on the matrix cores (fp32 MFMA 16x16x4, exact fmaf chains) for the large images.  Three output channels
 // cannot fill an MFMA tile, so the kernel column kx moves into the M dimension: rows r = co * K + kx (15 of 16 for the
 // 5x5 heads) and
@@ -337,6 +500,12 @@ __global__ __launch_bounds__(256) void conv_to3_mfma_kernel(To3Args a) {
   }
 }
 
+static int g_to3_pipe = [] {
+  const char* e = getenv("TGSR_TO3_PIPE");
+  return (e && e[0] == '0') ? 0 : 1;
+}();
+static bool to3_pipe() { return g_to3_pipe != 0; }
+
 template <int K, int ACT, int TH, int KS>
 static int launch_to3_th(To3Args a, hipStream_t s) {
   a.tiles_x = (a.W + 63) / 64;
@@ -345,7 +514,11 @@ static int launch_to3_th(To3Args a, hipStream_t s) {
   const bool vec4 = (a.W % 4 == 0) && (a.xbs % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.x) & 15) == 0) &&
                     ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0) &&
                     (!a.addend || (reinterpret_cast<uintptr_t>(a.addend) & 15) == 0);
-  if (vec4)
+  constexpr int WPC = (3 * K * K + 3) & ~3;
+  const size_t wbytes = (size_t)a.Cin * WPC * sizeof(float);
+  if (vec4 && wbytes <= 16 * 1024 && to3_pipe())
+    hipLaunchKernelGGL((conv_to3_pipe_kernel<K, ACT, TH, KS>), grid, dim3(16 * TH * KS), wbytes, s, a);
+  else if (vec4)
     hipLaunchKernelGGL((conv_to3_kernel<K, ACT, true, TH, KS>), grid, dim3(16 * TH * KS), 0, s, a);
   else
     hipLaunchKernelGGL((conv_to3_kernel<K, ACT, false, TH, KS>), grid, dim3(16 * TH * KS), 0, s, a);
@@ -376,6 +549,12 @@ static int launch_to3(To3Args a, hipStream_t s) {
 }  // namespace tgsr
 
 using namespace tgsr;
+
+extern "C" int tgsr_conv_to3_set_pipe(int on) {
+  const int was = g_to3_pipe;
+  g_to3_pipe = on ? 1 : 0;
+  return was;
+}
 
 extern "C" int tgsr_conv_to3_fwd(const float* x, int64_t x_bstride, int B, int Cin, int H, int W, const float* w,
                                  int K, int act, const float* addend, float alpha, float* out, void* stream) {

@@ -955,6 +955,11 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 
 # ----------------------------------------------------------------------------------------- training path primitives
+def conv_to3_set_pipe(on: bool) -> bool:
+    """The image heads' streaming kernel with its copies two stages ahead (default) or the plain double buffer; returns the previous setting."""
+    return bool(_lib.lib().tgsr_conv_to3_set_pipe(1 if on else 0))
+
+
 def bn_set_fuse_small(on: bool) -> bool:
     """Small BatchNorm layers (one workgroup per channel) as one launch per direction (default) or two; returns the previous setting."""
     return bool(_lib.lib().tgsr_bn_set_fuse_small(1 if on else 0))
