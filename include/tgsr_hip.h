@@ -436,6 +436,13 @@ int tgsr_axpy_images(int n, float* const* out, const float* const* t, const floa
  * tgsr_bilinear_*: nn.Upsample(size = (OH, OW), mode = 'bilinear') (align_corners = False), util.py:310, on dense planes.
  */
 int tgsr_gconv_set_form(int split); /*
+ * out[k] = ((parts[0][k] + parts[1][k]) + ...) over n dense tensors of m floats stacked back to back (m % 4 == 0, 16-byte aligned):
+ * the branches' contributions to a Mixed block's input gradient (util.py:281-298's blocks), each written by its own branch's stream,
+ * summed in the order a one-stream walk accumulates them.
+ */
+int tgsr_sum_stack(const float* parts, int n, int64_t m, float* out, void* stream);
+
+/*
  * dx[b][c][2Y + py][2X + px] (+)= t_{py px}[b][c][Y][X] over `planes` = B * C dense planes of H x W: weaves the four parity classes of
  * a stride-2 convolution's data gradient - each a stride-1 data gradient over its own taps (tgsr_gconv), dense at half resolution,
  * ceil((H - py) / 2) x ceil((W - px) / 2) pixels - into the gradient of the input (util.py:281-298's stride-2 layers: a quarter of the

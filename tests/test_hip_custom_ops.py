@@ -294,3 +294,4 @@ def test_opcheck_round6_operators():
                                torch.tensor([0.0, 1.0, 1.0], device=DEV), 1e-3, 0.5, 0.999, 1e-8, 0.0, True), test_utils=basic)
     chk(T.interleave2x2_.default, (R(2, 3, 3, 4), R(2, 3, 3, 3), R(2, 3, 2, 4), R(2, 3, 2, 3), torch.zeros(2, 3, 5, 7, device=DEV), True,
                                    R(2, 3, 5, 7)), test_utils=basic)
+    chk(T.sum_stack.default, (R(3, 2, 4, 6), 3, torch.zeros(2, 4, 6, device=DEV)), test_utils=basic)

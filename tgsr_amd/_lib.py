@@ -113,6 +113,7 @@ SIGNATURES = {
     "tgsr_maxpool3s2_fwd": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _vp]),
     "tgsr_maxpool3s2_bwd": (_i, [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp, _vp]),
     "tgsr_avgpool3": (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _i64, _i, _vp, _vp]),
+    "tgsr_sum_stack": (_i, [_vp, _i, _i64, _vp, _vp]),
     "tgsr_interleave2x2": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "tgsr_plane_mean": (_i, [_vp, _vp, _i64, _i, _vp]),
     "tgsr_plane_mean_bwd": (_i, [_vp, _vp, _i64, _i, _vp]),

@@ -368,6 +368,21 @@ __global__ __launch_bounds__(256) void interleave2x2_kernel(const float* __restr
   }
 }
 
+// out[k] = ((parts[0][k] + parts[1][k]) + parts[2][k]) + ...  over n dense tensors of m floats stacked back to back: the contributions
+// to a Mixed block's input gradient, each computed on its own branch's stream into its own slot, summed in the order a one-stream walk
+// would have accumulated them (the same bits).  m % 4 == 0, 16-byte aligned.
+__global__ __launch_bounds__(256) void sum_stack_kernel(const float* __restrict__ parts, int n, int64_t m4, float* __restrict__ out) {
+  const float4* p = reinterpret_cast<const float4*>(parts);
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < m4; k += (int64_t)gridDim.x * 256) {
+    float4 s = p[k];
+    for (int z = 1; z < n; ++z) {
+      const float4 v = p[(int64_t)z * m4 + k];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[k] = s;
+  }
+}
+
 // mean over the HW pixels of every (b, c) plane: one wave per plane (the 8 x 8 global average pool); backward: broadcast / HW
 __global__ __launch_bounds__(256) void plane_mean_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes, int HW) {
   const int64_t pl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -621,6 +636,13 @@ extern "C" int tgsr_interleave2x2(const float* t00, const float* t01, const floa
   hipLaunchKernelGGL(interleave2x2_kernel, dim3(gc_grid(total)), dim3(256), 0, as_stream(stream), t00, t01, t10, t11, dx, H, W, total,
                      accumulate, mask);
   return note_launch(hipGetLastError(), "interleave2x2_kernel");
+}
+
+extern "C" int tgsr_sum_stack(const float* parts, int n, int64_t m, float* out, void* stream) {
+  if (!parts || !out || n < 1 || m < 1) return TGSR_EINVAL;
+  if ((m & 3) || ((reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(out)) & 15)) return TGSR_EUNSUPPORTED;
+  hipLaunchKernelGGL(sum_stack_kernel, dim3(gc_grid(m >> 2)), dim3(256), 0, as_stream(stream), parts, n, m >> 2, out);
+  return note_launch(hipGetLastError(), "sum_stack_kernel");
 }
 
 extern "C" int tgsr_plane_mean(const float* x, float* out, int64_t planes, int HW, void* stream) {

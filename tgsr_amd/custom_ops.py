@@ -515,6 +515,7 @@ relu_mask_ = _define("relu_mask_(Tensor(a!) dy, Tensor y, int coff, int ch) -> (
                      lambda *a: None)
 bilinear = _define("bilinear(Tensor x, int OH, int OW) -> Tensor", lambda x, OH, OW: ops.bilinear(x, OH, OW),
                    lambda x, OH, OW: x.new_empty(x.shape[0], x.shape[1], OH, OW))
+sum_stack = _define("sum_stack(Tensor stack, int n, Tensor(a!) out) -> ()", lambda st, n, out: ops.sum_stack(st, n, out), lambda *a: None)
 interleave2x2_ = _define("interleave2x2_(Tensor t00, Tensor t01, Tensor t10, Tensor t11, Tensor(a!) dx, bool accumulate, Tensor? mask) -> ()",
                          lambda a, b, c, d, dx, acc, m: ops.interleave2x2((a, b, c, d), dx, acc, m), lambda *a: None)
 bilinear_bwd = _define("bilinear_bwd(Tensor dy, int H, int W) -> Tensor", lambda dy, H, W: ops.bilinear_bwd(dy, H, W),

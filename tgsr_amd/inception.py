@@ -30,6 +30,9 @@ RESIZE = 299
 TRUNK_STREAMS = max(1, min(4, int(os.environ.get("TGSR_TRUNK_STREAMS", "4"))))
 # stride-2 data gradients as four stride-1 class GEMMs + an interleave (_Layer.refresh); TGSR_TRUNK_CLASS_DGRAD=0: the direct form
 CLASS_DGRAD = os.environ.get("TGSR_TRUNK_CLASS_DGRAD", "1") != "0"
+# the branches' contributions to a block's input gradient each into a slot of their own, on their branch's stream, summed in the tape's
+# order behind the join (tgsr::sum_stack); TGSR_TRUNK_HEADS_PARALLEL=0: accumulated one after the other behind the join (same bits)
+HEADS_PARALLEL = os.environ.get("TGSR_TRUNK_HEADS_PARALLEL", "1") != "0"
 
 
 class _Layer:
@@ -341,17 +344,22 @@ class InceptionTrunk:
                 grads[i] = torch.empty_like(T[i])
                 return grads[i], False, m
             return grads[i], True, m
-        def one(kind, L, src, dst, coff, s):
+        def one(kind, L, src, dst, coff, s, into=None):
+            """The backward of one tape entry on stream index s; `into`: write the contribution (masked, not accumulated) there
+            instead of adding it to the gradient of tensor `src`.  False: nothing reached this entry."""
             g = grads[dst]
             if g is None:                       # nothing downstream of this tensor reached the loss
-                return
+                return False
             if self.keep_grads and dst not in self.snaps:
                 if block_src is not None:
                     self._join_streams()
                 self.snaps[dst] = g.clone()
                 if block_src is not None:
                     self._fork_streams()
-            dx, acc, m = target(src)            # (allocated on the caller's stream, outside the launch's stream scope)
+            if into is None:
+                dx, acc, m = target(src)        # (allocated on the caller's stream, outside the launch's stream scope)
+            else:
+                dx, acc, m = into, False, (T[src] if src != 0 else None)
             if kind == "conv" and L.class_dgrad_ok(dx.shape[2], dx.shape[3]):
                 Bn, _, H, W = dx.shape
                 parts = [torch.empty(Bn, L.cin, (H - py + 1) // 2, (W - px + 1) // 2, dtype=torch.float32, device=dx.device)
@@ -373,26 +381,50 @@ class InceptionTrunk:
             else:                               # avgpool3: symmetric
                 with self._run(s):
                     C.avgpool3(g, dx, acc, m)
+            return True
 
-        # A block's backward: fork, every branch's layers on its stream EXCEPT the ones that add into the gradient of the block
-        # input (the head of every branch) - those run after the join, on the caller's stream, in the order of the tape: the sum
-        # is formed in the same order as on one stream.
-        block_src, heads = None, []
+        # A block's backward: fork; every branch's layers on its stream.  The layers that feed the gradient of the block INPUT (the
+        # head of every branch) all add to one tensor: each writes its masked contribution into a slot of its own - on its
+        # branch's stream, beside the longer branches - and behind the join one pass sums the slots in the tape's order, so the
+        # sum has the bits of the one-stream walk's accumulation (which is what runs with one stream, or with
+        # TGSR_TRUNK_HEADS_PARALLEL=0: the heads one after the other behind the join).
+        slots = HEADS_PARALLEL and len(self._streams) > 1
+        block_src, heads, stack, nslot = None, [], None, 0
         for kind, L, src, dst, coff, s in reversed(self.tape):
             if kind == "join":                  # (the end of a block in the forward walk = where its backward begins)
                 if grads[dst] is not None:
-                    block_src, heads = src, []
+                    block_src, heads, nslot = src, [], 0
+                    if slots:
+                        stack = torch.empty((5,) + tuple(T[src].shape), dtype=torch.float32, device=T[src].device)
+                        self._ws_old.append(stack)
+                        if grads[src] is not None:          # a gradient that arrived earlier goes first, as it would in place
+                            stack[0].copy_(grads[src])
+                            nslot = 1
                     self._fork_streams()
                 continue
             if kind == "fork":
                 if block_src is not None:
                     self._join_streams()
-                    block_src = None
-                    for h in heads:
-                        one(*h[:5], 0)
+                    bs, block_src = block_src, None
+                    if slots:
+                        if nslot == 1 and grads[bs] is None:
+                            grads[bs] = stack[0]
+                        elif nslot >= 1:
+                            if grads[bs] is None:
+                                grads[bs] = torch.empty_like(T[bs])
+                            C.sum_stack(stack, nslot, grads[bs])
+                    else:
+                        for h in heads:
+                            one(*h[:5], 0)
                 continue
             if block_src is not None and src == block_src:
-                heads.append((kind, L, src, dst, coff))
+                if slots:
+                    if nslot >= 5:
+                        raise TgsrError("a Mixed block with more than four branches reading its input")
+                    if one(kind, L, src, dst, coff, self._sidx(s), into=stack[nslot]):
+                        nslot += 1
+                else:
+                    heads.append((kind, L, src, dst, coff))
                 continue
             one(kind, L, src, dst, coff, self._sidx(s) if block_src is not None else 0)
         d299 = grads[0]

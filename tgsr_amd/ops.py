@@ -1444,6 +1444,16 @@ def gconv(dgrad: bool, A: torch.Tensor, S: torch.Tensor, s_coff: int, s_ch: int,
 
 
 
+
+def sum_stack(stack: torch.Tensor, n: int, out: torch.Tensor):
+    """out = ((stack[0] + stack[1]) + ...) + stack[n - 1]: the first n slices of a dense stack [N, ...] summed in order (tgsr_sum_stack)."""
+    _need_hip(stack, out)
+    if stack.dtype != torch.float32 or not stack.is_contiguous() or not out.is_contiguous() or out.dtype != torch.float32:
+        raise TgsrError("sum_stack: dense fp32 tensors expected")
+    if n < 1 or n > stack.shape[0] or tuple(stack.shape[1:]) != tuple(out.shape):
+        raise TgsrError("sum_stack: %d slices of %s into %s" % (n, tuple(stack.shape), tuple(out.shape)))
+    check(_lib.lib().tgsr_sum_stack(_p(stack), n, out.numel(), _p(out), _stream()), "tgsr_sum_stack")
+
 def interleave2x2(parts, dx: torch.Tensor, accumulate: bool, mask: Optional[torch.Tensor] = None):
     """dx[:, :, py::2, px::2] (+)= parts[2 py + px] (dense [B, C, ceil((H - py) / 2), ceil((W - px) / 2)]), masked where mask <= 0:
     the four parity classes of a stride-2 convolution's data gradient woven into one tensor (tgsr_interleave2x2)."""
