@@ -712,3 +712,61 @@ def test_weighted_bce_op_equals_the_sum_of_torch_bce_terms():
     (3.0 * o1).backward()
     assert abs(float(o1) - float(bce(l1, torch.ones(5)))) < 1e-5 * float(bce(l1, torch.ones(5)))
     close(a1d.grad, a1.grad, atol=1e-7, rtol=1e-5)
+
+
+def test_image_encoder_beside_the_discriminator_updates(monkeypatch):
+    """generator_loss's image encoder reads the fake image only, so SRTrainer issues it BEFORE the discriminator updates on a stream of
+    its own (TGSR_ENC_EARLY, the default) - eagerly, and as a hipGraph of its own replayed beside the discriminators' graphs.  Three
+    trainers from one initialisation - encoder inside generator_loss (eager), encoder early (eager), encoder early (replayed) - take
+    the same G/D + DAMSM steps: the early forms are bit-identical to each other, and equal to the late form up to the order in which
+    autograd adds the fake image's gradient contributions."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from inception_v3_arch import InceptionV3Arch
+    from tgsr_amd.miscc.config import cfg, cfg_reset
+    from tgsr_amd import train
+    from tgsr_amd.util import CNN_ENCODER
+    cfg_reset()
+    cfg.GAN.GF_DIM, cfg.TEXT.EMBEDDING_DIM, cfg.GAN.DF_DIM = 32, 256, 16
+    cfg.TRAIN.FLAG = True
+    try:
+        B = 4
+        trs = []
+        for early, graphs in (("0", False), ("1", False), ("1", True)):
+            monkeypatch.setenv("TGSR_ENC_EARLY", early)
+            torch.manual_seed(5)
+            enc = CNN_ENCODER(cfg.TEXT.EMBEDDING_DIM, inception=InceptionV3Arch(seed=1)).to(DEV).eval()
+            for q in enc.parameters():
+                q.requires_grad = False
+            tr = train.SRTrainer(41, device=DEV, discriminators=True, image_encoder=enc)
+            assert (tr._encst is not None) == (early == "1")
+            tr._graph_g = graphs
+            trs.append(tr)
+        out = [[] for _ in trs]
+        for step in range(5):
+            cap, lens, LR, LRb = O.synthetic_batch(B, seed=40)               # (one caption shape: the replaying trainer captures once)
+            g = torch.Generator().manual_seed(step)
+            LR = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+            hr = [(torch.rand(B, 3, s, s, generator=g) * 2 - 1).to(DEV) for s in (64, 128, 256)]
+            for k, tr in enumerate(trs):
+                torch.manual_seed(100 + step)
+                errG, errsD = tr.step_gan(cap.to(DEV), lens.tolist(), LR.to(DEV), LRb.to(DEV), hr)
+                out[k].append([float(errG)] + [float(e) for e in errsD])
+        torch.cuda.synchronize()
+        caps = list(trs[2]._ggraphs.values())
+        assert caps and all(isinstance(c, dict) and c["enc"] is not None for c in caps), "the encoder's graph was not captured"
+        # early, eager == early, replayed: bit for bit
+        assert out[1] == out[2], (out[1], out[2])
+        for a, b in zip(trs[1].params, trs[2].params):
+            assert torch.equal(a, b)
+        for da, db in zip(trs[1].netsD, trs[2].netsD):
+            for (ka, va), (_kb, vb) in zip(da.state_dict().items(), db.state_dict().items()):
+                assert torch.equal(va, vb), ka
+        # early against late: the same terms, but the encoder's node is now OLDER than the discriminators' in the autograd graph, so the
+        # fake image's gradient adds its three contributions (discriminator, encoder, MSE) in another order: equal to rounding
+        # (the first step's losses - forward only - are the same bits; the second step's sit on parameters that differ by that rounding;
+        # from there the adversarial dynamics amplify it like any other rounding difference: 0.3 % by the fifth step)
+        assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+        assert np.allclose(np.array(out[0][1]), np.array(out[1][1]), rtol=1e-5, atol=0), (out[0][1], out[1][1])
+    finally:
+        cfg_reset()

@@ -114,6 +114,7 @@ class InceptionTrunk:
                         self.layers[name + "." + bname] = _Layer(sub)
         self.tape = None
         self.nstreams = TRUNK_STREAMS
+        self.bwd_stream = None                 # see TrunkFn.backward
         self._side = None                      # the side streams (created on first use, distinct from the caller's)
         self._streams = None                   # [caller's stream] + side streams of the walk in progress
 
@@ -469,7 +470,22 @@ class TrunkFn(torch.autograd.Function):
             return None, None
         ctx.runner.put_state(ctx.state)
         ctx.state = None
+        # autograd runs this node on the stream its forward ran on.  When the forward was issued early on a stream of its own
+        # (train.SRTrainer: beside the discriminator updates), that stream is a forked branch of the step's backward - and the
+        # walk's own forks off it would be forks nested in a forked branch, which ROCm 7.2's stream capture does not survive: the
+        # caller names the stream the backward walk belongs on (`runner.bwd_stream`: the step's main / capture stream); the node's
+        # own stream only hands the gradients over and takes the result back.
+        here = torch.cuda.current_stream(d_feats.device if d_feats is not None else d_pooled.device)
+        to = ctx.runner.bwd_stream
         try:
-            return ctx.runner.backward(d_feats, d_pooled), None
+            if to is None or int(to.cuda_stream) == int(here.cuda_stream):
+                return ctx.runner.backward(d_feats, d_pooled), None
+            to.wait_stream(here)
+            with torch.cuda.stream(to):
+                dx = ctx.runner.backward(d_feats, d_pooled)
+            here.wait_stream(to)
+            if dx is not None and not torch.cuda.is_current_stream_capturing():
+                dx.record_stream(here)           # (allocated on `to`, handed on by `here`)
+            return dx, None
         finally:
             ctx.runner.take_state()

@@ -220,12 +220,14 @@ def damsm_terms(regions, code, words_embs, sent_emb, cap_lens, class_ids, gather
 
 
 def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sent_emb, match_labels, cap_lens,
-                   class_ids, w=1, s=1, g=1, streams=None, lazy_log=False, gather_negatives=False):
+                   class_ids, w=1, s=1, g=1, streams=None, lazy_log=False, gather_negatives=False, enc_out=None):
     """losses.py:351-391: per-scale adversarial terms + the DAMSM words / sentence ranking loss on the last scale
     (x TRAIN.SMOOTH.LAMBDA).  Returns (total, log) like the reference: `log` is the same str; with `lazy_log=True` (not a
     reference argument) a _LazyLog stands in for it - the same text, formatted (and the device synchronised) only when it
     is looked at.  `image_encoder=None` (the reference
-    always has one; its Inception-v3 weights are third-party and not shipped) leaves the ranking term out."""
+    always has one; its Inception-v3 weights are third-party and not shipped) leaves the ranking term out.  `enc_out` (not a
+    reference argument): `image_encoder(fake_imgs[-1])` computed by the caller already - the encoder reads the fake image only, not
+    the discriminators, so train.SRTrainer runs it beside the discriminator updates that precede this call."""
     B = real_labels.size(0)
     total, parts = 0, []
     advs = []
@@ -256,8 +258,7 @@ def generator_loss(netsD, image_encoder, fake_imgs, real_labels, words_embs, sen
     # the ranking term's image encoder (the frozen trunk: ~190 launches forward) is issued BEFORE the calling stream joins the
     # discriminators' streams: it reads the last fake image only, so it runs beside their forward passes (and, through autograd's
     # stream rule, its backward beside theirs)
-    enc_out = None
-    if image_encoder is not None and len(netsD) > 0:
+    if enc_out is None and image_encoder is not None and len(netsD) > 0:
         enc_out = image_encoder(fake_imgs[len(netsD) - 1])
     for k, (netD, img) in enumerate(zip(netsD, fake_imgs)):
         adv = advs[k]

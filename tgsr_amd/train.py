@@ -183,6 +183,17 @@ class SRTrainer:
         self._dwside = distinct_streams(len(self._dstreams), self.device, avoid=taken) \
             if self._dstreams and os.environ.get("TGSR_D_WGRAD_SIDE", "0") == "1" else []
         taken = taken + [st.cuda_stream for st in self._dwside]
+        # TGSR_ENC_EARLY=1 (opt-in): generator_loss's image encoder (CNN_ENCODER: ~190 launches of small GEMMs forward) reads the fake
+        # image only - not the discriminators - so it can be issued BEFORE the discriminator updates, on a stream of its own (as a
+        # hipGraph of its own when the step is replayed), and run beside them; its backward stays where it was.  Built, parity-green
+        # (the early forms, eager and replayed, are bit-identical; against the late form the fake image's gradient adds its terms in
+        # another order) and NOT faster: 29.6 / 29.8 against 28.7 / 29.6 ms (two pairs, one box) - "one kernel in flight" during the
+        # 256^2 discriminator's update does not mean idle CUs: its GEMMs fill the chip, and the encoder's kernels only lengthen them.
+        self._encst = distinct_streams(1, self.device, avoid=taken)[0] \
+            if (self.device.type == "cuda" and image_encoder is not None and self.netsD and
+                os.environ.get("TGSR_ENC_EARLY", "0") == "1") else None
+        if self._encst is not None:
+            taken = taken + [self._encst.cuda_stream]
         # the stream the generators' graphs are captured on, and the branch their re-pack launches fork onto
         self._gcap, self._gpack = distinct_streams(2, self.device, avoid=taken) if self._graph_capable else (None, None)
 
@@ -319,14 +330,36 @@ class SRTrainer:
         return [losses.discriminator_loss(d, hr_pyramid[i], fine_im[i], sent_emb, real_labels, fake_labels)
                 for i, d in enumerate(self.netsD)]
 
-    def g_loss(self, fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids=None):
-        """generator_loss (losses.py:351-391) on the fine images + the pixel and KL terms of `loss`."""
+    def g_loss(self, fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids=None, enc_out=None):
+        """generator_loss (losses.py:351-391) on the fine images + the pixel and KL terms of `loss`.  enc_out: the image encoder's
+        outputs on the finest fake image when `_encode_early` has computed them already."""
         B = sent_emb.shape[0]
         real_labels, _fake, match_labels = prepare_labels(B, self.device)
         adv, _log = losses.generator_loss(self.netsD, self.image_encoder, fine_im, real_labels, words_embs, sent_emb,
                                           match_labels, cap_lens, class_ids, streams=self._dstreams or None, lazy_log=True,
-                                          gather_negatives=self.gather_negatives)
+                                          gather_negatives=self.gather_negatives, enc_out=enc_out)
         return adv + self._pixel_kl(fake_imgL, fine_im, mu, logvar, hr_pyramid)
+
+    def _encode_early(self, image):
+        """`self.image_encoder(image)` on the encoder's own stream, forked from the current one (the image is ready there); the
+        caller joins with `_encode_join` before it uses the outputs.  None when the early form is off."""
+        if self._encst is None:
+            return None
+        main = torch.cuda.current_stream(self.device)
+        self._encst.wait_stream(main)
+        with torch.cuda.stream(self._encst):
+            if not torch.cuda.is_current_stream_capturing():
+                image.record_stream(self._encst)
+            return self.image_encoder(image)
+
+    def _encode_join(self, enc_out):
+        if enc_out is None:
+            return
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(self._encst)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in enc_out:
+                t.record_stream(main)
 
     @contextlib.contextmanager
     def _use_packs(self):
@@ -541,6 +574,9 @@ class SRTrainer:
             self._arm_early()
         else:
             self._early, self._early_left = None, -1
+        trunk = getattr(self.image_encoder, "_hip_trunk", None)
+        if trunk is not None:
+            trunk.bwd_stream = torch.cuda.current_stream(self.device)      # (inception.TrunkFn.backward: where the walk belongs)
         with self._use_packs(), self._wgrad_side():
             errG.backward()
 
@@ -569,7 +605,7 @@ class SRTrainer:
         split = dp_world() > 1
         st = self._gcap
         buf = {"LR": LR.clone(), "LRb": LRb.clone(), "hr": [h.clone() for h in hr_pyramid], "words": words_embs.clone(),
-               "sent": sent_emb.clone(), "mask": mask.clone(), "fwd": None, "opt": None}
+               "sent": sent_emb.clone(), "mask": mask.clone(), "fwd": None, "opt": None, "enc": None}
         buf["dst"] = [buf["LR"], buf["LRb"], buf["words"], buf["sent"], buf["mask"]] + buf["hr"]
         pool = torch.cuda.graph_pool_handle()
         cap_lens = [int(v) for v in cap_lens]
@@ -584,6 +620,14 @@ class SRTrainer:
                     with self._use_packs():
                         nets = self._forward_nets(buf["LR"], buf["LRb"], buf["words"], buf["sent"], buf["mask"])
                 buf["fine"] = nets[1]
+                if self._encst is not None:
+                    # the image encoder's forward as a graph of its own, captured on ITS stream as the origin (its branch forks are
+                    # then plain diamonds) and replayed beside the discriminators' graphs; its autograd node stays alive for "fb"
+                    buf["enc"] = torch.cuda.CUDAGraph()
+                    self._encst.wait_stream(st)
+                    with torch.cuda.graph(buf["enc"], stream=self._encst, pool=pool):
+                        buf["enc_out"] = self.image_encoder(nets[1][len(self.netsD) - 1])
+                    st.wait_stream(self._encst)
             fb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(fb, stream=st, pool=pool):
                 self.bucket.begin_step()
@@ -591,7 +635,8 @@ class SRTrainer:
                 if gan:
                     for p in d_params:
                         p.requires_grad_(False)
-                    errG = self.g_loss(nets[0], nets[1], nets[2], nets[3], buf["words"], buf["sent"], cap_lens, buf["hr"], class_ids)
+                    errG = self.g_loss(nets[0], nets[1], nets[2], nets[3], buf["words"], buf["sent"], cap_lens, buf["hr"], class_ids,
+                                       enc_out=buf.get("enc_out"))
                 else:
                     with self._use_packs():
                         nets = self._forward_nets(buf["LR"], buf["LRb"], buf["words"], buf["sent"], buf["mask"])
@@ -673,13 +718,22 @@ class SRTrainer:
         if g is not None:
             self._g_load(g, LR, LRb, hr_pyramid, words_embs, sent_emb, mask)
             g["fwd"].replay()
+            if g["enc"] is not None:                        # the image encoder's forward beside the discriminator updates
+                main = torch.cuda.current_stream(self.device)
+                self._encst.wait_stream(main)
+                with torch.cuda.stream(self._encst):
+                    g["enc"].replay()
             errsD = self._d_updates(g["fine"], g["hr"], g["sent"])
+            if g["enc"] is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._encst)
             errG = self._g_update_replay(g)
             self._auto_end(True)
             return errG, [e.detach() for e in errsD]
         with self._use_packs():
             fake_imgL, fine_im, mu, logvar = self._forward_nets(LR, LRb, words_embs, sent_emb, mask)
+        enc_out = self._encode_early(fine_im[len(self.netsD) - 1])          # beside the discriminator updates
         errsD = self._d_updates(fine_im, hr_pyramid, sent_emb)
+        self._encode_join(enc_out)
         self._zero(self.bucket)
         # the discriminators only pass the gradient through to the images here: their own parameter gradients would be
         # discarded (the next discriminator update zeroes its bucket first), so they are not computed
@@ -687,7 +741,7 @@ class SRTrainer:
         for p in d_params:
             p.requires_grad_(False)
         try:
-            errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids)
+            errG = self.g_loss(fake_imgL, fine_im, mu, logvar, words_embs, sent_emb, cap_lens, hr_pyramid, class_ids, enc_out=enc_out)
             self._g_backward(errG)
         finally:
             for p in d_params:
