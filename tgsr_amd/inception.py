@@ -396,8 +396,9 @@ class InceptionTrunk:
                 if grads[dst] is not None:
                     block_src, heads, nslot = src, [], 0
                     if slots:
+                        # (allocated and - behind the join - summed on the caller's stream, written in between by side streams the
+                        # caller has joined by then: it can go back to the allocator as soon as the sum is queued)
                         stack = torch.empty((5,) + tuple(T[src].shape), dtype=torch.float32, device=T[src].device)
-                        self._ws_old.append(stack)
                         if grads[src] is not None:          # a gradient that arrived earlier goes first, as it would in place
                             stack[0].copy_(grads[src])
                             nslot = 1
@@ -414,6 +415,7 @@ class InceptionTrunk:
                             if grads[bs] is None:
                                 grads[bs] = torch.empty_like(T[bs])
                             C.sum_stack(stack, nslot, grads[bs])
+                        stack = None
                     else:
                         for h in heads:
                             one(*h[:5], 0)
