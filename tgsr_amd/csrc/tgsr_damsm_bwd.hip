@@ -6,12 +6,14 @@
 //   s[l][r]   = sum_d word[d][l] ctx[d][r]              a1 = softmax_l(s)   a2 = softmax_r(gamma1 * a1)
 //   wc[d][l]  = sum_r ctx[d][r] a2[l][r]                cos_l = <word_l, wc_l> / max(|word_l| |wc_l|, 1e-8)
 //   sim       = log sum_l exp(gamma2 cos_l)
-// Two thread mappings alternate: thread = region r (scores, both softmax backward passes; ctx columns are coalesced
-// global reads, the [ndf][32] word / dwc matrices are LDS broadcasts) and thread = feature d (weighted context and
-// every gradient row; each thread keeps its row of word, wc, dwc, gword in registers, ctx is staged through LDS in
-// [ndf][32 regions] chunks, the [32][S] attention images are broadcast reads of a per-pair global workspace).
+// Two thread mappings alternate: thread = region r (scores, both softmax backward passes; ctx arrives in 32-row slabs
+// through LDS, the [ndf][32] word / dwc matrices are LDS broadcasts) and thread = (feature d, half of the words)
+// (weighted context and every gradient row; each thread keeps its 16 words of word, wc, dwc, gword in registers, ctx and the
+// chunk's columns of the [32][S] attention images are staged through LDS in chunks of 32 regions).
 // Per-pair gradients go to gw_part[j][i][ndf][32] and gc_part[i][j][ndf][S]; tgsr_reduce_dim0 sums them in a fixed
-// order (deterministic, no float atomics).  This is a loss kernel (8 MFLOP per pair): clarity over speed.
+// order (deterministic, no float atomics).  A loss kernel (28 MFLOP per pair) on the vector units - which ran 0.96 ms ALONE on the
+// device in the G/D + DAMSM step and is a quarter of a DAMSM pre-training step: round 6 took its dependent global loads out
+// (0.69 ms with its reductions) and gave a pair 512 threads instead of 256 (two waves per SIMD).
 #include "tgsr_common.h"
 
 namespace tgsr {
@@ -29,8 +31,15 @@ struct DamsmBwdArgs {
 };
 
 constexpr int kBwdChunk = 32;   // regions per LDS chunk in the thread = d phases
+constexpr int kBwdNT = 512;     // threads per pair: 8 waves = 2 per SIMD (one wave per SIMD issues a VALU instruction every 4 cycles, two
+                                // fill the 2-cycle slots: the kernel is VALU / LDS issue bound)
 
-__global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
+// Thread mappings (round 6: 512 threads per pair instead of 256):
+//   thread = region r (tid < S <= 320: five waves, one pass): scores + softmax over words, the da2 products, softmax-r backward;
+//   thread = (feature d = tid & 255, word half h = tid >> 8): weighted context, cosine / log-sum-exp backward, every gradient row -
+//     a thread keeps its 16 words of word / wc / dwc / gword in registers; the two halves of a gctx value meet in LDS (h = 0 first).
+// Reductions over d per word: the four waves that hold a word's 256 features (waves 4 h .. 4 h + 3), combined in a fixed order.
+__global__ __launch_bounds__(kBwdNT) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int ndf = a.ndf, S = a.S;
   float* word_s = lds;                       // [ndf][32]
@@ -40,11 +49,10 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   // (cs .. gcs also hold the region-mapped phases' [32][S] ctx slab: the region is as large as the larger of the two uses)
   const int csz = 2 * ndf * 33 > 32 * S ? 2 * ndf * 33 : 32 * S;
   float* red = cs + csz;                     // [4][32] reductions
-  float* wpart = red + 128;                  // [4 waves][128]: the waves' partial sums of those, combined in a fixed order
+  float* wpart = red + 128;                  // [8 waves][128]: the waves' partial sums of those, combined in a fixed order
   // the chunk's columns of the attention images, [region][32 words]: the thread = d phases read every (word, region) value of the
-  // chunk in EVERY thread - as LDS broadcasts (8 ds_read_b128 per region) instead of 32 / 64 dependent global loads per region from
-  // the per-pair workspace (one wave per SIMD hides none of their latency: the kernel ran 0.95 ms, alone on the device, that way)
-  float* a2s = wpart + 4 * 128;              // [32 regions][32]
+  // chunk in EVERY thread - as LDS broadcasts instead of dependent global loads from the per-pair workspace
+  float* a2s = wpart + 8 * 128;              // [32 regions][32]
   float* a3s = a2s + kBwdChunk * 32;         // [32 regions][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -58,81 +66,63 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   float* a2 = a1 + 32 * S;
   float* a3 = a2 + 32 * S;
 
-  for (int o = tid; o < ndf * 32; o += 256) {
+  for (int o = tid; o < ndf * 32; o += kBwdNT) {
     const int d = o >> 5, l = o & 31;
     word_s[o] = l < L ? wb[d * a.Tw + l] : 0.f;
   }
   if (tid < 128) red[tid] = 0.f;
   __syncthreads();
 
-  // ---- thread = r: scores, softmax over words, x gamma1
-  // ctx arrives in slabs of 32 feature rows [32][S] through LDS (the cs .. gcs region: 64 x 33 x ndf / 32 >= 32 x 320 floats), loaded
-  // with every thread's requests in flight together: the per-row global load inside the accumulation loop (256 dependent round
-  // trips per region at one wave per SIMD) was most of this phase's time.  Both passes over the regions (r = tid, tid + 256) share a slab.
+  // ---- thread = r: scores s[l][r] = sum_d word[d][l] ctx[d][r] (ctx in slabs of 32 feature rows through LDS), softmax over words
   float* slab = cs;
-  float sA[32], sB[32];
-#pragma unroll
-  for (int l = 0; l < 32; ++l) { sA[l] = 0.f; sB[l] = 0.f; }
-  const bool hasB = tid + 256 < S;
-  for (int d0 = 0; d0 < ndf; d0 += 32) {
-    for (int o = tid; o < 32 * S; o += 256) slab[o] = cb[(int64_t)d0 * S + o];
-    __syncthreads();
-    if (tid < S) {
-      for (int dd = 0; dd < 32; ++dd) {
-        const float c = slab[dd * S + tid];
-        const float4* wp = reinterpret_cast<const float4*>(word_s + (d0 + dd) * 32);
-#pragma unroll
-        for (int l4 = 0; l4 < 8; ++l4) {
-          const float4 w4 = wp[l4];
-          sA[4 * l4] = fmaf(w4.x, c, sA[4 * l4]); sA[4 * l4 + 1] = fmaf(w4.y, c, sA[4 * l4 + 1]);
-          sA[4 * l4 + 2] = fmaf(w4.z, c, sA[4 * l4 + 2]); sA[4 * l4 + 3] = fmaf(w4.w, c, sA[4 * l4 + 3]);
-        }
-      }
-    }
-    if (hasB) {
-      for (int dd = 0; dd < 32; ++dd) {
-        const float c = slab[dd * S + tid + 256];
-        const float4* wp = reinterpret_cast<const float4*>(word_s + (d0 + dd) * 32);
-#pragma unroll
-        for (int l4 = 0; l4 < 8; ++l4) {
-          const float4 w4 = wp[l4];
-          sB[4 * l4] = fmaf(w4.x, c, sB[4 * l4]); sB[4 * l4 + 1] = fmaf(w4.y, c, sB[4 * l4 + 1]);
-          sB[4 * l4 + 2] = fmaf(w4.z, c, sB[4 * l4 + 2]); sB[4 * l4 + 3] = fmaf(w4.w, c, sB[4 * l4 + 3]);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  for (int r = tid; r < S; r += 256) {
+  {
     float s[32];
 #pragma unroll
-    for (int l = 0; l < 32; ++l) s[l] = r == tid ? sA[l] : sB[l];
-    float mx = -INFINITY;
+    for (int l = 0; l < 32; ++l) s[l] = 0.f;
+    for (int d0 = 0; d0 < ndf; d0 += 32) {
+      for (int o = tid; o < 32 * S; o += kBwdNT) slab[o] = cb[(int64_t)d0 * S + o];
+      __syncthreads();
+      if (tid < S) {
+        for (int dd = 0; dd < 32; ++dd) {
+          const float c = slab[dd * S + tid];
+          const float4* wp = reinterpret_cast<const float4*>(word_s + (d0 + dd) * 32);
 #pragma unroll
-    for (int l = 0; l < 32; ++l) {
-      if (l >= L) s[l] = -INFINITY;
-      mx = fmaxf(mx, s[l]);
+          for (int l4 = 0; l4 < 8; ++l4) {
+            const float4 w4 = wp[l4];
+            s[4 * l4] = fmaf(w4.x, c, s[4 * l4]); s[4 * l4 + 1] = fmaf(w4.y, c, s[4 * l4 + 1]);
+            s[4 * l4 + 2] = fmaf(w4.z, c, s[4 * l4 + 2]); s[4 * l4 + 3] = fmaf(w4.w, c, s[4 * l4 + 3]);
+          }
+        }
+      }
+      __syncthreads();
     }
-    float sum = 0.f;
+    if (tid < S) {
+      const int r = tid;
+      float mx = -INFINITY;
 #pragma unroll
-    for (int l = 0; l < 32; ++l) {
-      s[l] = expf(s[l] - mx);
-      sum += s[l];
-    }
-    const float inv = 1.f / sum;
+      for (int l = 0; l < 32; ++l) {
+        if (l >= L) s[l] = -INFINITY;
+        mx = fmaxf(mx, s[l]);
+      }
+      float sum = 0.f;
 #pragma unroll
-    for (int l = 0; l < 32; ++l) {
-      const float p = s[l] * inv;
-      a1[l * S + r] = p;
-      a2[l * S + r] = a.gamma1 * p;        // softmax over regions comes next
+      for (int l = 0; l < 32; ++l) {
+        s[l] = expf(s[l] - mx);
+        sum += s[l];
+      }
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int l = 0; l < 32; ++l) {
+        const float p = s[l] * inv;
+        a1[l * S + r] = p;
+        a2[l * S + r] = a.gamma1 * p;        // softmax over regions comes next
+      }
     }
   }
   __syncthreads();
 
-  // ---- wave per word row: softmax over regions -> a2
-  // (a lane's <= 5 values of the row stay in registers between the three passes: one read and one write of the global workspace per
-  // row instead of five dependent round trips - S <= 320, host-checked)
-  for (int l = wave; l < 32; l += 4) {
+  // ---- wave per word row: softmax over regions -> a2 (a lane's <= 5 values of the row stay in registers between the passes; S <= 320)
+  for (int l = wave; l < 32; l += kBwdNT / 64) {
     float* row = a2 + l * S;
     if (l < L) {
       float v[5];
@@ -163,21 +153,21 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   }
   __syncthreads();
 
-  // ---- thread = d: weighted context wc[d][l] (ctx staged through LDS in chunks of 32 regions)
-  const int d = tid;
+  // ---- thread = (d, h): weighted context wc[d][l] for the 16 words of half h (ctx and a2 staged through LDS in chunks of 32 regions)
+  const int d = tid & 255, h = tid >> 8, l0 = 16 * h;
   const bool dok = d < ndf;
-  float wrow[32], wc[32];
+  float wrow[16], wc[16];
 #pragma unroll
-  for (int l = 0; l < 32; ++l) {
-    wrow[l] = dok ? word_s[d * 32 + l] : 0.f;
+  for (int l = 0; l < 16; ++l) {
+    wrow[l] = dok ? word_s[d * 32 + l0 + l] : 0.f;
     wc[l] = 0.f;
   }
   for (int r0 = 0; r0 < S; r0 += kBwdChunk) {
-    for (int o = tid; o < ndf * kBwdChunk; o += 256) {
+    for (int o = tid; o < ndf * kBwdChunk; o += kBwdNT) {
       const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
       cs[dd * 33 + rr] = r0 + rr < S ? cb[(int64_t)dd * S + r0 + rr] : 0.f;
     }
-    for (int o = tid; o < 32 * kBwdChunk; o += 256) {      // a2[l][r0 + rr] -> a2s[rr][l] (coalesced over rr)
+    for (int o = tid; o < 32 * kBwdChunk; o += kBwdNT) {    // a2[l][r0 + rr] -> a2s[rr][l] (coalesced over rr)
       const int l = o / kBwdChunk, rr = o - l * kBwdChunk;
       a2s[rr * 32 + l] = r0 + rr < S ? a2[l * S + r0 + rr] : 0.f;
     }
@@ -186,9 +176,9 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
       const int nr = S - r0 < kBwdChunk ? S - r0 : kBwdChunk;
       for (int rr = 0; rr < nr; ++rr) {
         const float c = cs[d * 33 + rr];
-        const float4* ap = reinterpret_cast<const float4*>(a2s + rr * 32);
+        const float4* ap = reinterpret_cast<const float4*>(a2s + rr * 32 + l0);
 #pragma unroll
-        for (int l4 = 0; l4 < 8; ++l4) {
+        for (int l4 = 0; l4 < 4; ++l4) {
           const float4 av = ap[l4];
           wc[4 * l4] = fmaf(c, av.x, wc[4 * l4]);
           wc[4 * l4 + 1] = fmaf(c, av.y, wc[4 * l4 + 1]);
@@ -200,10 +190,10 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
     __syncthreads();
   }
 
-  // ---- cosine + log-sum-exp backward: per word dot / norms over d (LDS atomics), then dwc and the direct gword
+  // ---- cosine + log-sum-exp backward: per word dot / norms over d (a word's features sit in the four waves of its half)
   {
 #pragma unroll
-    for (int l = 0; l < 32; ++l) {
+    for (int l = 0; l < 16; ++l) {
       float dt = wrow[l] * wc[l], nc = wc[l] * wc[l], nw = wrow[l] * wrow[l];
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) {
@@ -212,38 +202,47 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
         nw += __shfl_xor(nw, o);
       }
       if (lane == 0) {
-        wpart[wave * 128 + l] = dt;
-        wpart[wave * 128 + 32 + l] = nc;
-        wpart[wave * 128 + 64 + l] = nw;
+        wpart[wave * 128 + l0 + l] = dt;
+        wpart[wave * 128 + 32 + l0 + l] = nc;
+        wpart[wave * 128 + 64 + l0 + l] = nw;
       }
     }
   }
   __syncthreads();
-  if (tid < 96) red[tid] = ((wpart[tid] + wpart[128 + tid]) + wpart[256 + tid]) + wpart[384 + tid];   // fixed order, no atomics
+  if (tid < 96) {                            // word tid & 31 lives in half (tid & 31) >> 4: waves 4 half .. 4 half + 3, in that order
+    const int w0 = 4 * ((tid & 31) >> 4);
+    red[tid] = ((wpart[w0 * 128 + tid] + wpart[(w0 + 1) * 128 + tid]) + wpart[(w0 + 2) * 128 + tid]) + wpart[(w0 + 3) * 128 + tid];
+  }
   __syncthreads();
-  float gw[32], dwc[32];
+  float gw[16], dwc[16];
   {
     // p_l = softmax_l(gamma2 cos_l) over the caption's words; dcos_l = G gamma2 p_l
-    float cosv[32], mx = -INFINITY;
-#pragma unroll
+    float mx = -INFINITY;
     for (int l = 0; l < 32; ++l) {
-      const float den = fmaxf(sqrtf(red[64 + l]) * sqrtf(red[32 + l]), 1e-8f);
-      cosv[l] = red[l] / den;
-      if (l < L) mx = fmaxf(mx, a.gamma2 * cosv[l]);
+      if (l < L) {
+        const float den = fmaxf(sqrtf(red[64 + l]) * sqrtf(red[32 + l]), 1e-8f);
+        mx = fmaxf(mx, a.gamma2 * (red[l] / den));
+      }
     }
     float sum = 0.f;
-#pragma unroll
-    for (int l = 0; l < 32; ++l) sum += l < L ? expf(a.gamma2 * cosv[l] - mx) : 0.f;
-#pragma unroll
     for (int l = 0; l < 32; ++l) {
-      float gwl = 0.f, dw = 0.f;
       if (l < L) {
-        const float dcos = G * a.gamma2 * expf(a.gamma2 * cosv[l] - mx) / sum;
-        const float nw = sqrtf(red[64 + l]), nc = sqrtf(red[32 + l]);
+        const float den = fmaxf(sqrtf(red[64 + l]) * sqrtf(red[32 + l]), 1e-8f);
+        sum += expf(a.gamma2 * (red[l] / den) - mx);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      const int lw = l0 + l;
+      float gwl = 0.f, dw = 0.f;
+      if (lw < L) {
+        const float nw = sqrtf(red[64 + lw]), nc = sqrtf(red[32 + lw]);
+        const float cosv = red[lw] / fmaxf(nw * nc, 1e-8f);
+        const float dcos = G * a.gamma2 * expf(a.gamma2 * cosv - mx) / sum;
         if (nw * nc > 1e-8f) {
           const float inv = 1.f / (nw * nc);
-          dw = dcos * (wrow[l] * inv - cosv[l] * wc[l] / (nc * nc));
-          gwl = dcos * (wc[l] * inv - cosv[l] * wrow[l] / (nw * nw));
+          dw = dcos * (wrow[l] * inv - cosv * wc[l] / (nc * nc));
+          gwl = dcos * (wc[l] * inv - cosv * wrow[l] / (nw * nw));
         } else {                                  // clamped denominator: cos = dot / eps
           dw = dcos * wrow[l] * 1e8f;
           gwl = dcos * wc[l] * 1e8f;
@@ -251,20 +250,18 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
       }
       dwc[l] = dw;
       gw[l] = gwl;
-      if (dok) dwc_s[d * 32 + l] = dw;
+      if (dok) dwc_s[d * 32 + lw] = dw;
     }
   }
   __syncthreads();
 
   // ---- thread = r, pass A: da2[l][r] = sum_d dwc[d][l] ctx[d][r]; row dots sum_r da2 a2 for the softmax-r backward
-  if (tid < 32) red[96 + tid] = 0.f;
-  __syncthreads();
   {
-    float rd[32];
+    float g[32];
 #pragma unroll
-    for (int l = 0; l < 32; ++l) { rd[l] = 0.f; sA[l] = 0.f; sB[l] = 0.f; }
+    for (int l = 0; l < 32; ++l) g[l] = 0.f;
     for (int d0 = 0; d0 < ndf; d0 += 32) {                 // ctx in slabs of 32 rows through LDS, as for the scores
-      for (int o = tid; o < 32 * S; o += 256) slab[o] = cb[(int64_t)d0 * S + o];
+      for (int o = tid; o < 32 * S; o += kBwdNT) slab[o] = cb[(int64_t)d0 * S + o];
       __syncthreads();
       if (tid < S) {
         for (int dd = 0; dd < 32; ++dd) {
@@ -273,33 +270,20 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
 #pragma unroll
           for (int l4 = 0; l4 < 8; ++l4) {
             const float4 w4 = wp[l4];
-            sA[4 * l4] = fmaf(w4.x, c, sA[4 * l4]); sA[4 * l4 + 1] = fmaf(w4.y, c, sA[4 * l4 + 1]);
-            sA[4 * l4 + 2] = fmaf(w4.z, c, sA[4 * l4 + 2]); sA[4 * l4 + 3] = fmaf(w4.w, c, sA[4 * l4 + 3]);
-          }
-        }
-      }
-      if (hasB) {
-        for (int dd = 0; dd < 32; ++dd) {
-          const float c = slab[dd * S + tid + 256];
-          const float4* wp = reinterpret_cast<const float4*>(dwc_s + (d0 + dd) * 32);
-#pragma unroll
-          for (int l4 = 0; l4 < 8; ++l4) {
-            const float4 w4 = wp[l4];
-            sB[4 * l4] = fmaf(w4.x, c, sB[4 * l4]); sB[4 * l4 + 1] = fmaf(w4.y, c, sB[4 * l4 + 1]);
-            sB[4 * l4 + 2] = fmaf(w4.z, c, sB[4 * l4 + 2]); sB[4 * l4 + 3] = fmaf(w4.w, c, sB[4 * l4 + 3]);
+            g[4 * l4] = fmaf(w4.x, c, g[4 * l4]); g[4 * l4 + 1] = fmaf(w4.y, c, g[4 * l4 + 1]);
+            g[4 * l4 + 2] = fmaf(w4.z, c, g[4 * l4 + 2]); g[4 * l4 + 3] = fmaf(w4.w, c, g[4 * l4 + 3]);
           }
         }
       }
       __syncthreads();
     }
-    for (int r = tid; r < S; r += 256) {
-      float g[32];
+    float rd[32];
 #pragma unroll
-      for (int l = 0; l < 32; ++l) g[l] = r == tid ? sA[l] : sB[l];
-#pragma unroll
-      for (int l = 0; l < 32; ++l) {
-        a3[l * S + r] = g[l];
-        rd[l] = fmaf(g[l], a2[l * S + r], rd[l]);
+    for (int l = 0; l < 32; ++l) {
+      rd[l] = 0.f;
+      if (tid < S) {
+        a3[l * S + tid] = g[l];
+        rd[l] = g[l] * a2[l * S + tid];
       }
     }
 #pragma unroll
@@ -311,10 +295,12 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
     }
   }
   __syncthreads();
-  if (tid < 32) red[96 + tid] = ((wpart[96 + tid] + wpart[224 + tid]) + wpart[352 + tid]) + wpart[480 + tid];
+  if (tid < 32)                              // the regions sit in waves 0 .. 4 (S <= 320): combined in that order
+    red[96 + tid] = (((wpart[96 + tid] + wpart[128 + 96 + tid]) + wpart[256 + 96 + tid]) + wpart[384 + 96 + tid]) + wpart[512 + 96 + tid];
   __syncthreads();
   // pass B: dx = a2 (da2 - rowdot); da1 = gamma1 dx; ds = a1 (da1 - sum_l da1 a1)  -> a3
-  for (int r = tid; r < S; r += 256) {
+  if (tid < S) {
+    const int r = tid;
     float da1[32], p1[32], acc = 0.f;
 #pragma unroll
     for (int l = 0; l < 32; ++l) {
@@ -327,14 +313,14 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
   }
   __syncthreads();
 
-  // ---- thread = d: gword[d][l] += sum_r ds[l][r] ctx[d][r];  gctx[d][r] = sum_l (word[d][l] ds[l][r] + dwc[d][l] a2[l][r])
+  // ---- thread = (d, h): gword[d][l] += sum_r ds[l][r] ctx[d][r];  gctx[d][r] = sum_l (word[d][l] ds[l][r] + dwc[d][l] a2[l][r])
   float* gc = a.gc_part + ((int64_t)i * a.B + j) * ndf * S;
   for (int r0 = 0; r0 < S; r0 += kBwdChunk) {
-    for (int o = tid; o < ndf * kBwdChunk; o += 256) {
+    for (int o = tid; o < ndf * kBwdChunk; o += kBwdNT) {
       const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
       cs[dd * 33 + rr] = r0 + rr < S ? cb[(int64_t)dd * S + r0 + rr] : 0.f;
     }
-    for (int o = tid; o < 32 * kBwdChunk; o += 256) {
+    for (int o = tid; o < 32 * kBwdChunk; o += kBwdNT) {
       const int l = o / kBwdChunk, rr = o - l * kBwdChunk;
       const bool in = r0 + rr < S;
       a2s[rr * 32 + l] = in ? a2[l * S + r0 + rr] : 0.f;
@@ -342,38 +328,51 @@ __global__ __launch_bounds__(256) void damsm_pair_bwd_kernel(DamsmBwdArgs a) {
     }
     __syncthreads();
     const int nr = S - r0 < kBwdChunk ? S - r0 : kBwdChunk;
+    float gpart[kBwdChunk];
     if (dok) {
-      for (int rr = 0; rr < nr; ++rr) {
-        const float c = cs[d * 33 + rr];
-        const float4* p2 = reinterpret_cast<const float4*>(a2s + rr * 32);
-        const float4* p3 = reinterpret_cast<const float4*>(a3s + rr * 32);
+#pragma unroll
+      for (int rr = 0; rr < kBwdChunk; ++rr) {
         float g = 0.f;
+        if (rr < nr) {
+          const float c = cs[d * 33 + rr];
+          const float4* p2 = reinterpret_cast<const float4*>(a2s + rr * 32 + l0);
+          const float4* p3 = reinterpret_cast<const float4*>(a3s + rr * 32 + l0);
 #pragma unroll
-        for (int l4 = 0; l4 < 8; ++l4) {
-          const float4 d4 = p3[l4], q4 = p2[l4];
-          const float dsv[4] = {d4.x, d4.y, d4.z, d4.w}, a2v[4] = {q4.x, q4.y, q4.z, q4.w};
+          for (int l4 = 0; l4 < 4; ++l4) {
+            const float4 d4 = p3[l4], q4 = p2[l4];
+            const float dsv[4] = {d4.x, d4.y, d4.z, d4.w}, a2v[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {                    // (word by word in ascending order: the sums keep their order)
-            const int l = 4 * l4 + k;
-            gw[l] = fmaf(dsv[k], c, gw[l]);
-            g = fmaf(wrow[l], dsv[k], g);
-            g = fmaf(dwc[l], a2v[k], g);
+            for (int k = 0; k < 4; ++k) {
+              const int l = 4 * l4 + k;
+              gw[l] = fmaf(dsv[k], c, gw[l]);
+              g = fmaf(wrow[l], dsv[k], g);
+              g = fmaf(dwc[l], a2v[k], g);
+            }
           }
         }
-        gcs[d * 33 + rr] = g;
+        gpart[rr] = g;
+      }
+      if (h == 0) {
+#pragma unroll
+        for (int rr = 0; rr < kBwdChunk; ++rr) gcs[d * 33 + rr] = gpart[rr];
       }
     }
     __syncthreads();
-    for (int o = tid; o < ndf * kBwdChunk; o += 256) {
+    if (dok && h == 1) {                     // the second half of the words on top of the first: a fixed order
+#pragma unroll
+      for (int rr = 0; rr < kBwdChunk; ++rr) gcs[d * 33 + rr] += gpart[rr];
+    }
+    __syncthreads();
+    for (int o = tid; o < ndf * kBwdChunk; o += kBwdNT) {
       const int dd = o / kBwdChunk, rr = o - dd * kBwdChunk;
       if (rr < nr) gc[(int64_t)dd * S + r0 + rr] = gcs[dd * 33 + rr];
     }
     __syncthreads();
   }
   if (dok) {
-    float* gwp = a.gw_part + (((int64_t)j * a.B + i) * ndf + d) * 32;
+    float* gwp = a.gw_part + (((int64_t)j * a.B + i) * ndf + d) * 32 + l0;
 #pragma unroll
-    for (int l = 0; l < 32; ++l) gwp[l] = gw[l];
+    for (int l = 0; l < 16; ++l) gwp[l] = gw[l];
   }
 }
 
@@ -406,7 +405,7 @@ extern "C" int tgsr_damsm_words_bwd(const float* words, const int32_t* cap_lens,
   a.gw_part = ws + (int64_t)B * B * 3 * 32 * S;
   a.gc_part = a.gw_part + (int64_t)B * B * ndf * 32;
   const size_t csz = (size_t)ndf * 33 * 2 > (size_t)32 * S ? (size_t)ndf * 33 * 2 : (size_t)32 * S;
-  const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + csz + 128 + 4 * 128 + 2 * kBwdChunk * 32);
+  const size_t lds = sizeof(float) * ((size_t)ndf * 32 * 2 + csz + 128 + 8 * 128 + 2 * kBwdChunk * 32);
   static bool attr_set[64] = {false};   // the > 64 KB opt-in belongs to the DEVICE's code object: once per device, not per
   int dev = 0;                          // process (one process driving two GPUs would otherwise fail on the second)
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -417,7 +416,7 @@ extern "C" int tgsr_damsm_words_bwd(const float* words, const int32_t* cap_lens,
     attr_set[dev] = true;
   }
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(damsm_pair_bwd_kernel, dim3(B * B), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(damsm_pair_bwd_kernel, dim3(B * B), dim3(kBwdNT), lds, s, a);
   int rc = note_launch(hipGetLastError(), "damsm_pair_bwd_kernel");
   if (rc) return rc;
   // grad_words32[i][ndf][32] = sum_j gw_part[j][i];  grad_ctx[j][ndf][S] = sum_i gc_part[i][j]
