@@ -85,3 +85,17 @@ def test_flat_adam_counts_its_steps_on_the_device_across_graph_replays():
     torch.cuda.synchronize()
     assert float(ob.counters[0]) == 4.0
     assert torch.equal(oa.flat, ob.flat) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+
+
+def test_flat_adam_refuses_parameters_that_left_its_buffer():
+    from tgsr_amd.optim import FlatAdam
+    from tgsr_amd.parallel import FlatGradBucket
+    net = _net(7)
+    bucket = FlatGradBucket(net.parameters()).attach()
+    opt = FlatAdam(bucket.params, bucket.flat, lr=1e-3, betas=(0.5, 0.999))
+    opt.step()                                              # fine: the parameters are the views the optimizer made
+    with torch.no_grad():
+        last = bucket.params[-1]
+        last.data = last.data.clone()                       # what a module.to(...) after construction amounts to
+    with pytest.raises(RuntimeError, match="no longer lives"):
+        opt.step()

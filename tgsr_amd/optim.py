@@ -48,6 +48,7 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = home                                   # the parameter now LIVES in the flat buffer
                 self.state[p] = {"step": step_view, "exp_avg": self.exp_avg[off:off + k].view_as(p),
                                  "exp_avg_sq": self.exp_avg_sq[off:off + k].view_as(p)}
+                self._last_off = off
                 off += (k + 3) & ~3
 
     @torch.no_grad()
@@ -57,6 +58,12 @@ class FlatAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         g = self.param_groups[0]
+        # the parameters must still LIVE in the flat buffer (a module.to(...) or `p.data = ...` after construction moves them out, and the
+        # update would run over memory nobody reads): the first and the last one are checked, two pointer reads per step
+        for p, off in ((g["params"][0], 0), (g["params"][-1], self._last_off)):
+            if p.data_ptr() != self.flat.data_ptr() + 4 * off:
+                raise RuntimeError("FlatAdam: a parameter no longer lives in the optimizer's flat buffer (moved or re-assigned after "
+                                   "the optimizer was built); build the optimizer after the modules are in place")
         C.adam_flat_(self.flat, self.grads_flat, self.exp_avg, self.exp_avg_sq, self.counters, float(g["lr"]), float(g["betas"][0]),
                      float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), True)
         return loss
