@@ -925,6 +925,9 @@ def func_attention(query: torch.Tensor, context: torch.Tensor, gamma1: float):
 
 
 # ----------------------------------------------------------------------------------------- CNN_ENCODER heads
+CONV1X1_GCONV = os.environ.get("TGSR_CONV1X1_GCONV", "1") != "0"
+
+
 def conv1x1(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """1x1 convolution [B,Cin,H,W] -> [B,Cout,H,W] (emb_features, util.py:300,367) as an MFMA GEMM."""
     _need_hip(x, w, bias)
@@ -934,6 +937,14 @@ def conv1x1(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     if w2.shape[1] != Cin:
         raise TgsrError("conv1x1: weight %s vs input channels %d" % (tuple(w.shape), Cin))
     out = torch.empty(B, w2.shape[0], H, W, dtype=torch.float32, device=x.device)
+    if bias is None and Cin % 16 == 0 and B * H * W >= 1024 and CONV1X1_GCONV:
+        # the implicit-GEMM kernel of CNN_ENCODER's trunk (three-piece bf16 operands: tgsr_gconv) takes a 1x1 filter as it is - the
+        # weight [Cout, Cin] IS its A operand: emb_features on the 17 x 17 x 768 region features, forward and (through the
+        # transposed weight, custom_ops._conv1x1_backward) data gradient, 80 -> ~20 us each at batch 16
+        need = gconv_ws_elems(B, w2.shape[0], H, W, Cin)
+        ws = torch.empty(need, dtype=torch.float32, device=x.device) if need else None
+        gconv(False, w2, x, 0, Cin, out, 0, 1, 1, 1, 0, 0, None, False, False, ws, None)
+        return out
     b = None if bias is None else _f32(bias.detach(), "bias").contiguous()
     check(_lib.lib().tgsr_conv1x1_fwd(_p(x), B, Cin, H * W, _p(w2), _p(b), w2.shape[0], _p(out), _stream()),
           "tgsr_conv1x1_fwd")
