@@ -759,3 +759,26 @@ def test_small_batchnorm_layers_in_one_launch_equal_the_two_pass_form_bit_for_bi
     y.backward(dout.double().cpu())
     assert torch.allclose(outs[0][0].cpu().double(), y.detach(), rtol=1e-4, atol=1e-4)
     assert torch.allclose(outs[0][5].cpu().double(), x64.grad, rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(16, 768, 256, 17, 17), (4, 64, 48, 16, 16), (2, 768, 256, 17, 17)])
+def test_conv1x1_forward_and_gradients_on_the_implicit_gemm_kernel(B, Cin, Cout, H, W):
+    """CNN_ENCODER.emb_features (util.py:300, 367) through torch.ops.tgsr.conv1x1: where the shape qualifies the forward, the data
+    gradient AND the weight gradient (K = B H W as the channels of a 1x1 convolution over Cin "pixels") run on the trunk's implicit
+    GEMM (three-piece bf16 operands); batch 2 (K % 16 != 0) keeps the plain GEMM kernel.  All against torch in float64."""
+    import tgsr_amd.custom_ops as C
+    from tgsr_amd import ops
+    g = torch.Generator().manual_seed(B + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xr, wr).backward(dy.double())
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    out = C.conv1x1(xd, wd)
+    out.backward(dy.to(DEV))
+    rel = lambda a, b: float((a.detach().cpu().double() - b).abs().max()) / float(b.abs().max())      # noqa: E731
+    assert rel(out, torch.nn.functional.conv2d(x.double(), w.double())) < 2e-5
+    assert rel(xd.grad, xr.grad) < 2e-5 and rel(wd.grad, wr.grad) < 5e-5, (rel(xd.grad, xr.grad), rel(wd.grad, wr.grad))
+    took = ops.conv1x1_wgrad(dy.to(DEV), x.to(DEV)) is not None
+    assert took == ((B * H * W) % 16 == 0 and B * H * W >= 1024 and Cin >= 64)

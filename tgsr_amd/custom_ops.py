@@ -387,9 +387,12 @@ def _conv1x1_backward(ctx, dy):
     if ctx.needs_input_grad[0]:                                    # (the frozen trunk's features need none)
         dx = conv1x1(dy, w.detach().reshape(Cout, Cin).t().contiguous())
     if ctx.needs_input_grad[1]:
-        dy2 = dy.permute(1, 0, 2, 3).reshape(Cout, -1)             # [Cout, B*S]
-        x2 = x.detach().permute(1, 0, 2, 3).reshape(Cin, -1)       # [Cin,  B*S]
-        dw = _gemm_nt(dy2, x2).reshape(w.shape)
+        dw = ops.conv1x1_wgrad(dy, x.detach())                     # the implicit-GEMM kernel where the shape qualifies
+        if dw is None:
+            dy2 = dy.permute(1, 0, 2, 3).reshape(Cout, -1)         # [Cout, B*S]
+            x2 = x.detach().permute(1, 0, 2, 3).reshape(Cin, -1)   # [Cin,  B*S]
+            dw = _gemm_nt(dy2, x2)
+        dw = dw.reshape(w.shape)
     return dx, dw
 
 

@@ -951,6 +951,26 @@ def conv1x1(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def conv1x1_wgrad(dy: torch.Tensor, x: torch.Tensor) -> Optional[torch.Tensor]:
+    """Weight gradient of a bias-free 1x1 convolution, dW[co][ci] = sum over (b, pixel) of dy[b][co][p] x[b][ci][p], on the implicit-GEMM
+    kernel: with K = B H W as the "channels" and Cin as the "pixels" it IS a 1x1 convolution - A = dy as [Cout, K], the image x as
+    [1, K, Cin, 1] - split over K into slabs summed in a fixed order (emb_features in DAMSM pre-training, pretrain_DAMSM.py:79-98: the
+    plain GEMM kernel took ~1 ms for these 1.8 GFLOP, half of the step's kernel time).  None when the shape does not qualify
+    (K % 16 != 0, few channels): the caller keeps its own form."""
+    _need_hip(dy, x)
+    B, Cout, H, W = dy.shape
+    Cin, K = x.shape[1], B * H * W
+    if not CONV1X1_GCONV or K % 16 != 0 or K < 1024 or Cin < 64 or tuple(x.shape) != (B, Cin, H, W):
+        return None
+    a = _f32(dy, "dy").permute(1, 0, 2, 3).reshape(Cout, K).contiguous()
+    xt = _f32(x, "x").permute(0, 2, 3, 1).reshape(1, K, Cin, 1).contiguous()
+    out = torch.empty(1, Cout, Cin, 1, dtype=torch.float32, device=dy.device)
+    need = gconv_ws_elems(1, Cout, Cin, 1, K)
+    ws = torch.empty(need, dtype=torch.float32, device=dy.device) if need else None
+    gconv(False, a, xt, 0, K, out, 0, 1, 1, 1, 0, 0, None, False, False, ws, None)
+    return out.reshape(Cout, Cin)
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [B,K] @ w[Cout,K]^T + bias (emb_cnn_code, util.py:301,364) as an MFMA GEMM."""
     _need_hip(x, w, bias)
