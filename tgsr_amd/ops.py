@@ -979,8 +979,18 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     B, K = x.shape
     if w2.shape[1] != K:
         raise TgsrError("linear: weight %s vs input %s" % (tuple(w.shape), tuple(x.shape)))
-    out = torch.empty(B, w2.shape[0], dtype=torch.float32, device=x.device)
     b = None if bias is None else _f32(bias.detach(), "bias").contiguous()
+    if CONV1X1_GCONV and K % 16 == 0 and K >= 256:
+        # long reductions over few rows (emb_cnn_code: 16 x 2048 -> 256; the recurrent weights' gradients: K = B T): on the plain
+        # GEMM kernel a handful of workgroups walk K alone (~100 us for a few MFLOP); the implicit-GEMM kernel splits K over the
+        # chip - x^T as a [1, K, B, 1] image, the weight as its A operand, the bias in its epilogue
+        xt = x.t().contiguous().view(1, K, B, 1)
+        img = torch.empty(1, w2.shape[0], B, 1, dtype=torch.float32, device=x.device)
+        need = gconv_ws_elems(1, w2.shape[0], B, 1, K)
+        ws = torch.empty(need, dtype=torch.float32, device=x.device) if need else None
+        gconv(False, w2, xt, 0, K, img, 0, 1, 1, 1, 0, 0, b, False, False, ws, None)
+        return img.view(w2.shape[0], B).t().contiguous()
+    out = torch.empty(B, w2.shape[0], dtype=torch.float32, device=x.device)
     check(_lib.lib().tgsr_linear_fwd(_p(x), B, K, _p(w2), _p(b), w2.shape[0], _p(out), _stream()), "tgsr_linear_fwd")
     return out
 

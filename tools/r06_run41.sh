@@ -3,7 +3,7 @@
 set -o pipefail
 OUT=gpurun_out/r06
 mkdir -p $OUT
-timeout -k 10 900 python -m pytest tests/test_hip_parity.py tests/test_hip_train.py tests/test_hip_custom_ops.py tests/test_hip_gan.py tests/test_hip_dp.py -x -q -k "conv1x1 or heads or cnn_encoder or implicit_gemm or damsm or DAMSM or opcheck or encoder or dp or two_rank" > $OUT/t41.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_hip_parity.py tests/test_hip_train.py tests/test_hip_custom_ops.py tests/test_hip_gan.py tests/test_hip_dp.py -x -q -k "conv1x1 or heads or cnn_encoder or implicit_gemm or linear or lstm or bilstm or gru or ca_net or attention or damsm or DAMSM or opcheck or encoder or dp or two_rank" > $OUT/t41.log 2>&1
 rc=$?; echo "pytest rc=$rc"; tail -n 6 $OUT/t41.log | cut -c1-220
 [ $rc -eq 0 ] || exit $rc
 for c in 1 0 1 0; do
