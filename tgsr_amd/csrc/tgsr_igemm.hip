@@ -498,12 +498,14 @@ extern "C" int tgsr_gconv_set_form(int split) {
   return was;
 }
 
-// Workgroups a launch should reach before the reduction is split no further (TGSR_GCONV_FILL; default 320 = ~1.25 per CU: the
-// trunk's branches run side by side on streams of their own, inception.py, so a launch need not fill the chip alone).
+// Workgroups a launch should reach before the reduction is split no further (TGSR_GCONV_FILL; default 224 = a little under one per
+// CU: the trunk's branches run side by side on streams of their own, inception.py, so a launch need not fill the chip alone.
+// Measured on the G/D + DAMSM step: 96 / 160 / 320 / 480 / 640 -> 34.8 / 31.8 / 31.2 / 31.0 / 31.1 ms with the branch heads behind the
+// join; with the heads in slots 224 / 320 / 448 -> 29.19, 29.04 / 29.28, 29.24 / 29.31).
 static int g_gconv_fill = [] {
   const char* e = getenv("TGSR_GCONV_FILL");
-  const int v = e ? atoi(e) : 320;
-  return v < 1 ? 320 : v;
+  const int v = e ? atoi(e) : 224;
+  return v < 1 ? 224 : v;
 }();
 
 // How many K slabs a shape is split into (1 = none): fill ~g_gconv_fill workgroups when M x N alone cannot.
